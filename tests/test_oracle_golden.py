@@ -1,0 +1,140 @@
+"""The oracle (oracle/faceoff_oracle.py) against golden outputs of the reference itself
+(tests/golden/*.npz, produced by tests/golden/make_golden.py beside /root/reference)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from faceoff_amd.synth import make_state_dict, make_batch, make_vgg_lpips_state
+from oracle import faceoff_oracle as O
+
+torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
+SUB = 61
+
+
+def _sub(t):
+    return t.detach().reshape(-1)[::SUB].numpy()
+
+
+def _stats(t):
+    t = t.detach().double()
+    return np.array([t.sum().item(), t.pow(2).sum().item(), t.abs().max().item()])
+
+
+def _close(a, b, rtol=1e-4, atol=1e-6):
+    np.testing.assert_allclose(np.asarray(a), np.asarray(b), rtol=rtol, atol=atol)
+
+
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_quantize_kat(golden_dir, mode):
+    g = np.load(os.path.join(golden_dir, "quantize_kat.npz"))
+    x = torch.from_numpy(g["x"]).requires_grad_(True)
+    embed = torch.from_numpy(g["embed"])
+    cs0 = torch.from_numpy(g["cluster_size0"])
+    q, diff, ind, new = O.quantize_forward(x, embed, cs0, embed * cs0[None, :], training=(mode == "train"))
+    assert np.array_equal(ind.numpy().astype(np.int16), g[f"{mode}_ind"])       # bit-exact indices
+    _close(q.detach(), g[f"{mode}_quantize"], rtol=1e-6)
+    _close(diff.detach(), g[f"{mode}_diff"], rtol=1e-6)
+    (q * torch.from_numpy(g[f"{mode}_gout"])).sum().add(diff * 3.0).backward()
+    _close(x.grad, g[f"{mode}_gx"], rtol=1e-5, atol=1e-7)
+    # analytic STE + commitment gradient
+    want = g[f"{mode}_gout"] + 3.0 * 2 * (g["x"] - g[f"{mode}_quantize"]) / g["x"].size
+    _close(x.grad, want, rtol=1e-4, atol=1e-6)
+    if mode == "train":
+        _close(new["embed"], g["train_embed_after"], rtol=1e-5)
+        _close(new["cluster_size"], g["train_cluster_size_after"], rtol=1e-6)
+        _close(new["embed_avg"], g["train_embed_avg_after"], rtol=1e-6)
+    else:
+        assert new is None
+        _close(g["eval_embed_after"], g["embed"], rtol=0)
+
+
+def _run_e2e(g, adam=True):
+    B, T, H, W = (int(g[k]) for k in "BTHW")
+    sd = make_state_dict(int(g["seed_w"]), codebook_scale=float(g["codebook_scale"]), gain=float(g["gain"]))
+    p = O.to_torch_state(sd)
+    img, gt = make_batch(int(g["seed_x"]), B, T, H, W)
+    state = {} if adam else None
+    r = O.train_step(torch.from_numpy(img), torch.from_numpy(gt), p, adam_state=state)
+    return p, r, torch.from_numpy(img)
+
+
+def _check_e2e(g, p, r, img, literal=False):
+    fw = r["fw"]
+    dec = fw["dec"].detach()
+    if g["dec"].ndim == 4:
+        _close(dec, g["dec"], rtol=1e-4, atol=2e-6)
+    else:
+        _close(_sub(dec), g["dec"], rtol=1e-4, atol=2e-6)
+    _close(_stats(dec), g["dec_stats"], rtol=1e-5)
+    _close(fw["diff"].detach(), g["diff"], rtol=1e-5)
+    _close(r["recon"].item(), g["recon"], rtol=1e-5)
+    _close(r["latent"].item(), g["latent"], rtol=1e-5)
+    if not literal:
+        assert np.array_equal(fw["id_t"].numpy().astype(np.int16), g["id_t"])
+        assert np.array_equal(fw["id_b"].numpy().astype(np.int16), g["id_b"])
+    names = [str(n) for n in g["param_names"]]
+    assert names == [k for k, v in p.items() if v.requires_grad]
+    gs = np.stack([_stats(r["grads"][n]) for n in names])
+    # sum can cancel: compare L2 and max tightly, sums against the L2 scale
+    _close(gs[:, 1], g["grad_stats"][:, 1], rtol=2e-4)
+    _close(gs[:, 2], g["grad_stats"][:, 2], rtol=2e-4)
+    scale = np.sqrt(g["grad_stats"][:, 1])
+    assert np.all(np.abs(gs[:, 0] - g["grad_stats"][:, 0]) <= 2e-4 * (scale + 1e-12) * 50)
+    sub = np.concatenate([_sub(r["grads"][n]) for n in names])
+    np.testing.assert_allclose(sub, g["grad_sub"], rtol=1e-3, atol=1e-6 * float(np.abs(g["grad_sub"]).max()) + 1e-9)
+    for n in names:
+        if "grad_full." + n in g.files:
+            _close(r["grads"][n], g["grad_full." + n], rtol=1e-3, atol=1e-7)
+    for k in [k for k in p if not p[k].requires_grad]:
+        _close(_stats(p[k]), g["buf_stats." + k], rtol=1e-4)
+        np.testing.assert_allclose(_sub(p[k]), g["buf_sub." + k], rtol=1e-3, atol=1e-4)
+
+
+def test_c1_e2e(golden_dir):
+    g = np.load(os.path.join(golden_dir, "c1_e2e.npz"))
+    p, r, img = _run_e2e(g)
+    _check_e2e(g, p, r, img)
+    names = [str(n) for n in g["param_names"]]
+    after = np.concatenate([_sub(p[n]) for n in names])
+    np.testing.assert_allclose(after, g["param_after_sub"], rtol=1e-4, atol=2e-5)
+    with torch.no_grad():
+        fw2 = O.vqvae_forward(img, p, training=False)
+    np.testing.assert_allclose(_sub(fw2["dec"]), g["dec2_sub"], rtol=2e-2, atol=2e-2)
+    _close(fw2["diff"], g["diff2"], rtol=2e-2)
+
+
+def test_b1_literal_forward(golden_dir):
+    """B=1: the clip generalisation collapses to the reference's VQVAE.forward exactly."""
+    g = np.load(os.path.join(golden_dir, "b1_literal.npz"))
+    p, r, img = _run_e2e(g)
+    _check_e2e(g, p, r, img, literal=True)
+
+
+def test_c2_oneclip(golden_dir):
+    g = np.load(os.path.join(golden_dir, "c2_oneclip.npz"))
+    p, r, img = _run_e2e(g, adam=False)
+    fw = r["fw"]
+    # near-ties exist at this size (min margin ~1e-5): mismatches only where the margin is tiny
+    for lvl in "tb":
+        bad = fw["id_" + lvl].numpy().astype(np.int16).reshape(-1) != g["id_" + lvl].reshape(-1)
+        assert np.all(g["margin_" + lvl][bad] < 1e-4), int(bad.sum())
+        assert bad.mean() < 1e-3
+    _close(r["recon"].item(), g["recon"], rtol=1e-4)
+    _close(r["latent"].item(), g["latent"], rtol=1e-4)
+    names = [str(n) for n in g["param_names"]]
+    gs = np.stack([_stats(r["grads"][n]) for n in names])
+    _close(gs[:, 1], g["grad_stats"][:, 1], rtol=2e-3)
+
+
+def test_lpips_kat(golden_dir):
+    g = np.load(os.path.join(golden_dir, "lpips_kat.npz"))
+    lp = {k: torch.from_numpy(v) for k, v in make_vgg_lpips_state(int(g["seed"])).items()}
+    rec = torch.from_numpy(g["recon"]).requires_grad_(True)
+    val = O.lpips_forward(torch.from_numpy(g["target"]), rec, lp)
+    _close(val.detach(), g["per_image"], rtol=1e-4)
+    val.mean().backward()
+    _close(val.mean().item(), g["value"], rtol=1e-4)
+    np.testing.assert_allclose(rec.grad.numpy(), g["grad_recon"], rtol=1e-3,
+                               atol=1e-5 * float(np.abs(g["grad_recon"]).max()))
