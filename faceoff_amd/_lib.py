@@ -1,0 +1,94 @@
+"""ctypes binding of libfaceoff_hip.so (C ABI: include/faceoff_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a call fails, this
+module raises.  Build with `python -c "import __graft_entry__ as g; g.build()"` or
+`make -C faceoff_amd/csrc`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfaceoff_hip.so")
+
+FO_IN_RELU, FO_BIAS, FO_MASK, FO_ADD, FO_OUT_RELU = 1, 2, 4, 8, 16
+
+
+class FaceoffHipError(RuntimeError):
+    pass
+
+
+class ConvDesc(C.Structure):
+    """Mirror of `fo_conv_desc` (include/faceoff_hip.h)."""
+    _fields_ = [(n, C.c_int32) for n in (
+        "N", "T", "Hin", "Win", "Hm", "Wm", "Hout", "Wout", "Cin", "Cout", "KD", "KH", "KW",
+        "stride", "padD", "padH", "padW", "ostride", "ophH", "ophW",
+        "ldIn", "ldOut", "ldMask", "ldAdd", "flags")]
+
+
+_P = C.c_void_p
+_I = C.c_int
+_L = C.c_int64
+_F = C.c_float
+_D = C.POINTER(ConvDesc)
+
+# name -> (restype, argtypes); must list every symbol include/faceoff_hip.h declares
+SIGNATURES = {
+    "fo_version": (_I, []),
+    "fo_last_error": (C.c_char_p, []),
+    "fo_device_info": (_I, [C.POINTER(C.c_int32)]),
+    "fo_nchw_to_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "fo_nhwc_to_nchw": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "fo_pack_conv": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "fo_pack_conv_dgrad": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "fo_pack_convT_k4s2": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "fo_conv_igemm": (_I, [_D, _P, _P, _P, _P, _P, _P, _P]),
+    "fo_wgrad_ws_bytes": (_L, [_D]),
+    "fo_conv_wgrad": (_I, [_D, _P, _P, _P, _I, _I, _P, _P, _L, _P]),
+    "fo_bias_grad": (_I, [_P, _P, _L, _I, _I, _I, _P, _P]),
+    "fo_vq_prepare": (_I, [_P, _P, _P, _P]),
+    "fo_vq_assign": (_I, [_P, _I, _L, _P, _P, _P, _P, _I, _P, _P, _P, _I, _P]),
+    "fo_vq_ema": (_I, [_P, _P, _P, _P, _P, _F, _F, _F, _P]),
+    "fo_vq_bwd": (_I, [_P, _I, _P, _I, _P, _I, _P, _F, _P, _I, _L, _P]),
+    "fo_vq_gather": (_I, [_P, _P, _P, _I, _L, _P]),
+    "fo_mse_slice_fwd": (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _P]),
+    "fo_mse_slice_bwd": (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _F, _P, _I, _P]),
+    "fo_adam_flat": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _F, _P]),
+    "fo_zero": (_I, [_P, _L, _P]),
+    "fo_relu": (_I, [_P, _I, _P, _I, _L, _I, _P]),
+    "fo_add": (_I, [_P, _I, _P, _I, _P, _I, _L, _I, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the library (once).  Raises FaceoffHipError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FaceoffHipError(
+            f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). "
+            "Build it with `make -C faceoff_amd/csrc` (hipcc --offload-arch=gfx950).")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError if the .so is stale
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().fo_last_error().decode(errors="replace")
+        raise FaceoffHipError(f"{what} failed with code {rc}: {msg}")
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        check(rc, name)

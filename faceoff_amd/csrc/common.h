@@ -1,0 +1,39 @@
+// Shared helpers for the FaceOff gfx950 kernels (internal; the public ABI is include/faceoff_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "faceoff_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+void fo_set_error(const char* fmt, ...);
+
+#define FO_CHECK_LAUNCH()                                                     \
+  do {                                                                        \
+    hipError_t e__ = hipGetLastError();                                       \
+    if (e__ != hipSuccess) {                                                  \
+      fo_set_error("%s:%d: %s", __FILE__, __LINE__, hipGetErrorString(e__)); \
+      return FO_E_HIP;                                                        \
+    }                                                                         \
+  } while (0)
+
+#define FO_REQUIRE(cond, code, ...) \
+  do {                              \
+    if (!(cond)) {                  \
+      fo_set_error(__VA_ARGS__);    \
+      return (code);                \
+    }                               \
+  } while (0)
+
+static inline bool fo_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// Blocks b and b+8 share an XCD (observed round-robin placement; speed only).  Give each XCD a
+// contiguous range of logical tiles so neighbouring tiles (shared halos / shared filter panels)
+// hit the same 4 MiB L2.  Bijective for any grid size.
+__device__ __forceinline__ int fo_xcd_remap(int bid, int nblk) {
+  const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + (bid >> 3);
+}

@@ -1,0 +1,311 @@
+// Filter-gradient (wgrad) kernels for gfx950 on the exact-fp32 MFMA.
+//
+//   dW[a][b][tap] = sum_m P[m][a] * Q[qpix(m,tap)][b]          qpix: coord = m*stride + k - pad
+//
+// Conv2d/Conv3d: P = grad_out (a = Cout), Q = layer input (b = Cin)      -> OIHW / OIDHW
+// ConvTranspose2d k4s2: P = layer input (a = Cin), Q = grad_out (b = Cout) -> [Ci][Co][kh][kw]
+// (autograd of the reference's convs under loss.backward(), train_faceoff_perceptual.py:100).
+//
+// The contraction runs over pixels, which is the row index of both channels-last operands, so
+// the LDS images are the natural [pixel][channel] rows and the MFMA fragments are conflict-free
+// ds_read_b32 row reads (lane -> consecutive channel).  K (pixels) is split across workgroups:
+// each writes an fp32 partial slab [tap][a][b]; a second kernel sums the slabs in a fixed order
+// (bitwise reproducible, no atomics) and scatters into the checkpoint layout.  Temporal taps that
+// only see clip padding are skipped per 32-pixel step.  The conv bias gradient (column sums of
+// P) rides along in the centre-tap workgroups.
+#include <algorithm>
+#include "common.h"
+
+namespace {
+
+struct WgradArgs {
+  fo_conv_desc d;
+  const float* P;
+  const float* Q;
+  float* ws;      // [nchunks][taps][Apad][Bpad]
+  float* wsBias;  // [nchunks][Apad] or null
+  int M, HWm;
+  int chunk;      // pixels per chunk (multiple of 32)
+  int nchunks;
+  int taps;       // tap groups iterated by blocks (SMALLC: KH)
+  int tilesA, tilesB;
+  int Apad, Bpad;
+  int biasTap;    // tap whose blocks also produce the bias partial (-1: none)
+  int stepFrameAligned;  // HWm % 32 == 0
+};
+
+constexpr int WK = 32;  // pixels per K-step
+
+template <int TA, int TB, int WAVES_A, int WAVES_B, int TMA, int TNB, bool SMALLC>
+__global__ __launch_bounds__(64 * WAVES_A * WAVES_B, 2) void conv_wgrad_kernel(const WgradArgs a) {
+  constexpr int NT = 64 * WAVES_A * WAVES_B;
+  static_assert(WAVES_A * TMA * 32 == TA && WAVES_B * TNB * 32 == TB, "tile");
+  constexpr int PA = (WK * TA / 4) / NT;  // float4 loads per thread per step for P
+  constexpr int PB = (WK * TB / 4) / NT;
+  constexpr int RPA = NT / (TA / 4);      // rows covered per pass
+  constexpr int RPB = NT / (TB / 4);
+  static_assert(PA >= 1 && PB >= 1, "tile too small for block");
+  __shared__ __attribute__((aligned(16))) float lds[2 * WK * (TA + TB)];
+  float* Ps0 = lds;
+  float* Qs0 = lds + 2 * WK * TA;
+
+  const fo_conv_desc& d = a.d;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int wa = wave / WAVES_B, wb = wave % WAVES_B;
+
+  // logical block -> (chunk, tap, tileA, tileB); taps of one chunk are neighbours on one XCD
+  int logical = fo_xcd_remap(blockIdx.x, gridDim.x);
+  const int tileB = logical % a.tilesB; logical /= a.tilesB;
+  const int tileA = logical % a.tilesA; logical /= a.tilesA;
+  const int tap = logical % a.taps;
+  const int chunk = logical / a.taps;
+
+  int kd, kh, kw;
+  const int khw = d.KH * d.KW;
+  if (SMALLC) { kd = 0; kh = tap; kw = 0; }
+  else { kd = tap / khw; const int r = tap - kd * khw; kh = r / d.KW; kw = r - kh * d.KW; }
+
+  const int m_begin = chunk * a.chunk;
+  const int m_end = min(a.M, m_begin + a.chunk);
+  const int nsteps = (m_end - m_begin + WK - 1) / WK;
+
+  const int pcolA = (tid % (TA / 4)) * 4, prowA = tid / (TA / 4);
+  const int pcolB = (tid % (TB / 4)) * 4, prowB = tid / (TB / 4);
+  const float* Pbase = a.P + tileA * TA + pcolA;
+  const bool in_relu = d.flags & FO_IN_RELU;
+  const bool do_bias = a.wsBias && tap == a.biasTap && tileB == 0;
+
+  f32x4 rp[PA], rq[PB];
+  f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+
+  auto step_valid = [&](int s) -> bool {
+    if (d.KD == 1 || !a.stepFrameAligned) return true;
+    const int t = ((m_begin + s * WK) / a.HWm) % d.T;
+    return (unsigned)(t + kd - d.padD) < (unsigned)d.T;
+  };
+  auto next_valid = [&](int s) { while (s < nsteps && !step_valid(s)) ++s; return s; };
+
+  auto load_regs = [&](int s) {
+    const int m0 = m_begin + s * WK;
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      const int m = m0 + prowA + RPA * i;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (m < m_end) v = *reinterpret_cast<const f32x4*>(Pbase + (size_t)m * d.ldOut);
+      rp[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+      const int m = m0 + prowB + RPB * i;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (m < m_end) {
+        const int n = m / a.HWm;
+        const int rem = m - n * a.HWm;
+        const int y = rem / d.Wm;
+        const int x = rem - y * d.Wm;
+        int kwt = kw, coff = tileB * TB + pcolB;
+        if (SMALLC) { kwt = pcolB >> 3; coff = pcolB & 7; }
+        const int it = (n % d.T) + kd - d.padD;
+        const int iy = y * d.stride - d.padH + kh;
+        const int ix = x * d.stride - d.padW + kwt;
+        if ((unsigned)it < (unsigned)d.T && (unsigned)iy < (unsigned)d.Hin && (unsigned)ix < (unsigned)d.Win) {
+          const size_t pix = ((size_t)(n + kd - d.padD) * d.Hin + iy) * d.Win + ix;
+          v = *reinterpret_cast<const f32x4*>(a.Q + pix * d.ldIn + coff);
+          if (in_relu) {
+            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+          }
+        }
+      }
+      rq[i] = v;
+    }
+  };
+  auto store_lds = [&](int buf) {
+    float* Ps = Ps0 + buf * WK * TA;
+    float* Qs = Qs0 + buf * WK * TB;
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      *reinterpret_cast<f32x4*>(Ps + (prowA + RPA * i) * TA + pcolA) = rp[i];
+      if (do_bias) bsum += rp[i];
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) *reinterpret_cast<f32x4*>(Qs + (prowB + RPB * i) * TB + pcolB) = rq[i];
+  };
+
+  f32x16 acc[TMA][TNB];
+#pragma unroll
+  for (int i = 0; i < TMA; ++i)
+#pragma unroll
+    for (int j = 0; j < TNB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  int s = next_valid(0);
+  if (s < nsteps) { load_regs(s); store_lds(0); }
+  __syncthreads();
+  int cur = 0;
+  while (s < nsteps) {
+    const int s2 = next_valid(s + 1);
+    if (s2 < nsteps) load_regs(s2);
+    const float* Ps = Ps0 + cur * WK * TA + half * TA + wa * TMA * 32 + l31;
+    const float* Qs = Qs0 + cur * WK * TB + half * TB + wb * TNB * 32 + l31;
+#pragma unroll
+    for (int kp = 0; kp < WK / 2; ++kp) {
+      float fa[TMA], fb[TNB];
+#pragma unroll
+      for (int i = 0; i < TMA; ++i) fa[i] = Ps[kp * 2 * TA + i * 32];
+#pragma unroll
+      for (int j = 0; j < TNB; ++j) fb[j] = Qs[kp * 2 * TB + j * 32];
+#pragma unroll
+      for (int i = 0; i < TMA; ++i)
+#pragma unroll
+        for (int j = 0; j < TNB; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    if (s2 < nsteps) store_lds(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+    s = s2;
+  }
+
+  // ---- partial slab [chunk][tap][Apad][Bpad]
+  float* slab = a.ws + ((size_t)chunk * a.taps + tap) * a.Apad * a.Bpad;
+#pragma unroll
+  for (int i = 0; i < TMA; ++i)
+#pragma unroll
+    for (int j = 0; j < TNB; ++j) {
+      const int col = tileB * TB + (wb * TNB + j) * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = tileA * TA + (wa * TMA + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        slab[(size_t)row * a.Bpad + col] = acc[i][j][r];
+      }
+    }
+
+  if (do_bias) {  // column sums of P over this chunk: reduce the RPA threads sharing a column group
+    __syncthreads();
+    f32x4* red = reinterpret_cast<f32x4*>(lds);
+    red[tid] = bsum;
+    __syncthreads();
+    if (tid < TA / 4) {
+      f32x4 t = red[tid];
+      for (int r = 1; r < RPA; ++r) t += red[tid + r * (TA / 4)];
+      *reinterpret_cast<f32x4*>(a.wsBias + (size_t)chunk * a.Apad + tileA * TA + tid * 4) = t;
+    }
+  }
+}
+
+// Sum the slabs in chunk order and scatter to the checkpoint layout dW[a][b][tap].
+__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nchunks, int taps,
+                                    int Apad, int Bpad, int Areal, int Breal, int smallc, int KW) {
+  const size_t slabElems = (size_t)taps * Apad * Bpad;
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < slabElems; e += (size_t)gridDim.x * blockDim.x) {
+    const int b = e % Bpad;
+    const int aidx = (e / Bpad) % Apad;
+    const int tap = e / ((size_t)Bpad * Apad);
+    int breal = b, tapOut = tap, tapsOut = taps;
+    if (smallc) { breal = b & 7; tapOut = tap * KW + (b >> 3); tapsOut = taps * KW; }
+    if (aidx >= Areal || breal >= Breal) continue;
+    float s = 0.f;
+    for (int c = 0; c < nchunks; ++c) s += ws[c * slabElems + e];
+    dw[((size_t)aidx * Breal + breal) * tapsOut + tapOut] = s;
+  }
+}
+
+__global__ void bias_reduce_kernel(const float* __restrict__ ws, float* __restrict__ db, int nchunks, int Apad, int Areal) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= Areal) return;
+  float s = 0.f;
+  for (int k = 0; k < nchunks; ++k) s += ws[(size_t)k * Apad + c];
+  db[c] = s;
+}
+
+struct Plan {
+  int TA, TB, tilesA, tilesB, Apad, Bpad, taps, chunk, nchunks;
+  bool smallc;
+};
+
+int make_plan(const fo_conv_desc* d, Plan* p) {
+  const int A = d->Cout, B = d->Cin;  // channels of P (a) and Q (b)
+  p->smallc = B < 32;
+  if (p->smallc) {
+    FO_REQUIRE(B == 8 && d->KW == 4 && d->KD == 1, FO_E_SHAPE, "wgrad: small Q channels need Cb==8, KW==4 (got %d,%d)", B, d->KW);
+    FO_REQUIRE(A == 64, FO_E_SHAPE, "wgrad: small-channel path needs Ca==64 (got %d)", A);
+    p->TA = 64; p->TB = 32; p->taps = d->KH; p->tilesA = 1; p->tilesB = 1;
+  } else {
+    FO_REQUIRE(A % 32 == 0 && B % 32 == 0, FO_E_SHAPE, "wgrad: channels must be multiples of 32 (a=%d b=%d)", A, B);
+    p->TA = A % 128 == 0 ? 128 : (A % 64 == 0 ? 64 : 32);
+    p->TB = B % 128 == 0 ? 128 : (B % 64 == 0 ? 64 : 32);
+    p->taps = d->KD * d->KH * d->KW;
+    p->tilesA = A / p->TA; p->tilesB = B / p->TB;
+  }
+  p->Apad = p->TA * p->tilesA; p->Bpad = p->TB * p->tilesB;
+  const long long M = (long long)d->N * d->Hm * d->Wm;
+  FO_REQUIRE(M > 0 && M < (1ll << 31), FO_E_SHAPE, "wgrad: M out of range");
+  // chunking: aim for ~1024 workgroups (4 per CU), >= 16 K-steps each, chunks a multiple of 32 pixels
+  const long long perChunkBlocks = (long long)p->taps * p->tilesA * p->tilesB;
+  long long want = (1024 + perChunkBlocks - 1) / perChunkBlocks;
+  if (want < 1) want = 1;
+  long long chunk = (M + want - 1) / want;
+  if (chunk < 512) chunk = 512;
+  chunk = (chunk + 31) / 32 * 32;
+  p->chunk = (int)chunk;
+  p->nchunks = (int)((M + chunk - 1) / chunk);
+  return FO_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t fo_wgrad_ws_bytes(const fo_conv_desc* d) {
+  Plan p;
+  if (make_plan(d, &p) != FO_OK) return -1;
+  return ((int64_t)p.nchunks * p.taps * p.Apad * p.Bpad + (int64_t)p.nchunks * p.Apad) * 4 + 256;
+}
+
+#define WG_LAUNCH(TA_, TB_, WA_, WB_, TM_, TN_, SC_)                                                        \
+  hipLaunchKernelGGL((conv_wgrad_kernel<TA_, TB_, WA_, WB_, TM_, TN_, SC_>), dim3(grid), dim3(64 * WA_ * WB_), \
+                     0, s, a)
+
+extern "C" int fo_conv_wgrad(const fo_conv_desc* d, const float* P, const float* Q, float* dw, int Areal, int Breal,
+                             float* dbias, float* ws, int64_t ws_bytes, void* stream) {
+  Plan p;
+  int rc = make_plan(d, &p);
+  if (rc != FO_OK) return rc;
+  FO_REQUIRE(ws_bytes >= fo_wgrad_ws_bytes(d), FO_E_WORKSPACE, "wgrad: workspace too small");
+  FO_REQUIRE(fo_aligned16(P) && fo_aligned16(Q) && fo_aligned16(ws) && d->ldIn % 4 == 0 && d->ldOut % 4 == 0, FO_E_ALIGN,
+             "wgrad: operands must be 16-byte aligned with ld %% 4 == 0");
+  WgradArgs a;
+  a.d = *d; a.P = P; a.Q = Q; a.ws = ws;
+  a.HWm = d->Hm * d->Wm;
+  a.M = d->N * a.HWm;
+  a.chunk = p.chunk; a.nchunks = p.nchunks; a.taps = p.taps;
+  a.tilesA = p.tilesA; a.tilesB = p.tilesB; a.Apad = p.Apad; a.Bpad = p.Bpad;
+  const size_t slab = (size_t)p.nchunks * p.taps * p.Apad * p.Bpad;
+  a.wsBias = dbias ? ws + ((slab + 63) / 64) * 64 : nullptr;
+  a.biasTap = p.smallc ? 0 : d->padD * d->KH * d->KW;
+  a.stepFrameAligned = (a.HWm % WK) == 0 && (p.chunk % WK) == 0;
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = p.nchunks * p.taps * p.tilesA * p.tilesB;
+  if (p.smallc) WG_LAUNCH(64, 32, 2, 1, 1, 1, true);
+  else if (p.TA == 128 && p.TB == 128) WG_LAUNCH(128, 128, 2, 2, 2, 2, false);
+  else if (p.TA == 128 && p.TB == 64) WG_LAUNCH(128, 64, 2, 2, 2, 1, false);
+  else if (p.TA == 64 && p.TB == 128) WG_LAUNCH(64, 128, 2, 2, 1, 2, false);
+  else if (p.TA == 128 && p.TB == 32) WG_LAUNCH(128, 32, 4, 1, 1, 1, false);
+  else if (p.TA == 32 && p.TB == 128) WG_LAUNCH(32, 128, 1, 4, 1, 1, false);
+  else if (p.TA == 64 && p.TB == 64) WG_LAUNCH(64, 64, 2, 2, 1, 1, false);
+  else if (p.TA == 64 && p.TB == 32) WG_LAUNCH(64, 32, 2, 1, 1, 1, false);
+  else if (p.TA == 32 && p.TB == 64) WG_LAUNCH(32, 64, 1, 2, 1, 1, false);
+  else if (p.TA == 32 && p.TB == 32) WG_LAUNCH(32, 32, 1, 1, 1, 1, false);
+  else FO_REQUIRE(false, FO_E_SHAPE, "wgrad: unsupported tile %dx%d", p.TA, p.TB);
+  FO_CHECK_LAUNCH();
+  const size_t slabElems = (size_t)p.taps * p.Apad * p.Bpad;
+  const int rgrid = (int)std::min<size_t>((slabElems + 255) / 256, 4096);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rgrid), dim3(256), 0, s, ws, dw, p.nchunks, p.taps, p.Apad, p.Bpad,
+                     Areal, Breal, p.smallc ? 1 : 0, d->KW);
+  FO_CHECK_LAUNCH();
+  if (dbias) {
+    hipLaunchKernelGGL(bias_reduce_kernel, dim3((Areal + 63) / 64), dim3(64), 0, s, a.wsBias, dbias, p.nchunks, p.Apad, Areal);
+    FO_CHECK_LAUNCH();
+  }
+  return FO_OK;
+}

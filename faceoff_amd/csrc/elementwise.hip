@@ -1,0 +1,188 @@
+// HBM-bound kernels of the step: losses, bias gradients, optimiser, small utilities.
+// All are grid-stride, 16 B per lane where the layout allows it.
+#include <algorithm>
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// criterion = nn.MSELoss() on out[:, :3] (train_faceoff_perceptual.py:21,37-39): dec is NHWC (ld floats
+// per pixel), gt is the loader's NCHW tensor.  Accumulates sum of squares into *sum.
+__global__ void mse_slice_fwd_kernel(const float* __restrict__ dec, int ldd, const float* __restrict__ gt, int HW,
+                                     long long npix, int C3, float* sum) {
+  float s = 0.f;
+  for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < npix; p += (long long)gridDim.x * blockDim.x) {
+    const long long n = p / HW;
+    const int hw = (int)(p - n * HW);
+    const f32x4 d = *reinterpret_cast<const f32x4*>(dec + p * ldd);
+    const float* g = gt + (n * C3) * (long long)HW + hw;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      if (c < C3) { const float e = d[c] - g[(long long)c * HW]; s = fmaf(e, e, s); }
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) atomicAdd(sum, s);
+}
+
+__global__ void mse_slice_bwd_kernel(const float* __restrict__ dec, int ldd, const float* __restrict__ gt, int HW,
+                                     long long npix, int C3, const float* __restrict__ gscale, float inv_numel,
+                                     float* __restrict__ gdec, int ldg) {
+  const float k = 2.f * inv_numel * gscale[0];
+  for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < npix; p += (long long)gridDim.x * blockDim.x) {
+    const long long n = p / HW;
+    const int hw = (int)(p - n * HW);
+    const f32x4 d = *reinterpret_cast<const f32x4*>(dec + p * ldd);
+    const float* g = gt + (n * C3) * (long long)HW + hw;
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      if (c < C3) o[c] = k * (d[c] - g[(long long)c * HW]);
+    *reinterpret_cast<f32x4*>(gdec + p * ldg) = o;
+    for (int c = 4; c < ldg; c += 4) *reinterpret_cast<f32x4*>(gdec + p * ldg + c) = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+}
+
+// column sums of g[M][ld] (first C channels): stage 1 -> ws[block][C], stage 2 sums blocks in order
+__global__ void colsum_stage1(const float* __restrict__ g, float* __restrict__ ws, long long M, int C, int ld) {
+  __shared__ f32x4 red[256];
+  const int cg = C / 4;  // float4 column groups
+  const int col = threadIdx.x % cg, rl = threadIdx.x / cg, nrl = blockDim.x / cg;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (rl < nrl)
+    for (long long m = (long long)blockIdx.x * nrl + rl; m < M; m += (long long)gridDim.x * nrl)
+      s += *reinterpret_cast<const f32x4*>(g + m * ld + col * 4);
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x < cg) {
+    f32x4 t = red[threadIdx.x];
+    for (int r = 1; r < nrl; ++r) t += red[threadIdx.x + r * cg];
+    *reinterpret_cast<f32x4*>(ws + (size_t)blockIdx.x * C + threadIdx.x * 4) = t;
+  }
+}
+__global__ void colsum_stage2(const float* __restrict__ ws, float* __restrict__ out, int nblk, int C, int Creal) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= Creal) return;
+  float s = 0.f;
+  for (int b = 0; b < nblk; ++b) s += ws[(size_t)b * C + c];
+  out[c] = s;
+}
+
+// torch.optim.Adam (defaults; train_faceoff_perceptual.py:190) over a flat arena.
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            long long n4, float lr_over_bc1, float b1, float b2, float eps, float inv_sqrt_bc2, float gscale) {
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < n4; e += (long long)gridDim.x * blockDim.x) {
+    const f32x4 gv = reinterpret_cast<const f32x4*>(g)[e] * gscale;
+    f32x4 mv = reinterpret_cast<f32x4*>(m)[e], vv = reinterpret_cast<f32x4*>(v)[e], pv = reinterpret_cast<f32x4*>(p)[e];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      mv[c] = mv[c] * b1 + gv[c] * (1.f - b1);
+      vv[c] = vv[c] * b2 + gv[c] * gv[c] * (1.f - b2);
+      const float denom = sqrtf(vv[c]) * inv_sqrt_bc2 + eps;
+      pv[c] = pv[c] - lr_over_bc1 * (mv[c] / denom);
+    }
+    reinterpret_cast<f32x4*>(m)[e] = mv;
+    reinterpret_cast<f32x4*>(v)[e] = vv;
+    reinterpret_cast<f32x4*>(p)[e] = pv;
+  }
+}
+
+__global__ void zero_kernel(float* p, long long n) {
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) p[e] = 0.f;
+}
+
+__global__ void relu_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, long long rows, int C4) {
+  const long long total = rows * C4;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const long long r = e / C4;
+    const int c = (int)(e % C4) * 4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(x + r * ldx + c);
+    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    *reinterpret_cast<f32x4*>(y + r * ldy + c) = v;
+  }
+}
+
+__global__ void add_kernel(const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb, float* __restrict__ y,
+                           int ldy, long long rows, int C4) {
+  const long long total = rows * C4;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const long long r = e / C4;
+    const int c = (int)(e % C4) * 4;
+    *reinterpret_cast<f32x4*>(y + r * ldy + c) =
+        *reinterpret_cast<const f32x4*>(a + r * lda + c) + *reinterpret_cast<const f32x4*>(b + r * ldb + c);
+  }
+}
+
+inline int grid_for(long long total, int cap = 4096) {
+  return (int)std::max<long long>(1, std::min<long long>((total + 255) / 256, cap));
+}
+
+}  // namespace
+
+extern "C" {
+
+int fo_mse_slice_fwd(const float* dec, int ldd, const float* gt_nchw, int N, int H, int W, int C3, float* sum, void* stream) {
+  FO_REQUIRE(C3 <= 3 && ldd % 4 == 0, FO_E_SHAPE, "mse: at most 3 channels, ld %% 4 == 0");
+  const long long npix = (long long)N * H * W;
+  hipLaunchKernelGGL(mse_slice_fwd_kernel, dim3(grid_for(npix, 2048)), dim3(256), 0, (hipStream_t)stream, dec, ldd, gt_nchw,
+                     H * W, npix, C3, sum);
+  FO_CHECK_LAUNCH();
+  return FO_OK;
+}
+
+int fo_mse_slice_bwd(const float* dec, int ldd, const float* gt_nchw, int N, int H, int W, int C3, const float* gscale,
+                     float inv_numel, float* gdec, int ldg, void* stream) {
+  FO_REQUIRE(C3 <= 3 && ldd % 4 == 0 && ldg % 4 == 0, FO_E_SHAPE, "mse: at most 3 channels, ld %% 4 == 0");
+  const long long npix = (long long)N * H * W;
+  hipLaunchKernelGGL(mse_slice_bwd_kernel, dim3(grid_for(npix, 4096)), dim3(256), 0, (hipStream_t)stream, dec, ldd, gt_nchw,
+                     H * W, npix, C3, gscale, inv_numel, gdec, ldg);
+  FO_CHECK_LAUNCH();
+  return FO_OK;
+}
+
+int fo_bias_grad(const float* g, float* dbias, int64_t M, int C, int Creal, int ld, float* ws, void* stream) {
+  FO_REQUIRE(C % 4 == 0 && C / 4 <= 256 && Creal <= C && ld % 4 == 0, FO_E_SHAPE, "bias_grad: C %% 4 == 0, C <= 1024");
+  const int nrl = 256 / (C / 4);
+  const int nblk = (int)std::max<long long>(1, std::min<long long>(1024, (M + nrl * 8 - 1) / (nrl * 8)));
+  hipLaunchKernelGGL(colsum_stage1, dim3(nblk), dim3(256), 0, (hipStream_t)stream, g, ws, (long long)M, C, ld);
+  FO_CHECK_LAUNCH();
+  hipLaunchKernelGGL(colsum_stage2, dim3((Creal + 63) / 64), dim3(64), 0, (hipStream_t)stream, ws, dbias, nblk, C, Creal);
+  FO_CHECK_LAUNCH();
+  return FO_OK;
+}
+
+int fo_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                 float bias_corr1, float bias_corr2, float grad_scale, void* stream) {
+  FO_REQUIRE(n % 4 == 0, FO_E_ALIGN, "adam: arena length must be a multiple of 4");
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4, 2048)), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
+                     (long long)(n / 4), lr / bias_corr1, beta1, beta2, eps, 1.f / sqrtf(bias_corr2), grad_scale);
+  FO_CHECK_LAUNCH();
+  return FO_OK;
+}
+
+int fo_zero(float* p, int64_t n, void* stream) {
+  hipLaunchKernelGGL(zero_kernel, dim3(grid_for(n, 2048)), dim3(256), 0, (hipStream_t)stream, p, (long long)n);
+  FO_CHECK_LAUNCH();
+  return FO_OK;
+}
+
+int fo_relu(const float* x, int ldx, float* y, int ldy, int64_t rows, int C, void* stream) {
+  FO_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0, FO_E_ALIGN, "relu: C/ld %% 4");
+  hipLaunchKernelGGL(relu_kernel, dim3(grid_for(rows * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy,
+                     (long long)rows, C / 4);
+  FO_CHECK_LAUNCH();
+  return FO_OK;
+}
+
+int fo_add(const float* a, int lda, const float* b, int ldb, float* y, int ldy, int64_t rows, int C, void* stream) {
+  FO_REQUIRE(C % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ldy % 4 == 0, FO_E_ALIGN, "add: C/ld %% 4");
+  hipLaunchKernelGGL(add_kernel, dim3(grid_for(rows * (C / 4))), dim3(256), 0, (hipStream_t)stream, a, lda, b, ldb, y, ldy,
+                     (long long)rows, C / 4);
+  FO_CHECK_LAUNCH();
+  return FO_OK;
+}
+}

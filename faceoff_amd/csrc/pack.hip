@@ -1,0 +1,141 @@
+// Filter packing (checkpoint layout -> K-contiguous GEMM-B rows) and NCHW <-> NHWC transforms.
+// The checkpoint layouts are the reference's state_dict shapes.
+#include <algorithm>
+#include "common.h"
+
+namespace {
+
+// wp[o][t][i] = w[o][i][t]                     (o < O, i < I; zero elsewhere)
+__global__ void pack_conv_kernel(const float* __restrict__ w, float* __restrict__ wp, int O, int I, int taps,
+                                 int Opad, int Ipad) {
+  const size_t total = (size_t)Opad * taps * Ipad;
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int i = e % Ipad;
+    const int t = (e / Ipad) % taps;
+    const int o = e / ((size_t)Ipad * taps);
+    wp[e] = (o < O && i < I) ? w[((size_t)o * I + i) * taps + t] : 0.f;
+  }
+}
+
+// wp[i][t][o] = w[o][i][taps-1-t]              (stride-1 dgrad: flipped taps, swapped channels)
+__global__ void pack_conv_dgrad_kernel(const float* __restrict__ w, float* __restrict__ wp, int O, int I, int taps,
+                                       int Opad, int Ipad) {
+  const size_t total = (size_t)Ipad * taps * Opad;
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int o = e % Opad;
+    const int t = (e / Opad) % taps;
+    const int i = e / ((size_t)Opad * taps);
+    wp[e] = (o < O && i < I) ? w[((size_t)o * I + i) * taps + (taps - 1 - t)] : 0.f;
+  }
+}
+
+// ConvTranspose2d k4 s2 p1, weight w[ci][co][kh][kw].  Output row oy = 2*iy - 1 + kh.
+// Phase py = oy & 1 uses two input rows; with tap ty in {0,1} at input row m + ty - padp,
+//   py = 0: padp = 1, kh = 3 - 2*ty   (rows m-1, m)
+//   py = 1: padp = 0, kh = 2 - 2*ty   (rows m, m+1)
+// wp[ph][co][ty*2+tx][ci]
+__global__ void pack_convT_kernel(const float* __restrict__ w, float* __restrict__ wp, int Ci, int Co, int Cipad,
+                                  int Copad) {
+  const size_t total = (size_t)4 * Copad * 4 * Cipad;
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int ci = e % Cipad;
+    const int t = (e / Cipad) % 4;
+    const int co = (e / ((size_t)Cipad * 4)) % Copad;
+    const int ph = e / ((size_t)Cipad * 4 * Copad);
+    const int py = ph >> 1, px = ph & 1, ty = t >> 1, tx = t & 1;
+    const int kh = (py == 0 ? 3 : 2) - 2 * ty;
+    const int kw = (px == 0 ? 3 : 2) - 2 * tx;
+    wp[e] = (ci < Ci && co < Co) ? w[(((size_t)ci * Co + co) * 4 + kh) * 4 + kw] : 0.f;
+  }
+}
+
+// [N,C,H,W] -> [N,H,W,ld] through an LDS tile so both sides are coalesced.
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y, int C, int HW, int Cpad, int ld) {
+  __shared__ float tile[64][33];  // [pixel][channel] up to 32 channels per pass
+  const int n = blockIdx.y;
+  const int p0 = blockIdx.x * 64;
+  for (int c0 = 0; c0 < Cpad; c0 += 32) {
+    for (int idx = threadIdx.x; idx < 32 * 64; idx += blockDim.x) {
+      const int c = idx / 64, p = idx % 64;
+      float v = 0.f;
+      if (c0 + c < C && p0 + p < HW) v = x[((size_t)n * C + c0 + c) * HW + p0 + p];
+      tile[p][c] = v;
+    }
+    __syncthreads();
+    const int cw = min(32, Cpad - c0);
+    for (int idx = threadIdx.x; idx < cw * 64; idx += blockDim.x) {
+      const int p = idx / cw, c = idx % cw;
+      if (p0 + p < HW) y[((size_t)n * HW + p0 + p) * ld + c0 + c] = tile[p][c];
+    }
+    __syncthreads();
+  }
+}
+
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ x, float* __restrict__ y, int C, int HW, int ld, int accumulate) {
+  __shared__ float tile[64][33];
+  const int n = blockIdx.y;
+  const int p0 = blockIdx.x * 64;
+  for (int c0 = 0; c0 < C; c0 += 32) {
+    const int cw = min(32, C - c0);
+    for (int idx = threadIdx.x; idx < cw * 64; idx += blockDim.x) {
+      const int p = idx / cw, c = idx % cw;
+      tile[p][c] = (p0 + p < HW) ? x[((size_t)n * HW + p0 + p) * ld + c0 + c] : 0.f;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < cw * 64; idx += blockDim.x) {
+      const int c = idx / 64, p = idx % 64;
+      if (p0 + p < HW) {
+        float* dst = y + ((size_t)n * C + c0 + c) * HW + p0 + p;
+        *dst = accumulate ? *dst + tile[p][c] : tile[p][c];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+inline int grid_for(size_t total) { return (int)std::min<size_t>((total + 255) / 256, 8192); }
+
+}  // namespace
+
+extern "C" {
+
+int fo_pack_conv(const float* w, float* wp, int O, int I, int taps, int Opad, int Ipad, void* stream) {
+  FO_REQUIRE(Opad >= O && Ipad >= I && taps > 0, FO_E_SHAPE, "pack_conv: bad padding");
+  hipLaunchKernelGGL(pack_conv_kernel, dim3(grid_for((size_t)Opad * taps * Ipad)), dim3(256), 0, (hipStream_t)stream, w, wp, O,
+                     I, taps, Opad, Ipad);
+  FO_CHECK_LAUNCH();
+  return FO_OK;
+}
+
+int fo_pack_conv_dgrad(const float* w, float* wp, int O, int I, int taps, int Opad, int Ipad, void* stream) {
+  FO_REQUIRE(Opad >= O && Ipad >= I && taps > 0, FO_E_SHAPE, "pack_conv_dgrad: bad padding");
+  hipLaunchKernelGGL(pack_conv_dgrad_kernel, dim3(grid_for((size_t)Opad * taps * Ipad)), dim3(256), 0, (hipStream_t)stream, w,
+                     wp, O, I, taps, Opad, Ipad);
+  FO_CHECK_LAUNCH();
+  return FO_OK;
+}
+
+int fo_pack_convT_k4s2(const float* w, float* wp, int Ci, int Co, int Cipad, int Copad, void* stream) {
+  FO_REQUIRE(Cipad >= Ci && Copad >= Co, FO_E_SHAPE, "pack_convT: bad padding");
+  hipLaunchKernelGGL(pack_convT_kernel, dim3(grid_for((size_t)16 * Copad * Cipad)), dim3(256), 0, (hipStream_t)stream, w, wp,
+                     Ci, Co, Cipad, Copad);
+  FO_CHECK_LAUNCH();
+  return FO_OK;
+}
+
+int fo_nchw_to_nhwc(const float* x, float* y, int N, int C, int H, int W, int Cpad, int ldy, void* stream) {
+  FO_REQUIRE(Cpad >= C && ldy >= Cpad, FO_E_SHAPE, "nchw_to_nhwc: bad channel padding");
+  const int HW = H * W;
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((HW + 63) / 64, N), dim3(256), 0, (hipStream_t)stream, x, y, C, HW, Cpad, ldy);
+  FO_CHECK_LAUNCH();
+  return FO_OK;
+}
+
+int fo_nhwc_to_nchw(const float* x, float* y, int N, int C, int H, int W, int ldx, int accumulate, void* stream) {
+  const int HW = H * W;
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((HW + 63) / 64, N), dim3(256), 0, (hipStream_t)stream, x, y, C, HW, ldx,
+                     accumulate);
+  FO_CHECK_LAUNCH();
+  return FO_OK;
+}
+}

@@ -1,0 +1,205 @@
+// Vector quantiser kernels (reference Quantize.forward, models/vqvae_conv3d_latent.py:47-83).
+//
+// fo_vq_assign fuses what the reference does with two sgemms, two materialised [Nvec,512]
+// matrices (dist :49-53, one_hot :55) and ~10 elementwise kernels:
+//   distance (expanded form, exact-fp32 MFMA)  ->  running first-index arg-min  ->  codebook
+//   gather + straight-through value (:57,78)   ->  commitment sum (:77)  ->  EMA statistics
+//   (:60-61) -- `dist` and the one-hot never exist in memory.
+//
+// Numerics contract (restated bit-for-bit by oracle/vq_oracle.c):
+//   dot(x,e)  = fp32 fma chain over k = 0..63 in order, starting from 0 (what the MFMA computes)
+//   ||v||^2   = chain over even k  +  chain over odd k
+//   dist      = (||x||^2 - 2*dot) + ||e||^2,   index = first minimum (torch.max tie-break on -dist)
+#include <algorithm>
+#include "common.h"
+
+namespace {
+
+constexpr int VQ_D = 64, VQ_K = 512, VQ_LD = 65;
+
+__global__ void vq_prepare_kernel(const float* __restrict__ embed, float* __restrict__ embedT, float* __restrict__ enorm) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= VQ_K) return;
+  float ev = 0.f, od = 0.f;
+  for (int k = 0; k < VQ_D; k += 2) {
+    const float a = embed[(size_t)k * VQ_K + c], b = embed[(size_t)(k + 1) * VQ_K + c];
+    embedT[(size_t)c * VQ_D + k] = a;
+    embedT[(size_t)c * VQ_D + k + 1] = b;
+    ev = fmaf(a, a, ev);
+    od = fmaf(b, b, od);
+  }
+  enorm[c] = ev + od;
+}
+
+// Persistent: one workgroup per CU keeps the whole codebook (512 x 64, rows padded to 65 floats:
+// conflict-free both for the MFMA A-fragment column reads and the row gathers) in LDS and its
+// four waves walk 32-vector tiles independently.  MFMA roles: A = codes (rows), B = vectors
+// (columns), so a lane owns ONE vector and sees 16 codes per 32-code tile in its accumulator:
+// the arg-min is a per-lane scan plus one cross-half exchange.
+__global__ __launch_bounds__(256, 1) void vq_assign_kernel(const float* __restrict__ x, int ldx, long long nvec,
+                                                           const float* __restrict__ embedT,
+                                                           const float* __restrict__ enorm, long long* __restrict__ ind,
+                                                           float* __restrict__ qout, int ldq, float* sq_sum,
+                                                           float* counts, float* esum, int train) {
+  __shared__ float E[VQ_K * VQ_LD + VQ_K];
+  float* En = E + VQ_K * VQ_LD;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
+  for (int idx = tid; idx < VQ_K * VQ_D; idx += 256) E[(idx >> 6) * VQ_LD + (idx & 63)] = embedT[idx];
+  for (int idx = tid; idx < VQ_K; idx += 256) En[idx] = enorm[idx];
+  __syncthreads();
+
+  const long long ntiles = (nvec + 31) / 32;
+  float sq = 0.f;
+  for (long long tile = (long long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long long)gridDim.x * 4) {
+    const long long v = tile * 32 + l31;
+    const bool valid = v < nvec;
+    float xr[32];
+    const float* xp = x + (size_t)(valid ? v : 0) * ldx + half;
+#pragma unroll
+    for (int s = 0; s < 32; ++s) xr[s] = valid ? xp[2 * s] : 0.f;
+    float xh = 0.f;
+#pragma unroll
+    for (int s = 0; s < 32; ++s) xh = fmaf(xr[s], xr[s], xh);
+    const float xx = xh + __shfl_xor(xh, 32);
+
+    float best_d = INFINITY;
+    int best_i = 0;
+    for (int ct = 0; ct < VQ_K / 32; ++ct) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const float* Erow = E + (ct * 32 + l31) * VQ_LD + half;
+#pragma unroll
+      for (int s = 0; s < 32; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Erow[2 * s], xr[s], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int code = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const float d = (xx - 2.f * acc[r]) + En[code];
+        if (d < best_d) { best_d = d; best_i = code; }
+      }
+    }
+    const float od = __shfl_xor(best_d, 32);
+    const int oi = __shfl_xor(best_i, 32);
+    if (od < best_d || (od == best_d && oi < best_i)) { best_d = od; best_i = oi; }
+    if (half == 0 && valid) ind[v] = best_i;
+
+    // gather + straight-through + statistics: the wave walks its 32 vectors, 64 lanes = 64 dims
+    const int nhere = (int)min<long long>(32, nvec - tile * 32);
+    for (int j = 0; j < nhere; ++j) {
+      const int idx = __shfl(best_i, j);
+      const size_t vj = (size_t)(tile * 32 + j);
+      const float xv = x[vj * ldx + lane];
+      const float q = E[idx * VQ_LD + lane];
+      const float diff = q - xv;
+      qout[vj * ldq + lane] = xv + diff;  // input + (quantize - input).detach()   (:78)
+      sq = fmaf(diff, diff, sq);
+      if (train) {
+        atomicAdd(&esum[(size_t)idx * VQ_D + lane], xv);  // 256 contiguous bytes per wave-instruction
+        if (lane == 0) atomicAdd(&counts[idx], 1.f);
+      }
+    }
+  }
+  // commitment sum: wave reduce, then one atomic per wave
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+  if (lane == 0) atomicAdd(sq_sum, sq);
+}
+
+// EMA update (:66-75).  One workgroup, one thread per code.
+__global__ __launch_bounds__(VQ_K) void vq_ema_kernel(float* embed, float* cluster_size, float* embed_avg,
+                                                     const float* __restrict__ counts, const float* __restrict__ esum,
+                                                     float decay, float alpha, float eps) {
+  __shared__ float red[VQ_K];
+  const int c = threadIdx.x;
+  const float cs = cluster_size[c] * decay + counts[c] * alpha;
+  cluster_size[c] = cs;
+  red[c] = cs;
+  __syncthreads();
+  for (int o = VQ_K / 2; o > 0; o >>= 1) {
+    if (c < o) red[c] += red[c + o];
+    __syncthreads();
+  }
+  const float n = red[0];
+  const float csn = (cs + eps) / (n + VQ_K * eps) * n;
+  for (int d = 0; d < VQ_D; ++d) {
+    const float ea = embed_avg[(size_t)d * VQ_K + c] * decay + esum[(size_t)c * VQ_D + d] * alpha;
+    embed_avg[(size_t)d * VQ_K + c] = ea;
+    embed[(size_t)d * VQ_K + c] = ea / csn;
+  }
+}
+
+__global__ void vq_bwd_kernel(const float* __restrict__ gq, int ldg, const float* __restrict__ x, int ldx,
+                              const float* __restrict__ q, int ldq, const float* __restrict__ gdiff, float scale,
+                              float* __restrict__ gx, int ldgx, long long nvec) {
+  const float gs = gdiff[0] * scale;
+  const long long total = nvec * (VQ_D / 4);
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const long long v = e / (VQ_D / 4);
+    const int c = (int)(e % (VQ_D / 4)) * 4;
+    const f32x4 g = *reinterpret_cast<const f32x4*>(gq + v * ldg + c);
+    const f32x4 xv = *reinterpret_cast<const f32x4*>(x + v * ldx + c);
+    const f32x4 qv = *reinterpret_cast<const f32x4*>(q + v * ldq + c);
+    *reinterpret_cast<f32x4*>(gx + v * ldgx + c) = g + gs * (xv - qv);
+  }
+}
+
+__global__ void vq_gather_kernel(const long long* __restrict__ ind, const float* __restrict__ embedT,
+                                 float* __restrict__ q, int ldq, long long nvec) {
+  const long long total = nvec * (VQ_D / 4);
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const long long v = e / (VQ_D / 4);
+    const int c = (int)(e % (VQ_D / 4)) * 4;
+    const long long i = ind[v];
+    *reinterpret_cast<f32x4*>(q + v * ldq + c) = *reinterpret_cast<const f32x4*>(embedT + i * VQ_D + c);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int fo_vq_prepare(const float* embed, float* embedT, float* enorm, void* stream) {
+  hipLaunchKernelGGL(vq_prepare_kernel, dim3(VQ_K / 64), dim3(64), 0, (hipStream_t)stream, embed, embedT, enorm);
+  FO_CHECK_LAUNCH();
+  return FO_OK;
+}
+
+int fo_vq_assign(const float* x, int ldx, int64_t nvec, const float* embedT, const float* enorm, int64_t* ind,
+                 float* q_ste, int ldq, float* sq_sum, float* counts, float* esum, int train, void* stream) {
+  FO_REQUIRE(nvec > 0 && ldx >= VQ_D && ldq >= VQ_D, FO_E_SHAPE, "vq_assign: bad shape");
+  int dev = 0, cus = 256;
+  hipGetDevice(&dev);
+  hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  const int64_t ntiles = (nvec + 31) / 32;
+  const int grid = (int)std::min<int64_t>(cus, (ntiles + 3) / 4);
+  hipLaunchKernelGGL(vq_assign_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, (long long)nvec, embedT, enorm,
+                     (long long*)ind, q_ste, ldq, sq_sum, counts, esum, train);
+  FO_CHECK_LAUNCH();
+  return FO_OK;
+}
+
+int fo_vq_ema(float* embed, float* cluster_size, float* embed_avg, const float* counts, const float* esum, float decay,
+              float alpha, float eps, void* stream) {
+  hipLaunchKernelGGL(vq_ema_kernel, dim3(1), dim3(VQ_K), 0, (hipStream_t)stream, embed, cluster_size, embed_avg, counts, esum,
+                     decay, alpha, eps);
+  FO_CHECK_LAUNCH();
+  return FO_OK;
+}
+
+int fo_vq_bwd(const float* gq, int ldg, const float* x, int ldx, const float* q, int ldq, const float* gdiff, float scale,
+              float* gx, int ldgx, int64_t nvec, void* stream) {
+  const int grid = (int)std::min<int64_t>((nvec * 16 + 255) / 256, 4096);
+  hipLaunchKernelGGL(vq_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, gq, ldg, x, ldx, q, ldq, gdiff, scale, gx,
+                     ldgx, (long long)nvec);
+  FO_CHECK_LAUNCH();
+  return FO_OK;
+}
+
+int fo_vq_gather(const int64_t* ind, const float* embedT, float* q, int ldq, int64_t nvec, void* stream) {
+  const int grid = (int)std::min<int64_t>((nvec * 16 + 255) / 256, 4096);
+  hipLaunchKernelGGL(vq_gather_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const long long*)ind, embedT, q, ldq,
+                     (long long)nvec);
+  FO_CHECK_LAUNCH();
+  return FO_OK;
+}
+}

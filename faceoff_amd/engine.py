@@ -1,0 +1,362 @@
+"""The FaceOff VQ-VAE training step as a planned sequence of gfx950 kernel launches.
+
+This is the MI355X-native counterpart of what torch autograd + cuDNN do for the reference's
+`VQVAE.forward` (models/vqvae_conv3d_latent.py:243-285) and `loss.backward()`
+(train_faceoff_perceptual.py:100): an explicit forward that keeps exactly the activations the
+backward needs, and an explicit backward in reverse-forward order that emits every parameter
+gradient into one flat arena (so data-parallel buckets are plain slices of it and become ready
+mid-backward).  No tracing, no graph compiler: the launch list is static Python over the C ABI.
+
+Layout: channels-last everywhere; frames (B*T) outermost, so the reference's
+`[N,C,H,W] <-> [1,C,N,H,W]` permutes (:247,251) are views.  Every ReLU, bias, residual add,
+ReLU-backward mask, gradient fan-in and torch.cat of the reference is an epilogue flag or a
+channel-slice view, never a standalone pass.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+
+import torch
+
+from . import ops
+from .ops import FO_IN_RELU, FO_OUT_RELU
+from .synth import vqvae_param_specs
+
+
+class _Layer:
+    """One conv-like layer: checkpoint-layout parameters + packed filters + launch helpers."""
+
+    def __init__(self, name, kind, w, b, gw, gb):
+        self.name, self.kind = name, kind
+        self.w, self.b, self.gw, self.gb = w, b, gw, gb
+        if kind == "convT":
+            self.ci, self.co = w.shape[0], w.shape[1]
+        else:
+            self.co, self.ci = w.shape[0], w.shape[1]
+        self.k = tuple(w.shape[2:])
+        self.cip, self.cop = ops.pad_in(self.ci), ops.pad_in(self.co) if self.co < 32 else self.co
+        self.wp = None     # forward filter
+        self.wpd = None    # dgrad filter
+        self.need_dgrad = True
+
+    # -- filter packing (every step: the optimiser rewrites the checkpoint-layout weights)
+    def pack(self):
+        if self.kind == "convT":
+            self.wp = ops.pack_convT(self.w, self.wp)
+            if self.need_dgrad:                      # dgrad = conv k4s2p1 with O:=ci, I:=co
+                self.wpd = ops.pack_conv(self.w, self.wpd)
+        else:
+            self.wp = ops.pack_conv(self.w, self.wp)
+            if not self.need_dgrad:
+                return
+            if self.k[-1] == 4:                      # dgrad of k4s2p1 conv = transposed conv, Ci_T:=co, Co_T:=ci
+                self.wpd = ops.pack_convT(self.w, self.wpd)
+            else:
+                self.wpd = ops.pack_conv_dgrad(self.w.reshape(self.co, self.ci, -1), self.wpd)
+
+    def _geom(self):
+        if self.kind == "conv3d":
+            return dict(k=(3, 3, 3), pad=(1, 1, 1), stride=1)
+        kk = self.k[-1]
+        if kk == 4:
+            return dict(k=(1, 4, 4), pad=(0, 1, 1), stride=2)
+        return dict(k=(1, kk, kk), pad=(0, kk // 2, kk // 2), stride=1)
+
+    # -- forward
+    def fwd(self, x, out, T=1, flags=0, add=None):
+        if self.kind == "convT":
+            ops.convT_phases(x, self.wp, self.b, out, cin=self.cip, cout=self.co, flags=flags, add=add)
+        else:
+            g = self._geom()
+            ops.conv_igemm(x, self.wp, self.b, out, T=T if self.kind == "conv3d" else 1, cin=self.cip, cout=self.co,
+                           flags=flags, add=add, **g)
+
+    # -- data gradient: gin = dgrad(g) [* (mask > 0)] [+ add]
+    def dgrad(self, g, gin, T=1, mask=None, add=None):
+        if self.kind == "convT":                     # conv k4 s2 p1 over g
+            ops.conv_igemm(g, self.wpd, None, gin, k=(1, 4, 4), stride=2, pad=(0, 1, 1), cin=ops.pad_in(self.co),
+                           cout=self.ci, mask=mask, add=add)
+        elif self.k[-1] == 4:                        # transposed conv over g
+            ops.convT_phases(g, self.wpd, None, gin, cin=self.co, cout=self.ci, mask=mask, add=add)
+        else:
+            geo = self._geom()
+            pad = tuple(kk - 1 - p for kk, p in zip(geo["k"], geo["pad"]))
+            ops.conv_igemm(g, self.wpd, None, gin, T=T if self.kind == "conv3d" else 1, k=geo["k"], stride=1, pad=pad,
+                           cin=self.co, cout=self.ci, mask=mask, add=add)
+
+    # -- filter + bias gradient
+    def wgrad(self, x, g, T=1, in_relu=False):
+        geo = self._geom()
+        if self.kind == "convT":
+            ops.conv_wgrad(x, g, self.gw, None, k=(1, 4, 4), stride=2, pad=(0, 1, 1), a_real=self.ci, b_real=self.co,
+                           in_relu=False)
+            ops.bias_grad(g, self.gb, self.co)
+        else:
+            ops.conv_wgrad(g, x, self.gw, self.gb, T=T if self.kind == "conv3d" else 1, a_real=self.co, b_real=self.ci,
+                           in_relu=in_relu, **geo)
+
+
+class VQVAEEngine:
+    """Owns the flat parameter / gradient arenas and runs forward / backward on `device`."""
+
+    def __init__(self, state_dict, device, in_channel=6, clip_len=None):
+        self.device = torch.device(device)
+        self.in_channel = in_channel
+        self.clip_len = clip_len
+        specs = vqvae_param_specs(in_channel=in_channel)
+        # ---- flat arenas (reference parameter order == state_dict order minus buffers)
+        sizes = []
+        for name, kind, shape in specs:
+            if kind == "vq":
+                continue
+            n_w = int(torch.tensor(shape).prod())
+            n_b = shape[1] if kind == "convT" else shape[0]
+            sizes += [(name + ".weight", shape, n_w), (name + ".bias", (n_b,), n_b)]
+        total = sum((n + 3) // 4 * 4 for _, _, n in sizes)
+        self.flat_params = torch.zeros(total, device=self.device)
+        self.flat_grads = torch.zeros(total, device=self.device)
+        self.params, self.grads, self.offsets = OrderedDict(), OrderedDict(), OrderedDict()
+        off = 0
+        for key, shape, n in sizes:
+            self.params[key] = self.flat_params[off:off + n].view(shape)
+            self.grads[key] = self.flat_grads[off:off + n].view(shape)
+            self.offsets[key] = (off, n)
+            off += (n + 3) // 4 * 4
+        self.buffers = OrderedDict()
+        for lvl in ("t", "b"):
+            self.buffers[f"quantize_{lvl}.embed"] = torch.zeros(64, 512, device=self.device)
+            self.buffers[f"quantize_{lvl}.cluster_size"] = torch.zeros(512, device=self.device)
+            self.buffers[f"quantize_{lvl}.embed_avg"] = torch.zeros(64, 512, device=self.device)
+        self.layers = OrderedDict()
+        for name, kind, shape in specs:
+            if kind == "vq":
+                continue
+            self.layers[name] = _Layer(name, kind, self.params[name + ".weight"], self.params[name + ".bias"],
+                                       self.grads[name + ".weight"], self.grads[name + ".bias"])
+        self.layers["enc_b.blocks.0"].need_dgrad = False   # the input image needs no gradient
+        if state_dict is not None:
+            self.load_state_dict(state_dict)
+        self.saved = None
+        self.grad_ready_hook = None   # callable(layer_name) fired as soon as a layer's grads are enqueued
+        self.vq_allreduce = None      # callable(stats tensor) -> summed over ranks (Quantize :63-64)
+
+    # ------------------------------------------------------------------ state
+    def load_state_dict(self, sd):
+        for k, v in sd.items():
+            t = torch.as_tensor(v, dtype=torch.float32).to(self.device)
+            if k in self.params:
+                self.params[k].copy_(t)
+            elif k in self.buffers:
+                self.buffers[k].copy_(t)
+            else:
+                raise KeyError(k)
+
+    def state_dict(self):
+        out = OrderedDict()
+        for name, kind, shape in vqvae_param_specs(in_channel=self.in_channel):
+            if kind == "vq":
+                for s in ("embed", "cluster_size", "embed_avg"):
+                    out[f"{name}.{s}"] = self.buffers[f"{name}.{s}"]
+            else:
+                out[name + ".weight"] = self.params[name + ".weight"]
+                out[name + ".bias"] = self.params[name + ".bias"]
+        return out
+
+    # ------------------------------------------------------------------ helpers
+    def _new(self, n, h, w, c):
+        return torch.empty((n, h, w, c), device=self.device, dtype=torch.float32)
+
+    def _resblock_fwd(self, prefix, x, out, out_relu):
+        """ResBlock.forward (:97-101): h = relu(conv3x3(relu(x))); out = conv1x1(h) + x  [optionally relu'd]."""
+        L = self.layers
+        n, h, w, _ = x.shape
+        hbuf = self._new(n, h, w, 32)
+        L[prefix + ".conv.1"].fwd(x, hbuf, flags=FO_IN_RELU | FO_OUT_RELU)
+        L[prefix + ".conv.3"].fwd(hbuf, out, flags=FO_OUT_RELU if out_relu else 0, add=x)
+        return hbuf
+
+    def _resblock_bwd(self, prefix, g_out, x, hbuf, g_x):
+        """g_out: grad wrt (pre-ReLU) block output.  g_x = g_out + dgrad3x3(dgrad1x1(g_out)*(h>0))*(x>0)."""
+        L = self.layers
+        c3, c1 = L[prefix + ".conv.3"], L[prefix + ".conv.1"]
+        c3.wgrad(hbuf, g_out)
+        self._ready(c3.name)
+        g_h = torch.empty_like(hbuf)
+        c3.dgrad(g_out, g_h, mask=hbuf)
+        c1.wgrad(x, g_h, in_relu=True)
+        self._ready(c1.name)
+        c1.dgrad(g_h, g_x, mask=x, add=g_out)
+
+    def _ready(self, name):
+        if self.grad_ready_hook is not None:
+            self.grad_ready_hook(name)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, img_nchw, training=True, T=None):
+        """img_nchw [N,6,H,W] (N = B*T frames).  Returns (dec NHWC[N,H,W,8], diff tensor[1], aux)."""
+        L = self.layers
+        N, Cin, H, W = img_nchw.shape
+        T = T or self.clip_len or N
+        assert N % T == 0, f"N={N} frames is not a whole number of clips of T={T}"
+        assert H % 8 == 0 and W % 8 == 0
+        for layer in L.values():
+            layer.pack()
+        S = {}
+        S["T"] = T
+        x8 = ops.nchw_to_nhwc(img_nchw, cpad=ops.pad_in(Cin))
+        S["x8"] = x8
+        h2, w2, h4, w4, h8, w8 = H // 2, W // 2, H // 4, W // 4, H // 8, W // 8
+        # ---- enc_b (Encoder stride 4, :107-126)
+        a0 = self._new(N, h2, w2, 64); L["enc_b.blocks.0"].fwd(x8, a0, flags=FO_OUT_RELU)
+        a1 = self._new(N, h4, w4, 128); L["enc_b.blocks.2"].fwd(a0, a1, flags=FO_OUT_RELU)
+        a2 = self._new(N, h4, w4, 128); L["enc_b.blocks.4"].fwd(a1, a2)
+        a3 = self._new(N, h4, w4, 128); S["h_eb5"] = self._resblock_fwd("enc_b.blocks.5", a2, a3, False)
+        eb = self._new(N, h4, w4, 128); S["h_eb6"] = self._resblock_fwd("enc_b.blocks.6", a3, eb, True)
+        S.update(a0=a0, a1=a1, a2=a2, a3=a3, eb=eb)
+        # ---- enc_t (Encoder stride 2, :116-126)
+        t0 = self._new(N, h8, w8, 64); L["enc_t.blocks.0"].fwd(eb, t0, flags=FO_OUT_RELU)
+        t1 = self._new(N, h8, w8, 128); L["enc_t.blocks.2"].fwd(t0, t1)
+        t2 = self._new(N, h8, w8, 128); S["h_et3"] = self._resblock_fwd("enc_t.blocks.3", t1, t2, False)
+        et = self._new(N, h8, w8, 128); S["h_et4"] = self._resblock_fwd("enc_t.blocks.4", t2, et, True)
+        S.update(t0=t0, t1=t1, t2=t2, et=et)
+        # ---- Conv3d latent post-nets (:172-176,250); bottom output lands in cat_b[..., 64:192]
+        cat_b = self._new(N, h4, w4, 192)
+        c1 = self._new(N, h4, w4, 128); L["conv3d_encoded_b.conv3d.0.0"].fwd(eb, c1, T=T, flags=FO_OUT_RELU)
+        c2 = self._new(N, h4, w4, 128); L["conv3d_encoded_b.conv3d.1.0"].fwd(c1, c2, T=T, flags=FO_OUT_RELU)
+        L["conv3d_encoded_b.conv3d.2.0"].fwd(c2, cat_b[..., 64:192], T=T)
+        d1 = self._new(N, h8, w8, 128); L["conv3d_encoded_t.conv3d.0.0"].fwd(et, d1, T=T, flags=FO_OUT_RELU)
+        d2 = self._new(N, h8, w8, 128); L["conv3d_encoded_t.conv3d.1.0"].fwd(d1, d2, T=T, flags=FO_OUT_RELU)
+        d3 = self._new(N, h8, w8, 128); L["conv3d_encoded_t.conv3d.2.0"].fwd(d2, d3, T=T)
+        S.update(c1=c1, c2=c2, d1=d1, d2=d2, d3=d3, cat_b=cat_b)
+        # ---- encode_quantized (:261-278)
+        qt_in = self._new(N, h8, w8, 64); L["quantize_conv_t"].fwd(d3, qt_in)
+        quant_t = self._new(N, h8, w8, 64)
+        id_t, stats_t = self._quantize("quantize_t", qt_in, quant_t, training)
+        u0 = self._new(N, h8, w8, 128); L["dec_t.blocks.0"].fwd(quant_t, u0)
+        u1 = self._new(N, h8, w8, 128); S["h_dt1"] = self._resblock_fwd("dec_t.blocks.1", u0, u1, False)
+        u2 = self._new(N, h8, w8, 128); S["h_dt2"] = self._resblock_fwd("dec_t.blocks.2", u1, u2, True)
+        L["dec_t.blocks.4"].fwd(u2, cat_b[..., 0:64])                      # torch.cat([dec_t, enc_b], 1) :271
+        qb_in = self._new(N, h4, w4, 64); L["quantize_conv_b"].fwd(cat_b, qb_in)
+        cat_d = self._new(N, h4, w4, 128)
+        id_b, stats_b = self._quantize("quantize_b", qb_in, cat_d[..., 64:128], training)
+        S.update(qt_in=qt_in, quant_t=quant_t, u0=u0, u1=u1, u2=u2, qb_in=qb_in, cat_d=cat_d)
+        # ---- decode (:280-285)
+        L["upsample_t"].fwd(quant_t, cat_d[..., 0:64])                     # torch.cat([upsample_t, quant_b], 1) :282
+        v0 = self._new(N, h4, w4, 128); L["dec.blocks.0"].fwd(cat_d, v0)
+        v1 = self._new(N, h4, w4, 128); S["h_d1"] = self._resblock_fwd("dec.blocks.1", v0, v1, False)
+        v2 = self._new(N, h4, w4, 128); S["h_d2"] = self._resblock_fwd("dec.blocks.2", v1, v2, True)
+        w1 = self._new(N, h2, w2, 64); L["dec.blocks.4"].fwd(v2, w1, flags=FO_OUT_RELU)
+        dec = torch.zeros((N, H, W, 8), device=self.device); L["dec.blocks.6"].fwd(w1, dec)
+        S.update(v0=v0, v1=v1, v2=v2, w1=w1, dec=dec)
+        # diff = diff_t + diff_b, each mean((q - x)^2) (:77,268,276,278)
+        diff = (stats_t[0:1] / float(qt_in.numel()) + stats_b[0:1] / float(qb_in.numel()))
+        # EMA codebook update after the (optional) cross-rank sum of the statistics (:59-75)
+        if training:
+            for lvl, st in (("t", stats_t), ("b", stats_b)):
+                if self.vq_allreduce is not None:
+                    self.vq_allreduce(st[1:])
+                ops.vq_ema(self.buffers[f"quantize_{lvl}.embed"], self.buffers[f"quantize_{lvl}.cluster_size"],
+                           self.buffers[f"quantize_{lvl}.embed_avg"], st)
+        self.saved = S
+        aux = dict(id_t=id_t, id_b=id_b, qt_in=qt_in, qb_in=qb_in, quant_t=quant_t, quant_b=cat_d[..., 64:128],
+                   enc_b=eb, enc_t=et)
+        return dec, diff, aux
+
+    def _quantize(self, name, x, q_out, training):
+        embedT, enorm = ops.vq_prepare(self.buffers[name + ".embed"])
+        stats = torch.zeros(1 + 512 + 512 * 64, device=self.device)
+        ind = ops.vq_assign(x, embedT, enorm, q_out, stats, training)
+        return ind, stats
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, g_dec, g_diff):
+        """g_dec NHWC [N,H,W,8] grad wrt dec; g_diff float32[1] device tensor grad wrt diff.
+        Fills self.grads (flat arena).  Order = reverse forward, so arena slices complete back-to-front."""
+        L, S = self.layers, self.saved
+        T = S["T"]
+        new_like = torch.empty_like
+        # ---- dec (Decoder stride 4)
+        l6, l4 = L["dec.blocks.6"], L["dec.blocks.4"]
+        l6.wgrad(S["w1"], g_dec); self._ready(l6.name)
+        g_w1 = new_like(S["w1"]); l6.dgrad(g_dec, g_w1, mask=S["w1"])
+        l4.wgrad(S["v2"], g_w1); self._ready(l4.name)
+        g_v2 = new_like(S["v2"]); l4.dgrad(g_w1, g_v2, mask=S["v2"])
+        g_v1 = new_like(S["v1"]); self._resblock_bwd("dec.blocks.2", g_v2, S["v1"], S["h_d2"], g_v1)
+        g_v0 = new_like(S["v0"]); self._resblock_bwd("dec.blocks.1", g_v1, S["v0"], S["h_d1"], g_v0)
+        l0 = L["dec.blocks.0"]
+        l0.wgrad(S["cat_d"], g_v0); self._ready(l0.name)
+        g_cat_d = new_like(S["cat_d"]); l0.dgrad(g_v0, g_cat_d)
+        # ---- upsample_t
+        up = L["upsample_t"]
+        up.wgrad(S["quant_t"], g_cat_d[..., 0:64]); self._ready(up.name)
+        g_quant_t = new_like(S["quant_t"]); up.dgrad(g_cat_d[..., 0:64], g_quant_t)
+        # ---- quantize_b (straight-through + commitment) and quantize_conv_b
+        g_qb_in = new_like(S["qb_in"])
+        ops.vq_bwd(g_cat_d[..., 64:128], S["qb_in"], S["cat_d"][..., 64:128], g_diff, g_qb_in)
+        qcb = L["quantize_conv_b"]
+        qcb.wgrad(S["cat_b"], g_qb_in); self._ready(qcb.name)
+        g_cat_b = new_like(S["cat_b"]); qcb.dgrad(g_qb_in, g_cat_b)
+        # ---- dec_t
+        dt4 = L["dec_t.blocks.4"]
+        dt4.wgrad(S["u2"], g_cat_b[..., 0:64]); self._ready(dt4.name)
+        g_u2 = new_like(S["u2"]); dt4.dgrad(g_cat_b[..., 0:64], g_u2, mask=S["u2"])
+        g_u1 = new_like(S["u1"]); self._resblock_bwd("dec_t.blocks.2", g_u2, S["u1"], S["h_dt2"], g_u1)
+        g_u0 = new_like(S["u0"]); self._resblock_bwd("dec_t.blocks.1", g_u1, S["u0"], S["h_dt1"], g_u0)
+        dt0 = L["dec_t.blocks.0"]
+        dt0.wgrad(S["quant_t"], g_u0); self._ready(dt0.name)
+        g_quant_t2 = new_like(S["quant_t"]); dt0.dgrad(g_u0, g_quant_t2, add=g_quant_t)   # fan-in of quant_t's two uses
+        # ---- quantize_t and quantize_conv_t
+        g_qt_in = new_like(S["qt_in"])
+        ops.vq_bwd(g_quant_t2, S["qt_in"], S["quant_t"], g_diff, g_qt_in)
+        qct = L["quantize_conv_t"]
+        qct.wgrad(S["d3"], g_qt_in); self._ready(qct.name)
+        g_d3 = new_like(S["d3"]); qct.dgrad(g_qt_in, g_d3)
+        # ---- conv3d_encoded_t
+        k2, k1, k0 = (L[f"conv3d_encoded_t.conv3d.{i}.0"] for i in (2, 1, 0))
+        k2.wgrad(S["d2"], g_d3, T=T); self._ready(k2.name)
+        g_d2 = new_like(S["d2"]); k2.dgrad(g_d3, g_d2, T=T, mask=S["d2"])
+        k1.wgrad(S["d1"], g_d2, T=T); self._ready(k1.name)
+        g_d1 = new_like(S["d1"]); k1.dgrad(g_d2, g_d1, T=T, mask=S["d1"])
+        k0.wgrad(S["et"], g_d1, T=T); self._ready(k0.name)
+        g_t3 = new_like(S["et"]); k0.dgrad(g_d1, g_t3, T=T, mask=S["et"])     # mask = encoder's final ReLU
+        # ---- enc_t
+        g_t2 = new_like(S["t2"]); self._resblock_bwd("enc_t.blocks.4", g_t3, S["t2"], S["h_et4"], g_t2)
+        g_t1 = new_like(S["t1"]); self._resblock_bwd("enc_t.blocks.3", g_t2, S["t1"], S["h_et3"], g_t1)
+        e2, e0 = L["enc_t.blocks.2"], L["enc_t.blocks.0"]
+        e2.wgrad(S["t0"], g_t1); self._ready(e2.name)
+        g_t0 = new_like(S["t0"]); e2.dgrad(g_t1, g_t0, mask=S["t0"])
+        e0.wgrad(S["eb"], g_t0); self._ready(e0.name)
+        g_eb_t = new_like(S["eb"]); e0.dgrad(g_t0, g_eb_t, mask=S["eb"])      # grad via enc_t, through enc_b's final ReLU
+        # ---- conv3d_encoded_b (its output gradient is cat_b[..., 64:192])
+        k2, k1, k0 = (L[f"conv3d_encoded_b.conv3d.{i}.0"] for i in (2, 1, 0))
+        g_c3 = g_cat_b[..., 64:192]
+        k2.wgrad(S["c2"], g_c3, T=T); self._ready(k2.name)
+        g_c2 = new_like(S["c2"]); k2.dgrad(g_c3, g_c2, T=T, mask=S["c2"])
+        k1.wgrad(S["c1"], g_c2, T=T); self._ready(k1.name)
+        g_c1 = new_like(S["c1"]); k1.dgrad(g_c2, g_c1, T=T, mask=S["c1"])
+        k0.wgrad(S["eb"], g_c1, T=T); self._ready(k0.name)
+        g_a4 = new_like(S["eb"]); k0.dgrad(g_c1, g_a4, T=T, mask=S["eb"], add=g_eb_t)
+        # ---- enc_b
+        g_a3 = new_like(S["a3"]); self._resblock_bwd("enc_b.blocks.6", g_a4, S["a3"], S["h_eb6"], g_a3)
+        g_a2 = new_like(S["a2"]); self._resblock_bwd("enc_b.blocks.5", g_a3, S["a2"], S["h_eb5"], g_a2)
+        b4, b2, b0 = L["enc_b.blocks.4"], L["enc_b.blocks.2"], L["enc_b.blocks.0"]
+        b4.wgrad(S["a1"], g_a2); self._ready(b4.name)
+        g_a1 = new_like(S["a1"]); b4.dgrad(g_a2, g_a1, mask=S["a1"])
+        b2.wgrad(S["a0"], g_a1); self._ready(b2.name)
+        g_a0 = new_like(S["a0"]); b2.dgrad(g_a1, g_a0, mask=S["a0"])
+        b0.wgrad(S["x8"], g_a0); self._ready(b0.name)
+        self.saved = None
+
+    # ------------------------------------------------------------------ fused train step (bench / trainer fast path)
+    def loss_and_backward(self, img_nchw, gt_nchw, T=None, latent_weight=1.0):
+        """run_step + backward (train_faceoff_perceptual.py:32-47,98-100) for recon + latent loss.
+        Returns device scalars (recon, latent).  Gradients land in self.flat_grads."""
+        dec, diff, aux = self.forward(img_nchw, training=True, T=T)
+        acc = torch.zeros(1, device=self.device)
+        ops.mse_slice_fwd(dec, gt_nchw, acc)
+        recon = acc / float(gt_nchw.numel())
+        one = torch.ones(1, device=self.device)
+        g_dec = torch.empty_like(dec)
+        ops.mse_slice_bwd(dec, gt_nchw, one, g_dec)
+        self.backward(g_dec, one * latent_weight)
+        return recon, diff, aux

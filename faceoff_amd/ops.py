@@ -1,0 +1,239 @@
+"""Host-side operator layer: torch tensors in (device memory + stream plumbing only), C-ABI calls out.
+
+Activations are channels-last views [N,H,W,C] whose last-dim stride is 1 and whose pixel
+stride `ld` may exceed C (channel slices of a wider buffer = free torch.cat).
+Filters stay in the reference's checkpoint layouts and are packed on the GPU each step.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, FO_IN_RELU, FO_BIAS, FO_MASK, FO_ADD, FO_OUT_RELU  # noqa: F401
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def ld_of(t):
+    """Pixel stride (floats) of a channels-last view [N,H,W,C] (or [rows,C])."""
+    assert t.dtype == torch.float32 and t.is_cuda, "fp32 device tensor required"
+    assert t.stride(-1) == 1, "channels must be contiguous"
+    ld = t.stride(-2)
+    if t.dim() == 4:
+        n, h, w, c = t.shape
+        assert t.stride(1) == w * ld and (n == 1 or t.stride(0) == h * w * ld), "rows must be dense"
+    return ld
+
+
+def pad_out(c):
+    """Output-channel padding the conv kernel's N tile implies (see fo_conv_igemm)."""
+    return (c + 127) // 128 * 128 if c > 64 else (64 if c > 32 else 32)
+
+
+def pad_in(c):
+    if c >= 32:
+        assert c % 32 == 0
+        return c
+    return 8 if c <= 8 else 16
+
+
+# ------------------------------------------------------------------ packing
+def pack_conv(w, out=None):
+    """[O][I][*taps] -> [Opad][taps][Ipad]"""
+    O, I = w.shape[:2]
+    taps = w[0, 0].numel()
+    Op, Ip = pad_out(O), pad_in(I)
+    if out is None:
+        out = torch.empty(Op * taps * Ip, device=w.device, dtype=torch.float32)
+    _lib.call("fo_pack_conv", _ptr(w), _ptr(out), O, I, taps, Op, Ip, _stream())
+    return out
+
+
+def pack_conv_dgrad(w, out=None):
+    """stride-1 dgrad filter: [O][I][taps] -> [Ipad_as_out][taps reversed][Opad_as_in]"""
+    O, I = w.shape[:2]
+    taps = w[0, 0].numel()
+    Op, Ip = pad_in(O), pad_out(I)
+    if out is None:
+        out = torch.empty(Ip * taps * Op, device=w.device, dtype=torch.float32)
+    _lib.call("fo_pack_conv_dgrad", _ptr(w), _ptr(out), O, I, taps, Op, Ip, _stream())
+    return out
+
+
+def pack_convT(w, out=None):
+    """[Ci][Co][4][4] -> [4][Copad][4][Cipad] (sub-pixel phases)"""
+    Ci, Co = w.shape[:2]
+    Cip, Cop = pad_in(Ci), pad_out(Co)
+    if out is None:
+        out = torch.empty(16 * Cop * Cip, device=w.device, dtype=torch.float32)
+    _lib.call("fo_pack_convT_k4s2", _ptr(w), _ptr(out), Ci, Co, Cip, Cop, _stream())
+    return out
+
+
+# ------------------------------------------------------------------ conv launches
+def _desc(**kw):
+    d = ConvDesc()
+    for k, v in kw.items():
+        setattr(d, k, int(v))
+    return d
+
+
+def conv_igemm(x, wp, bias, out, *, T=1, k=(1, 3, 3), stride=1, pad=(0, 1, 1), cin=None, cout=None,
+               flags=0, mask=None, add=None, ostride=1, oph=(0, 0), mgrid=None):
+    """One fo_conv_igemm launch.  x/out/mask/add: channels-last views."""
+    N, Hin, Win, _ = x.shape
+    _, Hout, Wout, _ = out.shape
+    Hm, Wm = mgrid if mgrid is not None else (Hout, Wout)
+    if bias is not None:
+        flags |= FO_BIAS
+    if mask is not None:
+        flags |= FO_MASK
+    if add is not None:
+        flags |= FO_ADD
+    d = _desc(N=N, T=T, Hin=Hin, Win=Win, Hm=Hm, Wm=Wm, Hout=Hout, Wout=Wout,
+              Cin=cin if cin is not None else x.shape[-1], Cout=cout if cout is not None else out.shape[-1],
+              KD=k[0], KH=k[1], KW=k[2], stride=stride, padD=pad[0], padH=pad[1], padW=pad[2],
+              ostride=ostride, ophH=oph[0], ophW=oph[1], ldIn=ld_of(x), ldOut=ld_of(out),
+              ldMask=ld_of(mask) if mask is not None else 0, ldAdd=ld_of(add) if add is not None else 0, flags=flags)
+    _lib.call("fo_conv_igemm", C.byref(d), _ptr(x), _ptr(wp), _ptr(bias), _ptr(mask), _ptr(add), _ptr(out), _stream())
+
+
+def convT_phases(x, wp4, bias, out, *, cin, cout, flags=0, mask=None, add=None):
+    """k4 s2 p1 transposed conv (or the dgrad of a k4 s2 p1 conv) as 4 sub-pixel launches."""
+    N, Hi, Wi, _ = x.shape
+    per_phase = pad_out(cout) * 4 * cin
+    for ph in range(4):
+        py, px = ph >> 1, ph & 1
+        conv_igemm(x, wp4[ph * per_phase:(ph + 1) * per_phase], bias, out, k=(1, 2, 2), stride=1,
+                   pad=(0, 1 - py, 1 - px), cin=cin, cout=cout, flags=flags, mask=mask, add=add,
+                   ostride=2, oph=(py, px), mgrid=(Hi, Wi))
+
+
+_ws_cache = {}
+
+
+def _workspace(nbytes, device):
+    key = (device, "wgrad")
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() * 4 < nbytes:
+        buf = torch.empty((nbytes + 3) // 4 + 1024, device=device, dtype=torch.float32)
+        _ws_cache[key] = buf
+    return buf
+
+
+def conv_wgrad(P, Q, dw, dbias, *, T=1, k=(1, 3, 3), stride=1, pad=(0, 1, 1), a_real, b_real, in_relu=False):
+    """dW[a][b][tap] = sum_m P[m][a] Q[qpix(m,tap)][b]; dbias (optional) = colsum(P)."""
+    N, Hm, Wm, Ca = P.shape
+    _, Hq, Wq, Cb = Q.shape
+    d = _desc(N=N, T=T, Hin=Hq, Win=Wq, Hm=Hm, Wm=Wm, Hout=Hm, Wout=Wm, Cin=Cb, Cout=Ca,
+              KD=k[0], KH=k[1], KW=k[2], stride=stride, padD=pad[0], padH=pad[1], padW=pad[2],
+              ostride=1, ophH=0, ophW=0, ldIn=ld_of(Q), ldOut=ld_of(P), ldMask=0, ldAdd=0,
+              flags=FO_IN_RELU if in_relu else 0)
+    nbytes = _lib.load().fo_wgrad_ws_bytes(C.byref(d))
+    if nbytes < 0:
+        _lib.check(-1, "fo_wgrad_ws_bytes")
+    ws = _workspace(nbytes, P.device)
+    _lib.call("fo_conv_wgrad", C.byref(d), _ptr(P), _ptr(Q), _ptr(dw), a_real, b_real, _ptr(dbias), _ptr(ws),
+              C.c_int64(ws.numel() * 4), _stream())
+
+
+def bias_grad(g, dbias, c_real):
+    rows = g.numel() // g.shape[-1] if g.is_contiguous() else g.shape[0] * g.shape[1] * g.shape[2]
+    Cc = g.shape[-1]
+    ws = _workspace(4 * Cc * 1024, g.device)
+    _lib.call("fo_bias_grad", _ptr(g), _ptr(dbias), C.c_int64(rows), Cc, c_real, ld_of(g), _ptr(ws), _stream())
+
+
+# ------------------------------------------------------------------ layout
+def nchw_to_nhwc(x, cpad=None):
+    N, Cc, H, W = x.shape
+    cpad = cpad or Cc
+    y = torch.empty((N, H, W, cpad), device=x.device, dtype=torch.float32)
+    _lib.call("fo_nchw_to_nhwc", _ptr(x.contiguous()), _ptr(y), N, Cc, H, W, cpad, cpad, _stream())
+    return y
+
+
+def nhwc_to_nchw(x, c_real, out=None, accumulate=False):
+    N, H, W, _ = x.shape
+    if out is None:
+        out = torch.empty((N, c_real, H, W), device=x.device, dtype=torch.float32)
+    _lib.call("fo_nhwc_to_nchw", _ptr(x), _ptr(out), N, c_real, H, W, ld_of(x), int(accumulate), _stream())
+    return out
+
+
+# ------------------------------------------------------------------ VQ
+def vq_prepare(embed):
+    embedT = torch.empty((512, 64), device=embed.device, dtype=torch.float32)
+    enorm = torch.empty(512, device=embed.device, dtype=torch.float32)
+    _lib.call("fo_vq_prepare", _ptr(embed), _ptr(embedT), _ptr(enorm), _stream())
+    return embedT, enorm
+
+
+def vq_assign(x, embedT, enorm, q_out, stats, train):
+    """x, q_out: [..., 64] views; stats: float32[1 + 512 + 512*64] = (sq_sum, counts, esum) zeroed by caller."""
+    nvec = x.numel() // 64 if x.is_contiguous() else x.shape[0] * x.shape[1] * x.shape[2]
+    ind = torch.empty(x.shape[:-1], device=x.device, dtype=torch.int64)
+    _lib.call("fo_vq_assign", _ptr(x), ld_of(x), C.c_int64(nvec), _ptr(embedT), _ptr(enorm), _ptr(ind), _ptr(q_out),
+              ld_of(q_out), _ptr(stats[0:1]), _ptr(stats[1:513]), _ptr(stats[513:]), int(train), _stream())
+    return ind
+
+
+def vq_ema(embed, cluster_size, embed_avg, stats, decay=0.99, eps=1e-5):
+    _lib.call("fo_vq_ema", _ptr(embed), _ptr(cluster_size), _ptr(embed_avg), _ptr(stats[1:513]), _ptr(stats[513:]),
+              C.c_float(decay), C.c_float(1 - decay), C.c_float(eps), _stream())
+
+
+def vq_bwd(gq, x, q, gdiff, gx):
+    nvec = x.shape[0] * x.shape[1] * x.shape[2]
+    _lib.call("fo_vq_bwd", _ptr(gq), ld_of(gq), _ptr(x), ld_of(x), _ptr(q), ld_of(q), _ptr(gdiff),
+              C.c_float(2.0 / (nvec * 64)), _ptr(gx), ld_of(gx), C.c_int64(nvec), _stream())
+
+
+def vq_gather(ind, embedT, q_out):
+    nvec = ind.numel()
+    _lib.call("fo_vq_gather", _ptr(ind.contiguous()), _ptr(embedT), _ptr(q_out), ld_of(q_out), C.c_int64(nvec), _stream())
+
+
+# ------------------------------------------------------------------ losses / optimiser
+def mse_slice_fwd(dec, gt_nchw, acc):
+    N, H, W, _ = dec.shape
+    _lib.call("fo_mse_slice_fwd", _ptr(dec), ld_of(dec), _ptr(gt_nchw), N, H, W, gt_nchw.shape[1], _ptr(acc), _stream())
+
+
+def mse_slice_bwd(dec, gt_nchw, gscale, gdec):
+    N, H, W, _ = dec.shape
+    c3 = gt_nchw.shape[1]
+    _lib.call("fo_mse_slice_bwd", _ptr(dec), ld_of(dec), _ptr(gt_nchw), N, H, W, c3, _ptr(gscale),
+              C.c_float(1.0 / (N * c3 * H * W)), _ptr(gdec), ld_of(gdec), _stream())
+
+
+def adam_flat(p, g, m, v, lr, step, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0):
+    b1, b2 = betas
+    _lib.call("fo_adam_flat", _ptr(p), _ptr(g), _ptr(m), _ptr(v), C.c_int64(p.numel()), C.c_float(lr), C.c_float(b1),
+              C.c_float(b2), C.c_float(eps), C.c_float(1 - b1 ** step), C.c_float(1 - b2 ** step), C.c_float(grad_scale),
+              _stream())
+
+
+def zero_(t):
+    _lib.call("fo_zero", _ptr(t), C.c_int64(t.numel()), _stream())
+    return t
+
+
+def relu(x, out):
+    rows = x.shape[0] * x.shape[1] * x.shape[2]
+    _lib.call("fo_relu", _ptr(x), ld_of(x), _ptr(out), ld_of(out), C.c_int64(rows), x.shape[-1], _stream())
+    return out
+
+
+def add(a, b, out):
+    rows = a.shape[0] * a.shape[1] * a.shape[2]
+    _lib.call("fo_add", _ptr(a), ld_of(a), _ptr(b), ld_of(b), _ptr(out), ld_of(out), C.c_int64(rows), a.shape[-1], _stream())
+    return out

@@ -1,0 +1,149 @@
+/*
+ * faceoff_hip.h -- C ABI of libfaceoff_hip.so: the MI355X (gfx950) kernels behind the FaceOff
+ * VQ-VAE-2 + Conv3d-latent training step.
+ *
+ * The reference (skymanaditya1/FaceOff) has no FFI: its hot path is torch.nn modules
+ * (SURVEY.md section 8b).  Each entry point below therefore replaces the library kernel that a
+ * reference call site dispatches to; the call site is cited as file:line relative to the
+ * reference root.  The Python mirror of the reference module API (faceoff_amd/models/...) binds
+ * these with ctypes; INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *  - Plain C: pointers, ints, a stream handle.  No C++/torch types.
+ *  - All pointers are DEVICE pointers (fp32 unless noted).  The caller owns every buffer,
+ *    including workspaces; functions only enqueue work on `stream` (hipStream_t passed as
+ *    void*), never allocate, never synchronise: they are graph-capturable.
+ *  - Activations are channels-last: [N,H,W,C] (frames outermost; a clip batch [B,T,H,W,C] is the
+ *    same memory with N=B*T).  Every activation argument carries a row stride `ld*` in floats
+ *    (>= its channel count, multiple of 4) so a tensor may be a channel slice of a wider
+ *    buffer: torch.cat along channels (vqvae_conv3d_latent.py:271,282) costs nothing.
+ *  - Filters are passed PACKED (see fo_pack_*), converted from the checkpoint layouts
+ *    (OIHW / IOHW / OIDHW) each step.
+ *  - Return value: 0 on success, negative FO_E_* otherwise; fo_last_error() gives a
+ *    thread-local description.
+ */
+#ifndef FACEOFF_HIP_H
+#define FACEOFF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FO_OK 0
+#define FO_E_SHAPE (-1)  /* unsupported geometry / channel count */
+#define FO_E_ALIGN (-2)  /* pointer or stride not 16-byte aligned */
+#define FO_E_ARCH (-3)   /* not running on gfx950 */
+#define FO_E_HIP (-4)    /* a HIP runtime call failed */
+#define FO_E_WORKSPACE (-5)
+
+/* epilogue / prologue flags of the conv kernels (value = ((acc + bias) masked) + add, relu'd) */
+#define FO_IN_RELU 1   /* relu() applied to the input operand as it is staged (ResBlock's leading ReLU, :91) */
+#define FO_BIAS 2      /* + bias[co] */
+#define FO_MASK 4      /* zero where mask[pixel][co] <= 0  (ReLU backward fused into a dgrad) */
+#define FO_ADD 8       /* + add[pixel][co]  (residual `out += input` :99, or gradient fan-in) */
+#define FO_OUT_RELU 16 /* relu() on the result (nn.ReLU after a conv, :110,112,119,126,145,151,186) */
+
+int fo_version(void);
+const char* fo_last_error(void);
+/* device properties the host needs for the roofline report: [0]=CU count, [1]=clock kHz, [2]=is gfx950 */
+int fo_device_info(int32_t* out3);
+
+/* ---------------------------------------------------------------- layout transforms */
+/* [N,C,H,W] -> [N,H,W,ldy] (channels >= C zero-filled up to Cpad).  Replaces the implicit NCHW
+ * layout of utils.py:32 `torch.cat([source, background], axis=2)` feeding Conv2d. */
+int fo_nchw_to_nhwc(const float* x, float* y, int N, int C, int H, int W, int Cpad, int ldy, void* stream);
+/* [N,H,W,ldx] (first C channels) -> [N,C,H,W]; optionally accumulates (+=) for gradient returns. */
+int fo_nhwc_to_nchw(const float* x, float* y, int N, int C, int H, int W, int ldx, int accumulate, void* stream);
+
+/* ---------------------------------------------------------------- filter packing */
+/* All packers write K-contiguous rows: wp[o][tap][i] so both GEMM operands stream along K.
+ * Opad/Ipad: channel counts rounded up by the caller (fo_packed_elems tells the size); padding is zero. */
+/* Conv forward.  src [O][I][taps] (nn.Conv2d / nn.Conv3d weight) -> wp[Opad][taps][Ipad]. */
+int fo_pack_conv(const float* w, float* wp, int O, int I, int taps, int Opad, int Ipad, void* stream);
+/* Stride-1 conv dgrad: src [O][I][taps] -> wp[Ipad][taps (reversed)][Opad]: the conv of the output
+ * gradient with the flipped, transposed filter (autograd of F.conv2d/F.conv3d, reference :100). */
+int fo_pack_conv_dgrad(const float* w, float* wp, int O, int I, int taps, int Opad, int Ipad, void* stream);
+/* k4 s2 p1 transposed conv as 4 sub-pixel phases.  src [Ci][Co][4][4] (nn.ConvTranspose2d weight,
+ * :150,152,160,215) -> wp[4 phases][Copad][2x2 taps][Cipad].  Also packs the dgrad of a k4 s2 p1
+ * Conv2d when handed that conv's OIHW weight (Ci:=O, Co:=I). */
+int fo_pack_convT_k4s2(const float* w, float* wp, int Ci, int Co, int Cipad, int Copad, void* stream);
+
+/* ---------------------------------------------------------------- convolution (implicit GEMM, fp32 MFMA) */
+typedef struct fo_conv_desc {
+  int32_t N, T;            /* frames; frames per clip (temporal taps never cross a clip). 2-D: T=1 */
+  int32_t Hin, Win;        /* input spatial size */
+  int32_t Hm, Wm;          /* GEMM-M grid (output pixels of this launch, per frame) */
+  int32_t Hout, Wout;      /* spatial size of the output tensor */
+  int32_t Cin, Cout;       /* packed (padded) input channels; real output channels (stores are clipped) */
+  int32_t KD, KH, KW;      /* tap grid */
+  int32_t stride;          /* input coord = m*stride + k - pad */
+  int32_t padD, padH, padW;
+  int32_t ostride, ophH, ophW; /* output coord = m*ostride + oph (sub-pixel phase of a transposed conv) */
+  int32_t ldIn, ldOut, ldMask, ldAdd;
+  int32_t flags;
+} fo_conv_desc;
+
+/* out[opix(m)][co] = epilogue( sum_{tap,ci} in[ipix(m,tap)][ci] * wp[co][tap][ci] ).
+ * Replaces cuDNN implicit-GEMM fwd/dgrad behind nn.Conv2d (:92,94,109,111,113,118,120,140,208,213),
+ * nn.ConvTranspose2d (:150,152,160,215), nn.Conv3d (:181,185) and their autograd dgrads. */
+int fo_conv_igemm(const fo_conv_desc* d, const float* in, const float* wp, const float* bias,
+                  const float* mask, const float* add, float* out, void* stream);
+
+/* Filter gradient:  dW[a][b][tap] = sum_m P[m][a] * Q[qpix(m,tap)][b]   (checkpoint layout out).
+ * Conv:  P = grad_out (a=Cout), Q = input (b=Cin)  -> OIHW / OIDHW.
+ * ConvT: P = input (a=Cin), Q = grad_out (b=Cout)  -> [Ci][Co][kh][kw].
+ * Geometry fields: Hm/Wm = P's spatial grid, Hin/Win = Q's, Cin := channels of Q (b), Cout := channels
+ * of P (a), ldIn := ld of Q, ldOut := ld of P; stride/pad/K* as for the forward conv.  FO_IN_RELU
+ * applies relu to Q, FO_MASK is unused.  Split-K partial slabs live in `ws` (fo_wgrad_ws_bytes);
+ * `dw` is overwritten; if `dbias` != NULL it receives sum_m P[m][a] (conv bias grad).
+ * Replaces cuDNN wgrad behind loss.backward() (train_faceoff_perceptual.py:100). */
+int64_t fo_wgrad_ws_bytes(const fo_conv_desc* d);
+int fo_conv_wgrad(const fo_conv_desc* d, const float* P, const float* Q, float* dw, int Areal, int Breal,
+                  float* dbias, float* ws, int64_t ws_bytes, void* stream);
+/* dbias[c] = sum over M rows of g[m*ld + c] for c < Creal (C = Creal rounded up to 4); ws >= 4*C*1024 bytes.
+ * Bias gradient of a transposed conv (its grad_out is the wgrad's Q operand, so it cannot ride along). */
+int fo_bias_grad(const float* g, float* dbias, int64_t M, int C, int Creal, int ld, float* ws, void* stream);
+
+/* ---------------------------------------------------------------- vector quantiser (Quantize.forward :47-80) */
+/* x[Nvec][ldx] (dim 64) vs embed[64][512].  Writes: ind (int64, :54), q_ste = x + (embed[:,ind] - x)
+ * (:57,78), and accumulates sum((q-x)^2) into *sq_sum (:77), counts[512] and esum[512][64] (:60-61,
+ * code-major) with float atomics -- zero them first (fo_zero).  Distances use the reference's
+ * expanded form ||x||^2 - 2 x.e + ||e||^2 in fp32 with k-ordered fma chains and first-index
+ * arg-min (torch.max tie-break), see oracle/vq_oracle.c.  `enorm`[512] from fo_vq_prepare. */
+int fo_vq_prepare(const float* embed, float* embedT, float* enorm, void* stream); /* [64][512] -> [512][64], ||e||^2 */
+int fo_vq_assign(const float* x, int ldx, int64_t nvec, const float* embedT, const float* enorm, int64_t* ind,
+                 float* q_ste, int ldq, float* sq_sum, float* counts, float* esum, int train, void* stream);
+/* EMA codebook update (:66-75) after the statistics all-reduce: in-place on the three buffers. */
+int fo_vq_ema(float* embed, float* cluster_size, float* embed_avg, const float* counts, const float* esum,
+              float decay, float alpha /* = 1 - decay as the reference rounds it */, float eps, void* stream);
+/* gx = gq + gdiff * 2 (x - q) / numel   (straight-through + commitment) */
+int fo_vq_bwd(const float* gq, int ldg, const float* x, int ldx, const float* q, int ldq, const float* gdiff,
+              float scale, float* gx, int ldgx, int64_t nvec, void* stream);
+/* F.embedding(code, embed^T) (:82-83, decode_code :287-295) */
+int fo_vq_gather(const int64_t* ind, const float* embedT, float* q, int ldq, int64_t nvec, void* stream);
+
+/* ---------------------------------------------------------------- losses */
+/* sum over n,c<3,h,w of (dec[n][h][w][c] - gt[n][c][h][w])^2 accumulated into *sum
+ * (criterion = nn.MSELoss() on out[:, :3], train_faceoff_perceptual.py:21,37-39). */
+int fo_mse_slice_fwd(const float* dec, int ldd, const float* gt_nchw, int N, int H, int W, int C3, float* sum, void* stream);
+/* gdec[n][h][w][c] = c<3 ? gscale * 2 (dec-gt)/numel : 0, for c < ldg  (gscale read from device) */
+int fo_mse_slice_bwd(const float* dec, int ldd, const float* gt_nchw, int N, int H, int W, int C3,
+                     const float* gscale, float inv_numel, float* gdec, int ldg, void* stream);
+
+/* ---------------------------------------------------------------- optimiser + utilities */
+/* torch.optim.Adam defaults (train_faceoff_perceptual.py:190) over one flat parameter arena. */
+int fo_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                 float eps, float bias_corr1 /* 1-beta1^t */, float bias_corr2 /* 1-beta2^t */, float grad_scale,
+                 void* stream);
+int fo_zero(float* p, int64_t n, void* stream);
+/* y = relu(x) elementwise over [rows][C] views with strides (only for API paths that hand out activations) */
+int fo_relu(const float* x, int ldx, float* y, int ldy, int64_t rows, int C, void* stream);
+/* y = a + b over strided [rows][C] views (gradient fan-in where no conv epilogue can take it) */
+int fo_add(const float* a, int lda, const float* b, int ldb, float* y, int ldy, int64_t rows, int C, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FACEOFF_HIP_H */

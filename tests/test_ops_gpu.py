@@ -1,0 +1,294 @@
+"""Per-kernel parity on a real MI355X: every C-ABI op against the CPU oracle (torch fp32 CPU for the
+floating-point convs -- the reference's own arithmetic -- and oracle/vq_oracle.c for the VQ search).
+Tolerance: 1e-3 relative (BASELINE.json north_star), measured against the tensor's scale; observed
+errors are ~1e-6.  VQ indices: bit-exact."""
+import os
+import zlib
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-3
+
+
+def _dev():
+    assert torch.cuda.is_available(), "gpu-marked tests need a GPU"
+    return torch.device("cuda:0")
+
+
+def _close(got, want, rtol=RTOL, what=""):
+    got = got.detach().float().cpu()
+    want = want.detach().float().cpu()
+    assert got.shape == want.shape, (got.shape, want.shape)
+    scale = want.abs().max().item() + 1e-30
+    err = (got - want).abs().max().item()
+    assert err <= rtol * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e}"
+    return err / scale
+
+
+def _rand(rng, *shape, scale=1.0):
+    return torch.from_numpy((rng.standard_normal(shape) * scale).astype(np.float32))
+
+
+def _nhwc(t):   # NCHW cpu -> NHWC cuda (padded to 8 channels if fewer)
+    t = t.permute(0, 2, 3, 1).contiguous()
+    if t.shape[-1] < 8:
+        t = F.pad(t, (0, 8 - t.shape[-1]))
+    return t.to(_dev())
+
+
+CONV_CASES = [
+    # (name, Cin, Cout, k, stride, N, H, W)
+    ("enc_b0_6to64_k4s2", 6, 64, 4, 2, 2, 32, 32),
+    ("k4s2_64to128", 64, 128, 4, 2, 3, 16, 24),
+    ("k4s2_128to64", 128, 64, 4, 2, 2, 16, 16),
+    ("k3_128to128", 128, 128, 3, 1, 2, 16, 16),
+    ("k3_64to128_odd", 64, 128, 3, 1, 3, 10, 14),
+    ("k3_128to32", 128, 32, 3, 1, 2, 16, 16),
+    ("k1_32to128", 32, 128, 1, 1, 2, 16, 16),
+    ("k1_128to64", 128, 64, 1, 1, 2, 8, 8),
+    ("k1_192to64", 192, 64, 1, 1, 2, 16, 16),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv2d_fwd_dgrad_wgrad(case):
+    from faceoff_amd import ops
+    name, Ci, Co, k, s, N, H, W = case
+    rng = np.random.default_rng(zlib.crc32(name.encode()))
+    x = _rand(rng, N, Ci, H, W).requires_grad_(True)
+    w = _rand(rng, Co, Ci, k, k, scale=0.1).requires_grad_(True)
+    b = _rand(rng, Co, scale=0.1).requires_grad_(True)
+    pad = 1 if k > 1 else 0
+    y = F.conv2d(x, w, b, stride=s, padding=pad)
+    gy = _rand(rng, *y.shape)
+    y.backward(gy)
+    dev = _dev()
+    xg, wg, bg = _nhwc(x.detach()), w.detach().to(dev), b.detach().to(dev)
+    out = torch.empty((N, y.shape[2], y.shape[3], Co), device=dev)
+    wp = ops.pack_conv(wg)
+    ops.conv_igemm(xg, wp, bg, out, k=(1, k, k), stride=s, pad=(0, pad, pad), cin=ops.pad_in(Ci), cout=Co)
+    _close(out.permute(0, 3, 1, 2), y, what="fwd")
+    # wgrad (+ bias grad riding along)
+    gyg = _nhwc(gy)
+    dw, db = torch.empty_like(wg), torch.empty_like(bg)
+    ops.conv_wgrad(gyg, xg, dw, db, k=(1, k, k), stride=s, pad=(0, pad, pad), a_real=Co, b_real=Ci)
+    _close(dw, w.grad, what="wgrad")
+    _close(db, b.grad, what="bias grad")
+    if Ci < 32:
+        return
+    gx = torch.empty((N, H, W, Ci), device=dev)
+    if k == 4:
+        wpd = ops.pack_convT(wg)
+        ops.convT_phases(gyg, wpd, None, gx, cin=Co, cout=Ci)
+    else:
+        wpd = ops.pack_conv_dgrad(wg.reshape(Co, Ci, -1))
+        ops.conv_igemm(gyg, wpd, None, gx, k=(1, k, k), stride=1, pad=(0, k - 1 - pad, k - 1 - pad), cin=Co, cout=Ci)
+    _close(gx.permute(0, 3, 1, 2), x.grad, what="dgrad")
+
+
+def test_conv_epilogue_flags_and_views():
+    """ResBlock pieces: IN_RELU, OUT_RELU, residual add, mask, and channel-slice views (free torch.cat)."""
+    from faceoff_amd import ops
+    from faceoff_amd.ops import FO_IN_RELU, FO_OUT_RELU
+    rng = np.random.default_rng(5)
+    dev = _dev()
+    N, H, W = 2, 16, 16
+    x = _rand(rng, N, 128, H, W)
+    w1, b1 = _rand(rng, 32, 128, 3, 3, scale=0.05), _rand(rng, 32, scale=0.1)
+    w3, b3 = _rand(rng, 128, 32, 1, 1, scale=0.1), _rand(rng, 128, scale=0.1)
+    h_ref = F.relu(F.conv2d(F.relu(x), w1, b1, padding=1))
+    y_ref = F.relu(F.conv2d(h_ref, w3, b3) + x)
+    xg = _nhwc(x)
+    wide = torch.zeros((N, H, W, 192), device=dev)          # write the block output into a slice of a wider buffer
+    h = torch.empty((N, H, W, 32), device=dev)
+    ops.conv_igemm(xg, ops.pack_conv(w1.to(dev)), b1.to(dev), h, k=(1, 3, 3), pad=(0, 1, 1), cin=128, cout=32,
+                   flags=FO_IN_RELU | FO_OUT_RELU)
+    ops.conv_igemm(h, ops.pack_conv(w3.to(dev)), b3.to(dev), wide[..., 64:192], k=(1, 1, 1), pad=(0, 0, 0), cin=32, cout=128,
+                   flags=FO_OUT_RELU, add=xg)
+    _close(h.permute(0, 3, 1, 2), h_ref, what="relu-conv-relu")
+    _close(wide[..., 64:192].permute(0, 3, 1, 2), y_ref, what="1x1 + residual + relu into slice")
+    assert wide[..., :64].abs().max().item() == 0.0
+    # masked dgrad with fan-in add: g_x = g + dgrad(gh) * (x > 0)
+    gh = _rand(rng, N, 32, H, W)
+    g = _rand(rng, N, 128, H, W)
+    want = g + F.conv_transpose2d(gh, w1, padding=1) * (x > 0)
+    gx = torch.empty((N, H, W, 128), device=dev)
+    ops.conv_igemm(_nhwc(gh), ops.pack_conv_dgrad(w1.to(dev).reshape(32, 128, -1)), None, gx, k=(1, 3, 3), pad=(0, 1, 1),
+                   cin=32, cout=128, mask=xg, add=_nhwc(g))
+    _close(gx.permute(0, 3, 1, 2), want, what="masked dgrad + add")
+    # wgrad with IN_RELU on Q
+    xr = x.clone().requires_grad_(False)
+    w1r = w1.clone().requires_grad_(True)
+    F.conv2d(F.relu(xr), w1r, None, padding=1).backward(gh)
+    dw = torch.empty_like(w1, device=dev)
+    ops.conv_wgrad(_nhwc(gh), xg, dw, None, k=(1, 3, 3), pad=(0, 1, 1), a_real=32, b_real=128, in_relu=True)
+    _close(dw, w1r.grad, what="wgrad in_relu")
+
+
+CONVT_CASES = [("convT_128to64", 128, 64, 2, 8, 8), ("convT_64to64", 64, 64, 2, 8, 12), ("convT_64to6", 64, 6, 2, 16, 16)]
+
+
+@pytest.mark.parametrize("case", CONVT_CASES, ids=[c[0] for c in CONVT_CASES])
+def test_conv_transpose_fwd_dgrad_wgrad(case):
+    from faceoff_amd import ops
+    name, Ci, Co, N, H, W = case
+    rng = np.random.default_rng(zlib.crc32(name.encode()))
+    x = _rand(rng, N, Ci, H, W).requires_grad_(True)
+    w = _rand(rng, Ci, Co, 4, 4, scale=0.1).requires_grad_(True)
+    b = _rand(rng, Co, scale=0.1).requires_grad_(True)
+    y = F.conv_transpose2d(x, w, b, stride=2, padding=1)
+    gy = _rand(rng, *y.shape)
+    y.backward(gy)
+    dev = _dev()
+    xg, wg, bg = _nhwc(x.detach()), w.detach().to(dev), b.detach().to(dev)
+    Cs = max(Co, 8)
+    out = torch.zeros((N, 2 * H, 2 * W, Cs), device=dev)
+    ops.convT_phases(xg, ops.pack_convT(wg), bg, out, cin=Ci, cout=Co)
+    _close(out[..., :Co].permute(0, 3, 1, 2), y, what="convT fwd")
+    gyg = _nhwc(gy)
+    gx = torch.empty((N, H, W, Ci), device=dev)
+    ops.conv_igemm(gyg, ops.pack_conv(wg), None, gx, k=(1, 4, 4), stride=2, pad=(0, 1, 1), cin=ops.pad_in(Co), cout=Ci)
+    _close(gx.permute(0, 3, 1, 2), x.grad, what="convT dgrad")
+    dw, db = torch.empty_like(wg), torch.empty_like(bg)
+    ops.conv_wgrad(xg, gyg, dw, None, k=(1, 4, 4), stride=2, pad=(0, 1, 1), a_real=Ci, b_real=Co)
+    ops.bias_grad(gyg, db, Co)
+    _close(dw, w.grad, what="convT wgrad")
+    _close(db, b.grad, what="convT bias grad")
+
+
+@pytest.mark.parametrize("B,T,H,W", [(1, 1, 8, 16), (2, 2, 8, 8), (1, 5, 16, 16), (2, 5, 16, 8), (3, 3, 6, 10)])
+def test_conv3d_fwd_dgrad_wgrad(B, T, H, W):
+    """Conv3d 128->128 k3 p1 (Conv3dLatentPostnet :181,185) incl. T=1,2,5 and tiles that straddle frames."""
+    from faceoff_amd import ops
+    rng = np.random.default_rng(100 + B * 10 + T)
+    x = _rand(rng, B, 128, T, H, W).requires_grad_(True)
+    w = _rand(rng, 128, 128, 3, 3, 3, scale=0.02).requires_grad_(True)
+    b = _rand(rng, 128, scale=0.1).requires_grad_(True)
+    y = F.conv3d(x, w, b, padding=1)
+    gy = _rand(rng, *y.shape)
+    y.backward(gy)
+    dev = _dev()
+
+    def frames(t5):   # [B,C,T,H,W] -> [B*T,H,W,C]
+        return t5.detach().permute(0, 2, 3, 4, 1).reshape(B * T, H, W, 128).contiguous().to(dev)
+
+    def clips(t4):    # inverse
+        return t4.reshape(B, T, H, W, 128).permute(0, 4, 1, 2, 3).cpu()
+
+    xg, gyg, wg, bg = frames(x), frames(gy), w.detach().to(dev), b.detach().to(dev)
+    out = torch.empty_like(xg)
+    ops.conv_igemm(xg, ops.pack_conv(wg), bg, out, T=T, k=(3, 3, 3), pad=(1, 1, 1), cin=128, cout=128)
+    _close(clips(out), y, what="conv3d fwd")
+    gx = torch.empty_like(xg)
+    ops.conv_igemm(gyg, ops.pack_conv_dgrad(wg.reshape(128, 128, -1)), None, gx, T=T, k=(3, 3, 3), pad=(1, 1, 1), cin=128,
+                   cout=128)
+    _close(clips(gx), x.grad, what="conv3d dgrad")
+    dw, db = torch.empty_like(wg), torch.empty_like(bg)
+    ops.conv_wgrad(gyg, xg, dw, db, T=T, k=(3, 3, 3), pad=(1, 1, 1), a_real=128, b_real=128)
+    _close(dw, w.grad, what="conv3d wgrad")
+    _close(db, b.grad, what="conv3d bias grad")
+
+
+def test_vq_assign_bit_exact_and_golden(golden_dir):
+    """Indices bit-exact vs oracle/vq_oracle.c and vs the reference's own (golden) indices."""
+    from faceoff_amd import ops
+    from oracle import vq_c
+    g = np.load(os.path.join(golden_dir, "quantize_kat.npz"))
+    dev = _dev()
+    for x_np, embed_np, tag in [(g["x"], g["embed"], "kat"),
+                                (np.random.default_rng(9).standard_normal((3, 7, 5, 64)).astype(np.float32) * 0.7,
+                                 np.random.default_rng(10).standard_normal((64, 512)).astype(np.float32), "ragged")]:
+        want = vq_c.assign(x_np, embed_np)
+        x = torch.from_numpy(x_np).to(dev)
+        embed = torch.from_numpy(embed_np).to(dev)
+        embedT, enorm = ops.vq_prepare(embed)
+        q = torch.empty_like(x)
+        stats = torch.zeros(1 + 512 + 512 * 64, device=dev)
+        ind = ops.vq_assign(x, embedT, enorm, q, stats, True)
+        assert np.array_equal(ind.cpu().numpy(), want["ind"]), tag
+        assert np.array_equal(q.cpu().numpy(), want["q_ste"]), tag           # x + (q - x) bit-exact
+        np.testing.assert_allclose(stats[0].item(), want["sq_sum"], rtol=1e-5)
+        assert np.array_equal(stats[1:513].cpu().numpy(), want["counts"])
+        np.testing.assert_allclose(stats[513:].view(512, 64).t().cpu().numpy(), want["esum"], rtol=1e-4, atol=1e-5)
+        if tag == "kat":
+            assert np.array_equal(ind.cpu().numpy().astype(np.int16), g["train_ind"])
+            np.testing.assert_allclose(q.cpu().numpy(), g["train_quantize"], rtol=1e-6)
+            # EMA update (:66-75) against the reference's post-step buffers
+            cs = torch.from_numpy(g["cluster_size0"]).to(dev)
+            ea = (embed * cs[None, :]).contiguous()
+            emb = embed.clone()
+            ops.vq_ema(emb, cs, ea, stats)
+            np.testing.assert_allclose(cs.cpu().numpy(), g["train_cluster_size_after"], rtol=1e-6)
+            np.testing.assert_allclose(ea.cpu().numpy(), g["train_embed_avg_after"], rtol=1e-5, atol=1e-6)
+            np.testing.assert_allclose(emb.cpu().numpy(), g["train_embed_after"], rtol=1e-5, atol=1e-6)
+            # backward: gx = g + gdiff * 2 (x - q)/numel
+            gq = torch.from_numpy(g["train_gout"]).to(dev)
+            gx = torch.empty_like(x)
+            ops.vq_bwd(gq, x, q, torch.full((1,), 3.0, device=dev), gx)
+            np.testing.assert_allclose(gx.cpu().numpy(), g["train_gx"], rtol=1e-5, atol=1e-7)
+            # decode_code gather
+            q2 = torch.empty_like(x)
+            ops.vq_gather(ind, embedT, q2)
+            np.testing.assert_allclose(q2.cpu().numpy(), embed_np.T[want["ind"]], rtol=0)
+
+
+def test_vq_large_property():
+    """BASELINE-size property check (655 360 vectors): every chosen code is a true nearest code in fp64
+    up to fp32 rounding of the distance, counts sum to Nvec, esum sums to sum(x)."""
+    from faceoff_amd import ops
+    dev = _dev()
+    gen = torch.Generator(device="cpu").manual_seed(3)
+    nvec = 160 * 64 * 64
+    x = (torch.randn(nvec, 64, generator=gen) * 0.5).to(dev).view(160, 64, 64, 64)
+    embed = torch.randn(64, 512, generator=gen).to(dev) * 0.5
+    embedT, enorm = ops.vq_prepare(embed)
+    q = torch.empty_like(x)
+    stats = torch.zeros(1 + 512 + 512 * 64, device=dev)
+    ind = ops.vq_assign(x, embedT, enorm, q, stats, True)
+    torch.cuda.synchronize()
+    assert stats[1:513].sum().item() == nvec
+    xf = x.view(-1, 64)
+    np.testing.assert_allclose(stats[513:].view(512, 64).sum(0).cpu().numpy(), xf.sum(0).cpu().numpy(), rtol=2e-3, atol=0.5)
+    sl = slice(0, 65536)
+    xd, ed = xf[sl].double(), embed.double()
+    dist = xd.pow(2).sum(1, keepdim=True) - 2 * xd @ ed + ed.pow(2).sum(0, keepdim=True)
+    best = dist.min(1).values
+    chosen = dist.gather(1, ind.view(-1)[sl].unsqueeze(1)).squeeze(1)
+    assert (chosen - best).max().item() <= 2e-5 * dist.abs().max().item()
+    assert torch.equal(q.view(-1, 64)[sl], xf[sl] + (embedT[ind.view(-1)[sl]] - xf[sl]))
+
+
+def test_layout_mse_adam():
+    from faceoff_amd import ops
+    dev = _dev()
+    rng = np.random.default_rng(4)
+    x = _rand(rng, 3, 6, 10, 12)
+    y = ops.nchw_to_nhwc(x.to(dev), cpad=8)
+    assert torch.equal(y[..., :6].cpu(), x.permute(0, 2, 3, 1)) and y[..., 6:].abs().max().item() == 0
+    assert torch.equal(ops.nhwc_to_nchw(y, 6).cpu(), x)
+    gt = _rand(rng, 3, 3, 10, 12)
+    acc = torch.zeros(1, device=dev)
+    ops.mse_slice_fwd(y, gt.to(dev), acc)
+    want = F.mse_loss(x[:, :3], gt)
+    np.testing.assert_allclose(acc.item() / gt.numel(), want.item(), rtol=1e-5)
+    gdec = torch.empty_like(y)
+    ops.mse_slice_bwd(y, gt.to(dev), torch.full((1,), 0.5, device=dev), gdec)
+    wantg = torch.zeros(3, 8, 10, 12)
+    wantg[:, :3] = 0.5 * 2 * (x[:, :3] - gt) / gt.numel()
+    np.testing.assert_allclose(gdec.permute(0, 3, 1, 2).cpu().numpy(), wantg.numpy(), rtol=1e-5, atol=1e-9)
+    # Adam vs torch.optim.Adam, 3 steps
+    p0 = _rand(rng, 1000)
+    p_ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([p_ref], lr=3e-4)
+    p, m, v = p0.to(dev), torch.zeros(1000, device=dev), torch.zeros(1000, device=dev)
+    for step in range(1, 4):
+        gcpu = _rand(rng, 1000)
+        p_ref.grad = gcpu.clone()
+        opt.step()
+        ops.adam_flat(p, gcpu.to(dev), m, v, 3e-4, step)
+    np.testing.assert_allclose(p.cpu().numpy(), p_ref.detach().numpy(), rtol=1e-5, atol=1e-7)
