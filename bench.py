@@ -1,0 +1,151 @@
+#!/usr/bin/env python3
+"""FaceOff MI355X bench: train frames/s of the VQ-VAE-2 + Conv3d-latent step (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+Workload (BASELINE.json configs[1], "C2"): 256x256, T=5, bs=32 clips per GPU (160 frames/GPU/step),
+recon + VQ loss, fp32, synthetic inputs resident in HBM, random-init weights.  A step is one full
+training iteration: forward, fused losses, backward (all 70 gradients), bucketed RCCL gradient
+all-reduce overlapped with backward (N>1), one multi-tensor Adam launch.  Weak scaling: per-GPU work
+is fixed.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+FLOP_PER_FRAME = 64.1e9                # 63.77 GFLOP conv + 0.34 GFLOP VQ distance per frame
+
+
+def cpu_baseline(T, H, W, steps=3):
+    """The CPU oracle (torch-CPU restatement of the reference step, kind "port") timed on this box's
+    host cores on a bounded sample: one clip of T frames at HxW, forward + backward + Adam."""
+    from oracle import faceoff_oracle as O
+    from faceoff_amd.synth import make_state_dict, make_batch
+    # torch-CPU (oneDNN) stops scaling well past a few dozen threads on these layer sizes: use up to 32
+    cores = min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(cores)
+    p = O.to_torch_state(make_state_dict(0, codebook_scale=0.3, gain=2.0))
+    img, gt = make_batch(1, 1, T, H, W)
+    img, gt = torch.from_numpy(img), torch.from_numpy(gt)
+    st = {}
+    O.train_step(img, gt, p, adam_state=st)          # warm-up
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        O.train_step(img, gt, p, adam_state=st)
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": round(T / dt, 3), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"1 clip x {T} frames {H}x{W}, fwd+bwd+Adam, {steps} timed steps after 1 warm-up, torch-CPU oracle"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--clips", type=int, default=32, help="clips per GPU (BASELINE: 32)")
+    ap.add_argument("--frames", type=int, default=5, help="frames per clip T (BASELINE: 5)")
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true", help="skip per-launch HIP-event timing")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.distributed.init_process_group("nccl", device_id=dev)
+
+    from faceoff_amd import ops
+    from faceoff_amd.engine import VQVAEEngine
+    from faceoff_amd.synth import make_state_dict
+    from faceoff_amd.trainer import FaceOffTrainer
+
+    B, T, H = args.clips, args.frames, args.size
+    eng = VQVAEEngine(make_state_dict(0, codebook_scale=0.3, gain=2.0), dev)
+    trainer = FaceOffTrainer(eng, lr=3e-4)
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    img = torch.rand((B * T, 6, H, H), device=dev, generator=gen) * 2 - 1       # U(-1,1): dataset.py:240-247
+    gt = torch.rand((B * T, 3, H, H), device=dev, generator=gen) * 2 - 1
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.step(img, gt, T=T)
+    prof = None
+    if not args.no_kernel_events:
+        prof = ops.KernelProfiler()
+        ops.PROFILER = prof
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        recon, latent, _ = trainer.step(img, gt, T=T)
+    sync()
+    dt = time.perf_counter() - t0
+    ops.PROFILER = None
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        dt = tmax.item()
+    if rank != 0:
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
+
+    ms = dt / args.steps * 1e3
+    fps = world * B * T * args.steps / dt
+    out = {
+        "metric": "train frames/sec (256x256, T=5, bs=32/GPU)", "value": round(fps, 2), "unit": "frames/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic U(-1,1) inputs resident in HBM; random-init weights (kaiming-uniform x2 gain, codebook N(0,0.3^2))",
+        "config": {"workload": f"C2: VQ-VAE-2 + Conv3d latent, {H}x{H}, T={T}, {B} clips/GPU, recon+VQ loss, fwd+bwd+Adam",
+                   "global_clips": B * world, "frames_per_step": B * T * world, "parallelism": f"dp{world}"},
+        "loss": {"recon": round(recon.item(), 6), "latent": round(latent.item(), 6)},
+        "step_frac_of_fp32_mfma_roofline": round(fps / world * FLOP_PER_FRAME / (FP32_MFMA_PEAK_TFLOPS * 1e12), 4),
+    }
+    if prof is not None:
+        summ = prof.summary()
+        dom = max(summ, key=lambda k: summ[k]["total_ms"])
+        d = summ[dom]
+        out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(d["tflops"], 2), "peak": FP32_MFMA_PEAK_TFLOPS,
+                           "unit": "TFLOP/s", "frac": round(d["tflops"] / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                           "launches_per_step": d["launches"] / args.steps, "avg_launch_ms": round(d["avg_ms"], 4),
+                           "algorithmic_gflop_per_launch": round(d["flops_per_launch"] / 1e9, 3),
+                           "share_of_step_time": round(d["total_ms"] / (ms * args.steps), 4)}
+        out["kernels"] = {k: {"launches_per_step": v["launches"] / args.steps, "avg_ms": round(v["avg_ms"], 4),
+                              "tflops": round(v["tflops"], 2), "ms_per_step": round(v["total_ms"] / args.steps, 3)}
+                          for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["total_ms"])}
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")       # written by profiles/collect.sh from rocprofv3 --pmc passes
+        if os.path.exists(pmc):
+            try:
+                out["roofline"]["traffic"] = json.load(open(pmc)).get(dom)
+            except Exception:
+                pass
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(T, H, H)
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,79 @@
+"""Data-parallel gradient exchange for the flat gradient arena (replaces nn.parallel.
+DistributedDataParallel at train_faceoff_perceptual.py:164-169).
+
+The engine's backward fills the arena from its END towards its START (VQVAEEngine.layer_order), so a
+bucket is a contiguous slice that becomes final when the layer at its low end is done.  As soon as
+that happens the slice is all-reduced (SUM; averaging is folded into the optimiser's grad_scale) on
+a side HIP stream, overlapping the rest of backward.  xGMI is point-to-point and the whole payload
+is 16.2 MB, so buckets are few and large (default 4 MiB -> 4-5 messages): latency, not bandwidth,
+is what there is to hide.
+"""
+import torch
+from torch import distributed as dist
+
+
+class GradBucketReducer:
+    def __init__(self, flat_grads, layer_order, offsets, bucket_bytes=4 << 20, group=None):
+        """layer_order: arena order of layer names (reverse of backward completion);
+        offsets: key -> (offset, numel) for '<layer>.weight' / '<layer>.bias'."""
+        self.flat = flat_grads
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        # walk the arena from the end (first-completed layer) building buckets
+        self.buckets = []          # (lo, hi, trigger_layer)
+        hi = flat_grads.numel()
+        cur_hi = hi
+        for name in reversed(layer_order):
+            lo = offsets[name + ".weight"][0]
+            if (cur_hi - lo) * 4 >= bucket_bytes:
+                self.buckets.append((lo, cur_hi, name))
+                cur_hi = lo
+        if cur_hi > 0:
+            self.buckets.append((0, cur_hi, layer_order[0]))
+        self._trigger = {t: i for i, (_, _, t) in enumerate(self.buckets)}
+        self._works = []
+        self.cuda = flat_grads.is_cuda
+        self.side = torch.cuda.Stream(device=flat_grads.device) if self.cuda and self.world > 1 else None
+        self.launched = []         # bucket indices in launch order (tests)
+
+    def layer_done(self, name):
+        """grad_ready_hook of the engine: fire the bucket whose last layer just completed."""
+        i = self._trigger.get(name)
+        if i is None or self.world == 1:
+            return
+        lo, hi, _ = self.buckets[i]
+        self.launched.append(i)
+        view = self.flat[lo:hi]
+        if self.cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self.side.wait_event(ev)
+            with torch.cuda.stream(self.side):
+                self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self):
+        """Join the side stream; afterwards the arena holds the SUM over ranks."""
+        if self.world == 1:
+            return
+        if self.cuda:
+            with torch.cuda.stream(self.side):
+                for w in self._works:
+                    w.wait()
+            torch.cuda.current_stream().wait_stream(self.side)
+        else:
+            for w in self._works:
+                w.wait()
+        self._works = []
+        self.launched = []
+
+
+def fused_vq_allreduce(group=None):
+    """Returns f(stats[512 + 512*64]) summing the EMA statistics of one quantiser over ranks in ONE
+    message (the reference issues two blocking all-reduces per quantiser, vqvae_conv3d_latent.py:63-64)."""
+    def f(stats):
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
+        return stats
+    return f

@@ -23,6 +23,20 @@ from .ops import FO_IN_RELU, FO_OUT_RELU
 from .synth import vqvae_param_specs
 
 
+def _rb(prefix):
+    return [prefix + ".conv.3", prefix + ".conv.1"]
+
+
+# The order in which VQVAEEngine.backward() finishes each layer's filter/bias gradient.
+BACKWARD_ORDER = (
+    ["dec.blocks.6", "dec.blocks.4"] + _rb("dec.blocks.2") + _rb("dec.blocks.1") + ["dec.blocks.0", "upsample_t",
+     "quantize_conv_b", "dec_t.blocks.4"] + _rb("dec_t.blocks.2") + _rb("dec_t.blocks.1") + ["dec_t.blocks.0",
+     "quantize_conv_t"] + [f"conv3d_encoded_t.conv3d.{i}.0" for i in (2, 1, 0)] + _rb("enc_t.blocks.4")
+    + _rb("enc_t.blocks.3") + ["enc_t.blocks.2", "enc_t.blocks.0"]
+    + [f"conv3d_encoded_b.conv3d.{i}.0" for i in (2, 1, 0)] + _rb("enc_b.blocks.6") + _rb("enc_b.blocks.5")
+    + ["enc_b.blocks.4", "enc_b.blocks.2", "enc_b.blocks.0"])
+
+
 class _Layer:
     """One conv-like layer: checkpoint-layout parameters + packed filters + launch helpers."""
 
@@ -104,11 +118,15 @@ class VQVAEEngine:
         self.in_channel = in_channel
         self.clip_len = clip_len
         specs = vqvae_param_specs(in_channel=in_channel)
-        # ---- flat arenas (reference parameter order == state_dict order minus buffers)
+        # ---- flat arenas.  Arena order = REVERSE of the order in which backward() completes layers, so
+        # the gradient arena fills from its end towards its start and every data-parallel bucket is one
+        # contiguous slice that becomes ready mid-backward.  (state_dict() re-emits reference order.)
+        by_name = {name: (kind, shape) for name, kind, shape in specs if kind != "vq"}
+        assert set(by_name) == set(BACKWARD_ORDER), "BACKWARD_ORDER must list every layer exactly once"
+        self.layer_order = list(reversed(BACKWARD_ORDER))
         sizes = []
-        for name, kind, shape in specs:
-            if kind == "vq":
-                continue
+        for name in self.layer_order:
+            kind, shape = by_name[name]
             n_w = int(torch.tensor(shape).prod())
             n_b = shape[1] if kind == "convT" else shape[0]
             sizes += [(name + ".weight", shape, n_w), (name + ".bias", (n_b,), n_b)]
@@ -136,7 +154,6 @@ class VQVAEEngine:
         self.layers["enc_b.blocks.0"].need_dgrad = False   # the input image needs no gradient
         if state_dict is not None:
             self.load_state_dict(state_dict)
-        self.saved = None
         self.grad_ready_hook = None   # callable(layer_name) fired as soon as a layer's grads are enqueued
         self.vq_allreduce = None      # callable(stats tensor) -> summed over ranks (Quantize :63-64)
 
@@ -191,35 +208,33 @@ class VQVAEEngine:
         if self.grad_ready_hook is not None:
             self.grad_ready_hook(name)
 
-    # ------------------------------------------------------------------ forward
-    def forward(self, img_nchw, training=True, T=None):
-        """img_nchw [N,6,H,W] (N = B*T frames).  Returns (dec NHWC[N,H,W,8], diff tensor[1], aux)."""
-        L = self.layers
-        N, Cin, H, W = img_nchw.shape
-        T = T or self.clip_len or N
-        assert N % T == 0, f"N={N} frames is not a whole number of clips of T={T}"
-        assert H % 8 == 0 and W % 8 == 0
-        for layer in L.values():
+    # ------------------------------------------------------------------ forward (staged so the reference's
+    # only_encode / encode_quantized / decode entry points can run the same launches)
+    def pack_filters(self):
+        for layer in self.layers.values():
             layer.pack()
-        S = {}
-        S["T"] = T
-        x8 = ops.nchw_to_nhwc(img_nchw, cpad=ops.pad_in(Cin))
-        S["x8"] = x8
+
+    def stage_encode(self, S):
+        """only_encode (:237-241): enc_b = Encoder(stride 4), enc_t = Encoder(stride 2)."""
+        L, x8 = self.layers, S["x8"]
+        N, H, W, _ = x8.shape
         h2, w2, h4, w4, h8, w8 = H // 2, W // 2, H // 4, W // 4, H // 8, W // 8
-        # ---- enc_b (Encoder stride 4, :107-126)
         a0 = self._new(N, h2, w2, 64); L["enc_b.blocks.0"].fwd(x8, a0, flags=FO_OUT_RELU)
         a1 = self._new(N, h4, w4, 128); L["enc_b.blocks.2"].fwd(a0, a1, flags=FO_OUT_RELU)
         a2 = self._new(N, h4, w4, 128); L["enc_b.blocks.4"].fwd(a1, a2)
         a3 = self._new(N, h4, w4, 128); S["h_eb5"] = self._resblock_fwd("enc_b.blocks.5", a2, a3, False)
         eb = self._new(N, h4, w4, 128); S["h_eb6"] = self._resblock_fwd("enc_b.blocks.6", a3, eb, True)
-        S.update(a0=a0, a1=a1, a2=a2, a3=a3, eb=eb)
-        # ---- enc_t (Encoder stride 2, :116-126)
         t0 = self._new(N, h8, w8, 64); L["enc_t.blocks.0"].fwd(eb, t0, flags=FO_OUT_RELU)
         t1 = self._new(N, h8, w8, 128); L["enc_t.blocks.2"].fwd(t0, t1)
         t2 = self._new(N, h8, w8, 128); S["h_et3"] = self._resblock_fwd("enc_t.blocks.3", t1, t2, False)
         et = self._new(N, h8, w8, 128); S["h_et4"] = self._resblock_fwd("enc_t.blocks.4", t2, et, True)
-        S.update(t0=t0, t1=t1, t2=t2, et=et)
-        # ---- Conv3d latent post-nets (:172-176,250); bottom output lands in cat_b[..., 64:192]
+        S.update(a0=a0, a1=a1, a2=a2, a3=a3, eb=eb, t0=t0, t1=t1, t2=t2, et=et)
+
+    def stage_conv3d(self, S):
+        """Conv3dLatentPostnet x2 (:172-176,247-251).  Bottom output lands in cat_b[..., 64:192]."""
+        L, T, eb, et = self.layers, S["T"], S["eb"], S["et"]
+        N, h4, w4, _ = eb.shape
+        _, h8, w8, _ = et.shape
         cat_b = self._new(N, h4, w4, 192)
         c1 = self._new(N, h4, w4, 128); L["conv3d_encoded_b.conv3d.0.0"].fwd(eb, c1, T=T, flags=FO_OUT_RELU)
         c2 = self._new(N, h4, w4, 128); L["conv3d_encoded_b.conv3d.1.0"].fwd(c1, c2, T=T, flags=FO_OUT_RELU)
@@ -228,7 +243,12 @@ class VQVAEEngine:
         d2 = self._new(N, h8, w8, 128); L["conv3d_encoded_t.conv3d.1.0"].fwd(d1, d2, T=T, flags=FO_OUT_RELU)
         d3 = self._new(N, h8, w8, 128); L["conv3d_encoded_t.conv3d.2.0"].fwd(d2, d3, T=T)
         S.update(c1=c1, c2=c2, d1=d1, d2=d2, d3=d3, cat_b=cat_b)
-        # ---- encode_quantized (:261-278)
+
+    def stage_quantize(self, S, training):
+        """encode_quantized (:261-278).  Needs S[d3] and S[cat_b][..., 64:192]."""
+        L, d3, cat_b = self.layers, S["d3"], S["cat_b"]
+        N, h8, w8, _ = d3.shape
+        _, h4, w4, _ = cat_b.shape
         qt_in = self._new(N, h8, w8, 64); L["quantize_conv_t"].fwd(d3, qt_in)
         quant_t = self._new(N, h8, w8, 64)
         id_t, stats_t = self._quantize("quantize_t", qt_in, quant_t, training)
@@ -239,17 +259,9 @@ class VQVAEEngine:
         qb_in = self._new(N, h4, w4, 64); L["quantize_conv_b"].fwd(cat_b, qb_in)
         cat_d = self._new(N, h4, w4, 128)
         id_b, stats_b = self._quantize("quantize_b", qb_in, cat_d[..., 64:128], training)
-        S.update(qt_in=qt_in, quant_t=quant_t, u0=u0, u1=u1, u2=u2, qb_in=qb_in, cat_d=cat_d)
-        # ---- decode (:280-285)
-        L["upsample_t"].fwd(quant_t, cat_d[..., 0:64])                     # torch.cat([upsample_t, quant_b], 1) :282
-        v0 = self._new(N, h4, w4, 128); L["dec.blocks.0"].fwd(cat_d, v0)
-        v1 = self._new(N, h4, w4, 128); S["h_d1"] = self._resblock_fwd("dec.blocks.1", v0, v1, False)
-        v2 = self._new(N, h4, w4, 128); S["h_d2"] = self._resblock_fwd("dec.blocks.2", v1, v2, True)
-        w1 = self._new(N, h2, w2, 64); L["dec.blocks.4"].fwd(v2, w1, flags=FO_OUT_RELU)
-        dec = torch.zeros((N, H, W, 8), device=self.device); L["dec.blocks.6"].fwd(w1, dec)
-        S.update(v0=v0, v1=v1, v2=v2, w1=w1, dec=dec)
+        S.update(qt_in=qt_in, quant_t=quant_t, u0=u0, u1=u1, u2=u2, qb_in=qb_in, cat_d=cat_d, id_t=id_t, id_b=id_b)
         # diff = diff_t + diff_b, each mean((q - x)^2) (:77,268,276,278)
-        diff = (stats_t[0:1] / float(qt_in.numel()) + stats_b[0:1] / float(qb_in.numel()))
+        S["diff"] = stats_t[0:1] / float(qt_in.numel()) + stats_b[0:1] / float(qb_in.numel())
         # EMA codebook update after the (optional) cross-rank sum of the statistics (:59-75)
         if training:
             for lvl, st in (("t", stats_t), ("b", stats_b)):
@@ -257,10 +269,33 @@ class VQVAEEngine:
                     self.vq_allreduce(st[1:])
                 ops.vq_ema(self.buffers[f"quantize_{lvl}.embed"], self.buffers[f"quantize_{lvl}.cluster_size"],
                            self.buffers[f"quantize_{lvl}.embed_avg"], st)
-        self.saved = S
-        aux = dict(id_t=id_t, id_b=id_b, qt_in=qt_in, qb_in=qb_in, quant_t=quant_t, quant_b=cat_d[..., 64:128],
-                   enc_b=eb, enc_t=et)
-        return dec, diff, aux
+
+    def stage_decode(self, S):
+        """decode (:280-285).  Needs S[quant_t] and S[cat_d][..., 64:128] (= quant_b)."""
+        L, quant_t, cat_d = self.layers, S["quant_t"], S["cat_d"]
+        N, h4, w4, _ = cat_d.shape
+        L["upsample_t"].fwd(quant_t, cat_d[..., 0:64])                     # torch.cat([upsample_t, quant_b], 1) :282
+        v0 = self._new(N, h4, w4, 128); L["dec.blocks.0"].fwd(cat_d, v0)
+        v1 = self._new(N, h4, w4, 128); S["h_d1"] = self._resblock_fwd("dec.blocks.1", v0, v1, False)
+        v2 = self._new(N, h4, w4, 128); S["h_d2"] = self._resblock_fwd("dec.blocks.2", v1, v2, True)
+        w1 = self._new(N, 2 * h4, 2 * w4, 64); L["dec.blocks.4"].fwd(v2, w1, flags=FO_OUT_RELU)
+        dec = torch.zeros((N, 4 * h4, 4 * w4, 8), device=self.device); L["dec.blocks.6"].fwd(w1, dec)
+        S.update(v0=v0, v1=v1, v2=v2, w1=w1, dec=dec)
+
+    def forward(self, img_nchw, training=True, T=None):
+        """VQVAE.forward (:243-259).  img_nchw [N,6,H,W] (N = B*T frames).
+        Returns S: dict of saved activations incl. S[dec] NHWC [N,H,W,8], S[diff] [1], S[id_t], S[id_b]."""
+        N, Cin, H, W = img_nchw.shape
+        T = T or self.clip_len or N
+        assert N % T == 0, f"N={N} frames is not a whole number of clips of T={T}"
+        assert H % 8 == 0 and W % 8 == 0, "spatial size must be a multiple of 8"
+        self.pack_filters()
+        S = {"T": T, "x8": ops.nchw_to_nhwc(img_nchw, cpad=ops.pad_in(Cin))}
+        self.stage_encode(S)
+        self.stage_conv3d(S)
+        self.stage_quantize(S, training)
+        self.stage_decode(S)
+        return S
 
     def _quantize(self, name, x, q_out, training):
         embedT, enorm = ops.vq_prepare(self.buffers[name + ".embed"])
@@ -269,10 +304,10 @@ class VQVAEEngine:
         return ind, stats
 
     # ------------------------------------------------------------------ backward
-    def backward(self, g_dec, g_diff):
-        """g_dec NHWC [N,H,W,8] grad wrt dec; g_diff float32[1] device tensor grad wrt diff.
+    def backward(self, S, g_dec, g_diff):
+        """S: the dict forward() returned.  g_dec NHWC [N,H,W,8] grad wrt dec; g_diff float32[1] device tensor.
         Fills self.grads (flat arena).  Order = reverse forward, so arena slices complete back-to-front."""
-        L, S = self.layers, self.saved
+        L = self.layers
         T = S["T"]
         new_like = torch.empty_like
         # ---- dec (Decoder stride 4)
@@ -345,18 +380,18 @@ class VQVAEEngine:
         b2.wgrad(S["a0"], g_a1); self._ready(b2.name)
         g_a0 = new_like(S["a0"]); b2.dgrad(g_a1, g_a0, mask=S["a0"])
         b0.wgrad(S["x8"], g_a0); self._ready(b0.name)
-        self.saved = None
 
     # ------------------------------------------------------------------ fused train step (bench / trainer fast path)
     def loss_and_backward(self, img_nchw, gt_nchw, T=None, latent_weight=1.0):
         """run_step + backward (train_faceoff_perceptual.py:32-47,98-100) for recon + latent loss.
         Returns device scalars (recon, latent).  Gradients land in self.flat_grads."""
-        dec, diff, aux = self.forward(img_nchw, training=True, T=T)
+        S = self.forward(img_nchw, training=True, T=T)
+        dec = S["dec"]
         acc = torch.zeros(1, device=self.device)
         ops.mse_slice_fwd(dec, gt_nchw, acc)
         recon = acc / float(gt_nchw.numel())
         one = torch.ones(1, device=self.device)
         g_dec = torch.empty_like(dec)
         ops.mse_slice_bwd(dec, gt_nchw, one, g_dec)
-        self.backward(g_dec, one * latent_weight)
-        return recon, diff, aux
+        self.backward(S, g_dec, one * latent_weight)
+        return recon, S["diff"], S

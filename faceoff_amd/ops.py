@@ -14,6 +14,40 @@ from . import _lib
 from ._lib import ConvDesc, FO_IN_RELU, FO_BIAS, FO_MASK, FO_ADD, FO_OUT_RELU  # noqa: F401
 
 
+class KernelProfiler:
+    """Live per-launch timing with HIP events on the launch stream (bench.py's roofline leg).
+    Groups launches by kernel instance name; `flops` is the ALGORITHMIC work of the launch."""
+
+    def __init__(self):
+        self.records = {}     # name -> list of (start_event, end_event, flops)
+        self._cur = None
+
+    def begin(self, name, flops):
+        s = torch.cuda.Event(enable_timing=True)
+        s.record(torch.cuda.current_stream())
+        self._cur = (name, s, flops)
+
+    def end(self):
+        name, s, flops = self._cur
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(torch.cuda.current_stream())
+        self.records.setdefault(name, []).append((s, e, flops))
+
+    def summary(self):
+        """name -> dict(launches, total_ms, avg_ms, flops_per_launch, tflops) (synchronises)."""
+        torch.cuda.synchronize()
+        out = {}
+        for name, recs in self.records.items():
+            ms = sum(s.elapsed_time(e) for s, e, _ in recs)
+            fl = sum(f for _, _, f in recs)
+            out[name] = dict(launches=len(recs), total_ms=ms, avg_ms=ms / len(recs), flops_per_launch=fl / len(recs),
+                             tflops=fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0)
+        return out
+
+
+PROFILER = None   # set to a KernelProfiler to time conv launches
+
+
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -103,7 +137,14 @@ def conv_igemm(x, wp, bias, out, *, T=1, k=(1, 3, 3), stride=1, pad=(0, 1, 1), c
               KD=k[0], KH=k[1], KW=k[2], stride=stride, padD=pad[0], padH=pad[1], padW=pad[2],
               ostride=ostride, ophH=oph[0], ophW=oph[1], ldIn=ld_of(x), ldOut=ld_of(out),
               ldMask=ld_of(mask) if mask is not None else 0, ldAdd=ld_of(add) if add is not None else 0, flags=flags)
+    prof = PROFILER
+    if prof is not None:
+        kname = "conv_igemm_bn%d%s" % (128 if d.Cout > 64 else (64 if d.Cout > 32 else 32), "_smallc" if d.Cin < 32 else "")
+        flops = 2.0 * N * Hm * Wm * d.Cout * (k[0] * k[1] * k[2] * d.Cin)
+        prof.begin(kname, flops)
     _lib.call("fo_conv_igemm", C.byref(d), _ptr(x), _ptr(wp), _ptr(bias), _ptr(mask), _ptr(add), _ptr(out), _stream())
+    if prof is not None:
+        prof.end()
 
 
 def convT_phases(x, wp4, bias, out, *, cin, cout, flags=0, mask=None, add=None):
@@ -141,8 +182,13 @@ def conv_wgrad(P, Q, dw, dbias, *, T=1, k=(1, 3, 3), stride=1, pad=(0, 1, 1), a_
     if nbytes < 0:
         _lib.check(-1, "fo_wgrad_ws_bytes")
     ws = _workspace(nbytes, P.device)
+    prof = PROFILER
+    if prof is not None:
+        prof.begin("conv_wgrad_%dx%d" % (Ca, Cb), 2.0 * N * Hm * Wm * Ca * Cb * k[0] * k[1] * k[2])
     _lib.call("fo_conv_wgrad", C.byref(d), _ptr(P), _ptr(Q), _ptr(dw), a_real, b_real, _ptr(dbias), _ptr(ws),
               C.c_int64(ws.numel() * 4), _stream())
+    if prof is not None:
+        prof.end()
 
 
 def bias_grad(g, dbias, c_real):

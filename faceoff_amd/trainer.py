@@ -1,0 +1,83 @@
+"""The training iteration of train_faceoff_perceptual.py:92-107 on the MI355X engine.
+
+    model.zero_grad(); run_step(); loss = recon + 1*latent + 1*perceptual; loss.backward();
+    scheduler.step(); optimizer.step()
+
+becomes: engine forward -> fused loss kernels -> engine backward (gradient buckets all-reduced on a
+side stream as they complete) -> one multi-tensor Adam launch over the flat arena.  No host
+synchronisation anywhere in the step: losses stay on the device until the caller asks.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from .distributed import GradBucketReducer, fused_vq_allreduce, get_world_size
+from .engine import VQVAEEngine
+
+LATENT_LOSS_WEIGHT = 1.0       # reference config.py:5
+PERCEPTUAL_LOSS_WEIGHT = 1.0   # reference config.py:6
+
+
+class FlatAdam:
+    """torch.optim.Adam(model.parameters(), lr) (train_faceoff_perceptual.py:190) as ONE launch."""
+
+    def __init__(self, engine: VQVAEEngine, lr=3e-4, betas=(0.9, 0.999), eps=1e-8):
+        self.engine = engine
+        self.param_groups = [dict(lr=lr, betas=betas, eps=eps)]
+        self.m = torch.zeros_like(engine.flat_params)
+        self.v = torch.zeros_like(engine.flat_params)
+        self.t = 0
+
+    def step(self, grad_scale=1.0):
+        g = self.param_groups[0]
+        self.t += 1
+        ops.adam_flat(self.engine.flat_params, self.engine.flat_grads, self.m, self.v, g["lr"], self.t, g["betas"],
+                      g["eps"], grad_scale)
+
+    def state_dict(self):
+        return dict(m=self.m, v=self.v, t=self.t, param_groups=self.param_groups)
+
+    def load_state_dict(self, sd):
+        self.m.copy_(sd["m"]); self.v.copy_(sd["v"]); self.t = sd["t"]; self.param_groups = sd["param_groups"]
+
+
+class FaceOffTrainer:
+    def __init__(self, engine: VQVAEEngine, lr=3e-4, scheduler=None, vqlpips=None, bucket_bytes=4 << 20, group=None):
+        self.engine = engine
+        self.optimizer = FlatAdam(engine, lr=lr)
+        self.scheduler = scheduler
+        self.vqlpips = vqlpips
+        self.world = get_world_size()
+        self.reducer = None
+        if self.world > 1:
+            self.reducer = GradBucketReducer(engine.flat_grads, engine.layer_order, engine.offsets, bucket_bytes, group)
+            engine.grad_ready_hook = self.reducer.layer_done
+            engine.vq_allreduce = fused_vq_allreduce(group)
+
+    def step(self, img, ground_truth, T=None):
+        """img [B,T,6,H,W] or [N,6,H,W]; ground_truth likewise with 3 channels (utils.py:29-38).
+        Returns device scalars (recon_loss, latent_loss, perceptual_loss)."""
+        if img.dim() == 5:
+            T = T or img.shape[1]
+            img = img.reshape(-1, *img.shape[2:])
+            ground_truth = ground_truth.reshape(-1, *ground_truth.shape[2:])
+        eng = self.engine
+        S = eng.forward(img, training=True, T=T)
+        dec = S["dec"]
+        acc = torch.zeros(1, device=eng.device)
+        ops.mse_slice_fwd(dec, ground_truth, acc)
+        recon = acc / float(ground_truth.numel())
+        one = torch.ones(1, device=eng.device)
+        g_dec = torch.empty_like(dec)
+        ops.mse_slice_bwd(dec, ground_truth, one, g_dec)
+        perceptual = torch.zeros(1, device=eng.device)
+        if self.vqlpips is not None:
+            perceptual = self.vqlpips.loss_and_grad(ground_truth, dec, g_dec, PERCEPTUAL_LOSS_WEIGHT)
+        eng.backward(S, g_dec, one * LATENT_LOSS_WEIGHT)
+        if self.reducer is not None:
+            self.reducer.finish()
+        if self.scheduler is not None:           # before optimizer.step(), as the reference (:104-107)
+            self.scheduler.step()
+        self.optimizer.step(grad_scale=1.0 / self.world)   # DDP averages gradients
+        return recon, S["diff"], perceptual

@@ -115,12 +115,15 @@ def gen_e2e(name, B, T, H, W, seed_w, seed_x, literal=False, with_adam=True):
     lat = {}
     m.quantize_t.register_forward_pre_hook(lambda mod, a: lat.__setitem__("t", (a[0].detach().clone(), mod.embed.clone())))
     m.quantize_b.register_forward_pre_hook(lambda mod, a: lat.__setitem__("b", (a[0].detach().clone(), mod.embed.clone())))
+    ids = {}
+    m.quantize_t.register_forward_hook(lambda mod, a, out: ids.__setitem__("t", out[2].detach().clone()))
+    m.quantize_b.register_forward_hook(lambda mod, a, out: ids.__setitem__("b", out[2].detach().clone()))
     opt = torch.optim.Adam(m.parameters(), lr=3e-4)
     m.zero_grad()
     if literal:
         assert B == 1
         dec, diff = m(img.reshape(B * T, 6, H, W))           # VQVAE.forward itself
-        id_t = id_b = None
+        id_t, id_b = ids["t"], ids["b"]
     else:
         dec, diff, id_t, id_b, eb, et = ref_forward_clips(m, img)
     out3 = dec[:, :3]
@@ -132,7 +135,7 @@ def gen_e2e(name, B, T, H, W, seed_w, seed_x, literal=False, with_adam=True):
                dec=dec.detach().numpy() if dec.numel() < 400000 else sub(dec),
                dec_stats=stats(dec), diff=diff.detach().numpy(), recon=recon.item(), latent=latent.item(),
                loss=loss.item())
-    if not literal:
+    if True:
         res.update(id_t=id_t.numpy().astype(np.int16), id_b=id_b.numpy().astype(np.int16),
                    margin_t=margins(*lat["t"]), margin_b=margins(*lat["b"]),
                    qt_in_sub=sub(lat["t"][0]), qb_in_sub=sub(lat["b"][0]),

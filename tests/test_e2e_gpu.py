@@ -1,0 +1,143 @@
+"""Whole-step parity on a real MI355X: forward + backward (+ Adam) of the HIP engine against
+(1) golden outputs of the reference itself (tests/golden/*.npz) and (2) the CPU oracle on the same
+seeded inputs.  Tolerance 1e-3 relative to each tensor's scale; VQ indices bit-exact (mismatches
+tolerated only where the reference's own top-2 margin is below the upstream fp32 error)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from faceoff_amd.synth import make_state_dict, make_batch
+
+pytestmark = pytest.mark.gpu
+SUB = 61
+
+
+def _sub(t):
+    return t.detach().reshape(-1)[::SUB].cpu().numpy()
+
+
+def _stats(t):
+    t = t.detach().double()
+    return np.array([t.sum().item(), t.pow(2).sum().item(), t.abs().max().item()])
+
+
+def _rel(got, want):
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    return np.abs(got - want).max() / (np.abs(want).max() + 1e-30)
+
+
+def _engine_step(g, T=None):
+    from faceoff_amd.engine import VQVAEEngine
+    B, T_, H, W = (int(g[k]) for k in "BTHW")
+    sd = make_state_dict(int(g["seed_w"]), codebook_scale=float(g["codebook_scale"]), gain=float(g["gain"]))
+    eng = VQVAEEngine(sd, "cuda:0")
+    img, gt = make_batch(int(g["seed_x"]), B, T_, H, W)
+    img = torch.from_numpy(img).reshape(B * T_, 6, H, W).cuda()
+    gt = torch.from_numpy(gt).reshape(B * T_, 3, H, W).cuda()
+    recon, diff, S = eng.loss_and_backward(img, gt, T=T or T_)
+    torch.cuda.synchronize()
+    return eng, recon, diff, S, img, gt
+
+
+def _check_against_golden(g, eng, recon, diff, S, literal=False, grad_rtol=1e-3):
+    from faceoff_amd import ops
+    dec = ops.nhwc_to_nchw(S["dec"], 6)
+    # VQ indices: bit-exact, except where the reference's own top-2 margin is below the upstream
+    # fp32 rounding; such a flip changes `dec` locally by O(1).
+    flips = 0
+    for lvl in "tb":
+        got = S["id_" + lvl].cpu().numpy().astype(np.int16).reshape(-1)
+        bad = got != g["id_" + lvl].reshape(-1)
+        assert np.all(g["margin_" + lvl][bad] < 1e-4), f"id_{lvl}: {int(bad.sum())} mismatches outside the near-tie gate"
+        assert bad.mean() < 2e-3
+        flips += int(bad.sum())
+    got_dec = dec.cpu().numpy() if g["dec"].ndim == 4 else _sub(dec)
+    if flips == 0:
+        assert _rel(got_dec, g["dec"]) < 1e-3
+    else:   # a flipped top-level code reaches a 40x40-pixel patch of one 64x64 frame through dec_t + dec
+        frac_bad = (np.abs(got_dec - g["dec"]) > 1e-3 * np.abs(g["dec"]).max()).mean()
+        assert frac_bad < 0.12 * flips, (flips, frac_bad)
+        grad_rtol = max(grad_rtol, 2e-2)
+    np.testing.assert_allclose(recon.item(), float(g["recon"]), rtol=1e-3)
+    np.testing.assert_allclose(diff.item(), float(g["latent"]), rtol=1e-3)
+    names = [str(n) for n in g["param_names"]]
+    gs = np.stack([_stats(eng.grads[n]) for n in names])
+    np.testing.assert_allclose(np.sqrt(gs[:, 1]), np.sqrt(g["grad_stats"][:, 1]), rtol=grad_rtol)
+    sub = np.concatenate([_sub(eng.grads[n]) for n in names])
+    # per-tensor scale: compare each tensor's subsample against its own max
+    off = 0
+    for n in names:
+        k = len(_sub(eng.grads[n]))
+        want = g["grad_sub"][off:off + k]
+        got = sub[off:off + k]
+        scale = np.sqrt(g["grad_stats"][names.index(n), 1] / eng.grads[n].numel()) + 1e-30   # rms of the tensor
+        assert np.abs(got - want).max() <= 5 * grad_rtol * max(scale, np.abs(want).max()), n
+        off += k
+    for n in names:
+        if "grad_full." + n in g.files:
+            assert _rel(eng.grads[n].cpu().numpy(), g["grad_full." + n]) < 1e-3, n
+    for k, b in eng.buffers.items():
+        np.testing.assert_allclose(_stats(b)[1], g["buf_stats." + k][1], rtol=2e-3)
+
+
+def test_c1_e2e_vs_reference_golden(golden_dir):
+    """BASELINE config 1 (64x64, T=2, bs=2): forward, losses, indices, all 70 gradients, EMA buffers."""
+    g = np.load(os.path.join(golden_dir, "c1_e2e.npz"))
+    eng, recon, diff, S, img, gt = _engine_step(g)
+    _check_against_golden(g, eng, recon, diff, S)
+    # Adam step (train_faceoff_perceptual.py:107) then an eval forward pins the whole state update
+    from faceoff_amd import ops
+    m, v = torch.zeros_like(eng.flat_params), torch.zeros_like(eng.flat_params)
+    ops.adam_flat(eng.flat_params, eng.flat_grads, m, v, 3e-4, 1)
+    names = [str(n) for n in g["param_names"]]
+    after = np.concatenate([_sub(eng.params[n]) for n in names])
+    np.testing.assert_allclose(after, g["param_after_sub"], rtol=1e-3, atol=3e-5)
+    S2 = eng.forward(img, training=False, T=int(g["T"]))
+    dec2 = ops.nhwc_to_nchw(S2["dec"], 6)
+    np.testing.assert_allclose(S2["diff"].item(), float(g["diff2"].reshape(-1)[0]), rtol=5e-2)
+    assert np.abs(_sub(dec2) - g["dec2_sub"]).max() < 5e-2 * np.abs(g["dec2_sub"]).max()
+
+
+def test_b1_literal_reference_forward(golden_dir):
+    """One clip of 4 frames (T = N): equals the reference's VQVAE.forward itself."""
+    g = np.load(os.path.join(golden_dir, "b1_literal.npz"))
+    eng, recon, diff, S, img, gt = _engine_step(g)
+    _check_against_golden(g, eng, recon, diff, S, literal=True)
+
+
+def test_c2_oneclip_vs_reference_golden(golden_dir):
+    """C2 shape (256x256, T=5), one clip: losses, indices (margin-gated), gradient norms."""
+    g = np.load(os.path.join(golden_dir, "c2_oneclip.npz"))
+    eng, recon, diff, S, img, gt = _engine_step(g)
+    _check_against_golden(g, eng, recon, diff, S, grad_rtol=3e-3)
+
+
+def test_e2e_vs_oracle_ragged():
+    """Odd sizes the golden set does not hold: 3 clips of T=3 at 40x24 (tiles straddle frames, M tails)."""
+    from faceoff_amd.engine import VQVAEEngine
+    from faceoff_amd import ops
+    from oracle import faceoff_oracle as O
+    B, T, H, W = 3, 3, 40, 24
+    sd = make_state_dict(11, codebook_scale=0.3, gain=2.0)
+    img, gt = make_batch(5, B, T, H, W)
+    p = O.to_torch_state(sd)
+    r = O.train_step(torch.from_numpy(img), torch.from_numpy(gt), p)
+    eng = VQVAEEngine(sd, "cuda:0")
+    x = torch.from_numpy(img).reshape(B * T, 6, H, W).cuda()
+    y = torch.from_numpy(gt).reshape(B * T, 3, H, W).cuda()
+    recon, diff, S = eng.loss_and_backward(x, y, T=T)
+    dec = ops.nhwc_to_nchw(S["dec"], 6).cpu()
+    assert _rel(dec.numpy(), r["fw"]["dec"].detach().numpy()) < 1e-3
+    np.testing.assert_allclose(recon.item(), r["recon"].item(), rtol=1e-3)
+    np.testing.assert_allclose(diff.item(), r["latent"].item(), rtol=1e-3)
+    for lvl in "tb":
+        same = (S["id_" + lvl].cpu() == r["fw"]["id_" + lvl]).float().mean().item()
+        assert same > 0.995, (lvl, same)
+    for n, gref in r["grads"].items():
+        got = eng.grads[n].cpu().numpy()
+        rms = gref.pow(2).mean().sqrt().item()
+        assert np.abs(got - gref.numpy()).max() <= 5e-3 * max(rms, gref.abs().max().item()), n
+    for k in eng.buffers:
+        assert _rel(eng.buffers[k].cpu().numpy(), p[k].numpy()) < 2e-3, k
