@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfaceoff_hip.so")
+LIB_PATH = os.environ.get("FACEOFF_HIP_LIB", os.path.join(_HERE, "libfaceoff_hip.so"))   # override: A/B kernel builds
 
 FO_IN_RELU, FO_BIAS, FO_MASK, FO_ADD, FO_OUT_RELU = 1, 2, 4, 8, 16
 
@@ -48,7 +48,9 @@ SIGNATURES = {
     "fo_conv_wgrad": (_I, [_D, _P, _P, _P, _I, _I, _P, _P, _L, _P]),
     "fo_bias_grad": (_I, [_P, _P, _L, _I, _I, _I, _P, _P]),
     "fo_vq_prepare": (_I, [_P, _P, _P, _P]),
-    "fo_vq_assign": (_I, [_P, _I, _L, _P, _P, _P, _P, _I, _P, _P, _P, _I, _P]),
+    "fo_vq_assign": (_I, [_P, _I, _L, _P, _P, _P, _P, _I, _P, _P]),
+    "fo_vq_stats_ws_bytes": (_L, [_L]),
+    "fo_vq_stats": (_I, [_P, _I, _L, _P, _P, _P, _P, _P]),
     "fo_vq_ema": (_I, [_P, _P, _P, _P, _P, _F, _F, _F, _P]),
     "fo_vq_bwd": (_I, [_P, _I, _P, _I, _P, _I, _P, _F, _P, _I, _L, _P]),
     "fo_vq_gather": (_I, [_P, _P, _P, _I, _L, _P]),

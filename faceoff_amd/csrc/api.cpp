@@ -12,6 +12,19 @@ void fo_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+int fo_cu_count() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+      cus = n;
+    else
+      cus = 256;
+  }
+  return cus;
+}
+
 extern "C" {
 int fo_version(void) { return 100; }
 const char* fo_last_error(void) { return g_err; }

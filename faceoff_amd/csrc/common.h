@@ -9,6 +9,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 void fo_set_error(const char* fmt, ...);
+int fo_cu_count();  // compute units of the current device (cached; 256 on MI355X)
 
 #define FO_CHECK_LAUNCH()                                                     \
   do {                                                                        \

@@ -14,9 +14,14 @@
 //    padded to 36 floats: the ds_read_b128 fragment reads and ds_write_b128 stores are
 //    bank-conflict free (36*r mod 64 is distinct over every 16-lane b128 group);
 //  * a lane's float4 holds 4 consecutive k for 4 consecutive MFMAs (the MFMA's two k slots are
-//    the two lane halves), so one ds_read_b128 feeds 4 MFMAs per tile;
+//    the two lane halves), so one ds_read_b128 feeds 4 MFMAs per tile; fragments are double
+//    buffered in registers so each LDS read has a full 16-MFMA group to land under;
 //  * 128 x BN block tile, 4 waves (one per SIMD) x up to 2x2 32x32 accumulators, LDS double
 //    buffered, next K-step prefetched into registers while the current one is on the matrix pipe;
+//  * loads are bounds-checked buffer loads: padding taps use an out-of-range offset and read
+//    zeros -- no branch, no select after the load, so the loads stay in flight under the MFMAs;
+//    per-row tap validity is a bitmask built once per tile, the K-step -> (tap, chunk) walk is
+//    incremental scalar arithmetic (no divisions in the loop);
 //  * temporal taps that fall entirely into clip padding are skipped per tile (T=5: 2/15 of Conv3d);
 //  * blockIdx is remapped so that each XCD's L2 sees a contiguous run of tiles (shared halos).
 #include "common.h"
@@ -38,11 +43,29 @@ struct ConvArgs {
   int cinShift;   // SMALLC: log2(Cin)
   int Ktot;       // taps*Cin  (row length of wp)
   int frameAligned;  // HWm % 128 == 0  -> a tile never straddles frames
+  unsigned inBytes;  // addressable extent behind `in` (buffer descriptor bound)
+  unsigned wpBytes;
 };
 
 constexpr int BM = 128;
 constexpr int BK = 32;
 constexpr int LDS_LD = 36;  // padded row (floats)
+constexpr unsigned OOB = 0x80000000u;
+#ifdef FO_STAMP   // diagnostic build only (tools/): per-step s_memtime of workgroup 0 / wave 0
+__device__ unsigned long long fo_stamps[4096];
+#define FO_STAMP_AT(i)                                                                            \
+  if (blockIdx.x == 0 && threadIdx.x == 0 && (i) < 4096) {                                        \
+    unsigned long long t_;                                                                        \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                    \
+    fo_stamps[(i)] = t_;                                                                          \
+  }
+#else
+#define FO_STAMP_AT(i)
+#endif
+
+__device__ __forceinline__ f32x4 bufload(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+}
 
 template <int BN, int WAVES_M, int WAVES_N, int TM, int TN, bool SMALLC>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
@@ -63,10 +86,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
   const int tile_n = logical % a.tilesN;
   const int tile_m = logical / a.tilesN;
 
+  const int khw = d.KH * d.KW;
+  const int ntaps = d.KD * khw;
+
   // ---- loader coordinates: thread covers rows lrow + 32*i, 16 bytes at column lcol
   const int lrow = tid >> 3;
   const int lcol = (tid & 7) * 4;
-  int pn[4], py[4], px[4], pt[4];
+  int rowoff[4];        // byte offset of (pixel at tap (padD,0,0)... see below) + lcol, may be negative
+  unsigned tapmask[4];  // bit t = tap t reads inside the image for this row
+  int py[4], px[4], pbase[4];
   bool pv[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -77,15 +105,24 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     const int rem = mm - n * a.HWm;
     const int y = rem / d.Wm;
     const int x = rem - y * d.Wm;
-    pn[i] = n;
-    pt[i] = n % d.T;
+    const int t = n % d.T;
     py[i] = y * d.stride - d.padH;
     px[i] = x * d.stride - d.padW;
+    pbase[i] = ((n - d.padD) * d.Hin + py[i]) * d.Win + px[i];   // pixel index of tap (0,0,0)
+    rowoff[i] = (pbase[i] * d.ldIn + lcol) * 4;
+    unsigned mk = 0;
+    if (!SMALLC) {
+      for (int tp = 0; tp < ntaps; ++tp) {
+        const int kd = tp / khw, r = tp - kd * khw, kh = r / d.KW, kw = r - kh * d.KW;
+        const bool ok = pv[i] & ((unsigned)(t + kd - d.padD) < (unsigned)d.T) & ((unsigned)(py[i] + kh) < (unsigned)d.Hin) &
+                        ((unsigned)(px[i] + kw) < (unsigned)d.Win);
+        mk |= (ok ? 1u : 0u) << tp;
+      }
+    }
+    tapmask[i] = mk;
   }
-  const float* wrow = a.wp + (size_t)(tile_n * BN + lrow) * a.Ktot + lcol;
 
   // ---- K range, with fully padded temporal taps skipped
-  const int khw = d.KH * d.KW;
   int kd_lo = 0, kd_hi = d.KD;
   if (d.KD > 1 && a.frameAligned) {
     const int t0 = ((tile_m * BM) / a.HWm) % d.T;
@@ -101,54 +138,57 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     step_end = kd_hi * khw * a.cinChunks;
   }
 
-  f32x4 ra[4], rb[BROWS];
-  const bool in_relu = d.flags & FO_IN_RELU;
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, a.inBytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rwp = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wp), 0, a.wpBytes, 0x00020000);
+  const unsigned wrow = (unsigned)(((size_t)(tile_n * BN + lrow) * a.Ktot + lcol) * 4);
+  const unsigned wstride32 = (unsigned)((size_t)32 * a.Ktot * 4);
 
-  auto load_regs = [&](int step) {
-    int kd, kh, kw, coff;
+  // incremental (tap, chunk) walk of the NEXT step to load (wave-uniform scalars)
+  int ld_step = step_begin;
+  int ld_tap = kd_lo * khw, ld_kh = 0, ld_kw = 0, ld_kd = kd_lo, ld_chunk = 0;
+
+  f32x4 ra[4], rb[BROWS];
+  const float relu_floor = (d.flags & FO_IN_RELU) ? 0.f : -INFINITY;   // fused input ReLU = one v_max per element
+
+  // The next K-step's loads are issued in four parts (one A row + one B row each) so that each part's
+  // address arithmetic sits between two 4-MFMA bursts and runs while the matrix pipe is busy.  Past
+  // the last step the walk yields out-of-range offsets (zeros): no branch on "is there a next step".
+  auto load_part = [&](int s) {
     if (SMALLC) {
-      const int k = step * BK + lcol;
+      const int k = ld_step * BK + lcol;
       const int tap = k >> a.cinShift;
-      coff = k & (d.Cin - 1);
-      kd = 0;
-      kh = tap / d.KW;
-      kw = tap - kh * d.KW;
+      const int coff = k & (d.Cin - 1);
+      const int kh = tap / d.KW;
+      const int kw = tap - kh * d.KW;
+      const bool ok = pv[s] & (tap < ntaps) & ((unsigned)(py[s] + kh) < (unsigned)d.Hin) & ((unsigned)(px[s] + kw) < (unsigned)d.Win);
+      const unsigned off = (unsigned)(((pbase[s] + kh * d.Win + kw) * d.ldIn + coff) * 4);
+      ra[s] = bufload(rin, ok ? off : OOB);
     } else {
-      const int tap = step / a.cinChunks;
-      coff = (step - tap * a.cinChunks) * BK + lcol;
-      kd = tap / khw;
-      const int r = tap - kd * khw;
-      kh = r / d.KW;
-      kw = r - kh * d.KW;
+      const int stepoff = ((((ld_kd * d.Hin) + ld_kh) * d.Win + ld_kw) * d.ldIn + ld_chunk * BK) * 4;
+      // branch-free: a padding tap gets bit 31 set = beyond the descriptor = zeros
+      const unsigned pad = (((tapmask[s] >> ld_tap) & 1u) - 1u) & OOB;
+      ra[s] = bufload(rin, (unsigned)(rowoff[s] + stepoff) | pad);
     }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int it = pt[i] + kd - d.padD;
-      const int iy = py[i] + kh;
-      const int ix = px[i] + kw;
-      const bool ok = pv[i] && (unsigned)it < (unsigned)d.T && (unsigned)iy < (unsigned)d.Hin &&
-                      (unsigned)ix < (unsigned)d.Win;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (ok) {
-        const size_t pix = ((size_t)(pn[i] + kd - d.padD) * d.Hin + iy) * d.Win + ix;
-        v = *reinterpret_cast<const f32x4*>(a.in + pix * d.ldIn + coff);
-        if (in_relu) {
-          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    if (s < BROWS) rb[s < BROWS ? s : 0] = bufload(rwp, wrow + s * wstride32 + ld_step * (BK * 4));
+    if (s == 3) {  // advance the (tap, chunk) walk
+      ++ld_step;
+      if (!SMALLC && ++ld_chunk == a.cinChunks) {
+        ld_chunk = 0;
+        ++ld_tap;
+        if (++ld_kw == d.KW) {
+          ld_kw = 0;
+          if (++ld_kh == d.KH) { ld_kh = 0; ++ld_kd; }
         }
       }
-      ra[i] = v;
     }
-#pragma unroll
-    for (int j = 0; j < BROWS; ++j)
-      rb[j] = *reinterpret_cast<const f32x4*>(wrow + (size_t)(32 * j) * a.Ktot + step * BK);
   };
-  auto store_lds = [&](int buf) {
+  auto store_part = [&](int s, int buf) {
     float* As = As0 + buf * BM * LDS_LD;
     float* Bs = Bs0 + buf * BN * LDS_LD;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(As + (lrow + 32 * i) * LDS_LD + lcol) = ra[i];
-#pragma unroll
-    for (int j = 0; j < BROWS; ++j) *reinterpret_cast<f32x4*>(Bs + (lrow + 32 * j) * LDS_LD + lcol) = rb[j];
+    f32x4 v = ra[s];
+    v.x = fmaxf(v.x, relu_floor); v.y = fmaxf(v.y, relu_floor); v.z = fmaxf(v.z, relu_floor); v.w = fmaxf(v.w, relu_floor);
+    *reinterpret_cast<f32x4*>(As + (lrow + 32 * s) * LDS_LD + lcol) = v;
+    if (s < BROWS) *reinterpret_cast<f32x4*>(Bs + (lrow + 32 * s) * LDS_LD + lcol) = rb[s < BROWS ? s : 0];
   };
 
   f32x16 acc[TM][TN];
@@ -159,33 +199,66 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  if (step_begin < step_end) {
-    load_regs(step_begin);
-    store_lds(0);
-  }
+#pragma unroll
+  for (int s = 0; s < 4; ++s) load_part(s);
+#pragma unroll
+  for (int s = 0; s < 4; ++s) store_part(s, 0);
   __syncthreads();
   int cur = 0;
   for (int step = step_begin; step < step_end; ++step) {
-    const bool more = step + 1 < step_end;
-    if (more) load_regs(step + 1);
+    FO_STAMP_AT(8 * (step - step_begin));
     const float* As = As0 + cur * BM * LDS_LD + (wm * TM * 32 + l31) * LDS_LD + half * 4;
     const float* Bs = Bs0 + cur * BN * LDS_LD + (wn * TN * 32 + l31) * LDS_LD + half * 4;
+    f32x4 fa[2][TM], fb[2][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const f32x4*>(As + i * 32 * LDS_LD);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb[0][j] = *reinterpret_cast<const f32x4*>(Bs + j * 32 * LDS_LD);
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      f32x4 fa[TM], fb[TN];
+      // Scheduling fences pin the software pipeline hipcc would otherwise undo:
+      //  * fragments of k-group kk+1 are requested before group kk's 16 MFMAs (1024 pipe cycles to land);
+      //  * group 0 carries the next step's address arithmetic + buffer loads, 1/4 per 4-MFMA burst;
+      //  * group 3 carries the LDS stores of those loads into the other buffer (landed ~2000 cycles ago).
+      // Only the barrier and the first fragment read of a step are left uncovered.
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4*>(As + i * 32 * LDS_LD + kk * 8);
+      for (int s = 0; s < 4; ++s) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (s == 0 && kk < 3) {
 #pragma unroll
-      for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const f32x4*>(Bs + j * 32 * LDS_LD + kk * 8);
+          for (int i = 0; i < TM; ++i) fa[(kk + 1) & 1][i] = *reinterpret_cast<const f32x4*>(As + i * 32 * LDS_LD + (kk + 1) * 8);
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
+          for (int j = 0; j < TN; ++j) fb[(kk + 1) & 1][j] = *reinterpret_cast<const f32x4*>(Bs + j * 32 * LDS_LD + (kk + 1) * 8);
+        }
+        if (kk == 0) load_part(s);
+        if (kk == 3) store_part(s, cur ^ 1);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk & 1][i][s], fb[kk & 1][j][s], acc[i][j], 0, 0, 0);
+        // Interleave 1 MFMA : a few issue slots of the side work, so the side work issues in the shadow
+        // of an MFMA (64 pipe cycles each) instead of in front of the burst.
+        // masks: 0x8 MFMA, 0x2 VALU, 0x20 VMEM read, 0x100 DS read, 0x200 DS write
+#pragma unroll
+        for (int q = 0; q < TM * TN; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+          if (s == 0 && kk < 3) __builtin_amdgcn_sched_group_barrier(0x100, (TM + TN + TM * TN - 1) / (TM * TN), 0);
+          if (kk == 0) {
+            __builtin_amdgcn_sched_group_barrier(0x2, 4, 0);
+            if (q == TM * TN - 1) __builtin_amdgcn_sched_group_barrier(0x20, 2, 0);
+          }
+          if (kk == 3) {
+            __builtin_amdgcn_sched_group_barrier(0x2, 2, 0);
+            if (q >= TM * TN - 2) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+          }
+        }
+      }
+      FO_STAMP_AT(8 * (step - step_begin) + 1 + kk);
     }
-    if (more) store_lds(cur ^ 1);
+    __builtin_amdgcn_sched_barrier(0);
+    FO_STAMP_AT(8 * (step - step_begin) + 5);
     __syncthreads();
     cur ^= 1;
   }
@@ -235,6 +308,12 @@ int launch(const ConvArgs& a, bool smallc, hipStream_t s) {
 
 }  // namespace
 
+#ifdef FO_STAMP
+extern "C" int fo_debug_read_stamps(unsigned long long* out, int n) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(fo_stamps), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -1;
+}
+#endif
+
 extern "C" int fo_conv_igemm(const fo_conv_desc* d, const float* in, const float* wp, const float* bias,
                              const float* mask, const float* add, float* out, void* stream) {
   ConvArgs a;
@@ -247,6 +326,7 @@ extern "C" int fo_conv_igemm(const fo_conv_desc* d, const float* in, const float
   FO_REQUIRE(!(d->flags & FO_MASK) || mask, FO_E_SHAPE, "conv: FO_MASK without mask");
   FO_REQUIRE(!(d->flags & FO_ADD) || add, FO_E_SHAPE, "conv: FO_ADD without add");
   const int taps = d->KD * d->KH * d->KW;
+  FO_REQUIRE(taps >= 1 && taps <= 31, FO_E_SHAPE, "conv: at most 31 taps (got %d)", taps);
   a.Ktot = taps * d->Cin;
   const bool smallc = d->Cin < 32;
   if (smallc) {
@@ -265,6 +345,12 @@ extern "C" int fo_conv_igemm(const fo_conv_desc* d, const float* in, const float
   a.M = (int)M;
   a.tilesM = (a.M + BM - 1) / BM;
   a.frameAligned = (a.HWm % BM) == 0;
+  const unsigned long long inBytes = (((unsigned long long)d->N * d->Hin * d->Win - 1) * d->ldIn + d->Cin) * 4ull;
+  const int opad = d->Cout > 64 ? (d->Cout + 127) / 128 * 128 : (d->Cout > 32 ? 64 : 32);
+  const unsigned long long wpBytes = (unsigned long long)opad * a.Ktot * 4ull;
+  FO_REQUIRE(inBytes < (1ull << 31) && wpBytes < (1ull << 31), FO_E_SHAPE, "conv: tensor exceeds the 2 GiB buffer-descriptor window");
+  a.inBytes = (unsigned)inBytes;
+  a.wpBytes = (unsigned)wpBytes;
   hipStream_t s = (hipStream_t)stream;
   // BN by output channels (filters are packed with Cout rounded up to the same BN)
   if (d->Cout > 64) {

@@ -32,6 +32,7 @@ struct WgradArgs {
   int Apad, Bpad;
   int biasTap;    // tap whose blocks also produce the bias partial (-1: none)
   int stepFrameAligned;  // HWm % 32 == 0
+  unsigned pBytes, qBytes;  // addressable extents behind P and Q (buffer descriptor bounds)
 };
 
 constexpr int WK = 32;  // pixels per K-step
@@ -72,12 +73,18 @@ __global__ __launch_bounds__(64 * WAVES_A * WAVES_B, 2) void conv_wgrad_kernel(c
 
   const int pcolA = (tid % (TA / 4)) * 4, prowA = tid / (TA / 4);
   const int pcolB = (tid % (TB / 4)) * 4, prowB = tid / (TB / 4);
-  const float* Pbase = a.P + tileA * TA + pcolA;
+  // bounds-checked buffer loads: padded taps / chunk tails read zeros without a branch or a select,
+  // so the loads stay in flight under the MFMAs (see conv_igemm.hip)
+  const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.P), 0, a.pBytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rQ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Q), 0, a.qBytes, 0x00020000);
+  constexpr unsigned OOB = 0x80000000u;
   const bool in_relu = d.flags & FO_IN_RELU;
   const bool do_bias = a.wsBias && tap == a.biasTap && tileB == 0;
 
   f32x4 rp[PA], rq[PB];
   f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+  int qn[PB], qy[PB], qx[PB];
+  int q_step = -1;
 
   auto step_valid = [&](int s) -> bool {
     if (d.KD == 1 || !a.stepFrameAligned) return true;
@@ -91,33 +98,44 @@ __global__ __launch_bounds__(64 * WAVES_A * WAVES_B, 2) void conv_wgrad_kernel(c
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
       const int m = m0 + prowA + RPA * i;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (m < m_end) v = *reinterpret_cast<const f32x4*>(Pbase + (size_t)m * d.ldOut);
-      rp[i] = v;
+      const unsigned off = m < m_end ? ((unsigned)m * (unsigned)d.ldOut + (unsigned)(tileA * TA + pcolA)) * 4u : OOB;
+      rp[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rP, off, 0, 0));
     }
+    // (frame, y, x) of this thread's Q rows: walked incrementally, one 32-pixel step at a time; a full
+    // decode (two integer divisions per row) only after a jump over skipped steps
+    if (q_step >= 0 && s == q_step + 1) {
 #pragma unroll
-    for (int i = 0; i < PB; ++i) {
-      const int m = m0 + prowB + RPB * i;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (m < m_end) {
-        const int n = m / a.HWm;
-        const int rem = m - n * a.HWm;
-        const int y = rem / d.Wm;
-        const int x = rem - y * d.Wm;
-        int kwt = kw, coff = tileB * TB + pcolB;
-        if (SMALLC) { kwt = pcolB >> 3; coff = pcolB & 7; }
-        const int it = (n % d.T) + kd - d.padD;
-        const int iy = y * d.stride - d.padH + kh;
-        const int ix = x * d.stride - d.padW + kwt;
-        if ((unsigned)it < (unsigned)d.T && (unsigned)iy < (unsigned)d.Hin && (unsigned)ix < (unsigned)d.Win) {
-          const size_t pix = ((size_t)(n + kd - d.padD) * d.Hin + iy) * d.Win + ix;
-          v = *reinterpret_cast<const f32x4*>(a.Q + pix * d.ldIn + coff);
-          if (in_relu) {
-            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-          }
+      for (int i = 0; i < PB; ++i) {
+        qx[i] += WK;
+        while (qx[i] >= d.Wm) {
+          qx[i] -= d.Wm;
+          if (++qy[i] == d.Hm) { qy[i] = 0; ++qn[i]; }
         }
       }
-      rq[i] = v;
+    } else {
+#pragma unroll
+      for (int i = 0; i < PB; ++i) {
+        const int m = m0 + prowB + RPB * i;
+        qn[i] = m / a.HWm;
+        const int rem = m - qn[i] * a.HWm;
+        qy[i] = rem / d.Wm;
+        qx[i] = rem - qy[i] * d.Wm;
+      }
+    }
+    q_step = s;
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+      const int n = qn[i], y = qy[i], x = qx[i];
+      int kwt = kw, coff = tileB * TB + pcolB;
+      if (SMALLC) { kwt = pcolB >> 3; coff = pcolB & 7; }
+      const int it = (n % d.T) + kd - d.padD;
+      const int iy = y * d.stride - d.padH + kh;
+      const int ix = x * d.stride - d.padW + kwt;
+      const bool ok = (m0 + prowB + RPB * i < m_end) & ((unsigned)it < (unsigned)d.T) & ((unsigned)iy < (unsigned)d.Hin) &
+                      ((unsigned)ix < (unsigned)d.Win);
+      const unsigned pix = (unsigned)(((n + kd - d.padD) * d.Hin + iy) * d.Win + ix);
+      const unsigned off = ok ? (pix * (unsigned)d.ldIn + (unsigned)coff) * 4u : OOB;
+      rq[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rQ, off, 0, 0));
     }
   };
   auto store_lds = [&](int buf) {
@@ -129,7 +147,11 @@ __global__ __launch_bounds__(64 * WAVES_A * WAVES_B, 2) void conv_wgrad_kernel(c
       if (do_bias) bsum += rp[i];
     }
 #pragma unroll
-    for (int i = 0; i < PB; ++i) *reinterpret_cast<f32x4*>(Qs + (prowB + RPB * i) * TB + pcolB) = rq[i];
+    for (int i = 0; i < PB; ++i) {
+      f32x4 v = rq[i];
+      if (in_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      *reinterpret_cast<f32x4*>(Qs + (prowB + RPB * i) * TB + pcolB) = v;
+    }
   };
 
   f32x16 acc[TMA][TNB];
@@ -146,22 +168,41 @@ __global__ __launch_bounds__(64 * WAVES_A * WAVES_B, 2) void conv_wgrad_kernel(c
   int cur = 0;
   while (s < nsteps) {
     const int s2 = next_valid(s + 1);
-    if (s2 < nsteps) load_regs(s2);
     const float* Ps = Ps0 + cur * WK * TA + half * TA + wa * TMA * 32 + l31;
     const float* Qs = Qs0 + cur * WK * TB + half * TB + wb * TNB * 32 + l31;
+    // 4 groups of 4 k-pairs; fragments of group g+1 are requested before group g's MFMAs, the next
+    // step's global loads go out behind group 0 (fences keep hipcc from undoing the pipeline)
+    float fa[2][4][TMA], fb[2][4][TNB];
 #pragma unroll
-    for (int kp = 0; kp < WK / 2; ++kp) {
-      float fa[TMA], fb[TNB];
+    for (int q = 0; q < 4; ++q) {
 #pragma unroll
-      for (int i = 0; i < TMA; ++i) fa[i] = Ps[kp * 2 * TA + i * 32];
+      for (int i = 0; i < TMA; ++i) fa[0][q][i] = Ps[q * 2 * TA + i * 32];
 #pragma unroll
-      for (int j = 0; j < TNB; ++j) fb[j] = Qs[kp * 2 * TB + j * 32];
-#pragma unroll
-      for (int i = 0; i < TMA; ++i)
-#pragma unroll
-        for (int j = 0; j < TNB; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < TNB; ++j) fb[0][q][j] = Qs[q * 2 * TB + j * 32];
     }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (g < 3) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+          for (int i = 0; i < TMA; ++i) fa[(g + 1) & 1][q][i] = Ps[((g + 1) * 4 + q) * 2 * TA + i * 32];
+#pragma unroll
+          for (int j = 0; j < TNB; ++j) fb[(g + 1) & 1][q][j] = Qs[((g + 1) * 4 + q) * 2 * TB + j * 32];
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < TMA; ++i)
+#pragma unroll
+          for (int j = 0; j < TNB; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g & 1][q][i], fb[g & 1][q][j], acc[i][j], 0, 0, 0);
+      if (g == 0 && s2 < nsteps) load_regs(s2);
+    }
+    __builtin_amdgcn_sched_barrier(0);
     if (s2 < nsteps) store_lds(cur ^ 1);
     __syncthreads();
     cur ^= 1;
@@ -242,12 +283,16 @@ int make_plan(const fo_conv_desc* d, Plan* p) {
   p->Apad = p->TA * p->tilesA; p->Bpad = p->TB * p->tilesB;
   const long long M = (long long)d->N * d->Hm * d->Wm;
   FO_REQUIRE(M > 0 && M < (1ll << 31), FO_E_SHAPE, "wgrad: M out of range");
-  // chunking: aim for ~1024 workgroups (4 per CU), >= 16 K-steps each, chunks a multiple of 32 pixels
+  // chunking: the grid must fill the chip's resident workgroup slots a whole number of times -- these
+  // workgroups are long (hundreds of K-steps), so 2052 of them on 512 slots would run 5 rounds where
+  // 4.008 are needed.  Size the grid to just under two full rounds.
   const long long perChunkBlocks = (long long)p->taps * p->tilesA * p->tilesB;
-  long long want = (1024 + perChunkBlocks - 1) / perChunkBlocks;
-  if (want < 1) want = 1;
+  const long long ldsBytes = 2ll * WK * (p->TA + p->TB) * 4;
+  const long long perCU = std::max(1ll, std::min(4ll, (160ll * 1024) / ldsBytes));
+  const long long slots = (long long)fo_cu_count() * perCU;
+  long long want = std::max(1ll, (2 * slots) / perChunkBlocks);
+  want = std::min(want, std::max(1ll, M / 512));   // >= 16 K-steps per workgroup
   long long chunk = (M + want - 1) / want;
-  if (chunk < 512) chunk = 512;
   chunk = (chunk + 31) / 32 * 32;
   p->chunk = (int)chunk;
   p->nchunks = (int)((M + chunk - 1) / chunk);
@@ -284,6 +329,11 @@ extern "C" int fo_conv_wgrad(const fo_conv_desc* d, const float* P, const float*
   a.wsBias = dbias ? ws + ((slab + 63) / 64) * 64 : nullptr;
   a.biasTap = p.smallc ? 0 : d->padD * d->KH * d->KW;
   a.stepFrameAligned = (a.HWm % WK) == 0 && (p.chunk % WK) == 0;
+  const unsigned long long pBytes = (((unsigned long long)a.M - 1) * d->ldOut + d->Cout) * 4ull;
+  const unsigned long long qBytes = (((unsigned long long)d->N * d->Hin * d->Win - 1) * d->ldIn + d->Cin) * 4ull;
+  FO_REQUIRE(pBytes < (1ull << 31) && qBytes < (1ull << 31), FO_E_SHAPE, "wgrad: tensor exceeds the 2 GiB buffer-descriptor window");
+  a.pBytes = (unsigned)pBytes;
+  a.qBytes = (unsigned)qBytes;
   hipStream_t s = (hipStream_t)stream;
   const int grid = p.nchunks * p.taps * p.tilesA * p.tilesB;
   if (p.smallc) WG_LAUNCH(64, 32, 2, 1, 1, 1, true);

@@ -3,8 +3,8 @@
 // fo_vq_assign fuses what the reference does with two sgemms, two materialised [Nvec,512]
 // matrices (dist :49-53, one_hot :55) and ~10 elementwise kernels:
 //   distance (expanded form, exact-fp32 MFMA)  ->  running first-index arg-min  ->  codebook
-//   gather + straight-through value (:57,78)   ->  commitment sum (:77)  ->  EMA statistics
-//   (:60-61) -- `dist` and the one-hot never exist in memory.
+//   gather + straight-through value (:57,78)   ->  commitment sum (:77);  fo_vq_stats produces the
+//   EMA statistics (:60-61) from LDS-privatised tables -- `dist` and the one-hot never exist in memory.
 //
 // Numerics contract (restated bit-for-bit by oracle/vq_oracle.c):
 //   dot(x,e)  = fp32 fma chain over k = 0..63 in order, starting from 0 (what the MFMA computes)
@@ -39,8 +39,7 @@ __global__ void vq_prepare_kernel(const float* __restrict__ embed, float* __rest
 __global__ __launch_bounds__(256, 1) void vq_assign_kernel(const float* __restrict__ x, int ldx, long long nvec,
                                                            const float* __restrict__ embedT,
                                                            const float* __restrict__ enorm, long long* __restrict__ ind,
-                                                           float* __restrict__ qout, int ldq, float* sq_sum,
-                                                           float* counts, float* esum, int train) {
+                                                           float* __restrict__ qout, int ldq, float* sq_sum) {
   __shared__ float E[VQ_K * VQ_LD + VQ_K];
   float* En = E + VQ_K * VQ_LD;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
@@ -83,19 +82,25 @@ __global__ __launch_bounds__(256, 1) void vq_assign_kernel(const float* __restri
     if (od < best_d || (od == best_d && oi < best_i)) { best_d = od; best_i = oi; }
     if (half == 0 && valid) ind[v] = best_i;
 
-    // gather + straight-through + statistics: the wave walks its 32 vectors, 64 lanes = 64 dims
+    // gather + straight-through: the wave walks its 32 vectors, 64 lanes = 64 dims; the x rows are
+    // fetched 8 at a time so the (L2-resident) loads overlap instead of serialising on latency
     const int nhere = (int)min<long long>(32, nvec - tile * 32);
-    for (int j = 0; j < nhere; ++j) {
-      const int idx = __shfl(best_i, j);
-      const size_t vj = (size_t)(tile * 32 + j);
-      const float xv = x[vj * ldx + lane];
-      const float q = E[idx * VQ_LD + lane];
-      const float diff = q - xv;
-      qout[vj * ldq + lane] = xv + diff;  // input + (quantize - input).detach()   (:78)
-      sq = fmaf(diff, diff, sq);
-      if (train) {
-        atomicAdd(&esum[(size_t)idx * VQ_D + lane], xv);  // 256 contiguous bytes per wave-instruction
-        if (lane == 0) atomicAdd(&counts[idx], 1.f);
+    for (int j0 = 0; j0 < nhere; j0 += 8) {
+      float xv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const size_t vj = (size_t)(tile * 32 + min(j0 + u, nhere - 1));
+        xv[u] = x[vj * ldx + lane];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (j0 + u < nhere) {
+          const int idx = __shfl(best_i, j0 + u);
+          const size_t vj = (size_t)(tile * 32 + j0 + u);
+          const float diff = E[idx * VQ_LD + lane] - xv[u];
+          qout[vj * ldq + lane] = xv[u] + diff;  // input + (quantize - input).detach()   (:78)
+          sq = fmaf(diff, diff, sq);
+        }
       }
     }
   }
@@ -104,6 +109,53 @@ __global__ __launch_bounds__(256, 1) void vq_assign_kernel(const float* __restri
   for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
   if (lane == 0) atomicAdd(sq_sum, sq);
 }
+
+// EMA statistics (:60-61): counts[c] = #vectors assigned to c, esum[c][:] = sum of those vectors.
+// The reference builds a [Nvec,512] one-hot and runs a second sgemm; here each workgroup keeps a
+// private [512][64] table in LDS (ds_add_f32: a wave adds one vector's 64 dims to 64 consecutive
+// banks, so hot codes cost nothing extra), writes it as a slab, and a second kernel sums the slabs
+// in a fixed order.  No global atomics: a degenerate codebook (all vectors on one code) is as fast
+// as a uniform one.
+__global__ __launch_bounds__(1024, 1) void vq_stats_kernel(const float* __restrict__ x, int ldx, long long nvec,
+                                                           const long long* __restrict__ ind, float* __restrict__ ws) {
+  __shared__ float tab[VQ_K * VQ_D + VQ_K];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < VQ_K * VQ_D + VQ_K; i += 1024) tab[i] = 0.f;
+  __syncthreads();
+  const long long per = (nvec + gridDim.x - 1) / gridDim.x;
+  const long long v0 = blockIdx.x * per, v1 = min(nvec, v0 + per);
+  for (long long v = v0 + wave * 4; v < v1; v += 16 * 4) {
+    float xv[4];
+    int id[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long long vv = min(v + u, v1 - 1);
+      xv[u] = x[(size_t)vv * ldx + lane];
+      id[u] = (int)ind[vv];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (v + u < v1) {
+        atomicAdd(&tab[id[u] * VQ_D + lane], xv[u]);
+        if (lane == 0) atomicAdd(&tab[VQ_K * VQ_D + id[u]], 1.f);
+      }
+  }
+  __syncthreads();
+  float* slab = ws + (size_t)blockIdx.x * (VQ_K * VQ_D + VQ_K);
+  for (int i = tid; i < VQ_K * VQ_D + VQ_K; i += 1024) slab[i] = tab[i];
+}
+
+__global__ void vq_stats_reduce_kernel(const float* __restrict__ ws, int nblk, float* __restrict__ counts,
+                                       float* __restrict__ esum) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= VQ_K * VQ_D + VQ_K) return;
+  float s = 0.f;
+  for (int b = 0; b < nblk; ++b) s += ws[(size_t)b * (VQ_K * VQ_D + VQ_K) + e];
+  if (e < VQ_K * VQ_D) esum[e] = s;
+  else counts[e - VQ_K * VQ_D] = s;
+}
+
+inline int stats_blocks(int64_t nvec) { return (int)std::max<int64_t>(1, std::min<int64_t>(128, nvec / 512)); }
 
 // EMA update (:66-75).  One workgroup, one thread per code.
 __global__ __launch_bounds__(VQ_K) void vq_ema_kernel(float* embed, float* cluster_size, float* embed_avg,
@@ -165,7 +217,7 @@ int fo_vq_prepare(const float* embed, float* embedT, float* enorm, void* stream)
 }
 
 int fo_vq_assign(const float* x, int ldx, int64_t nvec, const float* embedT, const float* enorm, int64_t* ind,
-                 float* q_ste, int ldq, float* sq_sum, float* counts, float* esum, int train, void* stream) {
+                 float* q_ste, int ldq, float* sq_sum, void* stream) {
   FO_REQUIRE(nvec > 0 && ldx >= VQ_D && ldq >= VQ_D, FO_E_SHAPE, "vq_assign: bad shape");
   int dev = 0, cus = 256;
   hipGetDevice(&dev);
@@ -173,7 +225,22 @@ int fo_vq_assign(const float* x, int ldx, int64_t nvec, const float* embedT, con
   const int64_t ntiles = (nvec + 31) / 32;
   const int grid = (int)std::min<int64_t>(cus, (ntiles + 3) / 4);
   hipLaunchKernelGGL(vq_assign_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, (long long)nvec, embedT, enorm,
-                     (long long*)ind, q_ste, ldq, sq_sum, counts, esum, train);
+                     (long long*)ind, q_ste, ldq, sq_sum);
+  FO_CHECK_LAUNCH();
+  return FO_OK;
+}
+
+int64_t fo_vq_stats_ws_bytes(int64_t nvec) { return (int64_t)stats_blocks(nvec) * (VQ_K * VQ_D + VQ_K) * 4; }
+
+int fo_vq_stats(const float* x, int ldx, int64_t nvec, const int64_t* ind, float* counts, float* esum, float* ws,
+                void* stream) {
+  FO_REQUIRE(nvec > 0 && ldx >= VQ_D, FO_E_SHAPE, "vq_stats: bad shape");
+  const int nblk = stats_blocks(nvec);
+  hipLaunchKernelGGL(vq_stats_kernel, dim3(nblk), dim3(1024), 0, (hipStream_t)stream, x, ldx, (long long)nvec,
+                     (const long long*)ind, ws);
+  FO_CHECK_LAUNCH();
+  hipLaunchKernelGGL(vq_stats_reduce_kernel, dim3((VQ_K * VQ_D + VQ_K + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws,
+                     nblk, counts, esum);
   FO_CHECK_LAUNCH();
   return FO_OK;
 }

@@ -18,9 +18,10 @@ class KernelProfiler:
     """Live per-launch timing with HIP events on the launch stream (bench.py's roofline leg).
     Groups launches by kernel instance name; `flops` is the ALGORITHMIC work of the launch."""
 
-    def __init__(self):
+    def __init__(self, detail=False):
         self.records = {}     # name -> list of (start_event, end_event, flops)
         self._cur = None
+        self.detail = detail  # key launches by geometry as well (tools/, not bench.py's JSON line)
 
     def begin(self, name, flops):
         s = torch.cuda.Event(enable_timing=True)
@@ -141,6 +142,8 @@ def conv_igemm(x, wp, bias, out, *, T=1, k=(1, 3, 3), stride=1, pad=(0, 1, 1), c
     if prof is not None:
         kname = "conv_igemm_bn%d%s" % (128 if d.Cout > 64 else (64 if d.Cout > 32 else 32), "_smallc" if d.Cin < 32 else "")
         flops = 2.0 * N * Hm * Wm * d.Cout * (k[0] * k[1] * k[2] * d.Cin)
+        if prof.detail:
+            kname += f" [{N}x{Hm}x{Wm} {d.Cin}->{d.Cout} k{k[0]}{k[1]}{k[2]} s{stride} f{flags}]"
         prof.begin(kname, flops)
     _lib.call("fo_conv_igemm", C.byref(d), _ptr(x), _ptr(wp), _ptr(bias), _ptr(mask), _ptr(add), _ptr(out), _stream())
     if prof is not None:
@@ -184,7 +187,10 @@ def conv_wgrad(P, Q, dw, dbias, *, T=1, k=(1, 3, 3), stride=1, pad=(0, 1, 1), a_
     ws = _workspace(nbytes, P.device)
     prof = PROFILER
     if prof is not None:
-        prof.begin("conv_wgrad_%dx%d" % (Ca, Cb), 2.0 * N * Hm * Wm * Ca * Cb * k[0] * k[1] * k[2])
+        wname = "conv_wgrad_%dx%d" % (Ca, Cb)
+        if prof.detail:
+            wname += f" [{N}x{Hm}x{Wm} k{k[0]}{k[1]}{k[2]} s{stride}]"
+        prof.begin(wname, 2.0 * N * Hm * Wm * Ca * Cb * k[0] * k[1] * k[2])
     _lib.call("fo_conv_wgrad", C.byref(d), _ptr(P), _ptr(Q), _ptr(dw), a_real, b_real, _ptr(dbias), _ptr(ws),
               C.c_int64(ws.numel() * 4), _stream())
     if prof is not None:
@@ -224,11 +230,17 @@ def vq_prepare(embed):
 
 
 def vq_assign(x, embedT, enorm, q_out, stats, train):
-    """x, q_out: [..., 64] views; stats: float32[1 + 512 + 512*64] = (sq_sum, counts, esum) zeroed by caller."""
+    """x, q_out: [..., 64] views; stats: float32[1 + 512 + 512*64] = (sq_sum, counts, esum[512][64]); stats[0]
+    must be zero on entry.  With train=True the EMA statistics (counts, esum) are written as well."""
     nvec = x.numel() // 64 if x.is_contiguous() else x.shape[0] * x.shape[1] * x.shape[2]
     ind = torch.empty(x.shape[:-1], device=x.device, dtype=torch.int64)
     _lib.call("fo_vq_assign", _ptr(x), ld_of(x), C.c_int64(nvec), _ptr(embedT), _ptr(enorm), _ptr(ind), _ptr(q_out),
-              ld_of(q_out), _ptr(stats[0:1]), _ptr(stats[1:513]), _ptr(stats[513:]), int(train), _stream())
+              ld_of(q_out), _ptr(stats[0:1]), _stream())
+    if train:
+        nbytes = _lib.load().fo_vq_stats_ws_bytes(C.c_int64(nvec))
+        ws = _workspace(nbytes, x.device)
+        _lib.call("fo_vq_stats", _ptr(x), ld_of(x), C.c_int64(nvec), _ptr(ind), _ptr(stats[1:513]), _ptr(stats[513:]),
+                  _ptr(ws), _stream())
     return ind
 
 

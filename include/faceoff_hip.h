@@ -107,14 +107,19 @@ int fo_conv_wgrad(const fo_conv_desc* d, const float* P, const float* Q, float* 
 int fo_bias_grad(const float* g, float* dbias, int64_t M, int C, int Creal, int ld, float* ws, void* stream);
 
 /* ---------------------------------------------------------------- vector quantiser (Quantize.forward :47-80) */
-/* x[Nvec][ldx] (dim 64) vs embed[64][512].  Writes: ind (int64, :54), q_ste = x + (embed[:,ind] - x)
- * (:57,78), and accumulates sum((q-x)^2) into *sq_sum (:77), counts[512] and esum[512][64] (:60-61,
- * code-major) with float atomics -- zero them first (fo_zero).  Distances use the reference's
- * expanded form ||x||^2 - 2 x.e + ||e||^2 in fp32 with k-ordered fma chains and first-index
- * arg-min (torch.max tie-break), see oracle/vq_oracle.c.  `enorm`[512] from fo_vq_prepare. */
+/* x[Nvec][ldx] (dim 64) vs embed[64][512].  Writes ind (int64, :54) and q_ste = x + (embed[:,ind] - x)
+ * (:57,78); accumulates sum((q-x)^2) into *sq_sum (:77; zero it first).  Distances use the reference's
+ * expanded form ||x||^2 - 2 x.e + ||e||^2 in fp32 with k-ordered fma chains and first-index arg-min
+ * (torch.max tie-break): restated bit-for-bit by oracle/vq_oracle.c.  `enorm`[512] from fo_vq_prepare. */
 int fo_vq_prepare(const float* embed, float* embedT, float* enorm, void* stream); /* [64][512] -> [512][64], ||e||^2 */
 int fo_vq_assign(const float* x, int ldx, int64_t nvec, const float* embedT, const float* enorm, int64_t* ind,
-                 float* q_ste, int ldq, float* sq_sum, float* counts, float* esum, int train, void* stream);
+                 float* q_ste, int ldq, float* sq_sum, void* stream);
+/* EMA statistics of the assignment (:60-61, replaces F.one_hot + the second sgemm): counts[512] and
+ * esum[512][64] (code-major) are OVERWRITTEN.  ws: fo_vq_stats_ws_bytes(nvec).  No global atomics;
+ * within-workgroup LDS float adds make the last bits run-dependent. */
+int64_t fo_vq_stats_ws_bytes(int64_t nvec);
+int fo_vq_stats(const float* x, int ldx, int64_t nvec, const int64_t* ind, float* counts, float* esum, float* ws,
+                void* stream);
 /* EMA codebook update (:66-75) after the statistics all-reduce: in-place on the three buffers. */
 int fo_vq_ema(float* embed, float* cluster_size, float* embed_avg, const float* counts, const float* esum,
               float decay, float alpha /* = 1 - decay as the reference rounds it */, float eps, void* stream);

@@ -1,0 +1,29 @@
+#!/bin/bash
+# Collect rocprofv3 evidence for bench.py on the GPU box.  Usage (from the repo root, via gpurun):
+#   bash profiles/collect.sh r01 [trace|pmc|all]
+# Writes raw CSVs under gpurun_out/prof_<tag>/ and summaries under gpurun_out/profiles_<tag>/ ;
+# copy the summaries you want judged into profiles/ (tracked).
+# Counters are collected in their own passes (never with --sys-trace etc.); FETCH_SIZE and
+# WRITE_SIZE need separate passes (TCC slot budget, MI355X_MICROARCH.md "rocprofv3 PMC slots").
+set -u
+TAG=${1:-r01}
+WHAT=${2:-all}
+OUT=gpurun_out/prof_$TAG
+SUM=gpurun_out/profiles_$TAG
+mkdir -p "$OUT" "$SUM"
+export TMPDIR=/tmp
+BENCH="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events"
+
+if [ "$WHAT" = "trace" ] || [ "$WHAT" = "all" ]; then
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace -- $BENCH > "$OUT/trace.log" 2>&1
+fi
+if [ "$WHAT" = "pmc" ] || [ "$WHAT" = "all" ]; then
+  rocprofv3 --kernel-trace --output-format csv -d "$OUT/pmc_sq" -o pmc \
+    --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE \
+    -- $BENCH > "$OUT/pmc_sq.log" 2>&1
+  rocprofv3 --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -o pmc --pmc FETCH_SIZE -- $BENCH > "$OUT/pmc_fetch.log" 2>&1
+  rocprofv3 --kernel-trace --output-format csv -d "$OUT/pmc_write" -o pmc --pmc WRITE_SIZE -- $BENCH > "$OUT/pmc_write.log" 2>&1
+  rocprofv3 --kernel-trace --output-format csv -d "$OUT/pmc_l2" -o pmc --pmc TCC_HIT_sum TCC_MISS_sum -- $BENCH > "$OUT/pmc_l2.log" 2>&1
+fi
+python3 profiles/summarize.py "$OUT" "$SUM" "$TAG"
+ls -la "$SUM"

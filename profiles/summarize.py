@@ -1,0 +1,126 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 CSV output (profiles/collect.sh) into small, committable files.
+
+  python3 profiles/summarize.py <raw_dir> <out_dir> <tag>
+
+Outputs: <tag>_kernel_stats.md (per-kernel time table from --kernel-trace --stats),
+<tag>_pmc.md (per-kernel counters: MFMA busy share, effective clock, HBM bytes with the gfx950
+FETCH_SIZE x2 correction for 16-B/lane streams, L2 hit rate) and pmc_traffic.json (bench.py kernel
+label -> HBM bytes per launch, read back by bench.py's roofline.traffic).
+"""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+from collections import defaultdict
+
+CUS, SIMDS = 256, 4
+
+
+def short(name):
+    name = re.sub(r"\(anonymous namespace\)::", "", name)
+    name = re.sub(r"^void ", "", name)
+    name = re.sub(r"\(.*\)$", "", name)
+    return name.strip()
+
+
+def label(name):
+    """bench.py's kernel label for a rocprof kernel name (None if not one of the conv kernels)."""
+    m = re.search(r"conv_igemm_kernel<(\d+), *\d+, *\d+, *\d+, *\d+, *(true|false|\(bool\)[01]|[01])>", name)
+    if m:
+        small = m.group(2) in ("true", "(bool)1", "1")
+        return f"conv_igemm_bn{m.group(1)}" + ("_smallc" if small else "")
+    m = re.search(r"conv_wgrad_kernel<(\d+), *(\d+)", name)
+    if m:
+        return f"conv_wgrad_tile{m.group(1)}x{m.group(2)}"
+    return None
+
+
+def find(raw, sub, pattern):
+    return sorted(glob.glob(os.path.join(raw, sub, "**", pattern), recursive=True))
+
+
+def read_counters(raw, sub):
+    """kernel -> counter -> list of per-dispatch values ; kernel -> list of durations (ns)"""
+    vals = defaultdict(lambda: defaultdict(list))
+    durs = defaultdict(dict)
+    for f in find(raw, sub, "*counter_collection.csv"):
+        with open(f, newline="") as fh:
+            for r in csv.DictReader(fh):
+                k = short(r.get("Kernel_Name", ""))
+                vals[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                try:
+                    durs[k][r["Dispatch_Id"]] = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+                except (KeyError, ValueError):
+                    pass
+    return vals, durs
+
+
+def main():
+    raw, out, tag = sys.argv[1], sys.argv[2], sys.argv[3]
+    os.makedirs(out, exist_ok=True)
+    # ---- kernel stats
+    stats = []
+    for f in find(raw, "trace", "*kernel_stats.csv"):
+        with open(f, newline="") as fh:
+            for r in csv.DictReader(fh):
+                stats.append(r)
+    trace_avg = {}
+    if stats:
+        tot = sum(float(r["TotalDurationNs"]) for r in stats) or 1.0
+        stats.sort(key=lambda r: -float(r["TotalDurationNs"]))
+        with open(os.path.join(out, f"{tag}_kernel_stats.md"), "w") as fh:
+            fh.write(f"# rocprofv3 --kernel-trace --stats: bench.py --steps 2 --warmup 1 (3 steps traced), tag {tag}\n\n")
+            fh.write("| kernel | calls | total ms | avg us | min us | max us | % of GPU time |\n|---|---|---|---|---|---|---|\n")
+            for r in stats[:40]:
+                n = short(r["Name"])
+                trace_avg[n] = float(r["AverageNs"])
+                fh.write(f"| `{n}` | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.3f} | {float(r['AverageNs'])/1e3:.1f} | "
+                         f"{float(r['MinNs'])/1e3:.1f} | {float(r['MaxNs'])/1e3:.1f} | {100*float(r['TotalDurationNs'])/tot:.2f} |\n")
+            fh.write(f"\nTotal GPU kernel time: {tot/1e6:.2f} ms over the traced run.\n")
+    # ---- counters
+    sq, sq_d = read_counters(raw, "pmc_sq")
+    fe, fe_d = read_counters(raw, "pmc_fetch")
+    wr, _ = read_counters(raw, "pmc_write")
+    l2, _ = read_counters(raw, "pmc_l2")
+    kernels = sorted(set(sq) | set(fe) | set(wr) | set(l2), key=lambda k: -sum(sq_d.get(k, {}).values()))
+    traffic = {}
+    if kernels:
+        with open(os.path.join(out, f"{tag}_pmc.md"), "w") as fh:
+            fh.write(f"# rocprofv3 --pmc passes (separate runs), per-dispatch averages, tag {tag}\n\n")
+            fh.write("MFMA busy share = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 4 SIMD * 256 CU); effective clock = "
+                     "GRBM_GUI_ACTIVE / 8 / duration.  HBM read = 2 x FETCH_SIZE KB (gfx950 counts 128-B requests of wide "
+                     "streams as 64 B; MI355X_MICROARCH.md, HBM), HBM write = WRITE_SIZE KB.\n\n")
+            fh.write("| kernel | dispatches | avg ms (profiled) | MFMA busy share | eff. clock GHz | wave cycles waiting (WAIT_ANY/WAVE_CYCLES) | "
+                     "LDS bank-conflict cycles / wave cycles | HBM read MB/launch | HBM write MB/launch | L2 hit rate |\n|" + "---|" * 10 + "\n")
+            for k in kernels[:30]:
+                def avg(src, c):
+                    v = src.get(k, {}).get(c)
+                    return sum(v) / len(v) if v else None
+                dl = list(sq_d.get(k, {}).values()) or list(fe_d.get(k, {}).values())
+                dur = sum(dl) / len(dl) if dl else None
+                mf, gui = avg(sq, "SQ_VALU_MFMA_BUSY_CYCLES"), avg(sq, "GRBM_GUI_ACTIVE")
+                wc, wa, ldsb = avg(sq, "SQ_WAVE_CYCLES"), avg(sq, "SQ_WAIT_ANY"), avg(sq, "SQ_LDS_BANK_CONFLICT")
+                f_, w_ = avg(fe, "FETCH_SIZE"), avg(wr, "WRITE_SIZE")
+                hit, miss = avg(l2, "TCC_HIT_sum"), avg(l2, "TCC_MISS_sum")
+                share = mf / (gui / 8 * SIMDS * CUS) if mf and gui else None
+                clk = gui / 8 / dur if gui and dur else None
+                rd = 2 * f_ * 1024 if f_ is not None else None
+                wrb = w_ * 1024 if w_ is not None else None
+                lab = label(k)
+                if lab and rd is not None:
+                    traffic[lab] = int(rd + (wrb or 0))
+                fmt = lambda v, s="{:.3f}": s.format(v) if v is not None else "-"
+                fh.write(f"| `{k}` | {len(dl)} | {fmt(dur/1e6 if dur else None)} | {fmt(share)} | {fmt(clk)} | "
+                         f"{fmt(wa/wc if wa and wc else None)} | {fmt(ldsb/wc if ldsb is not None and wc else None, '{:.4f}')} | "
+                         f"{fmt(rd/1e6 if rd is not None else None, '{:.1f}')} | {fmt(wrb/1e6 if wrb is not None else None, '{:.1f}')} | "
+                         f"{fmt(hit/(hit+miss) if hit is not None and miss is not None and hit+miss > 0 else None)} |\n")
+        with open(os.path.join(out, "pmc_traffic.json"), "w") as fh:
+            json.dump(traffic, fh, indent=1)
+    print("summaries written to", out)
+
+
+if __name__ == "__main__":
+    main()

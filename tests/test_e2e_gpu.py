@@ -77,7 +77,7 @@ def _check_against_golden(g, eng, recon, diff, S, literal=False, grad_rtol=1e-3)
         off += k
     for n in names:
         if "grad_full." + n in g.files:
-            assert _rel(eng.grads[n].cpu().numpy(), g["grad_full." + n]) < 1e-3, n
+            assert _rel(eng.grads[n].cpu().numpy(), g["grad_full." + n]) < (1e-3 if flips == 0 else 0.1), n
     for k, b in eng.buffers.items():
         np.testing.assert_allclose(_stats(b)[1], g["buf_stats." + k][1], rtol=2e-3)
 
