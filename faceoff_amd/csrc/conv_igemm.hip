@@ -263,34 +263,56 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     cur ^= 1;
   }
 
-  // ---- epilogue: lane holds column (co) l31 of each 32x32 tile, rows (r&3)+8*(r>>2)+4*half
-  const int flags = d.flags;
+  // ---- epilogue.  An MFMA accumulator holds one output column per lane, so storing it directly means
+  // 4-byte stores in 128-B pieces (and as many scalar loads for the mask / residual operands).  The tile
+  // is transposed through LDS instead (the staging buffers are free now): every thread then owns float4
+  // runs of an output row, and bias / ReLU-mask / residual / stores are all 16 B per lane, whole rows
+  // per wave.  This is what the short-K launches (1x1 convs, dgrads of the 32-channel layers) live on.
+  constexpr int C_LD = BN + 4;
+  static_assert(BM * C_LD <= 2 * (BM + BN) * LDS_LD, "C tile must fit the staging LDS");
+  float* Cs = lds;
+  __syncthreads();   // every wave is done reading the last K-step's fragments (and the spare stage stores)
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int co = tile_n * BN + (wn * TN + j) * 32 + l31;
-    if (co >= d.Cout) continue;
-    const float bv = (flags & FO_BIAS) ? a.bias[co] : 0.f;
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-        const int m = tile_m * BM + (wm * TM + i) * 32 + row;
-        if (m >= a.M) continue;
-        size_t opix = m;
-        if (d.ostride != 1 || d.Hm != d.Hout || d.Wm != d.Wout) {
-          const int n = m / a.HWm;
-          const int rem = m - n * a.HWm;
-          const int y = rem / d.Wm;
-          const int x = rem - y * d.Wm;
-          opix = ((size_t)n * d.Hout + (y * d.ostride + d.ophH)) * d.Wout + (x * d.ostride + d.ophW);
-        }
-        float v = acc[i][j][r] + bv;
-        if (flags & FO_MASK) v = (a.mask[opix * d.ldMask + co] > 0.f) ? v : 0.f;
-        if (flags & FO_ADD) v += a.add[opix * d.ldAdd + co];
-        if (flags & FO_OUT_RELU) v = fmaxf(v, 0.f);
-        a.out[opix * d.ldOut + co] = v;
+        const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        Cs[row * C_LD + (wn * TN + j) * 32 + l31] = acc[i][j][r];
       }
+  __syncthreads();
+  const int flags = d.flags;
+  constexpr int C4 = BN / 4;                 // float4 groups per tile row
+  constexpr int RPP = 256 / C4;              // rows per pass
+  const int c4 = tid % C4;
+  const int co = tile_n * BN + c4 * 4;
+  const bool identity_pix = (d.ostride == 1) & (d.Hm == d.Hout) & (d.Wm == d.Wout);
+  if (co < d.Cout) {
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (flags & FO_BIAS) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bv[e] = (co + e < d.Cout) ? a.bias[co + e] : 0.f;
+    }
+    for (int row = tid / C4; row < BM; row += RPP) {
+      const int m = tile_m * BM + row;
+      if (m >= a.M) break;
+      size_t opix = m;
+      if (!identity_pix) {
+        const int n = m / a.HWm;
+        const int rem = m - n * a.HWm;
+        const int y = rem / d.Wm;
+        const int x = rem - y * d.Wm;
+        opix = ((size_t)n * d.Hout + (y * d.ostride + d.ophH)) * d.Wout + (x * d.ostride + d.ophW);
+      }
+      f32x4 v = *reinterpret_cast<const f32x4*>(Cs + row * C_LD + c4 * 4) + bv;
+      if (flags & FO_MASK) {
+        const f32x4 mk = *reinterpret_cast<const f32x4*>(a.mask + opix * d.ldMask + co);
+        v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f; v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+      }
+      if (flags & FO_ADD) v += *reinterpret_cast<const f32x4*>(a.add + opix * d.ldAdd + co);
+      if (flags & FO_OUT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      *reinterpret_cast<f32x4*>(a.out + opix * d.ldOut + co) = v;
     }
   }
 }
@@ -322,6 +344,10 @@ extern "C" int fo_conv_igemm(const fo_conv_desc* d, const float* in, const float
   FO_REQUIRE(d->N > 0 && d->T > 0 && d->N % d->T == 0, FO_E_SHAPE, "conv: N=%d not a multiple of T=%d", d->N, d->T);
   FO_REQUIRE(d->Cin % 4 == 0 && d->ldIn % 4 == 0, FO_E_ALIGN, "conv: Cin/ldIn must be multiples of 4");
   FO_REQUIRE(fo_aligned16(in) && fo_aligned16(wp), FO_E_ALIGN, "conv: in/wp must be 16-byte aligned");
+  FO_REQUIRE(fo_aligned16(out) && d->ldOut % 4 == 0 && d->ldOut >= (d->Cout + 3) / 4 * 4, FO_E_ALIGN,
+             "conv: out must be 16-byte aligned with ldOut %% 4 == 0 and room for Cout rounded up to 4");
+  FO_REQUIRE(!(d->flags & FO_MASK) || (fo_aligned16(mask) && d->ldMask % 4 == 0), FO_E_ALIGN, "conv: mask alignment");
+  FO_REQUIRE(!(d->flags & FO_ADD) || (fo_aligned16(add) && d->ldAdd % 4 == 0), FO_E_ALIGN, "conv: add alignment");
   FO_REQUIRE(!(d->flags & FO_BIAS) || bias, FO_E_SHAPE, "conv: FO_BIAS without bias");
   FO_REQUIRE(!(d->flags & FO_MASK) || mask, FO_E_SHAPE, "conv: FO_MASK without mask");
   FO_REQUIRE(!(d->flags & FO_ADD) || add, FO_E_SHAPE, "conv: FO_ADD without add");

@@ -33,6 +33,7 @@ struct WgradArgs {
   int biasTap;    // tap whose blocks also produce the bias partial (-1: none)
   int stepFrameAligned;  // HWm % 32 == 0
   unsigned pBytes, qBytes;  // addressable extents behind P and Q (buffer descriptor bounds)
+  int fastWalk;             // Wm >= 32: a 32-pixel step wraps at most one image row
 };
 
 constexpr int WK = 32;  // pixels per K-step
@@ -93,26 +94,23 @@ __global__ __launch_bounds__(64 * WAVES_A * WAVES_B, 2) void conv_wgrad_kernel(c
   };
   auto next_valid = [&](int s) { while (s < nsteps && !step_valid(s)) ++s; return s; };
 
-  auto load_regs = [&](int s) {
-    const int m0 = m_begin + s * WK;
-#pragma unroll
-    for (int i = 0; i < PA; ++i) {
-      const int m = m0 + prowA + RPA * i;
-      const unsigned off = m < m_end ? ((unsigned)m * (unsigned)d.ldOut + (unsigned)(tileA * TA + pcolA)) * 4u : OOB;
-      rp[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rP, off, 0, 0));
-    }
-    // (frame, y, x) of this thread's Q rows: walked incrementally, one 32-pixel step at a time; a full
-    // decode (two integer divisions per row) only after a jump over skipped steps
-    if (q_step >= 0 && s == q_step + 1) {
+  // (frame, y, x) of this thread's Q rows for the step being loaded: walked incrementally (one wrap
+  // check per 32-pixel step when Wm >= 32), full decode (two integer divisions per row) after a jump
+  // over skipped steps.  Wave-uniform control flow, done at the top of an iteration.
+  auto walk_to = [&](int s) {
+    if (a.fastWalk && q_step >= 0 && s == q_step + 1) {
 #pragma unroll
       for (int i = 0; i < PB; ++i) {
         qx[i] += WK;
-        while (qx[i] >= d.Wm) {
-          qx[i] -= d.Wm;
-          if (++qy[i] == d.Hm) { qy[i] = 0; ++qn[i]; }
-        }
+        const bool c = qx[i] >= d.Wm;
+        qx[i] -= c ? d.Wm : 0;
+        qy[i] += c ? 1 : 0;
+        const bool c2 = qy[i] >= d.Hm;
+        qy[i] = c2 ? 0 : qy[i];
+        qn[i] += c2 ? 1 : 0;
       }
     } else {
+      const int m0 = m_begin + s * WK;
 #pragma unroll
       for (int i = 0; i < PB; ++i) {
         const int m = m0 + prowB + RPB * i;
@@ -123,33 +121,45 @@ __global__ __launch_bounds__(64 * WAVES_A * WAVES_B, 2) void conv_wgrad_kernel(c
       }
     }
     q_step = s;
-#pragma unroll
-    for (int i = 0; i < PB; ++i) {
+  };
+  int ld_m0 = 0;          // first pixel of the step whose loads are being issued
+  unsigned ld_pad = 0;    // OOB when there is no next step: every load then reads zeros (no branch)
+  // One quarter of a step's loads: P row q and Q row q of this thread (sits between two MFMA bursts).
+  auto load_part = [&](int q) {
+    if (q < PA) {
+      const int m = ld_m0 + prowA + RPA * q;
+      const unsigned pad = (m < m_end ? 0u : OOB) | ld_pad;
+      rp[q < PA ? q : 0] = __builtin_bit_cast(
+          f32x4, __builtin_amdgcn_raw_buffer_load_b128(rP, (((unsigned)m * (unsigned)d.ldOut + (unsigned)(tileA * TA + pcolA)) * 4u) | pad, 0, 0));
+    }
+    if (q < PB) {
+      const int i = q < PB ? q : 0;
       const int n = qn[i], y = qy[i], x = qx[i];
       int kwt = kw, coff = tileB * TB + pcolB;
       if (SMALLC) { kwt = pcolB >> 3; coff = pcolB & 7; }
       const int it = (n % d.T) + kd - d.padD;
       const int iy = y * d.stride - d.padH + kh;
       const int ix = x * d.stride - d.padW + kwt;
-      const bool ok = (m0 + prowB + RPB * i < m_end) & ((unsigned)it < (unsigned)d.T) & ((unsigned)iy < (unsigned)d.Hin) &
+      const bool ok = (ld_m0 + prowB + RPB * i < m_end) & ((unsigned)it < (unsigned)d.T) & ((unsigned)iy < (unsigned)d.Hin) &
                       ((unsigned)ix < (unsigned)d.Win);
       const unsigned pix = (unsigned)(((n + kd - d.padD) * d.Hin + iy) * d.Win + ix);
-      const unsigned off = ok ? (pix * (unsigned)d.ldIn + (unsigned)coff) * 4u : OOB;
-      rq[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rQ, off, 0, 0));
+      const unsigned pad = (ok ? 0u : OOB) | ld_pad;
+      rq[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rQ, ((pix * (unsigned)d.ldIn + (unsigned)coff) * 4u) | pad, 0, 0));
     }
   };
-  auto store_lds = [&](int buf) {
+  const float relu_floor = in_relu ? 0.f : -INFINITY;
+  auto store_part = [&](int q, int buf) {
     float* Ps = Ps0 + buf * WK * TA;
     float* Qs = Qs0 + buf * WK * TB;
-#pragma unroll
-    for (int i = 0; i < PA; ++i) {
+    if (q < PA) {
+      const int i = q < PA ? q : 0;
       *reinterpret_cast<f32x4*>(Ps + (prowA + RPA * i) * TA + pcolA) = rp[i];
       if (do_bias) bsum += rp[i];
     }
-#pragma unroll
-    for (int i = 0; i < PB; ++i) {
+    if (q < PB) {
+      const int i = q < PB ? q : 0;
       f32x4 v = rq[i];
-      if (in_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      v.x = fmaxf(v.x, relu_floor); v.y = fmaxf(v.y, relu_floor); v.z = fmaxf(v.z, relu_floor); v.w = fmaxf(v.w, relu_floor);
       *reinterpret_cast<f32x4*>(Qs + (prowB + RPB * i) * TB + pcolB) = v;
     }
   };
@@ -163,15 +173,24 @@ __global__ __launch_bounds__(64 * WAVES_A * WAVES_B, 2) void conv_wgrad_kernel(c
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   int s = next_valid(0);
-  if (s < nsteps) { load_regs(s); store_lds(0); }
+  if (s < nsteps) {
+    walk_to(s);
+    ld_m0 = m_begin + s * WK;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) load_part(q);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) store_part(q, 0);
+  }
   __syncthreads();
   int cur = 0;
   while (s < nsteps) {
     const int s2 = next_valid(s + 1);
+    if (s2 < nsteps) { walk_to(s2); ld_m0 = m_begin + s2 * WK; ld_pad = 0; } else { ld_pad = OOB; }
     const float* Ps = Ps0 + cur * WK * TA + half * TA + wa * TMA * 32 + l31;
     const float* Qs = Qs0 + cur * WK * TB + half * TB + wb * TNB * 32 + l31;
-    // 4 groups of 4 k-pairs; fragments of group g+1 are requested before group g's MFMAs, the next
-    // step's global loads go out behind group 0 (fences keep hipcc from undoing the pipeline)
+    // 4 groups of 4 k-pairs.  Fragments of group g+1 are requested inside group g, the next step's
+    // loads go out inside group 0 and their LDS stores inside group 3, each piece between two MFMAs
+    // (sched_group_barrier pins 1 MFMA : a few side instructions; hipcc would otherwise cluster them).
     float fa[2][4][TMA], fb[2][4][TNB];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -182,28 +201,39 @@ __global__ __launch_bounds__(64 * WAVES_A * WAVES_B, 2) void conv_wgrad_kernel(c
     }
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      __builtin_amdgcn_sched_barrier(0);
-      if (g < 3) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < 4; ++q) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (g < 3) {   // fragments of k-pair q of the next group
 #pragma unroll
           for (int i = 0; i < TMA; ++i) fa[(g + 1) & 1][q][i] = Ps[((g + 1) * 4 + q) * 2 * TA + i * 32];
 #pragma unroll
           for (int j = 0; j < TNB; ++j) fb[(g + 1) & 1][q][j] = Qs[((g + 1) * 4 + q) * 2 * TB + j * 32];
         }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
+        if (g == 0) load_part(q);
+        if (g == 3) store_part(q, cur ^ 1);
 #pragma unroll
         for (int i = 0; i < TMA; ++i)
 #pragma unroll
           for (int j = 0; j < TNB; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g & 1][q][i], fb[g & 1][q][j], acc[i][j], 0, 0, 0);
-      if (g == 0 && s2 < nsteps) load_regs(s2);
+        // masks: 0x8 MFMA, 0x2 VALU, 0x20 VMEM read, 0x100 DS read, 0x200 DS write
+#pragma unroll
+        for (int u = 0; u < TMA * TNB; ++u) {
+          __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+          if (g < 3) __builtin_amdgcn_sched_group_barrier(0x100, (TMA + TNB + TMA * TNB - 1) / (TMA * TNB), 0);
+          if (g == 0) {
+            __builtin_amdgcn_sched_group_barrier(0x2, 6, 0);
+            if (u == TMA * TNB - 1) __builtin_amdgcn_sched_group_barrier(0x20, 2, 0);
+          }
+          if (g == 3) {
+            __builtin_amdgcn_sched_group_barrier(0x2, 2, 0);
+            if (u >= TMA * TNB - 2) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+          }
+        }
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (s2 < nsteps) store_lds(cur ^ 1);
     __syncthreads();
     cur ^= 1;
     s = s2;
@@ -333,6 +363,7 @@ extern "C" int fo_conv_wgrad(const fo_conv_desc* d, const float* P, const float*
   const unsigned long long qBytes = (((unsigned long long)d->N * d->Hin * d->Win - 1) * d->ldIn + d->Cin) * 4ull;
   FO_REQUIRE(pBytes < (1ull << 31) && qBytes < (1ull << 31), FO_E_SHAPE, "wgrad: tensor exceeds the 2 GiB buffer-descriptor window");
   a.pBytes = (unsigned)pBytes;
+  a.fastWalk = d->Wm >= WK;
   a.qBytes = (unsigned)qBytes;
   hipStream_t s = (hipStream_t)stream;
   const int grid = p.nchunks * p.taps * p.tilesA * p.tilesB;
