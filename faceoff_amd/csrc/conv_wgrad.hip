@@ -11,8 +11,15 @@
 // ds_read_b32 row reads (lane -> consecutive channel).  K (pixels) is split across workgroups:
 // each writes an fp32 partial slab [tap][a][b]; a second kernel sums the slabs in a fixed order
 // (bitwise reproducible, no atomics) and scatters into the checkpoint layout.  Temporal taps that
-// only see clip padding are skipped per 32-pixel step.  The conv bias gradient (column sums of
-// P) rides along in the centre-tap workgroups.
+// only see clip padding are skipped per frame.  The conv bias gradient (column sums of P) rides
+// along in the centre-tap workgroups.
+//
+// A K-step is 32 consecutive pixels.  When the image width is a multiple of 32 (every layer of the
+// 256x256 model) a step is a run inside one image row, so for a fixed tap the shifted Q rows are a
+// linear run as well: the step's base offsets and a 32-bit row-validity mask are wave-uniform
+// SCALAR arithmetic (FASTROW), and a thread's share is one add per load.  Other shapes take the
+// generic per-row walk.  Either way the next step's loads go out inside MFMA group 0, the cursor
+// advances inside group 1, the LDS stores happen inside group 3 (1 MFMA : a few side instructions).
 #include <algorithm>
 #include "common.h"
 
@@ -34,19 +41,37 @@ struct WgradArgs {
   int stepFrameAligned;  // HWm % 32 == 0
   unsigned pBytes, qBytes;  // addressable extents behind P and Q (buffer descriptor bounds)
   int fastWalk;             // Wm >= 32: a 32-pixel step wraps at most one image row
+  int strideShift;          // log2(stride) (stride is 1 or 2)
 };
 
 constexpr int WK = 32;  // pixels per K-step
+constexpr unsigned OOB = 0x80000000u;
+#ifdef FO_STAMP   // diagnostic build only (tools/): s_memtime of workgroup 0 / wave 0
+__device__ unsigned long long fo_wstamps[4096];
+#define FO_WSTAMP_AT(i)                                                                           \
+  if (blockIdx.x == 0 && threadIdx.x == 0 && (i) < 4096) {                                        \
+    unsigned long long t_;                                                                        \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                    \
+    fo_wstamps[(i)] = t_;                                                                         \
+  }
+#else
+#define FO_WSTAMP_AT(i)
+#endif
 
-template <int TA, int TB, int WAVES_A, int WAVES_B, int TMA, int TNB, bool SMALLC>
+__device__ __forceinline__ f32x4 bufload(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+}
+
+template <int TA, int TB, int WAVES_A, int WAVES_B, int TMA, int TNB, bool SMALLC, bool FASTROW>
 __global__ __launch_bounds__(64 * WAVES_A * WAVES_B, 2) void conv_wgrad_kernel(const WgradArgs a) {
   constexpr int NT = 64 * WAVES_A * WAVES_B;
   static_assert(WAVES_A * TMA * 32 == TA && WAVES_B * TNB * 32 == TB, "tile");
+  static_assert(!(SMALLC && FASTROW), "FASTROW is for the regular channel layout");
   constexpr int PA = (WK * TA / 4) / NT;  // float4 loads per thread per step for P
   constexpr int PB = (WK * TB / 4) / NT;
   constexpr int RPA = NT / (TA / 4);      // rows covered per pass
   constexpr int RPB = NT / (TB / 4);
-  static_assert(PA >= 1 && PB >= 1, "tile too small for block");
+  static_assert(PA >= 1 && PB >= 1 && PA <= 4 && PB <= 4, "loads per step must fit the 4 parts");
   __shared__ __attribute__((aligned(16))) float lds[2 * WK * (TA + TB)];
   float* Ps0 = lds;
   float* Qs0 = lds + 2 * WK * TA;
@@ -70,7 +95,6 @@ __global__ __launch_bounds__(64 * WAVES_A * WAVES_B, 2) void conv_wgrad_kernel(c
 
   const int m_begin = chunk * a.chunk;
   const int m_end = min(a.M, m_begin + a.chunk);
-  const int nsteps = (m_end - m_begin + WK - 1) / WK;
 
   const int pcolA = (tid % (TA / 4)) * 4, prowA = tid / (TA / 4);
   const int pcolB = (tid % (TB / 4)) * 4, prowB = tid / (TB / 4);
@@ -78,76 +102,126 @@ __global__ __launch_bounds__(64 * WAVES_A * WAVES_B, 2) void conv_wgrad_kernel(c
   // so the loads stay in flight under the MFMAs (see conv_igemm.hip)
   const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.P), 0, a.pBytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rQ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Q), 0, a.qBytes, 0x00020000);
-  constexpr unsigned OOB = 0x80000000u;
-  const bool in_relu = d.flags & FO_IN_RELU;
+  const float relu_floor = (d.flags & FO_IN_RELU) ? 0.f : -INFINITY;
   const bool do_bias = a.wsBias && tap == a.biasTap && tileB == 0;
 
   f32x4 rp[PA], rq[PB];
   f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
-  int qn[PB], qy[PB], qx[PB];
-  int q_step = -1;
 
-  auto step_valid = [&](int s) -> bool {
-    if (d.KD == 1 || !a.stepFrameAligned) return true;
-    const int t = ((m_begin + s * WK) / a.HWm) % d.T;
-    return (unsigned)(t + kd - d.padD) < (unsigned)d.T;
+  // ------------------------------------------------------------------ cursor over the K-steps to load
+  // wave-uniform: first pixel of the step, its frame / row / column, and whether it exists
+  int c_pos = m_begin, c_n, c_t, c_y, c_x;
+  {
+    c_n = c_pos / a.HWm;
+    const int rem = c_pos - c_n * a.HWm;
+    c_y = rem / d.Wm;
+    c_x = rem - c_y * d.Wm;
+    c_t = c_n % d.T;
+  }
+  const bool can_skip = d.KD > 1 && a.stepFrameAligned;
+  auto frame_ok = [&]() { return !can_skip || (unsigned)(c_t + kd - d.padD) < (unsigned)d.T; };
+  auto skip_bad_frames = [&]() {   // jump to the start of the next frame while the tap only sees clip padding
+    while (c_pos < m_end && !frame_ok()) {
+      c_pos += a.HWm - (c_y * d.Wm + c_x);
+      c_x = 0; c_y = 0; ++c_n;
+      c_t = (c_t + 1 == d.T) ? 0 : c_t + 1;
+    }
   };
-  auto next_valid = [&](int s) { while (s < nsteps && !step_valid(s)) ++s; return s; };
-
-  // (frame, y, x) of this thread's Q rows for the step being loaded: walked incrementally (one wrap
-  // check per 32-pixel step when Wm >= 32), full decode (two integer divisions per row) after a jump
-  // over skipped steps.  Wave-uniform control flow, done at the top of an iteration.
-  auto walk_to = [&](int s) {
-    if (a.fastWalk && q_step >= 0 && s == q_step + 1) {
+  // generic walk: per-thread (frame, y, x) of each Q row
+  int qn[PB], qy[PB], qx[PB], qt[PB];
+  auto decode_rows = [&]() {
 #pragma unroll
-      for (int i = 0; i < PB; ++i) {
-        qx[i] += WK;
-        const bool c = qx[i] >= d.Wm;
-        qx[i] -= c ? d.Wm : 0;
-        qy[i] += c ? 1 : 0;
-        const bool c2 = qy[i] >= d.Hm;
-        qy[i] = c2 ? 0 : qy[i];
-        qn[i] += c2 ? 1 : 0;
+    for (int i = 0; i < PB; ++i) {
+      const int m = c_pos + prowB + RPB * i;
+      qn[i] = m / a.HWm;
+      const int rem = m - qn[i] * a.HWm;
+      qy[i] = rem / d.Wm;
+      qx[i] = rem - qy[i] * d.Wm;
+      qt[i] = qn[i] % d.T;
+    }
+  };
+  auto cursor_advance = [&]() {
+    const int before = c_pos;
+    c_pos += WK;
+    c_x += WK;
+    if (FASTROW) {
+      if (c_x == d.Wm) {
+        c_x = 0;
+        if (++c_y == d.Hm) { c_y = 0; ++c_n; c_t = (c_t + 1 == d.T) ? 0 : c_t + 1; }
       }
     } else {
-      const int m0 = m_begin + s * WK;
-#pragma unroll
-      for (int i = 0; i < PB; ++i) {
-        const int m = m0 + prowB + RPB * i;
-        qn[i] = m / a.HWm;
-        const int rem = m - qn[i] * a.HWm;
-        qy[i] = rem / d.Wm;
-        qx[i] = rem - qy[i] * d.Wm;
+      while (c_x >= d.Wm) {
+        c_x -= d.Wm;
+        if (++c_y == d.Hm) { c_y = 0; ++c_n; c_t = (c_t + 1 == d.T) ? 0 : c_t + 1; }
       }
     }
-    q_step = s;
+    skip_bad_frames();
+    if (!FASTROW) {
+      if (a.fastWalk && c_pos == before + WK) {   // one wrap check per row instead of two divisions
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+          qx[i] += WK;
+          const bool c = qx[i] >= d.Wm;
+          qx[i] -= c ? d.Wm : 0;
+          qy[i] += c ? 1 : 0;
+          const bool c2 = qy[i] >= d.Hm;
+          qy[i] = c2 ? 0 : qy[i];
+          qn[i] += c2 ? 1 : 0;
+          qt[i] = c2 ? ((qt[i] + 1 == d.T) ? 0 : qt[i] + 1) : qt[i];
+        }
+      } else {
+        decode_rows();
+      }
+    }
   };
-  int ld_m0 = 0;          // first pixel of the step whose loads are being issued
-  unsigned ld_pad = 0;    // OOB when there is no next step: every load then reads zeros (no branch)
+
+  // per-thread constants of the FASTROW address arithmetic
+  unsigned pconst[PA], qconst[PB];
+#pragma unroll
+  for (int i = 0; i < PA; ++i) pconst[i] = (unsigned)(((prowA + RPA * i) * d.ldOut + tileA * TA + pcolA) * 4);
+#pragma unroll
+  for (int i = 0; i < PB; ++i) qconst[i] = (unsigned)((((prowB + RPB * i) << a.strideShift) * d.ldIn + tileB * TB + pcolB) * 4);
+
   // One quarter of a step's loads: P row q and Q row q of this thread (sits between two MFMA bursts).
+  // Past the last step every offset is out of range: zeros, no branch.
   auto load_part = [&](int q) {
-    if (q < PA) {
-      const int m = ld_m0 + prowA + RPA * q;
-      const unsigned pad = (m < m_end ? 0u : OOB) | ld_pad;
-      rp[q < PA ? q : 0] = __builtin_bit_cast(
-          f32x4, __builtin_amdgcn_raw_buffer_load_b128(rP, (((unsigned)m * (unsigned)d.ldOut + (unsigned)(tileA * TA + pcolA)) * 4u) | pad, 0, 0));
-    }
-    if (q < PB) {
-      const int i = q < PB ? q : 0;
-      const int n = qn[i], y = qy[i], x = qx[i];
-      int kwt = kw, coff = tileB * TB + pcolB;
-      if (SMALLC) { kwt = pcolB >> 3; coff = pcolB & 7; }
-      const int it = (n % d.T) + kd - d.padD;
-      const int iy = y * d.stride - d.padH + kh;
-      const int ix = x * d.stride - d.padW + kwt;
-      const bool ok = (ld_m0 + prowB + RPB * i < m_end) & ((unsigned)it < (unsigned)d.T) & ((unsigned)iy < (unsigned)d.Hin) &
-                      ((unsigned)ix < (unsigned)d.Win);
-      const unsigned pix = (unsigned)(((n + kd - d.padD) * d.Hin + iy) * d.Win + ix);
-      const unsigned pad = (ok ? 0u : OOB) | ld_pad;
-      rq[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rQ, ((pix * (unsigned)d.ldIn + (unsigned)coff) * 4u) | pad, 0, 0));
+    const unsigned endpad = c_pos < m_end ? 0u : OOB;
+    if (FASTROW) {
+      if (q < PA) rp[q < PA ? q : 0] = bufload(rP, ((unsigned)c_pos * (unsigned)d.ldOut * 4u + pconst[q < PA ? q : 0]) | endpad);
+      if (q < PB) {
+        const int i = q < PB ? q : 0;
+        // scalar: input row / first input column of the step, row-validity mask over its 32 pixels
+        const int iy = (c_y << a.strideShift) - d.padH + kh;
+        const int xs = (c_x << a.strideShift) - d.padW + kw;
+        const int lo = max(0, (-xs + d.stride - 1) >> a.strideShift);
+        const int hi = min(WK, (d.Win - xs + d.stride - 1) >> a.strideShift);
+        unsigned mask = 0;
+        if ((unsigned)iy < (unsigned)d.Hin && hi > lo) mask = (hi >= 32 ? 0xFFFFFFFFu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u);
+        const unsigned qbase = (unsigned)((((c_n + kd - d.padD) * d.Hin + iy) * d.Win + xs) * d.ldIn * 4);
+        const unsigned pad = ((((mask >> (prowB + RPB * i)) & 1u) - 1u) & OOB) | endpad;
+        rq[i] = bufload(rQ, (qbase + qconst[i]) | pad);
+      }
+    } else {
+      if (q < PA) {
+        const int m = c_pos + prowA + RPA * q;
+        const unsigned pad = (m < m_end ? 0u : OOB) | endpad;
+        rp[q < PA ? q : 0] = bufload(rP, (((unsigned)m * (unsigned)d.ldOut + (unsigned)(tileA * TA + pcolA)) * 4u) | pad);
+      }
+      if (q < PB) {
+        const int i = q < PB ? q : 0;
+        const int n = qn[i], y = qy[i], x = qx[i];
+        int kwt = kw, coff = tileB * TB + pcolB;
+        if (SMALLC) { kwt = pcolB >> 3; coff = pcolB & 7; }
+        const int it = qt[i] + kd - d.padD;
+        const int iy = y * d.stride - d.padH + kh;
+        const int ix = x * d.stride - d.padW + kwt;
+        const bool ok = (c_pos + prowB + RPB * i < m_end) & ((unsigned)it < (unsigned)d.T) & ((unsigned)iy < (unsigned)d.Hin) &
+                        ((unsigned)ix < (unsigned)d.Win);
+        const unsigned pix = (unsigned)(((n + kd - d.padD) * d.Hin + iy) * d.Win + ix);
+        rq[i] = bufload(rQ, ((pix * (unsigned)d.ldIn + (unsigned)coff) * 4u) | (ok ? 0u : OOB) | endpad);
+      }
     }
   };
-  const float relu_floor = in_relu ? 0.f : -INFINITY;
   auto store_part = [&](int q, int buf) {
     float* Ps = Ps0 + buf * WK * TA;
     float* Qs = Qs0 + buf * WK * TB;
@@ -172,26 +246,28 @@ __global__ __launch_bounds__(64 * WAVES_A * WAVES_B, 2) void conv_wgrad_kernel(c
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  int s = next_valid(0);
-  if (s < nsteps) {
-    walk_to(s);
-    ld_m0 = m_begin + s * WK;
+  skip_bad_frames();
+  if (!FASTROW) decode_rows();
+  bool have = c_pos < m_end;          // a step is staged in LDS buffer `cur`
 #pragma unroll
-    for (int q = 0; q < 4; ++q) load_part(q);
+  for (int q = 0; q < 4; ++q) load_part(q);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) store_part(q, 0);
-  }
+  for (int q = 0; q < 4; ++q) store_part(q, 0);
+  if (have) cursor_advance();
   __syncthreads();
   int cur = 0;
-  while (s < nsteps) {
-    const int s2 = next_valid(s + 1);
-    if (s2 < nsteps) { walk_to(s2); ld_m0 = m_begin + s2 * WK; ld_pad = 0; } else { ld_pad = OOB; }
+  int stamp_i = 0;
+  while (have) {
+    FO_WSTAMP_AT(8 * stamp_i);
+    const bool have_next = c_pos < m_end;
     const float* Ps = Ps0 + cur * WK * TA + half * TA + wa * TMA * 32 + l31;
     const float* Qs = Qs0 + cur * WK * TB + half * TB + wb * TNB * 32 + l31;
     // 4 groups of 4 k-pairs.  Fragments of group g+1 are requested inside group g, the next step's
-    // loads go out inside group 0 and their LDS stores inside group 3, each piece between two MFMAs
-    // (sched_group_barrier pins 1 MFMA : a few side instructions; hipcc would otherwise cluster them).
+    // loads go out inside group 0, the cursor moves on inside group 1, the LDS stores of the loaded
+    // data happen inside group 3 -- each piece between two MFMAs (sched_group_barrier pins
+    // 1 MFMA : a few side instructions; hipcc would otherwise cluster the side work in front).
     float fa[2][4][TMA], fb[2][4][TNB];
+    FO_WSTAMP_AT(8 * stamp_i + 1);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
 #pragma unroll
@@ -211,6 +287,7 @@ __global__ __launch_bounds__(64 * WAVES_A * WAVES_B, 2) void conv_wgrad_kernel(c
           for (int j = 0; j < TNB; ++j) fb[(g + 1) & 1][q][j] = Qs[((g + 1) * 4 + q) * 2 * TB + j * 32];
         }
         if (g == 0) load_part(q);
+        if (g == 1 && q == 0 && have_next) cursor_advance();
         if (g == 3) store_part(q, cur ^ 1);
 #pragma unroll
         for (int i = 0; i < TMA; ++i)
@@ -232,11 +309,14 @@ __global__ __launch_bounds__(64 * WAVES_A * WAVES_B, 2) void conv_wgrad_kernel(c
           }
         }
       }
+      FO_WSTAMP_AT(8 * stamp_i + 2 + g);
     }
     __builtin_amdgcn_sched_barrier(0);
+    FO_WSTAMP_AT(8 * stamp_i + 6);
     __syncthreads();
     cur ^= 1;
-    s = s2;
+    have = have_next;
+    ++stamp_i;
   }
 
   // ---- partial slab [chunk][tap][Apad][Bpad]
@@ -331,15 +411,26 @@ int make_plan(const fo_conv_desc* d, Plan* p) {
 
 }  // namespace
 
+#ifdef FO_STAMP
+extern "C" int fo_debug_read_wstamps(unsigned long long* out, int n) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(fo_wstamps), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -1;
+}
+#endif
+
 extern "C" int64_t fo_wgrad_ws_bytes(const fo_conv_desc* d) {
   Plan p;
   if (make_plan(d, &p) != FO_OK) return -1;
   return ((int64_t)p.nchunks * p.taps * p.Apad * p.Bpad + (int64_t)p.nchunks * p.Apad) * 4 + 256;
 }
 
-#define WG_LAUNCH(TA_, TB_, WA_, WB_, TM_, TN_, SC_)                                                        \
-  hipLaunchKernelGGL((conv_wgrad_kernel<TA_, TB_, WA_, WB_, TM_, TN_, SC_>), dim3(grid), dim3(64 * WA_ * WB_), \
+#define WG_LAUNCH1(TA_, TB_, WA_, WB_, TM_, TN_, SC_, FR_)                                                       \
+  hipLaunchKernelGGL((conv_wgrad_kernel<TA_, TB_, WA_, WB_, TM_, TN_, SC_, FR_>), dim3(grid), dim3(64 * WA_ * WB_), \
                      0, s, a)
+#define WG_LAUNCH(TA_, TB_, WA_, WB_, TM_, TN_)                     \
+  do {                                                               \
+    if (fastrow) WG_LAUNCH1(TA_, TB_, WA_, WB_, TM_, TN_, false, true); \
+    else WG_LAUNCH1(TA_, TB_, WA_, WB_, TM_, TN_, false, false);     \
+  } while (0)
 
 extern "C" int fo_conv_wgrad(const fo_conv_desc* d, const float* P, const float* Q, float* dw, int Areal, int Breal,
                              float* dbias, float* ws, int64_t ws_bytes, void* stream) {
@@ -364,19 +455,23 @@ extern "C" int fo_conv_wgrad(const fo_conv_desc* d, const float* P, const float*
   FO_REQUIRE(pBytes < (1ull << 31) && qBytes < (1ull << 31), FO_E_SHAPE, "wgrad: tensor exceeds the 2 GiB buffer-descriptor window");
   a.pBytes = (unsigned)pBytes;
   a.fastWalk = d->Wm >= WK;
+  FO_REQUIRE(d->stride == 1 || d->stride == 2, FO_E_SHAPE, "wgrad: stride must be 1 or 2");
+  a.strideShift = d->stride == 2 ? 1 : 0;
+  // FASTROW: a 32-pixel K-step is a run inside one image row, chunks start on step boundaries
+  const bool fastrow = !p.smallc && d->Wm % WK == 0 && p.chunk % WK == 0;
   a.qBytes = (unsigned)qBytes;
   hipStream_t s = (hipStream_t)stream;
   const int grid = p.nchunks * p.taps * p.tilesA * p.tilesB;
-  if (p.smallc) WG_LAUNCH(64, 32, 2, 1, 1, 1, true);
-  else if (p.TA == 128 && p.TB == 128) WG_LAUNCH(128, 128, 2, 2, 2, 2, false);
-  else if (p.TA == 128 && p.TB == 64) WG_LAUNCH(128, 64, 2, 2, 2, 1, false);
-  else if (p.TA == 64 && p.TB == 128) WG_LAUNCH(64, 128, 2, 2, 1, 2, false);
-  else if (p.TA == 128 && p.TB == 32) WG_LAUNCH(128, 32, 4, 1, 1, 1, false);
-  else if (p.TA == 32 && p.TB == 128) WG_LAUNCH(32, 128, 1, 4, 1, 1, false);
-  else if (p.TA == 64 && p.TB == 64) WG_LAUNCH(64, 64, 2, 2, 1, 1, false);
-  else if (p.TA == 64 && p.TB == 32) WG_LAUNCH(64, 32, 2, 1, 1, 1, false);
-  else if (p.TA == 32 && p.TB == 64) WG_LAUNCH(32, 64, 1, 2, 1, 1, false);
-  else if (p.TA == 32 && p.TB == 32) WG_LAUNCH(32, 32, 1, 1, 1, 1, false);
+  if (p.smallc) WG_LAUNCH1(64, 32, 2, 1, 1, 1, true, false);
+  else if (p.TA == 128 && p.TB == 128) WG_LAUNCH(128, 128, 2, 2, 2, 2);
+  else if (p.TA == 128 && p.TB == 64) WG_LAUNCH(128, 64, 2, 2, 2, 1);
+  else if (p.TA == 64 && p.TB == 128) WG_LAUNCH(64, 128, 2, 2, 1, 2);
+  else if (p.TA == 128 && p.TB == 32) WG_LAUNCH(128, 32, 4, 1, 1, 1);
+  else if (p.TA == 32 && p.TB == 128) WG_LAUNCH(32, 128, 1, 4, 1, 1);
+  else if (p.TA == 64 && p.TB == 64) WG_LAUNCH(64, 64, 2, 2, 1, 1);
+  else if (p.TA == 64 && p.TB == 32) WG_LAUNCH(64, 32, 2, 1, 1, 1);
+  else if (p.TA == 32 && p.TB == 64) WG_LAUNCH(32, 64, 1, 2, 1, 1);
+  else if (p.TA == 32 && p.TB == 32) WG_LAUNCH(32, 32, 1, 1, 1, 1);
   else FO_REQUIRE(false, FO_E_SHAPE, "wgrad: unsupported tile %dx%d", p.TA, p.TB);
   FO_CHECK_LAUNCH();
   const size_t slabElems = (size_t)p.taps * p.Apad * p.Bpad;

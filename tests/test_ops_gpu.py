@@ -52,6 +52,13 @@ CONV_CASES = [
     ("k1_32to128", 32, 128, 1, 1, 2, 16, 16),
     ("k1_128to64", 128, 64, 1, 1, 2, 8, 8),
     ("k1_192to64", 192, 64, 1, 1, 2, 16, 16),
+    # widths that are multiples of 32: the wgrad FASTROW path (scalar row masks) and full 128-pixel tiles
+    ("k3_128to128_w32", 128, 128, 3, 1, 1, 8, 32),
+    ("k3_128to32_w64", 128, 32, 3, 1, 1, 6, 64),
+    ("k4s2_64to128_w64", 64, 128, 4, 2, 2, 8, 64),
+    ("k4s2_128to64_w128", 128, 64, 4, 2, 1, 4, 128),
+    ("k1_32to128_w32", 32, 128, 1, 1, 2, 4, 32),
+    ("enc_b0_6to64_w64", 6, 64, 4, 2, 1, 8, 64),
 ]
 
 
@@ -130,7 +137,8 @@ def test_conv_epilogue_flags_and_views():
     _close(dw, w1r.grad, what="wgrad in_relu")
 
 
-CONVT_CASES = [("convT_128to64", 128, 64, 2, 8, 8), ("convT_64to64", 64, 64, 2, 8, 12), ("convT_64to6", 64, 6, 2, 16, 16)]
+CONVT_CASES = [("convT_128to64", 128, 64, 2, 8, 8), ("convT_64to64", 64, 64, 2, 8, 12), ("convT_64to6", 64, 6, 2, 16, 16),
+               ("convT_128to64_w32", 128, 64, 1, 4, 32), ("convT_64to6_w64", 64, 6, 1, 4, 64)]
 
 
 @pytest.mark.parametrize("case", CONVT_CASES, ids=[c[0] for c in CONVT_CASES])
@@ -161,7 +169,8 @@ def test_conv_transpose_fwd_dgrad_wgrad(case):
     _close(db, b.grad, what="convT bias grad")
 
 
-@pytest.mark.parametrize("B,T,H,W", [(1, 1, 8, 16), (2, 2, 8, 8), (1, 5, 16, 16), (2, 5, 16, 8), (3, 3, 6, 10)])
+@pytest.mark.parametrize("B,T,H,W", [(1, 1, 8, 16), (2, 2, 8, 8), (1, 5, 16, 16), (2, 5, 16, 8), (3, 3, 6, 10),
+                                     (2, 5, 4, 32), (1, 3, 2, 64), (2, 2, 8, 32)])
 def test_conv3d_fwd_dgrad_wgrad(B, T, H, W):
     """Conv3d 128->128 k3 p1 (Conv3dLatentPostnet :181,185) incl. T=1,2,5 and tiles that straddle frames."""
     from faceoff_amd import ops
