@@ -347,28 +347,58 @@ __global__ __launch_bounds__(64 * WAVES_A * WAVES_B, 2) void conv_wgrad_kernel(c
 }
 
 // Sum the slabs in chunk order and scatter to the checkpoint layout dW[a][b][tap].
+// A workgroup owns 64 consecutive slab elements; its CL "chunk lanes" (blockDim = 64*CL) each sum every
+// CL-th slab with four independent accumulators (loads in flight instead of a latency chain), then
+// the lanes are combined through LDS in a fixed order: bitwise reproducible, no atomics.
 __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nchunks, int taps,
                                     int Apad, int Bpad, int Areal, int Breal, int smallc, int KW) {
+  __shared__ float red[1024];
   const size_t slabElems = (size_t)taps * Apad * Bpad;
-  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < slabElems; e += (size_t)gridDim.x * blockDim.x) {
+  const int CL = blockDim.x >> 6, cl = threadIdx.x >> 6, li = threadIdx.x & 63;
+  const size_t e = (size_t)blockIdx.x * 64 + li;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (e < slabElems) {
+    const float* p = ws + e;
+    int c = cl;
+    for (; c + 3 * CL < nchunks; c += 4 * CL) {
+      s0 += p[(size_t)c * slabElems];
+      s1 += p[(size_t)(c + CL) * slabElems];
+      s2 += p[(size_t)(c + 2 * CL) * slabElems];
+      s3 += p[(size_t)(c + 3 * CL) * slabElems];
+    }
+    for (; c < nchunks; c += CL) s0 += p[(size_t)c * slabElems];
+  }
+  red[threadIdx.x] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (cl == 0 && e < slabElems) {
+    float s = red[li];
+    for (int k = 1; k < CL; ++k) s += red[k * 64 + li];
     const int b = e % Bpad;
     const int aidx = (e / Bpad) % Apad;
     const int tap = e / ((size_t)Bpad * Apad);
     int breal = b, tapOut = tap, tapsOut = taps;
     if (smallc) { breal = b & 7; tapOut = tap * KW + (b >> 3); tapsOut = taps * KW; }
-    if (aidx >= Areal || breal >= Breal) continue;
-    float s = 0.f;
-    for (int c = 0; c < nchunks; ++c) s += ws[c * slabElems + e];
-    dw[((size_t)aidx * Breal + breal) * tapsOut + tapOut] = s;
+    if (aidx < Areal && breal < Breal) dw[((size_t)aidx * Breal + breal) * tapsOut + tapOut] = s;
   }
 }
 
 __global__ void bias_reduce_kernel(const float* __restrict__ ws, float* __restrict__ db, int nchunks, int Apad, int Areal) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= Areal) return;
-  float s = 0.f;
-  for (int k = 0; k < nchunks; ++k) s += ws[(size_t)k * Apad + c];
-  db[c] = s;
+  __shared__ float red[1024];
+  const int CL = blockDim.x >> 6, cl = threadIdx.x >> 6, li = threadIdx.x & 63;
+  const int c = blockIdx.x * 64 + li;
+  float s0 = 0.f, s1 = 0.f;
+  if (c < Areal) {
+    int k = cl;
+    for (; k + CL < nchunks; k += 2 * CL) { s0 += ws[(size_t)k * Apad + c]; s1 += ws[(size_t)(k + CL) * Apad + c]; }
+    for (; k < nchunks; k += CL) s0 += ws[(size_t)k * Apad + c];
+  }
+  red[threadIdx.x] = s0 + s1;
+  __syncthreads();
+  if (cl == 0 && c < Areal) {
+    float s = red[li];
+    for (int k = 1; k < CL; ++k) s += red[k * 64 + li];
+    db[c] = s;
+  }
 }
 
 struct Plan {
@@ -475,12 +505,12 @@ extern "C" int fo_conv_wgrad(const fo_conv_desc* d, const float* P, const float*
   else FO_REQUIRE(false, FO_E_SHAPE, "wgrad: unsupported tile %dx%d", p.TA, p.TB);
   FO_CHECK_LAUNCH();
   const size_t slabElems = (size_t)p.taps * p.Apad * p.Bpad;
-  const int rgrid = (int)std::min<size_t>((slabElems + 255) / 256, 4096);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rgrid), dim3(256), 0, s, ws, dw, p.nchunks, p.taps, p.Apad, p.Bpad,
-                     Areal, Breal, p.smallc ? 1 : 0, d->KW);
+  const int CL = p.nchunks >= 256 ? 16 : 4;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((slabElems + 63) / 64)), dim3(64 * CL), 0, s, ws, dw, p.nchunks,
+                     p.taps, p.Apad, p.Bpad, Areal, Breal, p.smallc ? 1 : 0, d->KW);
   FO_CHECK_LAUNCH();
   if (dbias) {
-    hipLaunchKernelGGL(bias_reduce_kernel, dim3((Areal + 63) / 64), dim3(64), 0, s, a.wsBias, dbias, p.nchunks, p.Apad, Areal);
+    hipLaunchKernelGGL(bias_reduce_kernel, dim3((Areal + 63) / 64), dim3(1024), 0, s, a.wsBias, dbias, p.nchunks, p.Apad, Areal);
     FO_CHECK_LAUNCH();
   }
   return FO_OK;

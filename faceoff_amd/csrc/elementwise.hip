@@ -65,11 +65,19 @@ __global__ void colsum_stage1(const float* __restrict__ g, float* __restrict__ w
   }
 }
 __global__ void colsum_stage2(const float* __restrict__ ws, float* __restrict__ out, int nblk, int C, int Creal) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= Creal) return;
+  __shared__ float red[1024];   // 64 channels x 16 partial-sum lanes, combined in a fixed order
+  const int cl = threadIdx.x >> 6, li = threadIdx.x & 63;
+  const int c = blockIdx.x * 64 + li;
   float s = 0.f;
-  for (int b = 0; b < nblk; ++b) s += ws[(size_t)b * C + c];
-  out[c] = s;
+  if (c < Creal)
+    for (int b = cl; b < nblk; b += 16) s += ws[(size_t)b * C + c];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (cl == 0 && c < Creal) {
+    float t = red[li];
+    for (int k = 1; k < 16; ++k) t += red[k * 64 + li];
+    out[c] = t;
+  }
 }
 
 // torch.optim.Adam (defaults; train_faceoff_perceptual.py:190) over a flat arena.
@@ -150,7 +158,7 @@ int fo_bias_grad(const float* g, float* dbias, int64_t M, int C, int Creal, int 
   const int nblk = (int)std::max<long long>(1, std::min<long long>(1024, (M + nrl * 8 - 1) / (nrl * 8)));
   hipLaunchKernelGGL(colsum_stage1, dim3(nblk), dim3(256), 0, (hipStream_t)stream, g, ws, (long long)M, C, ld);
   FO_CHECK_LAUNCH();
-  hipLaunchKernelGGL(colsum_stage2, dim3((Creal + 63) / 64), dim3(64), 0, (hipStream_t)stream, ws, dbias, nblk, C, Creal);
+  hipLaunchKernelGGL(colsum_stage2, dim3((Creal + 63) / 64), dim3(1024), 0, (hipStream_t)stream, ws, dbias, nblk, C, Creal);
   FO_CHECK_LAUNCH();
   return FO_OK;
 }
