@@ -53,6 +53,9 @@ def main():
     ap.add_argument("--clips", type=int, default=32, help="clips per GPU (BASELINE: 32)")
     ap.add_argument("--frames", type=int, default=5, help="frames per clip T (BASELINE: 5)")
     ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--perceptual", action="store_true",
+                    help="add the LPIPS/VGG-16 term (train_faceoff_perceptual.py path) in fp32 with seeded VGG weights; "
+                         "NOT the BASELINE metric configuration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-launch HIP-event timing")
     args = ap.parse_args()
@@ -78,7 +81,12 @@ def main():
 
     B, T, H = args.clips, args.frames, args.size
     eng = VQVAEEngine(make_state_dict(0, codebook_scale=0.3, gain=2.0), dev)
-    trainer = FaceOffTrainer(eng, lr=3e-4)
+    vqlpips = None
+    if args.perceptual:
+        from faceoff_amd.loss import VQLPIPS
+        from faceoff_amd.synth import make_vgg_lpips_state
+        vqlpips = VQLPIPS(make_vgg_lpips_state(7)).to(dev)
+    trainer = FaceOffTrainer(eng, lr=3e-4, vqlpips=vqlpips)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     img = torch.rand((B * T, 6, H, H), device=dev, generator=gen) * 2 - 1       # U(-1,1): dataset.py:240-247
     gt = torch.rand((B * T, 3, H, H), device=dev, generator=gen) * 2 - 1
@@ -117,10 +125,13 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic U(-1,1) inputs resident in HBM; random-init weights (kaiming-uniform x2 gain, codebook N(0,0.3^2))",
-        "config": {"workload": f"C2: VQ-VAE-2 + Conv3d latent, {H}x{H}, T={T}, {B} clips/GPU, recon+VQ loss, fwd+bwd+Adam",
+        "config": {"workload": (f"C2: VQ-VAE-2 + Conv3d latent, {H}x{H}, T={T}, {B} clips/GPU, recon+VQ loss, fwd+bwd+Adam"
+                                if not args.perceptual else
+                                f"C3 in fp32: C2 + LPIPS/VGG-16 perceptual loss (seeded VGG weights), {H}x{H}, T={T}, {B} clips/GPU"),
                    "global_clips": B * world, "frames_per_step": B * T * world, "parallelism": f"dp{world}"},
         "loss": {"recon": round(recon.item(), 6), "latent": round(latent.item(), 6)},
-        "step_frac_of_fp32_mfma_roofline": round(fps / world * FLOP_PER_FRAME / (FP32_MFMA_PEAK_TFLOPS * 1e12), 4),
+        "step_frac_of_fp32_mfma_roofline": round(fps / world * (FLOP_PER_FRAME + (120.3e9 if args.perceptual else 0.0))
+                                                 / (FP32_MFMA_PEAK_TFLOPS * 1e12), 4),
     }
     if prof is not None:
         summ = prof.summary()
@@ -140,7 +151,7 @@ def main():
                 out["roofline"]["traffic"] = json.load(open(pmc)).get(dom)
             except Exception:
                 pass
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and not args.perceptual:
         out["cpu_baseline"] = cpu_baseline(T, H, H)
     print(json.dumps(out), flush=True)
     if world > 1:

@@ -56,6 +56,12 @@ SIGNATURES = {
     "fo_vq_gather": (_I, [_P, _P, _P, _I, _L, _P]),
     "fo_mse_slice_fwd": (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _P]),
     "fo_mse_slice_bwd": (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _F, _P, _I, _P]),
+    "fo_lpips_prep": (_I, [_P, _I, _I, _P, _I, _I, _I, _P, _P, _P]),
+    "fo_lpips_prep_bwd": (_I, [_P, _I, _P, _I, _L, _P, _P, _F, _P]),
+    "fo_maxpool2_fwd": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "fo_maxpool2_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "fo_lpips_tap_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "fo_lpips_tap_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "fo_adam_flat": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _F, _P]),
     "fo_zero": (_I, [_P, _L, _P]),
     "fo_relu": (_I, [_P, _I, _P, _I, _L, _I, _P]),

@@ -1,0 +1,88 @@
+"""Mirror of the reference `loss.VQLPIPS` (loss.py:27-33): `VQLPIPS()(targets, reconstructions)` -> 0-dim tensor,
+all parameters frozen, always eval -- computed by faceoff_amd.lpips.LPIPSEngine on the gfx950 kernels.
+
+The reference constructor downloads vgg.pth + torchvision VGG-16 (lpips.py:12-48,118): there is no network
+here, so weights come from `load_state_dict` (reference key names under `perceptual_loss.`) or the
+`state_dict=` argument; constructing without weights and calling forward raises.
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from . import ops
+from .lpips import LPIPSEngine, conv_keys
+
+
+class _LPIPSFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, module, targets, recon):
+        eng = module._bind(recon.device)
+        N, _, H, W = recon.shape
+        dec = ops.nchw_to_nhwc(recon.float().contiguous(), cpad=8)
+        g_dec = torch.zeros_like(dec) if recon.requires_grad else None
+        loss = eng.loss_and_grad(targets.float().contiguous(), dec, g_dec)
+        ctx.g_dec = g_dec
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.g_dec is None:
+            return None, None, None
+        grad = ops.nhwc_to_nchw(ctx.g_dec, 3) * g
+        return None, None, grad
+
+
+class VQLPIPS(nn.Module):
+    def __init__(self, state_dict=None):
+        super().__init__()
+        holder = nn.Module()
+        for key, ci, co, _ in conv_keys():
+            _register(holder, key + ".weight", torch.zeros(co, ci, 3, 3))
+            _register(holder, key + ".bias", torch.zeros(co))
+        for k, c in enumerate([64, 128, 256, 512, 512]):
+            _register(holder, f"lin{k}.model.1.weight", torch.zeros(1, c, 1, 1))
+        self.perceptual_loss = holder
+        for p in self.parameters():
+            p.requires_grad = False                       # lpips.py:63-64
+        self._engine = None
+        self._loaded = False
+        if state_dict is not None:
+            self.load_state_dict(state_dict)
+        self.eval()
+
+    def load_state_dict(self, state_dict, strict=False):
+        sd = {(k if k.startswith("perceptual_loss.") else "perceptual_loss." + k): torch.as_tensor(v)
+              for k, v in state_dict.items() if "scaling_layer" not in k}
+        out = super().load_state_dict(sd, strict=strict)
+        self._loaded, self._engine = True, None
+        return out
+
+    def _bind(self, device):
+        if not self._loaded:
+            raise RuntimeError("VQLPIPS has no weights: the reference downloads them (lpips.py:12-48); "
+                               "call load_state_dict with the VGG-16 / lin tensors first")
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("faceoff_amd.VQLPIPS computes only on an MI355X (cuda/HIP device): there is no CPU fallback")
+        if self._engine is None or self._engine.device != device:
+            sd = {k[len("perceptual_loss."):]: v for k, v in self.state_dict().items()}
+            self._engine = LPIPSEngine(sd, device)
+        return self._engine
+
+    def forward(self, targets, reconstructions):
+        return _LPIPSFunction.apply(self, targets.contiguous(), reconstructions.contiguous())
+
+    # trainer fast path: loss + gradient accumulated straight into the NHWC decoder-output gradient
+    def loss_and_grad(self, gt_nchw, dec_nhwc, g_dec, weight=1.0):
+        return self._bind(dec_nhwc.device).loss_and_grad(gt_nchw, dec_nhwc, g_dec, weight)
+
+
+def _register(root, dotted, tensor):
+    parts = dotted.split(".")
+    mod = root
+    for p in parts[:-1]:
+        if p not in mod._modules:
+            mod.add_module(p, nn.Module())
+        mod = mod._modules[p]
+    mod.register_parameter(parts[-1], nn.Parameter(tensor))

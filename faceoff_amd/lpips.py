@@ -1,0 +1,188 @@
+"""LPIPS / VGG-16 perceptual loss on the gfx950 kernels (reference models/lpips.py:51-161, loss.py:27-33).
+
+`LPIPSEngine` holds the frozen VGG-16 feature weights (torchvision layout `features[0:30]`, sliced as in
+lpips.py:125-134) and the five `lin` layers, runs both branches forward (ground truth: taps only;
+reconstruction: every activation kept), evaluates the five fused tap heads and back-propagates to the
+reconstruction only -- all LPIPS parameters are frozen (lpips.py:63-64,135-137), so the backward is
+13 dgrads + 4 pool backwards + 5 head backwards, no wgrad.
+
+Weights: `state_dict` keys follow the reference (`net.sliceK.<idx>.weight/bias`, `linK.model.1.weight`).
+The pretrained files (torchvision VGG-16, vgg.pth from heibox, lpips.py:12-22) are a network download and
+are NOT bundled: load them with `load_state_dict`; tests use seeded random weights (parity unpinned for the
+pretrained values).  fp32 throughout (a bf16 MFMA conv family is the next step).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib, ops
+
+VGG_CFG = [64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 512, 512, 512]
+SLICE_OF = {}
+for _s, (_a, _b) in enumerate([(0, 4), (4, 9), (9, 16), (16, 23), (23, 30)], start=1):
+    for _i in range(_a, _b):
+        SLICE_OF[_i] = _s
+TAP_CONVS = (1, 3, 6, 9, 12)            # conv ordinals whose ReLU output is relu1_2 ... relu5_3
+SHIFT = (-.030, -.088, -.188)           # lpips.py:99
+SCALE = (.458, .448, .450)              # lpips.py:100
+_F3 = C.c_float * 3
+
+
+def conv_keys():
+    """[(state_dict prefix, Cin, Cout, pool_before)] for the 13 convs."""
+    out, idx, cin, pool = [], 0, 3, False
+    for v in VGG_CFG:
+        if v == "M":
+            idx += 1
+            pool = True
+            continue
+        out.append((f"net.slice{SLICE_OF[idx]}.{idx}", cin, v, pool))
+        cin, pool = v, False
+        idx += 2
+    return out
+
+
+class LPIPSEngine:
+    def __init__(self, state_dict, device):
+        self.device = torch.device(device)
+        self.convs = conv_keys()
+        sd = {k: torch.as_tensor(v, dtype=torch.float32).to(self.device) for k, v in state_dict.items()}
+        self.w, self.b, self.wp, self.wpd = [], [], [], []
+        for i, (key, ci, co, _) in enumerate(self.convs):
+            w, b = sd[key + ".weight"].contiguous(), sd[key + ".bias"].contiguous()
+            self.w.append(w)
+            self.b.append(b)
+            if i == 0:   # Cin 3 -> 8 channels, KW 3 -> 4 taps (zeros) so that K = 3*4*8 = 96 is a multiple of 32
+                wpad = torch.zeros((co, 8, 3, 4), device=self.device)
+                wpad[:, :3, :, :3] = w
+                self.wp.append(ops.pack_conv(wpad))
+            else:
+                self.wp.append(ops.pack_conv(w))
+            self.wpd.append(ops.pack_conv_dgrad(w.reshape(co, ci, 9)))     # frozen weights: packed once
+        self.lin = [sd[f"lin{k}.model.1.weight"].reshape(-1).contiguous() for k in range(5)]
+        self.shift, self.scale = _F3(*SHIFT), _F3(*SCALE)
+        self.window_bytes = (1 << 31) - 1     # the conv kernel's buffer-descriptor window
+
+    # ------------------------------------------------------------------ pieces
+    def _prep(self, src, nhwc):
+        if nhwc:
+            N, H, W, _ = src.shape
+            ld = ops.ld_of(src)
+        else:
+            N, _, H, W = src.shape
+            ld = 0
+            src = src.contiguous()
+        y = torch.empty((N, H, W, 8), device=self.device)
+        _lib.call("fo_lpips_prep", ops._ptr(src), int(nhwc), ld, ops._ptr(y), N, H, W, self.shift, self.scale, ops._stream())
+        return y
+
+    def _conv(self, i, x):
+        _, ci, co, _ = self.convs[i]
+        N, H, W, _ = x.shape
+        y = torch.empty((N, H, W, co), device=self.device)
+        if i == 0:
+            ops.conv_igemm(x, self.wp[0], self.b[0], y, k=(1, 3, 4), pad=(0, 1, 1), cin=8, cout=co, flags=ops.FO_OUT_RELU)
+        else:
+            ops.conv_igemm(x, self.wp[i], self.b[i], y, k=(1, 3, 3), pad=(0, 1, 1), cin=ci, cout=co, flags=ops.FO_OUT_RELU)
+        return y
+
+    def _pool(self, x):
+        N, H, W, Cc = x.shape
+        y = torch.empty((N, H // 2, W // 2, Cc), device=self.device)
+        _lib.call("fo_maxpool2_fwd", ops._ptr(x), ops._ptr(y), N, H, W, Cc, ops._stream())
+        return y
+
+    def features(self, x8, keep_all):
+        """vgg16.forward (lpips.py:139-152).  Returns (taps[5], acts) where acts[i] = ReLU output of conv i and
+        acts['p<i>'] = pooled input of conv i (only when keep_all)."""
+        taps, acts, x = [], {}, x8
+        for i, (_, _, _, pool) in enumerate(self.convs):
+            if pool:
+                x = self._pool(x)
+                if keep_all:
+                    acts[f"p{i}"] = x
+            x = self._conv(i, x)
+            if keep_all:
+                acts[i] = x
+            if i in TAP_CONVS:
+                taps.append(x)
+        return taps, acts
+
+    # ------------------------------------------------------------------ loss (+ gradient into g_dec)
+    def loss_and_grad(self, gt_nchw, dec_nhwc, g_dec=None, weight=1.0, gscale=None):
+        """perceptual = LPIPS(gt, dec[..., :3]).mean() (loss.py:33).  If g_dec (NHWC, same pixel stride as dec)
+        is given, adds weight * gscale * d perceptual / d dec[..., :3] to it.  Returns the loss as a [1] tensor.
+        Frames are independent in LPIPS, so large batches run in frame chunks that keep every activation
+        inside the conv kernel's 2 GiB buffer-descriptor window (relu1_2 is 64 channels at full resolution)."""
+        N, H, W, _ = dec_nhwc.shape
+        max_frames = max(1, self.window_bytes // (H * W * 64 * 4))
+        if N > max_frames:
+            nchunks = -(-N // max_frames)
+            per = -(-N // nchunks)
+            if gscale is None:
+                gscale = torch.ones(1, device=self.device)
+            total = torch.zeros(1, device=self.device)
+            vals = []
+            for a in range(0, N, per):
+                b = min(N, a + per)
+                frac = (b - a) / N
+                part = self._loss_and_grad(gt_nchw[a:b], dec_nhwc[a:b], None if g_dec is None else g_dec[a:b], weight,
+                                           gscale * frac)
+                total += part * frac
+                vals.append(self.last_per_image)
+            self.last_per_image = torch.cat(vals)
+            return total
+        return self._loss_and_grad(gt_nchw, dec_nhwc, g_dec, weight, gscale)
+
+    def _loss_and_grad(self, gt_nchw, dec_nhwc, g_dec, weight, gscale):
+        x0 = self._prep(gt_nchw, nhwc=False)
+        x1 = self._prep(dec_nhwc, nhwc=True)
+        N, H, W, _ = x1.shape
+        taps0, _ = self.features(x0, keep_all=False)
+        taps1, acts = self.features(x1, keep_all=g_dec is not None)
+        val = torch.zeros(N, device=self.device)
+        for k in range(5):
+            n, h, w, c = taps1[k].shape
+            _lib.call("fo_lpips_tap_fwd", ops._ptr(taps0[k]), ops._ptr(taps1[k]), ops._ptr(self.lin[k]), ops._ptr(val),
+                      n, h, w, c, ops._stream())
+        loss = val.mean().reshape(1)
+        self.last_per_image = val
+        if g_dec is None:
+            return loss
+        if gscale is None:
+            gscale = torch.ones(1, device=self.device)
+        # ---- backward, deepest stage first
+        head = []
+        for k in range(5):
+            n, h, w, c = taps1[k].shape
+            g = torch.empty_like(taps1[k])
+            _lib.call("fo_lpips_tap_bwd", ops._ptr(taps0[k]), ops._ptr(taps1[k]), ops._ptr(self.lin[k]), ops._ptr(gscale),
+                      ops._ptr(g), n, h, w, c, ops._stream())
+            head.append(g)
+        g = head[4]                                     # grad wrt (pre-ReLU) output of conv 12
+        for i in range(12, -1, -1):
+            _, ci, co, pool = self.convs[i]
+            if i == 0:
+                gin = torch.zeros((N, H, W, 8), device=self.device)
+                ops.conv_igemm(g, self.wpd[0], None, gin, k=(1, 3, 3), pad=(0, 1, 1), cin=co, cout=3)
+                g = gin
+                break
+            if pool:                                     # conv i reads the pooled tensor: no ReLU mask on its dgrad
+                gp = torch.empty_like(acts[f"p{i}"])
+                ops.conv_igemm(g, self.wpd[i], None, gp, k=(1, 3, 3), pad=(0, 1, 1), cin=co, cout=ci)
+                x = acts[i - 1]                          # pre-pool tensor = ReLU output of conv i-1 = a LPIPS tap
+                tap = TAP_CONVS.index(i - 1)
+                gx = torch.empty_like(x)
+                n, h, w, c = x.shape
+                _lib.call("fo_maxpool2_bwd", ops._ptr(x), ops._ptr(gp), ops._ptr(head[tap]), ops._ptr(gx), n, h, w, c,
+                          ops._stream())
+                g = gx
+            else:
+                gin = torch.empty_like(acts[i - 1])
+                ops.conv_igemm(g, self.wpd[i], None, gin, k=(1, 3, 3), pad=(0, 1, 1), cin=co, cout=ci, mask=acts[i - 1])
+                g = gin
+        _lib.call("fo_lpips_prep_bwd", ops._ptr(g), 8, ops._ptr(g_dec), ops.ld_of(g_dec), C.c_int64(N * H * W), self.scale,
+                  ops._ptr(gscale), C.c_float(weight), ops._stream())
+        return loss

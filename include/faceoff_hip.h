@@ -137,6 +137,27 @@ int fo_mse_slice_fwd(const float* dec, int ldd, const float* gt_nchw, int N, int
 int fo_mse_slice_bwd(const float* dec, int ldd, const float* gt_nchw, int N, int H, int W, int C3,
                      const float* gscale, float inv_numel, float* gdec, int ldg, void* stream);
 
+/* ---------------------------------------------------------------- LPIPS / VGG-16 (models/lpips.py:80-161, loss.py:27-33)
+ * The 13 VGG convolutions (+ReLU) are fo_conv_igemm launches (first layer: Cin 3 padded to 8, KW padded
+ * 3->4 with zero taps so K is a multiple of 32); these are the kernels between them. */
+/* ScalingLayer (:96-103) + layout: y[N,H,W,8] = (x - shift)/scale on channels 0..2, zeros on 3..7.
+ * src: NCHW [N,3,H,W] (src_is_nhwc=0) or channels-last with pixel stride ld (decoder output).
+ * shift3 / scale3 are HOST pointers to 3 floats. */
+int fo_lpips_prep(const float* src, int src_is_nhwc, int ld, float* y, int N, int H, int W, const float* shift3,
+                  const float* scale3, void* stream);
+/* gdec[p][c] += weight * gscale[0] * g[p][c] / scale_c for c < 3 (backward of the scaling into the decoder-output grad) */
+int fo_lpips_prep_bwd(const float* g, int ldg, float* gdec, int ldd, int64_t npix, const float* scale3, const float* gscale,
+                      float weight, void* stream);
+/* nn.MaxPool2d(2,2) of torchvision vgg16.features[4,9,16,23] (lpips.py:118-134), dense [N,H,W,C]. */
+int fo_maxpool2_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream);
+/* gx = relu'(x) * ([x is the first maximum of its 2x2 window] * gy + add); add may be NULL (a LPIPS tap gradient). */
+int fo_maxpool2_bwd(const float* x, const float* gy, const float* add, float* gx, int N, int H, int W, int C, void* stream);
+/* One LPIPS tap (:85-89,155-161): val[n] += mean_hw sum_c lin_c (f0/(|f0|+eps) - f1/(|f1|+eps))^2, C in {64,128,256,512}. */
+int fo_lpips_tap_fwd(const float* f0, const float* f1, const float* lin, float* val, int N, int H, int W, int C, void* stream);
+/* Gradient of mean_n(sum of taps) wrt f1 (the reconstruction branch), times gscale[0], through f1's own ReLU. */
+int fo_lpips_tap_bwd(const float* f0, const float* f1, const float* lin, const float* gscale, float* gf1, int N, int H, int W,
+                     int C, void* stream);
+
 /* ---------------------------------------------------------------- optimiser + utilities */
 /* torch.optim.Adam defaults (train_faceoff_perceptual.py:190) over one flat parameter arena. */
 int fo_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,

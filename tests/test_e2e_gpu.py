@@ -141,3 +141,28 @@ def test_e2e_vs_oracle_ragged():
         assert np.abs(got - gref.numpy()).max() <= 5e-3 * max(rms, gref.abs().max().item()), n
     for k in eng.buffers:
         assert _rel(eng.buffers[k].cpu().numpy(), p[k].numpy()) < 2e-3, k
+
+
+def test_perceptual_step_vs_oracle():
+    """train_faceoff_perceptual.py:32-47,98-107 with the LPIPS term: recon + latent + perceptual, all gradients."""
+    from faceoff_amd.engine import VQVAEEngine
+    from faceoff_amd.loss import VQLPIPS
+    from faceoff_amd.trainer import FaceOffTrainer
+    from faceoff_amd.synth import make_vgg_lpips_state
+    from oracle import faceoff_oracle as O
+    B, T, H, W = 2, 2, 64, 64
+    sd = make_state_dict(0, codebook_scale=0.3, gain=2.0)
+    lp = make_vgg_lpips_state(7)
+    img, gt = make_batch(1234, B, T, H, W)
+    p = O.to_torch_state(sd)
+    r = O.train_step(torch.from_numpy(img), torch.from_numpy(gt), p, lpips_state={k: torch.from_numpy(v) for k, v in lp.items()})
+    eng = VQVAEEngine(sd, "cuda:0")
+    tr = FaceOffTrainer(eng, lr=3e-4, vqlpips=VQLPIPS(lp).cuda())
+    tr.optimizer.step = lambda grad_scale=1.0: None          # keep the gradients, skip the update
+    recon, latent, perceptual = tr.step(torch.from_numpy(img).cuda(), torch.from_numpy(gt).cuda())
+    np.testing.assert_allclose(recon.item(), r["recon"].item(), rtol=1e-3)
+    np.testing.assert_allclose(latent.item(), r["latent"].item(), rtol=1e-3)
+    np.testing.assert_allclose(perceptual.item(), r["perceptual"].item(), rtol=1e-3)
+    for n, gref in r["grads"].items():
+        got = eng.grads[n].cpu().numpy()
+        assert np.abs(got - gref.numpy()).max() <= 2e-3 * gref.abs().max().item(), n
