@@ -183,6 +183,7 @@ class LPIPSEngine:
                 gin = torch.empty_like(acts[i - 1])
                 ops.conv_igemm(g, self.wpd[i], None, gin, k=(1, 3, 3), pad=(0, 1, 1), cin=co, cout=ci, mask=acts[i - 1])
                 g = gin
+        one = torch.ones(1, device=self.device)          # gscale already went into the tap gradients
         _lib.call("fo_lpips_prep_bwd", ops._ptr(g), 8, ops._ptr(g_dec), ops.ld_of(g_dec), C.c_int64(N * H * W), self.scale,
-                  ops._ptr(gscale), C.c_float(weight), ops._stream())
+                  ops._ptr(one), C.c_float(weight), ops._stream())
         return loss
