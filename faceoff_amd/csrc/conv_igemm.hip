@@ -24,6 +24,7 @@
 //    incremental scalar arithmetic (no divisions in the loop);
 //  * temporal taps that fall entirely into clip padding are skipped per tile (T=5: 2/15 of Conv3d);
 //  * blockIdx is remapped so that each XCD's L2 sees a contiguous run of tiles (shared halos).
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -317,6 +318,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
   }
 }
 
+#include "conv_igemm3.inc"
+
 template <int BN, int WAVES_M, int WAVES_N, int TM, int TN>
 int launch(const ConvArgs& a, bool smallc, hipStream_t s) {
   const int grid = a.tilesM * a.tilesN;
@@ -381,6 +384,19 @@ extern "C" int fo_conv_igemm(const fo_conv_desc* d, const float* in, const float
   // BN by output channels (filters are packed with Cout rounded up to the same BN)
   if (d->Cout > 64) {
     a.tilesN = (d->Cout + 127) / 128;
+    // 3 taps per staged A tile, one workgroup per CU.  Measured equal to the generic kernel (2 workgroups per CU)
+    // on long-K Conv3d tiles and behind it on short-K 2-D tiles (exposed prologue/epilogue), so it is used for
+    // Conv3d launches whose tile count does not fill the generic kernel's 2 x CU slots in whole rounds
+    // (32x32 latents at C2: 1280 tiles = 2.5 rounds of 512, but exactly 5 rounds of 256: +15 %).
+    const char* force3 = getenv("FACEOFF_IGEMM3");
+    const long long tiles = (long long)a.tilesM * a.tilesN;
+    bool use3 = d->KD > 1 && tiles % (2 * fo_cu_count()) != 0 && tiles % fo_cu_count() == 0;
+    if (force3) use3 = atoi(force3) != 0;
+    if (!smallc && igemm3_eligible(d) && use3) {
+      hipLaunchKernelGGL((conv_igemm3_kernel<2, 2>), dim3(a.tilesM * a.tilesN), dim3(256), 0, s, a);
+      FO_CHECK_LAUNCH();
+      return FO_OK;
+    }
     return launch<128, 2, 2, 2, 2>(a, smallc, s);
   } else if (d->Cout > 32) {
     a.tilesN = 1;
