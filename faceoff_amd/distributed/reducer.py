@@ -20,17 +20,25 @@ class GradBucketReducer:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         # walk the arena from the end (first-completed layer) building buckets
-        self.buckets = []          # (lo, hi, trigger_layer)
+        self.buckets = []          # (lo, hi, last layer of the bucket in backward order)
+        self.members = []          # layer names per bucket
         hi = flat_grads.numel()
-        cur_hi = hi
+        cur_hi, cur = hi, []
         for name in reversed(layer_order):
             lo = offsets[name + ".weight"][0]
+            cur.append(name)
             if (cur_hi - lo) * 4 >= bucket_bytes:
                 self.buckets.append((lo, cur_hi, name))
-                cur_hi = lo
+                self.members.append(cur)
+                cur_hi, cur = lo, []
         if cur_hi > 0:
             self.buckets.append((0, cur_hi, layer_order[0]))
-        self._trigger = {t: i for i, (_, _, t) in enumerate(self.buckets)}
+            self.members.append(cur)
+        # a bucket fires when ALL its layers have reported (the engine overlaps independent chains, so layers
+        # do not finish strictly in arena order); every filter gradient is enqueued on one stream, so an event
+        # recorded when the last member reports covers the whole slice
+        self._bucket_of = {n: i for i, ms in enumerate(self.members) for n in ms}
+        self._pending = [set(ms) for ms in self.members]
         self._works = []
         self.cuda = flat_grads.is_cuda
         self.side = torch.cuda.Stream(device=flat_grads.device) if self.cuda and self.world > 1 else None
@@ -38,8 +46,11 @@ class GradBucketReducer:
 
     def layer_done(self, name):
         """grad_ready_hook of the engine: fire the bucket whose last layer just completed."""
-        i = self._trigger.get(name)
+        i = self._bucket_of.get(name)
         if i is None or self.world == 1:
+            return
+        self._pending[i].discard(name)
+        if self._pending[i]:
             return
         lo, hi, _ = self.buckets[i]
         self.launched.append(i)
@@ -67,6 +78,7 @@ class GradBucketReducer:
                 w.wait()
         self._works = []
         self.launched = []
+        self._pending = [set(ms) for ms in self.members]
 
 
 def fused_vq_allreduce(group=None):

@@ -52,6 +52,7 @@ class _Layer:
         self.wp = None     # forward filter
         self.wpd = None    # dgrad filter
         self.need_dgrad = True
+        self.engine = None
 
     # -- filter packing (every step: the optimiser rewrites the checkpoint-layout weights)
     def pack(self):
@@ -100,6 +101,24 @@ class _Layer:
 
     # -- filter + bias gradient
     def wgrad(self, x, g, T=1, in_relu=False):
+        """Enqueued on the engine's side stream when wgrad overlap is on: a layer's filter gradient and its data
+        gradient both depend only on g, and an igemm workgroup (73 KB LDS) and a wgrad workgroup (64 KB) fit one CU
+        together, so each kernel's tail and prologue are filled by the other's workgroups."""
+        eng = self.engine
+        if eng is not None and eng.wgrad_stream is not None:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            eng.wgrad_stream.wait_event(ev)
+            eng._keepalive.append((x, g))          # allocated on the main stream, read on the side stream
+            with torch.cuda.stream(eng.wgrad_stream):
+                self._wgrad(x, g, T, in_relu)
+                eng._ready(self.name)
+        else:
+            self._wgrad(x, g, T, in_relu)
+            if eng is not None:
+                eng._ready(self.name)
+
+    def _wgrad(self, x, g, T, in_relu):
         geo = self._geom()
         if self.kind == "convT":
             ops.conv_wgrad(x, g, self.gw, None, k=(1, 4, 4), stride=2, pad=(0, 1, 1), a_real=self.ci, b_real=self.co,
@@ -152,6 +171,19 @@ class VQVAEEngine:
             self.layers[name] = _Layer(name, kind, self.params[name + ".weight"], self.params[name + ".bias"],
                                        self.grads[name + ".weight"], self.grads[name + ".bias"])
         self.layers["enc_b.blocks.0"].need_dgrad = False   # the input image needs no gradient
+        for layer in self.layers.values():
+            layer.engine = self
+        import os as _os
+        self.wgrad_stream = None
+        if self.device.type == "cuda" and not _os.environ.get("FACEOFF_NO_WGRAD_OVERLAP"):
+            self.wgrad_stream = torch.cuda.Stream(device=self.device)
+        # second side stream: the bottom Conv3d chain (forward and backward) is independent of the top-level chain
+        # (enc_t / quantize_t / dec_t), whose launches are small (1280 tiles); run side by side, each fills the
+        # other's tails -- two igemm workgroups per CU fit whichever kernel they come from.
+        self.aux_stream = None
+        if self.device.type == "cuda" and not _os.environ.get("FACEOFF_NO_CHAIN_OVERLAP"):
+            self.aux_stream = torch.cuda.Stream(device=self.device)
+        self._keepalive = []
         if state_dict is not None:
             self.load_state_dict(state_dict)
         self.grad_ready_hook = None   # callable(layer_name) fired as soon as a layer's grads are enqueued
@@ -197,11 +229,9 @@ class VQVAEEngine:
         L = self.layers
         c3, c1 = L[prefix + ".conv.3"], L[prefix + ".conv.1"]
         c3.wgrad(hbuf, g_out)
-        self._ready(c3.name)
         g_h = torch.empty_like(hbuf)
         c3.dgrad(g_out, g_h, mask=hbuf)
         c1.wgrad(x, g_h, in_relu=True)
-        self._ready(c1.name)
         c1.dgrad(g_h, g_x, mask=x, add=g_out)
 
     def _ready(self, name):
@@ -236,9 +266,22 @@ class VQVAEEngine:
         N, h4, w4, _ = eb.shape
         _, h8, w8, _ = et.shape
         cat_b = self._new(N, h4, w4, 192)
-        c1 = self._new(N, h4, w4, 128); L["conv3d_encoded_b.conv3d.0.0"].fwd(eb, c1, T=T, flags=FO_OUT_RELU)
-        c2 = self._new(N, h4, w4, 128); L["conv3d_encoded_b.conv3d.1.0"].fwd(c1, c2, T=T, flags=FO_OUT_RELU)
-        L["conv3d_encoded_b.conv3d.2.0"].fwd(c2, cat_b[..., 64:192], T=T)
+        c1 = self._new(N, h4, w4, 128)
+        c2 = self._new(N, h4, w4, 128)
+
+        def bottom():
+            L["conv3d_encoded_b.conv3d.0.0"].fwd(eb, c1, T=T, flags=FO_OUT_RELU)
+            L["conv3d_encoded_b.conv3d.1.0"].fwd(c1, c2, T=T, flags=FO_OUT_RELU)
+            L["conv3d_encoded_b.conv3d.2.0"].fwd(c2, cat_b[..., 64:192], T=T)
+
+        if self.aux_stream is not None:      # joined in stage_quantize, right before quantize_conv_b reads cat_b
+            self.aux_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.aux_stream):
+                bottom()
+                S["_join_conv3d_b"] = torch.cuda.Event()
+                S["_join_conv3d_b"].record(self.aux_stream)
+        else:
+            bottom()
         d1 = self._new(N, h8, w8, 128); L["conv3d_encoded_t.conv3d.0.0"].fwd(et, d1, T=T, flags=FO_OUT_RELU)
         d2 = self._new(N, h8, w8, 128); L["conv3d_encoded_t.conv3d.1.0"].fwd(d1, d2, T=T, flags=FO_OUT_RELU)
         d3 = self._new(N, h8, w8, 128); L["conv3d_encoded_t.conv3d.2.0"].fwd(d2, d3, T=T)
@@ -256,6 +299,8 @@ class VQVAEEngine:
         u1 = self._new(N, h8, w8, 128); S["h_dt1"] = self._resblock_fwd("dec_t.blocks.1", u0, u1, False)
         u2 = self._new(N, h8, w8, 128); S["h_dt2"] = self._resblock_fwd("dec_t.blocks.2", u1, u2, True)
         L["dec_t.blocks.4"].fwd(u2, cat_b[..., 0:64])                      # torch.cat([dec_t, enc_b], 1) :271
+        if S.get("_join_conv3d_b") is not None:
+            torch.cuda.current_stream().wait_event(S.pop("_join_conv3d_b"))
         qb_in = self._new(N, h4, w4, 64); L["quantize_conv_b"].fwd(cat_b, qb_in)
         cat_d = self._new(N, h4, w4, 128)
         id_b, stats_b = self._quantize("quantize_b", qb_in, cat_d[..., 64:128], training)
@@ -312,74 +357,91 @@ class VQVAEEngine:
         new_like = torch.empty_like
         # ---- dec (Decoder stride 4)
         l6, l4 = L["dec.blocks.6"], L["dec.blocks.4"]
-        l6.wgrad(S["w1"], g_dec); self._ready(l6.name)
+        l6.wgrad(S["w1"], g_dec)
         g_w1 = new_like(S["w1"]); l6.dgrad(g_dec, g_w1, mask=S["w1"])
-        l4.wgrad(S["v2"], g_w1); self._ready(l4.name)
+        l4.wgrad(S["v2"], g_w1)
         g_v2 = new_like(S["v2"]); l4.dgrad(g_w1, g_v2, mask=S["v2"])
         g_v1 = new_like(S["v1"]); self._resblock_bwd("dec.blocks.2", g_v2, S["v1"], S["h_d2"], g_v1)
         g_v0 = new_like(S["v0"]); self._resblock_bwd("dec.blocks.1", g_v1, S["v0"], S["h_d1"], g_v0)
         l0 = L["dec.blocks.0"]
-        l0.wgrad(S["cat_d"], g_v0); self._ready(l0.name)
+        l0.wgrad(S["cat_d"], g_v0)
         g_cat_d = new_like(S["cat_d"]); l0.dgrad(g_v0, g_cat_d)
         # ---- upsample_t
         up = L["upsample_t"]
-        up.wgrad(S["quant_t"], g_cat_d[..., 0:64]); self._ready(up.name)
+        up.wgrad(S["quant_t"], g_cat_d[..., 0:64])
         g_quant_t = new_like(S["quant_t"]); up.dgrad(g_cat_d[..., 0:64], g_quant_t)
         # ---- quantize_b (straight-through + commitment) and quantize_conv_b
         g_qb_in = new_like(S["qb_in"])
         ops.vq_bwd(g_cat_d[..., 64:128], S["qb_in"], S["cat_d"][..., 64:128], g_diff, g_qb_in)
         qcb = L["quantize_conv_b"]
-        qcb.wgrad(S["cat_b"], g_qb_in); self._ready(qcb.name)
+        qcb.wgrad(S["cat_b"], g_qb_in)
         g_cat_b = new_like(S["cat_b"]); qcb.dgrad(g_qb_in, g_cat_b)
+        # ---- conv3d_encoded_b, all but its last dgrad (its output gradient is cat_b[..., 64:192]): on the second
+        # side stream beside the top-level chain below; joined where the two gradients of enc_b meet
+        kb2, kb1, kb0 = (L[f"conv3d_encoded_b.conv3d.{i}.0"] for i in (2, 1, 0))
+        g_c3 = g_cat_b[..., 64:192]
+        g_c2, g_c1 = new_like(S["c2"]), new_like(S["c1"])
+
+        def bottom3d():
+            kb2.wgrad(S["c2"], g_c3, T=T)
+            kb2.dgrad(g_c3, g_c2, T=T, mask=S["c2"])
+            kb1.wgrad(S["c1"], g_c2, T=T)
+            kb1.dgrad(g_c2, g_c1, T=T, mask=S["c1"])
+            kb0.wgrad(S["eb"], g_c1, T=T)
+
+        if self.aux_stream is not None:
+            self.aux_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.aux_stream):
+                bottom3d()
         # ---- dec_t
         dt4 = L["dec_t.blocks.4"]
-        dt4.wgrad(S["u2"], g_cat_b[..., 0:64]); self._ready(dt4.name)
+        dt4.wgrad(S["u2"], g_cat_b[..., 0:64])
         g_u2 = new_like(S["u2"]); dt4.dgrad(g_cat_b[..., 0:64], g_u2, mask=S["u2"])
         g_u1 = new_like(S["u1"]); self._resblock_bwd("dec_t.blocks.2", g_u2, S["u1"], S["h_dt2"], g_u1)
         g_u0 = new_like(S["u0"]); self._resblock_bwd("dec_t.blocks.1", g_u1, S["u0"], S["h_dt1"], g_u0)
         dt0 = L["dec_t.blocks.0"]
-        dt0.wgrad(S["quant_t"], g_u0); self._ready(dt0.name)
+        dt0.wgrad(S["quant_t"], g_u0)
         g_quant_t2 = new_like(S["quant_t"]); dt0.dgrad(g_u0, g_quant_t2, add=g_quant_t)   # fan-in of quant_t's two uses
         # ---- quantize_t and quantize_conv_t
         g_qt_in = new_like(S["qt_in"])
         ops.vq_bwd(g_quant_t2, S["qt_in"], S["quant_t"], g_diff, g_qt_in)
         qct = L["quantize_conv_t"]
-        qct.wgrad(S["d3"], g_qt_in); self._ready(qct.name)
+        qct.wgrad(S["d3"], g_qt_in)
         g_d3 = new_like(S["d3"]); qct.dgrad(g_qt_in, g_d3)
         # ---- conv3d_encoded_t
         k2, k1, k0 = (L[f"conv3d_encoded_t.conv3d.{i}.0"] for i in (2, 1, 0))
-        k2.wgrad(S["d2"], g_d3, T=T); self._ready(k2.name)
+        k2.wgrad(S["d2"], g_d3, T=T)
         g_d2 = new_like(S["d2"]); k2.dgrad(g_d3, g_d2, T=T, mask=S["d2"])
-        k1.wgrad(S["d1"], g_d2, T=T); self._ready(k1.name)
+        k1.wgrad(S["d1"], g_d2, T=T)
         g_d1 = new_like(S["d1"]); k1.dgrad(g_d2, g_d1, T=T, mask=S["d1"])
-        k0.wgrad(S["et"], g_d1, T=T); self._ready(k0.name)
+        k0.wgrad(S["et"], g_d1, T=T)
         g_t3 = new_like(S["et"]); k0.dgrad(g_d1, g_t3, T=T, mask=S["et"])     # mask = encoder's final ReLU
         # ---- enc_t
         g_t2 = new_like(S["t2"]); self._resblock_bwd("enc_t.blocks.4", g_t3, S["t2"], S["h_et4"], g_t2)
         g_t1 = new_like(S["t1"]); self._resblock_bwd("enc_t.blocks.3", g_t2, S["t1"], S["h_et3"], g_t1)
         e2, e0 = L["enc_t.blocks.2"], L["enc_t.blocks.0"]
-        e2.wgrad(S["t0"], g_t1); self._ready(e2.name)
+        e2.wgrad(S["t0"], g_t1)
         g_t0 = new_like(S["t0"]); e2.dgrad(g_t1, g_t0, mask=S["t0"])
-        e0.wgrad(S["eb"], g_t0); self._ready(e0.name)
+        e0.wgrad(S["eb"], g_t0)
         g_eb_t = new_like(S["eb"]); e0.dgrad(g_t0, g_eb_t, mask=S["eb"])      # grad via enc_t, through enc_b's final ReLU
-        # ---- conv3d_encoded_b (its output gradient is cat_b[..., 64:192])
-        k2, k1, k0 = (L[f"conv3d_encoded_b.conv3d.{i}.0"] for i in (2, 1, 0))
-        g_c3 = g_cat_b[..., 64:192]
-        k2.wgrad(S["c2"], g_c3, T=T); self._ready(k2.name)
-        g_c2 = new_like(S["c2"]); k2.dgrad(g_c3, g_c2, T=T, mask=S["c2"])
-        k1.wgrad(S["c1"], g_c2, T=T); self._ready(k1.name)
-        g_c1 = new_like(S["c1"]); k1.dgrad(g_c2, g_c1, T=T, mask=S["c1"])
-        k0.wgrad(S["eb"], g_c1, T=T); self._ready(k0.name)
-        g_a4 = new_like(S["eb"]); k0.dgrad(g_c1, g_a4, T=T, mask=S["eb"], add=g_eb_t)
+        # ---- join the bottom Conv3d chain; its last dgrad fans in the gradient that came through enc_t
+        if self.aux_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.aux_stream)
+        else:
+            bottom3d()
+        g_a4 = new_like(S["eb"]); kb0.dgrad(g_c1, g_a4, T=T, mask=S["eb"], add=g_eb_t)
         # ---- enc_b
         g_a3 = new_like(S["a3"]); self._resblock_bwd("enc_b.blocks.6", g_a4, S["a3"], S["h_eb6"], g_a3)
         g_a2 = new_like(S["a2"]); self._resblock_bwd("enc_b.blocks.5", g_a3, S["a2"], S["h_eb5"], g_a2)
         b4, b2, b0 = L["enc_b.blocks.4"], L["enc_b.blocks.2"], L["enc_b.blocks.0"]
-        b4.wgrad(S["a1"], g_a2); self._ready(b4.name)
+        b4.wgrad(S["a1"], g_a2)
         g_a1 = new_like(S["a1"]); b4.dgrad(g_a2, g_a1, mask=S["a1"])
-        b2.wgrad(S["a0"], g_a1); self._ready(b2.name)
+        b2.wgrad(S["a0"], g_a1)
         g_a0 = new_like(S["a0"]); b2.dgrad(g_a1, g_a0, mask=S["a0"])
-        b0.wgrad(S["x8"], g_a0); self._ready(b0.name)
+        b0.wgrad(S["x8"], g_a0)
+        if self.wgrad_stream is not None:          # join: every filter gradient is in the arena after this
+            torch.cuda.current_stream().wait_stream(self.wgrad_stream)
+            self._keepalive.clear()
 
     # ------------------------------------------------------------------ fused train step (bench / trainer fast path)
     def loss_and_backward(self, img_nchw, gt_nchw, T=None, latent_weight=1.0):

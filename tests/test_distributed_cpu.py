@@ -40,6 +40,15 @@ def _worker(outdir):
     res["fired"] = fired
     red.finish()
     res["flat_sum_ok"] = bool(torch.equal(flat, torch.arange(5000, dtype=torch.float32) * sum(range(1, world + 1))))
+    # the engine overlaps independent chains, so layers may report out of arena order: a bucket must wait for ALL members
+    flat.copy_(torch.arange(5000, dtype=torch.float32) * (rank + 1))
+    fired2 = []
+    for n in ("L2", "L4", "L0", "L3", "L1"):
+        red.layer_done(n)
+        fired2.append(list(red.launched))
+    red.finish()
+    res["fired_out_of_order"] = fired2
+    res["flat_sum_ok2"] = bool(torch.equal(flat, torch.arange(5000, dtype=torch.float32) * sum(range(1, world + 1))))
     stats = torch.ones(512 + 512 * 64) * (rank + 1)
     fused_vq_allreduce()(stats)
     res["vq_stats"] = float(stats[0])
@@ -61,6 +70,8 @@ def test_world2_gloo_helpers_and_bucket_reducer():
         assert x["buckets"] == [(3000, 5000, "L3"), (1000, 3000, "L1"), (0, 1000, "L0")]
         # L4 done -> nothing; L3 done -> bucket 0; L2 -> nothing new; L1 -> bucket 1; L0 -> bucket 2
         assert x["fired"] == [[], [0], [0], [0, 1], [0, 1, 2]]
+        # L2, L4 done -> nothing complete; L0 -> bucket 2 (= {L0}); L3 -> bucket 0 (= {L4, L3}); L1 -> bucket 1 (= {L2, L1})
+        assert x["fired_out_of_order"] == [[], [], [2], [2, 0], [2, 0, 1]] and x["flat_sum_ok2"]
     assert r[0]["reduce_dict"] == {"a": 0.5, "b": 2.0}          # averaged on rank 0 (reference :127-128)
 
 
