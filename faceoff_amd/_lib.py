@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FACEOFF_HIP_LIB", os.path.join(_HERE, "libfaceoff_hip.so"))   # override: A/B kernel builds
 
-FO_IN_RELU, FO_BIAS, FO_MASK, FO_ADD, FO_OUT_RELU = 1, 2, 4, 8, 16
+FO_IN_RELU, FO_BIAS, FO_MASK, FO_ADD, FO_OUT_RELU, FO_DEPTH2SPACE = 1, 2, 4, 8, 16, 32
 
 
 class FaceoffHipError(RuntimeError):
@@ -43,6 +43,7 @@ SIGNATURES = {
     "fo_pack_conv": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "fo_pack_conv_dgrad": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "fo_pack_convT_k4s2": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "fo_pack_convT_k4s2_fused": (_I, [_P, _P, _I, _I, _I, _P]),
     "fo_conv_igemm": (_I, [_D, _P, _P, _P, _P, _P, _P, _P]),
     "fo_wgrad_ws_bytes": (_L, [_D]),
     "fo_conv_wgrad": (_I, [_D, _P, _P, _P, _I, _I, _P, _P, _L, _P]),

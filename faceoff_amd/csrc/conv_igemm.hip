@@ -289,6 +289,29 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
   const int c4 = tid % C4;
   const int co = tile_n * BN + c4 * 4;
   const bool identity_pix = (d.ostride == 1) & (d.Hm == d.Hout) & (d.Wm == d.Wout);
+  if ((flags & FO_DEPTH2SPACE) && co < d.Cout) {
+    // fused 4-phase transposed conv: GEMM column co = phase*8 + channel; pixel m = (n, y, x) of the INPUT grid
+    // writes output pixel (2y + py, 2x + px), channels c..c+3 of an 8-float pixel (d.ophW real channels carry a bias)
+    const int ph = co >> 3, c = co & 7, py = ph >> 1, px = ph & 1;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (flags & FO_BIAS) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bv[e] = (c + e < d.ophW) ? a.bias[c + e] : 0.f;
+    }
+    for (int row = tid / C4; row < BM; row += RPP) {
+      const int m = tile_m * BM + row;
+      if (m >= a.M) break;
+      const int n = m / a.HWm;
+      const int rem = m - n * a.HWm;
+      const int y = rem / d.Wm;
+      const int x = rem - y * d.Wm;
+      const size_t opix = ((size_t)n * d.Hout + (2 * y + py)) * d.Wout + (2 * x + px);
+      f32x4 v = *reinterpret_cast<const f32x4*>(Cs + row * C_LD + c4 * 4) + bv;
+      if (flags & FO_OUT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      *reinterpret_cast<f32x4*>(a.out + opix * d.ldOut + c) = v;
+    }
+    return;
+  }
   if (co < d.Cout) {
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
     if (flags & FO_BIAS) {
@@ -347,8 +370,13 @@ extern "C" int fo_conv_igemm(const fo_conv_desc* d, const float* in, const float
   FO_REQUIRE(d->N > 0 && d->T > 0 && d->N % d->T == 0, FO_E_SHAPE, "conv: N=%d not a multiple of T=%d", d->N, d->T);
   FO_REQUIRE(d->Cin % 4 == 0 && d->ldIn % 4 == 0, FO_E_ALIGN, "conv: Cin/ldIn must be multiples of 4");
   FO_REQUIRE(fo_aligned16(in) && fo_aligned16(wp), FO_E_ALIGN, "conv: in/wp must be 16-byte aligned");
-  FO_REQUIRE(fo_aligned16(out) && d->ldOut % 4 == 0 && d->ldOut >= (d->Cout + 3) / 4 * 4, FO_E_ALIGN,
-             "conv: out must be 16-byte aligned with ldOut %% 4 == 0 and room for Cout rounded up to 4");
+  if (d->flags & FO_DEPTH2SPACE) {
+    FO_REQUIRE(d->Cout == 32 && d->ldOut >= 8 && d->ldOut % 4 == 0 && fo_aligned16(out) && d->Hout == 2 * d->Hm &&
+                   d->Wout == 2 * d->Wm && !(d->flags & (FO_MASK | FO_ADD)) && d->ophW >= 1 && d->ophW <= 8,
+               FO_E_SHAPE, "conv: FO_DEPTH2SPACE needs Cout == 32 (4 phases x 8), ldOut >= 8, a 2x output grid, no mask/add");
+  } else
+    FO_REQUIRE(fo_aligned16(out) && d->ldOut % 4 == 0 && d->ldOut >= (d->Cout + 3) / 4 * 4, FO_E_ALIGN,
+               "conv: out must be 16-byte aligned with ldOut %% 4 == 0 and room for Cout rounded up to 4");
   FO_REQUIRE(!(d->flags & FO_MASK) || (fo_aligned16(mask) && d->ldMask % 4 == 0), FO_E_ALIGN, "conv: mask alignment");
   FO_REQUIRE(!(d->flags & FO_ADD) || (fo_aligned16(add) && d->ldAdd % 4 == 0), FO_E_ALIGN, "conv: add alignment");
   FO_REQUIRE(!(d->flags & FO_BIAS) || bias, FO_E_SHAPE, "conv: FO_BIAS without bias");

@@ -49,6 +49,22 @@ __global__ void pack_convT_kernel(const float* __restrict__ w, float* __restrict
   }
 }
 
+// Fused 4-phase form of the same transposed conv for Co <= 8: wp[ph*8 + co][(dy+1)*3 + (dx+1)][ci], input offsets
+// dy, dx in {-1,0,1}.  Phase py uses dy = -1 (kh 3), 0 (kh 1) when py = 0 and dy = 0 (kh 2), +1 (kh 0) when py = 1.
+__global__ void pack_convT_fused_kernel(const float* __restrict__ w, float* __restrict__ wp, int Ci, int Co, int Cipad) {
+  const size_t total = (size_t)32 * 9 * Cipad;
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int ci = e % Cipad;
+    const int t = (e / Cipad) % 9;
+    const int col = e / ((size_t)Cipad * 9);
+    const int ph = col >> 3, co = col & 7, py = ph >> 1, px = ph & 1;
+    const int dy = t / 3 - 1, dx = t % 3 - 1;
+    const int kh = py == 0 ? (dy == -1 ? 3 : (dy == 0 ? 1 : -1)) : (dy == 0 ? 2 : (dy == 1 ? 0 : -1));
+    const int kw = px == 0 ? (dx == -1 ? 3 : (dx == 0 ? 1 : -1)) : (dx == 0 ? 2 : (dx == 1 ? 0 : -1));
+    wp[e] = (ci < Ci && co < Co && kh >= 0 && kw >= 0) ? w[(((size_t)ci * Co + co) * 4 + kh) * 4 + kw] : 0.f;
+  }
+}
+
 // [N,C,H,W] -> [N,H,W,ld] through an LDS tile so both sides are coalesced.
 __global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y, int C, int HW, int Cpad, int ld) {
   __shared__ float tile[64][33];  // [pixel][channel] up to 32 channels per pass
@@ -119,6 +135,14 @@ int fo_pack_convT_k4s2(const float* w, float* wp, int Ci, int Co, int Cipad, int
   FO_REQUIRE(Cipad >= Ci && Copad >= Co, FO_E_SHAPE, "pack_convT: bad padding");
   hipLaunchKernelGGL(pack_convT_kernel, dim3(grid_for((size_t)16 * Copad * Cipad)), dim3(256), 0, (hipStream_t)stream, w, wp,
                      Ci, Co, Cipad, Copad);
+  FO_CHECK_LAUNCH();
+  return FO_OK;
+}
+
+int fo_pack_convT_k4s2_fused(const float* w, float* wp, int Ci, int Co, int Cipad, void* stream) {
+  FO_REQUIRE(Cipad >= Ci && Co <= 8, FO_E_SHAPE, "pack_convT_fused: Co <= 8");
+  hipLaunchKernelGGL(pack_convT_fused_kernel, dim3(grid_for((size_t)32 * 9 * Cipad)), dim3(256), 0, (hipStream_t)stream, w, wp,
+                     Ci, Co, Cipad);
   FO_CHECK_LAUNCH();
   return FO_OK;
 }

@@ -57,7 +57,10 @@ class _Layer:
     # -- filter packing (every step: the optimiser rewrites the checkpoint-layout weights)
     def pack(self):
         if self.kind == "convT":
-            self.wp = ops.pack_convT(self.w, self.wp)
+            if self.co <= 8:                         # few output channels: all 4 phases as one 3x3 filter bank
+                self.wp = ops.pack_convT_fused(self.w, self.wp)
+            else:
+                self.wp = ops.pack_convT(self.w, self.wp)
             if self.need_dgrad:                      # dgrad = conv k4s2p1 with O:=ci, I:=co
                 self.wpd = ops.pack_conv(self.w, self.wpd)
         else:
@@ -79,7 +82,10 @@ class _Layer:
 
     # -- forward
     def fwd(self, x, out, T=1, flags=0, add=None):
-        if self.kind == "convT":
+        if self.kind == "convT" and self.co <= 8:
+            assert add is None
+            ops.convT_fused(x, self.wp, self.b, out, cin=self.cip, cout=self.co, flags=flags)
+        elif self.kind == "convT":
             ops.convT_phases(x, self.wp, self.b, out, cin=self.cip, cout=self.co, flags=flags, add=add)
         else:
             g = self._geom()

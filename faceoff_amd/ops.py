@@ -11,7 +11,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import ConvDesc, FO_IN_RELU, FO_BIAS, FO_MASK, FO_ADD, FO_OUT_RELU  # noqa: F401
+from ._lib import ConvDesc, FO_IN_RELU, FO_BIAS, FO_MASK, FO_ADD, FO_OUT_RELU, FO_DEPTH2SPACE  # noqa: F401
 
 
 class KernelProfiler:
@@ -113,6 +113,16 @@ def pack_convT(w, out=None):
     return out
 
 
+def pack_convT_fused(w, out=None):
+    """[Ci][Co<=8][4][4] -> [32 = 4 phases x 8][9][Cipad]: the transposed conv as one 3x3 filter bank (FO_DEPTH2SPACE)"""
+    Ci, Co = w.shape[:2]
+    Cip = pad_in(Ci)
+    if out is None:
+        out = torch.empty(32 * 9 * Cip, device=w.device, dtype=torch.float32)
+    _lib.call("fo_pack_convT_k4s2_fused", _ptr(w), _ptr(out), Ci, Co, Cip, _stream())
+    return out
+
+
 # ------------------------------------------------------------------ conv launches
 def _desc(**kw):
     d = ConvDesc()
@@ -148,6 +158,14 @@ def conv_igemm(x, wp, bias, out, *, T=1, k=(1, 3, 3), stride=1, pad=(0, 1, 1), c
     _lib.call("fo_conv_igemm", C.byref(d), _ptr(x), _ptr(wp), _ptr(bias), _ptr(mask), _ptr(add), _ptr(out), _stream())
     if prof is not None:
         prof.end()
+
+
+def convT_fused(x, wpf, bias, out, *, cin, cout, flags=0):
+    """k4 s2 p1 transposed conv with cout <= 8 as ONE launch: 3x3 conv over the input grid, 32 GEMM columns =
+    4 sub-pixel phases x 8 channels, depth-to-space in the epilogue (out: [N, 2H, 2W, >=8])."""
+    N, Hi, Wi, _ = x.shape
+    conv_igemm(x, wpf, bias, out, k=(1, 3, 3), stride=1, pad=(0, 1, 1), cin=cin, cout=32, flags=flags | FO_DEPTH2SPACE,
+               mgrid=(Hi, Wi), oph=(0, cout))
 
 
 def convT_phases(x, wp4, bias, out, *, cin, cout, flags=0, mask=None, add=None):

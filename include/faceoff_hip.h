@@ -44,6 +44,10 @@ extern "C" {
 #define FO_MASK 4      /* zero where mask[pixel][co] <= 0  (ReLU backward fused into a dgrad) */
 #define FO_ADD 8       /* + add[pixel][co]  (residual `out += input` :99, or gradient fan-in) */
 #define FO_OUT_RELU 16 /* relu() on the result (nn.ReLU after a conv, :110,112,119,126,145,151,186) */
+#define FO_DEPTH2SPACE 32 /* fused k4 s2 p1 ConvTranspose2d with few output channels (dec.blocks.6, 64 -> 6, :152): one
+                             3x3 conv over the INPUT grid whose 32 GEMM columns are 4 sub-pixel phases x 8 channels
+                             (fo_pack_convT_k4s2_fused); column ph*8+c of input pixel (y,x) lands at output pixel
+                             (2y+ph/2, 2x+ph%2), channel c.  desc: Cout=32, Hout=2*Hm, ldOut>=8, ophW = real channels */
 
 int fo_version(void);
 const char* fo_last_error(void);
@@ -69,6 +73,9 @@ int fo_pack_conv_dgrad(const float* w, float* wp, int O, int I, int taps, int Op
  * :150,152,160,215) -> wp[4 phases][Copad][2x2 taps][Cipad].  Also packs the dgrad of a k4 s2 p1
  * Conv2d when handed that conv's OIHW weight (Ci:=O, Co:=I). */
 int fo_pack_convT_k4s2(const float* w, float* wp, int Ci, int Co, int Cipad, int Copad, void* stream);
+/* Same weight, Co <= 8, as ONE 3x3 filter bank for FO_DEPTH2SPACE: wp[32 = 4 phases x 8][9 taps][Cipad], zero where
+ * a tap of the 3x3 input neighbourhood does not contribute to a phase (5 of 9 per phase). */
+int fo_pack_convT_k4s2_fused(const float* w, float* wp, int Ci, int Co, int Cipad, void* stream);
 
 /* ---------------------------------------------------------------- convolution (implicit GEMM, fp32 MFMA) */
 typedef struct fo_conv_desc {

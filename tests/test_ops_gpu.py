@@ -158,6 +158,11 @@ def test_conv_transpose_fwd_dgrad_wgrad(case):
     out = torch.zeros((N, 2 * H, 2 * W, Cs), device=dev)
     ops.convT_phases(xg, ops.pack_convT(wg), bg, out, cin=Ci, cout=Co)
     _close(out[..., :Co].permute(0, 3, 1, 2), y, what="convT fwd")
+    if Co <= 8:   # the fused single-launch form (4 phases x 8 channels as GEMM columns, depth-to-space epilogue)
+        out2 = torch.zeros((N, 2 * H, 2 * W, 8), device=dev)
+        ops.convT_fused(xg, ops.pack_convT_fused(wg), bg, out2, cin=Ci, cout=Co)
+        _close(out2[..., :Co].permute(0, 3, 1, 2), y, what="convT fused fwd")
+        assert out2[..., Co:].abs().max().item() == 0.0
     gyg = _nhwc(gy)
     gx = torch.empty((N, H, W, Ci), device=dev)
     ops.conv_igemm(gyg, ops.pack_conv(wg), None, gx, k=(1, 4, 4), stride=2, pad=(0, 1, 1), cin=ops.pad_in(Co), cout=Ci)
