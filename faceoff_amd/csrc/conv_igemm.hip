@@ -362,6 +362,24 @@ extern "C" int fo_debug_read_stamps(unsigned long long* out, int n) {
 }
 #endif
 
+// Which instantiation fo_conv_igemm launches for d: 128 / 64 / 32 = conv_igemm_kernel<BN>, 3 = conv_igemm3_kernel.
+static int pick_variant(const fo_conv_desc* d) {
+  if (d->Cout <= 32) return 32;
+  if (d->Cout <= 64) return 64;
+  // 3 taps per staged A tile, one workgroup per CU.  Measured equal to the generic kernel (2 workgroups per CU)
+  // on long-K Conv3d tiles and behind it on short-K 2-D tiles (exposed prologue/epilogue), so it is used for
+  // Conv3d launches whose tile count does not fill the generic kernel's 2 x CU slots in whole rounds
+  // (32x32 latents at C2: 1280 tiles = 2.5 rounds of 512, but exactly 5 rounds of 256: +15 %).
+  const long long M = (long long)d->N * d->Hm * d->Wm;
+  const long long tiles = ((M + BM - 1) / BM) * ((d->Cout + 127) / 128);
+  bool use3 = d->KD > 1 && tiles % (2 * fo_cu_count()) != 0 && tiles % fo_cu_count() == 0;
+  const char* force3 = getenv("FACEOFF_IGEMM3");
+  if (force3) use3 = atoi(force3) != 0;
+  return (d->Cin >= 32 && igemm3_eligible(d) && use3) ? 3 : 128;
+}
+
+extern "C" int fo_conv_igemm_variant(const fo_conv_desc* d) { return d ? pick_variant(d) : FO_E_SHAPE; }
+
 extern "C" int fo_conv_igemm(const fo_conv_desc* d, const float* in, const float* wp, const float* bias,
                              const float* mask, const float* add, float* out, void* stream) {
   ConvArgs a;
@@ -412,15 +430,7 @@ extern "C" int fo_conv_igemm(const fo_conv_desc* d, const float* in, const float
   // BN by output channels (filters are packed with Cout rounded up to the same BN)
   if (d->Cout > 64) {
     a.tilesN = (d->Cout + 127) / 128;
-    // 3 taps per staged A tile, one workgroup per CU.  Measured equal to the generic kernel (2 workgroups per CU)
-    // on long-K Conv3d tiles and behind it on short-K 2-D tiles (exposed prologue/epilogue), so it is used for
-    // Conv3d launches whose tile count does not fill the generic kernel's 2 x CU slots in whole rounds
-    // (32x32 latents at C2: 1280 tiles = 2.5 rounds of 512, but exactly 5 rounds of 256: +15 %).
-    const char* force3 = getenv("FACEOFF_IGEMM3");
-    const long long tiles = (long long)a.tilesM * a.tilesN;
-    bool use3 = d->KD > 1 && tiles % (2 * fo_cu_count()) != 0 && tiles % fo_cu_count() == 0;
-    if (force3) use3 = atoi(force3) != 0;
-    if (!smallc && igemm3_eligible(d) && use3) {
+    if (pick_variant(d) == 3) {
       hipLaunchKernelGGL((conv_igemm3_kernel<2, 2>), dim3(a.tilesM * a.tilesN), dim3(256), 0, s, a);
       FO_CHECK_LAUNCH();
       return FO_OK;

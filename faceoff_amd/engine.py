@@ -189,6 +189,7 @@ class VQVAEEngine:
         self.aux_stream = None
         if self.device.type == "cuda" and not _os.environ.get("FACEOFF_NO_CHAIN_OVERLAP"):
             self.aux_stream = torch.cuda.Stream(device=self.device)
+        self._streams = (self.wgrad_stream, self.aux_stream)
         self._keepalive = []
         if state_dict is not None:
             self.load_state_dict(state_dict)
@@ -196,6 +197,13 @@ class VQVAEEngine:
         self.vq_allreduce = None      # callable(stats tensor) -> summed over ranks (Quantize :63-64)
 
     # ------------------------------------------------------------------ state
+    def set_stream_overlap(self, on: bool) -> None:
+        """Run the filter-gradient kernels and the bottom Conv3d chain on their side streams (default) or, with
+        ``on=False``, everything in program order on the current stream (each kernel then has the GPU to itself --
+        what per-kernel timing needs)."""
+        torch.cuda.synchronize(self.device)
+        self.wgrad_stream, self.aux_stream = self._streams if on else (None, None)
+
     def load_state_dict(self, sd):
         for k, v in sd.items():
             t = torch.as_tensor(v, dtype=torch.float32).to(self.device)

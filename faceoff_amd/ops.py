@@ -150,7 +150,8 @@ def conv_igemm(x, wp, bias, out, *, T=1, k=(1, 3, 3), stride=1, pad=(0, 1, 1), c
               ldMask=ld_of(mask) if mask is not None else 0, ldAdd=ld_of(add) if add is not None else 0, flags=flags)
     prof = PROFILER
     if prof is not None:
-        kname = "conv_igemm_bn%d%s" % (128 if d.Cout > 64 else (64 if d.Cout > 32 else 32), "_smallc" if d.Cin < 32 else "")
+        var = _lib.load().fo_conv_igemm_variant(C.byref(d))
+        kname = "conv_igemm3" if var == 3 else "conv_igemm_bn%d%s" % (var, "_smallc" if d.Cin < 32 else "")
         flops = 2.0 * N * Hm * Wm * d.Cout * (k[0] * k[1] * k[2] * d.Cin)
         if prof.detail:
             kname += f" [{N}x{Hm}x{Wm} {d.Cin}->{d.Cout} k{k[0]}{k[1]}{k[2]} s{stride} f{flags}]"

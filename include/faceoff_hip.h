@@ -98,6 +98,10 @@ typedef struct fo_conv_desc {
 int fo_conv_igemm(const fo_conv_desc* d, const float* in, const float* wp, const float* bias,
                   const float* mask, const float* add, float* out, void* stream);
 
+/* Which kernel instantiation fo_conv_igemm launches for `d` (no launch): 128 / 64 / 32 = conv_igemm_kernel<BN>,
+ * 3 = conv_igemm3_kernel (Conv3d, one workgroup per CU).  For profilers that attribute time per kernel. */
+int fo_conv_igemm_variant(const fo_conv_desc* d);
+
 /* Filter gradient:  dW[a][b][tap] = sum_m P[m][a] * Q[qpix(m,tap)][b]   (checkpoint layout out).
  * Conv:  P = grad_out (a=Cout), Q = input (b=Cin)  -> OIHW / OIDHW.
  * ConvT: P = input (a=Cin), Q = grad_out (b=Cout)  -> [Ci][Co][kh][kw].

@@ -32,6 +32,8 @@ def label(name):
     if m:
         small = m.group(2) in ("true", "(bool)1", "1")
         return f"conv_igemm_bn{m.group(1)}" + ("_smallc" if small else "")
+    if "conv_igemm3_kernel" in name:
+        return "conv_igemm3"
     m = re.search(r"conv_wgrad_kernel<(\d+), *(\d+)", name)
     if m:
         return f"conv_wgrad_tile{m.group(1)}x{m.group(2)}"
