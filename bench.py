@@ -21,6 +21,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+BF16_MFMA_PEAK_TFLOPS = 2500.0         # dense (same table)
 FLOP_PER_FRAME = 64.1e9                # 63.77 GFLOP conv + 0.34 GFLOP VQ distance per frame
 
 
@@ -57,6 +58,8 @@ def main():
                     help="add the LPIPS/VGG-16 term (train_faceoff_perceptual.py path) in fp32 with seeded VGG weights; "
                          "NOT the BASELINE metric configuration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lpips-dtype", choices=("bf16", "fp32"), default="bf16",
+                    help="--perceptual: arithmetic of the LPIPS / VGG-16 branch (BASELINE config 3 = bf16)")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-launch HIP-event timing")
     ap.add_argument("--serial-streams", action="store_true",
                     help="run the step without side-stream overlap (what profiles/collect.sh traces: kernels run alone)")
@@ -87,7 +90,7 @@ def main():
     if args.perceptual:
         from faceoff_amd.loss import VQLPIPS
         from faceoff_amd.synth import make_vgg_lpips_state
-        vqlpips = VQLPIPS(make_vgg_lpips_state(7)).to(dev)
+        vqlpips = VQLPIPS(make_vgg_lpips_state(7), dtype=args.lpips_dtype).to(dev)
     trainer = FaceOffTrainer(eng, lr=3e-4, vqlpips=vqlpips)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     img = torch.rand((B * T, 6, H, H), device=dev, generator=gen) * 2 - 1       # U(-1,1): dataset.py:240-247
@@ -143,18 +146,23 @@ def main():
         "data": "synthetic U(-1,1) inputs resident in HBM; random-init weights (kaiming-uniform x2 gain, codebook N(0,0.3^2))",
         "config": {"workload": (f"C2: VQ-VAE-2 + Conv3d latent, {H}x{H}, T={T}, {B} clips/GPU, recon+VQ loss, fwd+bwd+Adam"
                                 if not args.perceptual else
-                                f"C3 in fp32: C2 + LPIPS/VGG-16 perceptual loss (seeded VGG weights), {H}x{H}, T={T}, {B} clips/GPU"),
+                                f"C3: C2 (fp32) + LPIPS/VGG-16 perceptual loss in {args.lpips_dtype} (seeded VGG weights), {H}x{H}, T={T}, {B} clips/GPU"),
                    "global_clips": B * world, "frames_per_step": B * T * world, "parallelism": f"dp{world}"},
         "loss": {"recon": round(recon.item(), 6), "latent": round(latent.item(), 6)},
-        "step_frac_of_fp32_mfma_roofline": round(fps / world * (FLOP_PER_FRAME + (120.3e9 if args.perceptual else 0.0))
-                                                 / (FP32_MFMA_PEAK_TFLOPS * 1e12), 4),
     }
+    # whole-step roofline: time the step's algorithmic FLOP would take at the dense MFMA peak of the type each part runs in
+    ideal_s = FLOP_PER_FRAME / (FP32_MFMA_PEAK_TFLOPS * 1e12)
+    if args.perceptual:
+        ideal_s += 120.3e9 / ((BF16_MFMA_PEAK_TFLOPS if args.lpips_dtype == "bf16" else FP32_MFMA_PEAK_TFLOPS) * 1e12)
+        out["dtype"] = "f32 (VQ-VAE) + %s (LPIPS)" % ("bf16" if args.lpips_dtype == "bf16" else "f32")
+    out["step_frac_of_mfma_roofline"] = round(ideal_s * fps / world, 4)
     if prof is not None:
         summ = prof.summary()
         dom = max(summ, key=lambda k: summ[k]["total_ms"])
         d = summ[dom]
-        out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(d["tflops"], 2), "peak": FP32_MFMA_PEAK_TFLOPS,
-                           "unit": "TFLOP/s", "frac": round(d["tflops"] / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+        peak = BF16_MFMA_PEAK_TFLOPS if dom.startswith("conv_bf16") else FP32_MFMA_PEAK_TFLOPS
+        out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(d["tflops"], 2), "peak": peak,
+                           "unit": "TFLOP/s", "frac": round(d["tflops"] / peak, 4), "traffic": None,
                            "launches_per_step": d["launches"] / args.steps, "avg_launch_ms": round(d["avg_ms"], 4),
                            "algorithmic_gflop_per_launch": round(d["flops_per_launch"] / 1e9, 3),
                            "share_of_step_time": round(d["total_ms"] / (ms_serial * args.steps), 4),

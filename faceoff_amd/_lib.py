@@ -64,6 +64,15 @@ SIGNATURES = {
     "fo_maxpool2_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "fo_lpips_tap_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "fo_lpips_tap_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "fo_pack_conv_bf16": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "fo_pack_conv_dgrad_bf16": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "fo_conv_igemm_bf16": (_I, [_D, _P, _P, _P, _P, _P, _P]),
+    "fo_lpips_prep_bf16": (_I, [_P, _I, _I, _P, _I, _I, _I, _P, _P, _P]),
+    "fo_lpips_prep_bwd_bf16": (_I, [_P, _P, _I, _L, _P, _P, _F, _P]),
+    "fo_maxpool2_fwd_bf16": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "fo_maxpool2_bwd_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "fo_lpips_tap_fwd_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "fo_lpips_tap_bwd_bf16": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "fo_adam_flat": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _F, _P]),
     "fo_zero": (_I, [_P, _L, _P]),
     "fo_relu": (_I, [_P, _I, _P, _I, _L, _I, _P]),

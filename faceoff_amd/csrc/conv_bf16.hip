@@ -1,0 +1,353 @@
+// Implicit-GEMM 2-D convolution on the gfx950 bf16 MFMA (v_mfma_f32_32x32x16_bf16): bf16 operands, fp32
+// accumulate, bf16 result.  This is the LPIPS / VGG-16 branch of the perceptual step at BASELINE config 3
+// (reference models/lpips.py:115-152: thirteen 3x3 stride-1 convs + ReLU, forward on two image batches and the
+// data gradient through one of them; all LPIPS parameters are frozen, lpips.py:63-64, so there is no wgrad).
+//
+//   out[m][co] = epilogue( sum_{tap,ci} in[ipix(m,tap)][ci] * wp[co][tap][ci] )          (channels-last)
+//
+// Same shape of kernel as conv_igemm.hip, re-balanced for a matrix pipe that is 16x faster per byte:
+//  * K-step = 64 bf16 = the same 128-B row as the fp32 kernel's 32 floats, so the LDS image (144-B padded rows,
+//    conflict-free ds_read_b128 / ds_write_b128) and the 16-B-per-lane bounds-checked buffer loads carry over;
+//    one ds_read_b128 is exactly one lane's 8-element MFMA fragment (k = 8*(lane>>5) .. +7);
+//  * a K-step is only 16 MFMAs x 32 cycles per wave -- far shorter than an L2 round trip -- so the global loads
+//    run TWO K-steps ahead through a two-slot register ring (loads of step n+2 are issued while step n is on the
+//    matrix pipe and step n+1 sits in the other slot); LDS is double buffered behind it;
+//  * zero padding = out-of-range buffer offset (no branch, no select), tap validity is a per-row bitmask;
+//  * the fp32 accumulators are transposed through LDS so that bias / ReLU / ReLU-mask / bf16 rounding / stores
+//    are 8 channels = 16 B per lane, whole rows per wave.
+// Cin must be a multiple of 64, or 8 (the RGB input padded to 8 channels: one 16-B load = one tap of one pixel,
+// K = taps rounded up to a multiple of 8, times 8).
+#include <stdlib.h>
+#include <algorithm>
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+struct ConvArgsH {
+  fo_conv_desc d;
+  const void* in;
+  const void* wp;
+  const float* bias;
+  const void* mask;
+  void* out;
+  int M, HWm, tilesM, tilesN;
+  int cinChunks;   // Cin/64 ; SMALLC: unused
+  int Ktot;        // elements per filter row (multiple of 64)
+  int ksteps;      // Ktot/64
+  unsigned inBytes, wpBytes;
+};
+
+constexpr int BM = 128;
+constexpr int ROWB = 144;            // LDS row: 128 B of data + 16 B pad
+constexpr unsigned OOB = 0x80000000u;
+
+__device__ __forceinline__ u32x4 bufload16(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+}
+
+template <int BN, int WAVES_M, int WAVES_N, int TM, int TN, bool SMALLC>
+__global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvArgsH a) {
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+  static_assert(WAVES_M * TM * 32 == BM && WAVES_N * TN * 32 == BN, "tile");
+  constexpr int BROWS = BN / 32;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * (BM + BN) * ROWB];
+  unsigned char* As0 = lds;
+  unsigned char* Bs0 = lds + 2 * BM * ROWB;
+
+  const fo_conv_desc& d = a.d;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+  const int logical = fo_xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_n = logical % a.tilesN;
+  const int tile_m = logical / a.tilesN;
+  const int ntaps = d.KH * d.KW;
+
+  // ---- loader coordinates: thread covers rows lrow + 32*i, 16 bytes (8 elements) at byte column lcolB
+  const int lrow = tid >> 3;
+  const int lcolB = (tid & 7) * 16;
+  int rowoff[4];
+  unsigned tapmask[4];
+  int py[4], px[4], pbase[4];
+  bool pv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = tile_m * BM + lrow + 32 * i;
+    pv[i] = m < a.M;
+    const int mm = pv[i] ? m : 0;
+    const int n = mm / a.HWm;
+    const int rem = mm - n * a.HWm;
+    const int y = rem / d.Wm;
+    const int x = rem - y * d.Wm;
+    py[i] = y * d.stride - d.padH;
+    px[i] = x * d.stride - d.padW;
+    pbase[i] = (n * d.Hin + py[i]) * d.Win + px[i];      // pixel index of tap (0,0)
+    rowoff[i] = pbase[i] * d.ldIn * 2 + lcolB;
+    unsigned mk = 0;
+    if (!SMALLC) {
+      for (int tp = 0; tp < ntaps; ++tp) {
+        const int kh = tp / d.KW, kw = tp - kh * d.KW;
+        const bool ok = pv[i] & ((unsigned)(py[i] + kh) < (unsigned)d.Hin) & ((unsigned)(px[i] + kw) < (unsigned)d.Win);
+        mk |= (ok ? 1u : 0u) << tp;
+      }
+    }
+    tapmask[i] = mk;
+  }
+
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in), 0, a.inBytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rwp = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wp), 0, a.wpBytes, 0x00020000);
+  const unsigned wrow = (unsigned)(((size_t)(tile_n * BN + lrow) * a.Ktot) * 2 + lcolB);
+  const unsigned wstride32 = (unsigned)((size_t)32 * a.Ktot * 2);
+
+  // incremental (tap, chunk) walk of the next step to load (wave-uniform scalars)
+  int ld_step = 0, ld_tap = 0, ld_kh = 0, ld_kw = 0, ld_chunk = 0;
+  // SMALLC: this thread's tap of the step being loaded
+  int sc_off = 0, sc_kh = 0, sc_kw = 0;
+  bool sc_ok = false;
+
+  u32x4 ra[2][4], rb[2][BROWS];
+
+  auto load_step = [&](int slot) {
+    if (SMALLC) {
+      const int tap = ld_step * 8 + (tid & 7);
+      sc_kh = tap / d.KW;
+      sc_kw = tap - sc_kh * d.KW;
+      sc_ok = tap < ntaps;
+      sc_off = (sc_kh * d.Win + sc_kw) * d.ldIn * 2;
+    }
+    const int stepoff = ((ld_kh * d.Win + ld_kw) * d.ldIn + ld_chunk * 64) * 2;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      if (SMALLC) {
+        const bool ok = sc_ok & pv[s] & ((unsigned)(py[s] + sc_kh) < (unsigned)d.Hin) & ((unsigned)(px[s] + sc_kw) < (unsigned)d.Win);
+        ra[slot][s] = bufload16(rin, ok ? (unsigned)(pbase[s] * d.ldIn * 2 + sc_off) : OOB);
+      } else {
+        const unsigned pad = (((tapmask[s] >> ld_tap) & 1u) - 1u) & OOB;     // padding tap -> beyond the descriptor -> zeros
+        ra[slot][s] = bufload16(rin, (unsigned)(rowoff[s] + stepoff) | pad);
+      }
+      if (s < BROWS) rb[slot][s < BROWS ? s : 0] = bufload16(rwp, ld_step < a.ksteps ? wrow + s * wstride32 + ld_step * 128 : OOB);
+    }
+    ++ld_step;
+    if (!SMALLC && ++ld_chunk == a.cinChunks) {
+      ld_chunk = 0;
+      ++ld_tap;
+      if (++ld_kw == d.KW) { ld_kw = 0; ++ld_kh; }
+    }
+  };
+  auto store_step = [&](int slot, int buf) {
+    unsigned char* As = As0 + buf * BM * ROWB;
+    unsigned char* Bs = Bs0 + buf * BN * ROWB;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      *reinterpret_cast<u32x4*>(As + (lrow + 32 * s) * ROWB + lcolB) = ra[slot][s];
+      if (s < BROWS) *reinterpret_cast<u32x4*>(Bs + (lrow + 32 * s) * ROWB + lcolB) = rb[slot][s < BROWS ? s : 0];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  auto compute = [&](int buf) {
+    const unsigned char* As = As0 + buf * BM * ROWB + (wm * TM * 32 + l31) * ROWB + half * 16;
+    const unsigned char* Bs = Bs0 + buf * BN * ROWB + (wn * TN * 32 + l31) * ROWB + half * 16;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      bf16x8 fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(As + i * 32 * ROWB + s * 32);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(Bs + j * 32 * ROWB + s * 32);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  // ring slot 0 <- step 0, slot 1 <- step 1; LDS buffer 0 <- step 0
+  load_step(0);
+  load_step(1);
+  store_step(0, 0);
+  __syncthreads();
+  const int nsteps = a.ksteps;
+  for (int step = 0; step < nsteps; step += 2) {
+    load_step(0);                 // step + 2
+    compute(0);                   // step
+    store_step(1, 1);             // step + 1
+    __syncthreads();
+    if (step + 1 >= nsteps) break;
+    load_step(1);                 // step + 3
+    compute(1);                   // step + 1
+    store_step(0, 0);             // step + 2
+    __syncthreads();
+  }
+
+  // ---- epilogue through LDS (fp32 tile), 8 channels = 16 B of bf16 per lane
+  constexpr int C_LD = BN + 4;
+  static_assert(BM * C_LD * 4 <= 2 * (BM + BN) * ROWB, "C tile must fit the staging LDS");
+  float* Cs = reinterpret_cast<float*>(lds);
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        Cs[row * C_LD + (wn * TN + j) * 32 + l31] = acc[i][j][r];
+      }
+  __syncthreads();
+  const int flags = d.flags;
+  constexpr int C8 = BN / 8;
+  constexpr int RPP = 256 / C8;
+  const int c8 = tid % C8;
+  const int co = tile_n * BN + c8 * 8;
+  if (co >= d.Cout) return;
+  float bv[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bv[e] = ((flags & FO_BIAS) && co + e < d.Cout) ? a.bias[co + e] : 0.f;
+  const bool identity_pix = (d.ostride == 1) & (d.Hm == d.Hout) & (d.Wm == d.Wout);
+  __bf16* out = reinterpret_cast<__bf16*>(a.out);
+  const __bf16* mask = reinterpret_cast<const __bf16*>(a.mask);
+  for (int row = tid / C8; row < BM; row += RPP) {
+    const int m = tile_m * BM + row;
+    if (m >= a.M) break;
+    size_t opix = m;
+    if (!identity_pix) {
+      const int n = m / a.HWm;
+      const int rem = m - n * a.HWm;
+      const int y = rem / d.Wm;
+      const int x = rem - y * d.Wm;
+      opix = ((size_t)n * d.Hout + (y * d.ostride + d.ophH)) * d.Wout + (x * d.ostride + d.ophW);
+    }
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(Cs + row * C_LD + c8 * 8);
+    const f32x4 v1 = *reinterpret_cast<const f32x4*>(Cs + row * C_LD + c8 * 8 + 4);
+    float v[8] = {v0.x + bv[0], v0.y + bv[1], v0.z + bv[2], v0.w + bv[3], v1.x + bv[4], v1.y + bv[5], v1.z + bv[6], v1.w + bv[7]};
+    if (flags & FO_MASK) {
+      const bf16x8 mk = *reinterpret_cast<const bf16x8*>(mask + opix * d.ldMask + co);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (float)mk[e] > 0.f ? v[e] : 0.f;
+    }
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (__bf16)((flags & FO_OUT_RELU) ? fmaxf(v[e], 0.f) : v[e]);
+    *reinterpret_cast<bf16x8*>(out + opix * d.ldOut + co) = o;
+  }
+}
+
+template <int BN, int WAVES_M, int WAVES_N, int TM, int TN>
+int launch(const ConvArgsH& a, bool smallc, hipStream_t s) {
+  const int grid = a.tilesM * a.tilesN;
+  if (smallc)
+    hipLaunchKernelGGL((conv_bf16_kernel<BN, WAVES_M, WAVES_N, TM, TN, true>), dim3(grid), dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL((conv_bf16_kernel<BN, WAVES_M, WAVES_N, TM, TN, false>), dim3(grid), dim3(256), 0, s, a);
+  FO_CHECK_LAUNCH();
+  return FO_OK;
+}
+
+// wp[o][t][i] = bf16(w[o][i][t])  (o < O, i < I, t < taps; zero elsewhere), t < tapsPad
+__global__ void pack_conv_bf16_kernel(const float* __restrict__ w, __bf16* __restrict__ wp, int O, int I, int taps, int Opad,
+                                      int Ipad, int tapsPad) {
+  const size_t total = (size_t)Opad * tapsPad * Ipad;
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int i = e % Ipad;
+    const int t = (e / Ipad) % tapsPad;
+    const int o = e / ((size_t)Ipad * tapsPad);
+    wp[e] = (__bf16)((o < O && i < I && t < taps) ? w[((size_t)o * I + i) * taps + t] : 0.f);
+  }
+}
+
+// wp[i][t][o] = bf16(w[o][i][taps-1-t])  (stride-1 dgrad: flipped taps, swapped channels)
+__global__ void pack_conv_dgrad_bf16_kernel(const float* __restrict__ w, __bf16* __restrict__ wp, int O, int I, int taps,
+                                            int Opad, int Ipad) {
+  const size_t total = (size_t)Ipad * taps * Opad;
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int o = e % Opad;
+    const int t = (e / Opad) % taps;
+    const int i = e / ((size_t)Opad * taps);
+    wp[e] = (__bf16)((o < O && i < I) ? w[((size_t)o * I + i) * taps + (taps - 1 - t)] : 0.f);
+  }
+}
+
+inline int grid_for(size_t total) { return (int)std::min<size_t>((total + 255) / 256, 8192); }
+
+}  // namespace
+
+extern "C" {
+
+int fo_pack_conv_bf16(const float* w, void* wp, int O, int I, int taps, int Opad, int Ipad, int tapsPad, void* stream) {
+  FO_REQUIRE(Opad >= O && Ipad >= I && taps > 0 && tapsPad >= taps, FO_E_SHAPE, "pack_conv_bf16: bad padding");
+  hipLaunchKernelGGL(pack_conv_bf16_kernel, dim3(grid_for((size_t)Opad * tapsPad * Ipad)), dim3(256), 0, (hipStream_t)stream, w,
+                     reinterpret_cast<__bf16*>(wp), O, I, taps, Opad, Ipad, tapsPad);
+  FO_CHECK_LAUNCH();
+  return FO_OK;
+}
+
+int fo_pack_conv_dgrad_bf16(const float* w, void* wp, int O, int I, int taps, int Opad, int Ipad, void* stream) {
+  FO_REQUIRE(Opad >= O && Ipad >= I && taps > 0, FO_E_SHAPE, "pack_conv_dgrad_bf16: bad padding");
+  hipLaunchKernelGGL(pack_conv_dgrad_bf16_kernel, dim3(grid_for((size_t)Opad * taps * Ipad)), dim3(256), 0, (hipStream_t)stream,
+                     w, reinterpret_cast<__bf16*>(wp), O, I, taps, Opad, Ipad);
+  FO_CHECK_LAUNCH();
+  return FO_OK;
+}
+
+int fo_conv_igemm_bf16(const fo_conv_desc* d, const void* in, const void* wp, const float* bias, const void* mask, void* out,
+                       void* stream) {
+  ConvArgsH a;
+  a.d = *d;
+  a.in = in; a.wp = wp; a.bias = bias; a.mask = mask; a.out = out;
+  FO_REQUIRE(d->N > 0 && d->KD == 1 && d->padD == 0, FO_E_SHAPE, "conv_bf16: 2-D only (KD == 1)");
+  FO_REQUIRE(!(d->flags & ~(FO_BIAS | FO_MASK | FO_OUT_RELU)), FO_E_SHAPE, "conv_bf16: flags other than BIAS|MASK|OUT_RELU");
+  FO_REQUIRE(d->ldIn % 8 == 0 && d->ldOut % 8 == 0 && fo_aligned16(in) && fo_aligned16(wp) && fo_aligned16(out), FO_E_ALIGN,
+             "conv_bf16: 16-byte alignment (ld %% 8 == 0)");
+  FO_REQUIRE(d->ldOut >= (d->Cout + 7) / 8 * 8, FO_E_ALIGN, "conv_bf16: ldOut must hold Cout rounded up to 8");
+  FO_REQUIRE(!(d->flags & FO_MASK) || (mask && fo_aligned16(mask) && d->ldMask % 8 == 0), FO_E_ALIGN, "conv_bf16: mask alignment");
+  FO_REQUIRE(!(d->flags & FO_BIAS) || bias, FO_E_SHAPE, "conv_bf16: FO_BIAS without bias");
+  const int taps = d->KH * d->KW;
+  FO_REQUIRE(taps >= 1 && taps <= 31, FO_E_SHAPE, "conv_bf16: at most 31 taps (got %d)", taps);
+  const bool smallc = d->Cin < 64;
+  if (smallc) {
+    FO_REQUIRE(d->Cin == 8 && d->ldIn == 8, FO_E_SHAPE, "conv_bf16: small Cin must be 8 with 16-byte pixels (got %d)", d->Cin);
+    a.Ktot = (taps + 7) / 8 * 64;
+    a.cinChunks = 1;
+  } else {
+    FO_REQUIRE(d->Cin % 64 == 0, FO_E_SHAPE, "conv_bf16: Cin=%d must be a multiple of 64 (or 8)", d->Cin);
+    a.Ktot = taps * d->Cin;
+    a.cinChunks = d->Cin / 64;
+  }
+  a.ksteps = a.Ktot / 64;
+  a.HWm = d->Hm * d->Wm;
+  const long long M = (long long)d->N * a.HWm;
+  FO_REQUIRE(M > 0 && M < (1ll << 31), FO_E_SHAPE, "conv_bf16: M out of range");
+  a.M = (int)M;
+  a.tilesM = (a.M + BM - 1) / BM;
+  const unsigned long long inBytes = (((unsigned long long)d->N * d->Hin * d->Win - 1) * d->ldIn + d->Cin) * 2ull;
+  const int opad = d->Cout > 64 ? (d->Cout + 127) / 128 * 128 : (d->Cout > 32 ? 64 : 32);
+  const unsigned long long wpBytes = (unsigned long long)opad * a.Ktot * 2ull;
+  FO_REQUIRE(inBytes < (1ull << 31) && wpBytes < (1ull << 31), FO_E_SHAPE, "conv_bf16: tensor exceeds the 2 GiB buffer-descriptor window");
+  a.inBytes = (unsigned)inBytes;
+  a.wpBytes = (unsigned)wpBytes;
+  hipStream_t s = (hipStream_t)stream;
+  if (d->Cout > 64) {
+    a.tilesN = (d->Cout + 127) / 128;
+    return launch<128, 2, 2, 2, 2>(a, smallc, s);
+  } else if (d->Cout > 32) {
+    a.tilesN = 1;
+    return launch<64, 2, 2, 2, 1>(a, smallc, s);
+  } else {
+    a.tilesN = 1;
+    return launch<32, 4, 1, 1, 1>(a, smallc, s);
+  }
+}
+}

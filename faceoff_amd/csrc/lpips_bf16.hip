@@ -1,0 +1,294 @@
+// bf16 forms of the LPIPS support kernels (see lpips.hip for the fp32 ones and the reference citations:
+// models/lpips.py:80-161, loss.py:27-33).  Activations and their gradients are stored as bf16, channels-last,
+// 8 channels = 16 B per lane; all arithmetic is fp32 and each result is rounded to bf16 once (RNE).
+#include <algorithm>
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+template <int W>
+__device__ __forceinline__ float group_sum(float v) {   // sum over aligned groups of W lanes
+#pragma unroll
+  for (int o = W / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// ScalingLayer (lpips.py:96-103) + layout + rounding: y[p][c] = bf16((x_c - shift_c) / scale_c), c < 3; 0 for c in 3..7
+__global__ void lpips_prep_bf16_kernel(const float* __restrict__ src, int src_is_nhwc, int ld, bf16x8* __restrict__ y, int HW,
+                                       long long npix, f32x4 shift, f32x4 inv_scale) {
+  for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < npix; p += (long long)gridDim.x * blockDim.x) {
+    f32x4 v;
+    if (src_is_nhwc) {
+      v = *reinterpret_cast<const f32x4*>(src + p * ld);
+    } else {
+      const long long n = p / HW;
+      const int hw = (int)(p - n * HW);
+      const float* s = src + n * 3 * (long long)HW + hw;
+      v = f32x4{s[0], s[(long long)HW], s[2 * (long long)HW], 0.f};
+    }
+    const f32x4 o = (v - shift) * inv_scale;
+    bf16x8 r;
+    r[0] = (__bf16)o.x; r[1] = (__bf16)o.y; r[2] = (__bf16)o.z;
+#pragma unroll
+    for (int e = 3; e < 8; ++e) r[e] = (__bf16)0.f;
+    y[p] = r;
+  }
+}
+
+// gdec[p][c] += weight * gscale * g[p][c] / scale_c  (c < 3); g is the bf16 [p][8] image gradient
+__global__ void lpips_prep_bwd_bf16_kernel(const bf16x8* __restrict__ g, float* __restrict__ gdec, int ldd, long long npix,
+                                           f32x4 inv_scale, const float* __restrict__ gscale, float weight) {
+  const float k = weight * gscale[0];
+  for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < npix; p += (long long)gridDim.x * blockDim.x) {
+    const bf16x8 gv = g[p];
+    f32x4 d = *reinterpret_cast<f32x4*>(gdec + p * ldd);
+    d.x += k * (float)gv[0] * inv_scale.x; d.y += k * (float)gv[1] * inv_scale.y; d.z += k * (float)gv[2] * inv_scale.z;
+    *reinterpret_cast<f32x4*>(gdec + p * ldd) = d;
+  }
+}
+
+__global__ void maxpool2_fwd_bf16_kernel(const bf16x8* __restrict__ x, bf16x8* __restrict__ y, int N, int Ho, int Wo, int C8) {
+  const long long total = (long long)N * Ho * Wo * C8;
+  const int W = Wo * 2;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(e % C8);
+    long long q = e / C8;
+    const int xo = (int)(q % Wo); q /= Wo;
+    const int yo = (int)(q % Ho);
+    const long long n = q / Ho;
+    const bf16x8* base = x + ((n * (2 * Ho) + 2 * yo) * W + 2 * xo) * C8 + c;
+    const bf16x8 a = base[0], b = base[C8], cc = base[(long long)W * C8], d = base[(long long)W * C8 + C8];
+    bf16x8 m;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) m[k] = (__bf16)fmaxf(fmaxf((float)a[k], (float)b[k]), fmaxf((float)cc[k], (float)d[k]));
+    y[e] = m;
+  }
+}
+
+// gx = relu'(x) * ( [x is the FIRST maximum of its window] * gy + add ), rounded once
+__global__ void maxpool2_bwd_bf16_kernel(const bf16x8* __restrict__ x, const bf16x8* __restrict__ gy, const bf16x8* __restrict__ add,
+                                         bf16x8* __restrict__ gx, int N, int Ho, int Wo, int C8) {
+  const long long total = (long long)N * Ho * Wo * C8;
+  const int W = Wo * 2;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(e % C8);
+    long long q = e / C8;
+    const int xo = (int)(q % Wo); q /= Wo;
+    const int yo = (int)(q % Ho);
+    const long long n = q / Ho;
+    const long long i00 = ((n * (2 * Ho) + 2 * yo) * W + 2 * xo) * C8 + c;
+    const long long idx[4] = {i00, i00 + C8, i00 + (long long)W * C8, i00 + (long long)W * C8 + C8};
+    bf16x8 v[4];
+    float o[4][8];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) v[t] = x[idx[t]];
+    const bf16x8 g = gy[e];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float m = fmaxf(fmaxf((float)v[0][k], (float)v[1][k]), fmaxf((float)v[2][k], (float)v[3][k]));
+      bool taken = false;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const bool is = !taken && (float)v[t][k] == m;
+        taken = taken || is;
+        o[t][k] = is ? (float)g[k] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      bf16x8 r;
+      bf16x8 ad;
+      if (add) ad = add[idx[t]];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float s = add ? o[t][k] + (float)ad[k] : o[t][k];
+        r[k] = (__bf16)((float)v[t][k] > 0.f ? s : 0.f);
+      }
+      gx[idx[t]] = r;
+    }
+  }
+}
+
+// LPIPS head for one tap: LPP = C/8 lanes per pixel (a lane holds 8 channels = 16 B), 64/LPP pixels per wave pass.
+// Every wave walks a contiguous range of pixels and keeps a running sum per frame: one atomic per wave and frame.
+template <int LPP>
+__global__ void lpips_head_fwd_bf16_kernel(const bf16x8* __restrict__ f0, const bf16x8* __restrict__ f1, const float* __restrict__ lin,
+                                           float* __restrict__ val, int HW, long long npix, float inv_hw) {
+  constexpr int PPW = 64 / LPP;
+  const int lane = threadIdx.x & 63;
+  const int sub = lane % LPP, pl = lane / LPP;
+  const long long wave = (blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 6;
+  const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+  const long long per = ((npix + nwaves - 1) / nwaves + PPW - 1) / PPW * PPW;
+  const long long p_begin = wave * per, p_end = min(npix, p_begin + per);
+  float w[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) w[k] = lin[sub * 8 + k];
+  float run = 0.f;
+  long long run_n = -1;
+  for (long long p0 = p_begin; p0 < p_end; p0 += PPW) {
+    const long long p = p0 + pl;
+    const bool ok = p < p_end;
+    const long long pp = ok ? p : p_begin;
+    const bf16x8 a = f0[pp * LPP + sub], b = f1[pp * LPP + sub];
+    float sa = 0.f, sb = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { sa = fmaf((float)a[k], (float)a[k], sa); sb = fmaf((float)b[k], (float)b[k], sb); }
+    sa = group_sum<LPP>(sa); sb = group_sum<LPP>(sb);
+    const float ia = 1.f / (sqrtf(sa) + 1e-10f), ib = 1.f / (sqrtf(sb) + 1e-10f);
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { const float r = (float)a[k] * ia - (float)b[k] * ib; acc = fmaf(w[k] * r, r, acc); }
+    acc = ok ? acc : 0.f;
+    if (HW < 64) {   // tiny maps: a pass may span several frames -- one atomic per pixel (there are few)
+      acc = group_sum<LPP>(acc);
+      if (ok && sub == 0) atomicAdd(&val[p / HW], acc * inv_hw);
+      continue;
+    }
+    // frames of the first and last pixel of this pass (wave-uniform); a pass straddles at most two frames when PPW <= HW
+    const long long n_first = p0 / HW;
+    const long long last = min(p0 + PPW, p_end) - 1;
+    const long long n_last = last / HW;
+    if (n_first != run_n) {
+      if (run_n >= 0) { const float t = group_sum<64>(run); if (lane == 0) atomicAdd(&val[run_n], t * inv_hw); }
+      run = 0.f; run_n = n_first;
+    }
+    if (n_last == n_first) {
+      run += acc;
+    } else {   // split: pixels of frame n_first stay in run, the rest open the next frame
+      const bool mine = (pp / HW) == n_first;
+      run += mine ? acc : 0.f;
+      const float t = group_sum<64>(run);
+      if (lane == 0) atomicAdd(&val[run_n], t * inv_hw);
+      run = mine ? 0.f : acc;
+      run_n = n_last;
+    }
+  }
+  if (run_n >= 0) { const float t = group_sum<64>(run); if (lane == 0) atomicAdd(&val[run_n], t * inv_hw); }
+}
+
+// gradient wrt f1 through the normalisation and f1's own ReLU (see lpips.hip), rounded to bf16 once
+template <int LPP>
+__global__ void lpips_head_bwd_bf16_kernel(const bf16x8* __restrict__ f0, const bf16x8* __restrict__ f1, const float* __restrict__ lin,
+                                           const float* __restrict__ gscale, bf16x8* __restrict__ gf1, long long npix, float k_scale) {
+  constexpr int PPW = 64 / LPP;
+  const int lane = threadIdx.x & 63;
+  const int sub = lane % LPP, pl = lane / LPP;
+  const long long wave = (blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 6;
+  const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+  const float gk = gscale[0] * k_scale;
+  float w[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) w[k] = lin[sub * 8 + k];
+  for (long long p0 = wave * PPW; p0 < npix; p0 += nwaves * PPW) {
+    const long long p = p0 + pl;
+    const bool ok = p < npix;
+    const long long pp = ok ? p : 0;
+    const bf16x8 a = f0[pp * LPP + sub], b = f1[pp * LPP + sub];
+    float sa = 0.f, sb = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { sa = fmaf((float)a[k], (float)a[k], sa); sb = fmaf((float)b[k], (float)b[k], sb); }
+    sa = group_sum<LPP>(sa); sb = group_sum<LPP>(sb);
+    const float na = sqrtf(sa), nb = sqrtf(sb);
+    const float ia = 1.f / (na + 1e-10f), ib = 1.f / (nb + 1e-10f);
+    float gn[8], dot = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      gn[k] = gk * 2.f * w[k] * ((float)b[k] * ib - (float)a[k] * ia);
+      dot = fmaf(gn[k], (float)b[k], dot);
+    }
+    dot = group_sum<LPP>(dot);
+    const float c2 = nb > 0.f ? dot * ib * ib / nb : 0.f;
+    bf16x8 r;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r[k] = (__bf16)((float)b[k] > 0.f ? gn[k] * ib - (float)b[k] * c2 : 0.f);
+    if (ok) gf1[p * LPP + sub] = r;
+  }
+}
+
+inline int grid_for(long long total, int cap = 4096) {
+  return (int)std::max<long long>(1, std::min<long long>((total + 255) / 256, cap));
+}
+
+}  // namespace
+
+extern "C" {
+
+int fo_lpips_prep_bf16(const float* src, int src_is_nhwc, int ld, void* y, int N, int H, int W, const float* shift3,
+                       const float* scale3, void* stream) {
+  FO_REQUIRE(!src_is_nhwc || ld % 4 == 0, FO_E_ALIGN, "lpips_prep_bf16: ld %% 4");
+  FO_REQUIRE(fo_aligned16(y), FO_E_ALIGN, "lpips_prep_bf16: y alignment");
+  const f32x4 sh = {shift3[0], shift3[1], shift3[2], 0.f};
+  const f32x4 is = {1.f / scale3[0], 1.f / scale3[1], 1.f / scale3[2], 0.f};
+  const long long npix = (long long)N * H * W;
+  hipLaunchKernelGGL(lpips_prep_bf16_kernel, dim3(grid_for(npix)), dim3(256), 0, (hipStream_t)stream, src, src_is_nhwc, ld,
+                     reinterpret_cast<bf16x8*>(y), H * W, npix, sh, is);
+  FO_CHECK_LAUNCH();
+  return FO_OK;
+}
+
+int fo_lpips_prep_bwd_bf16(const void* g, float* gdec, int ldd, int64_t npix, const float* scale3, const float* gscale,
+                           float weight, void* stream) {
+  FO_REQUIRE(ldd % 4 == 0 && fo_aligned16(g), FO_E_ALIGN, "lpips_prep_bwd_bf16: alignment");
+  const f32x4 is = {1.f / scale3[0], 1.f / scale3[1], 1.f / scale3[2], 0.f};
+  hipLaunchKernelGGL(lpips_prep_bwd_bf16_kernel, dim3(grid_for(npix)), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const bf16x8*>(g), gdec, ldd, (long long)npix, is, gscale, weight);
+  FO_CHECK_LAUNCH();
+  return FO_OK;
+}
+
+int fo_maxpool2_fwd_bf16(const void* x, void* y, int N, int H, int W, int C, void* stream) {
+  FO_REQUIRE(H % 2 == 0 && W % 2 == 0 && C % 8 == 0, FO_E_SHAPE, "maxpool2_bf16: even H, W and C %% 8 == 0");
+  hipLaunchKernelGGL(maxpool2_fwd_bf16_kernel, dim3(grid_for((long long)N * (H / 2) * (W / 2) * (C / 8), 8192)), dim3(256), 0,
+                     (hipStream_t)stream, reinterpret_cast<const bf16x8*>(x), reinterpret_cast<bf16x8*>(y), N, H / 2, W / 2, C / 8);
+  FO_CHECK_LAUNCH();
+  return FO_OK;
+}
+
+int fo_maxpool2_bwd_bf16(const void* x, const void* gy, const void* add, void* gx, int N, int H, int W, int C, void* stream) {
+  FO_REQUIRE(H % 2 == 0 && W % 2 == 0 && C % 8 == 0, FO_E_SHAPE, "maxpool2_bf16: even H, W and C %% 8 == 0");
+  hipLaunchKernelGGL(maxpool2_bwd_bf16_kernel, dim3(grid_for((long long)N * (H / 2) * (W / 2) * (C / 8), 8192)), dim3(256), 0,
+                     (hipStream_t)stream, reinterpret_cast<const bf16x8*>(x), reinterpret_cast<const bf16x8*>(gy),
+                     reinterpret_cast<const bf16x8*>(add), reinterpret_cast<bf16x8*>(gx), N, H / 2, W / 2, C / 8);
+  FO_CHECK_LAUNCH();
+  return FO_OK;
+}
+
+int fo_lpips_tap_fwd_bf16(const void* f0, const void* f1, const float* lin, float* val, int N, int H, int W, int C, void* stream) {
+  const long long npix = (long long)N * H * W;
+  const int grid = grid_for(npix * (C / 8), 2048);
+  const float inv = 1.f / (float)(H * W);
+#define FO_HEAD_FWD(LPP_)                                                                                                \
+  hipLaunchKernelGGL(lpips_head_fwd_bf16_kernel<LPP_>, dim3(grid), dim3(256), 0, (hipStream_t)stream,                    \
+                     reinterpret_cast<const bf16x8*>(f0), reinterpret_cast<const bf16x8*>(f1), lin, val, H * W, npix, inv)
+  if (C == 64) FO_HEAD_FWD(8);
+  else if (C == 128) FO_HEAD_FWD(16);
+  else if (C == 256) FO_HEAD_FWD(32);
+  else if (C == 512) FO_HEAD_FWD(64);
+  else FO_REQUIRE(false, FO_E_SHAPE, "lpips_tap_bf16: C must be 64/128/256/512 (got %d)", C);
+#undef FO_HEAD_FWD
+  FO_CHECK_LAUNCH();
+  return FO_OK;
+}
+
+int fo_lpips_tap_bwd_bf16(const void* f0, const void* f1, const float* lin, const float* gscale, void* gf1, int N, int H, int W,
+                          int C, void* stream) {
+  const long long npix = (long long)N * H * W;
+  const int grid = grid_for(npix * (C / 8), 4096);
+  const float ks = 1.f / ((float)(H * W) * (float)N);
+#define FO_HEAD_BWD(LPP_)                                                                                                \
+  hipLaunchKernelGGL(lpips_head_bwd_bf16_kernel<LPP_>, dim3(grid), dim3(256), 0, (hipStream_t)stream,                    \
+                     reinterpret_cast<const bf16x8*>(f0), reinterpret_cast<const bf16x8*>(f1), lin, gscale,               \
+                     reinterpret_cast<bf16x8*>(gf1), npix, ks)
+  if (C == 64) FO_HEAD_BWD(8);
+  else if (C == 128) FO_HEAD_BWD(16);
+  else if (C == 256) FO_HEAD_BWD(32);
+  else if (C == 512) FO_HEAD_BWD(64);
+  else FO_REQUIRE(false, FO_E_SHAPE, "lpips_tap_bf16: C must be 64/128/256/512 (got %d)", C);
+#undef FO_HEAD_BWD
+  FO_CHECK_LAUNCH();
+  return FO_OK;
+}
+}

@@ -34,8 +34,12 @@ class _LPIPSFunction(torch.autograd.Function):
 
 
 class VQLPIPS(nn.Module):
-    def __init__(self, state_dict=None):
+    def __init__(self, state_dict=None, dtype="fp32"):
+        """dtype: "fp32" (reference arithmetic) or "bf16" (BASELINE config 3: bf16 storage / MFMA operands, fp32
+        accumulation -- what torch.autocast(bfloat16) around the reference's VQLPIPS would compute)."""
         super().__init__()
+        assert dtype in ("fp32", "bf16")
+        self.compute_dtype = dtype
         holder = nn.Module()
         for key, ci, co, _ in conv_keys():
             _register(holder, key + ".weight", torch.zeros(co, ci, 3, 3))
@@ -67,7 +71,7 @@ class VQLPIPS(nn.Module):
             raise RuntimeError("faceoff_amd.VQLPIPS computes only on an MI355X (cuda/HIP device): there is no CPU fallback")
         if self._engine is None or self._engine.device != device:
             sd = {k[len("perceptual_loss."):]: v for k, v in self.state_dict().items()}
-            self._engine = LPIPSEngine(sd, device)
+            self._engine = LPIPSEngine(sd, device, dtype=self.compute_dtype)
         return self._engine
 
     def forward(self, targets, reconstructions):

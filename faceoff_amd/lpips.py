@@ -9,7 +9,13 @@ reconstruction only -- all LPIPS parameters are frozen (lpips.py:63-64,135-137),
 Weights: `state_dict` keys follow the reference (`net.sliceK.<idx>.weight/bias`, `linK.model.1.weight`).
 The pretrained files (torchvision VGG-16, vgg.pth from heibox, lpips.py:12-22) are a network download and
 are NOT bundled: load them with `load_state_dict`; tests use seeded random weights (parity unpinned for the
-pretrained values).  fp32 throughout (a bf16 MFMA conv family is the next step).
+pretrained values).
+
+Two arithmetic modes (`dtype`): "fp32" -- everything on the exact-fp32 MFMA conv kernel (BASELINE config 2
+arithmetic, 1e-3 parity with the reference's fp32 CPU path); "bf16" -- BASELINE config 3: activations, their
+gradients and the frozen filters are stored as bf16 and contracted on the bf16 MFMA with fp32 accumulation
+(csrc/conv_bf16.hip, csrc/lpips_bf16.hip), head arithmetic in fp32; parity is against the oracle's
+bf16-simulated LPIPS (same rounding points), and the deviation from the fp32 oracle is reported next to it.
 """
 from __future__ import annotations
 
@@ -45,8 +51,11 @@ def conv_keys():
 
 
 class LPIPSEngine:
-    def __init__(self, state_dict, device):
+    def __init__(self, state_dict, device, dtype="fp32"):
+        assert dtype in ("fp32", "bf16")
         self.device = torch.device(device)
+        self.bf16 = dtype == "bf16"
+        self.act_dtype = torch.bfloat16 if self.bf16 else torch.float32
         self.convs = conv_keys()
         sd = {k: torch.as_tensor(v, dtype=torch.float32).to(self.device) for k, v in state_dict.items()}
         self.w, self.b, self.wp, self.wpd = [], [], [], []
@@ -54,6 +63,15 @@ class LPIPSEngine:
             w, b = sd[key + ".weight"].contiguous(), sd[key + ".bias"].contiguous()
             self.w.append(w)
             self.b.append(b)
+            if self.bf16:   # RGB layer: 3 -> 8 channels (one 16-byte pixel per tap), 9 -> 16 taps so that K = 128
+                if i == 0:
+                    wpad = torch.zeros((co, 8, 3, 3), device=self.device)
+                    wpad[:, :3] = w
+                    self.wp.append(ops.pack_conv_bf16(wpad, taps_pad=16))
+                else:
+                    self.wp.append(ops.pack_conv_bf16(w))
+                self.wpd.append(ops.pack_conv_dgrad_bf16(w.reshape(co, ci, 9)))
+                continue
             if i == 0:   # Cin 3 -> 8 channels, KW 3 -> 4 taps (zeros) so that K = 3*4*8 = 96 is a multiple of 32
                 wpad = torch.zeros((co, 8, 3, 4), device=self.device)
                 wpad[:, :3, :, :3] = w
@@ -74,15 +92,18 @@ class LPIPSEngine:
             N, _, H, W = src.shape
             ld = 0
             src = src.contiguous()
-        y = torch.empty((N, H, W, 8), device=self.device)
-        _lib.call("fo_lpips_prep", ops._ptr(src), int(nhwc), ld, ops._ptr(y), N, H, W, self.shift, self.scale, ops._stream())
+        y = torch.empty((N, H, W, 8), device=self.device, dtype=self.act_dtype)
+        _lib.call("fo_lpips_prep_bf16" if self.bf16 else "fo_lpips_prep", ops._ptr(src), int(nhwc), ld, ops._ptr(y), N, H, W,
+                  self.shift, self.scale, ops._stream())
         return y
 
     def _conv(self, i, x):
         _, ci, co, _ = self.convs[i]
         N, H, W, _ = x.shape
-        y = torch.empty((N, H, W, co), device=self.device)
-        if i == 0:
+        y = torch.empty((N, H, W, co), device=self.device, dtype=self.act_dtype)
+        if self.bf16:
+            ops.conv_bf16(x, self.wp[i], self.b[i], y, cin=8 if i == 0 else ci, cout=co, flags=ops.FO_OUT_RELU)
+        elif i == 0:
             ops.conv_igemm(x, self.wp[0], self.b[0], y, k=(1, 3, 4), pad=(0, 1, 1), cin=8, cout=co, flags=ops.FO_OUT_RELU)
         else:
             ops.conv_igemm(x, self.wp[i], self.b[i], y, k=(1, 3, 3), pad=(0, 1, 1), cin=ci, cout=co, flags=ops.FO_OUT_RELU)
@@ -90,8 +111,8 @@ class LPIPSEngine:
 
     def _pool(self, x):
         N, H, W, Cc = x.shape
-        y = torch.empty((N, H // 2, W // 2, Cc), device=self.device)
-        _lib.call("fo_maxpool2_fwd", ops._ptr(x), ops._ptr(y), N, H, W, Cc, ops._stream())
+        y = torch.empty((N, H // 2, W // 2, Cc), device=self.device, dtype=self.act_dtype)
+        _lib.call("fo_maxpool2_fwd_bf16" if self.bf16 else "fo_maxpool2_fwd", ops._ptr(x), ops._ptr(y), N, H, W, Cc, ops._stream())
         return y
 
     def features(self, x8, keep_all):
@@ -117,7 +138,7 @@ class LPIPSEngine:
         Frames are independent in LPIPS, so large batches run in frame chunks that keep every activation
         inside the conv kernel's 2 GiB buffer-descriptor window (relu1_2 is 64 channels at full resolution)."""
         N, H, W, _ = dec_nhwc.shape
-        max_frames = max(1, self.window_bytes // (H * W * 64 * 4))
+        max_frames = max(1, self.window_bytes // (H * W * 64 * (2 if self.bf16 else 4)))
         if N > max_frames:
             nchunks = -(-N // max_frames)
             per = -(-N // nchunks)
@@ -145,7 +166,7 @@ class LPIPSEngine:
         val = torch.zeros(N, device=self.device)
         for k in range(5):
             n, h, w, c = taps1[k].shape
-            _lib.call("fo_lpips_tap_fwd", ops._ptr(taps0[k]), ops._ptr(taps1[k]), ops._ptr(self.lin[k]), ops._ptr(val),
+            _lib.call("fo_lpips_tap_fwd_bf16" if self.bf16 else "fo_lpips_tap_fwd", ops._ptr(taps0[k]), ops._ptr(taps1[k]), ops._ptr(self.lin[k]), ops._ptr(val),
                       n, h, w, c, ops._stream())
         loss = val.mean().reshape(1)
         self.last_per_image = val
@@ -158,32 +179,43 @@ class LPIPSEngine:
         for k in range(5):
             n, h, w, c = taps1[k].shape
             g = torch.empty_like(taps1[k])
-            _lib.call("fo_lpips_tap_bwd", ops._ptr(taps0[k]), ops._ptr(taps1[k]), ops._ptr(self.lin[k]), ops._ptr(gscale),
+            _lib.call("fo_lpips_tap_bwd_bf16" if self.bf16 else "fo_lpips_tap_bwd", ops._ptr(taps0[k]), ops._ptr(taps1[k]), ops._ptr(self.lin[k]), ops._ptr(gscale),
                       ops._ptr(g), n, h, w, c, ops._stream())
             head.append(g)
         g = head[4]                                     # grad wrt (pre-ReLU) output of conv 12
         for i in range(12, -1, -1):
             _, ci, co, pool = self.convs[i]
             if i == 0:
-                gin = torch.zeros((N, H, W, 8), device=self.device)
-                ops.conv_igemm(g, self.wpd[0], None, gin, k=(1, 3, 3), pad=(0, 1, 1), cin=co, cout=3)
+                gin = torch.zeros((N, H, W, 8), device=self.device, dtype=self.act_dtype)
+                self._dgrad(g, 0, gin, co, 3, None)
                 g = gin
                 break
             if pool:                                     # conv i reads the pooled tensor: no ReLU mask on its dgrad
                 gp = torch.empty_like(acts[f"p{i}"])
-                ops.conv_igemm(g, self.wpd[i], None, gp, k=(1, 3, 3), pad=(0, 1, 1), cin=co, cout=ci)
+                self._dgrad(g, i, gp, co, ci, None)
                 x = acts[i - 1]                          # pre-pool tensor = ReLU output of conv i-1 = a LPIPS tap
                 tap = TAP_CONVS.index(i - 1)
                 gx = torch.empty_like(x)
                 n, h, w, c = x.shape
-                _lib.call("fo_maxpool2_bwd", ops._ptr(x), ops._ptr(gp), ops._ptr(head[tap]), ops._ptr(gx), n, h, w, c,
+                _lib.call("fo_maxpool2_bwd_bf16" if self.bf16 else "fo_maxpool2_bwd", ops._ptr(x), ops._ptr(gp), ops._ptr(head[tap]), ops._ptr(gx), n, h, w, c,
                           ops._stream())
                 g = gx
             else:
                 gin = torch.empty_like(acts[i - 1])
-                ops.conv_igemm(g, self.wpd[i], None, gin, k=(1, 3, 3), pad=(0, 1, 1), cin=co, cout=ci, mask=acts[i - 1])
+                self._dgrad(g, i, gin, co, ci, acts[i - 1])
                 g = gin
         one = torch.ones(1, device=self.device)          # gscale already went into the tap gradients
-        _lib.call("fo_lpips_prep_bwd", ops._ptr(g), 8, ops._ptr(g_dec), ops.ld_of(g_dec), C.c_int64(N * H * W), self.scale,
-                  ops._ptr(one), C.c_float(weight), ops._stream())
+        if self.bf16:
+            _lib.call("fo_lpips_prep_bwd_bf16", ops._ptr(g), ops._ptr(g_dec), ops.ld_of(g_dec), C.c_int64(N * H * W), self.scale,
+                      ops._ptr(one), C.c_float(weight), ops._stream())
+        else:
+            _lib.call("fo_lpips_prep_bwd", ops._ptr(g), 8, ops._ptr(g_dec), ops.ld_of(g_dec), C.c_int64(N * H * W), self.scale,
+                      ops._ptr(one), C.c_float(weight), ops._stream())
         return loss
+
+    def _dgrad(self, g, i, out, cin, cout, mask):
+        """Data gradient of conv i: the same 3x3 contraction with the flipped / channel-swapped filter."""
+        if self.bf16:
+            ops.conv_bf16(g, self.wpd[i], None, out, cin=cin, cout=cout, mask=mask)
+        else:
+            ops.conv_igemm(g, self.wpd[i], None, out, k=(1, 3, 3), pad=(0, 1, 1), cin=cin, cout=cout, mask=mask)

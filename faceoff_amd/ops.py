@@ -57,9 +57,9 @@ def _ptr(t):
     return C.c_void_p(0 if t is None else t.data_ptr())
 
 
-def ld_of(t):
-    """Pixel stride (floats) of a channels-last view [N,H,W,C] (or [rows,C])."""
-    assert t.dtype == torch.float32 and t.is_cuda, "fp32 device tensor required"
+def ld_of(t, dtype=torch.float32):
+    """Pixel stride (elements) of a channels-last view [N,H,W,C] (or [rows,C])."""
+    assert t.dtype == dtype and t.is_cuda, f"{dtype} device tensor required"
     assert t.stride(-1) == 1, "channels must be contiguous"
     ld = t.stride(-2)
     if t.dim() == 4:
@@ -157,6 +157,53 @@ def conv_igemm(x, wp, bias, out, *, T=1, k=(1, 3, 3), stride=1, pad=(0, 1, 1), c
             kname += f" [{N}x{Hm}x{Wm} {d.Cin}->{d.Cout} k{k[0]}{k[1]}{k[2]} s{stride} f{flags}]"
         prof.begin(kname, flops)
     _lib.call("fo_conv_igemm", C.byref(d), _ptr(x), _ptr(wp), _ptr(bias), _ptr(mask), _ptr(add), _ptr(out), _stream())
+    if prof is not None:
+        prof.end()
+
+
+# ------------------------------------------------------------------ bf16 conv family (LPIPS branch)
+def pack_conv_bf16(w, taps_pad=None):
+    """fp32 [O][I][*taps] -> bf16 [Opad][tapsPad][Ipad] (Ipad: multiple of 64, or 8 for the RGB layer)"""
+    O, I = w.shape[:2]
+    taps = w[0, 0].numel()
+    Ip = 8 if I <= 8 else (I + 63) // 64 * 64
+    tp = taps if taps_pad is None else taps_pad
+    out = torch.empty(pad_out(O) * tp * Ip, device=w.device, dtype=torch.bfloat16)
+    _lib.call("fo_pack_conv_bf16", _ptr(w), _ptr(out), O, I, taps, pad_out(O), Ip, tp, _stream())
+    return out
+
+
+def pack_conv_dgrad_bf16(w):
+    """stride-1 dgrad filter: fp32 [O][I][taps] -> bf16 [Ipad_as_out][taps reversed][Opad_as_in]"""
+    O, I = w.shape[:2]
+    taps = w[0, 0].numel()
+    Op, Ip = (O + 63) // 64 * 64, pad_out(I)
+    out = torch.empty(Ip * taps * Op, device=w.device, dtype=torch.bfloat16)
+    _lib.call("fo_pack_conv_dgrad_bf16", _ptr(w), _ptr(out), O, I, taps, Op, Ip, _stream())
+    return out
+
+
+def conv_bf16(x, wp, bias, out, *, k=(3, 3), stride=1, pad=(1, 1), cin=None, cout=None, flags=0, mask=None):
+    """One fo_conv_igemm_bf16 launch.  x/out/mask: bf16 channels-last views; bias fp32."""
+    N, Hin, Win, _ = x.shape
+    _, Hout, Wout, _ = out.shape
+    bf = torch.bfloat16
+    if bias is not None:
+        flags |= FO_BIAS
+    if mask is not None:
+        flags |= FO_MASK
+    d = _desc(N=N, T=1, Hin=Hin, Win=Win, Hm=Hout, Wm=Wout, Hout=Hout, Wout=Wout,
+              Cin=cin if cin is not None else x.shape[-1], Cout=cout if cout is not None else out.shape[-1],
+              KD=1, KH=k[0], KW=k[1], stride=stride, padD=0, padH=pad[0], padW=pad[1], ostride=1, ophH=0, ophW=0,
+              ldIn=ld_of(x, bf), ldOut=ld_of(out, bf), ldMask=ld_of(mask, bf) if mask is not None else 0, ldAdd=0, flags=flags)
+    prof = PROFILER
+    if prof is not None:
+        kname = "conv_bf16_bn%d%s" % (128 if d.Cout > 64 else (64 if d.Cout > 32 else 32), "_rgb" if d.Cin < 64 else "")
+        flops = 2.0 * N * Hout * Wout * d.Cout * (k[0] * k[1] * d.Cin)
+        if prof.detail:
+            kname += f" [{N}x{Hout}x{Wout} {d.Cin}->{d.Cout} f{flags}]"
+        prof.begin(kname, flops)
+    _lib.call("fo_conv_igemm_bf16", C.byref(d), _ptr(x), _ptr(wp), _ptr(bias), _ptr(mask), _ptr(out), _stream())
     if prof is not None:
         prof.end()
 

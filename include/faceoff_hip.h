@@ -169,6 +169,30 @@ int fo_lpips_tap_fwd(const float* f0, const float* f1, const float* lin, float* 
 int fo_lpips_tap_bwd(const float* f0, const float* f1, const float* lin, const float* gscale, float* gf1, int N, int H, int W,
                      int C, void* stream);
 
+/* ---------------------------------------------------------------- bf16 LPIPS branch (BASELINE config 3)
+ * The same VGG-16 / LPIPS chain with bf16 storage and bf16 MFMA operands, fp32 accumulation and fp32 head
+ * arithmetic; every stored tensor is rounded to bf16 once (round-to-nearest-even).  `void*` tensors below are
+ * bf16, channels-last; bias / lin / val / gdec stay fp32.  Replaces the cuDNN convs torch.autocast(bfloat16)
+ * would run under `VQLPIPS.forward` (loss.py:27-33, models/lpips.py:115-152). */
+/* wp[o][t][i] = bf16(w[o][i][t]) for t < taps, zero for taps <= t < tapsPad and the channel padding. */
+int fo_pack_conv_bf16(const float* w, void* wp, int O, int I, int taps, int Opad, int Ipad, int tapsPad, void* stream);
+/* wp[i][t][o] = bf16(w[o][i][taps-1-t]): the stride-1 data-gradient filter. */
+int fo_pack_conv_dgrad_bf16(const float* w, void* wp, int O, int I, int taps, int Opad, int Ipad, void* stream);
+/* 2-D implicit-GEMM conv, bf16 in / bf16 out.  d->ld* are in ELEMENTS; Cin % 64 == 0, or Cin == 8 == ldIn (RGB padded
+ * to a 16-byte pixel; filter packed with tapsPad = taps rounded up to 8).  Filters packed with Opad = Cout rounded up
+ * to 128 (Cout > 64), 64 (Cout > 32) or 32.  flags: FO_BIAS | FO_MASK (mask = bf16 activation, > 0) | FO_OUT_RELU. */
+int fo_conv_igemm_bf16(const fo_conv_desc* d, const void* in, const void* wp, const float* bias, const void* mask, void* out,
+                       void* stream);
+int fo_lpips_prep_bf16(const float* src, int src_is_nhwc, int ld, void* y, int N, int H, int W, const float* shift3,
+                       const float* scale3, void* stream);
+int fo_lpips_prep_bwd_bf16(const void* g /* [npix][8] */, float* gdec, int ldd, int64_t npix, const float* scale3,
+                           const float* gscale, float weight, void* stream);
+int fo_maxpool2_fwd_bf16(const void* x, void* y, int N, int H, int W, int C, void* stream);
+int fo_maxpool2_bwd_bf16(const void* x, const void* gy, const void* add, void* gx, int N, int H, int W, int C, void* stream);
+int fo_lpips_tap_fwd_bf16(const void* f0, const void* f1, const float* lin, float* val, int N, int H, int W, int C, void* stream);
+int fo_lpips_tap_bwd_bf16(const void* f0, const void* f1, const float* lin, const float* gscale, void* gf1, int N, int H, int W,
+                          int C, void* stream);
+
 /* ---------------------------------------------------------------- optimiser + utilities */
 /* torch.optim.Adam defaults (train_faceoff_perceptual.py:190) over one flat parameter arena. */
 int fo_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,

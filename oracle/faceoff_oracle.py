@@ -204,29 +204,53 @@ LPIPS_SHIFT = (-.030, -.088, -.188)   # lpips.py:99
 LPIPS_SCALE = (.458, .448, .450)      # lpips.py:100
 
 
-def vgg16_taps(x, lp):
-    """vgg16.forward (lpips.py:139-152): relu1_2, relu2_2, relu3_3, relu4_3, relu5_3."""
+class _RoundBF16(torch.autograd.Function):
+    """Storage rounding of the bf16 configuration (BASELINE config 3): the value is rounded to bfloat16 on the way
+    forward and its gradient is rounded to bfloat16 on the way back (what a bf16 tensor and its bf16 .grad hold);
+    all arithmetic around it stays fp32 (= bf16 operands, fp32 accumulate)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.bfloat16().float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.bfloat16().float()
+
+
+def _identity(x):
+    return x
+
+
+def vgg16_taps(x, lp, bf16sim=False):
+    """vgg16.forward (lpips.py:139-152): relu1_2, relu2_2, relu3_3, relu4_3, relu5_3.
+    bf16sim: every stored activation (and its gradient) and every filter is rounded to bfloat16."""
     taps, idx = [], 0
     tap_after = {3, 8, 15, 22, 29}   # last ReLU index of each slice (:125-134)
+    rnd = _RoundBF16.apply if bf16sim else _identity
+    x = rnd(x)
     for v in _VGG_CFG:
         if v == "M":
-            x = F.max_pool2d(x, 2, 2)
+            x = rnd(F.max_pool2d(x, 2, 2))
             idx += 1
             continue
         s = _VGG_SLICE_OF[idx]
-        x = F.relu(F.conv2d(x, lp[f"net.slice{s}.{idx}.weight"], lp[f"net.slice{s}.{idx}.bias"], padding=1))
+        w = lp[f"net.slice{s}.{idx}.weight"]
+        if bf16sim:
+            w = w.bfloat16().float()
+        x = rnd(F.relu(F.conv2d(x, w, lp[f"net.slice{s}.{idx}.bias"], padding=1)))
         idx += 2
         if idx - 1 in tap_after:
             taps.append(x)
     return taps
 
 
-def lpips_forward(inp, target, lp, per_tap=False):
+def lpips_forward(inp, target, lp, per_tap=False, bf16sim=False):
     """LPIPS.forward (lpips.py:80-93) -> [N,1,1,1]; Dropout is identity in eval (loss.py:30)."""
     shift = torch.tensor(LPIPS_SHIFT, dtype=inp.dtype).view(1, 3, 1, 1)
     scale = torch.tensor(LPIPS_SCALE, dtype=inp.dtype).view(1, 3, 1, 1)
-    f0 = vgg16_taps((inp - shift) / scale, lp)
-    f1 = vgg16_taps((target - shift) / scale, lp)
+    f0 = vgg16_taps((inp - shift) / scale, lp, bf16sim)
+    f1 = vgg16_taps((target - shift) / scale, lp, bf16sim)
     res = []
     for kk in range(5):
         n0 = f0[kk] / (torch.sqrt(torch.sum(f0[kk] ** 2, dim=1, keepdim=True)) + 1e-10)   # :155-157
