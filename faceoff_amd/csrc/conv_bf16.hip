@@ -219,29 +219,47 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvArgsH a) {
   const bool identity_pix = (d.ostride == 1) & (d.Hm == d.Hout) & (d.Wm == d.Wout);
   __bf16* out = reinterpret_cast<__bf16*>(a.out);
   const __bf16* mask = reinterpret_cast<const __bf16*>(a.mask);
-  for (int row = tid / C8; row < BM; row += RPP) {
-    const int m = tile_m * BM + row;
-    if (m >= a.M) break;
-    size_t opix = m;
-    if (!identity_pix) {
-      const int n = m / a.HWm;
-      const int rem = m - n * a.HWm;
-      const int y = rem / d.Wm;
-      const int x = rem - y * d.Wm;
-      opix = ((size_t)n * d.Hout + (y * d.ostride + d.ophH)) * d.Wout + (x * d.ostride + d.ophW);
+  // rows in batches: all mask loads of a batch are in flight before the first is used (see conv_igemm.hip store_tile)
+  constexpr int ROWS = BM / RPP, R = ROWS < 8 ? ROWS : 8;
+  const int r0 = tid / C8;
+#pragma unroll
+  for (int b = 0; b < ROWS; b += R) {
+    size_t opix[R];
+    bool ok[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      int m = tile_m * BM + r0 + (b + r) * RPP;
+      ok[r] = m < a.M;
+      m = min(m, a.M - 1);
+      opix[r] = m;
+      if (!identity_pix) {
+        const int n = m / a.HWm;
+        const int rem = m - n * a.HWm;
+        const int y = rem / d.Wm;
+        const int x = rem - y * d.Wm;
+        opix[r] = ((size_t)n * d.Hout + (y * d.ostride + d.ophH)) * d.Wout + (x * d.ostride + d.ophW);
+      }
     }
-    const f32x4 v0 = *reinterpret_cast<const f32x4*>(Cs + row * C_LD + c8 * 8);
-    const f32x4 v1 = *reinterpret_cast<const f32x4*>(Cs + row * C_LD + c8 * 8 + 4);
-    float v[8] = {v0.x + bv[0], v0.y + bv[1], v0.z + bv[2], v0.w + bv[3], v1.x + bv[4], v1.y + bv[5], v1.z + bv[6], v1.w + bv[7]};
+    bf16x8 mk[R];
     if (flags & FO_MASK) {
-      const bf16x8 mk = *reinterpret_cast<const bf16x8*>(mask + opix * d.ldMask + co);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (float)mk[e] > 0.f ? v[e] : 0.f;
+      for (int r = 0; r < R; ++r) mk[r] = *reinterpret_cast<const bf16x8*>(mask + opix[r] * d.ldMask + co);
     }
-    bf16x8 o;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (__bf16)((flags & FO_OUT_RELU) ? fmaxf(v[e], 0.f) : v[e]);
-    *reinterpret_cast<bf16x8*>(out + opix * d.ldOut + co) = o;
+    for (int r = 0; r < R; ++r) {
+      const float* crow = Cs + (r0 + (b + r) * RPP) * C_LD + c8 * 8;
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(crow);
+      const f32x4 v1 = *reinterpret_cast<const f32x4*>(crow + 4);
+      float v[8] = {v0.x + bv[0], v0.y + bv[1], v0.z + bv[2], v0.w + bv[3], v1.x + bv[4], v1.y + bv[5], v1.z + bv[6], v1.w + bv[7]};
+      if (flags & FO_MASK) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (float)mk[r][e] > 0.f ? v[e] : 0.f;
+      }
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (__bf16)((flags & FO_OUT_RELU) ? fmaxf(v[e], 0.f) : v[e]);
+      if (ok[r]) *reinterpret_cast<bf16x8*>(out + opix[r] * d.ldOut + co) = o;
+    }
   }
 }
 

@@ -68,6 +68,65 @@ __device__ __forceinline__ f32x4 bufload(__amdgpu_buffer_rsrc_t r, unsigned off)
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
 }
 
+// Rows of the LDS-transposed C tile -> global memory: bias, ReLU mask, residual, ReLU, 16 B per lane.  A thread's rows
+// go in batches of up to 8: the mask / residual loads of a whole batch are issued before the first one is used (a plain
+// row loop costs one L2 round trip per operand per row, which is what the short-K launches -- 1x1 convs, the dgrads of
+// the 32-channel ResBlock halves -- would then spend most of their time on).  Loads of rows past M are clamped to the
+// last row instead of predicated (a predicated load makes hipcc branch and drain vmcnt per row); only stores are guarded.
+template <int BN>
+__device__ __forceinline__ void store_tile(const ConvArgs& a, const float* Cs, int tile_m, int tile_n, int tid) {
+  const fo_conv_desc& d = a.d;
+  constexpr int C_LD = BN + 4, C4 = BN / 4, RPP = 256 / C4, ROWS = BM / RPP, R = ROWS < 8 ? ROWS : 8;
+  const int flags = d.flags;
+  const int c4 = tid % C4, r0 = tid / C4;
+  const int co = tile_n * BN + c4 * 4;
+  if (co >= d.Cout) return;
+  f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+  if (flags & FO_BIAS) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bv[e] = (co + e < d.Cout) ? a.bias[co + e] : 0.f;
+  }
+  const bool identity_pix = (d.ostride == 1) & (d.Hm == d.Hout) & (d.Wm == d.Wout);
+#pragma unroll
+  for (int b = 0; b < ROWS; b += R) {
+    size_t opix[R];
+    bool ok[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      int m = tile_m * BM + r0 + (b + r) * RPP;
+      ok[r] = m < a.M;
+      m = min(m, a.M - 1);
+      opix[r] = m;
+      if (!identity_pix) {
+        const int n = m / a.HWm;
+        const int rem = m - n * a.HWm;
+        const int y = rem / d.Wm;
+        const int x = rem - y * d.Wm;
+        opix[r] = ((size_t)n * d.Hout + (y * d.ostride + d.ophH)) * d.Wout + (x * d.ostride + d.ophW);
+      }
+    }
+    f32x4 mk[R], ad[R];
+    if (flags & FO_MASK) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) mk[r] = *reinterpret_cast<const f32x4*>(a.mask + opix[r] * d.ldMask + co);
+    }
+    if (flags & FO_ADD) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) ad[r] = *reinterpret_cast<const f32x4*>(a.add + opix[r] * d.ldAdd + co);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(Cs + (r0 + (b + r) * RPP) * C_LD + c4 * 4) + bv;
+      if (flags & FO_MASK) {
+        v.x = mk[r].x > 0.f ? v.x : 0.f; v.y = mk[r].y > 0.f ? v.y : 0.f; v.z = mk[r].z > 0.f ? v.z : 0.f; v.w = mk[r].w > 0.f ? v.w : 0.f;
+      }
+      if (flags & FO_ADD) v += ad[r];
+      if (flags & FO_OUT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      if (ok[r]) *reinterpret_cast<f32x4*>(a.out + opix[r] * d.ldOut + co) = v;
+    }
+  }
+}
+
 template <int BN, int WAVES_M, int WAVES_N, int TM, int TN, bool SMALLC>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
   static_assert(WAVES_M * WAVES_N == 4, "4 waves");
@@ -288,7 +347,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
   constexpr int RPP = 256 / C4;              // rows per pass
   const int c4 = tid % C4;
   const int co = tile_n * BN + c4 * 4;
-  const bool identity_pix = (d.ostride == 1) & (d.Hm == d.Hout) & (d.Wm == d.Wout);
   if ((flags & FO_DEPTH2SPACE) && co < d.Cout) {
     // fused 4-phase transposed conv: GEMM column co = phase*8 + channel; pixel m = (n, y, x) of the INPUT grid
     // writes output pixel (2y + py, 2x + px), channels c..c+3 of an 8-float pixel (d.ophW real channels carry a bias)
@@ -312,33 +370,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     }
     return;
   }
-  if (co < d.Cout) {
-    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-    if (flags & FO_BIAS) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) bv[e] = (co + e < d.Cout) ? a.bias[co + e] : 0.f;
-    }
-    for (int row = tid / C4; row < BM; row += RPP) {
-      const int m = tile_m * BM + row;
-      if (m >= a.M) break;
-      size_t opix = m;
-      if (!identity_pix) {
-        const int n = m / a.HWm;
-        const int rem = m - n * a.HWm;
-        const int y = rem / d.Wm;
-        const int x = rem - y * d.Wm;
-        opix = ((size_t)n * d.Hout + (y * d.ostride + d.ophH)) * d.Wout + (x * d.ostride + d.ophW);
-      }
-      f32x4 v = *reinterpret_cast<const f32x4*>(Cs + row * C_LD + c4 * 4) + bv;
-      if (flags & FO_MASK) {
-        const f32x4 mk = *reinterpret_cast<const f32x4*>(a.mask + opix * d.ldMask + co);
-        v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f; v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
-      }
-      if (flags & FO_ADD) v += *reinterpret_cast<const f32x4*>(a.add + opix * d.ldAdd + co);
-      if (flags & FO_OUT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-      *reinterpret_cast<f32x4*>(a.out + opix * d.ldOut + co) = v;
-    }
-  }
+  store_tile<BN>(a, Cs, tile_m, tile_n, tid);
 }
 
 #include "conv_igemm3.inc"

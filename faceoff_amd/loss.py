@@ -78,8 +78,11 @@ class VQLPIPS(nn.Module):
         return _LPIPSFunction.apply(self, targets.contiguous(), reconstructions.contiguous())
 
     # trainer fast path: loss + gradient accumulated straight into the NHWC decoder-output gradient
-    def loss_and_grad(self, gt_nchw, dec_nhwc, g_dec, weight=1.0):
-        return self._bind(dec_nhwc.device).loss_and_grad(gt_nchw, dec_nhwc, g_dec, weight)
+    def loss_and_grad(self, gt_nchw, dec_nhwc, g_dec, weight=1.0, taps0=None):
+        return self._bind(dec_nhwc.device).loss_and_grad(gt_nchw, dec_nhwc, g_dec, weight, taps0=taps0)
+
+    def target_taps(self, gt_nchw):
+        return self._bind(gt_nchw.device).target_taps(gt_nchw)
 
 
 def _register(root, dotted, tensor):

@@ -132,13 +132,26 @@ class LPIPSEngine:
         return taps, acts
 
     # ------------------------------------------------------------------ loss (+ gradient into g_dec)
-    def loss_and_grad(self, gt_nchw, dec_nhwc, g_dec=None, weight=1.0, gscale=None):
+    def max_frames(self, H, W):
+        """Frames per pass that keep relu1_2 (64 channels at full resolution) inside the conv kernel's 2 GiB window."""
+        return max(1, self.window_bytes // (H * W * 64 * (2 if self.bf16 else 4)))
+
+    def target_taps(self, gt_nchw):
+        """The five taps of the ground-truth branch (no dependence on the model: the trainer computes them on a side
+        stream while the VQ-VAE forward runs).  None when the batch needs frame chunking."""
+        N, _, H, W = gt_nchw.shape
+        if N > self.max_frames(H, W):
+            return None
+        taps0, _ = self.features(self._prep(gt_nchw, nhwc=False), keep_all=False)
+        return taps0
+
+    def loss_and_grad(self, gt_nchw, dec_nhwc, g_dec=None, weight=1.0, gscale=None, taps0=None):
         """perceptual = LPIPS(gt, dec[..., :3]).mean() (loss.py:33).  If g_dec (NHWC, same pixel stride as dec)
         is given, adds weight * gscale * d perceptual / d dec[..., :3] to it.  Returns the loss as a [1] tensor.
         Frames are independent in LPIPS, so large batches run in frame chunks that keep every activation
         inside the conv kernel's 2 GiB buffer-descriptor window (relu1_2 is 64 channels at full resolution)."""
         N, H, W, _ = dec_nhwc.shape
-        max_frames = max(1, self.window_bytes // (H * W * 64 * (2 if self.bf16 else 4)))
+        max_frames = self.max_frames(H, W)
         if N > max_frames:
             nchunks = -(-N // max_frames)
             per = -(-N // nchunks)
@@ -155,13 +168,13 @@ class LPIPSEngine:
                 vals.append(self.last_per_image)
             self.last_per_image = torch.cat(vals)
             return total
-        return self._loss_and_grad(gt_nchw, dec_nhwc, g_dec, weight, gscale)
+        return self._loss_and_grad(gt_nchw, dec_nhwc, g_dec, weight, gscale, taps0)
 
-    def _loss_and_grad(self, gt_nchw, dec_nhwc, g_dec, weight, gscale):
-        x0 = self._prep(gt_nchw, nhwc=False)
+    def _loss_and_grad(self, gt_nchw, dec_nhwc, g_dec, weight, gscale, taps0=None):
         x1 = self._prep(dec_nhwc, nhwc=True)
         N, H, W, _ = x1.shape
-        taps0, _ = self.features(x0, keep_all=False)
+        if taps0 is None:
+            taps0, _ = self.features(self._prep(gt_nchw, nhwc=False), keep_all=False)
         taps1, acts = self.features(x1, keep_all=g_dec is not None)
         val = torch.zeros(N, device=self.device)
         for k in range(5):

@@ -49,6 +49,13 @@ class FaceOffTrainer:
         self.scheduler = scheduler
         self.vqlpips = vqlpips
         self.world = get_world_size()
+        # the ground-truth branch of LPIPS does not depend on the model: it runs on its own stream beside the VQ-VAE
+        # forward (an fp32 conv workgroup and a bf16 one fit a CU's LDS together; the bf16 convs are L2-bound,
+        # the fp32 ones matrix-pipe-bound)
+        import os as _os
+        self.lpips_stream = None
+        if vqlpips is not None and engine.device.type == "cuda" and not _os.environ.get("FACEOFF_NO_LPIPS_OVERLAP"):
+            self.lpips_stream = torch.cuda.Stream(device=engine.device)
         self.reducer = None
         if self.world > 1:
             self.reducer = GradBucketReducer(engine.flat_grads, engine.layer_order, engine.offsets, bucket_bytes, group)
@@ -63,6 +70,16 @@ class FaceOffTrainer:
             img = img.reshape(-1, *img.shape[2:])
             ground_truth = ground_truth.reshape(-1, *ground_truth.shape[2:])
         eng = self.engine
+        taps0 = None
+        if self.vqlpips is not None and self.lpips_stream is not None and eng.wgrad_stream is not None:
+            main = torch.cuda.current_stream()
+            self.lpips_stream.wait_stream(main)
+            ground_truth.record_stream(self.lpips_stream)
+            with torch.cuda.stream(self.lpips_stream):
+                taps0 = self.vqlpips.target_taps(ground_truth)
+            if taps0 is not None:
+                for t in taps0:
+                    t.record_stream(main)        # allocated on the side stream, read (and freed) on the main one
         S = eng.forward(img, training=True, T=T)
         dec = S["dec"]
         acc = torch.zeros(1, device=eng.device)
@@ -73,7 +90,9 @@ class FaceOffTrainer:
         ops.mse_slice_bwd(dec, ground_truth, one, g_dec)
         perceptual = torch.zeros(1, device=eng.device)
         if self.vqlpips is not None:
-            perceptual = self.vqlpips.loss_and_grad(ground_truth, dec, g_dec, PERCEPTUAL_LOSS_WEIGHT)
+            if taps0 is not None:
+                torch.cuda.current_stream().wait_stream(self.lpips_stream)
+            perceptual = self.vqlpips.loss_and_grad(ground_truth, dec, g_dec, PERCEPTUAL_LOSS_WEIGHT, taps0=taps0)
         eng.backward(S, g_dec, one * LATENT_LOSS_WEIGHT)
         if self.reducer is not None:
             self.reducer.finish()
