@@ -20,6 +20,7 @@
 // SCALAR arithmetic (FASTROW), and a thread's share is one add per load.  Other shapes take the
 // generic per-row walk.  Either way the next step's loads go out inside MFMA group 0, the cursor
 // advances inside group 1, the LDS stores happen inside group 3 (1 MFMA : a few side instructions).
+#include <stdlib.h>
 #include <algorithm>
 #include "common.h"
 
@@ -42,6 +43,8 @@ struct WgradArgs {
   unsigned pBytes, qBytes;  // addressable extents behind P and Q (buffer descriptor bounds)
   int fastWalk;             // Wm >= 32: a 32-pixel step wraps at most one image row
   int strideShift;          // log2(stride) (stride is 1 or 2)
+  int kdLoop;               // Conv3d: a workgroup owns (chunk, kh, kw) and runs the KD depth taps one after another
+  int tapsSlab;             // taps per chunk in the slab layout (= KD*KH*KW; `taps` counts workgroups per chunk)
 };
 
 constexpr int WK = 32;  // pixels per K-step
@@ -91,10 +94,35 @@ __global__ __launch_bounds__(64 * WAVES_A * WAVES_B, 2) void conv_wgrad_kernel(c
   int kd, kh, kw;
   const int khw = d.KH * d.KW;
   if (SMALLC) { kd = 0; kh = tap; kw = 0; }
+  else if (a.kdLoop) { kd = 0; kh = tap / d.KW; kw = tap - kh * d.KW; }
   else { kd = tap / khw; const int r = tap - kd * khw; kh = r / d.KW; kw = r - kh * d.KW; }
 
-  const int m_begin = chunk * a.chunk;
-  const int m_end = min(a.M, m_begin + a.chunk);
+  int m_begin = chunk * a.chunk;
+  int m_end = min(a.M, m_begin + a.chunk);
+  if (a.kdLoop) {
+    // Chunk boundaries by equal WORK: frame t is visited by w_t = #{kd : 0 <= t + kd - padD < T} of the depth passes
+    // (the others see clip padding and are skipped), so equal pixel counts would give workgroups of unequal length --
+    // and these workgroups are half the launch long, so the longest one sets the launch time.
+    auto boundary = [&](int k) -> int {
+      if (k >= a.nchunks) return a.M;
+      int wclip = 0;
+      for (int t = 0; t < d.T; ++t) wclip += min(d.KD, d.T - t + d.padD) - max(0, d.padD - t);
+      const long long Wclip = (long long)wclip * a.HWm;
+      const long long target = Wclip * (d.N / d.T) * k / a.nchunks;
+      const int clip = (int)(target / Wclip);
+      long long rem = target - (long long)clip * Wclip;
+      int t = 0, px = 0;
+      for (; t < d.T; ++t) {
+        const int wt = min(d.KD, d.T - t + d.padD) - max(0, d.padD - t);
+        if (rem < (long long)wt * a.HWm) { px = (int)(rem / wt); break; }
+        rem -= (long long)wt * a.HWm;
+      }
+      const int m = (clip * d.T + t) * a.HWm + px;
+      return min(a.M, m & ~31);
+    };
+    m_begin = boundary(chunk);
+    m_end = boundary(chunk + 1);
+  }
 
   const int pcolA = (tid % (TA / 4)) * 4, prowA = tid / (TA / 4);
   const int pcolB = (tid % (TB / 4)) * 4, prowB = tid / (TB / 4);
@@ -103,7 +131,7 @@ __global__ __launch_bounds__(64 * WAVES_A * WAVES_B, 2) void conv_wgrad_kernel(c
   const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.P), 0, a.pBytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rQ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Q), 0, a.qBytes, 0x00020000);
   const float relu_floor = (d.flags & FO_IN_RELU) ? 0.f : -INFINITY;
-  const bool do_bias = a.wsBias && tap == a.biasTap && tileB == 0;
+  bool do_bias = a.wsBias && tap == a.biasTap && tileB == 0;
 
   f32x4 rp[PA], rq[PB];
   f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
@@ -111,13 +139,15 @@ __global__ __launch_bounds__(64 * WAVES_A * WAVES_B, 2) void conv_wgrad_kernel(c
   // ------------------------------------------------------------------ cursor over the K-steps to load
   // wave-uniform: first pixel of the step, its frame / row / column, and whether it exists
   int c_pos = m_begin, c_n, c_t, c_y, c_x;
-  {
+  auto cursor_reset = [&]() {
+    c_pos = m_begin;
     c_n = c_pos / a.HWm;
     const int rem = c_pos - c_n * a.HWm;
     c_y = rem / d.Wm;
     c_x = rem - c_y * d.Wm;
     c_t = c_n % d.T;
-  }
+  };
+  cursor_reset();
   const bool can_skip = d.KD > 1 && a.stepFrameAligned;
   auto frame_ok = [&]() { return !can_skip || (unsigned)(c_t + kd - d.padD) < (unsigned)d.T; };
   auto skip_bad_frames = [&]() {   // jump to the start of the next frame while the tap only sees clip padding
@@ -238,7 +268,21 @@ __global__ __launch_bounds__(64 * WAVES_A * WAVES_B, 2) void conv_wgrad_kernel(c
     }
   };
 
+  // Conv3d (kdLoop): a workgroup keeps its (chunk, kh, kw) and runs the depth taps one after another, one slab each.
+  // Every workgroup of the launch then does the same work (chunks are cut by work, above), and the KH*KW workgroups
+  // of a chunk walk the same P / Q rows at the same time (L2 reuse) -- per-tap workgroups would differ in length by
+  // T/(T-1), and cutting their chunks differently per tap loses the shared walk.
+  const int npass = a.kdLoop ? d.KD : 1;
+  const int tap2d = tap;
   f32x16 acc[TMA][TNB];
+  for (int pass = 0; pass < npass; ++pass) {
+  int tapFull = tap2d;
+  if (a.kdLoop) {
+    kd = pass;
+    tapFull = pass * khw + tap2d;
+    do_bias = a.wsBias && tapFull == a.biasTap && tileB == 0;
+    cursor_reset();
+  }
 #pragma unroll
   for (int i = 0; i < TMA; ++i)
 #pragma unroll
@@ -320,7 +364,7 @@ __global__ __launch_bounds__(64 * WAVES_A * WAVES_B, 2) void conv_wgrad_kernel(c
   }
 
   // ---- partial slab [chunk][tap][Apad][Bpad]
-  float* slab = a.ws + ((size_t)chunk * a.taps + tap) * a.Apad * a.Bpad;
+  float* slab = a.ws + ((size_t)chunk * a.tapsSlab + tapFull) * a.Apad * a.Bpad;
 #pragma unroll
   for (int i = 0; i < TMA; ++i)
 #pragma unroll
@@ -343,7 +387,9 @@ __global__ __launch_bounds__(64 * WAVES_A * WAVES_B, 2) void conv_wgrad_kernel(c
       for (int r = 1; r < RPA; ++r) t += red[tid + r * (TA / 4)];
       *reinterpret_cast<f32x4*>(a.wsBias + (size_t)chunk * a.Apad + tileA * TA + tid * 4) = t;
     }
+    __syncthreads();
   }
+  }  // pass
 }
 
 // Sum the slabs in chunk order and scatter to the checkpoint layout dW[a][b][tap].
@@ -402,7 +448,7 @@ __global__ void bias_reduce_kernel(const float* __restrict__ ws, float* __restri
 }
 
 struct Plan {
-  int TA, TB, tilesA, tilesB, Apad, Bpad, taps, chunk, nchunks;
+  int TA, TB, tilesA, tilesB, Apad, Bpad, taps, chunk, nchunks, kdLoop, tapsSlab;
   bool smallc;
 };
 
@@ -419,6 +465,12 @@ int make_plan(const fo_conv_desc* d, Plan* p) {
     p->TB = B % 128 == 0 ? 128 : (B % 64 == 0 ? 64 : 32);
     p->taps = d->KD * d->KH * d->KW;
     p->tilesA = A / p->TA; p->tilesB = B / p->TB;
+  }
+  p->tapsSlab = p->taps;
+  p->kdLoop = 0;
+  if (!p->smallc && d->KD > 1 && d->T > 1 && (d->Hm * d->Wm) % 32 == 0 && !getenv("FACEOFF_NO_KDLOOP")) {
+    p->kdLoop = 1;                 // workgroups enumerate (chunk, kh, kw) and loop over kd; chunks cut by work
+    p->taps = d->KH * d->KW;
   }
   p->Apad = p->TA * p->tilesA; p->Bpad = p->TB * p->tilesB;
   const long long M = (long long)d->N * d->Hm * d->Wm;
@@ -450,7 +502,7 @@ extern "C" int fo_debug_read_wstamps(unsigned long long* out, int n) {
 extern "C" int64_t fo_wgrad_ws_bytes(const fo_conv_desc* d) {
   Plan p;
   if (make_plan(d, &p) != FO_OK) return -1;
-  return ((int64_t)p.nchunks * p.taps * p.Apad * p.Bpad + (int64_t)p.nchunks * p.Apad) * 4 + 256;
+  return ((int64_t)p.nchunks * p.tapsSlab * p.Apad * p.Bpad + (int64_t)p.nchunks * p.Apad) * 4 + 256;
 }
 
 #define WG_LAUNCH1(TA_, TB_, WA_, WB_, TM_, TN_, SC_, FR_)                                                       \
@@ -475,8 +527,9 @@ extern "C" int fo_conv_wgrad(const fo_conv_desc* d, const float* P, const float*
   a.HWm = d->Hm * d->Wm;
   a.M = d->N * a.HWm;
   a.chunk = p.chunk; a.nchunks = p.nchunks; a.taps = p.taps;
+  a.kdLoop = p.kdLoop; a.tapsSlab = p.tapsSlab;
   a.tilesA = p.tilesA; a.tilesB = p.tilesB; a.Apad = p.Apad; a.Bpad = p.Bpad;
-  const size_t slab = (size_t)p.nchunks * p.taps * p.Apad * p.Bpad;
+  const size_t slab = (size_t)p.nchunks * p.tapsSlab * p.Apad * p.Bpad;
   a.wsBias = dbias ? ws + ((slab + 63) / 64) * 64 : nullptr;
   a.biasTap = p.smallc ? 0 : d->padD * d->KH * d->KW;
   a.stepFrameAligned = (a.HWm % WK) == 0 && (p.chunk % WK) == 0;
@@ -504,10 +557,10 @@ extern "C" int fo_conv_wgrad(const fo_conv_desc* d, const float* P, const float*
   else if (p.TA == 32 && p.TB == 32) WG_LAUNCH(32, 32, 1, 1, 1, 1);
   else FO_REQUIRE(false, FO_E_SHAPE, "wgrad: unsupported tile %dx%d", p.TA, p.TB);
   FO_CHECK_LAUNCH();
-  const size_t slabElems = (size_t)p.taps * p.Apad * p.Bpad;
+  const size_t slabElems = (size_t)p.tapsSlab * p.Apad * p.Bpad;
   const int CL = p.nchunks >= 256 ? 16 : 4;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((slabElems + 63) / 64)), dim3(64 * CL), 0, s, ws, dw, p.nchunks,
-                     p.taps, p.Apad, p.Bpad, Areal, Breal, p.smallc ? 1 : 0, d->KW);
+                     p.tapsSlab, p.Apad, p.Bpad, Areal, Breal, p.smallc ? 1 : 0, d->KW);
   FO_CHECK_LAUNCH();
   if (dbias) {
     hipLaunchKernelGGL(bias_reduce_kernel, dim3((Areal + 63) / 64), dim3(1024), 0, s, a.wsBias, dbias, p.nchunks, p.Apad, Areal);
