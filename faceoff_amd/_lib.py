@@ -39,6 +39,7 @@ SIGNATURES = {
     "fo_last_error": (C.c_char_p, []),
     "fo_device_info": (_I, [C.POINTER(C.c_int32)]),
     "fo_nchw_to_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "fo_nchw2_to_nhwc8": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _P]),
     "fo_nhwc_to_nchw": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "fo_pack_conv": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "fo_pack_conv_dgrad": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),

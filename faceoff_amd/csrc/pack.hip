@@ -87,6 +87,25 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, float* __restri
   }
 }
 
+// process_data's torch.cat([source, background], axis=channels) (reference utils.py:32) fused with the layout change:
+// y[n][p][c] = a[n][c][p] (c < Ca), b[n][c-Ca][p] (Ca <= c < Ca+Cb), 0 (padding).  One pass, 8-channel (32-B) pixels.
+__global__ void nchw2_to_nhwc8_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, int Ca,
+                                      int Cb, int HW, long long npix) {
+  for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < npix; p += (long long)gridDim.x * blockDim.x) {
+    const long long n = p / HW;
+    const int hw = (int)(p - n * HW);
+    float v[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      v[c] = 0.f;
+      if (c < Ca) v[c] = a[(n * Ca + c) * HW + hw];
+      else if (c < Ca + Cb) v[c] = b[(n * Cb + (c - Ca)) * HW + hw];
+    }
+    *reinterpret_cast<f32x4*>(y + p * 8) = f32x4{v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(y + p * 8 + 4) = f32x4{v[4], v[5], v[6], v[7]};
+  }
+}
+
 __global__ void nhwc_to_nchw_kernel(const float* __restrict__ x, float* __restrict__ y, int C, int HW, int ld, int accumulate) {
   __shared__ float tile[64][33];
   const int n = blockIdx.y;
@@ -151,6 +170,15 @@ int fo_nchw_to_nhwc(const float* x, float* y, int N, int C, int H, int W, int Cp
   FO_REQUIRE(Cpad >= C && ldy >= Cpad, FO_E_SHAPE, "nchw_to_nhwc: bad channel padding");
   const int HW = H * W;
   hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((HW + 63) / 64, N), dim3(256), 0, (hipStream_t)stream, x, y, C, HW, Cpad, ldy);
+  FO_CHECK_LAUNCH();
+  return FO_OK;
+}
+
+int fo_nchw2_to_nhwc8(const float* a, int Ca, const float* b, int Cb, float* y, int N, int H, int W, void* stream) {
+  FO_REQUIRE(Ca > 0 && Cb >= 0 && Ca + Cb <= 8 && fo_aligned16(y), FO_E_SHAPE, "nchw2_to_nhwc8: Ca + Cb <= 8, y 16-byte aligned");
+  const long long npix = (long long)N * H * W;
+  hipLaunchKernelGGL(nchw2_to_nhwc8_kernel, dim3(grid_for((size_t)npix)), dim3(256), 0, (hipStream_t)stream, a, b, y, Ca, Cb, H * W,
+                     npix);
   FO_CHECK_LAUNCH();
   return FO_OK;
 }

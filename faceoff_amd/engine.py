@@ -342,14 +342,22 @@ class VQVAEEngine:
         S.update(v0=v0, v1=v1, v2=v2, w1=w1, dec=dec)
 
     def forward(self, img_nchw, training=True, T=None):
-        """VQVAE.forward (:243-259).  img_nchw [N,6,H,W] (N = B*T frames).
+        """VQVAE.forward (:243-259).  img_nchw [N,6,H,W] (N = B*T frames), or the pair (source, background) of
+        [N,3,H,W] tensors process_data would concatenate (utils.py:32) -- the cat then happens inside the layout kernel.
         Returns S: dict of saved activations incl. S[dec] NHWC [N,H,W,8], S[diff] [1], S[id_t], S[id_b]."""
-        N, Cin, H, W = img_nchw.shape
+        parts = None
+        if isinstance(img_nchw, (tuple, list)):
+            parts = img_nchw
+            N, _, H, W = parts[0].shape
+            Cin = parts[0].shape[1] + parts[1].shape[1]
+        else:
+            N, Cin, H, W = img_nchw.shape
         T = T or self.clip_len or N
         assert N % T == 0, f"N={N} frames is not a whole number of clips of T={T}"
         assert H % 8 == 0 and W % 8 == 0, "spatial size must be a multiple of 8"
         self.pack_filters()
-        S = {"T": T, "x8": ops.nchw_to_nhwc(img_nchw, cpad=ops.pad_in(Cin))}
+        assert Cin <= 8
+        S = {"T": T, "x8": ops.cat_nchw_to_nhwc8(*parts) if parts is not None else ops.nchw_to_nhwc(img_nchw, cpad=ops.pad_in(Cin))}
         self.stage_encode(S)
         self.stage_conv3d(S)
         self.stage_quantize(S, training)

@@ -279,6 +279,16 @@ def nchw_to_nhwc(x, cpad=None):
     return y
 
 
+def cat_nchw_to_nhwc8(a, b):
+    """torch.cat([a, b], dim=1) of two NCHW tensors, written straight into the 8-channel NHWC input layout."""
+    N, Ca, H, W = a.shape
+    Cb = b.shape[1]
+    assert b.shape == (N, Cb, H, W) and Ca + Cb <= 8
+    y = torch.empty((N, H, W, 8), device=a.device, dtype=torch.float32)
+    _lib.call("fo_nchw2_to_nhwc8", _ptr(a.contiguous()), Ca, _ptr(b.contiguous()), Cb, _ptr(y), N, H, W, _stream())
+    return y
+
+
 def nhwc_to_nchw(x, c_real, out=None, accumulate=False):
     N, H, W, _ = x.shape
     if out is None:

@@ -65,7 +65,12 @@ class FaceOffTrainer:
     def step(self, img, ground_truth, T=None):
         """img [B,T,6,H,W] or [N,6,H,W]; ground_truth likewise with 3 channels (utils.py:29-38).
         Returns device scalars (recon_loss, latent_loss, perceptual_loss)."""
-        if img.dim() == 5:
+        if isinstance(img, (tuple, list)):       # (source, background): concatenated inside the input-layout kernel
+            if img[0].dim() == 5:
+                T = T or img[0].shape[1]
+                img = tuple(t.reshape(-1, *t.shape[2:]) for t in img)
+                ground_truth = ground_truth.reshape(-1, *ground_truth.shape[2:])
+        elif img.dim() == 5:
             T = T or img.shape[1]
             img = img.reshape(-1, *img.shape[2:])
             ground_truth = ground_truth.reshape(-1, *ground_truth.shape[2:])
@@ -100,3 +105,11 @@ class FaceOffTrainer:
             self.scheduler.step()
         self.optimizer.step(grad_scale=1.0 / self.world)   # DDP averages gradients
         return recon, S["diff"], perceptual
+
+    def step_from_batch(self, data):
+        """One iteration from the loader's 5-tuple (reference train loop :95 `process_data` + run_step + backward +
+        optimizer): returns (recon_loss, latent_loss, perceptual_loss, S) like run_step (:32-47), losses as device scalars."""
+        from .utils import split_batch
+        parts, T, ground_truth = split_batch(data, self.engine.device)
+        recon, latent, perceptual = self.step(parts, ground_truth, T=T)
+        return recon, latent, perceptual, T

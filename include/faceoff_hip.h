@@ -58,6 +58,9 @@ int fo_device_info(int32_t* out3);
 /* [N,C,H,W] -> [N,H,W,ldy] (channels >= C zero-filled up to Cpad).  Replaces the implicit NCHW
  * layout of utils.py:32 `torch.cat([source, background], axis=2)` feeding Conv2d. */
 int fo_nchw_to_nhwc(const float* x, float* y, int N, int C, int H, int W, int Cpad, int ldy, void* stream);
+/* process_data (utils.py:29-38): img = cat([source, background], channels) fused with the layout change:
+ * y[N,H,W,8] = channels of a [N,Ca,H,W], then of b [N,Cb,H,W], then zeros (Ca + Cb <= 8). */
+int fo_nchw2_to_nhwc8(const float* a, int Ca, const float* b, int Cb, float* y, int N, int H, int W, void* stream);
 /* [N,H,W,ldx] (first C channels) -> [N,C,H,W]; optionally accumulates (+=) for gradient returns. */
 int fo_nhwc_to_nchw(const float* x, float* y, int N, int C, int H, int W, int ldx, int accumulate, void* stream);
 

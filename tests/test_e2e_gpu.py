@@ -166,3 +166,29 @@ def test_perceptual_step_vs_oracle():
     for n, gref in r["grads"].items():
         got = eng.grads[n].cpu().numpy()
         assert np.abs(got - gref.numpy()).max() <= 2e-3 * gref.abs().max().item(), n
+
+
+def test_step_from_loader_batch_equals_step_on_concatenated_input():
+    """process_data fused into the input-layout kernel (fo_nchw2_to_nhwc8): feeding the loader's 5-tuple gives
+    identical losses and bit-identical gradients and updated parameters to feeding the concatenated [N,6,H,W] tensor."""
+    from faceoff_amd import ops
+    from faceoff_amd.engine import VQVAEEngine
+    from faceoff_amd.trainer import FaceOffTrainer
+    g = torch.Generator().manual_seed(11)
+    T, H, W = 3, 32, 48
+    data = tuple(torch.rand((1, T, 3, H, W), generator=g) * 2 - 1 for _ in range(5))
+    a, b = data[0][0].cuda(), data[2][0].cuda()
+    assert torch.equal(ops.cat_nchw_to_nhwc8(a, b), ops.nchw_to_nhwc(torch.cat([a, b], 1), cpad=8))
+    outs = []
+    for mode in ("tuple", "cat"):
+        eng = VQVAEEngine(make_state_dict(5, codebook_scale=0.3, gain=2.0), "cuda:0")
+        tr = FaceOffTrainer(eng)
+        if mode == "tuple":
+            recon, latent, _, S = tr.step_from_batch(data)
+            assert S == T
+        else:
+            recon, latent, _ = tr.step(torch.cat([a, b], 1), data[3][0].cuda(), T=T)
+        torch.cuda.synchronize()
+        outs.append((recon.item(), latent.item(), eng.flat_grads.clone(), eng.flat_params.clone()))
+    np.testing.assert_allclose(outs[0][:2], outs[1][:2], rtol=1e-6)      # loss sums use float atomics: order varies
+    assert torch.equal(outs[0][2], outs[1][2]) and torch.equal(outs[0][3], outs[1][3])

@@ -104,3 +104,22 @@ def test_bucket_plan_covers_arena_in_backward_order():
     trig = [BACKWARD_ORDER.index(t) for _, _, t in red.buckets]
     assert trig == sorted(trig)
     assert red.buckets[0][1] == off                                          # first bucket = end of the arena (dec.*)
+
+
+def test_process_data_mirrors_reference_contract():
+    """utils.py:29-38: loader 5-tuple of [1,T,3,H,W] -> (img [T,6,H,W] = source||background on channels, S = T,
+    ground_truth = source_images, source_images_original), and the zero-copy split the trainer uses."""
+    from faceoff_amd.utils import process_data, split_batch
+    g = torch.Generator().manual_seed(3)
+    T, H, W = 3, 8, 8
+    data = tuple(torch.rand((1, T, 3, H, W), generator=g) for _ in range(5))
+    img, S, gt, orig = process_data(data, "cpu", None)
+    assert img.shape == (T, 6, H, W) and S == T
+    assert torch.equal(img[:, :3], data[0][0]) and torch.equal(img[:, 3:], data[2][0])
+    assert torch.equal(gt, data[3][0]) and torch.equal(orig, data[4][0])
+    (src, bg), T2, gt2 = split_batch(data, "cpu")
+    assert T2 == T and torch.equal(torch.cat([src, bg], 1), img) and torch.equal(gt2, gt)
+    # clip batches [B,T,3,H,W] flatten to B*T frames
+    datab = tuple(torch.rand((2, T, 3, H, W), generator=g) for _ in range(5))
+    (src, bg), T3, gt3 = split_batch(datab, "cpu")
+    assert T3 == T and src.shape == (2 * T, 3, H, W) and gt3.shape == (2 * T, 3, H, W)
