@@ -44,6 +44,7 @@ struct ConvArgs {
   int cinShift;   // SMALLC: log2(Cin)
   int Ktot;       // taps*Cin  (row length of wp)
   int frameAligned;  // HWm % 128 == 0  -> a tile never straddles frames
+  int margin;        // bytes the input descriptor starts below `in`, so that per-row base offsets are never negative
   unsigned inBytes;  // addressable extent behind `in` (buffer descriptor bound)
   unsigned wpBytes;
 };
@@ -63,9 +64,12 @@ __device__ unsigned long long fo_stamps[4096];
 #else
 #define FO_STAMP_AT(i)
 #endif
+#ifndef FO_ABLATE   // diagnostic builds (tools/ablate_igemm.sh): bit 0 drop the loop's global loads, 1 its LDS stores,
+#define FO_ABLATE 0 // 2 its fragment reads, 3 its barrier -- results are wrong, only the timing is of interest
+#endif
 
-__device__ __forceinline__ f32x4 bufload(__amdgpu_buffer_rsrc_t r, unsigned off) {
-  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+__device__ __forceinline__ f32x4 bufload(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
 
 // Rows of the LDS-transposed C tile -> global memory: bias, ReLU mask, residual, ReLU, 16 B per lane.  A thread's rows
@@ -127,7 +131,7 @@ __device__ __forceinline__ void store_tile(const ConvArgs& a, const float* Cs, i
   }
 }
 
-template <int BN, int WAVES_M, int WAVES_N, int TM, int TN, bool SMALLC>
+template <int BN, int WAVES_M, int WAVES_N, int TM, int TN, bool SMALLC, bool INRELU>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
   static_assert(WAVES_M * WAVES_N == 4, "4 waves");
   static_assert(WAVES_M * TM * 32 == BM && WAVES_N * TN * 32 == BN, "tile");
@@ -169,7 +173,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     py[i] = y * d.stride - d.padH;
     px[i] = x * d.stride - d.padW;
     pbase[i] = ((n - d.padD) * d.Hin + py[i]) * d.Win + px[i];   // pixel index of tap (0,0,0)
-    rowoff[i] = (pbase[i] * d.ldIn + lcol) * 4;
+    rowoff[i] = (pbase[i] * d.ldIn + lcol) * 4 + a.margin;   // >= 0: the descriptor starts `margin` bytes below `in`
     unsigned mk = 0;
     if (!SMALLC) {
       for (int tp = 0; tp < ntaps; ++tp) {
@@ -179,7 +183,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
         mk |= (ok ? 1u : 0u) << tp;
       }
     }
-    tapmask[i] = mk;
+    tapmask[i] = ~mk;   // bit t SET = tap t is padding (or past the last tap) for this row
   }
 
   // ---- K range, with fully padded temporal taps skipped
@@ -198,17 +202,23 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     step_end = kd_hi * khw * a.cinChunks;
   }
 
-  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, a.inBytes, 0x00020000);
+  // The fp32 MFMA runs on the SIMD's fp32 ALUs (its rate IS the vector FMA rate), so every VALU instruction in the
+  // K-loop is taken from the matrix pipe: measured 0.85 -> 0.92 MFMA-busy with the loop's VALU work removed.  Hence:
+  // the per-step part of every address is a SCALAR offset (soffset of the buffer load), the per-row part a VGPR that
+  // only changes with the tap, padding is two VALU per row and step, and the input ReLU is a template parameter.
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(reinterpret_cast<const char*>(a.in) - a.margin), 0, a.inBytes + a.margin, 0x00020000);
   const __amdgpu_buffer_rsrc_t rwp = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wp), 0, a.wpBytes, 0x00020000);
-  const unsigned wrow = (unsigned)(((size_t)(tile_n * BN + lrow) * a.Ktot + lcol) * 4);
-  const unsigned wstride32 = (unsigned)((size_t)32 * a.Ktot * 4);
+  unsigned wrow[BROWS];
+#pragma unroll
+  for (int i = 0; i < BROWS; ++i) wrow[i] = (unsigned)(((size_t)(tile_n * BN + lrow + 32 * i) * a.Ktot + lcol) * 4);
 
+  const int step_last = step_end - 1;   // filter loads past the last step re-read it (their data is never used)
   // incremental (tap, chunk) walk of the NEXT step to load (wave-uniform scalars)
   int ld_step = step_begin;
   int ld_tap = kd_lo * khw, ld_kh = 0, ld_kw = 0, ld_kd = kd_lo, ld_chunk = 0;
 
   f32x4 ra[4], rb[BROWS];
-  const float relu_floor = (d.flags & FO_IN_RELU) ? 0.f : -INFINITY;   // fused input ReLU = one v_max per element
 
   // The next K-step's loads are issued in four parts (one A row + one B row each) so that each part's
   // address arithmetic sits between two 4-MFMA bursts and runs while the matrix pipe is busy.  Past
@@ -221,15 +231,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
       const int kh = tap / d.KW;
       const int kw = tap - kh * d.KW;
       const bool ok = pv[s] & (tap < ntaps) & ((unsigned)(py[s] + kh) < (unsigned)d.Hin) & ((unsigned)(px[s] + kw) < (unsigned)d.Win);
-      const unsigned off = (unsigned)(((pbase[s] + kh * d.Win + kw) * d.ldIn + coff) * 4);
-      ra[s] = bufload(rin, ok ? off : OOB);
+      const unsigned off = (unsigned)(((pbase[s] + kh * d.Win + kw) * d.ldIn + coff) * 4 + a.margin);
+      ra[s] = bufload(rin, ok ? off : OOB, 0);
     } else {
-      const int stepoff = ((((ld_kd * d.Hin) + ld_kh) * d.Win + ld_kw) * d.ldIn + ld_chunk * BK) * 4;
-      // branch-free: a padding tap gets bit 31 set = beyond the descriptor = zeros
-      const unsigned pad = (((tapmask[s] >> ld_tap) & 1u) - 1u) & OOB;
-      ra[s] = bufload(rin, (unsigned)(rowoff[s] + stepoff) | pad);
+      const int stepoff = ((((ld_kd * d.Hin) + ld_kh) * d.Win + ld_kw) * d.ldIn + ld_chunk * BK) * 4;   // scalar
+      // branch-free: a padding tap gets bit 31 of the VGPR offset set = beyond the descriptor = zeros
+      ra[s] = bufload(rin, ((tapmask[s] >> ld_tap) << 31) | (unsigned)rowoff[s], stepoff);
     }
-    if (s < BROWS) rb[s < BROWS ? s : 0] = bufload(rwp, wrow + s * wstride32 + ld_step * (BK * 4));
+    if (s < BROWS) rb[s < BROWS ? s : 0] = bufload(rwp, wrow[s < BROWS ? s : 0], min(ld_step, step_last) * (BK * 4));
     if (s == 3) {  // advance the (tap, chunk) walk
       ++ld_step;
       if (!SMALLC && ++ld_chunk == a.cinChunks) {
@@ -246,7 +255,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     float* As = As0 + buf * BM * LDS_LD;
     float* Bs = Bs0 + buf * BN * LDS_LD;
     f32x4 v = ra[s];
-    v.x = fmaxf(v.x, relu_floor); v.y = fmaxf(v.y, relu_floor); v.z = fmaxf(v.z, relu_floor); v.w = fmaxf(v.w, relu_floor);
+    if (INRELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
     *reinterpret_cast<f32x4*>(As + (lrow + 32 * s) * LDS_LD + lcol) = v;
     if (s < BROWS) *reinterpret_cast<f32x4*>(Bs + (lrow + 32 * s) * LDS_LD + lcol) = rb[s < BROWS ? s : 0];
   };
@@ -285,19 +294,19 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         __builtin_amdgcn_sched_barrier(0);
-        if (s == 0 && kk < 3) {
+        if (s == 0 && kk < 3 && !(FO_ABLATE & 4)) {
 #pragma unroll
           for (int i = 0; i < TM; ++i) fa[(kk + 1) & 1][i] = *reinterpret_cast<const f32x4*>(As + i * 32 * LDS_LD + (kk + 1) * 8);
 #pragma unroll
           for (int j = 0; j < TN; ++j) fb[(kk + 1) & 1][j] = *reinterpret_cast<const f32x4*>(Bs + j * 32 * LDS_LD + (kk + 1) * 8);
         }
-        if (kk == 0) load_part(s);
-        if (kk == 3) store_part(s, cur ^ 1);
+        if (kk == 0 && !(FO_ABLATE & 1)) load_part(s);
+        if (kk == 3 && !(FO_ABLATE & 2)) store_part(s, cur ^ 1);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk & 1][i][s], fb[kk & 1][j][s], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[(FO_ABLATE & 4) ? 0 : (kk & 1)][i][s], fb[(FO_ABLATE & 4) ? 0 : (kk & 1)][j][s], acc[i][j], 0, 0, 0);
         // Interleave 1 MFMA : a few issue slots of the side work, so the side work issues in the shadow
         // of an MFMA (64 pipe cycles each) instead of in front of the burst.
         // masks: 0x8 MFMA, 0x2 VALU, 0x20 VMEM read, 0x100 DS read, 0x200 DS write
@@ -319,7 +328,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     }
     __builtin_amdgcn_sched_barrier(0);
     FO_STAMP_AT(8 * (step - step_begin) + 5);
-    __syncthreads();
+    if (!(FO_ABLATE & 8)) __syncthreads();
     cur ^= 1;
   }
 
@@ -378,10 +387,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
 template <int BN, int WAVES_M, int WAVES_N, int TM, int TN>
 int launch(const ConvArgs& a, bool smallc, hipStream_t s) {
   const int grid = a.tilesM * a.tilesN;
-  if (smallc)
-    hipLaunchKernelGGL((conv_igemm_kernel<BN, WAVES_M, WAVES_N, TM, TN, true>), dim3(grid), dim3(256), 0, s, a);
+  const bool inrelu = (a.d.flags & FO_IN_RELU) != 0;
+  if (smallc && inrelu)
+    hipLaunchKernelGGL((conv_igemm_kernel<BN, WAVES_M, WAVES_N, TM, TN, true, true>), dim3(grid), dim3(256), 0, s, a);
+  else if (smallc)
+    hipLaunchKernelGGL((conv_igemm_kernel<BN, WAVES_M, WAVES_N, TM, TN, true, false>), dim3(grid), dim3(256), 0, s, a);
+  else if (inrelu)
+    hipLaunchKernelGGL((conv_igemm_kernel<BN, WAVES_M, WAVES_N, TM, TN, false, true>), dim3(grid), dim3(256), 0, s, a);
   else
-    hipLaunchKernelGGL((conv_igemm_kernel<BN, WAVES_M, WAVES_N, TM, TN, false>), dim3(grid), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<BN, WAVES_M, WAVES_N, TM, TN, false, false>), dim3(grid), dim3(256), 0, s, a);
   FO_CHECK_LAUNCH();
   return FO_OK;
 }
@@ -456,6 +470,9 @@ extern "C" int fo_conv_igemm(const fo_conv_desc* d, const float* in, const float
   const int opad = d->Cout > 64 ? (d->Cout + 127) / 128 * 128 : (d->Cout > 32 ? 64 : 32);
   const unsigned long long wpBytes = (unsigned long long)opad * a.Ktot * 4ull;
   FO_REQUIRE(inBytes < (1ull << 31) && wpBytes < (1ull << 31), FO_E_SHAPE, "conv: tensor exceeds the 2 GiB buffer-descriptor window");
+  const long long margin = (((long long)d->padD * d->Hin + d->padH) * d->Win + d->padW) * d->ldIn * 4ll;
+  FO_REQUIRE(margin >= 0 && inBytes + (unsigned long long)margin < (1ull << 31), FO_E_SHAPE, "conv: tensor exceeds the 2 GiB buffer-descriptor window");
+  a.margin = (int)margin;
   a.inBytes = (unsigned)inBytes;
   a.wpBytes = (unsigned)wpBytes;
   hipStream_t s = (hipStream_t)stream;
