@@ -22,6 +22,7 @@
 // advances inside group 1, the LDS stores happen inside group 3 (1 MFMA : a few side instructions).
 #include <stdlib.h>
 #include <algorithm>
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -41,6 +42,7 @@ struct WgradArgs {
   int biasTap;    // tap whose blocks also produce the bias partial (-1: none)
   int stepFrameAligned;  // HWm % 32 == 0
   unsigned pBytes, qBytes;  // addressable extents behind P and Q (buffer descriptor bounds)
+  int qMargin;              // bytes Q's descriptor starts below Q (see the kernel)
   int fastWalk;             // Wm >= 32: a 32-pixel step wraps at most one image row
   int strideShift;          // log2(stride) (stride is 1 or 2)
   int kdLoop;               // Conv3d: a workgroup owns (chunk, kh, kw) and runs the KD depth taps one after another
@@ -61,15 +63,16 @@ __device__ unsigned long long fo_wstamps[4096];
 #define FO_WSTAMP_AT(i)
 #endif
 
-__device__ __forceinline__ f32x4 bufload(__amdgpu_buffer_rsrc_t r, unsigned off) {
-  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+__device__ __forceinline__ f32x4 bufload(__amdgpu_buffer_rsrc_t r, unsigned off, int soff = 0) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, soff, 0));
 }
 
-template <int TA, int TB, int WAVES_A, int WAVES_B, int TMA, int TNB, bool SMALLC, bool FASTROW>
+template <int TA, int TB, int WAVES_A, int WAVES_B, int TMA, int TNB, bool SMALLC, bool FASTROW, bool INRELU>
 __global__ __launch_bounds__(64 * WAVES_A * WAVES_B, 2) void conv_wgrad_kernel(const WgradArgs a) {
   constexpr int NT = 64 * WAVES_A * WAVES_B;
   static_assert(WAVES_A * TMA * 32 == TA && WAVES_B * TNB * 32 == TB, "tile");
   static_assert(!(SMALLC && FASTROW), "FASTROW is for the regular channel layout");
+  static_assert(FASTROW || !INRELU, "the input ReLU is a template parameter on the FASTROW path, a runtime floor elsewhere");
   constexpr int PA = (WK * TA / 4) / NT;  // float4 loads per thread per step for P
   constexpr int PB = (WK * TB / 4) / NT;
   constexpr int RPA = NT / (TA / 4);      // rows covered per pass
@@ -129,7 +132,10 @@ __global__ __launch_bounds__(64 * WAVES_A * WAVES_B, 2) void conv_wgrad_kernel(c
   // bounds-checked buffer loads: padded taps / chunk tails read zeros without a branch or a select,
   // so the loads stay in flight under the MFMAs (see conv_igemm.hip)
   const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.P), 0, a.pBytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rQ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Q), 0, a.qBytes, 0x00020000);
+  // Q's descriptor starts qMargin bytes below Q so that the scalar per-step offset (first pixel of a tap's row run,
+  // which may lie in the left / top padding) is never negative; padding pixels themselves are never fetched.
+  const __amdgpu_buffer_rsrc_t rQ = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(reinterpret_cast<const char*>(a.Q) - a.qMargin), 0, a.qBytes + a.qMargin, 0x00020000);
   const float relu_floor = (d.flags & FO_IN_RELU) ? 0.f : -INFINITY;
   bool do_bias = a.wsBias && tap == a.biasTap && tileB == 0;
 
@@ -206,18 +212,25 @@ __global__ __launch_bounds__(64 * WAVES_A * WAVES_B, 2) void conv_wgrad_kernel(c
   };
 
   // per-thread constants of the FASTROW address arithmetic
-  unsigned pconst[PA], qconst[PB];
+  unsigned pconst[PA], qconst[PB], qrow[PB];
 #pragma unroll
   for (int i = 0; i < PA; ++i) pconst[i] = (unsigned)(((prowA + RPA * i) * d.ldOut + tileA * TA + pcolA) * 4);
 #pragma unroll
-  for (int i = 0; i < PB; ++i) qconst[i] = (unsigned)((((prowB + RPB * i) << a.strideShift) * d.ldIn + tileB * TB + pcolB) * 4);
+  for (int i = 0; i < PB; ++i) {
+    qconst[i] = (unsigned)((((prowB + RPB * i) << a.strideShift) * d.ldIn + tileB * TB + pcolB) * 4);
+    qrow[i] = prowB + RPB * i;
+  }
 
   // One quarter of a step's loads: P row q and Q row q of this thread (sits between two MFMA bursts).
   // Past the last step every offset is out of range: zeros, no branch.
   auto load_part = [&](int q) {
     const unsigned endpad = c_pos < m_end ? 0u : OOB;
     if (FASTROW) {
-      if (q < PA) rp[q < PA ? q : 0] = bufload(rP, ((unsigned)c_pos * (unsigned)d.ldOut * 4u + pconst[q < PA ? q : 0]) | endpad);
+      // Every per-step quantity is a wave-uniform scalar and rides in the loads' scalar offset; a thread's share is a
+      // constant VGPR (P) or that constant with the padding bit of its pixel (Q): the fp32 MFMA runs on the SIMD's
+      // fp32 ALUs, so VALU work in this loop comes straight out of the matrix rate.  Past the chunk's last step the
+      // P loads re-read a valid row (their data is never used), the Q loads are all padding.
+      if (q < PA) rp[q < PA ? q : 0] = bufload(rP, pconst[q < PA ? q : 0], min(c_pos, a.M - WK) * d.ldOut * 4);
       if (q < PB) {
         const int i = q < PB ? q : 0;
         // scalar: input row / first input column of the step, row-validity mask over its 32 pixels
@@ -226,10 +239,10 @@ __global__ __launch_bounds__(64 * WAVES_A * WAVES_B, 2) void conv_wgrad_kernel(c
         const int lo = max(0, (-xs + d.stride - 1) >> a.strideShift);
         const int hi = min(WK, (d.Win - xs + d.stride - 1) >> a.strideShift);
         unsigned mask = 0;
-        if ((unsigned)iy < (unsigned)d.Hin && hi > lo) mask = (hi >= 32 ? 0xFFFFFFFFu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u);
-        const unsigned qbase = (unsigned)((((c_n + kd - d.padD) * d.Hin + iy) * d.Win + xs) * d.ldIn * 4);
-        const unsigned pad = ((((mask >> (prowB + RPB * i)) & 1u) - 1u) & OOB) | endpad;
-        rq[i] = bufload(rQ, (qbase + qconst[i]) | pad);
+        if ((unsigned)iy < (unsigned)d.Hin && hi > lo && c_pos < m_end)
+          mask = (hi >= 32 ? 0xFFFFFFFFu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u);
+        const int qbase = (((c_n + kd - d.padD) * d.Hin + iy) * d.Win + xs) * d.ldIn * 4 + a.qMargin;
+        rq[i] = bufload(rQ, ((~mask >> qrow[i]) << 31) | qconst[i], c_pos < m_end ? qbase : 0);
       }
     } else {
       if (q < PA) {
@@ -248,22 +261,27 @@ __global__ __launch_bounds__(64 * WAVES_A * WAVES_B, 2) void conv_wgrad_kernel(c
         const bool ok = (c_pos + prowB + RPB * i < m_end) & ((unsigned)it < (unsigned)d.T) & ((unsigned)iy < (unsigned)d.Hin) &
                         ((unsigned)ix < (unsigned)d.Win);
         const unsigned pix = (unsigned)(((n + kd - d.padD) * d.Hin + iy) * d.Win + ix);
-        rq[i] = bufload(rQ, ((pix * (unsigned)d.ldIn + (unsigned)coff) * 4u) | (ok ? 0u : OOB) | endpad);
+        rq[i] = bufload(rQ, ((pix * (unsigned)d.ldIn + (unsigned)coff) * 4u + (unsigned)a.qMargin) | (ok ? 0u : OOB) | endpad);
       }
     }
   };
-  auto store_part = [&](int q, int buf) {
+  auto store_part = [&](int q, int buf, auto bias_c, bool real) {   // real: the rows belong to the chunk (not the overshoot prefetch)
+    constexpr bool BIAS = decltype(bias_c)::value;
     float* Ps = Ps0 + buf * WK * TA;
     float* Qs = Qs0 + buf * WK * TB;
     if (q < PA) {
       const int i = q < PA ? q : 0;
       *reinterpret_cast<f32x4*>(Ps + (prowA + RPA * i) * TA + pcolA) = rp[i];
-      if (do_bias) bsum += rp[i];
+      if (BIAS && real) bsum += rp[i];
     }
     if (q < PB) {
       const int i = q < PB ? q : 0;
       f32x4 v = rq[i];
-      v.x = fmaxf(v.x, relu_floor); v.y = fmaxf(v.y, relu_floor); v.z = fmaxf(v.z, relu_floor); v.w = fmaxf(v.w, relu_floor);
+      if (FASTROW) {
+        if (INRELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      } else {
+        v.x = fmaxf(v.x, relu_floor); v.y = fmaxf(v.y, relu_floor); v.z = fmaxf(v.z, relu_floor); v.w = fmaxf(v.w, relu_floor);
+      }
       *reinterpret_cast<f32x4*>(Qs + (prowB + RPB * i) * TB + pcolB) = v;
     }
   };
@@ -290,13 +308,15 @@ __global__ __launch_bounds__(64 * WAVES_A * WAVES_B, 2) void conv_wgrad_kernel(c
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // the K loop, compiled twice: the workgroups of one tap per chunk also sum P's columns (the conv bias gradient)
+  auto run_pass = [&](auto bias_c) {
   skip_bad_frames();
   if (!FASTROW) decode_rows();
   bool have = c_pos < m_end;          // a step is staged in LDS buffer `cur`
 #pragma unroll
   for (int q = 0; q < 4; ++q) load_part(q);
 #pragma unroll
-  for (int q = 0; q < 4; ++q) store_part(q, 0);
+  for (int q = 0; q < 4; ++q) store_part(q, 0, bias_c, have);
   if (have) cursor_advance();
   __syncthreads();
   int cur = 0;
@@ -304,8 +324,11 @@ __global__ __launch_bounds__(64 * WAVES_A * WAVES_B, 2) void conv_wgrad_kernel(c
   while (have) {
     FO_WSTAMP_AT(8 * stamp_i);
     const bool have_next = c_pos < m_end;
-    const float* Ps = Ps0 + cur * WK * TA + half * TA + wa * TMA * 32 + l31;
-    const float* Qs = Qs0 + cur * WK * TB + half * TB + wb * TNB * 32 + l31;
+    // A wave's 32-channel tiles are interleaved with the other waves' (tile i of wave wa = channels (i*WAVES_A + wa)*32),
+    // so every fragment of a step sits a multiple of 256 B from one per-lane base: ds_read2st64_b32 reaches them all
+    // with immediate offsets (no VALU add per pair -- VALU time comes out of the fp32 MFMA rate).
+    const float* Ps = Ps0 + cur * WK * TA + half * TA + wa * 32 + l31;
+    const float* Qs = Qs0 + cur * WK * TB + half * TB + wb * 32 + l31;
     // 4 groups of 4 k-pairs.  Fragments of group g+1 are requested inside group g, the next step's
     // loads go out inside group 0, the cursor moves on inside group 1, the LDS stores of the loaded
     // data happen inside group 3 -- each piece between two MFMAs (sched_group_barrier pins
@@ -315,9 +338,9 @@ __global__ __launch_bounds__(64 * WAVES_A * WAVES_B, 2) void conv_wgrad_kernel(c
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
 #pragma unroll
-      for (int i = 0; i < TMA; ++i) fa[0][q][i] = Ps[q * 2 * TA + i * 32];
+      for (int i = 0; i < TMA; ++i) fa[0][q][i] = Ps[q * 2 * TA + i * WAVES_A * 32];
 #pragma unroll
-      for (int j = 0; j < TNB; ++j) fb[0][q][j] = Qs[q * 2 * TB + j * 32];
+      for (int j = 0; j < TNB; ++j) fb[0][q][j] = Qs[q * 2 * TB + j * WAVES_B * 32];
     }
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -326,13 +349,13 @@ __global__ __launch_bounds__(64 * WAVES_A * WAVES_B, 2) void conv_wgrad_kernel(c
         __builtin_amdgcn_sched_barrier(0);
         if (g < 3) {   // fragments of k-pair q of the next group
 #pragma unroll
-          for (int i = 0; i < TMA; ++i) fa[(g + 1) & 1][q][i] = Ps[((g + 1) * 4 + q) * 2 * TA + i * 32];
+          for (int i = 0; i < TMA; ++i) fa[(g + 1) & 1][q][i] = Ps[((g + 1) * 4 + q) * 2 * TA + i * WAVES_A * 32];
 #pragma unroll
-          for (int j = 0; j < TNB; ++j) fb[(g + 1) & 1][q][j] = Qs[((g + 1) * 4 + q) * 2 * TB + j * 32];
+          for (int j = 0; j < TNB; ++j) fb[(g + 1) & 1][q][j] = Qs[((g + 1) * 4 + q) * 2 * TB + j * WAVES_B * 32];
         }
         if (g == 0) load_part(q);
         if (g == 1 && q == 0 && have_next) cursor_advance();
-        if (g == 3) store_part(q, cur ^ 1);
+        if (g == 3) store_part(q, cur ^ 1, bias_c, have_next);
 #pragma unroll
         for (int i = 0; i < TMA; ++i)
 #pragma unroll
@@ -362,6 +385,9 @@ __global__ __launch_bounds__(64 * WAVES_A * WAVES_B, 2) void conv_wgrad_kernel(c
     have = have_next;
     ++stamp_i;
   }
+  };   // run_pass
+  if (do_bias) run_pass(std::true_type{});
+  else run_pass(std::false_type{});
 
   // ---- partial slab [chunk][tap][Apad][Bpad]
   float* slab = a.ws + ((size_t)chunk * a.tapsSlab + tapFull) * a.Apad * a.Bpad;
@@ -369,10 +395,10 @@ __global__ __launch_bounds__(64 * WAVES_A * WAVES_B, 2) void conv_wgrad_kernel(c
   for (int i = 0; i < TMA; ++i)
 #pragma unroll
     for (int j = 0; j < TNB; ++j) {
-      const int col = tileB * TB + (wb * TNB + j) * 32 + l31;
+      const int col = tileB * TB + (j * WAVES_B + wb) * 32 + l31;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = tileA * TA + (wa * TMA + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int row = tileA * TA + (i * WAVES_A + wa) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
         slab[(size_t)row * a.Bpad + col] = acc[i][j][r];
       }
     }
@@ -505,13 +531,14 @@ extern "C" int64_t fo_wgrad_ws_bytes(const fo_conv_desc* d) {
   return ((int64_t)p.nchunks * p.tapsSlab * p.Apad * p.Bpad + (int64_t)p.nchunks * p.Apad) * 4 + 256;
 }
 
-#define WG_LAUNCH1(TA_, TB_, WA_, WB_, TM_, TN_, SC_, FR_)                                                       \
-  hipLaunchKernelGGL((conv_wgrad_kernel<TA_, TB_, WA_, WB_, TM_, TN_, SC_, FR_>), dim3(grid), dim3(64 * WA_ * WB_), \
+#define WG_LAUNCH1(TA_, TB_, WA_, WB_, TM_, TN_, SC_, FR_, IR_)                                                       \
+  hipLaunchKernelGGL((conv_wgrad_kernel<TA_, TB_, WA_, WB_, TM_, TN_, SC_, FR_, IR_>), dim3(grid), dim3(64 * WA_ * WB_), \
                      0, s, a)
 #define WG_LAUNCH(TA_, TB_, WA_, WB_, TM_, TN_)                     \
   do {                                                               \
-    if (fastrow) WG_LAUNCH1(TA_, TB_, WA_, WB_, TM_, TN_, false, true); \
-    else WG_LAUNCH1(TA_, TB_, WA_, WB_, TM_, TN_, false, false);     \
+    if (fastrow && inrelu) WG_LAUNCH1(TA_, TB_, WA_, WB_, TM_, TN_, false, true, true); \
+    else if (fastrow) WG_LAUNCH1(TA_, TB_, WA_, WB_, TM_, TN_, false, true, false); \
+    else WG_LAUNCH1(TA_, TB_, WA_, WB_, TM_, TN_, false, false, false);     \
   } while (0)
 
 extern "C" int fo_conv_wgrad(const fo_conv_desc* d, const float* P, const float* Q, float* dw, int Areal, int Breal,
@@ -543,9 +570,13 @@ extern "C" int fo_conv_wgrad(const fo_conv_desc* d, const float* P, const float*
   // FASTROW: a 32-pixel K-step is a run inside one image row, chunks start on step boundaries
   const bool fastrow = !p.smallc && d->Wm % WK == 0 && p.chunk % WK == 0;
   a.qBytes = (unsigned)qBytes;
+  const long long qMargin = (((long long)d->padD * d->Hin + d->padH) * d->Win + d->padW) * d->ldIn * 4ll;
+  FO_REQUIRE(qBytes + (unsigned long long)qMargin < (1ull << 31), FO_E_SHAPE, "wgrad: tensor exceeds the 2 GiB buffer-descriptor window");
+  a.qMargin = (int)qMargin;
   hipStream_t s = (hipStream_t)stream;
   const int grid = p.nchunks * p.taps * p.tilesA * p.tilesB;
-  if (p.smallc) WG_LAUNCH1(64, 32, 2, 1, 1, 1, true, false);
+  const bool inrelu = (d->flags & FO_IN_RELU) != 0;
+  if (p.smallc) WG_LAUNCH1(64, 32, 2, 1, 1, 1, true, false, false);
   else if (p.TA == 128 && p.TB == 128) WG_LAUNCH(128, 128, 2, 2, 2, 2);
   else if (p.TA == 128 && p.TB == 64) WG_LAUNCH(128, 64, 2, 2, 2, 1);
   else if (p.TA == 64 && p.TB == 128) WG_LAUNCH(64, 128, 2, 2, 1, 2);
