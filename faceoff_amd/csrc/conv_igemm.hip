@@ -480,7 +480,8 @@ extern "C" int fo_conv_igemm(const fo_conv_desc* d, const float* in, const float
   if (d->Cout > 64) {
     a.tilesN = (d->Cout + 127) / 128;
     if (pick_variant(d) == 3) {
-      hipLaunchKernelGGL((conv_igemm3_kernel<2, 2>), dim3(a.tilesM * a.tilesN), dim3(256), 0, s, a);
+      if (d->flags & FO_IN_RELU) hipLaunchKernelGGL((conv_igemm3_kernel<2, 2, true>), dim3(a.tilesM * a.tilesN), dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((conv_igemm3_kernel<2, 2, false>), dim3(a.tilesM * a.tilesN), dim3(256), 0, s, a);
       FO_CHECK_LAUNCH();
       return FO_OK;
     }
