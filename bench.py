@@ -155,7 +155,13 @@ def main():
     if args.perceptual:
         ideal_s += 120.3e9 / ((BF16_MFMA_PEAK_TFLOPS if args.lpips_dtype == "bf16" else FP32_MFMA_PEAK_TFLOPS) * 1e12)
         out["dtype"] = "f32 (VQ-VAE) + %s (LPIPS)" % ("bf16" if args.lpips_dtype == "bf16" else "f32")
-    out["step_frac_of_mfma_roofline"] = round(ideal_s * fps / world, 4)
+    out["step_frac_of_mfma_roofline"] = round(ideal_s * fps / world, 4)      # SURVEY 8(d) FLOP count: padded taps included
+    # the same with the Conv3d taps that fall into clip padding (structural zeros, skipped by the kernels) left out:
+    # 2 of 15 (frame, depth tap) pairs at T=5, on the 63.7 % of the conv FLOP that are Conv3d (fwd, dgrad, wgrad alike)
+    from faceoff_amd.ops import temporal_share
+    conv3d_flop = 3 * 2 * 6.795e9                                           # per frame: 6.795 GMAC fwd x 3 passes
+    executed = FLOP_PER_FRAME - conv3d_flop * (1.0 - temporal_share(T))
+    out["step_frac_executed_flop"] = round((ideal_s - (FLOP_PER_FRAME - executed) / (FP32_MFMA_PEAK_TFLOPS * 1e12)) * fps / world, 4)
     if prof is not None:
         summ = prof.summary()
         dom = max(summ, key=lambda k: summ[k]["total_ms"])
@@ -163,6 +169,7 @@ def main():
         peak = BF16_MFMA_PEAK_TFLOPS if dom.startswith("conv_bf16") else FP32_MFMA_PEAK_TFLOPS
         out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(d["tflops"], 2), "peak": peak,
                            "unit": "TFLOP/s", "frac": round(d["tflops"] / peak, 4), "traffic": None,
+                           "achieved_padded_taps_counted": round(d["tflops_nominal"], 2),
                            "launches_per_step": d["launches"] / args.steps, "avg_launch_ms": round(d["avg_ms"], 4),
                            "algorithmic_gflop_per_launch": round(d["flops_per_launch"] / 1e9, 3),
                            "share_of_step_time": round(d["total_ms"] / (ms_serial * args.steps), 4),
@@ -170,7 +177,7 @@ def main():
                                        "(kernels run alone; ms_per_step_serial is that region's step time incl. event overhead)"}
         out["ms_per_step_serial"] = round(ms_serial, 3)
         out["kernels"] = {k: {"launches_per_step": v["launches"] / args.steps, "avg_ms": round(v["avg_ms"], 4),
-                              "tflops": round(v["tflops"], 2), "ms_per_step": round(v["total_ms"] / args.steps, 3)}
+                              "tflops": round(v["tflops"], 2), "tflops_padded_taps_counted": round(v["tflops_nominal"], 2), "ms_per_step": round(v["total_ms"] / args.steps, 3)}
                           for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["total_ms"])}
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")       # written by profiles/collect.sh from rocprofv3 --pmc passes
         if os.path.exists(pmc):

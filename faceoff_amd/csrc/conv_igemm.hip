@@ -412,14 +412,11 @@ extern "C" int fo_debug_read_stamps(unsigned long long* out, int n) {
 static int pick_variant(const fo_conv_desc* d) {
   if (d->Cout <= 32) return 32;
   if (d->Cout <= 64) return 64;
-  // 3 taps per staged A tile, one workgroup per CU.  Measured equal to the generic kernel (2 workgroups per CU)
-  // on long-K Conv3d tiles and behind it on short-K 2-D tiles (exposed prologue/epilogue), so it is used for
-  // Conv3d launches whose tile count does not fill the generic kernel's 2 x CU slots in whole rounds
-  // (32x32 latents at C2: 1280 tiles = 2.5 rounds of 512, but exactly 5 rounds of 256: +15 %).
-  const long long M = (long long)d->N * d->Hm * d->Wm;
-  const long long tiles = ((M + BM - 1) / BM) * ((d->Cout + 127) / 128);
-  bool use3 = d->KD > 1 && tiles % (2 * fo_cu_count()) != 0 && tiles % fo_cu_count() == 0;
-  const char* force3 = getenv("FACEOFF_IGEMM3");
+  // 3 taps per staged A tile, one workgroup per CU: ahead of the generic kernel (two workgroups per CU) on the long-K
+  // Conv3d launches (162-165 vs 160 TFLOP/s nominal at 64^2, and 1280-tile launches fill 256 slots in whole rounds),
+  // behind it on short-K 2-D tiles (exposed prologue / epilogue): used for every eligible Conv3d launch.
+  bool use3 = d->KD > 1;
+  const char* force3 = getenv("FACEOFF_IGEMM3");   // diagnostics: 0 never, 1 every eligible launch
   if (force3) use3 = atoi(force3) != 0;
   return (d->Cin >= 32 && igemm3_eligible(d) && use3) ? 3 : 128;
 }

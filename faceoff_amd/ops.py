@@ -16,17 +16,19 @@ from ._lib import ConvDesc, FO_IN_RELU, FO_BIAS, FO_MASK, FO_ADD, FO_OUT_RELU, F
 
 class KernelProfiler:
     """Live per-launch timing with HIP events on the launch stream (bench.py's roofline leg).
-    Groups launches by kernel instance name; `flops` is the ALGORITHMIC work of the launch."""
+    Groups launches by kernel instance name; `flops` is the ALGORITHMIC work of the launch: multiply-adds whose
+    operands exist.  For a Conv3d that excludes the temporal taps that fall into clip padding (structural zeros the
+    kernels skip: 2 of 15 at T=5, `temporal_share`); `nominal` is the padded-tap count SURVEY.md section 8(d) quotes."""
 
     def __init__(self, detail=False):
         self.records = {}     # name -> list of (start_event, end_event, flops)
         self._cur = None
         self.detail = detail  # key launches by geometry as well (tools/, not bench.py's JSON line)
 
-    def begin(self, name, flops):
+    def begin(self, name, flops, nominal=None):
         s = torch.cuda.Event(enable_timing=True)
         s.record(torch.cuda.current_stream())
-        self._cur = (name, s, flops)
+        self._cur = (name, s, (flops, flops if nominal is None else nominal))
 
     def end(self):
         name, s, flops = self._cur
@@ -40,13 +42,21 @@ class KernelProfiler:
         out = {}
         for name, recs in self.records.items():
             ms = sum(s.elapsed_time(e) for s, e, _ in recs)
-            fl = sum(f for _, _, f in recs)
+            fl = sum(f[0] for _, _, f in recs)
+            fn = sum(f[1] for _, _, f in recs)
             out[name] = dict(launches=len(recs), total_ms=ms, avg_ms=ms / len(recs), flops_per_launch=fl / len(recs),
-                             tflops=fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0)
+                             tflops=fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
+                             tflops_nominal=fn / (ms * 1e-3) / 1e12 if ms > 0 else 0.0)
         return out
 
 
 PROFILER = None   # set to a KernelProfiler to time conv launches
+
+
+def temporal_share(T, kd=3, pad=1):
+    """Fraction of a Conv3d's (frame, depth tap) pairs that read a real frame of the clip: (3T-2)/3T for k=3, p=1."""
+    valid = sum(1 for t in range(T) for k in range(kd) if 0 <= t + k - pad < T)
+    return valid / float(T * kd)
 
 
 def _stream():
@@ -152,10 +162,11 @@ def conv_igemm(x, wp, bias, out, *, T=1, k=(1, 3, 3), stride=1, pad=(0, 1, 1), c
     if prof is not None:
         var = _lib.load().fo_conv_igemm_variant(C.byref(d))
         kname = "conv_igemm3" if var == 3 else "conv_igemm_bn%d%s" % (var, "_smallc" if d.Cin < 32 else "")
-        flops = 2.0 * N * Hm * Wm * d.Cout * (k[0] * k[1] * k[2] * d.Cin)
+        nominal = 2.0 * N * Hm * Wm * d.Cout * (k[0] * k[1] * k[2] * d.Cin)
+        flops = nominal * (temporal_share(T, k[0], pad[0]) if k[0] > 1 else 1.0)
         if prof.detail:
             kname += f" [{N}x{Hm}x{Wm} {d.Cin}->{d.Cout} k{k[0]}{k[1]}{k[2]} s{stride} f{flags}]"
-        prof.begin(kname, flops)
+        prof.begin(kname, flops, nominal)
     _lib.call("fo_conv_igemm", C.byref(d), _ptr(x), _ptr(wp), _ptr(bias), _ptr(mask), _ptr(add), _ptr(out), _stream())
     if prof is not None:
         prof.end()
@@ -256,7 +267,8 @@ def conv_wgrad(P, Q, dw, dbias, *, T=1, k=(1, 3, 3), stride=1, pad=(0, 1, 1), a_
         wname = "conv_wgrad_%dx%d" % (Ca, Cb)
         if prof.detail:
             wname += f" [{N}x{Hm}x{Wm} k{k[0]}{k[1]}{k[2]} s{stride}]"
-        prof.begin(wname, 2.0 * N * Hm * Wm * Ca * Cb * k[0] * k[1] * k[2])
+        nominal = 2.0 * N * Hm * Wm * Ca * Cb * k[0] * k[1] * k[2]
+        prof.begin(wname, nominal * (temporal_share(T, k[0], pad[0]) if k[0] > 1 else 1.0), nominal)
     _lib.call("fo_conv_wgrad", C.byref(d), _ptr(P), _ptr(Q), _ptr(dw), a_real, b_real, _ptr(dbias), _ptr(ws),
               C.c_int64(ws.numel() * 4), _stream())
     if prof is not None:

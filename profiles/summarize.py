@@ -28,7 +28,7 @@ def short(name):
 
 def label(name):
     """bench.py's kernel label for a rocprof kernel name (None if not one of the conv kernels)."""
-    m = re.search(r"conv_igemm_kernel<(\d+), *\d+, *\d+, *\d+, *\d+, *(true|false|\(bool\)[01]|[01])>", name)
+    m = re.search(r"conv_igemm_kernel<(\d+), *\d+, *\d+, *\d+, *\d+, *(true|false|\(bool\)[01]|[01])", name)
     if m:
         small = m.group(2) in ("true", "(bool)1", "1")
         return f"conv_igemm_bn{m.group(1)}" + ("_smallc" if small else "")
