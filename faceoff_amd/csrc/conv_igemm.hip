@@ -25,6 +25,7 @@
 //  * temporal taps that fall entirely into clip padding are skipped per tile (T=5: 2/15 of Conv3d);
 //  * blockIdx is remapped so that each XCD's L2 sees a contiguous run of tiles (shared halos).
 #include <stdlib.h>
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -44,6 +45,7 @@ struct ConvArgs {
   int cinShift;   // SMALLC: log2(Cin)
   int Ktot;       // taps*Cin  (row length of wp)
   int frameAligned;  // HWm % 128 == 0  -> a tile never straddles frames
+  int wShift;        // log2(Wm) if Wm is a power of two, else -1
   int margin;        // bytes the input descriptor starts below `in`, so that per-row base offsets are never negative
   unsigned inBytes;  // addressable extent behind `in` (buffer descriptor bound)
   unsigned wpBytes;
@@ -91,44 +93,58 @@ __device__ __forceinline__ void store_tile(const ConvArgs& a, const float* Cs, i
     for (int e = 0; e < 4; ++e) bv[e] = (co + e < d.Cout) ? a.bias[co + e] : 0.f;
   }
   const bool identity_pix = (d.ostride == 1) & (d.Hm == d.Hout) & (d.Wm == d.Wout);
+  // identity pixel map (every launch but the sub-pixel phases of a transposed conv): addresses are a uniform 64-bit
+  // tile base + a 32-bit per-thread offset, so a row costs one VALU add instead of 64-bit multiplies per operand
+  auto rows = [&](auto ident_c) {
+    constexpr bool IDENT = decltype(ident_c)::value;
+    const size_t tbase = IDENT ? (size_t)tile_m * BM : 0;
+    const float* maskb = a.mask + tbase * d.ldMask;
+    const float* addb = a.add + tbase * d.ldAdd;
+    float* outb = a.out + tbase * d.ldOut;
+    const int mrem = a.M - 1 - tile_m * BM;          // last valid row of this tile
 #pragma unroll
-  for (int b = 0; b < ROWS; b += R) {
-    size_t opix[R];
-    bool ok[R];
+    for (int b = 0; b < ROWS; b += R) {
+      size_t opix[R];
+      bool ok[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      int m = tile_m * BM + r0 + (b + r) * RPP;
-      ok[r] = m < a.M;
-      m = min(m, a.M - 1);
-      opix[r] = m;
-      if (!identity_pix) {
-        const int n = m / a.HWm;
-        const int rem = m - n * a.HWm;
-        const int y = rem / d.Wm;
-        const int x = rem - y * d.Wm;
-        opix[r] = ((size_t)n * d.Hout + (y * d.ostride + d.ophH)) * d.Wout + (x * d.ostride + d.ophW);
+      for (int r = 0; r < R; ++r) {
+        const int row = r0 + (b + r) * RPP;
+        ok[r] = row <= mrem;
+        if (IDENT) {
+          opix[r] = (unsigned)min(row, mrem);
+        } else {
+          const int m = min(tile_m * BM + row, a.M - 1);
+          const int n = m / a.HWm;
+          const int rem = m - n * a.HWm;
+          const int y = rem / d.Wm;
+          const int x = rem - y * d.Wm;
+          opix[r] = ((size_t)n * d.Hout + (y * d.ostride + d.ophH)) * d.Wout + (x * d.ostride + d.ophW);
+        }
       }
-    }
-    f32x4 mk[R], ad[R];
-    if (flags & FO_MASK) {
-#pragma unroll
-      for (int r = 0; r < R; ++r) mk[r] = *reinterpret_cast<const f32x4*>(a.mask + opix[r] * d.ldMask + co);
-    }
-    if (flags & FO_ADD) {
-#pragma unroll
-      for (int r = 0; r < R; ++r) ad[r] = *reinterpret_cast<const f32x4*>(a.add + opix[r] * d.ldAdd + co);
-    }
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      f32x4 v = *reinterpret_cast<const f32x4*>(Cs + (r0 + (b + r) * RPP) * C_LD + c4 * 4) + bv;
+      auto off = [&](int r, int ld) -> size_t { return IDENT ? (size_t)(unsigned)((int)opix[r] * ld + co) : opix[r] * ld + co; };
+      f32x4 mk[R], ad[R];
       if (flags & FO_MASK) {
-        v.x = mk[r].x > 0.f ? v.x : 0.f; v.y = mk[r].y > 0.f ? v.y : 0.f; v.z = mk[r].z > 0.f ? v.z : 0.f; v.w = mk[r].w > 0.f ? v.w : 0.f;
+#pragma unroll
+        for (int r = 0; r < R; ++r) mk[r] = *reinterpret_cast<const f32x4*>(maskb + off(r, d.ldMask));
       }
-      if (flags & FO_ADD) v += ad[r];
-      if (flags & FO_OUT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-      if (ok[r]) *reinterpret_cast<f32x4*>(a.out + opix[r] * d.ldOut + co) = v;
+      if (flags & FO_ADD) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) ad[r] = *reinterpret_cast<const f32x4*>(addb + off(r, d.ldAdd));
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(Cs + (r0 + (b + r) * RPP) * C_LD + c4 * 4) + bv;
+        if (flags & FO_MASK) {
+          v.x = mk[r].x > 0.f ? v.x : 0.f; v.y = mk[r].y > 0.f ? v.y : 0.f; v.z = mk[r].z > 0.f ? v.z : 0.f; v.w = mk[r].w > 0.f ? v.w : 0.f;
+        }
+        if (flags & FO_ADD) v += ad[r];
+        if (flags & FO_OUT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (ok[r]) *reinterpret_cast<f32x4*>(outb + off(r, d.ldOut)) = v;
+      }
     }
-  }
+  };
+  if (identity_pix) rows(std::true_type{});
+  else rows(std::false_type{});
 }
 
 template <int BN, int WAVES_M, int WAVES_N, int TM, int TN, bool SMALLC, bool INRELU>
@@ -160,28 +176,32 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
   unsigned tapmask[4];  // bit t = tap t reads inside the image for this row
   int py[4], px[4], pbase[4];
   bool pv[4];
+  // The tile set-up is VALU work too (it runs beside the other resident workgroup's MFMAs, on the same ALUs): the frame
+  // of a frame-aligned tile is a scalar, power-of-two widths decode with shifts, and tap validity is separable
+  // (depth x row x column) instead of a loop over all taps.
+  int n_tile = 0, t_tile = 0;
+  if (a.frameAligned) { n_tile = (tile_m * BM) / a.HWm; t_tile = n_tile % d.T; }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int m = tile_m * BM + lrow + 32 * i;
     pv[i] = m < a.M;
     const int mm = pv[i] ? m : 0;
-    const int n = mm / a.HWm;
-    const int rem = mm - n * a.HWm;
-    const int y = rem / d.Wm;
-    const int x = rem - y * d.Wm;
-    const int t = n % d.T;
+    int n, rem, t, y, x;
+    if (a.frameAligned) { n = n_tile; t = t_tile; rem = mm - n_tile * a.HWm; }
+    else { n = mm / a.HWm; rem = mm - n * a.HWm; t = n % d.T; }
+    if (a.wShift >= 0) { y = rem >> a.wShift; x = rem & (d.Wm - 1); }
+    else { y = rem / d.Wm; x = rem - y * d.Wm; }
     py[i] = y * d.stride - d.padH;
     px[i] = x * d.stride - d.padW;
     pbase[i] = ((n - d.padD) * d.Hin + py[i]) * d.Win + px[i];   // pixel index of tap (0,0,0)
     rowoff[i] = (pbase[i] * d.ldIn + lcol) * 4 + a.margin;   // >= 0: the descriptor starts `margin` bytes below `in`
     unsigned mk = 0;
     if (!SMALLC) {
-      for (int tp = 0; tp < ntaps; ++tp) {
-        const int kd = tp / khw, r = tp - kd * khw, kh = r / d.KW, kw = r - kh * d.KW;
-        const bool ok = pv[i] & ((unsigned)(t + kd - d.padD) < (unsigned)d.T) & ((unsigned)(py[i] + kh) < (unsigned)d.Hin) &
-                        ((unsigned)(px[i] + kw) < (unsigned)d.Win);
-        mk |= (ok ? 1u : 0u) << tp;
-      }
+      unsigned mw = 0, mrow = 0;
+      for (int kw = 0; kw < d.KW; ++kw) mw |= ((unsigned)(px[i] + kw) < (unsigned)d.Win ? 1u : 0u) << kw;
+      for (int kh = 0; kh < d.KH; ++kh) mrow |= ((unsigned)(py[i] + kh) < (unsigned)d.Hin ? mw : 0u) << (kh * d.KW);
+      for (int kd = 0; kd < d.KD; ++kd) mk |= ((unsigned)(t + kd - d.padD) < (unsigned)d.T ? mrow : 0u) << (kd * khw);
+      mk = pv[i] ? mk : 0u;
     }
     tapmask[i] = ~mk;   // bit t SET = tap t is padding (or past the last tap) for this row
   }
@@ -463,6 +483,9 @@ extern "C" int fo_conv_igemm(const fo_conv_desc* d, const float* in, const float
   a.M = (int)M;
   a.tilesM = (a.M + BM - 1) / BM;
   a.frameAligned = (a.HWm % BM) == 0;
+  a.wShift = -1;
+  for (int sft = 0; sft < 16; ++sft)
+    if ((1 << sft) == d->Wm) a.wShift = sft;
   const unsigned long long inBytes = (((unsigned long long)d->N * d->Hin * d->Win - 1) * d->ldIn + d->Cin) * 4ull;
   const int opad = d->Cout > 64 ? (d->Cout + 127) / 128 * 128 : (d->Cout > 32 ? 64 : 32);
   const unsigned long long wpBytes = (unsigned long long)opad * a.Ktot * 4ull;

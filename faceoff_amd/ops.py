@@ -242,10 +242,15 @@ _ws_cache = {}
 
 
 def _workspace(nbytes, device):
-    key = (device, "wgrad")
+    """Split-K / column-sum scratch, one buffer PER STREAM: a buffer is allocated while its stream is current, so it
+    lives in that stream's allocator pool and every kernel that touches it is ordered on that stream.  (A single
+    shared buffer was a race: when it grew, the old one -- possibly still read by a reduce kernel on the side
+    stream -- went back to the main stream's pool and was handed to the next activation.)"""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() * 4 < nbytes:
-        buf = torch.empty((nbytes + 3) // 4 + 1024, device=device, dtype=torch.float32)
+        grow = 0 if buf is None else buf.numel() * 4 * 3 // 2
+        buf = torch.empty((max(nbytes, grow) + 3) // 4 + 1024, device=device, dtype=torch.float32)
         _ws_cache[key] = buf
     return buf
 
