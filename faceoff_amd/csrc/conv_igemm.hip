@@ -46,6 +46,8 @@ struct ConvArgs {
   int Ktot;       // taps*Cin  (row length of wp)
   int frameAligned;  // HWm % 128 == 0  -> a tile never straddles frames
   int wShift;        // log2(Wm) if Wm is a power of two, else -1
+  int hwShift;       // log2(Hm*Wm) likewise
+  int kwShift;       // log2(KW) likewise
   int margin;        // bytes the input descriptor starts below `in`, so that per-row base offsets are never negative
   unsigned inBytes;  // addressable extent behind `in` (buffer descriptor bound)
   unsigned wpBytes;
@@ -72,6 +74,15 @@ __device__ unsigned long long fo_stamps[4096];
 
 __device__ __forceinline__ f32x4 bufload(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+
+// m -> (frame, y, x) of the GEMM-M grid; shifts when the grid is a power of two (every C2 shape), divisions otherwise
+__device__ __forceinline__ void decode_pixel(const ConvArgs& a, int m, int& n, int& y, int& x) {
+  int rem;
+  if (a.hwShift >= 0) { n = m >> a.hwShift; rem = m & (a.HWm - 1); }
+  else { n = m / a.HWm; rem = m - n * a.HWm; }
+  if (a.wShift >= 0) { y = rem >> a.wShift; x = rem & (a.d.Wm - 1); }
+  else { y = rem / a.d.Wm; x = rem - y * a.d.Wm; }
 }
 
 // Rows of the LDS-transposed C tile -> global memory: bias, ReLU mask, residual, ReLU, 16 B per lane.  A thread's rows
@@ -114,10 +125,8 @@ __device__ __forceinline__ void store_tile(const ConvArgs& a, const float* Cs, i
           opix[r] = (unsigned)min(row, mrem);
         } else {
           const int m = min(tile_m * BM + row, a.M - 1);
-          const int n = m / a.HWm;
-          const int rem = m - n * a.HWm;
-          const int y = rem / d.Wm;
-          const int x = rem - y * d.Wm;
+          int n, y, x;
+          decode_pixel(a, m, n, y, x);
           opix[r] = ((size_t)n * d.Hout + (y * d.ostride + d.ophH)) * d.Wout + (x * d.ostride + d.ophW);
         }
       }
@@ -188,6 +197,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     const int mm = pv[i] ? m : 0;
     int n, rem, t, y, x;
     if (a.frameAligned) { n = n_tile; t = t_tile; rem = mm - n_tile * a.HWm; }
+    else if (a.hwShift >= 0) { n = mm >> a.hwShift; rem = mm & (a.HWm - 1); t = n % d.T; }
     else { n = mm / a.HWm; rem = mm - n * a.HWm; t = n % d.T; }
     if (a.wShift >= 0) { y = rem >> a.wShift; x = rem & (d.Wm - 1); }
     else { y = rem / d.Wm; x = rem - y * d.Wm; }
@@ -248,8 +258,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
       const int k = ld_step * BK + lcol;
       const int tap = k >> a.cinShift;
       const int coff = k & (d.Cin - 1);
-      const int kh = tap / d.KW;
-      const int kw = tap - kh * d.KW;
+      int kh, kw;
+      if (a.kwShift >= 0) { kh = tap >> a.kwShift; kw = tap & (d.KW - 1); }
+      else { kh = tap / d.KW; kw = tap - kh * d.KW; }
       const bool ok = pv[s] & (tap < ntaps) & ((unsigned)(py[s] + kh) < (unsigned)d.Hin) & ((unsigned)(px[s] + kw) < (unsigned)d.Win);
       const unsigned off = (unsigned)(((pbase[s] + kh * d.Win + kw) * d.ldIn + coff) * 4 + a.margin);
       ra[s] = bufload(rin, ok ? off : OOB, 0);
@@ -388,10 +399,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     for (int row = tid / C4; row < BM; row += RPP) {
       const int m = tile_m * BM + row;
       if (m >= a.M) break;
-      const int n = m / a.HWm;
-      const int rem = m - n * a.HWm;
-      const int y = rem / d.Wm;
-      const int x = rem - y * d.Wm;
+      int n, y, x;
+      decode_pixel(a, m, n, y, x);
       const size_t opix = ((size_t)n * d.Hout + (2 * y + py)) * d.Wout + (2 * x + px);
       f32x4 v = *reinterpret_cast<const f32x4*>(Cs + row * C_LD + c4 * 4) + bv;
       if (flags & FO_OUT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
@@ -483,9 +492,12 @@ extern "C" int fo_conv_igemm(const fo_conv_desc* d, const float* in, const float
   a.M = (int)M;
   a.tilesM = (a.M + BM - 1) / BM;
   a.frameAligned = (a.HWm % BM) == 0;
-  a.wShift = -1;
-  for (int sft = 0; sft < 16; ++sft)
+  a.wShift = a.hwShift = a.kwShift = -1;
+  for (int sft = 0; sft < 30; ++sft) {
     if ((1 << sft) == d->Wm) a.wShift = sft;
+    if ((1 << sft) == a.HWm) a.hwShift = sft;
+    if ((1 << sft) == d->KW) a.kwShift = sft;
+  }
   const unsigned long long inBytes = (((unsigned long long)d->N * d->Hin * d->Win - 1) * d->ldIn + d->Cin) * 4ull;
   const int opad = d->Cout > 64 ? (d->Cout + 127) / 128 * 128 : (d->Cout > 32 ? 64 : 32);
   const unsigned long long wpBytes = (unsigned long long)opad * a.Ktot * 4ull;
