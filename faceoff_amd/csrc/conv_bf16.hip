@@ -40,6 +40,9 @@ struct ConvArgsH {
   unsigned inBytes, wpBytes;
 };
 
+#ifndef FO_ABLATE_H   // diagnostic builds (tools/ablate_bf16.sh): bit 0 drop the loop's global loads, 1 its LDS stores,
+#define FO_ABLATE_H 0 // 2 its fragment reads (results are wrong, only the timing is of interest)
+#endif
 constexpr int BM = 128;
 constexpr int ROWB = 144;            // LDS row: 128 B of data + 16 B pad
 constexpr unsigned OOB = 0x80000000u;
@@ -163,10 +166,18 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvArgsH a) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       bf16x8 fa[TM], fb[TN];
+      const int sr = (FO_ABLATE_H & 4) ? 0 : s;
+      if ((FO_ABLATE_H & 4) && s > 0) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(As + i * 32 * ROWB + s * 32);
+        for (int i = 0; i < TM; ++i) fa[i] = __builtin_bit_cast(bf16x8, ra[0][i]);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(Bs + j * 32 * ROWB + s * 32);
+        for (int j = 0; j < TN; ++j) fb[j] = __builtin_bit_cast(bf16x8, ra[1][j]);
+      } else {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(As + i * 32 * ROWB + sr * 32);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(Bs + j * 32 * ROWB + sr * 32);
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -181,14 +192,14 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvArgsH a) {
   __syncthreads();
   const int nsteps = a.ksteps;
   for (int step = 0; step < nsteps; step += 2) {
-    load_step(0);                 // step + 2
+    if (!(FO_ABLATE_H & 1)) load_step(0);                 // step + 2
     compute(0);                   // step
-    store_step(1, 1);             // step + 1
+    if (!(FO_ABLATE_H & 2)) store_step(1, 1);             // step + 1
     __syncthreads();
     if (step + 1 >= nsteps) break;
-    load_step(1);                 // step + 3
+    if (!(FO_ABLATE_H & 1)) load_step(1);                 // step + 3
     compute(1);                   // step + 1
-    store_step(0, 0);             // step + 2
+    if (!(FO_ABLATE_H & 2)) store_step(0, 0);             // step + 2
     __syncthreads();
   }
 
