@@ -219,9 +219,7 @@ int fo_vq_prepare(const float* embed, float* embedT, float* enorm, void* stream)
 int fo_vq_assign(const float* x, int ldx, int64_t nvec, const float* embedT, const float* enorm, int64_t* ind,
                  float* q_ste, int ldq, float* sq_sum, void* stream) {
   FO_REQUIRE(nvec > 0 && ldx >= VQ_D && ldq >= VQ_D, FO_E_SHAPE, "vq_assign: bad shape");
-  int dev = 0, cus = 256;
-  hipGetDevice(&dev);
-  hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  const int cus = fo_cu_count();
   const int64_t ntiles = (nvec + 31) / 32;
   const int grid = (int)std::min<int64_t>(cus, (ntiles + 3) / 4);
   hipLaunchKernelGGL(vq_assign_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, (long long)nvec, embedT, enorm,
