@@ -88,6 +88,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: its wheel bundles a HIP runtime, and the process must end up with ONE libamdhip64 -- the one torch's
+    # allocator and streams live in.  Loading this library before torch binds it to the system runtime instead, and
+    # launches then fail with "no ROCm-capable device is detected".
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise FaceoffHipError(
             f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). "
