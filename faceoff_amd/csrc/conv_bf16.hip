@@ -142,11 +142,11 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvArgsH a) {
       if (++ld_kw == d.KW) { ld_kw = 0; ++ld_kh; }
     }
   };
-  auto store_step = [&](int slot, int buf) {
+  auto store_step = [&](int slot, int buf, int s_lo = 0, int s_hi = 4) {
     unsigned char* As = As0 + buf * BM * ROWB;
     unsigned char* Bs = Bs0 + buf * BN * ROWB;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
+    for (int s = s_lo; s < s_hi; ++s) {
       *reinterpret_cast<u32x4*>(As + (lrow + 32 * s) * ROWB + lcolB) = ra[slot][s];
       if (s < BROWS) *reinterpret_cast<u32x4*>(Bs + (lrow + 32 * s) * ROWB + lcolB) = rb[slot][s < BROWS ? s : 0];
     }
@@ -160,7 +160,9 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvArgsH a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  auto compute = [&](int buf) {
+  // K-step `buf` on the matrix pipe; the LDS stores of the NEXT step (ring slot st_slot -> buffer st_buf, loaded a
+  // full step ago) ride in its second half, between the MFMAs, instead of in front of the barrier
+  auto compute = [&](int buf, int st_slot, int st_buf) {
     const unsigned char* As = As0 + buf * BM * ROWB + (wm * TM * 32 + l31) * ROWB + half * 16;
     const unsigned char* Bs = Bs0 + buf * BN * ROWB + (wn * TN * 32 + l31) * ROWB + half * 16;
 #pragma unroll
@@ -178,6 +180,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvArgsH a) {
 #pragma unroll
       for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(Bs + j * 32 * ROWB + sr * 32);
       }
+      if (s >= 2 && !(FO_ABLATE_H & 2)) store_step(st_slot, st_buf, 2 * (s - 2), 2 * (s - 2) + 2);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -193,13 +196,11 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvArgsH a) {
   const int nsteps = a.ksteps;
   for (int step = 0; step < nsteps; step += 2) {
     if (!(FO_ABLATE_H & 1)) load_step(0);                 // step + 2
-    compute(0);                   // step
-    if (!(FO_ABLATE_H & 2)) store_step(1, 1);             // step + 1
+    compute(0, 1, 1);             // step; stores step + 1
     __syncthreads();
     if (step + 1 >= nsteps) break;
     if (!(FO_ABLATE_H & 1)) load_step(1);                 // step + 3
-    compute(1);                   // step + 1
-    if (!(FO_ABLATE_H & 2)) store_step(0, 0);             // step + 2
+    compute(1, 0, 0);             // step + 1; stores step + 2
     __syncthreads();
   }
 
