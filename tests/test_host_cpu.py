@@ -123,3 +123,19 @@ def test_process_data_mirrors_reference_contract():
     datab = tuple(torch.rand((2, T, 3, H, W), generator=g) for _ in range(5))
     (src, bg), T3, gt3 = split_batch(datab, "cpu")
     assert T3 == T and src.shape == (2 * T, 3, H, W) and gt3.shape == (2 * T, 3, H, W)
+
+
+def test_product_never_imports_the_oracle():
+    """oracle/ is test infrastructure: nothing under faceoff_amd/, bench.py's product leg or __graft_entry__.build may
+    import it (bench.py's cpu_baseline leg and smoke() are the two permitted checkers)."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pat = re.compile(r"^\s*(from|import)\s+oracle\b", re.M)
+    for dirpath, _, files in os.walk(os.path.join(root, "faceoff_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not pat.search(src), os.path.join(dirpath, f)
+    bench = open(os.path.join(root, "bench.py")).read()
+    uses = [m.start() for m in pat.finditer(bench)]
+    assert uses and all("def cpu_baseline" in bench[:u] and "def main" not in bench[bench.index("def cpu_baseline"):u] for u in uses)
