@@ -48,6 +48,7 @@ struct ConvArgs {
   int wShift;        // log2(Wm) if Wm is a power of two, else -1
   int hwShift;       // log2(Hm*Wm) likewise
   int kwShift;       // log2(KW) likewise
+  int scRow;         // SMALLC: a K-step is one filter row (KW * Cin == 32)
   int margin;        // bytes the input descriptor starts below `in`, so that per-row base offsets are never negative
   unsigned inBytes;  // addressable extent behind `in` (buffer descriptor bound)
   unsigned wpBytes;
@@ -213,6 +214,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
       for (int kd = 0; kd < d.KD; ++kd) mk |= ((unsigned)(t + kd - d.padD) < (unsigned)d.T ? mrow : 0u) << (kd * khw);
       mk = pv[i] ? mk : 0u;
     }
+    if (SMALLC && a.scRow) {
+      // small-channel layers whose K-step is exactly one filter row (KW * Cin == 32, e.g. k4 over 8 channels): this
+      // thread's kw and channel offset never change, so column validity is folded into the row's VGPR offset once
+      // per tile and the per-step part (kh) is a scalar offset + one bit of a row mask -- as on the regular path
+      const int kw_t = lcol >> a.cinShift, coff_t = lcol & (d.Cin - 1);
+      const bool xok = pv[i] & ((unsigned)(px[i] + kw_t) < (unsigned)d.Win);
+      rowoff[i] = xok ? ((pbase[i] + kw_t) * d.ldIn + coff_t) * 4 + a.margin : (int)OOB;
+      for (int kh = 0; kh < d.KH; ++kh) mk |= ((unsigned)(py[i] + kh) < (unsigned)d.Hin ? 1u : 0u) << kh;
+    }
     tapmask[i] = ~mk;   // bit t SET = tap t is padding (or past the last tap) for this row
   }
 
@@ -254,7 +264,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
   // address arithmetic sits between two 4-MFMA bursts and runs while the matrix pipe is busy.  Past
   // the last step the walk yields out-of-range offsets (zeros): no branch on "is there a next step".
   auto load_part = [&](int s) {
-    if (SMALLC) {
+    if (SMALLC && a.scRow) {
+      ra[s] = bufload(rin, ((tapmask[s] >> min(ld_step, 31)) << 31) | (unsigned)rowoff[s], ld_step * d.Win * d.ldIn * 4);
+    } else if (SMALLC) {
       const int k = ld_step * BK + lcol;
       const int tap = k >> a.cinShift;
       const int coff = k & (d.Cin - 1);
@@ -492,6 +504,7 @@ extern "C" int fo_conv_igemm(const fo_conv_desc* d, const float* in, const float
   a.M = (int)M;
   a.tilesM = (a.M + BM - 1) / BM;
   a.frameAligned = (a.HWm % BM) == 0;
+  a.scRow = smallc && d->KW * d->Cin == BK && d->KD == 1;
   a.wShift = a.hwShift = a.kwShift = -1;
   for (int sft = 0; sft < 30; ++sft) {
     if ((1 << sft) == d->Wm) a.wShift = sft;
