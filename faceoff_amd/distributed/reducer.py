@@ -13,12 +13,14 @@ from torch import distributed as dist
 
 
 class GradBucketReducer:
-    def __init__(self, flat_grads, layer_order, offsets, bucket_bytes=4 << 20, group=None):
+    def __init__(self, flat_grads, layer_order, offsets, bucket_bytes=4 << 20, group=None, always=False):
         """layer_order: arena order of layer names (reverse of backward completion);
         offsets: key -> (offset, numel) for '<layer>.weight' / '<layer>.bias'."""
         self.flat = flat_grads
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        # always=True: issue the collectives even in a one-rank group (exercises the RCCL path on a single GPU)
+        self.active = self.world > 1 or (always and dist.is_available() and dist.is_initialized())
         # walk the arena from the end (first-completed layer) building buckets
         self.buckets = []          # (lo, hi, last layer of the bucket in backward order)
         self.members = []          # layer names per bucket
@@ -41,13 +43,13 @@ class GradBucketReducer:
         self._pending = [set(ms) for ms in self.members]
         self._works = []
         self.cuda = flat_grads.is_cuda
-        self.side = torch.cuda.Stream(device=flat_grads.device) if self.cuda and self.world > 1 else None
+        self.side = torch.cuda.Stream(device=flat_grads.device) if self.cuda and self.active else None
         self.launched = []         # bucket indices in launch order (tests)
 
     def layer_done(self, name):
         """grad_ready_hook of the engine: fire the bucket whose last layer just completed."""
         i = self._bucket_of.get(name)
-        if i is None or self.world == 1:
+        if i is None or not self.active:
             return
         self._pending[i].discard(name)
         if self._pending[i]:
@@ -66,7 +68,7 @@ class GradBucketReducer:
 
     def finish(self):
         """Join the side stream; afterwards the arena holds the SUM over ranks."""
-        if self.world == 1:
+        if not self.active:
             return
         if self.cuda:
             with torch.cuda.stream(self.side):
@@ -84,8 +86,8 @@ class GradBucketReducer:
 def fused_vq_allreduce(group=None):
     """Returns f(stats[512 + 512*64]) summing the EMA statistics of one quantiser over ranks in ONE
     message (the reference issues two blocking all-reduces per quantiser, vqvae_conv3d_latent.py:63-64)."""
-    def f(stats):
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    def f(stats, always=False):
+        if dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or always):
             dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
         return stats
     return f

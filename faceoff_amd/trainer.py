@@ -43,7 +43,10 @@ class FlatAdam:
 
 
 class FaceOffTrainer:
-    def __init__(self, engine: VQVAEEngine, lr=3e-4, scheduler=None, vqlpips=None, bucket_bytes=4 << 20, group=None):
+    def __init__(self, engine: VQVAEEngine, lr=3e-4, scheduler=None, vqlpips=None, bucket_bytes=4 << 20, group=None,
+                 force_collectives=False):
+        """force_collectives: run the gradient-bucket and VQ-statistics all-reduces even in a one-rank process group
+        (tests: the RCCL path on a single GPU)."""
         self.engine = engine
         self.optimizer = FlatAdam(engine, lr=lr)
         self.scheduler = scheduler
@@ -57,10 +60,12 @@ class FaceOffTrainer:
         if vqlpips is not None and engine.device.type == "cuda" and not _os.environ.get("FACEOFF_NO_LPIPS_OVERLAP"):
             self.lpips_stream = torch.cuda.Stream(device=engine.device)
         self.reducer = None
-        if self.world > 1:
-            self.reducer = GradBucketReducer(engine.flat_grads, engine.layer_order, engine.offsets, bucket_bytes, group)
+        if self.world > 1 or force_collectives:
+            self.reducer = GradBucketReducer(engine.flat_grads, engine.layer_order, engine.offsets, bucket_bytes, group,
+                                             always=force_collectives)
             engine.grad_ready_hook = self.reducer.layer_done
-            engine.vq_allreduce = fused_vq_allreduce(group)
+            vq_ar = fused_vq_allreduce(group)
+            engine.vq_allreduce = (lambda st: vq_ar(st, always=True)) if force_collectives else vq_ar
 
     def step(self, img, ground_truth, T=None):
         """img [B,T,6,H,W] or [N,6,H,W]; ground_truth likewise with 3 channels (utils.py:29-38).

@@ -59,3 +59,52 @@ def test_two_ranks_equal_one_process_on_the_concatenated_batch():
         2e-3 * eng.buffers["quantize_b.embed"].abs().max().item()
     dp = (r[0]["params"] - eng.flat_params.cpu()).abs().max().item()
     assert dp <= 1e-4, dp                                             # one Adam step of lr 3e-4
+
+
+_RCCL_SCRIPT = r"""
+import os, sys, torch
+sys.path.insert(0, os.getcwd())
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+torch.cuda.set_device(0)
+torch.distributed.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % int(sys.argv[1]), rank=0, world_size=1,
+                                     device_id=torch.device("cuda", 0))
+from faceoff_amd.engine import VQVAEEngine
+from faceoff_amd.synth import make_state_dict, make_batch
+from faceoff_amd.trainer import FaceOffTrainer
+img, gt = make_batch(100, 2, 2, 64, 64)
+img, gt = torch.from_numpy(img).cuda(), torch.from_numpy(gt).cuda()
+out = []
+for force in (True, False):
+    eng = VQVAEEngine(make_state_dict(0, codebook_scale=0.3, gain=2.0), "cuda:0")
+    tr = FaceOffTrainer(eng, lr=3e-4, bucket_bytes=2 << 20, force_collectives=force)
+    assert (tr.reducer is not None) == force
+    recon, latent, _ = tr.step(img, gt)
+    torch.distributed.barrier()
+    torch.cuda.synchronize()
+    if force:
+        assert len(tr.reducer.buckets) >= 4
+    out.append((eng.flat_params.clone(), eng.flat_grads.clone(), eng.buffers["quantize_b.embed"].clone(), recon.item()))
+    tr.step(img, gt)                      # a second step re-arms the buckets (EMA rounding makes it non-bitwise)
+    torch.cuda.synchronize()
+    assert torch.isfinite(eng.flat_params).all()
+assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1]), "one-rank RCCL all-reduce changed the result"
+assert (out[0][2] - out[1][2]).abs().max().item() <= 1e-5 * out[1][2].abs().max().item()
+torch.distributed.destroy_process_group()
+print("RCCL_PATH_OK")
+"""
+
+
+def test_rccl_code_path_in_a_one_rank_group():
+    """The GPU box has ONE device and RCCL refuses two ranks on it, so the RCCL-specific plumbing (process group with
+    device_id, async all-reduce of arena slices issued under the side stream, work.wait() on that stream, the in-forward
+    VQ-statistics all-reduce, barrier) is exercised with a one-rank "nccl" group and forced collectives: a training
+    step must give exactly the parameters and gradients of the plain path."""
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", _RCCL_SCRIPT, str(port)], capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0 and "RCCL_PATH_OK" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
