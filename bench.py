@@ -75,8 +75,20 @@ def main():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # FACEOFF_BENCH_FORCE_DDP=1 (diagnostic): take the multi-GPU code path -- RCCL process group, bucketed gradient
+    # all-reduce on the side stream, VQ-statistics all-reduce, barrier, max-over-ranks -- with however many ranks there
+    # are, including one (the GPU box used for development has a single device)
+    ddp = world > 1 or bool(os.environ.get("FACEOFF_BENCH_FORCE_DDP"))
+    # The contract is ONE JSON line on stdout.  RCCL prints its version banner to stdout, so everything any library
+    # writes to fd 1 from here on goes to stderr; the JSON line is written to the saved descriptor at the end.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    if ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.distributed.init_process_group("nccl", device_id=dev)
 
@@ -92,13 +104,13 @@ def main():
         from faceoff_amd.loss import VQLPIPS
         from faceoff_amd.synth import make_vgg_lpips_state
         vqlpips = VQLPIPS(make_vgg_lpips_state(7), dtype=args.lpips_dtype).to(dev)
-    trainer = FaceOffTrainer(eng, lr=3e-4, vqlpips=vqlpips)
+    trainer = FaceOffTrainer(eng, lr=3e-4, vqlpips=vqlpips, force_collectives=ddp and world == 1)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     img = torch.rand((B * T, 6, H, H), device=dev, generator=gen) * 2 - 1       # U(-1,1): dataset.py:240-247
     gt = torch.rand((B * T, 3, H, H), device=dev, generator=gen) * 2 - 1
 
     def sync():
-        if world > 1:
+        if ddp:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -133,13 +145,12 @@ def main():
         sync()
         ms_serial = (time.perf_counter() - t1) / args.steps * 1e3
         ops.PROFILER = None
-    if world > 1:
+    if ddp:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         dt = tmax.item()
     if rank != 0:
-        if world > 1:
-            torch.distributed.destroy_process_group()
+        torch.distributed.destroy_process_group()
         return
 
     ms = dt / args.steps * 1e3
@@ -193,9 +204,11 @@ def main():
                 pass
     if world == 1 and not args.no_cpu_baseline and not args.perceptual:
         out["cpu_baseline"] = cpu_baseline(T, H, H)
-    print(json.dumps(out), flush=True)
-    if world > 1:
+    if ddp:
         torch.distributed.destroy_process_group()
+    sys.stdout.flush()
+    os.write(json_fd, (json.dumps(out) + "\n").encode())
+    os.close(json_fd)
 
 
 if __name__ == "__main__":
