@@ -30,3 +30,16 @@ def test_bench_emits_one_valid_json_line():
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     # achieved = algorithmic FLOP per launch / average launch duration
     assert abs(r["achieved"] - r["algorithmic_gflop_per_launch"] / r["avg_launch_ms"]) < 0.02 * r["achieved"]
+
+
+def test_bench_multi_gpu_code_path_with_one_rank():
+    """The branch the driver's 2/4/8-GPU runs take (RCCL group, bucketed all-reduce, barrier, max over ranks), forced on
+    with a single rank: still exactly one JSON line on stdout (RCCL writes its banner to stdout) and a sane value."""
+    env = dict(os.environ, FACEOFF_BENCH_FORCE_DDP="1", MASTER_PORT="29577")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                          "--no-kernel-events"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["parallelism"] == "dp1"
