@@ -173,3 +173,25 @@ def test_lpips_bf16_vs_bf16_simulated_oracle():
     np.testing.assert_allclose(loss.item(), vals[False], rtol=2e-2)
     assert rel(got, grads[False]) <= 1e-1
     assert torch.equal(g_dec[..., 3:], torch.zeros_like(g_dec[..., 3:]))
+
+
+def test_lpips_bf16_frame_chunking_and_precomputed_target_taps():
+    """bf16 branch: frame chunks (2 GiB window) and the side-stream form (target taps computed ahead) give the same loss and
+    gradient as the plain call -- bit-identical gradient (same kernels on the same data), loss equal up to atomic order."""
+    from faceoff_amd.lpips import LPIPSEngine
+    eng = LPIPSEngine(make_vgg_lpips_state(5), "cuda:0", dtype="bf16")
+    rng = np.random.default_rng(2)
+    tgt = torch.from_numpy(rng.uniform(-1, 1, (5, 3, 32, 32)).astype(np.float32)).cuda()
+    dec = torch.zeros((5, 32, 32, 8), device="cuda")
+    dec[..., :3] = tgt.permute(0, 2, 3, 1) + 0.3 * torch.from_numpy(rng.standard_normal((5, 32, 32, 3)).astype(np.float32)).cuda()
+    g1, g2, g3 = torch.zeros_like(dec), torch.zeros_like(dec), torch.zeros_like(dec)
+    l1 = eng.loss_and_grad(tgt, dec, g1)
+    taps0 = eng.target_taps(tgt)
+    assert taps0 is not None and taps0[0].dtype == torch.bfloat16
+    l3 = eng.loss_and_grad(tgt, dec, g3, taps0=taps0)
+    eng.window_bytes = 2 * 32 * 32 * 64 * 2              # two frames per chunk -> chunks of 2, 2, 1
+    assert eng.target_taps(tgt) is None                  # chunked batches compute the target branch inline
+    l2 = eng.loss_and_grad(tgt, dec, g2)
+    np.testing.assert_allclose([l2.item(), l3.item()], l1.item(), rtol=1e-5)
+    assert torch.equal(g1, g3)
+    assert (g1 - g2).abs().max().item() <= 1e-6 * g1.abs().max().item()
