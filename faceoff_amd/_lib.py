@@ -47,6 +47,10 @@ SIGNATURES = {
     "fo_pack_convT_k4s2_fused": (_I, [_P, _P, _I, _I, _I, _P]),
     "fo_conv_igemm": (_I, [_D, _P, _P, _P, _P, _P, _P, _P]),
     "fo_conv_igemm_variant": (_I, [_D]),
+    "fo_conv_igemm_banked": (_I, [_D, _P, _P, _P, _I, _P]),
+    "fo_wino_filter": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "fo_wino_input": (_I, [_P, _I, _P, _I, _I, _I, _I, _P]),
+    "fo_wino_output": (_I, [_P, _P, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
     "fo_wgrad_ws_bytes": (_L, [_D]),
     "fo_conv_wgrad": (_I, [_D, _P, _P, _P, _I, _I, _P, _P, _L, _P]),
     "fo_bias_grad": (_I, [_P, _P, _L, _I, _I, _I, _P, _P]),

@@ -49,6 +49,8 @@ struct ConvArgs {
   int hwShift;       // log2(Hm*Wm) likewise
   int kwShift;       // log2(KW) likewise
   int scRow;         // SMALLC: a K-step is one filter row (KW * Cin == 32)
+  int bankFrames;    // > 0: the filter bank is chosen by frame index, bank = frame / bankFrames (Winograd plane stacks)
+  unsigned bankBytes;  // bytes between consecutive filter banks
   int margin;        // bytes the input descriptor starts below `in`, so that per-row base offsets are never negative
   unsigned inBytes;  // addressable extent behind `in` (buffer descriptor bound)
   unsigned wpBytes;
@@ -252,6 +254,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
   unsigned wrow[BROWS];
 #pragma unroll
   for (int i = 0; i < BROWS; ++i) wrow[i] = (unsigned)(((size_t)(tile_n * BN + lrow + 32 * i) * a.Ktot + lcol) * 4);
+  if (a.bankFrames > 0) {   // frame-aligned tiles only: one frame, hence one filter bank, per tile
+    const unsigned boff = (unsigned)(n_tile / a.bankFrames) * a.bankBytes;
+#pragma unroll
+    for (int i = 0; i < BROWS; ++i) wrow[i] += boff;
+  }
 
   const int step_last = step_end - 1;   // filter loads past the last step re-read it (their data is never used)
   // incremental (tap, chunk) walk of the NEXT step to load (wave-uniform scalars)
@@ -464,8 +471,8 @@ static int pick_variant(const fo_conv_desc* d) {
 
 extern "C" int fo_conv_igemm_variant(const fo_conv_desc* d) { return d ? pick_variant(d) : FO_E_SHAPE; }
 
-extern "C" int fo_conv_igemm(const fo_conv_desc* d, const float* in, const float* wp, const float* bias,
-                             const float* mask, const float* add, float* out, void* stream) {
+static int conv_igemm_impl(const fo_conv_desc* d, const float* in, const float* wp, const float* bias, const float* mask,
+                           const float* add, float* out, void* stream, int bank_frames) {
   ConvArgs a;
   a.d = *d;
   a.in = in; a.wp = wp; a.bias = bias; a.mask = mask; a.add = add; a.out = out;
@@ -520,11 +527,19 @@ extern "C" int fo_conv_igemm(const fo_conv_desc* d, const float* in, const float
   a.margin = (int)margin;
   a.inBytes = (unsigned)inBytes;
   a.wpBytes = (unsigned)wpBytes;
+  a.bankFrames = bank_frames;
+  a.bankBytes = (unsigned)wpBytes;
+  if (bank_frames > 0) {
+    FO_REQUIRE(a.frameAligned && !smallc && d->N % bank_frames == 0, FO_E_SHAPE, "conv: filter banks need frame-aligned tiles");
+    const unsigned long long allBanks = (unsigned long long)(d->N / bank_frames) * wpBytes;
+    FO_REQUIRE(allBanks < (1ull << 31), FO_E_SHAPE, "conv: filter banks exceed the 2 GiB window");
+    a.wpBytes = (unsigned)allBanks;
+  }
   hipStream_t s = (hipStream_t)stream;
   // BN by output channels (filters are packed with Cout rounded up to the same BN)
   if (d->Cout > 64) {
     a.tilesN = (d->Cout + 127) / 128;
-    if (pick_variant(d) == 3) {
+    if (pick_variant(d) == 3 && bank_frames == 0) {
       if (d->flags & FO_IN_RELU) hipLaunchKernelGGL((conv_igemm3_kernel<2, 2, true>), dim3(a.tilesM * a.tilesN), dim3(256), 0, s, a);
       else hipLaunchKernelGGL((conv_igemm3_kernel<2, 2, false>), dim3(a.tilesM * a.tilesN), dim3(256), 0, s, a);
       FO_CHECK_LAUNCH();
@@ -538,4 +553,18 @@ extern "C" int fo_conv_igemm(const fo_conv_desc* d, const float* in, const float
     a.tilesN = 1;
     return launch<32, 4, 1, 1, 1>(a, smallc, s);
   }
+}
+
+extern "C" int fo_conv_igemm(const fo_conv_desc* d, const float* in, const float* wp, const float* bias,
+                             const float* mask, const float* add, float* out, void* stream) {
+  return conv_igemm_impl(d, in, wp, bias, mask, add, out, stream, 0);
+}
+
+// The same contraction with the filter chosen per frame: frames [b*bank_frames, (b+1)*bank_frames) use the b-th filter
+// bank (banks are consecutive packed filters of Opad*taps*Cin floats).  The 16 GEMMs of a Winograd-transformed Conv3d are
+// one such launch over the stack of transformed planes (winograd.hip).  Tiles must not straddle frames (Hm*Wm % 128 == 0).
+extern "C" int fo_conv_igemm_banked(const fo_conv_desc* d, const float* in, const float* wp, float* out, int bank_frames,
+                                    void* stream) {
+  FO_REQUIRE(bank_frames > 0 && !(d->flags & (FO_BIAS | FO_MASK | FO_ADD | FO_DEPTH2SPACE)), FO_E_SHAPE, "conv_banked: plain GEMM only");
+  return conv_igemm_impl(d, in, wp, nullptr, nullptr, nullptr, out, stream, bank_frames);
 }

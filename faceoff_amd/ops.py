@@ -172,6 +172,69 @@ def conv_igemm(x, wp, bias, out, *, T=1, k=(1, 3, 3), stride=1, pad=(0, 1, 1), c
         prof.end()
 
 
+# ------------------------------------------------------------------ Winograd F(2x2,3x3) Conv3d
+def wino_filter(w, dgrad=False):
+    """[O][I][KD][3][3] -> 16 packed (3,1,1) filter banks [16][Opad][KD][Ipad] (dgrad: flipped taps, swapped channels)."""
+    O, I, KD = w.shape[:3]
+    rows, cols = (I, O) if dgrad else (O, I)
+    Op, Ip = pad_out(rows), pad_in(cols)
+    U = torch.empty(16 * Op * KD * Ip, device=w.device, dtype=torch.float32)
+    _lib.call("fo_wino_filter", _ptr(w.contiguous()), _ptr(U), O, I, KD, Op, Ip, int(dgrad), _stream())
+    return U
+
+
+_wino_cache = {}
+
+
+def _wino_buffers(nfloats, device):
+    """(V, M) scratch of the transformed planes, one pair per stream (see _workspace)."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    buf = _wino_cache.get(key)
+    if buf is None or buf[0].numel() < nfloats[0] or buf[1].numel() < nfloats[1]:
+        buf = (torch.empty(nfloats[0], device=device, dtype=torch.float32), torch.empty(nfloats[1], device=device, dtype=torch.float32))
+        _wino_cache[key] = buf
+    return buf
+
+
+def conv3d_winograd(x, U, bias, out, *, T, cin, cout, flags=0, mask=None, add=None):
+    """Conv3d k3 p1 s1 (or its data gradient, with the dgrad filter banks) on [N,H,W,C] frames, clips of T frames."""
+    N, H, W, _ = x.shape
+    Ht, Wt = H // 2, W // 2
+    assert H % 2 == 0 and W % 2 == 0 and cin % 32 == 0
+    if bias is not None:
+        flags |= FO_BIAS
+    if mask is not None:
+        flags |= FO_MASK
+    if add is not None:
+        flags |= FO_ADD
+    plane_v, plane_m = N * Ht * Wt * cin, N * Ht * Wt * cout
+    V, M = _wino_buffers((16 * plane_v, 16 * plane_m), x.device)
+    _lib.call("fo_wino_input", _ptr(x), ld_of(x), _ptr(V), N, H, W, cin, _stream())
+    bank = pad_out(cout) * 3 * cin                                  # floats per filter bank
+    banked = (Ht * Wt) % 128 == 0
+    per = max(1, min(16, ((1 << 31) - 1) // max(plane_v * 4, plane_m * 4))) if banked else 1   # planes per launch (2 GiB window)
+    prof = PROFILER
+    for p0 in range(0, 16, per):
+        np_ = min(per, 16 - p0)
+        d = _desc(N=np_ * N, T=T, Hin=Ht, Win=Wt, Hm=Ht, Wm=Wt, Hout=Ht, Wout=Wt, Cin=cin, Cout=cout, KD=3, KH=1, KW=1, stride=1,
+                  padD=1, padH=0, padW=0, ostride=1, ophH=0, ophW=0, ldIn=cin, ldOut=cout, ldMask=0, ldAdd=0, flags=0)
+        vin = V[p0 * plane_v:(p0 + np_) * plane_v]
+        mout = M[p0 * plane_m:(p0 + np_) * plane_m]
+        wp = U[p0 * bank:(p0 + np_) * bank]
+        if prof is not None:
+            nominal = 2.0 * np_ * N * Ht * Wt * cout * 3 * cin
+            prof.begin("conv_igemm_bn128_wino" + (f" [{np_}x{N}x{Ht}x{Wt} {cin}->{cout}]" if prof.detail else ""),
+                       nominal * temporal_share(T), nominal)
+        if banked:
+            _lib.call("fo_conv_igemm_banked", C.byref(d), _ptr(vin), _ptr(wp), _ptr(mout), N, _stream())
+        else:
+            _lib.call("fo_conv_igemm", C.byref(d), _ptr(vin), _ptr(wp), None, None, None, _ptr(mout), _stream())
+        if prof is not None:
+            prof.end()
+    _lib.call("fo_wino_output", _ptr(M), _ptr(bias), _ptr(mask), ld_of(mask) if mask is not None else 0, _ptr(add),
+              ld_of(add) if add is not None else 0, _ptr(out), ld_of(out), N, H, W, cout, flags, _stream())
+
+
 # ------------------------------------------------------------------ bf16 conv family (LPIPS branch)
 def pack_conv_bf16(w, taps_pad=None):
     """fp32 [O][I][*taps] -> bf16 [Opad][tapsPad][Ipad] (Ipad: multiple of 64, or 8 for the RGB layer)"""

@@ -101,6 +101,10 @@ typedef struct fo_conv_desc {
 int fo_conv_igemm(const fo_conv_desc* d, const float* in, const float* wp, const float* bias,
                   const float* mask, const float* add, float* out, void* stream);
 
+/* fo_conv_igemm with the filter chosen per frame: frames [b*bank_frames, (b+1)*bank_frames) use the b-th of the
+ * consecutive packed filter banks behind `wp`.  No bias / mask / residual.  Needs Hm*Wm % 128 == 0. */
+int fo_conv_igemm_banked(const fo_conv_desc* d, const float* in, const float* wp, float* out, int bank_frames, void* stream);
+
 /* Which kernel instantiation fo_conv_igemm launches for `d` (no launch): 128 / 64 / 32 = conv_igemm_kernel<BN>,
  * 3 = conv_igemm3_kernel (Conv3d, one workgroup per CU).  For profilers that attribute time per kernel. */
 int fo_conv_igemm_variant(const fo_conv_desc* d);
@@ -171,6 +175,19 @@ int fo_lpips_tap_fwd(const float* f0, const float* f1, const float* lin, float* 
 /* Gradient of mean_n(sum of taps) wrt f1 (the reconstruction branch), times gscale[0], through f1's own ReLU. */
 int fo_lpips_tap_bwd(const float* f0, const float* f1, const float* lin, const float* gscale, float* gf1, int N, int H, int W,
                      int C, void* stream);
+
+/* ---------------------------------------------------------------- Winograd F(2x2,3x3) for the Conv3d k3 p1 layers (:181,185)
+ * out = A^T [ sum_{kd,ci} (G g_kd G^T) . (B^T d B) ] A: the two spatial dimensions are transformed (16 multiplies per
+ * 2x2 outputs instead of 36), depth taps and channels stay a contraction = a (3,1,1) Conv3d over the stack of 16
+ * transformed planes, run by fo_conv_igemm_banked (or one fo_conv_igemm per plane). */
+/* U[16][Opad][KD][Ipad] from the checkpoint filter w[O][I][KD][3][3]; dgrad=1: the data-gradient filter (flipped
+ * taps, channel roles swapped: rows = I, K columns = O). */
+int fo_wino_filter(const float* w, float* U, int O, int I, int KD, int Opad, int Ipad, int dgrad, void* stream);
+/* V[16][N][H/2][W/2][C] = B^T d B of the zero-padded 4x4 patches of x [N,H,W,ldx]. */
+int fo_wino_input(const float* x, int ldx, float* V, int N, int H, int W, int C, void* stream);
+/* out [N,H,W,ldOut] = epilogue(A^T M A), M[16][N][H/2][W/2][C]; flags: FO_BIAS | FO_MASK | FO_ADD | FO_OUT_RELU. */
+int fo_wino_output(const float* M, const float* bias, const float* mask, int ldMask, const float* add, int ldAdd, float* out,
+                   int ldOut, int N, int H, int W, int C, int flags, void* stream);
 
 /* ---------------------------------------------------------------- bf16 LPIPS branch (BASELINE config 3)
  * The same VGG-16 / LPIPS chain with bf16 storage and bf16 MFMA operands, fp32 accumulation and fp32 head

@@ -208,6 +208,40 @@ def test_conv3d_fwd_dgrad_wgrad(B, T, H, W):
     _close(db, b.grad, what="conv3d bias grad")
 
 
+@pytest.mark.parametrize("B,T,H,W", [(1, 1, 8, 16), (2, 2, 8, 8), (1, 5, 16, 16), (2, 5, 32, 32), (3, 3, 6, 10), (1, 5, 16, 32)])
+def test_conv3d_winograd_fwd_dgrad(B, T, H, W):
+    """The Winograd F(2x2,3x3) form of Conv3d 128->128 k3 p1 (transforms + banked (3,1,1) implicit GEMM) against
+    torch-CPU: forward with bias + ReLU, data gradient with ReLU mask + residual, banked (H/2*W/2 % 128 == 0) and
+    per-plane launches, clip padding (T = 1, 3, 5), a channel-slice output view."""
+    from faceoff_amd import ops
+    rng = np.random.default_rng(300 + B * 10 + T + H)
+    x = _rand(rng, B, 128, T, H, W).requires_grad_(True)
+    w = _rand(rng, 128, 128, 3, 3, 3, scale=0.02)
+    b = _rand(rng, 128, scale=0.1)
+    y_pre = F.conv3d(x, w, b, padding=1)
+    gy = _rand(rng, *y_pre.shape)
+    y_pre.backward(gy)
+    dev = _dev()
+
+    def frames(t5):   # [B,C,T,H,W] -> [B*T,H,W,C]
+        return t5.detach().permute(0, 2, 3, 4, 1).reshape(B * T, H, W, 128).contiguous().to(dev)
+
+    def clips(t4):
+        return t4.reshape(B, T, H, W, 128).permute(0, 4, 1, 2, 3).cpu()
+
+    xg, gyg, wg, bg = frames(x), frames(gy), w.to(dev), b.to(dev)
+    wide = torch.zeros((B * T, H, W, 192), device=dev)
+    ops.conv3d_winograd(xg, ops.wino_filter(wg), bg, wide[..., 64:192], T=T, cin=128, cout=128, flags=ops.FO_OUT_RELU)
+    _close(clips(wide[..., 64:192].contiguous()), torch.relu(y_pre), what="winograd conv3d fwd")
+    assert (wide[..., :64] == 0).all()
+    mask = frames(_rand(rng, B, 128, T, H, W)).clamp_min(0)
+    addt = frames(_rand(rng, B, 128, T, H, W))
+    gx = torch.empty_like(xg)
+    ops.conv3d_winograd(gyg, ops.wino_filter(wg, dgrad=True), None, gx, T=T, cin=128, cout=128, mask=mask, add=addt)
+    want = x.grad * (clips(mask) > 0) + clips(addt)
+    _close(clips(gx), want, what="winograd conv3d dgrad")
+
+
 def test_vq_assign_bit_exact_and_golden(golden_dir):
     """Indices bit-exact vs oracle/vq_oracle.c and vs the reference's own (golden) indices."""
     from faceoff_amd import ops
