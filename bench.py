@@ -175,16 +175,16 @@ def main():
     out["step_frac_of_mfma_roofline"] = round(ideal_s * fps / world, 4)      # SURVEY 8(d) FLOP count: padded taps included
     # the same with only the FLOP the matrix pipe actually executes: (a) Conv3d taps that fall into clip padding are
     # structural zeros, skipped by the kernels (2 of 15 (frame, depth tap) pairs at T=5; Conv3d is 63.7 % of the conv
-    # FLOP, fwd / dgrad / wgrad alike); (b) Conv3d forward and data gradient run as Winograd F(2x2,3x3): 16 multiplies
-    # per 2x2 outputs instead of 36.  With (b) the direct-convolution FLOP count is no longer a bound on the step.
+    # FLOP, fwd / dgrad / wgrad alike); (b) Conv3d forward, data gradient and filter gradient run as Winograd F(2x2,3x3):
+    # 16 multiplies per 2x2 outputs instead of 36.  With (b) the direct-convolution FLOP count is no longer a bound.
     from faceoff_amd.ops import temporal_share
     conv3d_flop = 3 * 2 * 6.795e9                                           # per frame: 6.795 GMAC fwd x 3 passes
     executed = FLOP_PER_FRAME - conv3d_flop * (1.0 - temporal_share(T))
     out["step_frac_direct_flop_without_padding_taps"] = round(executed * fps / world / (FP32_MFMA_PEAK_TFLOPS * 1e12), 4)
     if eng.winograd:
-        executed -= (2.0 / 3.0) * conv3d_flop * temporal_share(T) * (1.0 - 16.0 / 36.0)
+        executed -= conv3d_flop * temporal_share(T) * (1.0 - 16.0 / 36.0)
     out["step_frac_executed_flop"] = round(executed * fps / world / (FP32_MFMA_PEAK_TFLOPS * 1e12), 4)
-    out["config"]["conv3d_algorithm"] = "winograd F(2x2,3x3) fwd+dgrad, direct wgrad" if eng.winograd else "direct"
+    out["config"]["conv3d_algorithm"] = "winograd F(2x2,3x3) fwd, dgrad and wgrad" if eng.winograd else "direct"
     if prof is not None:
         summ = prof.summary()
         dom = max(summ, key=lambda k: summ[k]["total_ms"])

@@ -43,6 +43,8 @@ struct WgradArgs {
   int stepFrameAligned;  // HWm % 32 == 0
   unsigned pBytes, qBytes;  // addressable extents behind P and Q (buffer descriptor bounds)
   int qMargin;              // bytes Q's descriptor starts below Q (see the kernel)
+  int banks;                // > 1: the pixel axis is `banks` independent planes of N/banks frames; chunks never straddle a
+  int cpp;                  //      plane (cpp chunks per plane) and the slabs of a plane reduce to their own dW (Winograd)
   int fastWalk;             // Wm >= 32: a 32-pixel step wraps at most one image row
   int strideShift;          // log2(stride) (stride is 1 or 2)
   int kdLoop;               // Conv3d: a workgroup owns (chunk, kh, kw) and runs the KD depth taps one after another
@@ -111,6 +113,20 @@ __global__ __launch_bounds__(64 * WAVES_A * WAVES_B, 2) void conv_wgrad_kernel(c
       int wclip = 0;
       for (int t = 0; t < d.T; ++t) wclip += min(d.KD, d.T - t + d.padD) - max(0, d.padD - t);
       const long long Wclip = (long long)wclip * a.HWm;
+      if (a.banks > 1) {   // per plane: cpp equal-work chunks of its N/banks frames
+        const int bank = k / a.cpp, kk = k - bank * a.cpp;
+        const int planeM = a.M / a.banks;
+        const long long target = Wclip * (d.N / a.banks / d.T) * kk / a.cpp;
+        const int clip = (int)(target / Wclip);
+        long long rem = target - (long long)clip * Wclip;
+        int t = 0, px = 0;
+        for (; t < d.T; ++t) {
+          const int wt = min(d.KD, d.T - t + d.padD) - max(0, d.padD - t);
+          if (rem < (long long)wt * a.HWm) { px = (int)(rem / wt); break; }
+          rem -= (long long)wt * a.HWm;
+        }
+        return bank * planeM + min(planeM, ((clip * d.T + t) * a.HWm + px) & ~31);
+      }
       const long long target = Wclip * (d.N / d.T) * k / a.nchunks;
       const int clip = (int)(target / Wclip);
       long long rem = target - (long long)clip * Wclip;
@@ -426,6 +442,9 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restr
                                     int Apad, int Bpad, int Areal, int Breal, int smallc, int KW) {
   __shared__ float red[1024];
   const size_t slabElems = (size_t)taps * Apad * Bpad;
+  // blockIdx.y = bank: its nchunks slabs follow each other in ws, its dW follows the previous bank's
+  ws += (size_t)blockIdx.y * nchunks * slabElems;
+  dw += (size_t)blockIdx.y * Areal * Breal * taps * (smallc ? KW : 1);
   const int CL = blockDim.x >> 6, cl = threadIdx.x >> 6, li = threadIdx.x & 63;
   const size_t e = (size_t)blockIdx.x * 64 + li;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -474,11 +493,11 @@ __global__ void bias_reduce_kernel(const float* __restrict__ ws, float* __restri
 }
 
 struct Plan {
-  int TA, TB, tilesA, tilesB, Apad, Bpad, taps, chunk, nchunks, kdLoop, tapsSlab;
+  int TA, TB, tilesA, tilesB, Apad, Bpad, taps, chunk, nchunks, kdLoop, tapsSlab, cpp;
   bool smallc;
 };
 
-int make_plan(const fo_conv_desc* d, Plan* p) {
+int make_plan(const fo_conv_desc* d, Plan* p, int banks = 1) {
   const int A = d->Cout, B = d->Cin;  // channels of P (a) and Q (b)
   p->smallc = B < 32;
   if (p->smallc) {
@@ -514,6 +533,12 @@ int make_plan(const fo_conv_desc* d, Plan* p) {
   chunk = (chunk + 31) / 32 * 32;
   p->chunk = (int)chunk;
   p->nchunks = (int)((M + chunk - 1) / chunk);
+  p->cpp = p->nchunks;
+  if (banks > 1) {   // chunks per plane: the same total number of workgroups, never straddling a plane
+    FO_REQUIRE(p->kdLoop && d->N % (banks * d->T) == 0, FO_E_SHAPE, "wgrad: banks need the Conv3d walk and whole clips per plane");
+    p->cpp = std::max(1, p->nchunks / banks);
+    p->nchunks = p->cpp * banks;
+  }
   return FO_OK;
 }
 
@@ -525,11 +550,14 @@ extern "C" int fo_debug_read_wstamps(unsigned long long* out, int n) {
 }
 #endif
 
-extern "C" int64_t fo_wgrad_ws_bytes(const fo_conv_desc* d) {
+static int64_t wgrad_ws_bytes(const fo_conv_desc* d, int banks) {
   Plan p;
-  if (make_plan(d, &p) != FO_OK) return -1;
+  if (make_plan(d, &p, banks) != FO_OK) return -1;
   return ((int64_t)p.nchunks * p.tapsSlab * p.Apad * p.Bpad + (int64_t)p.nchunks * p.Apad) * 4 + 256;
 }
+
+extern "C" int64_t fo_wgrad_ws_bytes(const fo_conv_desc* d) { return wgrad_ws_bytes(d, 1); }
+extern "C" int64_t fo_wgrad_banked_ws_bytes(const fo_conv_desc* d, int banks) { return wgrad_ws_bytes(d, banks); }
 
 #define WG_LAUNCH1(TA_, TB_, WA_, WB_, TM_, TN_, SC_, FR_, IR_)                                                       \
   hipLaunchKernelGGL((conv_wgrad_kernel<TA_, TB_, WA_, WB_, TM_, TN_, SC_, FR_, IR_>), dim3(grid), dim3(64 * WA_ * WB_), \
@@ -541,12 +569,13 @@ extern "C" int64_t fo_wgrad_ws_bytes(const fo_conv_desc* d) {
     else WG_LAUNCH1(TA_, TB_, WA_, WB_, TM_, TN_, false, false, false);     \
   } while (0)
 
-extern "C" int fo_conv_wgrad(const fo_conv_desc* d, const float* P, const float* Q, float* dw, int Areal, int Breal,
-                             float* dbias, float* ws, int64_t ws_bytes, void* stream) {
+static int conv_wgrad_impl(const fo_conv_desc* d, const float* P, const float* Q, float* dw, int Areal, int Breal,
+                           float* dbias, float* ws, int64_t ws_bytes, void* stream, int banks) {
   Plan p;
-  int rc = make_plan(d, &p);
+  int rc = make_plan(d, &p, banks);
   if (rc != FO_OK) return rc;
-  FO_REQUIRE(ws_bytes >= fo_wgrad_ws_bytes(d), FO_E_WORKSPACE, "wgrad: workspace too small");
+  FO_REQUIRE(ws_bytes >= wgrad_ws_bytes(d, banks), FO_E_WORKSPACE, "wgrad: workspace too small");
+  FO_REQUIRE(banks == 1 || !dbias, FO_E_SHAPE, "wgrad: no bias sum with banks");
   FO_REQUIRE(fo_aligned16(P) && fo_aligned16(Q) && fo_aligned16(ws) && d->ldIn % 4 == 0 && d->ldOut % 4 == 0, FO_E_ALIGN,
              "wgrad: operands must be 16-byte aligned with ld %% 4 == 0");
   WgradArgs a;
@@ -555,6 +584,7 @@ extern "C" int fo_conv_wgrad(const fo_conv_desc* d, const float* P, const float*
   a.M = d->N * a.HWm;
   a.chunk = p.chunk; a.nchunks = p.nchunks; a.taps = p.taps;
   a.kdLoop = p.kdLoop; a.tapsSlab = p.tapsSlab;
+  a.banks = banks; a.cpp = p.cpp;
   a.tilesA = p.tilesA; a.tilesB = p.tilesB; a.Apad = p.Apad; a.Bpad = p.Bpad;
   const size_t slab = (size_t)p.nchunks * p.tapsSlab * p.Apad * p.Bpad;
   a.wsBias = dbias ? ws + ((slab + 63) / 64) * 64 : nullptr;
@@ -589,8 +619,8 @@ extern "C" int fo_conv_wgrad(const fo_conv_desc* d, const float* P, const float*
   else FO_REQUIRE(false, FO_E_SHAPE, "wgrad: unsupported tile %dx%d", p.TA, p.TB);
   FO_CHECK_LAUNCH();
   const size_t slabElems = (size_t)p.tapsSlab * p.Apad * p.Bpad;
-  const int CL = p.nchunks >= 256 ? 16 : 4;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((slabElems + 63) / 64)), dim3(64 * CL), 0, s, ws, dw, p.nchunks,
+  const int CL = p.cpp >= 256 ? 16 : 4;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((slabElems + 63) / 64), banks), dim3(64 * CL), 0, s, ws, dw, p.cpp,
                      p.tapsSlab, p.Apad, p.Bpad, Areal, Breal, p.smallc ? 1 : 0, d->KW);
   FO_CHECK_LAUNCH();
   if (dbias) {
@@ -598,4 +628,18 @@ extern "C" int fo_conv_wgrad(const fo_conv_desc* d, const float* P, const float*
     FO_CHECK_LAUNCH();
   }
   return FO_OK;
+}
+
+extern "C" int fo_conv_wgrad(const fo_conv_desc* d, const float* P, const float* Q, float* dw, int Areal, int Breal,
+                             float* dbias, float* ws, int64_t ws_bytes, void* stream) {
+  return conv_wgrad_impl(d, P, Q, dw, Areal, Breal, dbias, ws, ws_bytes, stream, 1);
+}
+
+// `banks` independent filter gradients in one launch: the frame axis of P and Q is `banks` planes of N/banks frames
+// (whole clips each); dw receives banks consecutive [Areal][Breal][taps] tensors.  Conv3d geometry only (KD > 1): this is
+// the weight-gradient GEMM of the Winograd-transformed Conv3d, dU[xi] = sum_m dM[xi][m] (x) V[xi][m + kd - 1] (winograd.hip).
+extern "C" int fo_conv_wgrad_banked(const fo_conv_desc* d, const float* P, const float* Q, float* dw, int Areal, int Breal,
+                                    float* ws, int64_t ws_bytes, int banks, void* stream) {
+  FO_REQUIRE(banks >= 1, FO_E_SHAPE, "wgrad_banked: banks >= 1");
+  return conv_wgrad_impl(d, P, Q, dw, Areal, Breal, nullptr, ws, ws_bytes, stream, banks);
 }

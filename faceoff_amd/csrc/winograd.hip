@@ -144,6 +144,59 @@ __global__ void wino_output_kernel(const float* __restrict__ M, const float* __r
   }
 }
 
+// Filter gradient in the transformed domain.  With Y = A^T [U . V] A the gradient of U is (A dY A^T) . V summed over tiles:
+//   dM[xi][n][tile][co] = (A dY A^T)[xi]                              A = [[1,0],[1,1],[1,-1],[0,-1]]
+//   dU[xi][co][ci][kd]  = sum_{n,tile} dM[xi][n][tile][co] * V[xi][n + kd - 1][tile][ci]     (16 wgrad GEMMs, banked)
+//   dW[co][ci][kd]      = G^T dU G                                    (4x4 -> 3x3)
+__global__ void wino_gradout_kernel(const float* __restrict__ g, int ldg, float* __restrict__ dM, int N, int H, int W, int C4) {
+  const int Ht = H >> 1, Wt = W >> 1;
+  const long long total = (long long)N * Ht * Wt * C4;
+  const size_t plane = (size_t)N * Ht * Wt * C4 * 4;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(e % C4);
+    long long q = e / C4;
+    const int tx = (int)(q % Wt); q /= Wt;
+    const int ty = (int)(q % Ht);
+    const long long n = q / Ht;
+    const float* base = g + ((n * H + 2 * ty) * (long long)W + 2 * tx) * ldg + c * 4;
+    const f32x4 y00 = ld4(base), y01 = ld4(base + ldg), y10 = ld4(base + (long long)W * ldg), y11 = ld4(base + (long long)W * ldg + ldg);
+    // rows: r = A y  (4x2)
+    const f32x4 r[4][2] = {{y00, y01}, {y00 + y10, y01 + y11}, {y00 - y10, y01 - y11}, {-y10, -y11}};
+    float* dst = dM + (size_t)e * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {   // columns: m = r A^T
+      st4(dst + (size_t)(4 * i + 0) * plane, r[i][0]);
+      st4(dst + (size_t)(4 * i + 1) * plane, r[i][0] + r[i][1]);
+      st4(dst + (size_t)(4 * i + 2) * plane, r[i][0] - r[i][1]);
+      st4(dst + (size_t)(4 * i + 3) * plane, -r[i][1]);
+    }
+  }
+}
+
+// dW[o][i][kd][3][3] = G^T dU[.][o][i][kd] G ;  G^T = [[1,.5,.5,0],[0,.5,-.5,0],[0,.5,.5,1]]
+__global__ void wino_wgrad_out_kernel(const float* __restrict__ dU, float* __restrict__ dW, long long per /* O*I*KD */) {
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < per; e += (long long)gridDim.x * blockDim.x) {
+    float u[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) u[r][c] = dU[(size_t)(4 * r + c) * per + e];
+    float t[3][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      t[0][c] = u[0][c] + 0.5f * (u[1][c] + u[2][c]);
+      t[1][c] = 0.5f * (u[1][c] - u[2][c]);
+      t[2][c] = 0.5f * (u[1][c] + u[2][c]) + u[3][c];
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      dW[e * 9 + r * 3 + 0] = t[r][0] + 0.5f * (t[r][1] + t[r][2]);
+      dW[e * 9 + r * 3 + 1] = 0.5f * (t[r][1] - t[r][2]);
+      dW[e * 9 + r * 3 + 2] = 0.5f * (t[r][1] + t[r][2]) + t[r][3];
+    }
+  }
+}
+
 inline int grid_for(long long total, int cap = 16384) {
   return (int)std::max<long long>(1, std::min<long long>((total + 255) / 256, cap));
 }
@@ -180,6 +233,22 @@ int fo_wino_output(const float* M, const float* bias, const float* mask, int ldM
   FO_REQUIRE(!(flags & ~(FO_BIAS | FO_MASK | FO_ADD | FO_OUT_RELU)), FO_E_SHAPE, "wino_output: unsupported flag");
   hipLaunchKernelGGL(wino_output_kernel, dim3(grid_for((long long)N * (H / 2) * (W / 2) * (C / 4))), dim3(256), 0,
                      (hipStream_t)stream, M, bias, mask, ldMask, add, ldAdd, out, ldOut, N, H, W, C / 4, flags);
+  FO_CHECK_LAUNCH();
+  return FO_OK;
+}
+
+int fo_wino_gradout(const float* g, int ldg, float* dM, int N, int H, int W, int C, void* stream) {
+  FO_REQUIRE(H % 2 == 0 && W % 2 == 0 && C % 4 == 0 && ldg % 4 == 0 && fo_aligned16(g) && fo_aligned16(dM), FO_E_SHAPE,
+             "wino_gradout: even H, W; C, ld %% 4 == 0; 16-byte alignment");
+  hipLaunchKernelGGL(wino_gradout_kernel, dim3(grid_for((long long)N * (H / 2) * (W / 2) * (C / 4))), dim3(256), 0,
+                     (hipStream_t)stream, g, ldg, dM, N, H, W, C / 4);
+  FO_CHECK_LAUNCH();
+  return FO_OK;
+}
+
+int fo_wino_wgrad_out(const float* dU, float* dW, int O, int I, int KD, void* stream) {
+  const long long per = (long long)O * I * KD;
+  hipLaunchKernelGGL(wino_wgrad_out_kernel, dim3(grid_for(per)), dim3(256), 0, (hipStream_t)stream, dU, dW, per);
   FO_CHECK_LAUNCH();
   return FO_OK;
 }

@@ -145,6 +145,9 @@ class _Layer:
             ops.conv_wgrad(x, g, self.gw, None, k=(1, 4, 4), stride=2, pad=(0, 1, 1), a_real=self.ci, b_real=self.co,
                            in_relu=False)
             ops.bias_grad(g, self.gb, self.co)
+        elif (self._winograd_ok(x) and not in_relu and self.ci == self.cip
+              and ops.wino_wgrad_ok(x.shape[1], x.shape[2], x.shape[0], T)):
+            ops.conv3d_wgrad_winograd(g, x, self.gw, self.gb, T=T, a_real=self.co, b_real=self.ci)
         else:
             ops.conv_wgrad(g, x, self.gw, self.gb, T=T if self.kind == "conv3d" else 1, a_real=self.co, b_real=self.ci,
                            in_relu=in_relu, **geo)

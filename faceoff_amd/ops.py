@@ -235,6 +235,42 @@ def conv3d_winograd(x, U, bias, out, *, T, cin, cout, flags=0, mask=None, add=No
               ld_of(add) if add is not None else 0, _ptr(out), ld_of(out), N, H, W, cout, flags, _stream())
 
 
+def wino_wgrad_ok(H, W, N, T):
+    """The Winograd filter-gradient form needs even frames, (H/2 * W/2) % 32 == 0 (the wgrad kernel's row-run walk over
+    a plane flattened to one row per frame) and plane stacks inside the 2 GiB buffer window."""
+    return T > 1 and H % 2 == 0 and W % 2 == 0 and ((H // 2) * (W // 2)) % 32 == 0 and N % T == 0 and 16 * N * (H // 2) * (W // 2) * 128 * 4 < (1 << 31)
+
+
+def conv3d_wgrad_winograd(g, x, dw, dbias, *, T, a_real, b_real):
+    """Filter gradient of a Conv3d k3 p1 in the Winograd domain: dU[xi] = sum dM[xi] (x) V[xi] (16 banked wgrad GEMMs
+    with a (3,1,1) geometry), dW = G^T dU G; 2.25x fewer MFMA FLOP than the direct form.  dbias = column sums of g."""
+    N, H, W, _ = x.shape
+    Ht, Wt = H // 2, W // 2
+    cin, cout = b_real, a_real
+    plane_v, plane_m = N * Ht * Wt * cin, N * Ht * Wt * cout
+    V, dM = _wino_buffers((16 * plane_v, 16 * plane_m), x.device)
+    _lib.call("fo_wino_input", _ptr(x), ld_of(x), _ptr(V), N, H, W, cin, _stream())
+    _lib.call("fo_wino_gradout", _ptr(g), ld_of(g), _ptr(dM), N, H, W, cout, _stream())
+    d = _desc(N=16 * N, T=T, Hin=1, Win=Ht * Wt, Hm=1, Wm=Ht * Wt, Hout=1, Wout=Ht * Wt, Cin=cin, Cout=cout, KD=3, KH=1, KW=1,
+              stride=1, padD=1, padH=0, padW=0, ostride=1, ophH=0, ophW=0, ldIn=cin, ldOut=cout, ldMask=0, ldAdd=0, flags=0)
+    nbytes = _lib.load().fo_wgrad_banked_ws_bytes(C.byref(d), 16)
+    if nbytes < 0:
+        _lib.check(-1, "fo_wgrad_banked_ws_bytes")
+    ws = _workspace(nbytes + 16 * cout * cin * 3 * 4 + 64, x.device)
+    dU = ws[(nbytes + 3) // 4 // 4 * 4 + 4:][:16 * cout * cin * 3]
+    prof = PROFILER
+    if prof is not None:
+        nominal = 2.0 * 16 * N * Ht * Wt * cout * cin * 3
+        prof.begin("conv_wgrad_%dx%d_wino" % (cout, cin) + (f" [16x{N}x{Ht}x{Wt}]" if prof.detail else ""),
+                   nominal * temporal_share(T), nominal)
+    _lib.call("fo_conv_wgrad_banked", C.byref(d), _ptr(dM), _ptr(V), _ptr(dU), cout, cin, _ptr(ws), C.c_int64(nbytes), 16, _stream())
+    if prof is not None:
+        prof.end()
+    _lib.call("fo_wino_wgrad_out", _ptr(dU), _ptr(dw), cout, cin, 3, _stream())
+    if dbias is not None:
+        bias_grad(g, dbias, cout)
+
+
 # ------------------------------------------------------------------ bf16 conv family (LPIPS branch)
 def pack_conv_bf16(w, taps_pad=None):
     """fp32 [O][I][*taps] -> bf16 [Opad][tapsPad][Ipad] (Ipad: multiple of 64, or 8 for the RGB layer)"""

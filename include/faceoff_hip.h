@@ -105,6 +105,12 @@ int fo_conv_igemm(const fo_conv_desc* d, const float* in, const float* wp, const
  * consecutive packed filter banks behind `wp`.  No bias / mask / residual.  Needs Hm*Wm % 128 == 0. */
 int fo_conv_igemm_banked(const fo_conv_desc* d, const float* in, const float* wp, float* out, int bank_frames, void* stream);
 
+/* fo_conv_wgrad for `banks` independent planes of N/banks frames (whole clips each) in one launch: dw receives `banks`
+ * consecutive [Areal][Breal][taps] tensors.  Conv3d geometry (KD > 1) only; no bias sum. */
+int64_t fo_wgrad_banked_ws_bytes(const fo_conv_desc* d, int banks);
+int fo_conv_wgrad_banked(const fo_conv_desc* d, const float* P, const float* Q, float* dw, int Areal, int Breal, float* ws,
+                         int64_t ws_bytes, int banks, void* stream);
+
 /* Which kernel instantiation fo_conv_igemm launches for `d` (no launch): 128 / 64 / 32 = conv_igemm_kernel<BN>,
  * 3 = conv_igemm3_kernel (Conv3d, one workgroup per CU).  For profilers that attribute time per kernel. */
 int fo_conv_igemm_variant(const fo_conv_desc* d);
@@ -188,6 +194,12 @@ int fo_wino_input(const float* x, int ldx, float* V, int N, int H, int W, int C,
 /* out [N,H,W,ldOut] = epilogue(A^T M A), M[16][N][H/2][W/2][C]; flags: FO_BIAS | FO_MASK | FO_ADD | FO_OUT_RELU. */
 int fo_wino_output(const float* M, const float* bias, const float* mask, int ldMask, const float* add, int ldAdd, float* out,
                    int ldOut, int N, int H, int W, int C, int flags, void* stream);
+
+/* Filter gradient of the same convolution in the transformed domain: dM[16][N][H/2][W/2][C] = A dY A^T of the output
+ * gradient g [N,H,W,ldg]; then dU[xi] = sum_pixels dM[xi] (x) V[xi] shifted by the depth tap -- 16 wgrad GEMMs in one
+ * fo_conv_wgrad_banked launch ((3,1,1) geometry, planes as banks); then dW[O][I][KD][3][3] = G^T dU G. */
+int fo_wino_gradout(const float* g, int ldg, float* dM, int N, int H, int W, int C, void* stream);
+int fo_wino_wgrad_out(const float* dU /* [16][O][I][KD] */, float* dW, int O, int I, int KD, void* stream);
 
 /* ---------------------------------------------------------------- bf16 LPIPS branch (BASELINE config 3)
  * The same VGG-16 / LPIPS chain with bf16 storage and bf16 MFMA operands, fp32 accumulation and fp32 head

@@ -208,7 +208,8 @@ def test_conv3d_fwd_dgrad_wgrad(B, T, H, W):
     _close(db, b.grad, what="conv3d bias grad")
 
 
-@pytest.mark.parametrize("B,T,H,W", [(1, 1, 8, 16), (2, 2, 8, 8), (1, 5, 16, 16), (2, 5, 32, 32), (3, 3, 6, 10), (1, 5, 16, 32)])
+@pytest.mark.parametrize("B,T,H,W", [(1, 1, 8, 16), (2, 2, 8, 8), (1, 5, 16, 16), (2, 5, 32, 32), (3, 3, 6, 10), (1, 5, 16, 32),
+                                     (2, 2, 16, 16)])
 def test_conv3d_winograd_fwd_dgrad(B, T, H, W):
     """The Winograd F(2x2,3x3) form of Conv3d 128->128 k3 p1 (transforms + banked (3,1,1) implicit GEMM) against
     torch-CPU: forward with bias + ReLU, data gradient with ReLU mask + residual, banked (H/2*W/2 % 128 == 0) and
@@ -240,6 +241,14 @@ def test_conv3d_winograd_fwd_dgrad(B, T, H, W):
     ops.conv3d_winograd(gyg, ops.wino_filter(wg, dgrad=True), None, gx, T=T, cin=128, cout=128, mask=mask, add=addt)
     want = x.grad * (clips(mask) > 0) + clips(addt)
     _close(clips(gx), want, what="winograd conv3d dgrad")
+    if ops.wino_wgrad_ok(H, W, B * T, T):                # filter gradient in the transformed domain (banked wgrad GEMMs)
+        w2 = w.clone().requires_grad_(True)
+        b2 = b.clone().requires_grad_(True)
+        F.conv3d(x.detach(), w2, b2, padding=1).backward(gy)
+        dw, db = torch.empty_like(wg), torch.empty_like(bg)
+        ops.conv3d_wgrad_winograd(gyg, xg, dw, db, T=T, a_real=128, b_real=128)
+        _close(dw, w2.grad, what="winograd conv3d wgrad")
+        _close(db, b2.grad, what="winograd conv3d bias grad")
 
 
 def test_vq_assign_bit_exact_and_golden(golden_dir):

@@ -33,3 +33,16 @@ for H in (64, 32):
     gemm = sum(v["total_ms"] for v in g.values())
     print(f"{H}^2: direct {t_d:.3f} ms   winograd {t_w:.3f} ms (masked dgrad form {t_wm:.3f})   of which GEMMs {gemm:.3f} ms "
           + ", ".join(f"{v['tflops']:.0f} TF" for v in g.values()))
+
+print("wgrad:")
+for H in (64, 32):
+    x = torch.randn((N, H, H, 128), device=dev)
+    g = torch.randn((N, H, H, 128), device=dev)
+    dw = torch.empty((128, 128, 3, 3, 3), device=dev); db = torch.empty(128, device=dev)
+    t_d = timeit(lambda: ops.conv_wgrad(g, x, dw, db, T=T, k=(3, 3, 3), pad=(1, 1, 1), a_real=128, b_real=128))
+    t_w = timeit(lambda: ops.conv3d_wgrad_winograd(g, x, dw, db, T=T, a_real=128, b_real=128))
+    prof = ops.KernelProfiler(detail=True); ops.PROFILER = prof
+    ops.conv3d_wgrad_winograd(g, x, dw, db, T=T, a_real=128, b_real=128)
+    ops.PROFILER = None
+    gm = prof.summary()
+    print(f"{H}^2: direct {t_d:.3f} ms   winograd {t_w:.3f} ms   of which GEMM " + ", ".join(f"{v['total_ms']:.3f} ms {v['tflops']:.0f} TF" for v in gm.values()))
