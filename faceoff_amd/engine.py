@@ -92,7 +92,9 @@ class _Layer:
         elif self.kind == "convT":
             ops.convT_phases(x, self.wp, self.b, out, cin=self.cip, cout=self.co, flags=flags, add=add)
         elif self._winograd_ok(x):
-            ops.conv3d_winograd(x, self.wpw, self.b, out, T=T, cin=self.ci, cout=self.co, flags=flags, add=add)
+            keep = self.engine.keep_wino_v and ops.wino_wgrad_ok(x.shape[1], x.shape[2], x.shape[0], T)
+            self.saved_v = ops.conv3d_winograd(x, self.wpw, self.b, out, T=T, cin=self.ci, cout=self.co, flags=flags, add=add,
+                                               keep_v=keep)
         else:
             g = self._geom()
             ops.conv_igemm(x, self.wp, self.b, out, T=T if self.kind == "conv3d" else 1, cin=self.cip, cout=self.co,
@@ -147,7 +149,10 @@ class _Layer:
             ops.bias_grad(g, self.gb, self.co)
         elif (self._winograd_ok(x) and not in_relu and self.ci == self.cip
               and ops.wino_wgrad_ok(x.shape[1], x.shape[2], x.shape[0], T)):
-            ops.conv3d_wgrad_winograd(g, x, self.gw, self.gb, T=T, a_real=self.co, b_real=self.ci)
+            V, self.saved_v = getattr(self, "saved_v", None), None     # the forward's transformed input, if it was kept
+            if V is not None and self.engine is not None and self.engine.wgrad_stream is not None:
+                self.engine._keepalive.append(V)                      # read on the side stream: must outlive this call
+            ops.conv3d_wgrad_winograd(g, x, self.gw, self.gb, T=T, a_real=self.co, b_real=self.ci, V=V)
         else:
             ops.conv_wgrad(g, x, self.gw, self.gb, T=T if self.kind == "conv3d" else 1, a_real=self.co, b_real=self.ci,
                            in_relu=in_relu, **geo)
@@ -210,6 +215,7 @@ class VQVAEEngine:
         self._streams = (self.wgrad_stream, self.aux_stream)
         # Conv3d forward / data gradient as Winograd F(2x2,3x3) + a (3,1,1) implicit GEMM (FACEOFF_NO_WINOGRAD=1: direct)
         self.winograd = not _os.environ.get("FACEOFF_NO_WINOGRAD")
+        self.keep_wino_v = False      # training forward: keep each Conv3d's transformed input for its filter gradient
         self._keepalive = []
         if state_dict is not None:
             self.load_state_dict(state_dict)
@@ -376,6 +382,7 @@ class VQVAEEngine:
         assert N % T == 0, f"N={N} frames is not a whole number of clips of T={T}"
         assert H % 8 == 0 and W % 8 == 0, "spatial size must be a multiple of 8"
         self.pack_filters()
+        self.keep_wino_v = bool(training)
         assert Cin <= 8
         S = {"T": T, "x8": ops.cat_nchw_to_nhwc8(*parts) if parts is not None else ops.nchw_to_nhwc(img_nchw, cpad=ops.pad_in(Cin))}
         self.stage_encode(S)

@@ -196,8 +196,10 @@ def _wino_buffers(nfloats, device):
     return buf
 
 
-def conv3d_winograd(x, U, bias, out, *, T, cin, cout, flags=0, mask=None, add=None):
-    """Conv3d k3 p1 s1 (or its data gradient, with the dgrad filter banks) on [N,H,W,C] frames, clips of T frames."""
+def conv3d_winograd(x, U, bias, out, *, T, cin, cout, flags=0, mask=None, add=None, keep_v=False):
+    """Conv3d k3 p1 s1 (or its data gradient, with the dgrad filter banks) on [N,H,W,C] frames, clips of T frames.
+    keep_v: return the transformed input planes in their own tensor (the filter gradient of the same layer needs exactly
+    them: conv3d_wgrad_winograd(V=...)) instead of using the per-stream scratch."""
     N, H, W, _ = x.shape
     Ht, Wt = H // 2, W // 2
     assert H % 2 == 0 and W % 2 == 0 and cin % 32 == 0
@@ -208,7 +210,9 @@ def conv3d_winograd(x, U, bias, out, *, T, cin, cout, flags=0, mask=None, add=No
     if add is not None:
         flags |= FO_ADD
     plane_v, plane_m = N * Ht * Wt * cin, N * Ht * Wt * cout
-    V, M = _wino_buffers((16 * plane_v, 16 * plane_m), x.device)
+    V, M = _wino_buffers((0 if keep_v else 16 * plane_v, 16 * plane_m), x.device)
+    if keep_v:
+        V = torch.empty(16 * plane_v, device=x.device, dtype=torch.float32)
     _lib.call("fo_wino_input", _ptr(x), ld_of(x), _ptr(V), N, H, W, cin, _stream())
     bank = pad_out(cout) * 3 * cin                                  # floats per filter bank
     banked = (Ht * Wt) % 128 == 0
@@ -233,6 +237,7 @@ def conv3d_winograd(x, U, bias, out, *, T, cin, cout, flags=0, mask=None, add=No
             prof.end()
     _lib.call("fo_wino_output", _ptr(M), _ptr(bias), _ptr(mask), ld_of(mask) if mask is not None else 0, _ptr(add),
               ld_of(add) if add is not None else 0, _ptr(out), ld_of(out), N, H, W, cout, flags, _stream())
+    return V if keep_v else None
 
 
 def wino_wgrad_ok(H, W, N, T):
@@ -241,15 +246,19 @@ def wino_wgrad_ok(H, W, N, T):
     return T > 1 and H % 2 == 0 and W % 2 == 0 and ((H // 2) * (W // 2)) % 32 == 0 and N % T == 0 and 16 * N * (H // 2) * (W // 2) * 128 * 4 < (1 << 31)
 
 
-def conv3d_wgrad_winograd(g, x, dw, dbias, *, T, a_real, b_real):
+def conv3d_wgrad_winograd(g, x, dw, dbias, *, T, a_real, b_real, V=None):
     """Filter gradient of a Conv3d k3 p1 in the Winograd domain: dU[xi] = sum dM[xi] (x) V[xi] (16 banked wgrad GEMMs
     with a (3,1,1) geometry), dW = G^T dU G; 2.25x fewer MFMA FLOP than the direct form.  dbias = column sums of g."""
     N, H, W, _ = x.shape
     Ht, Wt = H // 2, W // 2
     cin, cout = b_real, a_real
     plane_v, plane_m = N * Ht * Wt * cin, N * Ht * Wt * cout
-    V, dM = _wino_buffers((16 * plane_v, 16 * plane_m), x.device)
-    _lib.call("fo_wino_input", _ptr(x), ld_of(x), _ptr(V), N, H, W, cin, _stream())
+    if V is not None:                        # the forward pass kept its transformed input
+        assert V.numel() == 16 * plane_v
+        _, dM = _wino_buffers((0, 16 * plane_m), x.device)
+    else:
+        V, dM = _wino_buffers((16 * plane_v, 16 * plane_m), x.device)
+        _lib.call("fo_wino_input", _ptr(x), ld_of(x), _ptr(V), N, H, W, cin, _stream())
     _lib.call("fo_wino_gradout", _ptr(g), ld_of(g), _ptr(dM), N, H, W, cout, _stream())
     d = _desc(N=16 * N, T=T, Hin=1, Win=Ht * Wt, Hm=1, Wm=Ht * Wt, Hout=1, Wout=Ht * Wt, Cin=cin, Cout=cout, KD=3, KH=1, KW=1,
               stride=1, padD=1, padH=0, padW=0, ostride=1, ophH=0, ophW=0, ldIn=cin, ldOut=cout, ldMask=0, ldAdd=0, flags=0)
