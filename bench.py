@@ -182,9 +182,14 @@ def main():
     executed = FLOP_PER_FRAME - conv3d_flop * (1.0 - temporal_share(T))
     out["step_frac_direct_flop_without_padding_taps"] = round(executed * fps / world / (FP32_MFMA_PEAK_TFLOPS * 1e12), 4)
     if eng.winograd:
-        executed -= conv3d_flop * temporal_share(T) * (1.0 - 16.0 / 36.0)
+        # bottom chain (64^2 latents at 256^2 input): F(4x4,3x3) = 36 multiplies per 16 outputs instead of 144; top chain
+        # (32^2): F(2x2,3x3) = 16 per 4 instead of 36 (per-frame GMAC of the two chains: SURVEY 8a, row a4)
+        f_b = 36.0 / 144.0 if (H // 4) % 4 == 0 and ((H // 16) * (H // 16)) % 128 == 0 and eng.winograd_max_tile >= 4 else 16.0 / 36.0
+        f_t = 16.0 / 36.0
+        executed -= 3 * 2 * temporal_share(T) * (5.436e9 * (1.0 - f_b) + 1.359e9 * (1.0 - f_t))
     out["step_frac_executed_flop"] = round(executed * fps / world / (FP32_MFMA_PEAK_TFLOPS * 1e12), 4)
-    out["config"]["conv3d_algorithm"] = "winograd F(2x2,3x3) fwd, dgrad and wgrad" if eng.winograd else "direct"
+    out["config"]["conv3d_algorithm"] = ("winograd (fwd, dgrad, wgrad): F(4x4,3x3) on 64x64 latents, F(2x2,3x3) on 32x32"
+                                         if eng.winograd else "direct")
     if prof is not None:
         summ = prof.summary()
         dom = max(summ, key=lambda k: summ[k]["total_ms"])

@@ -50,11 +50,11 @@ SIGNATURES = {
     "fo_conv_igemm_banked": (_I, [_D, _P, _P, _P, _I, _P]),
     "fo_wgrad_banked_ws_bytes": (_L, [_D, _I]),
     "fo_conv_wgrad_banked": (_I, [_D, _P, _P, _P, _I, _I, _P, _L, _I, _P]),
-    "fo_wino_gradout": (_I, [_P, _I, _P, _I, _I, _I, _I, _P]),
-    "fo_wino_wgrad_out": (_I, [_P, _P, _I, _I, _I, _P]),
-    "fo_wino_filter": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
-    "fo_wino_input": (_I, [_P, _I, _P, _I, _I, _I, _I, _P]),
-    "fo_wino_output": (_I, [_P, _P, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "fo_wino_gradout": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P]),
+    "fo_wino_wgrad_out": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "fo_wino_filter": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "fo_wino_input": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P]),
+    "fo_wino_output": (_I, [_P, _P, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "fo_wgrad_ws_bytes": (_L, [_D]),
     "fo_conv_wgrad": (_I, [_D, _P, _P, _P, _I, _I, _P, _P, _L, _P]),
     "fo_bias_grad": (_I, [_P, _P, _L, _I, _I, _I, _P, _P]),

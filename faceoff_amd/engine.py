@@ -65,10 +65,7 @@ class _Layer:
                 self.wpd = ops.pack_conv(self.w, self.wpd)
         else:
             self.wp = ops.pack_conv(self.w, self.wp)
-            if self.kind == "conv3d" and self.engine is not None and self.engine.winograd:
-                # Winograd F(2x2,3x3) filter banks of the forward and the data-gradient convolution (csrc/winograd.hip)
-                self.wpw = ops.wino_filter(self.w)
-                self.wpwd = ops.wino_filter(self.w, dgrad=True)
+            self._wino_u = {}      # Winograd filter banks of this step, made on first use: (m, dgrad) -> U
             if not self.need_dgrad:
                 return
             if self.k[-1] == 4:                      # dgrad of k4s2p1 conv = transposed conv, Ci_T:=co, Co_T:=ci
@@ -91,21 +88,30 @@ class _Layer:
             ops.convT_fused(x, self.wp, self.b, out, cin=self.cip, cout=self.co, flags=flags)
         elif self.kind == "convT":
             ops.convT_phases(x, self.wp, self.b, out, cin=self.cip, cout=self.co, flags=flags, add=add)
-        elif self._winograd_ok(x):
-            keep = self.engine.keep_wino_v and ops.wino_wgrad_ok(x.shape[1], x.shape[2], x.shape[0], T)
-            self.saved_v = ops.conv3d_winograd(x, self.wpw, self.b, out, T=T, cin=self.ci, cout=self.co, flags=flags, add=add,
-                                               keep_v=keep)
+        elif self._winograd_m(x):
+            m = self._winograd_m(x)
+            keep = self.engine.keep_wino_v and ops.wino_wgrad_ok(x.shape[1], x.shape[2], x.shape[0], T, m)
+            self.saved_v = ops.conv3d_winograd(x, self._wino_filter(m, False), self.b, out, T=T, cin=self.ci, cout=self.co,
+                                               flags=flags, add=add, keep_v=keep, m=m)
         else:
             g = self._geom()
             ops.conv_igemm(x, self.wp, self.b, out, T=T if self.kind == "conv3d" else 1, cin=self.cip, cout=self.co,
                            flags=flags, add=add, **g)
 
-    def _winograd_ok(self, x):
-        """Conv3d k3 p1 on even-sized frames: Winograd F(2x2,3x3) over the two spatial dimensions (2.25x fewer MFMA
-        FLOP; -30 % per launch at C2 sizes incl. the transforms).  Odd sizes take the direct kernel."""
+    def _winograd_m(self, x):
+        """Output-tile size of the Winograd form for a Conv3d k3 p1 on frames like x: 4 (64x64 latents: 4x fewer MFMA
+        FLOP), 2 (other even sizes: 2.25x fewer) or 0 = direct kernel (odd sizes, other layer kinds, FACEOFF_NO_WINOGRAD)."""
         eng = self.engine
-        return (self.kind == "conv3d" and eng is not None and eng.winograd and getattr(self, "wpw", None) is not None
-                and x.shape[1] % 2 == 0 and x.shape[2] % 2 == 0 and self.ci % 32 == 0 and self.co % 4 == 0)
+        if self.kind != "conv3d" or eng is None or not eng.winograd or self.ci % 32 or self.co % 4:
+            return 0
+        m = ops.wino_tile(x.shape[1], x.shape[2], x.shape[0])
+        return min(m, eng.winograd_max_tile)
+
+    def _wino_filter(self, m, dgrad):
+        key = (m, dgrad)
+        if key not in self._wino_u:
+            self._wino_u[key] = ops.wino_filter(self.w, dgrad=dgrad, m=m)
+        return self._wino_u[key]
 
     # -- data gradient: gin = dgrad(g) [* (mask > 0)] [+ add]
     def dgrad(self, g, gin, T=1, mask=None, add=None):
@@ -114,8 +120,9 @@ class _Layer:
                            cout=self.ci, mask=mask, add=add)
         elif self.k[-1] == 4:                        # transposed conv over g
             ops.convT_phases(g, self.wpd, None, gin, cin=self.co, cout=self.ci, mask=mask, add=add)
-        elif self._winograd_ok(g):
-            ops.conv3d_winograd(g, self.wpwd, None, gin, T=T, cin=self.co, cout=self.ci, mask=mask, add=add)
+        elif self._winograd_m(g):
+            m = self._winograd_m(g)
+            ops.conv3d_winograd(g, self._wino_filter(m, True), None, gin, T=T, cin=self.co, cout=self.ci, mask=mask, add=add, m=m)
         else:
             geo = self._geom()
             pad = tuple(kk - 1 - p for kk, p in zip(geo["k"], geo["pad"]))
@@ -147,12 +154,12 @@ class _Layer:
             ops.conv_wgrad(x, g, self.gw, None, k=(1, 4, 4), stride=2, pad=(0, 1, 1), a_real=self.ci, b_real=self.co,
                            in_relu=False)
             ops.bias_grad(g, self.gb, self.co)
-        elif (self._winograd_ok(x) and not in_relu and self.ci == self.cip
-              and ops.wino_wgrad_ok(x.shape[1], x.shape[2], x.shape[0], T)):
+        elif (self._winograd_m(x) and not in_relu and self.ci == self.cip
+              and ops.wino_wgrad_ok(x.shape[1], x.shape[2], x.shape[0], T, self._winograd_m(x))):
             V, self.saved_v = getattr(self, "saved_v", None), None     # the forward's transformed input, if it was kept
             if V is not None and self.engine is not None and self.engine.wgrad_stream is not None:
                 self.engine._keepalive.append(V)                      # read on the side stream: must outlive this call
-            ops.conv3d_wgrad_winograd(g, x, self.gw, self.gb, T=T, a_real=self.co, b_real=self.ci, V=V)
+            ops.conv3d_wgrad_winograd(g, x, self.gw, self.gb, T=T, a_real=self.co, b_real=self.ci, V=V, m=self._winograd_m(x))
         else:
             ops.conv_wgrad(g, x, self.gw, self.gb, T=T if self.kind == "conv3d" else 1, a_real=self.co, b_real=self.ci,
                            in_relu=in_relu, **geo)
@@ -215,6 +222,7 @@ class VQVAEEngine:
         self._streams = (self.wgrad_stream, self.aux_stream)
         # Conv3d forward / data gradient as Winograd F(2x2,3x3) + a (3,1,1) implicit GEMM (FACEOFF_NO_WINOGRAD=1: direct)
         self.winograd = not _os.environ.get("FACEOFF_NO_WINOGRAD")
+        self.winograd_max_tile = int(_os.environ.get("FACEOFF_WINOGRAD_TILE", "4"))   # 2: F(2x2,3x3) everywhere
         self.keep_wino_v = False      # training forward: keep each Conv3d's transformed input for its filter gradient
         self._keepalive = []
         if state_dict is not None:

@@ -172,14 +172,23 @@ def conv_igemm(x, wp, bias, out, *, T=1, k=(1, 3, 3), stride=1, pad=(0, 1, 1), c
         prof.end()
 
 
-# ------------------------------------------------------------------ Winograd F(2x2,3x3) Conv3d
-def wino_filter(w, dgrad=False):
-    """[O][I][KD][3][3] -> 16 packed (3,1,1) filter banks [16][Opad][KD][Ipad] (dgrad: flipped taps, swapped channels)."""
+# ------------------------------------------------------------------ Winograd F(m x m, 3x3) Conv3d, m = 2 or 4
+def wino_tile(H, W, N=None):
+    """Output-tile size for a Conv3d on HxW frames: 4 (4x fewer MFMA FLOP, fp32 error ~3e-6 of scale) when the plane
+    stack can run as ONE banked GEMM launch (a frame's H/4 * W/4 tiles fill whole 128-row GEMM tiles and the 36 planes fit
+    the 2 GiB buffer window), else 2 (2.25x fewer, error as the direct convolution), else 0 (odd sizes: direct)."""
+    if H % 4 == 0 and W % 4 == 0 and ((H // 4) * (W // 4)) % 128 == 0 and (N is None or 36 * N * (H // 4) * (W // 4) * 128 * 4 < (1 << 31)):
+        return 4
+    return 2 if H % 2 == 0 and W % 2 == 0 else 0
+
+
+def wino_filter(w, dgrad=False, m=2):
+    """[O][I][KD][3][3] -> (m+2)^2 packed (3,1,1) filter banks [P][Opad][KD][Ipad] (dgrad: flipped taps, swapped channels)."""
     O, I, KD = w.shape[:3]
     rows, cols = (I, O) if dgrad else (O, I)
     Op, Ip = pad_out(rows), pad_in(cols)
-    U = torch.empty(16 * Op * KD * Ip, device=w.device, dtype=torch.float32)
-    _lib.call("fo_wino_filter", _ptr(w.contiguous()), _ptr(U), O, I, KD, Op, Ip, int(dgrad), _stream())
+    U = torch.empty((m + 2) ** 2 * Op * KD * Ip, device=w.device, dtype=torch.float32)
+    _lib.call("fo_wino_filter", _ptr(w.contiguous()), _ptr(U), O, I, KD, Op, Ip, int(dgrad), m, _stream())
     return U
 
 
@@ -191,18 +200,20 @@ def _wino_buffers(nfloats, device):
     key = (device, torch.cuda.current_stream(device).cuda_stream)
     buf = _wino_cache.get(key)
     if buf is None or buf[0].numel() < nfloats[0] or buf[1].numel() < nfloats[1]:
-        buf = (torch.empty(nfloats[0], device=device, dtype=torch.float32), torch.empty(nfloats[1], device=device, dtype=torch.float32))
+        n0 = max(nfloats[0], 0 if buf is None else buf[0].numel())
+        n1 = max(nfloats[1], 0 if buf is None else buf[1].numel())
+        buf = (torch.empty(n0, device=device, dtype=torch.float32), torch.empty(n1, device=device, dtype=torch.float32))
         _wino_cache[key] = buf
     return buf
 
 
-def conv3d_winograd(x, U, bias, out, *, T, cin, cout, flags=0, mask=None, add=None, keep_v=False):
+def conv3d_winograd(x, U, bias, out, *, T, cin, cout, flags=0, mask=None, add=None, keep_v=False, m=2):
     """Conv3d k3 p1 s1 (or its data gradient, with the dgrad filter banks) on [N,H,W,C] frames, clips of T frames.
     keep_v: return the transformed input planes in their own tensor (the filter gradient of the same layer needs exactly
     them: conv3d_wgrad_winograd(V=...)) instead of using the per-stream scratch."""
     N, H, W, _ = x.shape
-    Ht, Wt = H // 2, W // 2
-    assert H % 2 == 0 and W % 2 == 0 and cin % 32 == 0
+    Ht, Wt, P = H // m, W // m, (m + 2) ** 2
+    assert H % m == 0 and W % m == 0 and cin % 32 == 0
     if bias is not None:
         flags |= FO_BIAS
     if mask is not None:
@@ -210,16 +221,16 @@ def conv3d_winograd(x, U, bias, out, *, T, cin, cout, flags=0, mask=None, add=No
     if add is not None:
         flags |= FO_ADD
     plane_v, plane_m = N * Ht * Wt * cin, N * Ht * Wt * cout
-    V, M = _wino_buffers((0 if keep_v else 16 * plane_v, 16 * plane_m), x.device)
+    V, M = _wino_buffers((0 if keep_v else P * plane_v, P * plane_m), x.device)
     if keep_v:
-        V = torch.empty(16 * plane_v, device=x.device, dtype=torch.float32)
-    _lib.call("fo_wino_input", _ptr(x), ld_of(x), _ptr(V), N, H, W, cin, _stream())
+        V = torch.empty(P * plane_v, device=x.device, dtype=torch.float32)
+    _lib.call("fo_wino_input", _ptr(x), ld_of(x), _ptr(V), N, H, W, cin, m, _stream())
     bank = pad_out(cout) * 3 * cin                                  # floats per filter bank
     banked = (Ht * Wt) % 128 == 0
-    per = max(1, min(16, ((1 << 31) - 1) // max(plane_v * 4, plane_m * 4))) if banked else 1   # planes per launch (2 GiB window)
+    per = max(1, min(P, ((1 << 31) - 1) // max(plane_v * 4, plane_m * 4))) if banked else 1   # planes per launch (2 GiB window)
     prof = PROFILER
-    for p0 in range(0, 16, per):
-        np_ = min(per, 16 - p0)
+    for p0 in range(0, P, per):
+        np_ = min(per, P - p0)
         d = _desc(N=np_ * N, T=T, Hin=Ht, Win=Wt, Hm=Ht, Wm=Wt, Hout=Ht, Wout=Wt, Cin=cin, Cout=cout, KD=3, KH=1, KW=1, stride=1,
                   padD=1, padH=0, padW=0, ostride=1, ophH=0, ophW=0, ldIn=cin, ldOut=cout, ldMask=0, ldAdd=0, flags=0)
         vin = V[p0 * plane_v:(p0 + np_) * plane_v]
@@ -227,7 +238,10 @@ def conv3d_winograd(x, U, bias, out, *, T, cin, cout, flags=0, mask=None, add=No
         wp = U[p0 * bank:(p0 + np_) * bank]
         if prof is not None:
             nominal = 2.0 * np_ * N * Ht * Wt * cout * 3 * cin
-            prof.begin("conv_igemm_bn128_wino" + (f" [{np_}x{N}x{Ht}x{Wt} {cin}->{cout}]" if prof.detail else ""),
+            # the same kernel instantiation as every other 128-column launch: one label, so that rocprofv3's per-kernel
+            # averages and these events describe the same set of launches
+            prof.begin("conv_igemm_bn%d" % (128 if cout > 64 else (64 if cout > 32 else 32))
+                       + (f" [winograd F{m} GEMM {np_}x{N}x{Ht}x{Wt} {cin}->{cout} k311]" if prof.detail else ""),
                        nominal * temporal_share(T), nominal)
         if banked:
             _lib.call("fo_conv_igemm_banked", C.byref(d), _ptr(vin), _ptr(wp), _ptr(mout), N, _stream())
@@ -236,46 +250,48 @@ def conv3d_winograd(x, U, bias, out, *, T, cin, cout, flags=0, mask=None, add=No
         if prof is not None:
             prof.end()
     _lib.call("fo_wino_output", _ptr(M), _ptr(bias), _ptr(mask), ld_of(mask) if mask is not None else 0, _ptr(add),
-              ld_of(add) if add is not None else 0, _ptr(out), ld_of(out), N, H, W, cout, flags, _stream())
+              ld_of(add) if add is not None else 0, _ptr(out), ld_of(out), N, H, W, cout, flags, m, _stream())
     return V if keep_v else None
 
 
-def wino_wgrad_ok(H, W, N, T):
-    """The Winograd filter-gradient form needs even frames, (H/2 * W/2) % 32 == 0 (the wgrad kernel's row-run walk over
-    a plane flattened to one row per frame) and plane stacks inside the 2 GiB buffer window."""
-    return T > 1 and H % 2 == 0 and W % 2 == 0 and ((H // 2) * (W // 2)) % 32 == 0 and N % T == 0 and 16 * N * (H // 2) * (W // 2) * 128 * 4 < (1 << 31)
+def wino_wgrad_ok(H, W, N, T, m=2):
+    """The Winograd filter-gradient form needs frames that are multiples of m, (H/m * W/m) % 32 == 0 (the wgrad kernel's
+    row-run walk over a plane flattened to one row per frame) and plane stacks inside the 2 GiB buffer window."""
+    return (T > 1 and m in (2, 4) and H % m == 0 and W % m == 0 and ((H // m) * (W // m)) % 32 == 0 and N % T == 0
+            and (m + 2) ** 2 * N * (H // m) * (W // m) * 128 * 4 < (1 << 31))
 
 
-def conv3d_wgrad_winograd(g, x, dw, dbias, *, T, a_real, b_real, V=None):
-    """Filter gradient of a Conv3d k3 p1 in the Winograd domain: dU[xi] = sum dM[xi] (x) V[xi] (16 banked wgrad GEMMs
-    with a (3,1,1) geometry), dW = G^T dU G; 2.25x fewer MFMA FLOP than the direct form.  dbias = column sums of g."""
+def conv3d_wgrad_winograd(g, x, dw, dbias, *, T, a_real, b_real, V=None, m=2):
+    """Filter gradient of a Conv3d k3 p1 in the Winograd domain: dU[xi] = sum dM[xi] (x) V[xi] ((m+2)^2 banked wgrad
+    GEMMs with a (3,1,1) geometry), dW = G^T dU G; 2.25x (m=2) / 4x (m=4) fewer MFMA FLOP than the direct form.
+    dbias = column sums of g."""
     N, H, W, _ = x.shape
-    Ht, Wt = H // 2, W // 2
+    Ht, Wt, P = H // m, W // m, (m + 2) ** 2
     cin, cout = b_real, a_real
     plane_v, plane_m = N * Ht * Wt * cin, N * Ht * Wt * cout
     if V is not None:                        # the forward pass kept its transformed input
-        assert V.numel() == 16 * plane_v
-        _, dM = _wino_buffers((0, 16 * plane_m), x.device)
+        assert V.numel() == P * plane_v
+        _, dM = _wino_buffers((0, P * plane_m), x.device)
     else:
-        V, dM = _wino_buffers((16 * plane_v, 16 * plane_m), x.device)
-        _lib.call("fo_wino_input", _ptr(x), ld_of(x), _ptr(V), N, H, W, cin, _stream())
-    _lib.call("fo_wino_gradout", _ptr(g), ld_of(g), _ptr(dM), N, H, W, cout, _stream())
-    d = _desc(N=16 * N, T=T, Hin=1, Win=Ht * Wt, Hm=1, Wm=Ht * Wt, Hout=1, Wout=Ht * Wt, Cin=cin, Cout=cout, KD=3, KH=1, KW=1,
+        V, dM = _wino_buffers((P * plane_v, P * plane_m), x.device)
+        _lib.call("fo_wino_input", _ptr(x), ld_of(x), _ptr(V), N, H, W, cin, m, _stream())
+    _lib.call("fo_wino_gradout", _ptr(g), ld_of(g), _ptr(dM), N, H, W, cout, m, _stream())
+    d = _desc(N=P * N, T=T, Hin=1, Win=Ht * Wt, Hm=1, Wm=Ht * Wt, Hout=1, Wout=Ht * Wt, Cin=cin, Cout=cout, KD=3, KH=1, KW=1,
               stride=1, padD=1, padH=0, padW=0, ostride=1, ophH=0, ophW=0, ldIn=cin, ldOut=cout, ldMask=0, ldAdd=0, flags=0)
-    nbytes = _lib.load().fo_wgrad_banked_ws_bytes(C.byref(d), 16)
+    nbytes = _lib.load().fo_wgrad_banked_ws_bytes(C.byref(d), P)
     if nbytes < 0:
         _lib.check(-1, "fo_wgrad_banked_ws_bytes")
-    ws = _workspace(nbytes + 16 * cout * cin * 3 * 4 + 64, x.device)
-    dU = ws[(nbytes + 3) // 4 // 4 * 4 + 4:][:16 * cout * cin * 3]
+    ws = _workspace(nbytes + P * cout * cin * 3 * 4 + 64, x.device)
+    dU = ws[(nbytes + 3) // 4 // 4 * 4 + 4:][:P * cout * cin * 3]
     prof = PROFILER
     if prof is not None:
-        nominal = 2.0 * 16 * N * Ht * Wt * cout * cin * 3
-        prof.begin("conv_wgrad_%dx%d_wino" % (cout, cin) + (f" [16x{N}x{Ht}x{Wt}]" if prof.detail else ""),
+        nominal = 2.0 * P * N * Ht * Wt * cout * cin * 3
+        prof.begin("conv_wgrad_%dx%d" % (cout, cin) + (f" [winograd F{m} GEMM {P}x{N}x{Ht}x{Wt} k311]" if prof.detail else ""),
                    nominal * temporal_share(T), nominal)
-    _lib.call("fo_conv_wgrad_banked", C.byref(d), _ptr(dM), _ptr(V), _ptr(dU), cout, cin, _ptr(ws), C.c_int64(nbytes), 16, _stream())
+    _lib.call("fo_conv_wgrad_banked", C.byref(d), _ptr(dM), _ptr(V), _ptr(dU), cout, cin, _ptr(ws), C.c_int64(nbytes), P, _stream())
     if prof is not None:
         prof.end()
-    _lib.call("fo_wino_wgrad_out", _ptr(dU), _ptr(dw), cout, cin, 3, _stream())
+    _lib.call("fo_wino_wgrad_out", _ptr(dU), _ptr(dw), cout, cin, 3, m, _stream())
     if dbias is not None:
         bias_grad(g, dbias, cout)
 

@@ -182,24 +182,25 @@ int fo_lpips_tap_fwd(const float* f0, const float* f1, const float* lin, float* 
 int fo_lpips_tap_bwd(const float* f0, const float* f1, const float* lin, const float* gscale, float* gf1, int N, int H, int W,
                      int C, void* stream);
 
-/* ---------------------------------------------------------------- Winograd F(2x2,3x3) for the Conv3d k3 p1 layers (:181,185)
- * out = A^T [ sum_{kd,ci} (G g_kd G^T) . (B^T d B) ] A: the two spatial dimensions are transformed (16 multiplies per
- * 2x2 outputs instead of 36), depth taps and channels stay a contraction = a (3,1,1) Conv3d over the stack of 16
- * transformed planes, run by fo_conv_igemm_banked (or one fo_conv_igemm per plane). */
-/* U[16][Opad][KD][Ipad] from the checkpoint filter w[O][I][KD][3][3]; dgrad=1: the data-gradient filter (flipped
+/* ---------------------------------------------------------------- Winograd F(m x m, 3x3), m = 2 or 4, for the Conv3d k3 p1 layers (:181,185)
+ * out = A^T [ sum_{kd,ci} (G g_kd G^T) . (B^T d B) ] A: the two spatial dimensions are transformed ((m+2)^2 multiplies
+ * per m x m outputs instead of 9 m^2: 2.25x / 4x fewer), depth taps and channels stay a contraction = a (3,1,1) Conv3d
+ * over the stack of (m+2)^2 transformed planes, run by fo_conv_igemm_banked (or one fo_conv_igemm per plane).
+ * fp32 error: m = 2 as the direct convolution, m = 4 about 10x that (3e-6 of the tensor's scale). */
+/* U[(m+2)^2][Opad][KD][Ipad] from the checkpoint filter w[O][I][KD][3][3]; dgrad=1: the data-gradient filter (flipped
  * taps, channel roles swapped: rows = I, K columns = O). */
-int fo_wino_filter(const float* w, float* U, int O, int I, int KD, int Opad, int Ipad, int dgrad, void* stream);
-/* V[16][N][H/2][W/2][C] = B^T d B of the zero-padded 4x4 patches of x [N,H,W,ldx]. */
-int fo_wino_input(const float* x, int ldx, float* V, int N, int H, int W, int C, void* stream);
-/* out [N,H,W,ldOut] = epilogue(A^T M A), M[16][N][H/2][W/2][C]; flags: FO_BIAS | FO_MASK | FO_ADD | FO_OUT_RELU. */
+int fo_wino_filter(const float* w, float* U, int O, int I, int KD, int Opad, int Ipad, int dgrad, int m, void* stream);
+/* V[(m+2)^2][N][H/m][W/m][C] = B^T d B of the zero-padded (m+2)x(m+2) patches of x [N,H,W,ldx]. */
+int fo_wino_input(const float* x, int ldx, float* V, int N, int H, int W, int C, int m, void* stream);
+/* out [N,H,W,ldOut] = epilogue(A^T M A), M[(m+2)^2][N][H/m][W/m][C]; flags: FO_BIAS | FO_MASK | FO_ADD | FO_OUT_RELU. */
 int fo_wino_output(const float* M, const float* bias, const float* mask, int ldMask, const float* add, int ldAdd, float* out,
-                   int ldOut, int N, int H, int W, int C, int flags, void* stream);
+                   int ldOut, int N, int H, int W, int C, int flags, int m, void* stream);
 
-/* Filter gradient of the same convolution in the transformed domain: dM[16][N][H/2][W/2][C] = A dY A^T of the output
- * gradient g [N,H,W,ldg]; then dU[xi] = sum_pixels dM[xi] (x) V[xi] shifted by the depth tap -- 16 wgrad GEMMs in one
+/* Filter gradient of the same convolution in the transformed domain: dM[(m+2)^2][N][H/m][W/m][C] = A dY A^T of the output
+ * gradient g [N,H,W,ldg]; then dU[xi] = sum_pixels dM[xi] (x) V[xi] shifted by the depth tap -- (m+2)^2 wgrad GEMMs in one
  * fo_conv_wgrad_banked launch ((3,1,1) geometry, planes as banks); then dW[O][I][KD][3][3] = G^T dU G. */
-int fo_wino_gradout(const float* g, int ldg, float* dM, int N, int H, int W, int C, void* stream);
-int fo_wino_wgrad_out(const float* dU /* [16][O][I][KD] */, float* dW, int O, int I, int KD, void* stream);
+int fo_wino_gradout(const float* g, int ldg, float* dM, int N, int H, int W, int C, int m, void* stream);
+int fo_wino_wgrad_out(const float* dU /* [(m+2)^2][O][I][KD] */, float* dW, int O, int I, int KD, int m, void* stream);
 
 /* ---------------------------------------------------------------- bf16 LPIPS branch (BASELINE config 3)
  * The same VGG-16 / LPIPS chain with bf16 storage and bf16 MFMA operands, fp32 accumulation and fp32 head

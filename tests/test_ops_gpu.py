@@ -208,14 +208,15 @@ def test_conv3d_fwd_dgrad_wgrad(B, T, H, W):
     _close(db, b.grad, what="conv3d bias grad")
 
 
-@pytest.mark.parametrize("B,T,H,W", [(1, 1, 8, 16), (2, 2, 8, 8), (1, 5, 16, 16), (2, 5, 32, 32), (3, 3, 6, 10), (1, 5, 16, 32),
-                                     (2, 2, 16, 16)])
-def test_conv3d_winograd_fwd_dgrad(B, T, H, W):
-    """The Winograd F(2x2,3x3) form of Conv3d 128->128 k3 p1 (transforms + banked (3,1,1) implicit GEMM) against
-    torch-CPU: forward with bias + ReLU, data gradient with ReLU mask + residual, banked (H/2*W/2 % 128 == 0) and
-    per-plane launches, clip padding (T = 1, 3, 5), a channel-slice output view."""
+@pytest.mark.parametrize("B,T,H,W,m", [(1, 1, 8, 16, 2), (2, 2, 8, 8, 2), (1, 5, 16, 16, 2), (2, 5, 32, 32, 2), (3, 3, 6, 10, 2),
+                                       (1, 5, 16, 32, 2), (2, 2, 16, 16, 2), (1, 5, 64, 64, 4), (2, 2, 32, 64, 4), (1, 3, 16, 16, 4),
+                                       (1, 1, 8, 12, 4)])
+def test_conv3d_winograd_fwd_dgrad(B, T, H, W, m):
+    """The Winograd F(m x m, 3x3) forms (m = 2, 4) of Conv3d 128->128 k3 p1 (transforms + banked (3,1,1) implicit GEMM)
+    against torch-CPU: forward with bias + ReLU, data gradient with ReLU mask + residual, filter gradient; banked
+    (tiles per frame % 128 == 0) and per-plane launches, clip padding (T = 1, 3, 5), a channel-slice output view."""
     from faceoff_amd import ops
-    rng = np.random.default_rng(300 + B * 10 + T + H)
+    rng = np.random.default_rng(300 + B * 10 + T + H + m)
     x = _rand(rng, B, 128, T, H, W).requires_grad_(True)
     w = _rand(rng, 128, 128, 3, 3, 3, scale=0.02)
     b = _rand(rng, 128, scale=0.1)
@@ -232,21 +233,21 @@ def test_conv3d_winograd_fwd_dgrad(B, T, H, W):
 
     xg, gyg, wg, bg = frames(x), frames(gy), w.to(dev), b.to(dev)
     wide = torch.zeros((B * T, H, W, 192), device=dev)
-    ops.conv3d_winograd(xg, ops.wino_filter(wg), bg, wide[..., 64:192], T=T, cin=128, cout=128, flags=ops.FO_OUT_RELU)
+    ops.conv3d_winograd(xg, ops.wino_filter(wg, m=m), bg, wide[..., 64:192], T=T, cin=128, cout=128, flags=ops.FO_OUT_RELU, m=m)
     _close(clips(wide[..., 64:192].contiguous()), torch.relu(y_pre), what="winograd conv3d fwd")
     assert (wide[..., :64] == 0).all()
     mask = frames(_rand(rng, B, 128, T, H, W)).clamp_min(0)
     addt = frames(_rand(rng, B, 128, T, H, W))
     gx = torch.empty_like(xg)
-    ops.conv3d_winograd(gyg, ops.wino_filter(wg, dgrad=True), None, gx, T=T, cin=128, cout=128, mask=mask, add=addt)
+    ops.conv3d_winograd(gyg, ops.wino_filter(wg, dgrad=True, m=m), None, gx, T=T, cin=128, cout=128, mask=mask, add=addt, m=m)
     want = x.grad * (clips(mask) > 0) + clips(addt)
     _close(clips(gx), want, what="winograd conv3d dgrad")
-    if ops.wino_wgrad_ok(H, W, B * T, T):                # filter gradient in the transformed domain (banked wgrad GEMMs)
+    if ops.wino_wgrad_ok(H, W, B * T, T, m):             # filter gradient in the transformed domain (banked wgrad GEMMs)
         w2 = w.clone().requires_grad_(True)
         b2 = b.clone().requires_grad_(True)
         F.conv3d(x.detach(), w2, b2, padding=1).backward(gy)
         dw, db = torch.empty_like(wg), torch.empty_like(bg)
-        ops.conv3d_wgrad_winograd(gyg, xg, dw, db, T=T, a_real=128, b_real=128)
+        ops.conv3d_wgrad_winograd(gyg, xg, dw, db, T=T, a_real=128, b_real=128, m=m)
         _close(dw, w2.grad, what="winograd conv3d wgrad")
         _close(db, b2.grad, what="winograd conv3d bias grad")
 
