@@ -182,13 +182,15 @@ def main():
     executed = FLOP_PER_FRAME - conv3d_flop * (1.0 - temporal_share(T))
     out["step_frac_direct_flop_without_padding_taps"] = round(executed * fps / world / (FP32_MFMA_PEAK_TFLOPS * 1e12), 4)
     if eng.winograd:
-        # bottom chain (64^2 latents at 256^2 input): F(4x4,3x3) = 36 multiplies per 16 outputs instead of 144; top chain
-        # (32^2): F(2x2,3x3) = 16 per 4 instead of 36 (per-frame GMAC of the two chains: SURVEY 8a, row a4)
-        f_b = 36.0 / 144.0 if (H // 4) % 4 == 0 and ((H // 16) * (H // 16)) % 128 == 0 and eng.winograd_max_tile >= 4 else 16.0 / 36.0
-        f_t = 16.0 / 36.0
+        # F(4x4,3x3) = 36 multiplies per 16 outputs instead of 144, F(2x2,3x3) = 16 per 4 instead of 36 (per-frame GMAC of
+        # the bottom / top Conv3d chains: SURVEY 8a, row a4)
+        from faceoff_amd.ops import wino_tile
+        frac = {4: 36.0 / 144.0, 2: 16.0 / 36.0, 0: 1.0}
+        f_b = frac[min(wino_tile(H // 4, H // 4, B * T), eng.winograd_max_tile)]
+        f_t = frac[min(wino_tile(H // 8, H // 8, B * T), eng.winograd_max_tile)]
         executed -= 3 * 2 * temporal_share(T) * (5.436e9 * (1.0 - f_b) + 1.359e9 * (1.0 - f_t))
     out["step_frac_executed_flop"] = round(executed * fps / world / (FP32_MFMA_PEAK_TFLOPS * 1e12), 4)
-    out["config"]["conv3d_algorithm"] = ("winograd (fwd, dgrad, wgrad): F(4x4,3x3) on 64x64 latents, F(2x2,3x3) on 32x32"
+    out["config"]["conv3d_algorithm"] = ("winograd (fwd, dgrad, wgrad), F(4x4,3x3) where a plane is whole GEMM tiles else F(2x2,3x3)"
                                          if eng.winograd else "direct")
     if prof is not None:
         summ = prof.summary()

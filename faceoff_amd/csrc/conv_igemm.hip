@@ -254,8 +254,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
   unsigned wrow[BROWS];
 #pragma unroll
   for (int i = 0; i < BROWS; ++i) wrow[i] = (unsigned)(((size_t)(tile_n * BN + lrow + 32 * i) * a.Ktot + lcol) * 4);
-  if (a.bankFrames > 0) {   // frame-aligned tiles only: one frame, hence one filter bank, per tile
-    const unsigned boff = (unsigned)(n_tile / a.bankFrames) * a.bankBytes;
+  if (a.bankFrames > 0) {   // a tile never straddles a bank (rows per bank % 128 == 0): the bank of its first row
+    const unsigned boff = (unsigned)(((tile_m * BM) / a.HWm) / a.bankFrames) * a.bankBytes;
 #pragma unroll
     for (int i = 0; i < BROWS; ++i) wrow[i] += boff;
   }
@@ -530,7 +530,8 @@ static int conv_igemm_impl(const fo_conv_desc* d, const float* in, const float* 
   a.bankFrames = bank_frames;
   a.bankBytes = (unsigned)wpBytes;
   if (bank_frames > 0) {
-    FO_REQUIRE(a.frameAligned && !smallc && d->N % bank_frames == 0, FO_E_SHAPE, "conv: filter banks need frame-aligned tiles");
+    FO_REQUIRE(((long long)bank_frames * a.HWm) % BM == 0 && !smallc && d->N % bank_frames == 0, FO_E_SHAPE,
+               "conv: a filter bank's rows (bank_frames * Hm * Wm) must be a multiple of 128");
     const unsigned long long allBanks = (unsigned long long)(d->N / bank_frames) * wpBytes;
     FO_REQUIRE(allBanks < (1ull << 31), FO_E_SHAPE, "conv: filter banks exceed the 2 GiB window");
     a.wpBytes = (unsigned)allBanks;
@@ -562,7 +563,7 @@ extern "C" int fo_conv_igemm(const fo_conv_desc* d, const float* in, const float
 
 // The same contraction with the filter chosen per frame: frames [b*bank_frames, (b+1)*bank_frames) use the b-th filter
 // bank (banks are consecutive packed filters of Opad*taps*Cin floats).  The 16 GEMMs of a Winograd-transformed Conv3d are
-// one such launch over the stack of transformed planes (winograd.hip).  Tiles must not straddle frames (Hm*Wm % 128 == 0).
+// one such launch over the stack of transformed planes (winograd.hip).  bank_frames * Hm * Wm must be a multiple of 128.
 extern "C" int fo_conv_igemm_banked(const fo_conv_desc* d, const float* in, const float* wp, float* out, int bank_frames,
                                     void* stream) {
   FO_REQUIRE(bank_frames > 0 && !(d->flags & (FO_BIAS | FO_MASK | FO_ADD | FO_DEPTH2SPACE)), FO_E_SHAPE, "conv_banked: plain GEMM only");

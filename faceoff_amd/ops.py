@@ -175,9 +175,9 @@ def conv_igemm(x, wp, bias, out, *, T=1, k=(1, 3, 3), stride=1, pad=(0, 1, 1), c
 # ------------------------------------------------------------------ Winograd F(m x m, 3x3) Conv3d, m = 2 or 4
 def wino_tile(H, W, N=None):
     """Output-tile size for a Conv3d on HxW frames: 4 (4x fewer MFMA FLOP, fp32 error ~3e-6 of scale) when the plane
-    stack can run as ONE banked GEMM launch (a frame's H/4 * W/4 tiles fill whole 128-row GEMM tiles and the 36 planes fit
-    the 2 GiB buffer window), else 2 (2.25x fewer, error as the direct convolution), else 0 (odd sizes: direct)."""
-    if H % 4 == 0 and W % 4 == 0 and ((H // 4) * (W // 4)) % 128 == 0 and (N is None or 36 * N * (H // 4) * (W // 4) * 128 * 4 < (1 << 31)):
+    stack can run as ONE banked GEMM launch (a plane's N * H/4 * W/4 rows are whole 128-row GEMM tiles and the 36 planes
+    fit the 2 GiB buffer window), else 2 (2.25x fewer, error as the direct convolution), else 0 (odd sizes: direct)."""
+    if H % 4 == 0 and W % 4 == 0 and N is not None and (N * (H // 4) * (W // 4)) % 128 == 0 and 36 * N * (H // 4) * (W // 4) * 128 * 4 < (1 << 31):
         return 4
     return 2 if H % 2 == 0 and W % 2 == 0 else 0
 
@@ -226,7 +226,7 @@ def conv3d_winograd(x, U, bias, out, *, T, cin, cout, flags=0, mask=None, add=No
         V = torch.empty(P * plane_v, device=x.device, dtype=torch.float32)
     _lib.call("fo_wino_input", _ptr(x), ld_of(x), _ptr(V), N, H, W, cin, m, _stream())
     bank = pad_out(cout) * 3 * cin                                  # floats per filter bank
-    banked = (Ht * Wt) % 128 == 0
+    banked = (N * Ht * Wt) % 128 == 0
     per = max(1, min(P, ((1 << 31) - 1) // max(plane_v * 4, plane_m * 4))) if banked else 1   # planes per launch (2 GiB window)
     prof = PROFILER
     for p0 in range(0, P, per):

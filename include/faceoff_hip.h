@@ -102,7 +102,7 @@ int fo_conv_igemm(const fo_conv_desc* d, const float* in, const float* wp, const
                   const float* mask, const float* add, float* out, void* stream);
 
 /* fo_conv_igemm with the filter chosen per frame: frames [b*bank_frames, (b+1)*bank_frames) use the b-th of the
- * consecutive packed filter banks behind `wp`.  No bias / mask / residual.  Needs Hm*Wm % 128 == 0. */
+ * consecutive packed filter banks behind `wp`.  No bias / mask / residual.  Needs bank_frames*Hm*Wm % 128 == 0. */
 int fo_conv_igemm_banked(const fo_conv_desc* d, const float* in, const float* wp, float* out, int bank_frames, void* stream);
 
 /* fo_conv_wgrad for `banks` independent planes of N/banks frames (whole clips each) in one launch: dw receives `banks`
