@@ -513,7 +513,7 @@ int make_plan(const fo_conv_desc* d, Plan* p, int banks = 1) {
   }
   p->tapsSlab = p->taps;
   p->kdLoop = 0;
-  if (!p->smallc && d->KD > 1 && d->T > 1 && (d->Hm * d->Wm) % 32 == 0 && !getenv("FACEOFF_NO_KDLOOP")) {
+  if (!p->smallc && ((d->KD > 1 && d->T > 1 && !getenv("FACEOFF_NO_KDLOOP")) || banks > 1) && (d->Hm * d->Wm) % 32 == 0) {
     p->kdLoop = 1;                 // workgroups enumerate (chunk, kh, kw) and loop over kd; chunks cut by work
     p->taps = d->KH * d->KW;
   }
@@ -535,7 +535,7 @@ int make_plan(const fo_conv_desc* d, Plan* p, int banks = 1) {
   p->nchunks = (int)((M + chunk - 1) / chunk);
   p->cpp = p->nchunks;
   if (banks > 1) {   // chunks per plane: the same total number of workgroups, never straddling a plane
-    FO_REQUIRE(p->kdLoop && d->N % (banks * d->T) == 0, FO_E_SHAPE, "wgrad: banks need the Conv3d walk and whole clips per plane");
+    FO_REQUIRE(p->kdLoop && d->N % (banks * d->T) == 0, FO_E_SHAPE, "wgrad: banks need Hm*Wm %% 32 == 0 and whole clips per plane");
     p->cpp = std::max(1, p->nchunks / banks);
     p->nchunks = p->cpp * banks;
   }

@@ -90,9 +90,10 @@ class _Layer:
             ops.convT_phases(x, self.wp, self.b, out, cin=self.cip, cout=self.co, flags=flags, add=add)
         elif self._winograd_m(x):
             m = self._winograd_m(x)
-            keep = self.engine.keep_wino_v and ops.wino_wgrad_ok(x.shape[1], x.shape[2], x.shape[0], T, m)
+            kd = self._wino_kd
+            keep = self.engine.keep_wino_v and ops.wino_wgrad_ok(x.shape[1], x.shape[2], x.shape[0], T, m, kd)
             self.saved_v = ops.conv3d_winograd(x, self._wino_filter(m, False), self.b, out, T=T, cin=self.ci, cout=self.co,
-                                               flags=flags, add=add, keep_v=keep, m=m)
+                                               flags=flags, add=add, keep_v=keep, m=m, kd=kd)
         else:
             g = self._geom()
             ops.conv_igemm(x, self.wp, self.b, out, T=T if self.kind == "conv3d" else 1, cin=self.cip, cout=self.co,
@@ -102,10 +103,19 @@ class _Layer:
         """Output-tile size of the Winograd form for a Conv3d k3 p1 on frames like x: 4 (64x64 latents: 4x fewer MFMA
         FLOP), 2 (other even sizes: 2.25x fewer) or 0 = direct kernel (odd sizes, other layer kinds, FACEOFF_NO_WINOGRAD)."""
         eng = self.engine
-        if self.kind != "conv3d" or eng is None or not eng.winograd or self.ci % 32 or self.co % 4:
+        if eng is None or not eng.winograd or self.ci % 32 or self.co % 4:
             return 0
-        m = ops.wino_tile(x.shape[1], x.shape[2], x.shape[0])
-        return min(m, eng.winograd_max_tile)
+        m = min(ops.wino_tile(x.shape[1], x.shape[2], x.shape[0]), eng.winograd_max_tile)
+        if self.kind == "conv3d":
+            return m
+        # Conv2d 3x3 s1 128->128 (enc_b.blocks.4, dec.blocks.0): one depth tap, K = Cin only -- pays with F(4x4) alone
+        if self.kind == "conv" and self.k == (3, 3) and self.ci >= 128 and self.co >= 128 and m == 4:
+            return 4
+        return 0
+
+    @property
+    def _wino_kd(self):
+        return 3 if self.kind == "conv3d" else 1
 
     def _wino_filter(self, m, dgrad):
         key = (m, dgrad)
@@ -122,7 +132,8 @@ class _Layer:
             ops.convT_phases(g, self.wpd, None, gin, cin=self.co, cout=self.ci, mask=mask, add=add)
         elif self._winograd_m(g):
             m = self._winograd_m(g)
-            ops.conv3d_winograd(g, self._wino_filter(m, True), None, gin, T=T, cin=self.co, cout=self.ci, mask=mask, add=add, m=m)
+            ops.conv3d_winograd(g, self._wino_filter(m, True), None, gin, T=T, cin=self.co, cout=self.ci, mask=mask, add=add, m=m,
+                                kd=self._wino_kd)
         else:
             geo = self._geom()
             pad = tuple(kk - 1 - p for kk, p in zip(geo["k"], geo["pad"]))
@@ -155,11 +166,12 @@ class _Layer:
                            in_relu=False)
             ops.bias_grad(g, self.gb, self.co)
         elif (self._winograd_m(x) and not in_relu and self.ci == self.cip
-              and ops.wino_wgrad_ok(x.shape[1], x.shape[2], x.shape[0], T, self._winograd_m(x))):
+              and ops.wino_wgrad_ok(x.shape[1], x.shape[2], x.shape[0], T, self._winograd_m(x), self._wino_kd)):
             V, self.saved_v = getattr(self, "saved_v", None), None     # the forward's transformed input, if it was kept
             if V is not None and self.engine is not None and self.engine.wgrad_stream is not None:
                 self.engine._keepalive.append(V)                      # read on the side stream: must outlive this call
-            ops.conv3d_wgrad_winograd(g, x, self.gw, self.gb, T=T, a_real=self.co, b_real=self.ci, V=V, m=self._winograd_m(x))
+            ops.conv3d_wgrad_winograd(g, x, self.gw, self.gb, T=T, a_real=self.co, b_real=self.ci, V=V, m=self._winograd_m(x),
+                                      kd=self._wino_kd)
         else:
             ops.conv_wgrad(g, x, self.gw, self.gb, T=T if self.kind == "conv3d" else 1, a_real=self.co, b_real=self.ci,
                            in_relu=in_relu, **geo)

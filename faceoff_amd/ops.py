@@ -184,6 +184,8 @@ def wino_tile(H, W, N=None):
 
 def wino_filter(w, dgrad=False, m=2):
     """[O][I][KD][3][3] -> (m+2)^2 packed (3,1,1) filter banks [P][Opad][KD][Ipad] (dgrad: flipped taps, swapped channels)."""
+    if w.dim() == 4:                       # Conv2d filter [O][I][3][3]: one depth tap
+        w = w.unsqueeze(2)
     O, I, KD = w.shape[:3]
     rows, cols = (I, O) if dgrad else (O, I)
     Op, Ip = pad_out(rows), pad_in(cols)
@@ -207,8 +209,9 @@ def _wino_buffers(nfloats, device):
     return buf
 
 
-def conv3d_winograd(x, U, bias, out, *, T, cin, cout, flags=0, mask=None, add=None, keep_v=False, m=2):
-    """Conv3d k3 p1 s1 (or its data gradient, with the dgrad filter banks) on [N,H,W,C] frames, clips of T frames.
+def conv3d_winograd(x, U, bias, out, *, T, cin, cout, flags=0, mask=None, add=None, keep_v=False, m=2, kd=3):
+    """Conv3d k3 p1 s1 (kd=3; or Conv2d 3x3 p1 s1, kd=1, T=1), or its data gradient with the dgrad filter banks, on
+    [N,H,W,C] frames, clips of T frames.
     keep_v: return the transformed input planes in their own tensor (the filter gradient of the same layer needs exactly
     them: conv3d_wgrad_winograd(V=...)) instead of using the per-stream scratch."""
     N, H, W, _ = x.shape
@@ -225,24 +228,24 @@ def conv3d_winograd(x, U, bias, out, *, T, cin, cout, flags=0, mask=None, add=No
     if keep_v:
         V = torch.empty(P * plane_v, device=x.device, dtype=torch.float32)
     _lib.call("fo_wino_input", _ptr(x), ld_of(x), _ptr(V), N, H, W, cin, m, _stream())
-    bank = pad_out(cout) * 3 * cin                                  # floats per filter bank
+    bank = pad_out(cout) * kd * cin                                 # floats per filter bank
     banked = (N * Ht * Wt) % 128 == 0
     per = max(1, min(P, ((1 << 31) - 1) // max(plane_v * 4, plane_m * 4))) if banked else 1   # planes per launch (2 GiB window)
     prof = PROFILER
     for p0 in range(0, P, per):
         np_ = min(per, P - p0)
-        d = _desc(N=np_ * N, T=T, Hin=Ht, Win=Wt, Hm=Ht, Wm=Wt, Hout=Ht, Wout=Wt, Cin=cin, Cout=cout, KD=3, KH=1, KW=1, stride=1,
-                  padD=1, padH=0, padW=0, ostride=1, ophH=0, ophW=0, ldIn=cin, ldOut=cout, ldMask=0, ldAdd=0, flags=0)
+        d = _desc(N=np_ * N, T=T if kd > 1 else 1, Hin=Ht, Win=Wt, Hm=Ht, Wm=Wt, Hout=Ht, Wout=Wt, Cin=cin, Cout=cout, KD=kd, KH=1, KW=1,
+                  stride=1, padD=kd // 2, padH=0, padW=0, ostride=1, ophH=0, ophW=0, ldIn=cin, ldOut=cout, ldMask=0, ldAdd=0, flags=0)
         vin = V[p0 * plane_v:(p0 + np_) * plane_v]
         mout = M[p0 * plane_m:(p0 + np_) * plane_m]
         wp = U[p0 * bank:(p0 + np_) * bank]
         if prof is not None:
-            nominal = 2.0 * np_ * N * Ht * Wt * cout * 3 * cin
+            nominal = 2.0 * np_ * N * Ht * Wt * cout * kd * cin
             # the same kernel instantiation as every other 128-column launch: one label, so that rocprofv3's per-kernel
             # averages and these events describe the same set of launches
             prof.begin("conv_igemm_bn%d" % (128 if cout > 64 else (64 if cout > 32 else 32))
-                       + (f" [winograd F{m} GEMM {np_}x{N}x{Ht}x{Wt} {cin}->{cout} k311]" if prof.detail else ""),
-                       nominal * temporal_share(T), nominal)
+                       + (f" [winograd F{m} GEMM {np_}x{N}x{Ht}x{Wt} {cin}->{cout} k{kd}11]" if prof.detail else ""),
+                       nominal * (temporal_share(T) if kd > 1 else 1.0), nominal)
         if banked:
             _lib.call("fo_conv_igemm_banked", C.byref(d), _ptr(vin), _ptr(wp), _ptr(mout), N, _stream())
         else:
@@ -254,14 +257,14 @@ def conv3d_winograd(x, U, bias, out, *, T, cin, cout, flags=0, mask=None, add=No
     return V if keep_v else None
 
 
-def wino_wgrad_ok(H, W, N, T, m=2):
+def wino_wgrad_ok(H, W, N, T, m=2, kd=3):
     """The Winograd filter-gradient form needs frames that are multiples of m, (H/m * W/m) % 32 == 0 (the wgrad kernel's
     row-run walk over a plane flattened to one row per frame) and plane stacks inside the 2 GiB buffer window."""
-    return (T > 1 and m in (2, 4) and H % m == 0 and W % m == 0 and ((H // m) * (W // m)) % 32 == 0 and N % T == 0
+    return ((T > 1 or kd == 1) and m in (2, 4) and H % m == 0 and W % m == 0 and ((H // m) * (W // m)) % 32 == 0 and N % T == 0
             and (m + 2) ** 2 * N * (H // m) * (W // m) * 128 * 4 < (1 << 31))
 
 
-def conv3d_wgrad_winograd(g, x, dw, dbias, *, T, a_real, b_real, V=None, m=2):
+def conv3d_wgrad_winograd(g, x, dw, dbias, *, T, a_real, b_real, V=None, m=2, kd=3):
     """Filter gradient of a Conv3d k3 p1 in the Winograd domain: dU[xi] = sum dM[xi] (x) V[xi] ((m+2)^2 banked wgrad
     GEMMs with a (3,1,1) geometry), dW = G^T dU G; 2.25x (m=2) / 4x (m=4) fewer MFMA FLOP than the direct form.
     dbias = column sums of g."""
@@ -276,22 +279,23 @@ def conv3d_wgrad_winograd(g, x, dw, dbias, *, T, a_real, b_real, V=None, m=2):
         V, dM = _wino_buffers((P * plane_v, P * plane_m), x.device)
         _lib.call("fo_wino_input", _ptr(x), ld_of(x), _ptr(V), N, H, W, cin, m, _stream())
     _lib.call("fo_wino_gradout", _ptr(g), ld_of(g), _ptr(dM), N, H, W, cout, m, _stream())
-    d = _desc(N=P * N, T=T, Hin=1, Win=Ht * Wt, Hm=1, Wm=Ht * Wt, Hout=1, Wout=Ht * Wt, Cin=cin, Cout=cout, KD=3, KH=1, KW=1,
-              stride=1, padD=1, padH=0, padW=0, ostride=1, ophH=0, ophW=0, ldIn=cin, ldOut=cout, ldMask=0, ldAdd=0, flags=0)
+    d = _desc(N=P * N, T=T if kd > 1 else 1, Hin=1, Win=Ht * Wt, Hm=1, Wm=Ht * Wt, Hout=1, Wout=Ht * Wt, Cin=cin, Cout=cout, KD=kd,
+              KH=1, KW=1, stride=1, padD=kd // 2, padH=0, padW=0, ostride=1, ophH=0, ophW=0, ldIn=cin, ldOut=cout, ldMask=0, ldAdd=0,
+              flags=0)
     nbytes = _lib.load().fo_wgrad_banked_ws_bytes(C.byref(d), P)
     if nbytes < 0:
         _lib.check(-1, "fo_wgrad_banked_ws_bytes")
-    ws = _workspace(nbytes + P * cout * cin * 3 * 4 + 64, x.device)
-    dU = ws[(nbytes + 3) // 4 // 4 * 4 + 4:][:P * cout * cin * 3]
+    ws = _workspace(nbytes + P * cout * cin * kd * 4 + 64, x.device)
+    dU = ws[(nbytes + 3) // 4 // 4 * 4 + 4:][:P * cout * cin * kd]
     prof = PROFILER
     if prof is not None:
-        nominal = 2.0 * P * N * Ht * Wt * cout * cin * 3
-        prof.begin("conv_wgrad_%dx%d" % (cout, cin) + (f" [winograd F{m} GEMM {P}x{N}x{Ht}x{Wt} k311]" if prof.detail else ""),
-                   nominal * temporal_share(T), nominal)
+        nominal = 2.0 * P * N * Ht * Wt * cout * cin * kd
+        prof.begin("conv_wgrad_%dx%d" % (cout, cin) + (f" [winograd F{m} GEMM {P}x{N}x{Ht}x{Wt} k{kd}11]" if prof.detail else ""),
+                   nominal * (temporal_share(T) if kd > 1 else 1.0), nominal)
     _lib.call("fo_conv_wgrad_banked", C.byref(d), _ptr(dM), _ptr(V), _ptr(dU), cout, cin, _ptr(ws), C.c_int64(nbytes), P, _stream())
     if prof is not None:
         prof.end()
-    _lib.call("fo_wino_wgrad_out", _ptr(dU), _ptr(dw), cout, cin, 3, m, _stream())
+    _lib.call("fo_wino_wgrad_out", _ptr(dU), _ptr(dw), cout, cin, kd, m, _stream())
     if dbias is not None:
         bias_grad(g, dbias, cout)
 

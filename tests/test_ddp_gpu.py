@@ -57,8 +57,14 @@ def test_two_ranks_equal_one_process_on_the_concatenated_batch():
     np.testing.assert_allclose((r[0]["latent"] + r[1]["latent"]).item() / 2, latent.item(), rtol=1e-4)
     assert (r[0]["embed_b"] - eng.buffers["quantize_b.embed"].cpu()).abs().max().item() <= \
         2e-3 * eng.buffers["quantize_b.embed"].abs().max().item()
-    dp = (r[0]["params"] - eng.flat_params.cpu()).abs().max().item()
-    assert dp <= 1e-4, dp                                             # one Adam step of lr 3e-4
+    # one Adam step of lr 3e-4 moves every parameter by ~lr * sign(g): the two runs may pick different (equally valid)
+    # conv algorithms for their batch sizes, so a gradient that is zero up to rounding can change sign and its parameter
+    # end up 2 lr apart.  Everything else must agree, and such elements must be rare and have negligible gradients.
+    dpar = (r[0]["params"] - eng.flat_params.cpu()).abs()
+    off = dpar > 1e-4
+    assert dpar.max().item() <= 2.1 * 3e-4, dpar.max().item()
+    assert off.float().mean().item() < 1e-3, off.float().mean().item()
+    assert (g_serial.abs()[off] <= 1e-3 * g_serial.abs().max()).all()
 
 
 _RCCL_SCRIPT = r"""

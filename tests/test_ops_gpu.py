@@ -252,6 +252,32 @@ def test_conv3d_winograd_fwd_dgrad(B, T, H, W, m):
         _close(db, b2.grad, what="winograd conv3d bias grad")
 
 
+@pytest.mark.parametrize("N,H,W,m", [(2, 16, 16, 2), (3, 8, 12, 4), (4, 32, 32, 4), (2, 64, 64, 4)])
+def test_conv2d_winograd_fwd_dgrad_wgrad(N, H, W, m):
+    """The same Winograd path with one depth tap: Conv2d 128->128 k3 p1 (enc_b.blocks.4, dec.blocks.0 :113,140)."""
+    from faceoff_amd import ops
+    rng = np.random.default_rng(700 + N + H + m)
+    x = _rand(rng, N, 128, H, W).requires_grad_(True)
+    w = _rand(rng, 128, 128, 3, 3, scale=0.03).requires_grad_(True)
+    b = _rand(rng, 128, scale=0.1).requires_grad_(True)
+    y = F.conv2d(x, w, b, padding=1)
+    gy = _rand(rng, *y.shape)
+    y.backward(gy)
+    dev = _dev()
+    xg, gyg, wg, bg = _nhwc(x.detach()), _nhwc(gy), w.detach().to(dev), b.detach().to(dev)
+    out = torch.empty_like(xg)
+    V = ops.conv3d_winograd(xg, ops.wino_filter(wg, m=m), bg, out, T=1, cin=128, cout=128, m=m, kd=1, keep_v=True)
+    _close(out.permute(0, 3, 1, 2), y, what="winograd conv2d fwd")
+    gx = torch.empty_like(xg)
+    ops.conv3d_winograd(gyg, ops.wino_filter(wg, dgrad=True, m=m), None, gx, T=1, cin=128, cout=128, m=m, kd=1)
+    _close(gx.permute(0, 3, 1, 2), x.grad, what="winograd conv2d dgrad")
+    if ops.wino_wgrad_ok(H, W, N, 1, m, kd=1):
+        dw, db = torch.empty_like(wg), torch.empty_like(bg)
+        ops.conv3d_wgrad_winograd(gyg, xg, dw, db, T=1, a_real=128, b_real=128, V=V, m=m, kd=1)
+        _close(dw, w.grad, what="winograd conv2d wgrad")
+        _close(db, b.grad, what="winograd conv2d bias grad")
+
+
 def test_vq_assign_bit_exact_and_golden(golden_dir):
     """Indices bit-exact vs oracle/vq_oracle.c and vs the reference's own (golden) indices."""
     from faceoff_amd import ops

@@ -46,3 +46,16 @@ for H in (64, 32):
     ops.PROFILER = None
     gm = prof.summary()
     print(f"{H}^2: direct {t_d:.3f} ms   winograd {t_w:.3f} ms   of which GEMM " + ", ".join(f"{v['total_ms']:.3f} ms {v['tflops']:.0f} TF" for v in gm.values()))
+
+print("2-D 3x3 128->128 @64^2:")
+x = torch.randn((N, 64, 64, 128), device=dev); g = torch.randn((N, 64, 64, 128), device=dev)
+w = torch.randn((128, 128, 3, 3), device=dev) * 0.03; b = torch.randn(128, device=dev); out = torch.empty_like(x)
+wp = ops.pack_conv(w); dw = torch.empty_like(w); db = torch.empty(128, device=dev)
+t_d = timeit(lambda: ops.conv_igemm(x, wp, b, out, k=(1, 3, 3), pad=(0, 1, 1), cin=128, cout=128))
+t_dw = timeit(lambda: ops.conv_wgrad(g, x, dw, db, k=(1, 3, 3), pad=(0, 1, 1), a_real=128, b_real=128))
+for m in (2, 4):
+    U = ops.wino_filter(w, m=m)
+    t_w = timeit(lambda: ops.conv3d_winograd(x, U, b, out, T=1, cin=128, cout=128, m=m, kd=1))
+    V = ops.conv3d_winograd(x, U, b, out, T=1, cin=128, cout=128, m=m, kd=1, keep_v=True)
+    t_ww = timeit(lambda: ops.conv3d_wgrad_winograd(g, x, dw, db, T=1, a_real=128, b_real=128, V=V, m=m, kd=1))
+    print(f"  F{m}: fwd direct {t_d:.3f} ms  winograd {t_w:.3f} ms ;  wgrad direct {t_dw:.3f} ms  winograd (V kept) {t_ww:.3f} ms")
