@@ -61,11 +61,16 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lpips-dtype", choices=("bf16", "fp32"), default="bf16",
                     help="--perceptual: arithmetic of the LPIPS / VGG-16 branch (BASELINE config 3 = bf16)")
+    ap.add_argument("--direct-conv", action="store_true",
+                    help="run the Conv3d / 3x3 128->128 layers on the direct implicit-GEMM kernels instead of Winograd "
+                         "(the kernel-quality reference: same results to fp32 rounding, 1.5x the step time)")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-launch HIP-event timing")
     ap.add_argument("--serial-streams", action="store_true",
                     help="run the step without side-stream overlap (what profiles/collect.sh traces: kernels run alone)")
     args = ap.parse_args()
 
+    if args.direct_conv:
+        os.environ["FACEOFF_NO_WINOGRAD"] = "1"
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
