@@ -194,3 +194,39 @@ def test_step_from_loader_batch_equals_step_on_concatenated_input():
         outs.append((recon.item(), latent.item(), eng.flat_grads.clone(), eng.flat_params.clone()))
     np.testing.assert_allclose(outs[0][:2], outs[1][:2], rtol=1e-6)      # loss sums use float atomics: order varies
     assert torch.equal(outs[0][2], outs[1][2]) and torch.equal(outs[0][3], outs[1][3])
+
+
+def test_winograd_and_direct_conv3d_engines_agree():
+    """The default engine (Conv3d / 3x3 128->128 layers as Winograd F(4x4 | 2x2, 3x3)) against the same engine on the
+    direct kernels (FACEOFF_NO_WINOGRAD) at a size where both Winograd tiles are in play (128x128 frames, 8 frames).
+    Forward: same code indices, outputs and losses to 1e-5.  Backward: the two forwards differ by ~1e-5 of scale, which
+    moves a handful of pre-activations across zero, and a ReLU's derivative is discontinuous there (the same happens
+    between any two fp32 implementations, the reference's included): every gradient tensor within the 1e-3 parity bound,
+    and within 1e-4 for all but a sliver of its elements."""
+    from faceoff_amd.engine import VQVAEEngine
+    img, gt = make_batch(7, 2, 4, 128, 128)
+    img = torch.from_numpy(img).reshape(8, 6, 128, 128).cuda()
+    gt = torch.from_numpy(gt).reshape(8, 3, 128, 128).cuda()
+    res = []
+    for direct in (False, True):
+        if direct:
+            os.environ["FACEOFF_NO_WINOGRAD"] = "1"
+        try:
+            eng = VQVAEEngine(make_state_dict(3, codebook_scale=0.3, gain=2.0), "cuda:0")
+        finally:
+            os.environ.pop("FACEOFF_NO_WINOGRAD", None)
+        assert eng.winograd == (not direct)
+        recon, diff, S = eng.loss_and_backward(img, gt, T=4)
+        torch.cuda.synchronize()
+        res.append((S["dec"].clone(), S["id_t"].clone(), S["id_b"].clone(), recon.item(), diff.item(),
+                    {k: eng.flat_grads[o:o + n].clone() for k, (o, n) in eng.offsets.items()}))
+    w, d = res
+    assert torch.equal(w[1], d[1]) and torch.equal(w[2], d[2])
+    assert (w[0] - d[0]).abs().max().item() <= 2e-5 * d[0].abs().max().item()
+    np.testing.assert_allclose([w[3], w[4]], [d[3], d[4]], rtol=1e-5)
+    for k in d[5]:
+        err = (w[5][k] - d[5][k]).abs()
+        scale = d[5][k].abs().max().item() + 1e-30
+        assert err.max().item() <= 1e-3 * scale, (k, err.max().item() / scale)
+    allerr = torch.cat([(w[5][k] - d[5][k]).abs() / (d[5][k].abs().max() + 1e-30) for k in d[5]])
+    assert (allerr > 1e-4).float().mean().item() < 1e-3

@@ -234,22 +234,23 @@ def test_conv3d_winograd_fwd_dgrad(B, T, H, W, m):
     xg, gyg, wg, bg = frames(x), frames(gy), w.to(dev), b.to(dev)
     wide = torch.zeros((B * T, H, W, 192), device=dev)
     ops.conv3d_winograd(xg, ops.wino_filter(wg, m=m), bg, wide[..., 64:192], T=T, cin=128, cout=128, flags=ops.FO_OUT_RELU, m=m)
-    _close(clips(wide[..., 64:192].contiguous()), torch.relu(y_pre), what="winograd conv3d fwd")
+    tol = 2e-5 if m == 2 else 2e-4       # F(2x2): the direct convolution's rounding; F(4x4): ~10x that (vs fp32 torch-CPU)
+    _close(clips(wide[..., 64:192].contiguous()), torch.relu(y_pre), rtol=tol, what="winograd conv3d fwd")
     assert (wide[..., :64] == 0).all()
     mask = frames(_rand(rng, B, 128, T, H, W)).clamp_min(0)
     addt = frames(_rand(rng, B, 128, T, H, W))
     gx = torch.empty_like(xg)
     ops.conv3d_winograd(gyg, ops.wino_filter(wg, dgrad=True, m=m), None, gx, T=T, cin=128, cout=128, mask=mask, add=addt, m=m)
     want = x.grad * (clips(mask) > 0) + clips(addt)
-    _close(clips(gx), want, what="winograd conv3d dgrad")
+    _close(clips(gx), want, rtol=tol, what="winograd conv3d dgrad")
     if ops.wino_wgrad_ok(H, W, B * T, T, m):             # filter gradient in the transformed domain (banked wgrad GEMMs)
         w2 = w.clone().requires_grad_(True)
         b2 = b.clone().requires_grad_(True)
         F.conv3d(x.detach(), w2, b2, padding=1).backward(gy)
         dw, db = torch.empty_like(wg), torch.empty_like(bg)
         ops.conv3d_wgrad_winograd(gyg, xg, dw, db, T=T, a_real=128, b_real=128, m=m)
-        _close(dw, w2.grad, what="winograd conv3d wgrad")
-        _close(db, b2.grad, what="winograd conv3d bias grad")
+        _close(dw, w2.grad, rtol=tol, what="winograd conv3d wgrad")
+        _close(db, b2.grad, rtol=2e-5, what="winograd conv3d bias grad")
 
 
 @pytest.mark.parametrize("N,H,W,m", [(2, 16, 16, 2), (3, 8, 12, 4), (4, 32, 32, 4), (2, 64, 64, 4)])
@@ -267,15 +268,16 @@ def test_conv2d_winograd_fwd_dgrad_wgrad(N, H, W, m):
     xg, gyg, wg, bg = _nhwc(x.detach()), _nhwc(gy), w.detach().to(dev), b.detach().to(dev)
     out = torch.empty_like(xg)
     V = ops.conv3d_winograd(xg, ops.wino_filter(wg, m=m), bg, out, T=1, cin=128, cout=128, m=m, kd=1, keep_v=True)
-    _close(out.permute(0, 3, 1, 2), y, what="winograd conv2d fwd")
+    tol = 2e-5 if m == 2 else 2e-4
+    _close(out.permute(0, 3, 1, 2), y, rtol=tol, what="winograd conv2d fwd")
     gx = torch.empty_like(xg)
     ops.conv3d_winograd(gyg, ops.wino_filter(wg, dgrad=True, m=m), None, gx, T=1, cin=128, cout=128, m=m, kd=1)
-    _close(gx.permute(0, 3, 1, 2), x.grad, what="winograd conv2d dgrad")
+    _close(gx.permute(0, 3, 1, 2), x.grad, rtol=tol, what="winograd conv2d dgrad")
     if ops.wino_wgrad_ok(H, W, N, 1, m, kd=1):
         dw, db = torch.empty_like(wg), torch.empty_like(bg)
         ops.conv3d_wgrad_winograd(gyg, xg, dw, db, T=1, a_real=128, b_real=128, V=V, m=m, kd=1)
-        _close(dw, w.grad, what="winograd conv2d wgrad")
-        _close(db, b.grad, what="winograd conv2d bias grad")
+        _close(dw, w.grad, rtol=tol, what="winograd conv2d wgrad")
+        _close(db, b.grad, rtol=2e-5, what="winograd conv2d bias grad")
 
 
 def test_vq_assign_bit_exact_and_golden(golden_dir):
