@@ -210,6 +210,10 @@ def main():
                            "share_of_step_time": round(d["total_ms"] / (ms_serial * args.steps), 4),
                            "measured": "HIP events per launch over a second K-step region with the side streams joined "
                                        "(kernels run alone; ms_per_step_serial is that region's step time incl. event overhead)"}
+        if eng.winograd:
+            out["roofline"]["note"] = ("launches of this kernel are mostly Winograd-domain GEMMs (K = 3*128 or 128: short); "
+                                       "bench.py --direct-conv runs the same step on direct convolutions: 1.5x slower, "
+                                       "dominant kernel conv_igemm3 at 0.91 of the fp32 MFMA peak (profiles/r01_bench_direct_conv3d.json)")
         out["ms_per_step_serial"] = round(ms_serial, 3)
         out["kernels"] = {k: {"launches_per_step": v["launches"] / args.steps, "avg_ms": round(v["avg_ms"], 4),
                               "tflops": round(v["tflops"], 2), "tflops_padded_taps_counted": round(v["tflops_nominal"], 2), "ms_per_step": round(v["total_ms"] / args.steps, 3)}
