@@ -1,17 +1,29 @@
 #!/usr/bin/env python3
 """FaceOff MI355X bench: train frames/s of the VQ-VAE-2 + Conv3d-latent step (BASELINE.json metric).
 
-  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1: either launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` (RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* in the environment), or -- when WORLD_SIZE is not set -- this process starts the N ranks itself
+(fresh interpreters, before anything here touches the GPU; the reference spawns its ranks the same way:
+train_faceoff_perceptual.py:253 -> distributed/launch.py:22-49) and exits with their status.  Fewer than N visible
+GPUs is an error, never a silent one-GPU run.
 
 Workload (BASELINE.json configs[1], "C2"): 256x256, T=5, bs=32 clips per GPU (160 frames/GPU/step),
 recon + VQ loss, fp32, synthetic inputs resident in HBM, random-init weights.  A step is one full
 training iteration: forward, fused losses, backward (all 70 gradients), bucketed RCCL gradient
 all-reduce overlapped with backward (N>1), one multi-tensor Adam launch.  Weak scaling: per-GPU work
-is fixed.  Rank 0 prints ONE JSON line.
+is fixed.  Rank 0 prints ONE JSON line.  Besides the headline it carries
+
+  roofline              dominant kernel of the timed (Winograd) step, HIP events per launch
+  roofline.direct_conv  the same step on the direct implicit-GEMM kernels (no Winograd): step time + its dominant kernel
+  c3                    BASELINE configs[2]: the same step + LPIPS/VGG-16 perceptual loss in bf16 (seeded VGG weights)
+  cpu_baseline          the CPU oracle on the host cores, bounded sample (N = 1 only)
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -23,6 +35,8 @@ sys.path.insert(0, ROOT)
 FP32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
 BF16_MFMA_PEAK_TFLOPS = 2500.0         # dense (same table)
 FLOP_PER_FRAME = 64.1e9                # 63.77 GFLOP conv + 0.34 GFLOP VQ distance per frame
+VQ_FLOP_PER_FRAME = 0.34e9             # 2 * (32*32 + 64*64) vectors * 64 * 512 at 256x256
+LPIPS_FLOP_PER_FRAME = 120.3e9         # 20.04 GMAC x (2 forward + 1 dgrad)
 
 
 def cpu_baseline(T, H, W, steps=20):
@@ -47,7 +61,7 @@ def cpu_baseline(T, H, W, steps=20):
             "sample": f"1 clip x {T} frames {H}x{W}, fwd+bwd+Adam, {steps} timed steps (~{dt * steps:.0f} s) after 2 warm-ups, torch-CPU oracle"}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -56,28 +70,74 @@ def main():
     ap.add_argument("--frames", type=int, default=5, help="frames per clip T (BASELINE: 5)")
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--perceptual", action="store_true",
-                    help="BASELINE config 3: add the LPIPS/VGG-16 term (train_faceoff_perceptual.py path, seeded VGG "
-                         "weights, --lpips-dtype); the headline metric is config 2 (without it)")
+                    help="make BASELINE config 3 (C2 + LPIPS/VGG-16 term, --lpips-dtype) the timed workload; "
+                         "the headline metric is config 2, which reports config 3 under the key `c3` anyway")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-c3", action="store_true", help="skip the short config-3 leg")
+    ap.add_argument("--no-direct-leg", action="store_true", help="skip the short direct-convolution leg")
     ap.add_argument("--lpips-dtype", choices=("bf16", "fp32"), default="bf16",
-                    help="--perceptual: arithmetic of the LPIPS / VGG-16 branch (BASELINE config 3 = bf16)")
+                    help="arithmetic of the LPIPS / VGG-16 branch (BASELINE config 3 = bf16)")
     ap.add_argument("--direct-conv", action="store_true",
                     help="run the Conv3d / 3x3 128->128 layers on the direct implicit-GEMM kernels instead of Winograd "
                          "(the kernel-quality reference: same results to fp32 rounding, 1.5x the step time)")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-launch HIP-event timing")
     ap.add_argument("--serial-streams", action="store_true",
                     help="run the step without side-stream overlap (what profiles/collect.sh traces: kernels run alone)")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
+
+def launch_ranks(n, argv):
+    """Start n ranks of this script (one per GPU) and return their worst exit status.  Runs BEFORE this process has
+    made any HIP call: torch.cuda.device_count() does not initialise the runtime, and the children are fresh
+    interpreters, so nothing re-execs or forks with a live GPU context."""
+    have = torch.cuda.device_count()
+    if have < n:
+        sys.stderr.write(f"bench.py --gpus {n}: only {have} GPU(s) visible -- refusing to fall back to fewer\n")
+        return 2
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+        # rank 0 owns stdout (the JSON line); the other ranks' stdout goes to stderr
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    alive = list(procs)
+    while alive:
+        for p in list(alive):
+            try:
+                code = p.wait(timeout=0.5)
+            except subprocess.TimeoutExpired:
+                continue
+            alive.remove(p)
+            if code != 0:
+                rc = rc or code
+                for q in alive:               # one rank failed: the others would hang in a collective
+                    q.terminate()
+    return rc
+
+
+def main():
+    args = parse_args()
     if args.direct_conv:
         os.environ["FACEOFF_NO_WINOGRAD"] = "1"
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"bench.py: LOCAL_RANK={local_rank} but {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # FACEOFF_BENCH_FORCE_DDP=1 (diagnostic): take the multi-GPU code path -- RCCL process group, bucketed gradient
@@ -103,63 +163,95 @@ def main():
     from faceoff_amd.trainer import FaceOffTrainer
 
     B, T, H = args.clips, args.frames, args.size
-    eng = VQVAEEngine(make_state_dict(0, codebook_scale=0.3, gain=2.0), dev)
-    vqlpips = None
-    if args.perceptual:
-        from faceoff_amd.loss import VQLPIPS
-        from faceoff_amd.synth import make_vgg_lpips_state
-        vqlpips = VQLPIPS(make_vgg_lpips_state(7), dtype=args.lpips_dtype).to(dev)
-    trainer = FaceOffTrainer(eng, lr=3e-4, vqlpips=vqlpips, force_collectives=ddp and world == 1)
+    frames = B * T
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-    img = torch.rand((B * T, 6, H, H), device=dev, generator=gen) * 2 - 1       # U(-1,1): dataset.py:240-247
-    gt = torch.rand((B * T, 3, H, H), device=dev, generator=gen) * 2 - 1
+    img = torch.rand((frames, 6, H, H), device=dev, generator=gen) * 2 - 1       # U(-1,1): dataset.py:240-247
+    gt = torch.rand((frames, 3, H, H), device=dev, generator=gen) * 2 - 1
 
     def sync():
         if ddp:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    if args.serial_streams:
+    def max_over_ranks(x):
+        if not ddp:
+            return x
+        t = torch.tensor([x], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        return t.item()
+
+    def make_trainer(winograd=True, perceptual=False):
+        eng = VQVAEEngine(make_state_dict(0, codebook_scale=0.3, gain=2.0), dev)
+        if not winograd:
+            eng.winograd = False
+        vqlpips = None
+        if perceptual:
+            from faceoff_amd.loss import VQLPIPS
+            from faceoff_amd.synth import make_vgg_lpips_state
+            vqlpips = VQLPIPS(make_vgg_lpips_state(7), dtype=args.lpips_dtype).to(dev)
+        tr = FaceOffTrainer(eng, lr=3e-4, vqlpips=vqlpips, force_collectives=ddp and world == 1)
+        if args.serial_streams:
+            eng.set_stream_overlap(False)
+        return eng, tr
+
+    def timed(tr, steps, warmup):
+        """W untimed + K timed steps bracketed by barrier + synchronize on both sides; max over ranks.
+        Returns (seconds for the K steps, HIP-event ms per step on this rank, last losses)."""
+        for _ in range(warmup):
+            tr.step(img, gt, T=T)
+        sync()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()
+        for _ in range(steps):
+            losses = tr.step(img, gt, T=T)
+        ev1.record()                      # every side stream is joined into this one at the end of a step
+        sync()
+        dt = time.perf_counter() - t0
+        return max_over_ranks(dt), ev0.elapsed_time(ev1) / steps, losses
+
+    def per_kernel(eng, tr, steps):
+        """The same steps again with the side streams folded into the main one, so that every launch has the GPU to
+        itself (kernels sharing the chip stretch each other's event-to-event time); HIP events bracket each launch on
+        the stream it is launched on.  Returns (KernelProfiler summary, serial ms per step)."""
         eng.set_stream_overlap(False)
-    for _ in range(args.warmup):
-        trainer.step(img, gt, T=T)
-    sync()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    for _ in range(args.steps):
-        recon, latent, _ = trainer.step(img, gt, T=T)
-    ev1.record()                      # every side stream is joined into this one at the end of a step
-    sync()
-    dt = time.perf_counter() - t0
-    ms_events = ev0.elapsed_time(ev1) / args.steps
-    # Per-kernel durations: the same K steps again with the side streams folded into the main one, so that every
-    # launch has the GPU to itself (kernels sharing the chip stretch each other's event-to-event time; the step time
-    # above is the overlapped one).  HIP events bracket each launch on the stream it is launched on.
-    prof = None
-    ms_serial = None
-    if not args.no_kernel_events:
-        eng.set_stream_overlap(False)
-        trainer.step(img, gt, T=T)
+        tr.step(img, gt, T=T)
         prof = ops.KernelProfiler()
         ops.PROFILER = prof
         sync()
         t1 = time.perf_counter()
-        for _ in range(args.steps):
-            trainer.step(img, gt, T=T)
+        for _ in range(steps):
+            tr.step(img, gt, T=T)
         sync()
-        ms_serial = (time.perf_counter() - t1) / args.steps * 1e3
+        ms_serial = (time.perf_counter() - t1) / steps * 1e3
         ops.PROFILER = None
-    if ddp:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-        dt = tmax.item()
-    if rank != 0:
-        torch.distributed.destroy_process_group()
-        return
+        eng.set_stream_overlap(not args.serial_streams)
+        return prof.summary(), ms_serial
+
+    def dominant(summ, steps, ms_serial):
+        dom = max(summ, key=lambda k: summ[k]["total_ms"])
+        d = summ[dom]
+        peak = BF16_MFMA_PEAK_TFLOPS if dom.startswith("conv_bf16") else FP32_MFMA_PEAK_TFLOPS
+        return {"bound": "mfma", "kernel": dom, "achieved": round(d["tflops"], 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(d["tflops"] / peak, 4), "traffic": None,
+                "achieved_padded_taps_counted": round(d["tflops_nominal"], 2),
+                "launches_per_step": d["launches"] / steps, "avg_launch_ms": round(d["avg_ms"], 4),
+                "algorithmic_gflop_per_launch": round(d["flops_per_launch"] / 1e9, 3),
+                "share_of_step_time": round(d["total_ms"] / (ms_serial * steps), 4)}
+
+    # ------------------------------------------------------------------ the timed workload
+    eng, trainer = make_trainer(winograd=not args.direct_conv, perceptual=args.perceptual)
+    dt, ms_events, (recon, latent, _) = timed(trainer, args.steps, args.warmup)
+    summ = ms_serial = None
+    if not args.no_kernel_events:
+        summ, ms_serial = per_kernel(eng, trainer, args.steps)
+    winograd_on = eng.winograd
+    wino_max_tile = eng.winograd_max_tile
+    del trainer, eng
+    torch.cuda.empty_cache()
 
     ms = dt / args.steps * 1e3
-    fps = world * B * T * args.steps / dt
+    fps = world * frames * args.steps / dt
     out = {
         "metric": "train frames/sec (256x256, T=5, bs=32/GPU)", "value": round(fps, 2), "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
@@ -169,61 +261,81 @@ def main():
         "config": {"workload": (f"C2: VQ-VAE-2 + Conv3d latent, {H}x{H}, T={T}, {B} clips/GPU, recon+VQ loss, fwd+bwd+Adam"
                                 if not args.perceptual else
                                 f"C3: C2 (fp32) + LPIPS/VGG-16 perceptual loss in {args.lpips_dtype} (seeded VGG weights), {H}x{H}, T={T}, {B} clips/GPU"),
-                   "global_clips": B * world, "frames_per_step": B * T * world, "parallelism": f"dp{world}"},
+                   "global_clips": B * world, "frames_per_step": frames * world, "parallelism": f"dp{world}",
+                   "conv3d_algorithm": ("winograd (fwd, dgrad, wgrad), F(4x4,3x3) where a plane is whole GEMM tiles else F(2x2,3x3)"
+                                        if winograd_on else "direct")},
         "loss": {"recon": round(recon.item(), 6), "latent": round(latent.item(), 6)},
     }
-    # whole-step roofline: time the step's algorithmic FLOP would take at the dense MFMA peak of the type each part runs in
+    if args.perceptual:
+        out["dtype"] = "f32 (VQ-VAE) + %s (LPIPS)" % ("bf16" if args.lpips_dtype == "bf16" else "f32")
+    # Speed against an IDEAL direct-convolution implementation (SURVEY 8(d)'s FLOP count at the dense MFMA peak of the
+    # type each part runs in).  NOT a roofline fraction: Winograd executes 2.25-4x fewer multiplies on the Conv3d and
+    # 3x3 128->128 layers, so this ratio exceeds 1 when the step is faster than any direct convolution could be.
     ideal_s = FLOP_PER_FRAME / (FP32_MFMA_PEAK_TFLOPS * 1e12)
     if args.perceptual:
-        ideal_s += 120.3e9 / ((BF16_MFMA_PEAK_TFLOPS if args.lpips_dtype == "bf16" else FP32_MFMA_PEAK_TFLOPS) * 1e12)
-        out["dtype"] = "f32 (VQ-VAE) + %s (LPIPS)" % ("bf16" if args.lpips_dtype == "bf16" else "f32")
-    out["step_frac_of_mfma_roofline"] = round(ideal_s * fps / world, 4)      # SURVEY 8(d) FLOP count: padded taps included
-    # the same with only the FLOP the matrix pipe actually executes: (a) Conv3d taps that fall into clip padding are
-    # structural zeros, skipped by the kernels (2 of 15 (frame, depth tap) pairs at T=5; Conv3d is 63.7 % of the conv
-    # FLOP, fwd / dgrad / wgrad alike); (b) Conv3d forward, data gradient and filter gradient run as Winograd F(2x2,3x3):
-    # 16 multiplies per 2x2 outputs instead of 36.  With (b) the direct-convolution FLOP count is no longer a bound.
-    from faceoff_amd.ops import temporal_share
-    conv3d_flop = 3 * 2 * 6.795e9                                           # per frame: 6.795 GMAC fwd x 3 passes
-    executed = FLOP_PER_FRAME - conv3d_flop * (1.0 - temporal_share(T))
-    out["step_frac_direct_flop_without_padding_taps"] = round(executed * fps / world / (FP32_MFMA_PEAK_TFLOPS * 1e12), 4)
-    if eng.winograd:
-        # F(4x4,3x3) = 36 multiplies per 16 outputs instead of 144, F(2x2,3x3) = 16 per 4 instead of 36 (per-frame GMAC of
-        # the bottom / top Conv3d chains: SURVEY 8a, row a4)
-        from faceoff_amd.ops import wino_tile
-        frac = {4: 36.0 / 144.0, 2: 16.0 / 36.0, 0: 1.0}
-        f_b = frac[min(wino_tile(H // 4, H // 4, B * T), eng.winograd_max_tile)]
-        f_t = frac[min(wino_tile(H // 8, H // 8, B * T), eng.winograd_max_tile)]
-        executed -= 3 * 2 * temporal_share(T) * (5.436e9 * (1.0 - f_b) + 1.359e9 * (1.0 - f_t))
-    out["step_frac_executed_flop"] = round(executed * fps / world / (FP32_MFMA_PEAK_TFLOPS * 1e12), 4)
-    out["config"]["conv3d_algorithm"] = ("winograd (fwd, dgrad, wgrad), F(4x4,3x3) where a plane is whole GEMM tiles else F(2x2,3x3)"
-                                         if eng.winograd else "direct")
-    if prof is not None:
-        summ = prof.summary()
-        dom = max(summ, key=lambda k: summ[k]["total_ms"])
-        d = summ[dom]
-        peak = BF16_MFMA_PEAK_TFLOPS if dom.startswith("conv_bf16") else FP32_MFMA_PEAK_TFLOPS
-        out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(d["tflops"], 2), "peak": peak,
-                           "unit": "TFLOP/s", "frac": round(d["tflops"] / peak, 4), "traffic": None,
-                           "achieved_padded_taps_counted": round(d["tflops_nominal"], 2),
-                           "launches_per_step": d["launches"] / args.steps, "avg_launch_ms": round(d["avg_ms"], 4),
-                           "algorithmic_gflop_per_launch": round(d["flops_per_launch"] / 1e9, 3),
-                           "share_of_step_time": round(d["total_ms"] / (ms_serial * args.steps), 4),
-                           "measured": "HIP events per launch over a second K-step region with the side streams joined "
-                                       "(kernels run alone; ms_per_step_serial is that region's step time incl. event overhead)"}
-        if eng.winograd:
-            out["roofline"]["note"] = ("launches of this kernel are mostly Winograd-domain GEMMs (K = 3*128 or 128: short); "
-                                       "bench.py --direct-conv runs the same step on direct convolutions: 1.5x slower, "
-                                       "dominant kernel conv_igemm3 at 0.91 of the fp32 MFMA peak (profiles/r01_bench_direct_conv3d.json)")
+        ideal_s += LPIPS_FLOP_PER_FRAME / ((BF16_MFMA_PEAK_TFLOPS if args.lpips_dtype == "bf16" else FP32_MFMA_PEAK_TFLOPS) * 1e12)
+    out["speed_vs_ideal_direct_conv"] = round(ideal_s * fps / world, 4)
+    if summ is not None:
+        out["roofline"] = dominant(summ, args.steps, ms_serial)
+        out["roofline"]["measured"] = ("HIP events per launch over a second K-step region with the side streams joined "
+                                       "(kernels run alone; ms_per_step_serial is that region's step time incl. event overhead)")
         out["ms_per_step_serial"] = round(ms_serial, 3)
         out["kernels"] = {k: {"launches_per_step": v["launches"] / args.steps, "avg_ms": round(v["avg_ms"], 4),
-                              "tflops": round(v["tflops"], 2), "tflops_padded_taps_counted": round(v["tflops_nominal"], 2), "ms_per_step": round(v["total_ms"] / args.steps, 3)}
+                              "tflops": round(v["tflops"], 2), "tflops_padded_taps_counted": round(v["tflops_nominal"], 2),
+                              "ms_per_step": round(v["total_ms"] / args.steps, 3)}
                           for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["total_ms"])}
+        # whole-step matrix-pipe fraction from what the launches really execute: sum of every profiled launch's FLOP
+        # (Winograd-domain GEMMs counted as the GEMMs they are, clip-padding taps excluded) + the VQ distance GEMM
+        fp32_flop = sum(v["flops_per_launch"] * v["launches"] for k, v in summ.items() if not k.startswith("conv_bf16")) / args.steps
+        fp32_flop += VQ_FLOP_PER_FRAME * frames
+        out["executed_matrix_tflop_per_step"] = round(fp32_flop / 1e12, 4)
+        if not args.perceptual:
+            out["step_frac_executed_flop"] = round(fp32_flop / (ms * 1e-3) / (FP32_MFMA_PEAK_TFLOPS * 1e12), 4)
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")       # written by profiles/collect.sh from rocprofv3 --pmc passes
         if os.path.exists(pmc):
             try:
-                out["roofline"]["traffic"] = json.load(open(pmc)).get(dom)
+                tr_json = json.load(open(pmc))
+                out["roofline"]["traffic"] = tr_json.get(out["roofline"]["kernel"])
+                out["roofline"]["traffic_source"] = ("HBM bytes per launch from the committed rocprofv3 --pmc passes "
+                                                     f"({tr_json.get('_source', 'profiles/pmc_traffic.json')}), not re-measured in this run")
             except Exception:
                 pass
+
+    # ------------------------------------------------------------------ the same step on direct convolutions
+    if winograd_on and not args.no_direct_leg and not args.no_kernel_events and not args.perceptual:
+        eng_d, tr_d = make_trainer(winograd=False)
+        k_d = max(2, min(args.steps, 5))
+        dt_d, _, _ = timed(tr_d, k_d, 2)
+        summ_d, ms_serial_d = per_kernel(eng_d, tr_d, k_d)
+        dd = dominant(summ_d, k_d, ms_serial_d)
+        dd.pop("traffic")
+        dd.update(ms_per_step=round(dt_d / k_d * 1e3, 3), steps=k_d,
+                  frames_per_s=round(world * frames * k_d / dt_d, 2),
+                  step_frac_of_direct_conv_roofline=round(FLOP_PER_FRAME / (FP32_MFMA_PEAK_TFLOPS * 1e12) * frames * k_d / dt_d, 4),
+                  note="Conv3d and 3x3 128->128 layers on conv_igemm3 / conv_igemm instead of Winograd, same process")
+        out["roofline"]["direct_conv"] = dd
+        del eng_d, tr_d
+        torch.cuda.empty_cache()
+
+    # ------------------------------------------------------------------ BASELINE config 3: + LPIPS in bf16
+    if not args.no_c3 and not args.perceptual and not args.direct_conv:
+        eng_c, tr_c = make_trainer(winograd=True, perceptual=True)
+        k_c = max(2, min(args.steps, 5))
+        dt_c, _, (r_c, l_c, p_c) = timed(tr_c, k_c, 2)
+        fps_c = world * frames * k_c / dt_c
+        ideal_c = FLOP_PER_FRAME / (FP32_MFMA_PEAK_TFLOPS * 1e12) + LPIPS_FLOP_PER_FRAME / (
+            (BF16_MFMA_PEAK_TFLOPS if args.lpips_dtype == "bf16" else FP32_MFMA_PEAK_TFLOPS) * 1e12)
+        out["c3"] = {"workload": f"C3: C2 (fp32 VQ-VAE) + LPIPS/VGG-16 perceptual loss in {args.lpips_dtype} (seeded VGG weights)",
+                     "value": round(fps_c, 2), "unit": "frames/s", "ms_per_step": round(dt_c / k_c * 1e3, 3), "steps": k_c, "warmup": 2,
+                     "dtype": "f32 (VQ-VAE) + %s (LPIPS)" % args.lpips_dtype,
+                     "speed_vs_ideal_direct_conv": round(ideal_c * fps_c / world, 4),
+                     "loss": {"recon": round(r_c.item(), 6), "latent": round(l_c.item(), 6), "perceptual": round(p_c.item(), 6)}}
+        del eng_c, tr_c
+        torch.cuda.empty_cache()
+
+    if rank != 0:
+        torch.distributed.destroy_process_group()
+        return
     if world == 1 and not args.no_cpu_baseline and not args.perceptual:
         out["cpu_baseline"] = cpu_baseline(T, H, H)
     if ddp:

@@ -37,10 +37,12 @@ class GradBucketReducer:
             self.buckets.append((0, cur_hi, layer_order[0]))
             self.members.append(cur)
         # a bucket fires when ALL its layers have reported (the engine overlaps independent chains, so layers
-        # do not finish strictly in arena order); every filter gradient is enqueued on one stream, so an event
-        # recorded when the last member reports covers the whole slice
+        # do not finish strictly in arena order).  Members may report from DIFFERENT streams (filter-gradient side
+        # stream, the bottom Conv3d chain's stream, or the main stream when an overlap switch is off), so each member
+        # records its own event on the stream that is current when it reports, and the all-reduce waits on all of them.
         self._bucket_of = {n: i for i, ms in enumerate(self.members) for n in ms}
         self._pending = [set(ms) for ms in self.members]
+        self._events = [[] for _ in self.members]
         self._works = []
         self.cuda = flat_grads.is_cuda
         self.side = torch.cuda.Stream(device=flat_grads.device) if self.cuda and self.active else None
@@ -52,15 +54,19 @@ class GradBucketReducer:
         if i is None or not self.active:
             return
         self._pending[i].discard(name)
+        if self.cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self._events[i].append(ev)
         if self._pending[i]:
             return
         lo, hi, _ = self.buckets[i]
         self.launched.append(i)
         view = self.flat[lo:hi]
         if self.cuda:
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream())
-            self.side.wait_event(ev)
+            for ev in self._events[i]:
+                self.side.wait_event(ev)
+            self._events[i] = []
             with torch.cuda.stream(self.side):
                 self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:
@@ -81,6 +87,7 @@ class GradBucketReducer:
         self._works = []
         self.launched = []
         self._pending = [set(ms) for ms in self.members]
+        self._events = [[] for _ in self.members]
 
 
 def fused_vq_allreduce(group=None):

@@ -66,13 +66,18 @@ def vqvae_param_specs(in_channel=6, channel=128, n_res_block=2, n_res_channel=32
     return s
 
 
-def make_state_dict(seed=0, codebook_scale=1.0, in_channel=6, gain=1.0, **kw):
-    """Reference-keyed state dict of float32 numpy arrays (70 params + 6 buffers)."""
+def make_state_dict(seed=0, codebook_scale=1.0, in_channel=6, gain=1.0, codebook_center=None, **kw):
+    """Reference-keyed state dict of float32 numpy arrays (70 params + 6 buffers).
+    codebook_center: optional {"quantize_t": vec[64], "quantize_b": vec[64]} added to every code of that level (an
+    untrained encoder's latents sit far from the origin; a codebook centred on them uses hundreds of codes instead of
+    a few dozen -- the golden fixtures store the centres they were generated with)."""
     rng = np.random.default_rng(seed)
     sd = OrderedDict()
     for name, kind, shape in vqvae_param_specs(in_channel=in_channel, **kw):
         if kind == "vq":
             e = (rng.standard_normal(shape) * codebook_scale).astype(np.float32)
+            if codebook_center is not None and codebook_center.get(name) is not None:
+                e = (e + np.asarray(codebook_center[name], np.float32).reshape(-1, 1)).astype(np.float32)
             sd[name + ".embed"] = e
             sd[name + ".cluster_size"] = np.zeros(shape[1], np.float32)
             sd[name + ".embed_avg"] = e.copy()
@@ -84,6 +89,16 @@ def make_state_dict(seed=0, codebook_scale=1.0, in_channel=6, gain=1.0, **kw):
         nb = shape[1] if kind == "convT" else shape[0]
         sd[name + ".bias"] = rng.uniform(-bound, bound, (nb,)).astype(np.float32)
     return sd
+
+
+def golden_state(g):
+    """The state dict a golden fixture (tests/golden/*.npz) was generated with: seeds, scales and -- where the
+    fixture holds them -- the codebook centres."""
+    center = None
+    if "codebook_center_t" in g.files:
+        center = {"quantize_t": g["codebook_center_t"], "quantize_b": g["codebook_center_b"]}
+    return make_state_dict(int(g["seed_w"]), codebook_scale=float(g["codebook_scale"]), gain=float(g["gain"]),
+                           codebook_center=center)
 
 
 def make_batch(seed, B, T, H, W):

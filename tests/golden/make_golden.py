@@ -106,8 +106,28 @@ def ref_forward_clips(m, img):
     return dec, diff, id_t, id_b, eb, et
 
 
-def gen_e2e(name, B, T, H, W, seed_w, seed_x, literal=False, with_adam=True):
-    sd = make_state_dict(seed_w, codebook_scale=CODEBOOK_SCALE, gain=GAIN)
+def latent_centers(seed_w, img, scale):
+    """Mean pre-quantize latent of each level under the reference model (top first: the bottom latents depend on the
+    quantised top ones).  A codebook centred there uses > 100 codes per level where the zero-centred one
+    uses a few dozen; the centres are stored in the fixture as inputs."""
+    center = {}
+    for lvl in ("t", "b"):
+        sd = make_state_dict(seed_w, codebook_scale=scale, gain=GAIN, codebook_center=center or None)
+        m = load_ref_model(sd, train=False)
+        lat = {}
+        getattr(m, "quantize_" + lvl).register_forward_pre_hook(lambda mod, a: lat.__setitem__("x", a[0].detach()))
+        with torch.no_grad():
+            ref_forward_clips(m, img)
+        center["quantize_" + lvl] = lat["x"].reshape(-1, 64).mean(0).numpy().astype(np.float32)
+    return center
+
+
+def gen_e2e(name, B, T, H, W, seed_w, seed_x, literal=False, with_adam=True, centered_scale=None):
+    scale, center = CODEBOOK_SCALE, None
+    if centered_scale is not None:
+        scale = centered_scale
+        center = latent_centers(seed_w, torch.from_numpy(make_batch(seed_x, B, T, H, W)[0]), scale)
+    sd = make_state_dict(seed_w, codebook_scale=scale, gain=GAIN, codebook_center=center)
     m = load_ref_model(sd, train=True)
     img_np, gt_np = make_batch(seed_x, B, T, H, W)
     img, gt = torch.from_numpy(img_np), torch.from_numpy(gt_np).reshape(B * T, 3, H, W)
@@ -131,10 +151,12 @@ def gen_e2e(name, B, T, H, W, seed_w, seed_x, literal=False, with_adam=True):
     latent = diff.mean()
     loss = recon + 1 * latent
     loss.backward()
-    res = dict(B=B, T=T, H=H, W=W, seed_w=seed_w, seed_x=seed_x, codebook_scale=CODEBOOK_SCALE, gain=GAIN,
-               dec=dec.detach().numpy() if dec.numel() < 400000 else sub(dec),
+    res = dict(B=B, T=T, H=H, W=W, seed_w=seed_w, seed_x=seed_x, codebook_scale=scale, gain=GAIN,
+               dec=dec.detach().numpy() if dec.numel() < 200000 else sub(dec),
                dec_stats=stats(dec), diff=diff.detach().numpy(), recon=recon.item(), latent=latent.item(),
                loss=loss.item())
+    if center is not None:
+        res.update(codebook_center_t=center["quantize_t"], codebook_center_b=center["quantize_b"])
     if True:
         res.update(id_t=id_t.numpy().astype(np.int16), id_b=id_b.numpy().astype(np.int16),
                    margin_t=margins(*lat["t"]), margin_b=margins(*lat["b"]),
@@ -218,11 +240,13 @@ def gen_lpips():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["quantize", "c1", "b1", "lpips", "c2smoke"]
+    which = sys.argv[1:] or ["quantize", "c1", "c1w", "b1", "lpips", "c2smoke"]
     if "quantize" in which:
         gen_quantize()
     if "c1" in which:      # BASELINE config 1: 64x64, T=2, bs=2
-        gen_e2e("c1_e2e", 2, 2, 64, 64, seed_w=0, seed_x=1234)
+        gen_e2e("c1_e2e", 2, 2, 64, 64, seed_w=0, seed_x=1234, centered_scale=0.1)
+    if "c1w" in which:     # the same at 96x96 (576 / 2304 latent vectors): > 100 codes in use on BOTH levels
+        gen_e2e("c1w_e2e", 2, 2, 96, 96, seed_w=4, seed_x=4321, centered_scale=0.1, with_adam=False)
     if "b1" in which:      # literal VQVAE.forward, one clip of 4 frames
         gen_e2e("b1_literal", 1, 4, 64, 64, seed_w=0, seed_x=77, literal=True)
     if "c2smoke" in which:  # C2 shape, one clip (256x256, T=5): checksums only

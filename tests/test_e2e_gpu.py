@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from faceoff_amd.synth import make_state_dict, make_batch
+from faceoff_amd.synth import make_state_dict, make_batch, golden_state
 
 pytestmark = pytest.mark.gpu
 SUB = 61
@@ -31,7 +31,7 @@ def _rel(got, want):
 def _engine_step(g, T=None):
     from faceoff_amd.engine import VQVAEEngine
     B, T_, H, W = (int(g[k]) for k in "BTHW")
-    sd = make_state_dict(int(g["seed_w"]), codebook_scale=float(g["codebook_scale"]), gain=float(g["gain"]))
+    sd = golden_state(g)
     eng = VQVAEEngine(sd, "cuda:0")
     img, gt = make_batch(int(g["seed_x"]), B, T_, H, W)
     img = torch.from_numpy(img).reshape(B * T_, 6, H, W).cuda()
@@ -41,11 +41,12 @@ def _engine_step(g, T=None):
     return eng, recon, diff, S, img, gt
 
 
-def _check_against_golden(g, eng, recon, diff, S, literal=False, grad_rtol=1e-3):
+def _check_against_golden(g, eng, recon, diff, S, literal=False, what=""):
+    """Bounds: 1e-3 of each tensor's scale (BASELINE.json north_star) whenever every code index equals the reference's.
+    An index may differ only where the REFERENCE's own top-2 distance margin is below 1e-4 (an fp32 near-tie: any
+    summation order may flip it); a flipped code changes `dec` locally by O(1), so only then the bounds widen."""
     from faceoff_amd import ops
     dec = ops.nhwc_to_nchw(S["dec"], 6)
-    # VQ indices: bit-exact, except where the reference's own top-2 margin is below the upstream
-    # fp32 rounding; such a flip changes `dec` locally by O(1).
     flips = 0
     for lvl in "tb":
         got = S["id_" + lvl].cpu().numpy().astype(np.int16).reshape(-1)
@@ -53,42 +54,46 @@ def _check_against_golden(g, eng, recon, diff, S, literal=False, grad_rtol=1e-3)
         assert np.all(g["margin_" + lvl][bad] < 1e-4), f"id_{lvl}: {int(bad.sum())} mismatches outside the near-tie gate"
         assert bad.mean() < 2e-3
         flips += int(bad.sum())
+    tol = 1e-3 if flips == 0 else 2e-2
     got_dec = dec.cpu().numpy() if g["dec"].ndim == 4 else _sub(dec)
+    obs = {"dec": _rel(got_dec, g["dec"])}
     if flips == 0:
-        assert _rel(got_dec, g["dec"]) < 1e-3
+        assert obs["dec"] < 1e-3
     else:   # a flipped top-level code reaches a 40x40-pixel patch of one 64x64 frame through dec_t + dec
         frac_bad = (np.abs(got_dec - g["dec"]) > 1e-3 * np.abs(g["dec"]).max()).mean()
         assert frac_bad < 0.12 * flips, (flips, frac_bad)
-        grad_rtol = max(grad_rtol, 2e-2)
     np.testing.assert_allclose(recon.item(), float(g["recon"]), rtol=1e-3)
     np.testing.assert_allclose(diff.item(), float(g["latent"]), rtol=1e-3)
     names = [str(n) for n in g["param_names"]]
     gs = np.stack([_stats(eng.grads[n]) for n in names])
     l2, want_l2 = np.sqrt(gs[:, 1]), np.sqrt(g["grad_stats"][:, 1])
-    bad = [(n, a, b) for n, a, b in zip(names, l2, want_l2) if abs(a - b) > grad_rtol * abs(b)]
+    obs["grad_l2"] = float(np.max(np.abs(l2 - want_l2) / want_l2))
+    bad = [(n, a, b) for n, a, b in zip(names, l2, want_l2) if abs(a - b) > tol * abs(b)]
     assert not bad, f"gradient L2 norms off: {bad}"
-    sub = np.concatenate([_sub(eng.grads[n]) for n in names])
-    # per-tensor scale: compare each tensor's subsample against its own max
-    off = 0
-    for n in names:
-        k = len(_sub(eng.grads[n]))
-        want = g["grad_sub"][off:off + k]
-        got = sub[off:off + k]
-        scale = np.sqrt(g["grad_stats"][names.index(n), 1] / eng.grads[n].numel()) + 1e-30   # rms of the tensor
-        assert np.abs(got - want).max() <= 5 * grad_rtol * max(scale, np.abs(want).max()), n
-        off += k
+    # every tensor's strided subsample against the tensor's own scale
+    off, worst = 0, (0.0, "")
+    for i, n in enumerate(names):
+        got = _sub(eng.grads[n])
+        want = g["grad_sub"][off:off + len(got)]
+        off += len(got)
+        scale = max(np.sqrt(g["grad_stats"][i, 1] / eng.grads[n].numel()), np.abs(want).max()) + 1e-30
+        err = np.abs(got - want).max() / scale
+        worst = max(worst, (float(err), n))
+        assert err <= tol, (n, err)
+    obs["grad_sub"] = worst
     for n in names:
         if "grad_full." + n in g.files:
             assert _rel(eng.grads[n].cpu().numpy(), g["grad_full." + n]) < (1e-3 if flips == 0 else 0.1), n
     for k, b in eng.buffers.items():
-        np.testing.assert_allclose(_stats(b)[1], g["buf_stats." + k][1], rtol=2e-3)
+        np.testing.assert_allclose(_stats(b)[1], g["buf_stats." + k][1], rtol=1e-3 if flips == 0 else 2e-3)
+    print(f"[parity {what}] index flips {flips}; observed max rel err: {obs}")
 
 
 def test_c1_e2e_vs_reference_golden(golden_dir):
     """BASELINE config 1 (64x64, T=2, bs=2): forward, losses, indices, all 70 gradients, EMA buffers."""
     g = np.load(os.path.join(golden_dir, "c1_e2e.npz"))
     eng, recon, diff, S, img, gt = _engine_step(g)
-    _check_against_golden(g, eng, recon, diff, S)
+    _check_against_golden(g, eng, recon, diff, S, what="c1")
     # Adam step (train_faceoff_perceptual.py:107) then an eval forward pins the whole state update
     from faceoff_amd import ops
     m, v = torch.zeros_like(eng.flat_params), torch.zeros_like(eng.flat_params)
@@ -102,18 +107,26 @@ def test_c1_e2e_vs_reference_golden(golden_dir):
     assert np.abs(_sub(dec2) - g["dec2_sub"]).max() < 5e-2 * np.abs(g["dec2_sub"]).max()
 
 
+def test_c1w_e2e_many_codes_vs_reference_golden(golden_dir):
+    """96x96, codebooks centred on the latents: > 100 distinct codes in use on both levels."""
+    g = np.load(os.path.join(golden_dir, "c1w_e2e.npz"))
+    assert len(np.unique(g["id_t"])) > 100 and len(np.unique(g["id_b"])) > 100
+    eng, recon, diff, S, img, gt = _engine_step(g)
+    _check_against_golden(g, eng, recon, diff, S, what="c1w")
+
+
 def test_b1_literal_reference_forward(golden_dir):
     """One clip of 4 frames (T = N): equals the reference's VQVAE.forward itself."""
     g = np.load(os.path.join(golden_dir, "b1_literal.npz"))
     eng, recon, diff, S, img, gt = _engine_step(g)
-    _check_against_golden(g, eng, recon, diff, S, literal=True)
+    _check_against_golden(g, eng, recon, diff, S, literal=True, what="b1 literal")
 
 
 def test_c2_oneclip_vs_reference_golden(golden_dir):
     """C2 shape (256x256, T=5), one clip: losses, indices (margin-gated), gradient norms."""
     g = np.load(os.path.join(golden_dir, "c2_oneclip.npz"))
     eng, recon, diff, S, img, gt = _engine_step(g)
-    _check_against_golden(g, eng, recon, diff, S, grad_rtol=3e-3)
+    _check_against_golden(g, eng, recon, diff, S, what="c2 one clip")
 
 
 def test_e2e_vs_oracle_ragged():
@@ -131,18 +144,26 @@ def test_e2e_vs_oracle_ragged():
     y = torch.from_numpy(gt).reshape(B * T, 3, H, W).cuda()
     recon, diff, S = eng.loss_and_backward(x, y, T=T)
     dec = ops.nhwc_to_nchw(S["dec"], 6).cpu()
-    assert _rel(dec.numpy(), r["fw"]["dec"].detach().numpy()) < 1e-3
     np.testing.assert_allclose(recon.item(), r["recon"].item(), rtol=1e-3)
     np.testing.assert_allclose(diff.item(), r["latent"].item(), rtol=1e-3)
-    for lvl in "tb":
-        same = (S["id_" + lvl].cpu() == r["fw"]["id_" + lvl]).float().mean().item()
-        assert same > 0.995, (lvl, same)
+    flips = 0
+    for lvl in "tb":                                          # indices: equal, or the oracle's own margin is a near-tie
+        bad = (S["id_" + lvl].cpu() != r["fw"]["id_" + lvl]).reshape(-1)
+        margin = O.vq_margin(r["fw"][f"q{lvl}_in"].detach(), torch.from_numpy(sd[f"quantize_{lvl}.embed"]))
+        assert bool((margin[bad] < 1e-4).all()) and bad.float().mean().item() < 2e-3, (lvl, int(bad.sum()))
+        flips += int(bad.sum())
+    if flips == 0:
+        assert _rel(dec.numpy(), r["fw"]["dec"].detach().numpy()) < 1e-3
+    tol, worst = (1e-3 if flips == 0 else 2e-2), (0.0, "")
     for n, gref in r["grads"].items():
         got = eng.grads[n].cpu().numpy()
         rms = gref.pow(2).mean().sqrt().item()
-        assert np.abs(got - gref.numpy()).max() <= 5e-3 * max(rms, gref.abs().max().item()), n
+        err = np.abs(got - gref.numpy()).max() / max(rms, gref.abs().max().item())
+        worst = max(worst, (float(err), n))
+        assert err <= tol, (n, err)
     for k in eng.buffers:
-        assert _rel(eng.buffers[k].cpu().numpy(), p[k].numpy()) < 2e-3, k
+        assert _rel(eng.buffers[k].cpu().numpy(), p[k].numpy()) < (1e-3 if flips == 0 else 2e-2), k
+    print(f"[parity ragged] index flips {flips}; worst gradient rel err {worst}")
 
 
 def test_perceptual_step_vs_oracle():
@@ -167,7 +188,7 @@ def test_perceptual_step_vs_oracle():
     np.testing.assert_allclose(perceptual.item(), r["perceptual"].item(), rtol=1e-3)
     for n, gref in r["grads"].items():
         got = eng.grads[n].cpu().numpy()
-        assert np.abs(got - gref.numpy()).max() <= 2e-3 * gref.abs().max().item(), n
+        assert np.abs(got - gref.numpy()).max() <= 1e-3 * gref.abs().max().item(), n
 
 
 def test_step_from_loader_batch_equals_step_on_concatenated_input():

@@ -91,3 +91,114 @@ def test_c2_training_step_is_finite_reproducible_and_updates_everything():
     assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
     e0, e1 = runs[0][2], runs[1][2]
     assert (e0 - e1).abs().max().item() <= 1e-5 * e0.abs().max().item()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The path bench.py times by default runs the Conv3d layers and the two 3x3 128->128 Conv2d layers as Winograd
+# F(4x4,3x3): 36 banked planes x 160 frames through fo_conv_igemm_banked / fo_conv_wgrad_banked.  Value checks of that
+# path AT THE TIMED SIZE (N = 160, T = 5) against the direct kernels on the same tensors (the direct kernels are oracle-
+# and adjointness-checked above and in test_ops_gpu.py).  Bound: 2e-4 of the tensor's scale (F(4x4) fp32 error).
+WINO_TOL = 2e-4
+
+
+def _relmax(a, b):
+    return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+
+@pytest.mark.parametrize("name,H,kd", [("conv3d_b @64^2", 64, 3), ("conv3d_t @32^2", 32, 3), ("conv2d 3x3 128->128 @64^2", 64, 1)])
+def test_winograd_ops_equal_direct_kernels_at_c2_size(name, H, kd):
+    from faceoff_amd import ops
+    from faceoff_amd.ops import FO_OUT_RELU
+    ci = co = 128
+    Tt = T if kd == 3 else 1
+    k, pad = (kd, 3, 3), (kd // 2, 1, 1)
+    m = ops.wino_tile(H, H, N)
+    assert m == 4, "C2 latents run F(4x4,3x3)"
+    x = _rand((N, H, H, ci), 11)
+    g = _rand((N, H, H, co), 12)
+    msk = _rand((N, H, H, ci), 13)                      # a saved activation: its sign is the ReLU-backward mask
+    res = _rand((N, H, H, ci), 14)                      # gradient fan-in operand
+    w = _rand((co, ci, 3, 3, 3) if kd == 3 else (co, ci, 3, 3), 15, scale=0.05)
+    b = _rand((co,), 16)
+    obs = {}
+    # forward (+ bias + ReLU), keeping the transformed input for the filter gradient like the training forward does
+    y_d, y_w = torch.empty((N, H, H, co), device="cuda"), torch.empty((N, H, H, co), device="cuda")
+    ops.conv_igemm(x, ops.pack_conv(w), b, y_d, T=Tt, k=k, pad=pad, cin=ci, cout=co, flags=FO_OUT_RELU)
+    keep = ops.wino_wgrad_ok(H, H, N, Tt, m, kd)
+    assert keep, "the timed path keeps V for the filter gradient at this size"
+    V = ops.conv3d_winograd(x, ops.wino_filter(w, m=m), b, y_w, T=Tt, cin=ci, cout=co, flags=FO_OUT_RELU, keep_v=True, m=m, kd=kd)
+    obs["fwd"] = _relmax(y_w, y_d)
+    # data gradient with ReLU mask and fan-in add
+    gx_d, gx_w = torch.empty_like(x), torch.empty_like(x)
+    ops.conv_igemm(g, ops.pack_conv_dgrad(w.reshape(co, ci, -1)), None, gx_d, T=Tt, k=k, pad=pad, cin=co, cout=ci, mask=msk, add=res)
+    ops.conv3d_winograd(g, ops.wino_filter(w, dgrad=True, m=m), None, gx_w, T=Tt, cin=co, cout=ci, mask=msk, add=res, m=m, kd=kd)
+    obs["dgrad"] = _relmax(gx_w, gx_d)
+    # filter + bias gradient, from the kept V (the timed path) and from a fresh input transform
+    dw_d, db_d = torch.empty_like(w), torch.empty(co, device="cuda")
+    ops.conv_wgrad(g, x, dw_d, db_d, T=Tt, k=k, pad=pad, a_real=co, b_real=ci)
+    for tag, v in (("wgrad(kept V)", V), ("wgrad(fresh V)", None)):
+        dw_w, db_w = torch.empty_like(w), torch.empty(co, device="cuda")
+        ops.conv3d_wgrad_winograd(g, x, dw_w, db_w, T=Tt, a_real=co, b_real=ci, V=v, m=m, kd=kd)
+        obs[tag] = _relmax(dw_w, dw_d)
+        assert _relmax(db_w, db_d) <= 1e-5
+    # the adjoint triple THROUGH the Winograd ops (no bias / mask / add): <conv(x), g> = <x, dgrad(g)> = <W, wgrad(x, g)>
+    y0, gx0 = torch.empty_like(y_w), torch.empty_like(x)
+    ops.conv3d_winograd(x, ops.wino_filter(w, m=m), None, y0, T=Tt, cin=ci, cout=co, m=m, kd=kd)
+    ops.conv3d_winograd(g, ops.wino_filter(w, dgrad=True, m=m), None, gx0, T=Tt, cin=co, cout=ci, m=m, kd=kd)
+    _check((_dot(y0, g), _dot(x, gx0), _dot(w, dw_w)), name + " (winograd)")
+    print(f"[winograd vs direct, N={N} {name}] max rel err {obs}")
+    for kname, e in obs.items():
+        assert e <= WINO_TOL, (kname, e)
+
+
+def test_c2_step_winograd_engine_equals_direct_engine():
+    """The whole timed C2 step (160 frames of 256x256, T=5) on the default Winograd engine against the same engine on
+    the direct kernels (FACEOFF_NO_WINOGRAD): code indices equal (a mismatch only where the top-2 margin, in fp64, is a
+    near-tie below 1e-4), losses to 1e-5, decoder output to 1e-4, every one of the 70 gradient tensors to 1e-3 of its
+    scale (the north-star parity bound)."""
+    import os
+    from faceoff_amd.engine import VQVAEEngine
+    from faceoff_amd.synth import make_state_dict
+    img, gt = _rand((N, 6, 256, 256), 7), _rand((N, 3, 256, 256), 8)
+    res = []
+    for direct in (False, True):
+        if direct:
+            os.environ["FACEOFF_NO_WINOGRAD"] = "1"
+        try:
+            eng = VQVAEEngine(make_state_dict(0, codebook_scale=0.3, gain=2.0), "cuda:0")
+        finally:
+            os.environ.pop("FACEOFF_NO_WINOGRAD", None)
+        assert eng.winograd == (not direct)
+        recon, diff, S = eng.loss_and_backward(img, gt, T=T)
+        torch.cuda.synchronize()
+        res.append(dict(dec=S["dec"].clone(), id_t=S["id_t"].clone(), id_b=S["id_b"].clone(), qt_in=S["qt_in"].clone(),
+                        qb_in=S["qb_in"].clone(), recon=recon.item(), diff=diff.item(), grads=eng.flat_grads.clone(),
+                        offsets=dict(eng.offsets), embed={l: eng.buffers[f"quantize_{l}.embed"].clone() for l in "tb"}))
+        del eng, S
+        torch.cuda.empty_cache()
+    w, d = res
+    sd = make_state_dict(0, codebook_scale=0.3, gain=2.0)
+    flips = 0
+    for lvl in "tb":
+        bad = (w["id_" + lvl] != d["id_" + lvl]).reshape(-1)
+        nbad = int(bad.sum())
+        if nbad:
+            x = d[f"q{lvl}_in"].reshape(-1, 64)[bad].double()
+            e = torch.from_numpy(sd[f"quantize_{lvl}.embed"]).cuda().double()
+            dist = x.pow(2).sum(1, keepdim=True) - 2 * x @ e + e.pow(2).sum(0, keepdim=True)
+            top2 = torch.topk(-dist, 2, dim=1).values
+            assert ((top2[:, 0] - top2[:, 1]) < 1e-4).all(), f"id_{lvl}: mismatch outside the near-tie gate"
+            assert nbad <= 1e-5 * bad.numel() + 2
+        flips += nbad
+    np.testing.assert_allclose([w["recon"], w["diff"]], [d["recon"], d["diff"]], rtol=1e-5)
+    dec_err = _relmax(w["dec"], d["dec"])
+    worst = (0.0, "")
+    tol = 1e-3 if flips == 0 else 2e-2
+    for key, (off, n) in d["offsets"].items():
+        a, b = w["grads"][off:off + n], d["grads"][off:off + n]
+        err = ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+        worst = max(worst, (err, key))
+        assert err <= tol, (key, err)
+    print(f"[C2 step winograd vs direct engine, N={N}] index flips {flips}; dec rel err {dec_err:.2e}; worst gradient {worst}")
+    if flips == 0:
+        assert dec_err <= 1e-4

@@ -77,6 +77,17 @@ def test_cycle_scheduler_restatement():
         o = Opt()
         r = mod.CycleScheduler(o, lr, n_iter=n_iter, momentum=None, warmup_proportion=0.05)
         np.testing.assert_allclose([r.step()[0] for _ in range(n_iter)], got, rtol=1e-12)
+        # default arguments (momentum cycling through betas[0] / momentum, 30 % warm-up), over two and a half cycles
+        for groups in ([{"lr": 0.0, "betas": (0.9, 0.999)}], [{"lr": 0.0, "momentum": 0.9}]):
+            class A:
+                param_groups = [dict(g) for g in groups]
+
+            class B:
+                param_groups = [dict(g) for g in groups]
+            mine, ref = CycleScheduler(A(), 1e-3, n_iter=37), mod.CycleScheduler(B(), 1e-3, n_iter=37)
+            for _ in range(93):
+                assert mine.step() == ref.step()
+                assert A.param_groups == B.param_groups
 
 
 def test_bucket_plan_covers_arena_in_backward_order():
@@ -139,3 +150,19 @@ def test_product_never_imports_the_oracle():
     bench = open(os.path.join(root, "bench.py")).read()
     uses = [m.start() for m in pat.finditer(bench)]
     assert uses and all("def cpu_baseline" in bench[:u] and "def main" not in bench[bench.index("def cpu_baseline"):u] for u in uses)
+
+
+def test_bench_refuses_to_run_fewer_gpus_than_asked():
+    """`python bench.py --gpus N` starts its own ranks; with fewer than N devices it must fail, not measure one GPU
+    and report n_gpus 1 (this container has no GPU at all).  A WORLD_SIZE that contradicts --gpus is an error too."""
+    import subprocess
+    import sys
+    bench = os.path.join(ROOT, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    if torch.cuda.device_count() < 2:
+        out = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True,
+                             text=True, timeout=300, env=env)
+        assert out.returncode != 0 and out.stdout.strip() == "" and "refusing" in out.stderr
+    out = subprocess.run([sys.executable, bench, "--gpus", "2"], capture_output=True, text=True, timeout=300,
+                         env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
+    assert out.returncode != 0 and out.stdout.strip() == "" and "WORLD_SIZE" in out.stderr

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from faceoff_amd.synth import make_state_dict, make_batch
+from faceoff_amd.synth import make_state_dict, make_batch, golden_state
 
 pytestmark = pytest.mark.gpu
 SUB = 61
@@ -22,7 +22,7 @@ def test_reference_style_training_step(golden_dir):
     g = np.load(os.path.join(golden_dir, "c1_e2e.npz"))
     B, T, H, W = (int(g[k]) for k in "BTHW")
     model = VQVAE(in_channel=3 * 2).to("cuda")                       # utils.py:52
-    sd = make_state_dict(int(g["seed_w"]), codebook_scale=float(g["codebook_scale"]), gain=float(g["gain"]))
+    sd = golden_state(g)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     model.train()
     img, gt = make_batch(int(g["seed_x"]), B, T, H, W)

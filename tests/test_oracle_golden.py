@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from faceoff_amd.synth import make_state_dict, make_batch, make_vgg_lpips_state
+from faceoff_amd.synth import make_state_dict, make_batch, golden_state, make_vgg_lpips_state
 from oracle import faceoff_oracle as O
 
 torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
@@ -52,7 +52,7 @@ def test_quantize_kat(golden_dir, mode):
 
 def _run_e2e(g, adam=True):
     B, T, H, W = (int(g[k]) for k in "BTHW")
-    sd = make_state_dict(int(g["seed_w"]), codebook_scale=float(g["codebook_scale"]), gain=float(g["gain"]))
+    sd = golden_state(g)
     p = O.to_torch_state(sd)
     img, gt = make_batch(int(g["seed_x"]), B, T, H, W)
     state = {} if adam else None
@@ -103,6 +103,15 @@ def test_c1_e2e(golden_dir):
         fw2 = O.vqvae_forward(img, p, training=False)
     np.testing.assert_allclose(_sub(fw2["dec"]), g["dec2_sub"], rtol=2e-2, atol=2e-2)
     _close(fw2["diff"], g["diff2"], rtol=2e-2)
+
+
+def test_c1w_e2e_many_codes(golden_dir):
+    """96x96 variant with codebooks centred on the latents: > 100 distinct codes on BOTH levels, so a wrong codebook row
+    anywhere in the first few hundred would show."""
+    g = np.load(os.path.join(golden_dir, "c1w_e2e.npz"))
+    assert len(np.unique(g["id_t"])) > 100 and len(np.unique(g["id_b"])) > 100
+    p, r, img = _run_e2e(g, adam=False)
+    _check_e2e(g, p, r, img)
 
 
 def test_b1_literal_forward(golden_dir):
