@@ -91,9 +91,15 @@ class _Layer:
         elif self._winograd_m(x):
             m = self._winograd_m(x)
             kd = self._wino_kd
-            keep = self.engine.keep_wino_v and ops.wino_wgrad_ok(x.shape[1], x.shape[2], x.shape[0], T, m, kd)
-            self.saved_v = ops.conv3d_winograd(x, self._wino_filter(m, False), self.b, out, T=T, cin=self.ci, cout=self.co,
-                                               flags=flags, add=add, keep_v=keep, m=m, kd=kd)
+            # the transformed input is kept for this layer's filter gradient IN THE FORWARD'S OWN STATE DICT (two
+            # forwards followed by the backward of the older one must not mix them up)
+            S = self.engine._cur_S
+            keep = (S is not None and self.engine.keep_wino_v
+                    and ops.wino_wgrad_ok(x.shape[1], x.shape[2], x.shape[0], T, m, kd))
+            V = ops.conv3d_winograd(x, self._wino_filter(m, False), self.b, out, T=T, cin=self.ci, cout=self.co,
+                                    flags=flags, add=add, keep_v=keep, m=m, kd=kd)
+            if keep:
+                S.setdefault("_wino_v", {})[self.name] = V
         else:
             g = self._geom()
             ops.conv_igemm(x, self.wp, self.b, out, T=T if self.kind == "conv3d" else 1, cin=self.cip, cout=self.co,
@@ -167,7 +173,8 @@ class _Layer:
             ops.bias_grad(g, self.gb, self.co)
         elif (self._winograd_m(x) and not in_relu and self.ci == self.cip
               and ops.wino_wgrad_ok(x.shape[1], x.shape[2], x.shape[0], T, self._winograd_m(x), self._wino_kd)):
-            V, self.saved_v = getattr(self, "saved_v", None), None     # the forward's transformed input, if it was kept
+            S = self.engine._cur_S if self.engine is not None else None
+            V = S.get("_wino_v", {}).pop(self.name, None) if S is not None else None   # the forward's transformed input, if kept
             if V is not None and self.engine is not None and self.engine.wgrad_stream is not None:
                 self.engine._keepalive.append(V)                      # read on the side stream: must outlive this call
             ops.conv3d_wgrad_winograd(g, x, self.gw, self.gb, T=T, a_real=self.co, b_real=self.ci, V=V, m=self._winograd_m(x),
@@ -237,6 +244,7 @@ class VQVAEEngine:
         self.winograd_max_tile = int(_os.environ.get("FACEOFF_WINOGRAD_TILE", "4"))   # 2: F(2x2,3x3) everywhere
         self.keep_wino_v = False      # training forward: keep each Conv3d's transformed input for its filter gradient
         self._keepalive = []
+        self._cur_S = None            # state dict of the forward / backward in flight (kept Winograd planes live in it)
         if state_dict is not None:
             self.load_state_dict(state_dict)
         self.grad_ready_hook = None   # callable(layer_name) fired as soon as a layer's grads are enqueued
@@ -306,6 +314,7 @@ class VQVAEEngine:
 
     def stage_encode(self, S):
         """only_encode (:237-241): enc_b = Encoder(stride 4), enc_t = Encoder(stride 2)."""
+        self._cur_S = S
         L, x8 = self.layers, S["x8"]
         N, H, W, _ = x8.shape
         h2, w2, h4, w4, h8, w8 = H // 2, W // 2, H // 4, W // 4, H // 8, W // 8
@@ -322,6 +331,7 @@ class VQVAEEngine:
 
     def stage_conv3d(self, S):
         """Conv3dLatentPostnet x2 (:172-176,247-251).  Bottom output lands in cat_b[..., 64:192]."""
+        self._cur_S = S
         L, T, eb, et = self.layers, S["T"], S["eb"], S["et"]
         N, h4, w4, _ = eb.shape
         _, h8, w8, _ = et.shape
@@ -349,6 +359,7 @@ class VQVAEEngine:
 
     def stage_quantize(self, S, training):
         """encode_quantized (:261-278).  Needs S[d3] and S[cat_b][..., 64:192]."""
+        self._cur_S = S
         L, d3, cat_b = self.layers, S["d3"], S["cat_b"]
         N, h8, w8, _ = d3.shape
         _, h4, w4, _ = cat_b.shape
@@ -377,6 +388,7 @@ class VQVAEEngine:
 
     def stage_decode(self, S):
         """decode (:280-285).  Needs S[quant_t] and S[cat_d][..., 64:128] (= quant_b)."""
+        self._cur_S = S
         L, quant_t, cat_d = self.layers, S["quant_t"], S["cat_d"]
         N, h4, w4, _ = cat_d.shape
         L["upsample_t"].fwd(quant_t, cat_d[..., 0:64])                     # torch.cat([upsample_t, quant_b], 1) :282
@@ -423,6 +435,7 @@ class VQVAEEngine:
         Fills self.grads (flat arena).  Order = reverse forward, so arena slices complete back-to-front."""
         L = self.layers
         T = S["T"]
+        self._cur_S = S
         new_like = torch.empty_like
         # ---- dec (Decoder stride 4)
         l6, l4 = L["dec.blocks.6"], L["dec.blocks.4"]
@@ -511,6 +524,8 @@ class VQVAEEngine:
         if self.wgrad_stream is not None:          # join: every filter gradient is in the arena after this
             torch.cuda.current_stream().wait_stream(self.wgrad_stream)
             self._keepalive.clear()
+        S.pop("_wino_v", None)
+        self._cur_S = None
 
     # ------------------------------------------------------------------ fused train step (bench / trainer fast path)
     def loss_and_backward(self, img_nchw, gt_nchw, T=None, latent_weight=1.0):

@@ -69,7 +69,9 @@ class _VQVAEFunction(torch.autograd.Function):
             g_diff = torch.zeros(1, device=eng.device)
         eng.backward(S, g8, g_diff.contiguous().reshape(1).float())
         ctx.S = None
-        grads = tuple(eng.grads[k].clone() for k in model._param_keys)   # the arena is overwritten by the next backward
+        # the arena is overwritten by the next backward: hand autograd views of ONE flat copy (one launch, not 70)
+        flat = eng.flat_grads.clone()
+        grads = tuple(flat[o:o + n].view(eng.params[k].shape) for k, (o, n) in ((k, eng.offsets[k]) for k in model._param_keys))
         return (None, None, None) + grads
 
 
@@ -101,7 +103,11 @@ class Quantize(nn.Module):
         return quantize, diff.reshape(()), ind
 
     def embed_code(self, embed_id):
-        return torch.nn.functional.embedding(embed_id, self.embed.transpose(0, 1))
+        """:82-83 F.embedding(embed_id, embed^T) -> [..., dim], by the gather kernel (fo_vq_gather)."""
+        embedT, _ = ops.vq_prepare(self.embed)
+        q = torch.empty((*embed_id.shape, self.dim), device=self.embed.device, dtype=torch.float32)
+        ops.vq_gather(embed_id.contiguous(), embedT, q.view(-1, 1, 1, self.dim))
+        return q
 
 
 class _QuantizeSTE(torch.autograd.Function):
@@ -171,14 +177,23 @@ class VQVAE(nn.Module):
             named[k].grad = None
         for k, b in bufs.items():
             b.data = eng.buffers[k]
-        if dist_fn.get_world_size() > 1:
-            eng.vq_allreduce = dist_fn.fused_vq_allreduce()
+        eng.vq_allreduce = dist_fn.fused_vq_allreduce()      # checks the world size at call time (a no-op for one rank)
         self._engine = eng
         return eng
 
     @property
     def engine(self):
         return self._bind(next(self.parameters()).device)
+
+    def _apply(self, fn, *a, **kw):
+        """`.to(device)` / `.cuda()`: once the parameters sit on a GPU, re-home them in the engine's flat arena right
+        away (not lazily at the first forward), so anything that captures the parameters afterwards -- an optimiser,
+        nn.parallel.DistributedDataParallel -- sees their final storage."""
+        out = super()._apply(fn, *a, **kw)
+        dev = next(self.parameters()).device
+        if dev.type == "cuda":
+            self._bind(dev)
+        return out
 
     # ------------------------------------------------------------------ reference API
     def forward(self, input):

@@ -78,6 +78,15 @@ def ld_of(t, dtype=torch.float32):
     return ld
 
 
+def dense_f32(t, what):
+    """Loader-side tensors (NCHW images) go to the kernels as raw pointers: they must be dense fp32 device memory.
+    A wrong dtype, a CPU tensor or a strided view would otherwise be read as garbage or fault on the GPU."""
+    if not (torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32):
+        raise TypeError(f"{what}: a float32 tensor on the GPU is required, got "
+                        f"{getattr(t, 'dtype', type(t))} on {getattr(t, 'device', '?')}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
 def pad_out(c):
     """Output-channel padding the conv kernel's N tile implies (see fo_conv_igemm)."""
     return (c + 127) // 128 * 128 if c > 64 else (64 if c > 32 else 32)
@@ -420,7 +429,7 @@ def nchw_to_nhwc(x, cpad=None):
     N, Cc, H, W = x.shape
     cpad = cpad or Cc
     y = torch.empty((N, H, W, cpad), device=x.device, dtype=torch.float32)
-    _lib.call("fo_nchw_to_nhwc", _ptr(x.contiguous()), _ptr(y), N, Cc, H, W, cpad, cpad, _stream())
+    _lib.call("fo_nchw_to_nhwc", _ptr(dense_f32(x, "nchw_to_nhwc input")), _ptr(y), N, Cc, H, W, cpad, cpad, _stream())
     return y
 
 
@@ -430,7 +439,8 @@ def cat_nchw_to_nhwc8(a, b):
     Cb = b.shape[1]
     assert b.shape == (N, Cb, H, W) and Ca + Cb <= 8
     y = torch.empty((N, H, W, 8), device=a.device, dtype=torch.float32)
-    _lib.call("fo_nchw2_to_nhwc8", _ptr(a.contiguous()), Ca, _ptr(b.contiguous()), Cb, _ptr(y), N, H, W, _stream())
+    _lib.call("fo_nchw2_to_nhwc8", _ptr(dense_f32(a, "source frames")), Ca, _ptr(dense_f32(b, "background frames")), Cb, _ptr(y), N, H, W,
+              _stream())
     return y
 
 
@@ -484,11 +494,14 @@ def vq_gather(ind, embedT, q_out):
 # ------------------------------------------------------------------ losses / optimiser
 def mse_slice_fwd(dec, gt_nchw, acc):
     N, H, W, _ = dec.shape
+    gt_nchw = dense_f32(gt_nchw, "ground truth")
+    assert gt_nchw.shape[0] == N and gt_nchw.shape[2:] == (H, W), "ground truth must be [N,C,H,W] like the decoder output"
     _lib.call("fo_mse_slice_fwd", _ptr(dec), ld_of(dec), _ptr(gt_nchw), N, H, W, gt_nchw.shape[1], _ptr(acc), _stream())
 
 
 def mse_slice_bwd(dec, gt_nchw, gscale, gdec):
     N, H, W, _ = dec.shape
+    gt_nchw = dense_f32(gt_nchw, "ground truth")
     c3 = gt_nchw.shape[1]
     _lib.call("fo_mse_slice_bwd", _ptr(dec), ld_of(dec), _ptr(gt_nchw), N, H, W, c3, _ptr(gscale),
               C.c_float(1.0 / (N * c3 * H * W)), _ptr(gdec), ld_of(gdec), _stream())

@@ -17,7 +17,8 @@ Parity pinning: the reference ships no tests or golden vectors (SURVEY.md sectio
 oracle is pinned by outputs of the reference itself, generated in the build container by
 tests/golden/make_golden.py (imports /root/reference) and committed under tests/golden/;
 tests/test_oracle_golden.py checks the oracle against them, and
-tests/test_oracle_vs_reference.py re-checks live wherever /root/reference exists.
+tests/test_oracle_vs_reference.py re-checks it live against the imported reference wherever
+/root/reference exists (the build container; skipped on the GPU box).
 LPIPS: pretrained VGG/lin weights are not obtainable offline => LPIPS parity is on topology
 and arithmetic with seeded random weights ("pretrained-weight parity unpinned").
 """
@@ -264,7 +265,7 @@ def lpips_forward(inp, target, lp, per_tap=False, bf16sim=False):
 
 
 # --------------------------------------------------------------------------- the step
-def run_step(x, ground_truth, p, lpips_state=None, training=True, all_reduce=None):
+def run_step(x, ground_truth, p, lpips_state=None, training=True, all_reduce=None, lpips_bf16sim=False):
     """run_step + loss composition (train_faceoff_perceptual.py:32-47,97-98).
 
     x[B,T,6,H,W], ground_truth[B,T,3,H,W].  Returns dict with recon/latent/perceptual/loss
@@ -276,7 +277,7 @@ def run_step(x, ground_truth, p, lpips_state=None, training=True, all_reduce=Non
     recon = F.mse_loss(out, gt)                              # :21,39
     latent = fw["diff"].mean()                               # :40
     if lpips_state is not None:
-        perceptual = lpips_forward(gt.contiguous(), out.contiguous(), lpips_state).mean()   # loss.py:33
+        perceptual = lpips_forward(gt.contiguous(), out.contiguous(), lpips_state, bf16sim=lpips_bf16sim).mean()   # loss.py:33
     else:
         perceptual = torch.zeros(())
     loss = recon + LATENT_LOSS_WEIGHT * latent + PERCEPTUAL_LOSS_WEIGHT * perceptual   # :98
@@ -298,12 +299,12 @@ def adam_step(p, grads, state, lr=3e-4, betas=(0.9, 0.999), eps=1e-8):
             p[k].addcdiv_(m, denom, value=-lr / (1 - b1 ** t))
 
 
-def train_step(x, ground_truth, p, lpips_state=None, adam_state=None, lr=3e-4):
+def train_step(x, ground_truth, p, lpips_state=None, adam_state=None, lr=3e-4, lpips_bf16sim=False):
     """One iteration of train() (:93-107): zero_grad, run_step, backward, (Adam), EMA buffers."""
     params = {k: v for k, v in p.items() if v.requires_grad}
     for v in params.values():
         v.grad = None
-    r = run_step(x, ground_truth, p, lpips_state, training=True)
+    r = run_step(x, ground_truth, p, lpips_state, training=True, lpips_bf16sim=lpips_bf16sim)
     r["loss"].backward()
     grads = {k: v.grad.detach().clone() for k, v in params.items()}
     with torch.no_grad():

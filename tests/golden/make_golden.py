@@ -248,7 +248,7 @@ if __name__ == "__main__":
     if "c1w" in which:     # the same at 96x96 (576 / 2304 latent vectors): > 100 codes in use on BOTH levels
         gen_e2e("c1w_e2e", 2, 2, 96, 96, seed_w=4, seed_x=4321, centered_scale=0.1, with_adam=False)
     if "b1" in which:      # literal VQVAE.forward, one clip of 4 frames
-        gen_e2e("b1_literal", 1, 4, 64, 64, seed_w=0, seed_x=77, literal=True)
+        gen_e2e("b1_literal", 1, 4, 64, 64, seed_w=0, seed_x=79, literal=True)   # seed chosen so that no code is a near-tie (min margin 1e-3)
     if "c2smoke" in which:  # C2 shape, one clip (256x256, T=5): checksums only
         gen_e2e("c2_oneclip", 1, 5, 256, 256, seed_w=3, seed_x=99, with_adam=False)
     if "lpips" in which:

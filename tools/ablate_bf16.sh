@@ -7,8 +7,7 @@ CS=faceoff_amd/csrc
 if [ "${1:-build}" = "build" ]; then
   for m in 1 3 4 7; do
     /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 -Iinclude -DFO_ABLATE_H=$m -c $CS/conv_bf16.hip -o /tmp/cbf_ab$m.o || exit 1
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC /tmp/cbf_ab$m.o $CS/conv_igemm.o $CS/conv_wgrad.o $CS/pack.o $CS/vq.o $CS/elementwise.o \
-        $CS/lpips.o $CS/lpips_bf16.o $CS/api.o -o tools/_libfaceoff_hab$m.so || exit 1
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC /tmp/cbf_ab$m.o $(ls $CS/*.o | grep -v /conv_bf16.o) -o tools/_libfaceoff_hab$m.so || exit 1
   done
 else
   python tools/bench_bf16.py "${2:-fwd}" 2>&1 | grep TFLOP

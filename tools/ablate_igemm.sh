@@ -8,8 +8,7 @@ CS=faceoff_amd/csrc
 if [ "${1:-build}" = "build" ]; then
   for m in 1 2 3 4 8 12 15; do
     /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 -Iinclude -DFO_ABLATE=$m -c $CS/conv_igemm.hip -o /tmp/igemm_ab$m.o || exit 1
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC /tmp/igemm_ab$m.o $CS/conv_wgrad.o $CS/pack.o $CS/vq.o $CS/elementwise.o \
-        $CS/lpips.o $CS/conv_bf16.o $CS/lpips_bf16.o $CS/api.o -o tools/_libfaceoff_ab$m.so || exit 1
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC /tmp/igemm_ab$m.o $(ls $CS/*.o | grep -v /conv_igemm.o) -o tools/_libfaceoff_ab$m.so || exit 1
   done
 else
   python tools/bench_kernels.py "${2:-conv3d_b fwd}" 2>&1 | grep TFLOP
