@@ -3,7 +3,7 @@
 TAG=${1:-run}; shift
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
-python -m pytest tests -m gpu -x -q -s "$@" > $OUT/pytest.log 2>&1
+python -m pytest tests -m gpu -q -s "$@" > $OUT/pytest.log 2>&1
 echo "pytest rc=$?" >> $OUT/pytest.log
 grep -E "^\[|passed|failed|error|rc=" $OUT/pytest.log | tail -40
 python bench.py --steps 10 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
