@@ -7,6 +7,7 @@ Filters stay in the reference's checkpoint layouts and are packed on the GPU eac
 from __future__ import annotations
 
 import ctypes as C
+import os as _os
 
 import torch
 
@@ -241,7 +242,17 @@ def conv3d_winograd(x, U, bias, out, *, T, cin, cout, flags=0, mask=None, add=No
     banked = (N * Ht * Wt) % 128 == 0
     per = max(1, min(P, ((1 << 31) - 1) // max(plane_v * 4, plane_m * 4))) if banked else 1   # planes per launch (2 GiB window)
     prof = PROFILER
-    for p0 in range(0, P, per):
+    # every C2 shape: the whole plane stack as ONE launch of the persistent plane-stack GEMM kernel
+    if banked and per == P and cin >= 64 and cout % 128 == 0 and not _os.environ.get("FACEOFF_NO_WINO_GEMM"):
+        if prof is not None:
+            nominal = 2.0 * P * N * Ht * Wt * cout * kd * cin
+            prof.begin("wino_gemm" + (f" [F{m} {P}x{N}x{Ht}x{Wt} {cin}->{cout} k{kd}11]" if prof.detail else ""),
+                       nominal * (temporal_share(T) if kd > 1 else 1.0), nominal)
+        _lib.call("fo_wino_gemm", _ptr(V), _ptr(U), _ptr(M), P, N, T if kd > 1 else 1, Ht * Wt, cin, cout, kd, _stream())
+        if prof is not None:
+            prof.end()
+        per = 0
+    for p0 in (range(0, P, per) if per else ()):
         np_ = min(per, P - p0)
         d = _desc(N=np_ * N, T=T if kd > 1 else 1, Hin=Ht, Win=Wt, Hm=Ht, Wm=Wt, Hout=Ht, Wout=Wt, Cin=cin, Cout=cout, KD=kd, KH=1, KW=1,
                   stride=1, padD=kd // 2, padH=0, padW=0, ostride=1, ophH=0, ophW=0, ldIn=cin, ldOut=cout, ldMask=0, ldAdd=0, flags=0)

@@ -105,6 +105,12 @@ int fo_conv_igemm(const fo_conv_desc* d, const float* in, const float* wp, const
  * consecutive packed filter banks behind `wp`.  No bias / mask / residual.  Needs bank_frames*Hm*Wm % 128 == 0. */
 int fo_conv_igemm_banked(const fo_conv_desc* d, const float* in, const float* wp, float* out, int bank_frames, void* stream);
 
+/* The same plane-stack GEMM as a persistent kernel of its own (csrc/wino_gemm.hip), used when a plane is whole 128-row
+ * tiles, Cin >= 64 and Cout % 128 == 0 (every C2 shape):
+ *   M[xi][r][co] = sum_{kd,ci} V[xi][r + (kd - KD/2)*P][ci] * U[xi][co][kd][ci]      r < N*P rows per plane, P rows per frame,
+ * depth taps outside a clip of T frames skipped.  V [planes][N*P][Cin], U [planes][Cout][KD][Cin], M [planes][N*P][Cout]. */
+int fo_wino_gemm(const float* V, const float* U, float* M, int planes, int N, int T, int P, int Cin, int Cout, int KD, void* stream);
+
 /* fo_conv_wgrad for `banks` independent planes of N/banks frames (whole clips each) in one launch: dw receives `banks`
  * consecutive [Areal][Breal][taps] tensors.  Conv3d geometry (KD > 1) only; no bias sum. */
 int64_t fo_wgrad_banked_ws_bytes(const fo_conv_desc* d, int banks);
