@@ -53,6 +53,9 @@ __device__ __forceinline__ f32x4 bufload(__amdgpu_buffer_rsrc_t r, unsigned voff
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
 
+// x / d for x * d < 2^32 with magic = ceil(2^32 / d) (which does not fit 32 bits for d == 1)
+__device__ __forceinline__ unsigned udiv(unsigned x, int d, unsigned magic) { return d == 1 ? x : __umulhi(x, magic); }
+
 __global__ __launch_bounds__(256, 2) void wino_gemm_kernel(const WGArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * LDS_LD];
   float* As0 = lds;
@@ -84,14 +87,14 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_kernel(const WGArgs a) {
   auto setup = [&](int tile) {
     const int tile_n = tile % a.tilesN, tile_m = tile / a.tilesN;
     const int row0 = tile_m * BM;
-    const int plane = (int)__umulhi((unsigned)tile_m, a.planeMagic);
+    const int plane = (int)udiv((unsigned)tile_m, a.tilesPerPlane, a.planeMagic);
     const unsigned boff = (unsigned)plane * a.bankBytes;
     unsigned any = 0;      // bit kd set: some row of the tile has a real frame behind depth tap kd
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int r = row0 + lrow + 32 * i;
-      const unsigned F = a.pShift >= 0 ? (unsigned)r >> a.pShift : __umulhi((unsigned)r, a.pMagic);
-      const int t = (int)(F - __umulhi(F, a.tMagic) * (unsigned)a.T);
+      const unsigned F = a.pShift >= 0 ? (unsigned)r >> a.pShift : udiv((unsigned)r, a.P, a.pMagic);
+      const int t = (int)(F - udiv(F, a.T, a.tMagic) * (unsigned)a.T);
       unsigned bad = 0;
       for (int kd = 0; kd < a.KD; ++kd) bad |= ((unsigned)(t + kd - a.padD) < (unsigned)a.T ? 0u : 1u) << kd;
       ld_mask[i] = bad;
@@ -99,11 +102,11 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_kernel(const WGArgs a) {
       ld_wrow[i] = boff + (unsigned)((tile_n * BN + lrow + 32 * i) * a.Ktot + lcol) * 4u;
     }
     {  // tile-uniform K range: the frames of the first and the last row (a tile spans at most two frames when P >= 64)
-      const unsigned F0 = a.pShift >= 0 ? (unsigned)row0 >> a.pShift : __umulhi((unsigned)row0, a.pMagic);
-      const unsigned F1 = a.pShift >= 0 ? (unsigned)(row0 + BM - 1) >> a.pShift : __umulhi((unsigned)(row0 + BM - 1), a.pMagic);
+      const unsigned F0 = a.pShift >= 0 ? (unsigned)row0 >> a.pShift : udiv((unsigned)row0, a.P, a.pMagic);
+      const unsigned F1 = a.pShift >= 0 ? (unsigned)(row0 + BM - 1) >> a.pShift : udiv((unsigned)(row0 + BM - 1), a.P, a.pMagic);
       if (F1 - F0 > 1) any = (1u << a.KD) - 1;
       else {
-        const int t0 = (int)(F0 - __umulhi(F0, a.tMagic) * (unsigned)a.T), t1 = (int)(F1 - __umulhi(F1, a.tMagic) * (unsigned)a.T);
+        const int t0 = (int)(F0 - udiv(F0, a.T, a.tMagic) * (unsigned)a.T), t1 = (int)(F1 - udiv(F1, a.T, a.tMagic) * (unsigned)a.T);
         for (int kd = 0; kd < a.KD; ++kd)
           any |= ((((unsigned)(t0 + kd - a.padD) < (unsigned)a.T) | ((unsigned)(t1 + kd - a.padD) < (unsigned)a.T)) ? 1u : 0u) << kd;
       }
@@ -215,17 +218,21 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_kernel(const WGArgs a) {
           const int soff = (i * 32 + (r & 3) + 8 * (r >> 2)) * a.ldM * 4;
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[i][j][r]), rout, voff + j * 128, soff, 0);
-            acc[i][j][r] = 0.f;
+            const float v = acc[i][j][r];     // (a bit_cast applied to the vector element itself reads element 0)
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rout, voff + j * 128, soff, 0);
           }
         }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       if (!ld_live && nx_row0 == cur_row0 && nx_tn == cur_tn) break;   // that was the last tile of this workgroup
       cur_row0 = nx_row0; cur_tn = nx_tn; cur_left = nx_steps;
     }
   }
 }
 
-static unsigned magic_of(unsigned d) { return (unsigned)(((1ull << 32) + d - 1) / d); }
+static unsigned magic_of(unsigned d) { return d <= 1 ? 0u : (unsigned)(((1ull << 32) + d - 1) / d); }
 
 }  // namespace
 

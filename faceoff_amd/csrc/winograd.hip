@@ -97,7 +97,7 @@ __global__ void wino_filter_kernel(const float* __restrict__ w, float* __restric
 
 // V[xi][n][ty][tx][c] = (B^T d B)[xi].  One thread: one tile, 4 channels.
 template <int MT>
-__global__ void wino_input_kernel(const float* __restrict__ x, int ldx, float* __restrict__ V, int N, int H, int W, int C4) {
+__global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, int ldx, float* __restrict__ V, int N, int H, int W, int C4) {
   using Wn = Wino<MT>;
   constexpr int A = Wn::A;
   const int Ht = H / MT, Wt = W / MT;
@@ -146,7 +146,7 @@ __global__ void wino_input_kernel(const float* __restrict__ x, int ldx, float* _
 // out = epilogue(A^T M A).  One thread: one tile (m x m output pixels), 4 channels.
 // epilogue order as in the conv kernels: (+ bias) -> ReLU mask -> + residual -> ReLU.
 template <int MT>
-__global__ void wino_output_kernel(const float* __restrict__ M, const float* __restrict__ bias, const float* __restrict__ mask,
+__global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ M, const float* __restrict__ bias, const float* __restrict__ mask,
                                    int ldMask, const float* __restrict__ add, int ldAdd, float* __restrict__ out, int ldOut, int N,
                                    int H, int W, int C4, int flags) {
   using Wn = Wino<MT>;
@@ -201,7 +201,7 @@ __global__ void wino_output_kernel(const float* __restrict__ M, const float* __r
 //   dU[xi][co][ci][kd]  = sum_{n,tile} dM[xi][n][tile][co] * V[xi][n + kd - 1][tile][ci]     (a*a wgrad GEMMs, banked)
 //   dW[co][ci][kd]      = G^T dU G                                    (a x a -> 3 x 3)
 template <int MT>
-__global__ void wino_gradout_kernel(const float* __restrict__ g, int ldg, float* __restrict__ dM, int N, int H, int W, int C4) {
+__global__ __launch_bounds__(256) void wino_gradout_kernel(const float* __restrict__ g, int ldg, float* __restrict__ dM, int N, int H, int W, int C4) {
   using Wn = Wino<MT>;
   constexpr int A = Wn::A;
   const int Ht = H / MT, Wt = W / MT;

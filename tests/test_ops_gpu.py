@@ -378,3 +378,37 @@ def test_layout_mse_adam():
         opt.step()
         ops.adam_flat(p, gcpu.to(dev), m, v, 3e-4, step)
     np.testing.assert_allclose(p.cpu().numpy(), p_ref.detach().numpy(), rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("N,T,Ht,Wt,kd,ci,co", [(10, 5, 8, 8, 3, 128, 128), (4, 2, 16, 16, 3, 128, 128), (8, 4, 12, 12, 3, 64, 128),
+                                                 (6, 1, 8, 8, 3, 128, 128), (8, 1, 16, 8, 1, 128, 128), (32, 4, 4, 4, 3, 96, 256)])
+def test_wino_gemm_equals_the_banked_implicit_gemm(N, T, Ht, Wt, kd, ci, co):
+    """fo_wino_gemm (persistent plane-stack GEMM: tiles that straddle frames and clips, skipped depth taps, rows per
+    frame that are / are not powers of two, several tiles per workgroup) against fo_conv_igemm_banked on the same
+    planes: the same k-ordered fp32 MFMA chain, so the results must be the same BITS."""
+    import ctypes as C
+    from faceoff_amd import ops, _lib
+    planes = 16
+    g = torch.Generator(device="cuda").manual_seed(5)
+    V = torch.randn((planes * N * Ht * Wt, ci), device="cuda", generator=g)
+    U = torch.randn((planes, co, kd, ci), device="cuda", generator=g) * 0.05
+    M0 = torch.full((planes * N * Ht * Wt, co), 7.0, device="cuda")
+    M1 = torch.full_like(M0, -3.0)
+    d = ops._desc(N=planes * N, T=T if kd > 1 else 1, Hin=Ht, Win=Wt, Hm=Ht, Wm=Wt, Hout=Ht, Wout=Wt, Cin=ci, Cout=co, KD=kd, KH=1, KW=1,
+                  stride=1, padD=kd // 2, padH=0, padW=0, ostride=1, ophH=0, ophW=0, ldIn=ci, ldOut=co, ldMask=0, ldAdd=0, flags=0)
+    _lib.call("fo_conv_igemm_banked", C.byref(d), ops._ptr(V), ops._ptr(U), ops._ptr(M0), N, ops._stream())
+    _lib.call("fo_wino_gemm", ops._ptr(V), ops._ptr(U), ops._ptr(M1), planes, N, T if kd > 1 else 1, Ht * Wt, ci, co, kd, ops._stream())
+    torch.cuda.synchronize()
+    assert torch.equal(M0, M1), (M0 - M1).abs().max().item()
+    # and against plain torch on one plane (fp64 reference of the definition)
+    p = 3
+    v = V.view(planes, N // T, T, Ht * Wt, ci)[p].double()
+    u = U[p].double()
+    ref = torch.zeros((N // T, T, Ht * Wt, co), device="cuda", dtype=torch.float64)
+    for k in range(kd):
+        dt = k - kd // 2
+        for t in range(T):
+            if 0 <= t + dt < T:
+                ref[:, t] += v[:, t + dt] @ u[:, k].T
+    got = M1.view(planes, N // T, T, Ht * Wt, co)[p].double()
+    assert (got - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
