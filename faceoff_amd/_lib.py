@@ -89,6 +89,29 @@ SIGNATURES = {
     "fo_add": (_I, [_P, _I, _P, _I, _P, _I, _L, _I, _P]),
 }
 
+class ConvNdDesc(C.Structure):
+    """Mirror of `fo_convnd_desc` (include/faceoff_hip.h)."""
+    _fields_ = [(n, C.c_int32) for n in (
+        "N", "Ds", "Hs", "Ws", "Cs", "ldS", "Dd", "Hd", "Wd", "Cd", "ldD", "KD", "KH", "KW", "sD", "sH", "sW", "pD", "pH", "pW",
+        "ldMask", "flags")] + [("slope", C.c_float)]
+
+
+_ND = C.POINTER(ConvNdDesc)
+FO_OUT_LRELU, FO_MASK_LRELU = 64, 128
+SIGNATURES.update({
+    "fo_pack_convnd": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "fo_convnd": (_I, [_ND, _I, _P, _P, _P, _P, _P, _P]),
+    "fo_wgradnd_splits": (_I, [_ND]),
+    "fo_wgradnd": (_I, [_ND, _P, _P, _P, _I, _P]),
+    "fo_instnorm_lrelu_fwd": (_I, [_P, _I, _P, _I, _L, _I, _F, _F, _P, _P, _F, _I, _P]),
+    "fo_instnorm_lrelu_bwd": (_I, [_P, _I, _P, _I, _P, _P, _I, _L, _I, _F, _P]),
+    "fo_avgpool3_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "fo_avgpool3_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "fo_disc_pairs": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P]),
+    "fo_disc_pairs_bwd": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _F, _P]),
+    "fo_ralsgan": (_I, [_P, _I, _P, _I, _I, _F, _F, _F, _P, _P, _P, _P, _P]),
+})
+
 _lib = None
 
 

@@ -1,0 +1,403 @@
+// General N-d convolution kernels for the MoCoGAN-HD discriminators (BASELINE config 5; reference
+// TemporalAlignment/models/mocoganhd_video_disc.py:133-158 Conv3d k4 s2/s1 p2, mocoganhd_content_disc.py the Conv2d twins):
+// any kernel size / stride / padding in three dimensions, channels-last [N][D][H][W][C] activations, exact-fp32 MFMA.
+//
+//   forward      out[n][od][oh][ow][co] = sum_{kd,kh,kw,ci} in[n][od*sD+kd-pD][oh*sH+kh-pH][ow*sW+kw-pW][ci] * w[co][kd,kh,kw][ci]
+//   transposed   gin[n][id][ih][iw][ci] = sum_{taps,co : (id+pD-kd) % sD == 0 ...} g[n][(id+pD-kd)/sD][..][..][co] * w[co][taps][ci]
+//                (the data gradient, as a gather: no atomics)
+//   wgrad        dw[co][ci][tap]        = sum_{n,od,oh,ow} g[..][co] * in[src(od,oh,ow,tap)][ci]
+//
+// The layers are small (<= 133k output positions, one video per step), so the tile is 64 x 64 (4 waves x one 32x32
+// accumulator: many workgroups even for the 4 624-position layers) and the structure is the simple one: per K-step one
+// (tap, 32-channel chunk), row validity recomputed per tap (3 unsigned compares per row), addresses = per-row VGPR base +
+// per-tap scalar offset, padding via out-of-range buffer offsets, LDS rows of 36 floats (conflict-free b128 fragment reads),
+// accumulators stored straight to memory (bias / LeakyReLU / LeakyReLU-backward mask / accumulate in the epilogue).
+// The transposed form orders its GEMM rows PHASE-MAJOR (destination coordinate = stride * q + phase): all rows of a tile
+// share the phase, so only the taps whose parity matches it are visited (1/8 of a k4 s2 Conv3d's taps) -- the sub-pixel
+// decomposition expressed as an index map instead of 8 launches.
+#include <algorithm>
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 64, BN = 64, BK = 32, LDS_LD = 36;
+constexpr unsigned OOB = 0x80000000u;
+
+struct GenArgs {
+  fo_convnd_desc d;
+  const float* src;
+  const float* wp;      // [CdPad64][taps][Cs]
+  const float* bias;
+  const float* mask;
+  float* dst;
+  int transposed;
+  int Dq, Hq, Wq;       // per-phase row grid (transposed: ceil(Dd/sD) ...; forward: Dd, Hd, Wd)
+  int rowsPerPhase;     // N * Dq * Hq * Wq
+  int tilesPerPhase, tilesN, taps;
+  unsigned srcBytes, wpBytes;
+  int margin;
+};
+
+__device__ __forceinline__ f32x4 bufload(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+
+__global__ __launch_bounds__(256, 2) void conv_gen_kernel(const GenArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * LDS_LD];
+  __shared__ long long rowdst[BM];      // destination pixel index of each tile row, -1 = no such pixel
+  float* As0 = lds;
+  float* Bs0 = lds + 2 * BM * LDS_LD;
+  const fo_convnd_desc& d = a.d;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lrow = tid >> 3, lcol = (tid & 7) * 4;
+
+  const int tile_n = blockIdx.x % a.tilesN;
+  const int tile_m = blockIdx.x / a.tilesN;
+  const int phase = tile_m / a.tilesPerPhase;
+  const int mt = tile_m - phase * a.tilesPerPhase;
+  int phD = 0, phH = 0, phW = 0;
+  if (a.transposed) { phW = phase % d.sW; phH = (phase / d.sW) % d.sH; phD = phase / (d.sW * d.sH); }
+
+  // ---- rows: GEMM row m of this phase -> (n, qd, qh, qw); destination coordinate = q (forward) or s*q + phase (transposed)
+  auto decode = [&](int m, int& n, int& qd, int& qh, int& qw) {
+    qw = m % a.Wq; m /= a.Wq;
+    qh = m % a.Hq; m /= a.Hq;
+    qd = m % a.Dq; n = m / a.Dq;
+  };
+  if (tid < BM) {
+    const int m = mt * BM + tid;
+    long long pix = -1;
+    if (m < a.rowsPerPhase) {
+      int n, qd, qh, qw;
+      decode(m, n, qd, qh, qw);
+      const int dd = a.transposed ? qd * d.sD + phD : qd, dh = a.transposed ? qh * d.sH + phH : qh, dw = a.transposed ? qw * d.sW + phW : qw;
+      if (dd < d.Dd && dh < d.Hd && dw < d.Wd) pix = (((long long)n * d.Dd + dd) * d.Hd + dh) * d.Wd + dw;
+    }
+    rowdst[tid] = pix;
+  }
+  // ---- tap walk.  transposed: only taps with (phase + pad - k) % stride == 0; their source offset e = (phase + pad - k) / s
+  const int stD = a.transposed ? d.sD : 1, stH = a.transposed ? d.sH : 1, stW = a.transposed ? d.sW : 1;
+  const int k0D = a.transposed ? (phD + d.pD) % d.sD : 0, k0H = a.transposed ? (phH + d.pH) % d.sH : 0, k0W = a.transposed ? (phW + d.pW) % d.sW : 0;
+  const int nD = k0D < d.KD ? (d.KD - k0D + stD - 1) / stD : 0, nH = k0H < d.KH ? (d.KH - k0H + stH - 1) / stH : 0,
+            nW = k0W < d.KW ? (d.KW - k0W + stW - 1) / stW : 0;
+  // the smallest source offset over the visited taps goes into the row base, so that the per-tap scalar part is >= 0
+  // (a buffer load's scalar offset is unsigned); the descriptor starts `margin` bytes below src for the rows it makes negative
+  int eminD = 0, eminH = 0, eminW = 0;
+  if (a.transposed) {
+    eminD = nD > 0 ? (phD + d.pD - (k0D + (nD - 1) * stD)) / d.sD : 0;
+    eminH = nH > 0 ? (phH + d.pH - (k0H + (nH - 1) * stH)) / d.sH : 0;
+    eminW = nW > 0 ? (phW + d.pW - (k0W + (nW - 1) * stW)) / d.sW : 0;
+  }
+  // loader rows lrow, lrow + 32: base source coordinates (the tap adds a scalar) and the byte offset of (n, bd, bh, bw)
+  int bd[2], bh[2], bw[2];
+  unsigned rowoff[2];
+  bool rv[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = mt * BM + lrow + 32 * i;
+    rv[i] = m < a.rowsPerPhase;
+    int n, qd, qh, qw;
+    decode(rv[i] ? m : 0, n, qd, qh, qw);
+    if (a.transposed) { bd[i] = qd + eminD; bh[i] = qh + eminH; bw[i] = qw + eminW; }
+    else { bd[i] = qd * d.sD - d.pD; bh[i] = qh * d.sH - d.pH; bw[i] = qw * d.sW - d.pW; }
+    const long long p = (((long long)n * d.Ds + bd[i]) * d.Hs + bh[i]) * d.Ws + bw[i];
+    rowoff[i] = (unsigned)((p * d.ldS + lcol) * 4 + a.margin);
+  }
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(reinterpret_cast<const char*>(a.src) - a.margin), 0, a.srcBytes + a.margin, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rwp = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wp), 0, a.wpBytes, 0x00020000);
+  const int Ktot = a.taps * d.Cs;
+  unsigned wrow[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) wrow[i] = (unsigned)(((size_t)(tile_n * BN + lrow + 32 * i) * Ktot + lcol) * 4);
+
+  const int chunks = d.Cs / BK;
+  const int nsteps = nD * nH * nW * chunks;
+
+  int ld_kd = k0D, ld_kh = k0H, ld_kw = k0W, ld_chunk = 0;
+  unsigned ld_bad[2] = {0, 0};     // bit 31 set: this row reads padding at the current tap
+  int ld_soffA = 0, ld_soffB = 0;
+  auto tap_setup = [&]() {
+    int ed, eh, ew;
+    if (a.transposed) {
+      ed = (phD + d.pD - ld_kd) / d.sD - eminD; eh = (phH + d.pH - ld_kh) / d.sH - eminH; ew = (phW + d.pW - ld_kw) / d.sW - eminW;
+    }
+    else { ed = ld_kd; eh = ld_kh; ew = ld_kw; }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const bool ok = rv[i] & ((unsigned)(bd[i] + ed) < (unsigned)d.Ds) & ((unsigned)(bh[i] + eh) < (unsigned)d.Hs) &
+                      ((unsigned)(bw[i] + ew) < (unsigned)d.Ws);
+      ld_bad[i] = ok ? 0u : OOB;
+    }
+    ld_soffA = ((ed * d.Hs + eh) * d.Ws + ew) * d.ldS * 4;
+    ld_soffB = (((ld_kd * d.KH + ld_kh) * d.KW + ld_kw) * d.Cs) * 4;
+  };
+  f32x4 ra[2], rb[2];
+  auto load_step = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      ra[i] = bufload(rin, ld_bad[i] | rowoff[i], ld_soffA + ld_chunk * (BK * 4));
+      rb[i] = bufload(rwp, wrow[i], ld_soffB + ld_chunk * (BK * 4));
+    }
+    if (++ld_chunk == chunks) {
+      ld_chunk = 0;
+      ld_kw += stW;
+      if (ld_kw >= d.KW) {
+        ld_kw = k0W; ld_kh += stH;
+        if (ld_kh >= d.KH) { ld_kh = k0H; ld_kd += stD; }
+      }
+      if (ld_kd < d.KD) tap_setup();
+      else { ld_bad[0] = ld_bad[1] = OOB; }
+    }
+  };
+  auto store_step = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      *reinterpret_cast<f32x4*>(As0 + buf * BM * LDS_LD + (lrow + 32 * i) * LDS_LD + lcol) = ra[i];
+      *reinterpret_cast<f32x4*>(Bs0 + buf * BN * LDS_LD + (lrow + 32 * i) * LDS_LD + lcol) = rb[i];
+    }
+  };
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  if (nsteps > 0) {
+    tap_setup();
+    load_step();
+    store_step(0);
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int step = 0; step < nsteps; ++step) {
+    const float* As = As0 + cur * BM * LDS_LD + (wm * 32 + l31) * LDS_LD + half * 4;
+    const float* Bs = Bs0 + cur * BN * LDS_LD + (wn * 32 + l31) * LDS_LD + half * 4;
+    if (step + 1 < nsteps) load_step();
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const f32x4 fa = *reinterpret_cast<const f32x4*>(As + kk * 8);
+      const f32x4 fb = *reinterpret_cast<const f32x4*>(Bs + kk * 8);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s], fb[s], acc, 0, 0, 0);
+    }
+    if (step + 1 < nsteps) store_step(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- epilogue: register r of the accumulator = tile row (r&3) + 8(r>>2) + 4*half, column l31 (32 consecutive channels)
+  const int co = tile_n * BN + wn * 32 + l31;
+  if (co >= d.Cd) return;
+  const float bv = (d.flags & FO_BIAS) ? a.bias[co] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+    const long long pix = rowdst[row];
+    if (pix < 0) continue;
+    float v = acc[r] + bv;
+    if (d.flags & FO_OUT_LRELU) v = v > 0.f ? v : v * d.slope;
+    if (d.flags & FO_MASK_LRELU) v = a.mask[pix * d.ldMask + co] > 0.f ? v : v * d.slope;
+    float* o = a.dst + pix * d.ldD + co;
+    if (d.flags & FO_ADD) v += *o;
+    *o = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ filter gradient
+//   dw[co][ci][tap] (+)= sum_m g[m][co] * in[src(m, tap)][ci]      one workgroup: (tap, 64 co, 64 ci, one slice of the rows)
+struct WgArgs {
+  fo_convnd_desc d;
+  const float* g;       // [M][ldD]   (M = N*Dd*Hd*Wd)
+  const float* src;
+  float* dw;            // [Cd][CsReal][taps]
+  int M, taps, tilesCo, tilesCi, splits, rowsPerSplit, CsReal;
+  unsigned srcBytes, gBytes;
+  int margin;
+};
+
+__global__ __launch_bounds__(256, 2) void wgrad_gen_kernel(const WgArgs a) {
+  constexpr int RK = 32;                   // rows (GEMM K) per step
+  constexpr int PITCH = 64 + 4;            // floats per staged row: [row][64 channels]
+  __shared__ __attribute__((aligned(16))) float Gs[2][RK * PITCH];
+  __shared__ __attribute__((aligned(16))) float Xs[2][RK * PITCH];
+  const fo_convnd_desc& d = a.d;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  int b = blockIdx.x;
+  const int split = b % a.splits; b /= a.splits;
+  const int tci = b % a.tilesCi; b /= a.tilesCi;
+  const int tco = b % a.tilesCo; b /= a.tilesCo;
+  const int tap = b;
+  const int kw = tap % d.KW, kh = (tap / d.KW) % d.KH, kd = tap / (d.KW * d.KH);
+
+  const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.g), 0, a.gBytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(reinterpret_cast<const char*>(a.src) - a.margin), 0, a.srcBytes + a.margin, 0x00020000);
+  // loader: thread -> (row r = tid / 16 (+16), 16 B at channel (tid % 16) * 4) of the 32 x 64 staged blocks
+  const int lr = tid >> 4, lc = (tid & 15) * 4;
+  const int m_begin = split * a.rowsPerSplit, m_end = min(a.M, m_begin + a.rowsPerSplit);
+  f32x4 rgv[2], rxv[2];
+  auto load = [&](int m0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = m0 + lr + 16 * i;
+      const bool ok = m < m_end;
+      int t = ok ? m : 0;
+      const int ow = t % d.Wd; t /= d.Wd;
+      const int oh = t % d.Hd; t /= d.Hd;
+      const int od = t % d.Dd; const int n = t / d.Dd;
+      const int id = od * d.sD - d.pD + kd, ih = oh * d.sH - d.pH + kh, iw = ow * d.sW - d.pW + kw;
+      const bool in_ok = ok & ((unsigned)id < (unsigned)d.Ds) & ((unsigned)ih < (unsigned)d.Hs) & ((unsigned)iw < (unsigned)d.Ws);
+      const long long p = (((long long)n * d.Ds + id) * d.Hs + ih) * d.Ws + iw;
+      const bool gch = tco * 64 + lc < d.Cd;      // channel group inside the tensor (Cd may be < 64: the 1-channel head)
+      rgv[i] = bufload(rg, (ok && gch) ? (unsigned)(((long long)m * d.ldD + tco * 64 + lc) * 4) : OOB, 0);
+      rxv[i] = bufload(rx, in_ok ? (unsigned)((p * d.ldS + tci * 64 + lc) * 4 + a.margin) : OOB, 0);
+    }
+  };
+  auto store = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      *reinterpret_cast<f32x4*>(&Gs[buf][(lr + 16 * i) * PITCH + lc]) = rgv[i];
+      *reinterpret_cast<f32x4*>(&Xs[buf][(lr + 16 * i) * PITCH + lc]) = rxv[i];
+    }
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  if (m_begin < m_end) { load(m_begin); store(0); }
+  __syncthreads();
+  int cur = 0;
+  for (int m0 = m_begin; m0 < m_end; m0 += RK) {
+    if (m0 + RK < m_end) load(m0 + RK);
+    const float* gs = &Gs[cur][half * PITCH + wm * 32 + l31];
+    const float* xs = &Xs[cur][half * PITCH + wn * 32 + l31];
+#pragma unroll
+    for (int k = 0; k < RK / 2; ++k)       // MFMA k-slot = lane half = staged row 2k + half
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(gs[2 * k * PITCH], xs[2 * k * PITCH], acc, 0, 0, 0);
+    if (m0 + RK < m_end) store(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+  const int ci = tci * 64 + wn * 32 + l31;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int co = tco * 64 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+    if (co < d.Cd && ci < a.CsReal) {
+      float* o = a.dw + ((size_t)co * a.CsReal + ci) * a.taps + tap;
+      if (a.splits > 1) atomicAdd(o, acc[r]);
+      else *o = acc[r];
+    }
+  }
+}
+
+// filters: checkpoint layout w[O][I][taps] -> forward pack [Opad64][taps][Ipad32], transposed pack [Ipad64][taps][Opad32]
+__global__ void pack_gen_kernel(const float* __restrict__ w, float* __restrict__ out, int O, int I, int taps, int rowsPad, int colsPad,
+                                int transposed) {
+  const size_t total = (size_t)rowsPad * taps * colsPad;
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int c = e % colsPad;
+    const int t = (e / colsPad) % taps;
+    const int r = e / ((size_t)colsPad * taps);
+    const int o = transposed ? c : r, i = transposed ? r : c;
+    out[e] = (o < O && i < I) ? w[((size_t)o * I + i) * taps + t] : 0.f;
+  }
+}
+
+int check_desc(const fo_convnd_desc* d) {
+  FO_REQUIRE(d && d->N > 0 && d->Ds > 0 && d->Hs > 0 && d->Ws > 0 && d->Dd > 0 && d->Hd > 0 && d->Wd > 0, FO_E_SHAPE, "convnd: empty grid");
+  FO_REQUIRE(d->KD >= 1 && d->KH >= 1 && d->KW >= 1 && d->sD >= 1 && d->sH >= 1 && d->sW >= 1 && d->pD >= 0 && d->pH >= 0 && d->pW >= 0,
+             FO_E_SHAPE, "convnd: bad kernel / stride / padding");
+  FO_REQUIRE(d->Cs % 32 == 0 && d->Cs > 0 && d->Cd > 0, FO_E_SHAPE, "convnd: source channels must be a multiple of 32 (pad with zeros)");
+  FO_REQUIRE(d->ldS % 4 == 0 && d->ldS >= d->Cs && d->ldD >= d->Cd, FO_E_ALIGN, "convnd: ldS %% 4, ldS >= Cs, ldD >= Cd");
+  return FO_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fo_pack_convnd(const float* w, float* wp, int O, int I, int taps, int transposed, void* stream) {
+  FO_REQUIRE(w && wp && O > 0 && I > 0 && taps > 0, FO_E_SHAPE, "pack_convnd: bad sizes");
+  const int rows = transposed ? I : O, cols = transposed ? O : I;
+  const int rowsPad = (rows + 63) / 64 * 64, colsPad = (cols + 31) / 32 * 32;
+  const size_t total = (size_t)rowsPad * taps * colsPad;
+  const int grid = (int)std::min<size_t>((total + 255) / 256, 16384);
+  hipLaunchKernelGGL(pack_gen_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, wp, O, I, taps, rowsPad, colsPad, transposed);
+  FO_CHECK_LAUNCH();
+  return FO_OK;
+}
+
+// forward (transposed = 0): src = input, dst = output.  transposed = 1: src = output gradient (on the conv's OUTPUT grid,
+// Cs = the conv's Cout), dst = input gradient (on the conv's INPUT grid, Cd = the conv's Cin); K*, s*, p* are the CONV's.
+int fo_convnd(const fo_convnd_desc* d, int transposed, const float* src, const float* wp, const float* bias, const float* mask,
+              float* dst, void* stream) {
+  if (int rc = check_desc(d)) return rc;
+  FO_REQUIRE(src && wp && dst && fo_aligned16(src) && fo_aligned16(wp), FO_E_ALIGN, "convnd: pointers");
+  FO_REQUIRE(!(d->flags & FO_BIAS) || bias, FO_E_SHAPE, "convnd: FO_BIAS without bias");
+  FO_REQUIRE(!(d->flags & FO_MASK_LRELU) || (mask && d->ldMask >= d->Cd), FO_E_SHAPE, "convnd: FO_MASK_LRELU without mask");
+  FO_REQUIRE(!(d->flags & ~(FO_BIAS | FO_OUT_LRELU | FO_MASK_LRELU | FO_ADD)), FO_E_SHAPE, "convnd: unsupported flag");
+  GenArgs a;
+  a.d = *d; a.src = src; a.wp = wp; a.bias = bias; a.mask = mask; a.dst = dst; a.transposed = transposed;
+  a.taps = d->KD * d->KH * d->KW;
+  int phases = 1;
+  if (transposed) {
+    a.Dq = (d->Dd + d->sD - 1) / d->sD; a.Hq = (d->Hd + d->sH - 1) / d->sH; a.Wq = (d->Wd + d->sW - 1) / d->sW;
+    phases = d->sD * d->sH * d->sW;
+  } else { a.Dq = d->Dd; a.Hq = d->Hd; a.Wq = d->Wd; }
+  const long long rows = (long long)d->N * a.Dq * a.Hq * a.Wq;
+  FO_REQUIRE(rows < (1ll << 30), FO_E_SHAPE, "convnd: too many rows");
+  a.rowsPerPhase = (int)rows;
+  a.tilesPerPhase = (a.rowsPerPhase + BM - 1) / BM;
+  a.tilesN = (d->Cd + BN - 1) / BN;
+  const unsigned long long srcBytes = (((unsigned long long)d->N * d->Ds * d->Hs * d->Ws - 1) * d->ldS + d->Cs) * 4ull;
+  const unsigned long long wpBytes = (unsigned long long)a.tilesN * BN * a.taps * d->Cs * 4ull;
+  // the descriptor starts `margin` bytes below src so that (base coordinate < 0) row offsets stay non-negative
+  const long long margin = transposed ? ((((long long)(d->KD - 1) * d->Hs + (d->KH - 1)) * d->Ws + (d->KW - 1)) * d->ldS) * 4ll
+                                      : ((((long long)d->pD * d->Hs + d->pH) * d->Ws + d->pW) * d->ldS) * 4ll;
+  FO_REQUIRE(srcBytes + (unsigned long long)margin < (1ull << 31) && wpBytes < (1ull << 31), FO_E_SHAPE, "convnd: tensor exceeds the 2 GiB window");
+  a.srcBytes = (unsigned)srcBytes; a.wpBytes = (unsigned)wpBytes; a.margin = (int)margin;
+  const long long grid = (long long)phases * a.tilesPerPhase * a.tilesN;
+  FO_REQUIRE(grid < (1ll << 31), FO_E_SHAPE, "convnd: grid");
+  hipLaunchKernelGGL(conv_gen_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
+  FO_CHECK_LAUNCH();
+  return FO_OK;
+}
+
+// dw [Cd][CsReal][taps] = filter gradient of the forward conv described by d (src = the conv's input with Cs >= CsReal
+// padded channels, g = output gradient [N*Dd*Hd*Wd][ldD]).  dw must be ZERO on entry when fo_wgradnd_splits(d) > 1
+// (row slices are combined with float atomics).
+int fo_wgradnd_splits(const fo_convnd_desc* d) {
+  if (check_desc(d)) return -1;
+  const long long M = (long long)d->N * d->Dd * d->Hd * d->Wd;
+  const long long wgs = (long long)d->KD * d->KH * d->KW * ((d->Cd + 63) / 64) * (d->Cs / 64 > 0 ? (d->Cs + 63) / 64 : 1);
+  long long s = 1;
+  while (wgs * s < 1024 && M / (s * 2) >= 256) s *= 2;
+  return (int)s;
+}
+
+int fo_wgradnd(const fo_convnd_desc* d, const float* g, const float* src, float* dw, int CsReal, void* stream) {
+  if (int rc = check_desc(d)) return rc;
+  FO_REQUIRE(g && src && dw && fo_aligned16(g) && fo_aligned16(src) && d->ldD % 4 == 0, FO_E_ALIGN, "wgradnd: pointers / ldD %% 4");
+  FO_REQUIRE(CsReal > 0 && CsReal <= d->Cs, FO_E_SHAPE, "wgradnd: CsReal");
+  WgArgs a;
+  a.d = *d; a.g = g; a.src = src; a.dw = dw; a.CsReal = CsReal;
+  const long long M = (long long)d->N * d->Dd * d->Hd * d->Wd;
+  FO_REQUIRE(M < (1ll << 30), FO_E_SHAPE, "wgradnd: too many rows");
+  a.M = (int)M;
+  a.taps = d->KD * d->KH * d->KW;
+  a.tilesCo = (d->Cd + 63) / 64;
+  a.tilesCi = (d->Cs + 63) / 64;
+  a.splits = fo_wgradnd_splits(d);
+  a.rowsPerSplit = ((a.M + a.splits - 1) / a.splits + 31) / 32 * 32;
+  const unsigned long long srcBytes = (((unsigned long long)d->N * d->Ds * d->Hs * d->Ws - 1) * d->ldS + d->Cs) * 4ull;
+  const unsigned long long gBytes = (((unsigned long long)M - 1) * d->ldD + (unsigned long long)((d->Cd + 3) / 4 * 4)) * 4ull;
+  FO_REQUIRE(srcBytes < (1ull << 31) && gBytes < (1ull << 31), FO_E_SHAPE, "wgradnd: tensor exceeds the 2 GiB window");
+  a.srcBytes = (unsigned)srcBytes; a.gBytes = (unsigned)gBytes; a.margin = 0;
+  const long long grid = (long long)a.taps * a.tilesCo * a.tilesCi * a.splits;
+  hipLaunchKernelGGL(wgrad_gen_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
+  FO_CHECK_LAUNCH();
+  return FO_OK;
+}
+}

@@ -1,0 +1,311 @@
+// HBM-bound pieces of the MoCoGAN-HD discriminators (reference TemporalAlignment/models/mocoganhd_video_disc.py,
+// mocoganhd_content_disc.py, mocoganhd_losses.py:108-126, disc_trainers/train_vqvae_mocoganhd_disc.py:303-432):
+// InstanceNorm + LeakyReLU forward / backward, AvgPool(3, count_include_pad=False) forward / backward, the frame pairing
+// that builds the discriminator inputs (and its gradient), the relativistic average LSGAN loss.  Channels-last, 16 B per lane.
+#include <algorithm>
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+// sum over the 64 row slots of each of the 4 channel groups of a 256-thread workgroup (thread = slot * 4 + group)
+__device__ __forceinline__ f32x4 reduce_slots(f32x4 v, f32x4* sh, int tid) {
+  sh[tid] = v;
+  __syncthreads();
+  for (int s = 128; s >= 4; s >>= 1) {
+    if (tid < s) sh[tid] += sh[tid + s];
+    __syncthreads();
+  }
+  const f32x4 r = sh[tid & 3];
+  __syncthreads();
+  return r;
+}
+
+// One workgroup = 16 channels x all rows of the sample (the normed layers have <= 21k positions x 128..512 channels).
+__global__ __launch_bounds__(256) void instnorm_lrelu_fwd_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy,
+                                                                 long long rows, int C, float eps, float slope, float* __restrict__ stats,
+                                                                 float* __restrict__ running, float momentum, int use_running) {
+  __shared__ f32x4 sh[256];
+  const int tid = threadIdx.x, grp = tid & 3, slot = tid >> 2;
+  const int c = blockIdx.x * 16 + grp * 4;
+  f32x4 mean, rstd;
+  if (use_running) {
+    mean = ld4(running + c);
+    const f32x4 v = ld4(running + C + c);
+    for (int e = 0; e < 4; ++e) rstd[e] = 1.f / sqrtf(v[e] + eps);
+  } else {
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (long long r = slot; r < rows; r += 64) s += ld4(x + r * ldx + c);
+    mean = reduce_slots(s, sh, tid) * (1.f / (float)rows);
+    f32x4 q = {0.f, 0.f, 0.f, 0.f};
+    for (long long r = slot; r < rows; r += 64) { const f32x4 dlt = ld4(x + r * ldx + c) - mean; q += dlt * dlt; }
+    const f32x4 var = reduce_slots(q, sh, tid) * (1.f / (float)rows);       // biased, as F.instance_norm normalises
+    for (int e = 0; e < 4; ++e) rstd[e] = 1.f / sqrtf(var[e] + eps);
+    if (running && slot == 0) {          // running statistics: momentum update with the UNBIASED variance
+      const float unb = rows > 1 ? (float)rows / (float)(rows - 1) : 1.f;
+      st4(running + c, ld4(running + c) * (1.f - momentum) + mean * momentum);
+      st4(running + C + c, ld4(running + C + c) * (1.f - momentum) + var * (unb * momentum));
+    }
+  }
+  if (slot == 0) { st4(stats + c, mean); st4(stats + C + c, rstd); }
+  for (long long r = slot; r < rows; r += 64) {
+    f32x4 z = (ld4(x + r * ldx + c) - mean) * rstd;
+    for (int e = 0; e < 4; ++e) z[e] = z[e] > 0.f ? z[e] : z[e] * slope;
+    st4(y + r * ldy + c, z);
+  }
+}
+
+// z = normalised value (recovered from y), gz = gy * lrelu'(z);  gx = rstd * (gz - mean(gz) - z * mean(gz * z))
+__global__ __launch_bounds__(256) void instnorm_lrelu_bwd_kernel(const float* __restrict__ gy, int ldg, const float* __restrict__ y, int ldy,
+                                                                 const float* __restrict__ stats, float* __restrict__ gx, int ldgx,
+                                                                 long long rows, int C, float slope) {
+  __shared__ f32x4 sh[256];
+  const int tid = threadIdx.x, grp = tid & 3, slot = tid >> 2;
+  const int c = blockIdx.x * 16 + grp * 4;
+  const float inv_slope = 1.f / slope;
+  f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+  for (long long r = slot; r < rows; r += 64) {
+    const f32x4 yv = ld4(y + r * ldy + c);
+    f32x4 g = ld4(gy + r * ldg + c);
+    for (int e = 0; e < 4; ++e) {
+      const bool pos = yv[e] > 0.f;
+      const float z = pos ? yv[e] : yv[e] * inv_slope;
+      g[e] = pos ? g[e] : g[e] * slope;
+      s1[e] += g[e];
+      s2[e] += g[e] * z;
+    }
+  }
+  const float inv = 1.f / (float)rows;
+  const f32x4 m1 = reduce_slots(s1, sh, tid) * inv, m2 = reduce_slots(s2, sh, tid) * inv;
+  const f32x4 rstd = ld4(stats + C + c);
+  for (long long r = slot; r < rows; r += 64) {
+    const f32x4 yv = ld4(y + r * ldy + c);
+    f32x4 g = ld4(gy + r * ldg + c), o;
+    for (int e = 0; e < 4; ++e) {
+      const bool pos = yv[e] > 0.f;
+      const float z = pos ? yv[e] : yv[e] * inv_slope;
+      const float gz = pos ? g[e] : g[e] * slope;
+      o[e] = rstd[e] * (gz - m1[e] - z * m2[e]);
+    }
+    st4(gx + r * ldgx + c, o);
+  }
+}
+
+// window of output o along one dimension: inputs [o*s - 1, o*s + 1] clipped to [0, n) (k = 3, pad = 1); k = 1: just o*s
+__device__ __forceinline__ void win(int o, int s, int n, int k, int& lo, int& hi) {
+  if (k == 1) { lo = hi = o * s; return; }
+  lo = max(0, o * s - 1); hi = min(n - 1, o * s + 1);
+}
+
+__global__ void avgpool3_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int D, int H, int W, int C4, int ld, int kD,
+                                    int sD, int sH, int sW, int Do, int Ho, int Wo) {
+  const long long total = (long long)Do * Ho * Wo * C4;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(e % C4);
+    long long q = e / C4;
+    const int ow = (int)(q % Wo); q /= Wo;
+    const int oh = (int)(q % Ho);
+    const int od = (int)(q / Ho);
+    int d0, d1, h0, h1, w0, w1;
+    win(od, sD, D, kD, d0, d1); win(oh, sH, H, 3, h0, h1); win(ow, sW, W, 3, w0, w1);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int d = d0; d <= d1; ++d)
+      for (int h = h0; h <= h1; ++h)
+        for (int w = w0; w <= w1; ++w) s += ld4(x + (((long long)d * H + h) * W + w) * ld + c * 4);
+    const float inv = 1.f / (float)((d1 - d0 + 1) * (h1 - h0 + 1) * (w1 - w0 + 1));    // count_include_pad = False
+    st4(y + (((long long)od * Ho + oh) * Wo + ow) * ld + c * 4, s * inv);
+  }
+}
+
+// gather form of the backward: input position i collects gy[o] / count(o) from every output whose window holds it
+__global__ void avgpool3_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx, int D, int H, int W, int C4, int ld, int kD,
+                                    int sD, int sH, int sW, int Do, int Ho, int Wo) {
+  const long long total = (long long)D * H * W * C4;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(e % C4);
+    long long q = e / C4;
+    const int iw = (int)(q % W); q /= W;
+    const int ih = (int)(q % H);
+    const int id = (int)(q / H);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    // candidate outputs along a dimension: o with |o*s - i| <= 1 (k = 3) or o*s == i (k = 1)
+    const int od_lo = kD == 1 ? (id % sD == 0 ? id / sD : Do) : max(0, (id - 1 + sD - 1) / sD), od_hi = kD == 1 ? id / sD : min(Do - 1, (id + 1) / sD);
+    const int oh_lo = max(0, (ih - 1 + sH - 1) / sH), oh_hi = min(Ho - 1, (ih + 1) / sH);
+    const int ow_lo = max(0, (iw - 1 + sW - 1) / sW), ow_hi = min(Wo - 1, (iw + 1) / sW);
+    for (int od = od_lo; od <= od_hi; ++od)
+      for (int oh = oh_lo; oh <= oh_hi; ++oh)
+        for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+          int d0, d1, h0, h1, w0, w1;
+          win(od, sD, D, kD, d0, d1); win(oh, sH, H, 3, h0, h1); win(ow, sW, W, 3, w0, w1);
+          const float inv = 1.f / (float)((d1 - d0 + 1) * (h1 - h0 + 1) * (w1 - w0 + 1));
+          s += ld4(gy + (((long long)od * Ho + oh) * Wo + ow) * ld + c * 4) * inv;
+        }
+    float* o = gx + (((long long)id * H + ih) * W + iw) * ld + c * 4;
+    st4(o, ld4(o) + s);
+  }
+}
+
+__global__ void disc_pairs_kernel(const float* __restrict__ src, int nchw, int ldSrc, int H, int W, int f0, int first, int step, int n,
+                                  float* __restrict__ out, int ldOut) {
+  const int G = ldOut / 4;
+  const long long HW = (long long)H * W, total = (long long)n * HW * G;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int g = (int)(e % G);
+    const long long q = e / G;
+    const long long pix = q % HW;
+    const int j = (int)(q / HW);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (g < 2) {
+      const int fk = first + j * step;
+      for (int k = 0; k < 4; ++k) {
+        const int c = g * 4 + k;                  // channels 0..2 = frame f0, 3..5 = frame fk
+        if (c >= 6) break;
+        const int f = c < 3 ? f0 : fk, cc = c < 3 ? c : c - 3;
+        v[k] = nchw ? src[((long long)f * 3 + cc) * HW + pix] : src[((long long)f * HW + pix) * ldSrc + cc];
+      }
+    }
+    st4(out + ((long long)j * HW + pix) * ldOut + g * 4, v);
+  }
+}
+
+// one thread per (frame, pixel): a single writer, so the accumulation order is fixed
+__global__ void disc_pairs_bwd_kernel(const float* __restrict__ gout, int ldOut, int H, int W, int F, int f0, int first, int step, int n,
+                                      float* __restrict__ gsrc, int ldG, float scale) {
+  const long long HW = (long long)H * W, total = (long long)F * HW;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const long long pix = e % HW;
+    const int f = (int)(e / HW);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    if (f == f0)
+      for (int j = 0; j < n; ++j) {
+        const float* p = gout + ((long long)j * HW + pix) * ldOut;
+        a0 += p[0]; a1 += p[1]; a2 += p[2];
+      }
+    const int dj = f - first;
+    if (dj % step == 0) {
+      const int j = dj / step;
+      if (j >= 0 && j < n) {
+        const float* p = gout + ((long long)j * HW + pix) * ldOut;
+        a0 += p[3]; a1 += p[4]; a2 += p[5];
+      }
+    }
+    float* o = gsrc + ((long long)f * HW + pix) * ldG;
+    o[0] += a0 * scale; o[1] += a1 * scale; o[2] += a2 * scale;
+  }
+}
+
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+  const int tid = threadIdx.x;
+  sh[tid] = v;
+  __syncthreads();
+  for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+    if (tid < s) sh[tid] += sh[tid + s];
+    __syncthreads();
+  }
+  const float r = sh[0];
+  __syncthreads();
+  return r;
+}
+
+__global__ __launch_bounds__(1024) void ralsgan_kernel(const float* __restrict__ a, int na, const float* __restrict__ b, int nb, int ld,
+                                                       float ta, float tb, float w, float* loss_acc, const float* gscale,
+                                                       float* __restrict__ ga, float* __restrict__ gb) {
+  __shared__ float sh[1024];
+  const int tid = threadIdx.x;
+  float sa = 0.f, sb = 0.f;
+  for (int i = tid; i < na; i += 1024) sa += a[(long long)i * ld];
+  for (int i = tid; i < nb; i += 1024) sb += b[(long long)i * ld];
+  const float ma = block_sum(sa, sh) / (float)na, mb = block_sum(sb, sh) / (float)nb;
+  float l1 = 0.f, l2 = 0.f;
+  for (int i = tid; i < na; i += 1024) { const float e = a[(long long)i * ld] - mb - ta; l1 += e * e; }
+  for (int i = tid; i < nb; i += 1024) { const float e = b[(long long)i * ld] - ma - tb; l2 += e * e; }
+  l1 = block_sum(l1, sh) / (float)na;
+  l2 = block_sum(l2, sh) / (float)nb;
+  if (tid == 0) atomicAdd(loss_acc, w * (l1 + l2));
+  const float gs = w * (gscale ? gscale[0] : 1.f);
+  // d/da_i = 2 (a_i - mb - ta) / na  (own term)  -  2 (mb - ma - tb) / na  (through mean(a) in the other term); b likewise
+  if (ga)
+    for (int i = tid; i < na; i += 1024)
+      ga[(long long)i * ld] = gs * 2.f / (float)na * ((a[(long long)i * ld] - mb - ta) - (mb - ma - tb));
+  if (gb)
+    for (int i = tid; i < nb; i += 1024)
+      gb[(long long)i * ld] = gs * 2.f / (float)nb * ((b[(long long)i * ld] - ma - tb) - (ma - mb - ta));
+}
+
+inline int grid_for(long long total) { return (int)std::max<long long>(1, std::min<long long>((total + 255) / 256, 16384)); }
+
+}  // namespace
+
+extern "C" {
+
+int fo_instnorm_lrelu_fwd(const float* x, int ldx, float* y, int ldy, int64_t rows, int C, float eps, float slope, float* stats,
+                          float* running, float momentum, int use_running, void* stream) {
+  FO_REQUIRE(x && y && stats && rows > 0 && C > 0 && C % 16 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && fo_aligned16(x) && fo_aligned16(y),
+             FO_E_SHAPE, "instnorm: C %% 16 == 0, ld %% 4 == 0, 16-byte alignment");
+  FO_REQUIRE(!use_running || running, FO_E_SHAPE, "instnorm: eval mode needs the running statistics");
+  hipLaunchKernelGGL(instnorm_lrelu_fwd_kernel, dim3(C / 16), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, (long long)rows, C, eps,
+                     slope, stats, running, momentum, use_running);
+  FO_CHECK_LAUNCH();
+  return FO_OK;
+}
+
+int fo_instnorm_lrelu_bwd(const float* gy, int ldg, const float* y, int ldy, const float* stats, float* gx, int ldgx, int64_t rows,
+                          int C, float slope, void* stream) {
+  FO_REQUIRE(gy && y && stats && gx && rows > 0 && C % 16 == 0 && ldg % 4 == 0 && ldy % 4 == 0 && ldgx % 4 == 0 && slope != 0.f, FO_E_SHAPE,
+             "instnorm_bwd: C %% 16 == 0, ld %% 4 == 0, slope != 0");
+  hipLaunchKernelGGL(instnorm_lrelu_bwd_kernel, dim3(C / 16), dim3(256), 0, (hipStream_t)stream, gy, ldg, y, ldy, stats, gx, ldgx,
+                     (long long)rows, C, slope);
+  FO_CHECK_LAUNCH();
+  return FO_OK;
+}
+
+static int pool_out(int n, int k, int s) { return k == 1 ? (n - 1) / s + 1 : (n + 2 - 3) / s + 1; }
+
+int fo_avgpool3_fwd(const float* x, float* y, int D, int H, int W, int C, int ld, int kD, int sD, int sH, int sW, void* stream) {
+  FO_REQUIRE(x && y && (kD == 1 || kD == 3) && C % 4 == 0 && ld % 4 == 0 && ld >= C && sD >= 1 && sH >= 1 && sW >= 1, FO_E_SHAPE, "avgpool3: bad arguments");
+  const int Do = pool_out(D, kD, sD), Ho = pool_out(H, 3, sH), Wo = pool_out(W, 3, sW);
+  hipLaunchKernelGGL(avgpool3_fwd_kernel, dim3(grid_for((long long)Do * Ho * Wo * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, y, D, H, W,
+                     C / 4, ld, kD, sD, sH, sW, Do, Ho, Wo);
+  FO_CHECK_LAUNCH();
+  return FO_OK;
+}
+
+int fo_avgpool3_bwd(const float* gy, float* gx, int D, int H, int W, int C, int ld, int kD, int sD, int sH, int sW, void* stream) {
+  FO_REQUIRE(gy && gx && (kD == 1 || kD == 3) && C % 4 == 0 && ld % 4 == 0 && ld >= C, FO_E_SHAPE, "avgpool3_bwd: bad arguments");
+  const int Do = pool_out(D, kD, sD), Ho = pool_out(H, 3, sH), Wo = pool_out(W, 3, sW);
+  hipLaunchKernelGGL(avgpool3_bwd_kernel, dim3(grid_for((long long)D * H * W * (C / 4))), dim3(256), 0, (hipStream_t)stream, gy, gx, D, H, W,
+                     C / 4, ld, kD, sD, sH, sW, Do, Ho, Wo);
+  FO_CHECK_LAUNCH();
+  return FO_OK;
+}
+
+int fo_disc_pairs(const float* src, int nchw, int ldSrc, int H, int W, int f0, int first, int step, int n, float* out, int ldOut,
+                  void* stream) {
+  FO_REQUIRE(src && out && n > 0 && step != 0 && ldOut >= 8 && ldOut % 4 == 0 && fo_aligned16(out), FO_E_SHAPE, "disc_pairs: bad arguments");
+  hipLaunchKernelGGL(disc_pairs_kernel, dim3(grid_for((long long)n * H * W * (ldOut / 4))), dim3(256), 0, (hipStream_t)stream, src, nchw,
+                     ldSrc, H, W, f0, first, step, n, out, ldOut);
+  FO_CHECK_LAUNCH();
+  return FO_OK;
+}
+
+int fo_disc_pairs_bwd(const float* gout, int ldOut, int H, int W, int f0, int first, int step, int n, float* gsrc, int ldG, float scale,
+                      void* stream) {
+  FO_REQUIRE(gout && gsrc && n > 0 && step != 0 && ldOut >= 6 && ldG >= 3, FO_E_SHAPE, "disc_pairs_bwd: bad arguments");
+  const int last = first + (n - 1) * step;
+  const int F = std::max(std::max(first, last), f0) + 1;
+  hipLaunchKernelGGL(disc_pairs_bwd_kernel, dim3(grid_for((long long)F * H * W)), dim3(256), 0, (hipStream_t)stream, gout, ldOut, H, W, F,
+                     f0, first, step, n, gsrc, ldG, scale);
+  FO_CHECK_LAUNCH();
+  return FO_OK;
+}
+
+int fo_ralsgan(const float* a, int na, const float* b, int nb, int ld, float ta, float tb, float w, float* loss_acc,
+               const float* gscale, float* ga, float* gb, void* stream) {
+  FO_REQUIRE(a && b && loss_acc && na > 0 && nb > 0 && ld >= 1, FO_E_SHAPE, "ralsgan: bad arguments");
+  hipLaunchKernelGGL(ralsgan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a, na, b, nb, ld, ta, tb, w, loss_acc, gscale, ga, gb);
+  FO_CHECK_LAUNCH();
+  return FO_OK;
+}
+}

@@ -133,3 +133,46 @@ def make_vgg_lpips_state(seed=0):
     for k, c in enumerate([64, 128, 256, 512, 512]):
         sd[f"lin{k}.model.1.weight"] = rng.uniform(0, 1.0 / c, (1, c, 1, 1)).astype(np.float32)
     return sd
+
+
+DISC_CHANNELS = (64, 128, 256, 512, 1)      # NLayerDiscriminator(ndf=64, n_layers=3): mocoganhd_video_disc.py:133-158
+
+
+def disc_param_specs(dims=3, nc=6, num_D=2):
+    """(key, shape) of every parameter / buffer of ModelD_3d (dims=3) or ModelD_img (dims=2) in reference state_dict order
+    (TemporalAlignment/models/mocoganhd_video_disc.py:56-76: scale{i}_layer{j}.0 = conv, .1 = InstanceNorm with running stats)."""
+    out = []
+    for i in range(num_D):
+        cin = nc
+        for j, co in enumerate(DISC_CHANNELS):
+            key = f"netD.scale{i}_layer{j}"
+            out.append((key + ".0.weight", (co, cin) + (4,) * dims))
+            out.append((key + ".0.bias", (co,)))
+            if 1 <= j <= 3:
+                out.append((key + ".1.running_mean", (co,)))
+                out.append((key + ".1.running_var", (co,)))
+                out.append((key + ".1.num_batches_tracked", ()))
+            cin = co
+    return out
+
+
+def make_disc_state(seed=0, dims=3, nc=6, num_D=2, weight_std=0.02):
+    """Seeded discriminator state: conv weights N(0, 0.02) (weights_init, mocoganhd_video_disc.py:32-38), biases torch's
+    default U(-1/sqrt(fan_in), 1/sqrt(fan_in)), running_mean 0, running_var 1, num_batches_tracked 0."""
+    rng = np.random.default_rng(seed)
+    sd = OrderedDict()
+    fan_in = None
+    for key, shape in disc_param_specs(dims, nc, num_D):
+        if key.endswith(".weight"):
+            fan_in = int(np.prod(shape[1:]))
+            sd[key] = (rng.standard_normal(shape) * weight_std).astype(np.float32)
+        elif key.endswith(".bias"):
+            b = 1.0 / math.sqrt(fan_in)
+            sd[key] = rng.uniform(-b, b, shape).astype(np.float32)
+        elif key.endswith("running_mean"):
+            sd[key] = np.zeros(shape, np.float32)
+        elif key.endswith("running_var"):
+            sd[key] = np.ones(shape, np.float32)
+        else:
+            sd[key] = np.zeros(shape, np.int64)
+    return sd

@@ -208,6 +208,64 @@ int fo_wino_output(const float* M, const float* bias, const float* mask, int ldM
 int fo_wino_gradout(const float* g, int ldg, float* dM, int N, int H, int W, int C, int m, void* stream);
 int fo_wino_wgrad_out(const float* dU /* [(m+2)^2][O][I][KD] */, float* dW, int O, int I, int KD, int m, void* stream);
 
+/* ---------------------------------------------------------------- MoCoGAN-HD discriminators (BASELINE config 5)
+ * Replaces the cuDNN kernels behind ModelD_3d / ModelD_img (TemporalAlignment/models/mocoganhd_video_disc.py:8-176,
+ * mocoganhd_content_disc.py:8-165): Conv3d / Conv2d k4 s2|s1 p2 forward, data gradient, filter gradient;
+ * InstanceNorm (affine=False, track_running_stats=True) + LeakyReLU(0.2); AvgPool(3, count_include_pad=False);
+ * the relativistic average LSGAN loss (mocoganhd_losses.py:108-126); the frame pairing of the trainer
+ * (disc_trainers/train_vqvae_mocoganhd_disc.py:364-365,395-396).  Activations are channels-last [N][D][H][W][ld]
+ * (a 2-D tensor has D = 1). */
+#define FO_OUT_LRELU 64   /* fo_convnd: LeakyReLU(slope) on the result */
+#define FO_MASK_LRELU 128 /* fo_convnd: result *= (mask[pixel][c] > 0 ? 1 : slope)  (LeakyReLU backward fused into a data gradient) */
+typedef struct fo_convnd_desc {
+  int32_t N;
+  int32_t Ds, Hs, Ws, Cs, ldS; /* SOURCE tensor of the launch (forward: the conv's input; transposed: the output gradient) */
+  int32_t Dd, Hd, Wd, Cd, ldD; /* DESTINATION tensor (forward: the conv's output; transposed: the input gradient) */
+  int32_t KD, KH, KW, sD, sH, sW, pD, pH, pW; /* the CONVOLUTION's kernel / stride / padding in either direction */
+  int32_t ldMask;              /* pixel stride of `mask` (FO_MASK_LRELU), on the destination grid */
+  int32_t flags;               /* FO_BIAS | FO_OUT_LRELU | FO_MASK_LRELU | FO_ADD (accumulate into dst) */
+  float slope;                 /* LeakyReLU negative slope */
+} fo_convnd_desc;
+/* w[O][I][taps] (checkpoint OIDHW / OIHW) -> forward pack [O pad 64][taps][I pad 32] (transposed = 0) or the data-gradient
+ * pack [I pad 64][taps][O pad 32] (transposed = 1). */
+int fo_pack_convnd(const float* w, float* wp, int O, int I, int taps, int transposed, void* stream);
+/* transposed = 0: dst = conv(src) (+ bias, LeakyReLU).  transposed = 1: dst = data gradient of that conv for the output
+ * gradient src (Cs = the conv's Cout padded to 32 with zero channels, Cd = the conv's Cin), as a gather (no atomics).
+ * Source channels must be a multiple of 32. */
+int fo_convnd(const fo_convnd_desc* d, int transposed, const float* src, const float* wp, const float* bias, const float* mask,
+              float* dst, void* stream);
+/* dw[Cd][CsReal][taps] = sum over output positions of g (x) src for the FORWARD conv d (g on the destination grid).
+ * Row slices are combined with float atomics when fo_wgradnd_splits(d) > 1: dw must then be zero on entry. */
+int fo_wgradnd_splits(const fo_convnd_desc* d);
+int fo_wgradnd(const fo_convnd_desc* d, const float* g, const float* src, float* dw, int CsReal, void* stream);
+/* InstanceNorm(affine=False) over the `rows` positions of one sample, per channel, then LeakyReLU:
+ *   y = lrelu((x - mean_c) * rstd_c), biased variance, eps inside the sqrt.  stats = [mean(C) | rstd(C)] (kept for backward);
+ * running (may be NULL) = [running_mean(C) | running_var(C)], updated with `momentum` and the UNBIASED variance, as
+ * nn.InstanceNorm*d(track_running_stats=True) does in training mode.  use_running != 0 (eval mode): normalise with them. */
+int fo_instnorm_lrelu_fwd(const float* x, int ldx, float* y, int ldy, int64_t rows, int C, float eps, float slope, float* stats,
+                          float* running, float momentum, int use_running, void* stream);
+/* gx = d loss / d x given gy = d loss / d y and the saved y, stats (training-mode statistics). */
+int fo_instnorm_lrelu_bwd(const float* gy, int ldg, const float* y, int ldy, const float* stats, float* gx, int ldgx, int64_t rows,
+                          int C, float slope, void* stream);
+/* AvgPool(k = 3 in every pooled dimension, padding 1, count_include_pad = False) of [D][H][W][C] with strides (sD, sH, sW);
+ * kD = 1 leaves the depth axis alone (2-D pooling).  _bwd ADDS the gradient into gx (zero it first). */
+int fo_avgpool3_fwd(const float* x, float* y, int D, int H, int W, int C, int ld, int kD, int sD, int sH, int sW, void* stream);
+int fo_avgpool3_bwd(const float* gy, float* gx, int D, int H, int W, int C, int ld, int kD, int sD, int sH, int sW, void* stream);
+/* Discriminator inputs: out[j][h][w][0:3] = frame f0, [3:6] = frame (first + j*step) of a window of frames, zero up to ldOut
+ * channels (train_vqvae_mocoganhd_disc.py:364-365: `cat((x[:,0] repeated, x[:,1:]), dim=2)`; step = -1 with first = F-1 is
+ * flip_video :169-174; n = 1 is the image discriminator's pair :354-357).  src: nchw != 0 -> [F][3][H][W] (ground truth),
+ * else channels-last [F][H][W][ldSrc] (decoder output).  _bwd adds the pair gradient into gsrc [F][H][W][ldG] channels 0..2
+ * times `scale`. */
+int fo_disc_pairs(const float* src, int nchw, int ldSrc, int H, int W, int f0, int first, int step, int n, float* out, int ldOut,
+                  void* stream);
+int fo_disc_pairs_bwd(const float* gout, int ldOut, int H, int W, int f0, int first, int step, int n, float* gsrc, int ldG, float scale,
+                      void* stream);
+/* Relativistic average LSGAN (mocoganhd_losses.py:108-126) on one scale's patch logits a[na], b[nb] (pixel stride ld):
+ *   loss = w * ( mean((a - mean(b) - ta)^2) + mean((b - mean(a) - tb)^2) )       accumulated into *loss_acc;
+ * ga / gb (either may be NULL) receive d loss / d a, d loss / d b times gscale[0] (stride ld, written not added). */
+int fo_ralsgan(const float* a, int na, const float* b, int nb, int ld, float ta, float tb, float w, float* loss_acc,
+               const float* gscale, float* ga, float* gb, void* stream);
+
 /* ---------------------------------------------------------------- bf16 LPIPS branch (BASELINE config 3)
  * The same VGG-16 / LPIPS chain with bf16 storage and bf16 MFMA operands, fp32 accumulation and fp32 head
  * arithmetic; every stored tensor is rounded to bf16 once (round-to-nearest-even).  `void*` tensors below are

@@ -16,6 +16,8 @@ dev = torch.device("cuda:0")
 B, T, H = 32, 5, 256
 eng = VQVAEEngine(make_state_dict(0, codebook_scale=0.3, gain=2.0), dev)
 tr = FaceOffTrainer(eng)
+if "--overlap" not in sys.argv:          # default: every kernel alone on the GPU (side streams folded into the main one)
+    eng.set_stream_overlap(False)
 gen = torch.Generator(device=dev).manual_seed(1234)
 img = torch.rand((B * T, 6, H, H), device=dev, generator=gen) * 2 - 1
 gt = torch.rand((B * T, 3, H, H), device=dev, generator=gen) * 2 - 1
