@@ -1,0 +1,278 @@
+"""MoCoGAN-HD multiscale PatchGAN discriminators on the gfx950 kernels (BASELINE config 5).
+
+`DiscEngine(dims=3)` = ModelD_3d.netD, `DiscEngine(dims=2)` = ModelD_img.netD of the reference
+(TemporalAlignment/models/mocoganhd_video_disc.py:56-176, mocoganhd_content_disc.py): num_D scales of
+Conv k4 s2 p2 -> LeakyReLU | (Conv k4 s2 p2 -> InstanceNorm -> LeakyReLU) x2 | Conv k4 s1 p2 -> IN -> LReLU | Conv k4 s1 p2 -> 1,
+the input of scale i+1 being the AvgPool(3, count_include_pad=False) of scale i's.
+
+Like VQVAEEngine: an explicit forward that keeps what the backward needs (layer inputs, post-activation outputs, instance
+statistics), an explicit backward, parameters and gradients in two flat arenas in reference state_dict order / shapes
+(OIDHW), one Adam launch over the arena.  Real and fake inputs go through as a batch of samples (N = 2): InstanceNorm is
+per sample, convolutions and filter gradients run once over both.
+
+Layout: channels-last [N][D][H][W][C], input channels padded to 32 with zeros (the general conv kernel contracts 32-channel
+chunks); the 1-channel patch logits live in a 32-float pixel (channel 0), which is also what their data gradient reads.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from collections import OrderedDict
+
+import torch
+
+from . import _lib, ops
+from ._lib import ConvNdDesc, FO_BIAS, FO_ADD, FO_OUT_LRELU, FO_MASK_LRELU
+from .synth import disc_param_specs, DISC_CHANNELS
+
+STRIDES = (2, 2, 2, 1, 1)
+PAD, K, SLOPE, IN_EPS, IN_MOMENTUM = 2, 4, 0.2, 1e-5, 0.1
+
+
+def _out(n, s):
+    return (n + 2 * PAD - K) // s + 1
+
+
+class DiscEngine:
+    def __init__(self, state_dict, device, dims=3, nc=6, num_D=2, n_frames=15):
+        assert dims in (2, 3)
+        self.device, self.dims, self.nc, self.num_D, self.n_frames = torch.device(device), dims, nc, num_D, n_frames
+        self.specs = disc_param_specs(dims, nc, num_D)
+        sizes = [(k, s, int(torch.tensor(s).prod()) if len(s) else 1) for k, s in self.specs if k.endswith((".weight", ".bias"))]
+        total = sum((n + 3) // 4 * 4 for _, _, n in sizes)
+        self.flat_params = torch.zeros(total, device=self.device)
+        self.flat_grads = torch.zeros(total, device=self.device)
+        self.params, self.grads, off = OrderedDict(), OrderedDict(), 0
+        for k, s, n in sizes:
+            self.params[k] = self.flat_params[off:off + n].view(s)
+            self.grads[k] = self.flat_grads[off:off + n].view(s)
+            off += (n + 3) // 4 * 4
+        self.buffers = OrderedDict()
+        for k, s in self.specs:
+            if k.endswith("running_mean"):
+                # [running_mean | running_var] of a layer live side by side (one kernel argument)
+                base = k[:-len("running_mean")]
+                both = torch.zeros(2 * s[0], device=self.device)
+                both[s[0]:] = 1.0
+                self.buffers[base + "running_mean"] = both[:s[0]]
+                self.buffers[base + "running_var"] = both[s[0]:]
+                self.buffers[base + "_both"] = both
+            elif k.endswith("num_batches_tracked"):
+                self.buffers[k] = torch.zeros((), dtype=torch.int64, device=self.device)
+        self.m = torch.zeros_like(self.flat_params)
+        self.v = torch.zeros_like(self.flat_params)
+        self.t = 0
+        self._wp, self._wpt = {}, {}
+        if state_dict is not None:
+            self.load_state_dict(state_dict)
+
+    # ------------------------------------------------------------------ state
+    def load_state_dict(self, sd):
+        for k, v in sd.items():
+            k = k[len("module."):] if k.startswith("module.") else k
+            t = torch.as_tensor(v).to(self.device)
+            if k in self.params:
+                self.params[k].copy_(t.float())
+            elif k in self.buffers:
+                self.buffers[k].copy_(t)
+            else:
+                raise KeyError(k)
+
+    def state_dict(self):
+        out = OrderedDict()
+        for k, _ in self.specs:
+            out[k] = self.params[k] if k in self.params else self.buffers[k]
+        return out
+
+    def adam_step(self, lr, betas=(0.5, 0.999), eps=1e-8):
+        """torch.optim.Adam(netD.parameters(), lr, betas=(0.5, 0.999)) (mocoganhd_video_disc.py:24-26) as one launch."""
+        self.t += 1
+        ops.adam_flat(self.flat_params, self.flat_grads, self.m, self.v, lr, self.t, betas, eps)
+
+    # ------------------------------------------------------------------ helpers
+    def _desc(self, N, src_dims, cs, ld_s, dst_dims, cd, ld_d, stride, flags=0, ld_mask=0):
+        d = ConvNdDesc()
+        d.N = N
+        d.Ds, d.Hs, d.Ws = src_dims
+        d.Dd, d.Hd, d.Wd = dst_dims
+        d.Cs, d.ldS, d.Cd, d.ldD = cs, ld_s, cd, ld_d
+        three = self.dims == 3
+        d.KD, d.KH, d.KW = (K if three else 1), K, K
+        d.sD, d.sH, d.sW = (stride if three else 1), stride, stride
+        d.pD, d.pH, d.pW = (PAD if three else 0), PAD, PAD
+        d.ldMask, d.flags, d.slope = ld_mask, flags, SLOPE
+        return d
+
+    def pack_filters(self):
+        """Checkpoint-layout filters -> forward and data-gradient packs (every step: the optimiser rewrites the weights)."""
+        taps = K ** self.dims
+        for k, w in self.params.items():
+            if not k.endswith(".weight"):
+                continue
+            O, I = w.shape[:2]
+            for store, tr in ((self._wp, 0), (self._wpt, 1)):
+                rows, cols = (I, O) if tr else (O, I)
+                n = ((rows + 63) // 64 * 64) * taps * ((cols + 31) // 32 * 32)
+                if k not in store or store[k].numel() != n:
+                    store[k] = torch.empty(n, device=self.device)
+                _lib.call("fo_pack_convnd", ops._ptr(w), ops._ptr(store[k]), O, I, taps, tr, ops._stream())
+
+    def _dims_of(self, x):
+        return tuple(x.shape[1:4])
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x, training=True, sample_order=None):
+        """x [N][D][H][W][32] (channels >= nc zero; D = 1 for the image discriminator).  Returns S with S['logits'][i] =
+        patch logits [N][Do][Ho][Wo][32] (channel 0) of result[i] in the reference's order (scale{num_D-1-i} on the input
+        downsampled i times).  sample_order: the order in which the reference called the module on the samples (it moves
+        the InstanceNorm running statistics once per call)."""
+        assert x.dim() == 5 and x.shape[-1] == 32 and x.is_contiguous()
+        self.pack_filters()
+        N = x.shape[0]
+        order = list(sample_order) if sample_order is not None else list(range(N))
+        S = {"scales": [], "logits": [], "N": N, "training": training}
+        h = x
+        for i in range(self.num_D):
+            S["scales"].append(self._scale_fwd(h, f"netD.scale{self.num_D - 1 - i}", training, order))
+            S["logits"].append(S["scales"][-1]["feat"][4])
+            if i != self.num_D - 1:
+                h = self._downsample(h)
+        return S
+
+    def _pool_args(self):
+        if self.dims == 3:
+            return (3, 2 if self.n_frames > 16 else 1, 2, 2)
+        return (1, 1, 2, 2)
+
+    def _downsample(self, h):
+        N, D, H, W, Cc = h.shape
+        kD, sD, sH, sW = self._pool_args()
+        Do = (D - 1) // sD + 1 if kD == 1 else (D - 1) // sD + 1
+        Ho, Wo = (H - 1) // sH + 1, (W - 1) // sW + 1
+        out = torch.empty((N, Do, Ho, Wo, Cc), device=self.device)
+        for n in range(N):
+            _lib.call("fo_avgpool3_fwd", ops._ptr(h[n]), ops._ptr(out[n]), D, H, W, Cc, Cc, kD, sD, sH, sW, ops._stream())
+        return out
+
+    def _scale_fwd(self, x, prefix, training, order):
+        N = x.shape[0]
+        feat, stats, inp = [], [None] * 5, [x]
+        h, cin = x, 32
+        for j, (co, s) in enumerate(zip(DISC_CHANNELS, STRIDES)):
+            key = f"{prefix}_layer{j}"
+            sd = self._dims_of(h)
+            dd = tuple((_out(n, s) if (self.dims == 3 or a > 0) else 1) for a, n in enumerate(sd))
+            ld_out = max(32, co)
+            # the 1-channel head is written into a zeroed 32-float pixel
+            y = (torch.zeros if co < 32 else torch.empty)((N,) + dd + (ld_out,), device=self.device)
+            flags = FO_BIAS | (FO_OUT_LRELU if j == 0 else 0)
+            d = self._desc(N, sd, cin, h.shape[-1], dd, co, ld_out, s, flags)
+            _lib.call("fo_convnd", C.byref(d), 0, ops._ptr(h), ops._ptr(self._wp[key + ".0.weight"]), ops._ptr(self.params[key + ".0.bias"]),
+                      None, ops._ptr(y), ops._stream())
+            if 1 <= j <= 3:
+                rows = dd[0] * dd[1] * dd[2]
+                st = torch.empty((N, 2 * co), device=self.device)
+                z = torch.empty_like(y)
+                run = self.buffers[key + ".1._both"]
+                for n in order:
+                    _lib.call("fo_instnorm_lrelu_fwd", ops._ptr(y[n]), ld_out, ops._ptr(z[n]), ld_out, C.c_int64(rows), co, C.c_float(IN_EPS),
+                              C.c_float(SLOPE), ops._ptr(st[n]), ops._ptr(run), C.c_float(IN_MOMENTUM), int(not training), ops._stream())
+                stats[j] = st
+                y = z
+            feat.append(y)
+            inp.append(y)
+            h, cin = y, max(32, co)
+        return {"feat": feat, "stats": stats, "inp": inp[:5], "prefix": prefix}
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, S, g_logits, param_grads=True, input_grad=False):
+        """g_logits[i]: gradient of the loss with respect to S['logits'][i] (same shape; only channel 0 is read).
+        Fills self.grads (param_grads) and / or returns the gradient with respect to the input x [N][D][H][W][32]."""
+        N = S["N"]
+        gx_scale = [None] * self.num_D
+        for i in range(self.num_D):
+            gx_scale[i] = self._scale_bwd(S["scales"][i], g_logits[i], param_grads, input_grad)
+        if not input_grad:
+            return None
+        # chain the scales: the input of scale i+1 is the average pool of the input of scale i
+        kD, sD, sH, sW = self._pool_args()
+        for i in range(self.num_D - 2, -1, -1):
+            gx, gnext = gx_scale[i], gx_scale[i + 1]
+            _, D, H, W, Cc = gx.shape
+            for n in range(N):
+                _lib.call("fo_avgpool3_bwd", ops._ptr(gnext[n]), ops._ptr(gx[n]), D, H, W, Cc, Cc, kD, sD, sH, sW, ops._stream())
+        return gx_scale[0]
+
+    def _wgrad(self, d, g, src, key, cs_real):
+        dw = self.grads[key + ".0.weight"]
+        if _lib.load().fo_wgradnd_splits(C.byref(d)) > 1:
+            ops.zero_(dw.view(-1))
+        _lib.call("fo_wgradnd", C.byref(d), ops._ptr(g), ops._ptr(src), ops._ptr(dw), cs_real, ops._stream())
+        rows = g.numel() // g.shape[-1]
+        ops.bias_grad(g.view(rows, 1, 1, g.shape[-1]), self.grads[key + ".0.bias"], d.Cd)
+
+    def _scale_bwd(self, sc, g_logit, param_grads, input_grad):
+        prefix, feat, stats, inp = sc["prefix"], sc["feat"], sc["stats"], sc["inp"]
+        N = inp[0].shape[0]
+        g = g_logit                      # gradient wrt the conv output of layer j (pre-norm), channels-last, ld = max(32, co)
+        for j in range(4, -1, -1):
+            key = f"{prefix}_layer{j}"
+            co, s = DISC_CHANNELS[j], STRIDES[j]
+            x_in = inp[j]
+            cin_pad = x_in.shape[-1]
+            cin_real = self.nc if j == 0 else DISC_CHANNELS[j - 1]
+            sd, dd = self._dims_of(x_in), self._dims_of(feat[j])
+            if 1 <= j <= 3:              # g is wrt the post-activation output: through LeakyReLU and InstanceNorm
+                rows = dd[0] * dd[1] * dd[2]
+                gc = torch.empty_like(g)
+                for n in range(N):
+                    _lib.call("fo_instnorm_lrelu_bwd", ops._ptr(g[n]), g.shape[-1], ops._ptr(feat[j][n]), feat[j].shape[-1],
+                              ops._ptr(stats[j][n]), ops._ptr(gc[n]), gc.shape[-1], C.c_int64(rows), co, C.c_float(SLOPE), ops._stream())
+                g = gc
+            if param_grads:
+                d = self._desc(N, sd, cin_pad, cin_pad, dd, co, g.shape[-1], s)
+                self._wgrad(d, g, x_in, key, cin_real)
+            if j == 0 and not input_grad:
+                return None
+            # data gradient: source = g on the conv's output grid (channels padded to 32), destination = the conv's input
+            cs = max(32, co)
+            gin = torch.empty_like(x_in) if j > 0 else torch.zeros_like(x_in)
+            flags = FO_MASK_LRELU if j == 1 else 0          # layer 0's LeakyReLU (no norm in between): mask = its output
+            d = self._desc(N, dd, cs, g.shape[-1], sd, cin_real, cin_pad, s, flags, ld_mask=cin_pad if j == 1 else 0)
+            _lib.call("fo_convnd", C.byref(d), 1, ops._ptr(g), ops._ptr(self._wpt[key + ".0.weight"]), None,
+                      ops._ptr(x_in) if j == 1 else None, ops._ptr(gin), ops._stream())
+            g = gin
+        return g
+
+
+# ---------------------------------------------------------------------------------------------------- loss + inputs
+def ralsgan_pair(logits, ia, ib, target_a, target_b, weight, loss_acc, want_ga=True, want_gb=True, gscale=None):
+    """For every scale's logits tensor [N][..][32] with samples a = logits[ia], b = logits[ib]:
+        loss_acc += weight * (MSE(a - mean(b), target_a) + MSE(b - mean(a), target_b))
+    i.e. Relativistic_Average_LSGAN both ways, summed over scales (mocoganhd_losses.py:113-126; trainer :359-360,372-373,
+    404-408,416-420 with weight 0.5).  Returns per-scale gradients shaped like the logits (zero for samples not wanted)."""
+    grads = []
+    for lg in logits:
+        g = torch.zeros_like(lg)
+        n, ld = lg[0].numel() // lg.shape[-1], lg.shape[-1]
+        _lib.call("fo_ralsgan", ops._ptr(lg[ia]), n, ops._ptr(lg[ib]), n, ld, C.c_float(target_a), C.c_float(target_b), C.c_float(weight),
+                  ops._ptr(loss_acc), ops._ptr(gscale), ops._ptr(g[ia]) if want_ga else None, ops._ptr(g[ib]) if want_gb else None,
+                  ops._stream())
+        grads.append(g)
+    return grads
+
+
+def make_pairs(frames, nchw, f0, first, step, n, out):
+    """out[j] = (frame f0 | frame first + j*step) channels 0..5 of a 32-float pixel (see fo_disc_pairs)."""
+    if nchw:
+        F, _, H, W = frames.shape
+        ld = 0
+    else:
+        F, H, W, ld = frames.shape
+    _lib.call("fo_disc_pairs", ops._ptr(frames), int(nchw), ld, H, W, f0, first, step, n, ops._ptr(out), 32, ops._stream())
+    return out
+
+
+def pairs_backward(g_pairs, f0, first, step, n, g_frames, scale=1.0):
+    """Adds the gradient of `make_pairs` into g_frames [F][H][W][ld] channels 0..2."""
+    _, H, W, ld = g_frames.shape
+    _lib.call("fo_disc_pairs_bwd", ops._ptr(g_pairs), 32, H, W, f0, first, step, n, ops._ptr(g_frames), ld, C.c_float(scale), ops._stream())

@@ -1,0 +1,221 @@
+"""MoCoGAN-HD discriminators on the MI355X (BASELINE config 5 building blocks) against (1) golden outputs of the reference's
+own ModelD_3d / ModelD_img / Relativistic_Average_LSGAN (tests/golden/disc_kat.npz) and (2) the CPU oracle: multiscale patch
+logits, the discriminator- and generator-form losses, gradients of all 20 parameter tensors and of the fake input,
+InstanceNorm running statistics, the Adam(0.5, 0.999) update; plus per-kernel checks of the general N-d conv kernels."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from faceoff_amd.synth import make_disc_state
+
+pytestmark = pytest.mark.gpu
+SUB = 211
+
+
+def _sub(t):
+    return t.detach().reshape(-1)[::SUB].cpu().numpy()
+
+
+def _cl(x):
+    """[N,C,(D,)H,W] torch tensor -> channels-last [N,D,H,W,32] on the GPU, zero-padded channels."""
+    if x.dim() == 4:
+        x = x.unsqueeze(2)
+    N, Cc, D, H, W = x.shape
+    out = torch.zeros((N, D, H, W, 32), device="cuda")
+    out[..., :Cc] = x.permute(0, 2, 3, 4, 1).cuda()
+    return out.contiguous()
+
+
+def _inputs(g, tag, dims):
+    F, H, W = (int(g[f"{tag}_{k}"]) for k in "FHW")
+    rng = np.random.default_rng(int(g[f"{tag}_seed_x"]))
+    shape = (1, 6, F - 1, H, W) if dims == 3 else (1, 6, H, W)
+    real = torch.from_numpy(rng.uniform(-1, 1, shape).astype(np.float32))
+    fake = torch.from_numpy(rng.uniform(-1, 1, shape).astype(np.float32))
+    return real, fake, F
+
+
+@pytest.mark.parametrize("tag,dims", [("v", 3), ("i", 2)])
+def test_discriminator_engine_vs_reference_golden(golden_dir, tag, dims):
+    from faceoff_amd.disc import DiscEngine, ralsgan_pair
+    g = np.load(os.path.join(golden_dir, "disc_kat.npz"))
+    real, fake, F = _inputs(g, tag, dims)
+    sd = make_disc_state(int(g[f"{tag}_seed_w"]), dims)
+    eng = DiscEngine(sd, "cuda:0", dims=dims, n_frames=F - 1)
+    x = torch.cat([_cl(fake), _cl(real)], 0)                       # sample 0 = fake, 1 = real (module calls: fake, then real)
+    S = eng.forward(x, training=True, sample_order=[0, 1])
+    for s in range(2):
+        lg = S["logits"][s][..., 0].cpu().numpy()
+        for n, key in ((0, f"{tag}_fake_s{s}_logits"), (1, f"{tag}_real_s{s}_logits")):
+            want = g[key].reshape(lg[n].shape)
+            assert np.abs(lg[n] - want).max() <= 1e-3 * np.abs(want).max(), key
+    # discriminator-form loss: 0.5 * (crit(real, fake, True) + crit(fake, real, False)), both samples carry gradient
+    loss = torch.zeros(1, device="cuda")
+    g_logits = ralsgan_pair(S["logits"], 1, 0, 1.0, 0.0, 0.5, loss)
+    np.testing.assert_allclose(loss.item(), float(g[f"{tag}_d_loss"]), rtol=1e-3)
+    gx = eng.backward(S, g_logits, param_grads=True, input_grad=True)
+    names = [str(n) for n in g[f"{tag}_param_names"]]
+    assert names == list(eng.grads)
+    got = np.concatenate([_sub(eng.grads[n]) for n in names])
+    want = g[f"{tag}_d_grad_sub"]
+    off, worst = 0, (0.0, "")
+    for i, n in enumerate(names):                                   # every tensor on its own scale (rms | max of the subsample)
+        k = len(_sub(eng.grads[n]))
+        w_, g_ = want[off:off + k], got[off:off + k]
+        off += k
+        scale = max(np.sqrt(g[f"{tag}_d_grad_stats"][i, 1] / eng.grads[n].numel()), np.abs(w_).max())
+        if scale < 1e-6 * np.abs(want).max():                       # bias in front of an InstanceNorm: zero up to rounding
+            assert np.abs(g_).max() <= 1e-5 * np.abs(want).max(), n
+            continue
+        err = np.abs(g_ - w_).max() / scale
+        worst = max(worst, (float(err), n))
+        assert err <= 1e-3, (n, err)
+    gfake = gx[0, ..., :6].permute(3, 0, 1, 2).reshape(fake.shape)
+    wsub = g[f"{tag}_d_gfake_sub"]
+    assert np.abs(_sub(gfake) - wsub).max() <= 1e-3 * np.abs(wsub).max()
+    assert torch.equal(gx[..., 6:], torch.zeros_like(gx[..., 6:]))
+    for k, b in eng.state_dict().items():                           # running statistics after (fake, real)
+        if "running" in k:
+            np.testing.assert_allclose(b.cpu().numpy(), g[f"{tag}_buf.{k}"], rtol=1e-3, atol=1e-6)
+    # Adam(lr=1e-4, betas=(0.5, 0.999)) on those gradients
+    eng.adam_step(1e-4)
+    after = np.concatenate([_sub(eng.params[n]) for n in names])
+    big = np.abs(want) > 1e-3 * np.abs(want).max()
+    assert np.abs(after - g[f"{tag}_param_after_sub"])[big].max() <= 5e-6
+    # generator-form loss: 0.5 * (crit(fake, real, True) + crit(real, fake, False)); gradient to the fake input only
+    eng2 = DiscEngine(sd, "cuda:0", dims=dims, n_frames=F - 1)
+    S2 = eng2.forward(x, training=True, sample_order=[0, 1])
+    loss2 = torch.zeros(1, device="cuda")
+    g2 = ralsgan_pair(S2["logits"], 0, 1, 1.0, 0.0, 0.5, loss2, want_gb=False)
+    np.testing.assert_allclose(loss2.item(), float(g[f"{tag}_g_loss"]), rtol=1e-3)
+    gx2 = eng2.backward(S2, g2, param_grads=False, input_grad=True)
+    gf2 = gx2[0, ..., :6].permute(3, 0, 1, 2).reshape(fake.shape)
+    wsub2 = g[f"{tag}_g_gfake_sub"]
+    assert np.abs(_sub(gf2) - wsub2).max() <= 1e-3 * np.abs(wsub2).max()
+    print(f"[disc {tag}] d_loss {loss.item():.6f} (reference {float(g[f'{tag}_d_loss']):.6f}); worst parameter-gradient rel err {worst}")
+
+
+@pytest.mark.parametrize("dims,N,Cin,Cout,size,stride", [(3, 2, 32, 64, (5, 9, 11), 2), (3, 1, 64, 128, (4, 10, 7), 1), (2, 2, 96, 64, (1, 13, 12), 2),
+                                                         (3, 1, 64, 1, (3, 6, 6), 1), (2, 1, 32, 200, (1, 17, 9), 1)])
+def test_convnd_forward_transposed_and_wgrad_vs_torch(dims, N, Cin, Cout, size, stride):
+    """fo_convnd forward / transposed (gather data gradient, phase-major rows) / fo_wgradnd against torch-CPU conv k4 p2."""
+    from faceoff_amd import _lib, ops
+    from faceoff_amd._lib import ConvNdDesc, FO_BIAS
+    g = torch.Generator().manual_seed(dims * 100 + Cin + Cout)
+    D, H, W = size
+    x = torch.randn((N, Cin, D, H, W), generator=g)
+    kshape = (4, 4, 4) if dims == 3 else (1, 4, 4)
+    w = torch.randn((Cout, Cin) + kshape, generator=g) * 0.05
+    b = torch.randn(Cout, generator=g)
+    pad = (2, 2, 2) if dims == 3 else (0, 2, 2)
+    st = (stride,) * 3 if dims == 3 else (1, stride, stride)
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    y = torch.nn.functional.conv3d(xr, wr, b, stride=st, padding=pad)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    Do, Ho, Wo = y.shape[2:]
+    ldo = max(32, (Cout + 31) // 32 * 32)
+    d = ConvNdDesc(N=N, Ds=D, Hs=H, Ws=W, Cs=Cin, ldS=Cin, Dd=Do, Hd=Ho, Wd=Wo, Cd=Cout, ldD=ldo, KD=kshape[0], KH=4, KW=4,
+                   sD=st[0], sH=st[1], sW=st[2], pD=pad[0], pH=2, pW=2, ldMask=0, flags=FO_BIAS, slope=0.2)
+    xc = x.permute(0, 2, 3, 4, 1).contiguous().cuda()
+    taps = kshape[0] * 16
+    wc = w.reshape(Cout, Cin, taps).contiguous().cuda()
+    wp = torch.empty(((Cout + 63) // 64 * 64) * taps * Cin, device="cuda")
+    _lib.call("fo_pack_convnd", ops._ptr(wc), ops._ptr(wp), Cout, Cin, taps, 0, ops._stream())
+    out = torch.zeros((N, Do, Ho, Wo, ldo), device="cuda")
+    _lib.call("fo_convnd", C.byref(d), 0, ops._ptr(xc), ops._ptr(wp), ops._ptr(b.cuda()), None, ops._ptr(out), ops._stream())
+    got = out[..., :Cout].permute(0, 4, 1, 2, 3).cpu()
+    assert (got - y.detach()).abs().max().item() <= 2e-5 * y.detach().abs().max().item()
+    # transposed: source = gy padded to a multiple of 32 channels
+    cs = (Cout + 31) // 32 * 32
+    gc = torch.zeros((N, Do, Ho, Wo, cs), device="cuda")
+    gc[..., :Cout] = gy.permute(0, 2, 3, 4, 1).cuda()
+    wpt = torch.empty(((Cin + 63) // 64 * 64) * taps * cs, device="cuda")
+    _lib.call("fo_pack_convnd", ops._ptr(wc), ops._ptr(wpt), Cout, Cin, taps, 1, ops._stream())
+    dt = ConvNdDesc(N=N, Ds=Do, Hs=Ho, Ws=Wo, Cs=cs, ldS=cs, Dd=D, Hd=H, Wd=W, Cd=Cin, ldD=Cin, KD=kshape[0], KH=4, KW=4,
+                    sD=st[0], sH=st[1], sW=st[2], pD=pad[0], pH=2, pW=2, ldMask=0, flags=0, slope=0.2)
+    gin = torch.full((N, D, H, W, Cin), 9.0, device="cuda")
+    _lib.call("fo_convnd", C.byref(dt), 1, ops._ptr(gc), ops._ptr(wpt), None, None, ops._ptr(gin), ops._stream())
+    got = gin.permute(0, 4, 1, 2, 3).cpu()
+    assert (got - xr.grad).abs().max().item() <= 2e-5 * xr.grad.abs().max().item()
+    # filter gradient
+    d.flags = 0
+    d.ldD = cs
+    dw = torch.zeros((Cout, Cin, taps), device="cuda")
+    _lib.call("fo_wgradnd", C.byref(d), ops._ptr(gc), ops._ptr(xc), ops._ptr(dw), Cin, ops._stream())
+    want = wr.grad.reshape(Cout, Cin, taps)
+    assert (dw.cpu() - want).abs().max().item() <= 5e-5 * want.abs().max().item()
+
+
+def test_avgpool_instnorm_pairs_ralsgan_vs_torch():
+    from faceoff_amd import _lib, ops
+    g = torch.Generator().manual_seed(3)
+    # AvgPool3d(3, stride (1,2,2), padding 1, count_include_pad=False) forward / backward, odd sizes
+    x = torch.randn((1, 32, 5, 9, 12), generator=g, requires_grad=True)
+    y = torch.nn.functional.avg_pool3d(x, 3, stride=(1, 2, 2), padding=1, count_include_pad=False)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    xc = x.detach().permute(0, 2, 3, 4, 1)[0].contiguous().cuda()
+    out = torch.empty(tuple(y.shape[2:]) + (32,), device="cuda")
+    _lib.call("fo_avgpool3_fwd", ops._ptr(xc), ops._ptr(out), 5, 9, 12, 32, 32, 3, 1, 2, 2, ops._stream())
+    assert (out.permute(3, 0, 1, 2).cpu() - y.detach()[0]).abs().max().item() <= 1e-6
+    gx = torch.zeros_like(xc)
+    _lib.call("fo_avgpool3_bwd", ops._ptr(gy[0].permute(1, 2, 3, 0).contiguous().cuda()), ops._ptr(gx), 5, 9, 12, 32, 32, 3, 1, 2, 2, ops._stream())
+    assert (gx.permute(3, 0, 1, 2).cpu() - x.grad[0]).abs().max().item() <= 1e-6
+    # InstanceNorm + LeakyReLU forward / backward + running statistics
+    rows, Cc = 7 * 5 * 3, 48
+    x = (torch.randn((1, Cc, 7, 5, 3), generator=g) * 2 + 0.7).requires_grad_(True)
+    inorm = torch.nn.InstanceNorm3d(Cc, affine=False, track_running_stats=True)
+    yy = torch.nn.functional.leaky_relu(inorm(x), 0.2)
+    gyy = torch.randn(yy.shape, generator=g)
+    yy.backward(gyy)
+    xc = x.detach().permute(0, 2, 3, 4, 1).reshape(rows, Cc).contiguous().cuda()
+    yc, st = torch.empty_like(xc), torch.empty(2 * Cc, device="cuda")
+    run = torch.cat([torch.zeros(Cc), torch.ones(Cc)]).cuda()
+    _lib.call("fo_instnorm_lrelu_fwd", ops._ptr(xc), Cc, ops._ptr(yc), Cc, C.c_int64(rows), Cc, C.c_float(1e-5), C.c_float(0.2), ops._ptr(st),
+              ops._ptr(run), C.c_float(0.1), 0, ops._stream())
+    want = yy.detach().permute(0, 2, 3, 4, 1).reshape(rows, Cc)
+    assert (yc.cpu() - want).abs().max().item() <= 1e-5 * want.abs().max().item()
+    np.testing.assert_allclose(run[:Cc].cpu().numpy(), inorm.running_mean.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(run[Cc:].cpu().numpy(), inorm.running_var.numpy(), rtol=1e-5)
+    gxc = torch.empty_like(xc)
+    _lib.call("fo_instnorm_lrelu_bwd", ops._ptr(gyy.permute(0, 2, 3, 4, 1).reshape(rows, Cc).contiguous().cuda()), Cc, ops._ptr(yc), Cc, ops._ptr(st),
+              ops._ptr(gxc), Cc, C.c_int64(rows), Cc, C.c_float(0.2), ops._stream())
+    wantg = x.grad.permute(0, 2, 3, 4, 1).reshape(rows, Cc)
+    assert (gxc.cpu() - wantg).abs().max().item() <= 2e-5 * wantg.abs().max().item()
+    # frame pairing (both source layouts, flipped order) and its gradient
+    from faceoff_amd.disc import make_pairs, pairs_backward
+    F, H, W = 6, 4, 5
+    fr = torch.randn((F, 3, H, W), generator=g)
+    want = torch.cat((fr[0:1].expand(F - 1, 3, H, W), fr[1:]), dim=1)            # [F-1, 6, H, W]
+    out = torch.empty((F - 1, H, W, 32), device="cuda")
+    make_pairs(fr.cuda(), True, 0, 1, 1, F - 1, out)
+    assert torch.equal(out[..., :6].permute(0, 3, 1, 2).cpu(), want) and torch.equal(out[..., 6:], torch.zeros_like(out[..., 6:]))
+    nh = torch.zeros((F, H, W, 8), device="cuda")
+    nh[..., :3] = fr.permute(0, 2, 3, 1).cuda()
+    make_pairs(nh, False, 0, F - 1, -1, F - 1, out)                              # flip_video: reversed pair order
+    assert torch.equal(out[..., :6].permute(0, 3, 1, 2).cpu(), torch.flip(want, [0]))
+    gp = torch.randn((F - 1, H, W, 32), generator=g).cuda()
+    gfr = torch.zeros((F, H, W, 8), device="cuda")
+    pairs_backward(gp, 0, F - 1, -1, F - 1, gfr, scale=2.0)
+    wg = torch.zeros((F, 3, H, W))
+    gpp = torch.flip(gp[..., :6].permute(0, 3, 1, 2).cpu(), [0])                 # back to natural pair order
+    wg[0] = gpp[:, :3].sum(0)
+    wg[1:] += gpp[:, 3:]
+    assert (gfr[..., :3].permute(0, 3, 1, 2).cpu() - 2.0 * wg).abs().max().item() <= 1e-5
+    # relativistic average LSGAN, both ways, with gradients
+    a = torch.randn(37, generator=g, requires_grad=True)
+    b = torch.randn(37, generator=g, requires_grad=True)
+    L = 0.5 * (torch.nn.functional.mse_loss(a - b.mean(), torch.ones(37)) + torch.nn.functional.mse_loss(b - a.mean(), torch.zeros(37)))
+    L.backward()
+    ab = torch.zeros((2, 37, 32), device="cuda")
+    ab[0, :, 0], ab[1, :, 0] = a.detach().cuda(), b.detach().cuda()
+    gab, acc = torch.zeros_like(ab), torch.zeros(1, device="cuda")
+    _lib.call("fo_ralsgan", ops._ptr(ab[0]), 37, ops._ptr(ab[1]), 37, 32, C.c_float(1.0), C.c_float(0.0), C.c_float(0.5), ops._ptr(acc), None,
+              ops._ptr(gab[0]), ops._ptr(gab[1]), ops._stream())
+    np.testing.assert_allclose(acc.item(), L.item(), rtol=1e-5)
+    assert (gab[0, :, 0].cpu() - a.grad).abs().max().item() <= 1e-6 and (gab[1, :, 0].cpu() - b.grad).abs().max().item() <= 1e-6
