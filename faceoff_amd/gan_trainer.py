@@ -1,0 +1,130 @@
+"""The two-optimiser GAN iteration of the reference's disc_trainers/train_vqvae_mocoganhd_disc.py (:303-432, BASELINE
+config 5) on the MI355X engines: the VQ-VAE generator (VQVAEEngine) against a video discriminator (ModelD_3d) and an image
+discriminator (ModelD_img), relativistic average LSGAN, generator and discriminators updated on alternating iterations.
+
+    even iteration (:346-383)  G_loss = recon + latent + G_loss_2d + G_loss_3d  -> generator backward -> scheduler -> Adam(G)
+    odd iteration  (:385-432)  D_loss_3d -> Adam(D_3d, betas (0.5, .999));  D_loss (image) -> Adam(D_img, betas (0.5, .999))
+
+Every iteration first runs the generator on the clip in training mode (run_step :43-53; the EMA codebooks move on
+discriminator iterations too, as in the reference), cuts a window of `window` consecutive frames at a random offset (:332-335),
+pairs frame 0 of the window with every later frame on the channel axis for the video discriminator (:364-365,395-396, randomly
+reversed in time by flip_video :169-174) and with ONE random later frame for the image discriminator (:354-357,412-413).
+
+Not reproduced from the reference (documented in oracle/disc_oracle.py too): the generator branch repeats the first REAL frame
+window-2 instead of window-1 times (:364, a shape error at run time); `modelD.module.optim` presumes a DDP wrap.
+Random choices are drawn from a `random.Random` in the reference's call order, or passed in explicitly (tests)."""
+from __future__ import annotations
+
+import random as _random
+
+import torch
+
+from . import ops
+from .disc import DiscEngine, make_pairs, pairs_backward, ralsgan_pair
+from .engine import VQVAEEngine
+from .trainer import FlatAdam, LATENT_LOSS_WEIGHT
+
+
+class GANTrainer:
+    def __init__(self, engine: VQVAEEngine, disc3d: DiscEngine, disc2d: DiscEngine, lr=3e-4, d_lr=1e-4, scheduler=None, window=16,
+                 rng=None):
+        self.engine, self.d3, self.d2 = engine, disc3d, disc2d
+        self.optimizer = FlatAdam(engine, lr=lr)
+        self.scheduler = scheduler
+        self.d_lr = d_lr
+        self.window = window
+        self.rng = rng if rng is not None else _random.Random()
+        self.iteration = 0
+
+    # ------------------------------------------------------------------ the random choices, in the reference's call order
+    def draw(self, num_frames, generator_iteration):
+        r, w = self.rng, self.window
+        c = {"random_idx": r.randint(0, num_frames - w)}                      # :330
+        if generator_iteration:
+            c["frame_id"] = r.randint(1, w - 1)                               # :351
+            c["flip_real"] = r.randint(0, 1) == 0                             # flip_video(real) :368
+            c["flip_fake"] = r.randint(0, 1) == 0                             # flip_video(fake) :369
+        else:
+            c["flip_fake"] = r.randint(0, 1) == 0                             # :392
+            c["flip_real"] = r.randint(0, 1) == 0                             # :393
+            c["frame_id"] = r.randint(1, w - 1)                               # :411
+        return c
+
+    # ------------------------------------------------------------------ discriminator inputs for one window
+    def _video_pairs(self, dec_win, gt_win, c):
+        """-> x [2][w-1][H][W][32]: sample 0 = fake pairs, sample 1 = real pairs."""
+        w = self.window
+        _, H, W, _ = dec_win.shape
+        x = torch.empty((2, w - 1, H, W, 32), device=self.engine.device)
+        for n, (src, nchw, flip) in enumerate(((dec_win, False, c["flip_fake"]), (gt_win, True, c["flip_real"]))):
+            first, step = (w - 1, -1) if flip else (1, 1)
+            make_pairs(src, nchw, 0, first, step, w - 1, x[n])
+        return x
+
+    def _image_pairs(self, dec_win, gt_win, c):
+        _, H, W, _ = dec_win.shape
+        x = torch.empty((2, 1, H, W, 32), device=self.engine.device)
+        make_pairs(dec_win, False, 0, c["frame_id"], 1, 1, x[0])
+        make_pairs(gt_win, True, 0, c["frame_id"], 1, 1, x[1])
+        return x
+
+    # ------------------------------------------------------------------ one iteration
+    def step(self, img, ground_truth, choices=None):
+        """img [N,6,H,W] (one clip of N >= window frames, utils.py:29-38), ground_truth [N,3,H,W].  Returns a dict of
+        device scalars; which keys depends on the iteration's parity (generator: recon, latent, g_loss_2d, g_loss_3d;
+        discriminator: recon, latent, d_loss_3d, d_loss_2d)."""
+        eng = self.engine
+        gen_iter = self.iteration % 2 == 0                                    # :338-341
+        self.iteration += 1
+        N = img.shape[0]
+        c = choices if choices is not None else self.draw(N, gen_iter)
+        w, r = self.window, c["random_idx"]
+        assert N >= w and 0 <= r <= N - w
+        S = eng.forward(img, training=True, T=N)
+        dec = S["dec"]
+        acc = torch.zeros(1, device=eng.device)
+        ops.mse_slice_fwd(dec, ground_truth, acc)
+        out = {"recon": acc / float(ground_truth.numel()), "latent": S["diff"]}
+        dec_win, gt_win = dec[r:r + w], ground_truth[r:r + w]
+        if gen_iter:
+            one = torch.ones(1, device=eng.device)
+            g_dec = torch.empty_like(dec)
+            ops.mse_slice_bwd(dec, ground_truth, one, g_dec)
+            g_win = g_dec[r:r + w]
+            # image discriminator: module calls fake, then real (:354,357); only the fake logits reach the generator
+            x2 = self._image_pairs(dec_win, gt_win, c)
+            S2 = self.d2.forward(x2, training=True, sample_order=[0, 1])
+            l2 = torch.zeros(1, device=eng.device)
+            g2 = ralsgan_pair(S2["logits"], 0, 1, 1.0, 0.0, 0.5, l2, want_gb=False)
+            gx2 = self.d2.backward(S2, g2, param_grads=False, input_grad=True)
+            pairs_backward(gx2[0], 0, c["frame_id"], 1, 1, g_win)
+            # video discriminator: module calls real, then fake (:368-369)
+            x3 = self._video_pairs(dec_win, gt_win, c)
+            S3 = self.d3.forward(x3, training=True, sample_order=[1, 0])
+            l3 = torch.zeros(1, device=eng.device)
+            g3 = ralsgan_pair(S3["logits"], 0, 1, 1.0, 0.0, 0.5, l3, want_gb=False)
+            gx3 = self.d3.backward(S3, g3, param_grads=False, input_grad=True)
+            first, step = (w - 1, -1) if c["flip_fake"] else (1, 1)
+            pairs_backward(gx3[0], 0, first, step, w - 1, g_win)
+            eng.backward(S, g_dec, one * LATENT_LOSS_WEIGHT)                  # G_loss = recon + latent + G_2d + G_3d (:375)
+            if self.scheduler is not None:
+                self.scheduler.step()                                         # :380-381, before the optimiser
+            self.optimizer.step()
+            out.update(g_loss_2d=l2, g_loss_3d=l3)
+        else:
+            # video discriminator: module calls fake, then real (:392-393); both logits carry gradient to its parameters
+            x3 = self._video_pairs(dec_win, gt_win, c)
+            S3 = self.d3.forward(x3, training=True, sample_order=[0, 1])
+            l3 = torch.zeros(1, device=eng.device)
+            g3 = ralsgan_pair(S3["logits"], 1, 0, 1.0, 0.0, 0.5, l3)
+            self.d3.backward(S3, g3, param_grads=True, input_grad=False)
+            self.d3.adam_step(self.d_lr)
+            # image discriminator: module calls real, then fake (:412-413)
+            x2 = self._image_pairs(dec_win, gt_win, c)
+            S2 = self.d2.forward(x2, training=True, sample_order=[1, 0])
+            l2 = torch.zeros(1, device=eng.device)
+            g2 = ralsgan_pair(S2["logits"], 1, 0, 1.0, 0.0, 0.5, l2)
+            self.d2.backward(S2, g2, param_grads=True, input_grad=False)
+            self.d2.adam_step(self.d_lr)
+            out.update(d_loss_3d=l3, d_loss_2d=l2)
+        return out
