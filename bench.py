@@ -75,6 +75,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-c3", action="store_true", help="skip the short config-3 leg")
     ap.add_argument("--no-direct-leg", action="store_true", help="skip the short direct-convolution leg")
+    ap.add_argument("--no-c5", action="store_true", help="skip the short config-5 (GAN iteration) leg")
     ap.add_argument("--lpips-dtype", choices=("bf16", "fp32"), default="bf16",
                     help="arithmetic of the LPIPS / VGG-16 branch (BASELINE config 3 = bf16)")
     ap.add_argument("--direct-conv", action="store_true",
@@ -331,6 +332,33 @@ def main():
                      "speed_vs_ideal_direct_conv": round(ideal_c * fps_c / world, 4),
                      "loss": {"recon": round(r_c.item(), 6), "latent": round(l_c.item(), 6), "perceptual": round(p_c.item(), 6)}}
         del eng_c, tr_c
+        torch.cuda.empty_cache()
+
+    # ------------------------------------------------------------------ BASELINE config 5: the two-optimiser GAN iteration
+    if not args.no_c5 and not args.perceptual and not args.direct_conv:
+        from faceoff_amd.disc import DiscEngine
+        from faceoff_amd.gan_trainer import GANTrainer
+        from faceoff_amd.synth import make_disc_state
+        import random as _random
+        clip, win = 30, 16            # one clip of up to 30 frames per iteration (TemporalAlignmentDataset('train', 30)), 16-frame window
+        eng_g = VQVAEEngine(make_state_dict(0, codebook_scale=0.3, gain=2.0), dev)
+        gan = GANTrainer(eng_g, DiscEngine(make_disc_state(1, 3), dev, dims=3, n_frames=win - 1), DiscEngine(make_disc_state(2, 2), dev, dims=2),
+                         window=win, rng=_random.Random(7 + rank))
+        cimg, cgt = img[:clip].contiguous(), gt[:clip].contiguous()
+        for _ in range(2):
+            gan.step(cimg, cgt)
+        sync()
+        t0 = time.perf_counter()
+        iters = 6                     # 3 generator + 3 discriminator iterations
+        for _ in range(iters):
+            o5 = gan.step(cimg, cgt)
+        sync()
+        dt5 = max_over_ranks(time.perf_counter() - t0)
+        out["c5"] = {"workload": f"C5: GAN iteration of disc_trainers/train_vqvae_mocoganhd_disc.py on one {clip}-frame clip per GPU, {H}x{H}: "
+                                 f"VQ-VAE generator + MoCoGAN-HD video (15 frame pairs) and image discriminators, RaLSGAN, alternating G / D updates",
+                     "value": round(world * clip * iters / dt5, 2), "unit": "frames/s", "ms_per_iteration": round(dt5 / iters * 1e3, 3),
+                     "iterations": iters, "dtype": "f32", "loss": {k: round(v.item(), 6) for k, v in o5.items()}}
+        del gan, eng_g
         torch.cuda.empty_cache()
 
     if rank != 0:

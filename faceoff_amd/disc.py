@@ -83,10 +83,10 @@ class DiscEngine:
             out[k] = self.params[k] if k in self.params else self.buffers[k]
         return out
 
-    def adam_step(self, lr, betas=(0.5, 0.999), eps=1e-8):
+    def adam_step(self, lr, betas=(0.5, 0.999), eps=1e-8, grad_scale=1.0):
         """torch.optim.Adam(netD.parameters(), lr, betas=(0.5, 0.999)) (mocoganhd_video_disc.py:24-26) as one launch."""
         self.t += 1
-        ops.adam_flat(self.flat_params, self.flat_grads, self.m, self.v, lr, self.t, betas, eps)
+        ops.adam_flat(self.flat_params, self.flat_grads, self.m, self.v, lr, self.t, betas, eps, grad_scale)
 
     # ------------------------------------------------------------------ helpers
     def _desc(self, N, src_dims, cs, ld_s, dst_dims, cd, ld_d, stride, flags=0, ld_mask=0):

@@ -20,6 +20,7 @@ import random as _random
 import torch
 
 from . import ops
+from .distributed import fused_vq_allreduce, get_world_size
 from .disc import DiscEngine, make_pairs, pairs_backward, ralsgan_pair
 from .engine import VQVAEEngine
 from .trainer import FlatAdam, LATENT_LOSS_WEIGHT
@@ -35,6 +36,17 @@ class GANTrainer:
         self.window = window
         self.rng = rng if rng is not None else _random.Random()
         self.iteration = 0
+        # data parallel (the reference wraps generator and both discriminators in DDP): every rank runs its own clip, the
+        # flat gradient arenas are summed over ranks in one all-reduce each and averaged inside the Adam launch; the VQ
+        # statistics are summed in the forward (vqvae_conv3d_latent.py:63-64)
+        self.world = get_world_size()
+        if self.world > 1:
+            engine.vq_allreduce = fused_vq_allreduce()
+
+    def _sum_over_ranks(self, flat):
+        if self.world > 1:
+            torch.distributed.all_reduce(flat)
+        return 1.0 / self.world
 
     # ------------------------------------------------------------------ the random choices, in the reference's call order
     def draw(self, num_frames, generator_iteration):
@@ -109,7 +121,7 @@ class GANTrainer:
             eng.backward(S, g_dec, one * LATENT_LOSS_WEIGHT)                  # G_loss = recon + latent + G_2d + G_3d (:375)
             if self.scheduler is not None:
                 self.scheduler.step()                                         # :380-381, before the optimiser
-            self.optimizer.step()
+            self.optimizer.step(grad_scale=self._sum_over_ranks(eng.flat_grads))
             out.update(g_loss_2d=l2, g_loss_3d=l3)
         else:
             # video discriminator: module calls fake, then real (:392-393); both logits carry gradient to its parameters
@@ -118,13 +130,13 @@ class GANTrainer:
             l3 = torch.zeros(1, device=eng.device)
             g3 = ralsgan_pair(S3["logits"], 1, 0, 1.0, 0.0, 0.5, l3)
             self.d3.backward(S3, g3, param_grads=True, input_grad=False)
-            self.d3.adam_step(self.d_lr)
+            self.d3.adam_step(self.d_lr, grad_scale=self._sum_over_ranks(self.d3.flat_grads))
             # image discriminator: module calls real, then fake (:412-413)
             x2 = self._image_pairs(dec_win, gt_win, c)
             S2 = self.d2.forward(x2, training=True, sample_order=[1, 0])
             l2 = torch.zeros(1, device=eng.device)
             g2 = ralsgan_pair(S2["logits"], 1, 0, 1.0, 0.0, 0.5, l2)
             self.d2.backward(S2, g2, param_grads=True, input_grad=False)
-            self.d2.adam_step(self.d_lr)
+            self.d2.adam_step(self.d_lr, grad_scale=self._sum_over_ranks(self.d2.flat_grads))
             out.update(d_loss_3d=l3, d_loss_2d=l2)
         return out

@@ -219,3 +219,43 @@ def test_avgpool_instnorm_pairs_ralsgan_vs_torch():
               ops._ptr(gab[0]), ops._ptr(gab[1]), ops._stream())
     np.testing.assert_allclose(acc.item(), L.item(), rtol=1e-5)
     assert (gab[0, :, 0].cpu() - a.grad).abs().max().item() <= 1e-6 and (gab[1, :, 0].cpu() - b.grad).abs().max().item() <= 1e-6
+
+
+@pytest.mark.parametrize("tag,dims", [("v", 3), ("i", 2)])
+def test_module_mirror_runs_the_reference_discriminator_update(golden_dir, tag, dims):
+    """The reference's own lines (train_vqvae_mocoganhd_disc.py:392-408,428-432) on the mirrored classes through the
+    reference's import paths: D(fake), D(real), Relativistic_Average_LSGAN both ways, optim.zero_grad / backward / step --
+    losses, parameter gradients, the gradient reaching the fake input, and the updated parameters against the goldens."""
+    from TemporalAlignment.models.mocoganhd_video_disc import ModelD_3d
+    from TemporalAlignment.models.mocoganhd_content_disc import ModelD_img
+    from TemporalAlignment.models import mocoganhd_losses
+    g = np.load(os.path.join(golden_dir, "disc_kat.npz"))
+    real, fake, F = _inputs(g, tag, dims)
+    m = (ModelD_3d(nc=3, norm_D_3d="instance", num_D=2, lr=1e-4, cross_domain=False, n_frames_G=F) if dims == 3
+         else ModelD_img(nc=3, norm_D_3d="instance", num_D=2, lr=1e-4)).to("cuda")
+    sd = make_disc_state(int(g[f"{tag}_seed_w"]), dims)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    assert list(m.state_dict()) == list(sd)
+    m.train()
+    fake = fake.cuda().requires_grad_(True)
+    D_fake = m(fake)
+    D_real = m(real.cuda())
+    assert [tuple(t.shape) for t in D_fake[0]][-1] == g[f"{tag}_fake_s0_logits"].shape
+    criterionGAN = mocoganhd_losses.Relativistic_Average_LSGAN()
+    D_loss_real = criterionGAN(D_real, D_fake, True)
+    D_loss_fake = criterionGAN(D_fake, D_real, False)
+    D_loss = (D_loss_real + D_loss_fake) * 0.5
+    m.optim.zero_grad()
+    D_loss.backward()
+    np.testing.assert_allclose([D_loss_real.item(), D_loss_fake.item()], [g[f"{tag}_d_loss_real"], g[f"{tag}_d_loss_fake"]], rtol=1e-3)
+    names = [str(n) for n in g[f"{tag}_param_names"]]
+    params = dict(m.named_parameters())
+    got = np.concatenate([_sub(params[n].grad) for n in names])
+    want = g[f"{tag}_d_grad_sub"]
+    assert np.abs(got - want).max() <= 1e-3 * np.abs(want).max()
+    wsub = g[f"{tag}_d_gfake_sub"]
+    assert np.abs(_sub(fake.grad) - wsub).max() <= 1e-3 * np.abs(wsub).max()
+    m.optim.step()
+    after = np.concatenate([_sub(params[n]) for n in names])
+    big = np.abs(want) > 1e-3 * np.abs(want).max()
+    assert np.abs(after - g[f"{tag}_param_after_sub"])[big].max() <= 5e-6
