@@ -109,6 +109,8 @@ SIGNATURES.update({
     "fo_avgpool3_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "fo_disc_pairs": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P]),
     "fo_disc_pairs_bwd": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _F, _P]),
+    "fo_affine_warp": (_I, [_P, _P, _I, _I, _I, _I, C.POINTER(C.c_float), _I, _P]),
+    "fo_denorm_u8": (_I, [_P, _I, _I, _I, _P, _I, _I, _I, _I, _P]),
     "fo_ralsgan": (_I, [_P, _I, _P, _I, _I, _F, _F, _F, _P, _P, _P, _P, _P]),
 })
 

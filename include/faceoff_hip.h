@@ -208,6 +208,17 @@ int fo_wino_output(const float* M, const float* bias, const float* mask, int ldM
 int fo_wino_gradout(const float* g, int ldg, float* dM, int N, int H, int W, int C, int m, void* stream);
 int fo_wino_wgrad_out(const float* dU /* [(m+2)^2][O][I][KD] */, float* dW, int O, int I, int KD, int m, void* stream);
 
+/* ---------------------------------------------------------------- input pipeline / validation helpers on the device
+ * dst[n][c] = warp of src[n][c] ([N][C][H][W] frames) by the affine map M (6 floats, HOST pointer, row-major 2x3) taking
+ * DESTINATION pixel (x, y) to its SOURCE position -- what cv2.warpAffine applies after inverting its argument
+ * (TemporalAlignment/perturbations.py:45-83) -- zero outside the image; mode 0 = bilinear, 1 = bicubic (A = -0.75, the
+ * INTER_CUBIC kernel of cv2.resize, :88).  Exact arithmetic: OpenCV's 1/32-pixel coordinate quantisation is not reproduced. */
+int fo_affine_warp(const float* src, float* dst, int N, int C, int H, int W, const float* M_dst_to_src, int mode, void* stream);
+/* out[n][y][x][3] uint8 = (uint8)(255 * (clamp(v, -1, 1) + 1) / 2) of channels c0..c0+2: `denormalize` + the uint8 cast of
+ * the validation videos (train_faceoff_perceptual.py:71-77, utils.py:9-17).  src: [N][C][H][W] (ld = 0) or channels-last with
+ * pixel stride ld (C unused).  bgr != 0 swaps to BGR (cv2.cvtColor(..., COLOR_RGB2BGR)). */
+int fo_denorm_u8(const float* src, int ld, int C, int c0, uint8_t* out, int N, int H, int W, int bgr, void* stream);
+
 /* ---------------------------------------------------------------- MoCoGAN-HD discriminators (BASELINE config 5)
  * Replaces the cuDNN kernels behind ModelD_3d / ModelD_img (TemporalAlignment/models/mocoganhd_video_disc.py:8-176,
  * mocoganhd_content_disc.py:8-165): Conv3d / Conv2d k4 s2|s1 p2 forward, data gradient, filter gradient;
