@@ -34,6 +34,8 @@ def label(name):
         return f"conv_igemm_bn{m.group(1)}" + ("_smallc" if small else "")
     if "conv_igemm3_kernel" in name:
         return "conv_igemm3"
+    if "wino_gemm_kernel" in name:
+        return "wino_gemm"
     m = re.search(r"conv_wgrad_kernel<(\d+), *(\d+)", name)
     if m:
         return f"conv_wgrad_tile{m.group(1)}x{m.group(2)}"
@@ -119,6 +121,7 @@ def main():
                          f"{fmt(wa/wc if wa and wc else None)} | {fmt(ldsb/wc if ldsb is not None and wc else None, '{:.4f}')} | "
                          f"{fmt(rd/1e6 if rd is not None else None, '{:.1f}')} | {fmt(wrb/1e6 if wrb is not None else None, '{:.1f}')} | "
                          f"{fmt(hit/(hit+miss) if hit is not None and miss is not None and hit+miss > 0 else None)} |\n")
+        traffic["_source"] = f"profiles/{tag}_pmc.md"
         with open(os.path.join(out, "pmc_traffic.json"), "w") as fh:
             json.dump(traffic, fh, indent=1)
     print("summaries written to", out)
