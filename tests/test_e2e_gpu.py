@@ -251,3 +251,35 @@ def test_winograd_and_direct_conv3d_engines_agree():
         assert err.max().item() <= 1e-3 * scale, (k, err.max().item() / scale)
     worst = sorted((w[5][k] - d[5][k]).abs().max().item() / (d[5][k].abs().max().item() + 1e-30) for k in d[5])
     assert worst[len(worst) // 2] <= 1e-4, worst[len(worst) // 2]        # the typical tensor is an order of magnitude closer
+
+
+def test_three_training_steps_track_the_oracle():
+    """Parity over consecutive iterations (zero_grad -> forward -> backward -> Adam, EMA codebooks moving; reference
+    train_faceoff_perceptual.py:93-107): the losses of steps 2 and 3 depend on step 1's parameter update and codebook
+    update.  Adam's first steps move every parameter by ~lr * sign(g), so a gradient that is zero up to rounding may move
+    its parameter the other way (2 lr apart): losses and EMA codebooks within 1e-3 / 2e-3 at every step, parameters after three
+    steps within 3 x 2.1 lr everywhere and within 3e-5 for at least 99 % of the 4 M elements."""
+    from faceoff_amd.engine import VQVAEEngine
+    from faceoff_amd.trainer import FaceOffTrainer
+    from oracle import faceoff_oracle as O
+    B, T, H, W = 2, 2, 64, 64
+    sd = make_state_dict(6, codebook_scale=0.3, gain=2.0)
+    img, gt = make_batch(21, B, T, H, W)
+    p, st = O.to_torch_state(sd), {}
+    eng = VQVAEEngine(sd, "cuda:0")
+    tr = FaceOffTrainer(eng, lr=3e-4)
+    x, y = torch.from_numpy(img).cuda(), torch.from_numpy(gt).cuda()
+    for step in range(3):
+        r = O.train_step(torch.from_numpy(img), torch.from_numpy(gt), p, adam_state=st)
+        recon, latent, _ = tr.step(x, y)
+        np.testing.assert_allclose([recon.item(), latent.item()], [r["recon"].item(), r["latent"].item()], rtol=1e-3, err_msg=f"step {step}")
+        for k in eng.buffers:
+            assert _rel(eng.buffers[k].cpu().numpy(), p[k].numpy()) < 2e-3, (step, k)
+    lr = 3e-4
+    off = tot = 0
+    for k, g in r["grads"].items():
+        d = (eng.params[k].cpu() - p[k].detach()).abs()
+        assert d.max().item() <= 3 * 2.1 * lr, k                      # at worst one sign flip per step
+        off += int((d > 3e-5).sum())
+        tot += d.numel()
+    assert off <= 0.01 * tot, (off, tot)                              # ... and that is rare
