@@ -275,6 +275,201 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvArgsH a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------ big tiles
+// 256 x BN tile, ONE workgroup per CU with 8 waves (two per SIMD), each wave (TM x TN) 32x32 accumulators (128 x 64 for the
+// 256 x 256 tile).  Why: at the bf16 rate a 128 x 128 tile with 2 x 2 accumulators per wave asks for ~39 TB/s from L2 (32 KB
+// per 2.1 MFLOP K-step) and ~190 B/clk from LDS (every fragment feeds only 2 MFMAs) -- both beyond the hardware.  256 x 256
+// halves the L2 bytes per FLOP, 4 x 2 accumulators per wave cut the LDS reads per MFMA by a third, and a K-step becomes
+// 64 MFMAs per wave x 2 waves per SIMD = ~4000 cycles -- longer than an HBM miss -- so a one-deep prefetch (loads of step
+// n+1 issued before step n's MFMAs, stored to the other LDS buffer behind them) covers the memory latency, while the two
+// waves of a SIMD cover each other's fragment reads and barrier waits.  Epilogue: each wave transposes its accumulators 32
+// rows at a time through its own LDS patch (wave-local) so that bias / ReLU / mask / rounding / stores are 16 B per lane.
+// Stride-1, same-size convolutions with Cin % 64 == 0 (every LPIPS layer but the RGB one).
+template <int BN, int WAVES_M, int WAVES_N, int TM, int TN>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 1) void conv_bf16_big_kernel(const ConvArgsH a) {
+  constexpr int NT = 64 * WAVES_M * WAVES_N;              // threads
+  constexpr int BMB = WAVES_M * TM * 32;
+  static_assert(WAVES_N * TN * 32 == BN && BMB == 256, "tile");
+  constexpr int RP = NT / 8;                              // rows per loader pass (8 threads x 16 B per 128-B row)
+  constexpr int AR = BMB / RP, BR = BN / RP;
+  static_assert(AR >= 1 && BR >= 1, "loader passes");
+  constexpr int C_LD = TN * 32 + 4;                       // floats per row of a wave's epilogue patch
+  static_assert(WAVES_M * WAVES_N * 32 * C_LD * 4 <= 2 * (BMB + BN) * ROWB, "epilogue patches must fit the staging LDS");
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  unsigned char* As0 = lds;
+  unsigned char* Bs0 = lds + 2 * BMB * ROWB;
+
+  const fo_conv_desc& d = a.d;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int logical = fo_xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_n = logical % a.tilesN;
+  const int tile_m = logical / a.tilesN;
+  const int ntaps = d.KH * d.KW;
+
+  const int lrow = tid >> 3;
+  const int lcolB = (tid & 7) * 16;
+  int rowoff[AR];
+  unsigned tapmask[AR];
+#pragma unroll
+  for (int i = 0; i < AR; ++i) {
+    const int m = tile_m * BMB + lrow + RP * i;
+    const bool pv = m < a.M;
+    const int mm = pv ? m : 0;
+    const int n = mm / a.HWm;
+    const int rem = mm - n * a.HWm;
+    const int y = rem / d.Wm;
+    const int x = rem - y * d.Wm;
+    const int py = y - d.padH, px = x - d.padW;
+    rowoff[i] = ((n * d.Hin + py) * d.Win + px) * d.ldIn * 2 + lcolB;
+    unsigned mk = 0;
+    for (int tp = 0; tp < ntaps; ++tp) {
+      const int kh = tp / d.KW, kw = tp - kh * d.KW;
+      const bool ok = pv & ((unsigned)(py + kh) < (unsigned)d.Hin) & ((unsigned)(px + kw) < (unsigned)d.Win);
+      mk |= (ok ? 1u : 0u) << tp;
+    }
+    tapmask[i] = mk;
+  }
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in), 0, a.inBytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rwp = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wp), 0, a.wpBytes, 0x00020000);
+  const unsigned wrow = (unsigned)(((size_t)(tile_n * BN + lrow) * a.Ktot) * 2 + lcolB);
+  const unsigned wstrideRP = (unsigned)((size_t)RP * a.Ktot * 2);
+
+  int ld_step = 0, ld_tap = 0, ld_kh = 0, ld_kw = 0, ld_chunk = 0;
+  u32x4 ra[AR], rb[BR];
+  auto load_step = [&]() {
+    const int stepoff = ((ld_kh * d.Win + ld_kw) * d.ldIn + ld_chunk * 64) * 2;
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+      const unsigned pad = (((tapmask[i] >> ld_tap) & 1u) - 1u) & OOB;
+      ra[i] = bufload16(rin, (unsigned)(rowoff[i] + stepoff) | pad);
+    }
+#pragma unroll
+    for (int i = 0; i < BR; ++i) rb[i] = bufload16(rwp, ld_step < a.ksteps ? wrow + i * wstrideRP + ld_step * 128 : OOB);
+    ++ld_step;
+    if (++ld_chunk == a.cinChunks) {
+      ld_chunk = 0;
+      ++ld_tap;
+      if (++ld_kw == d.KW) { ld_kw = 0; ++ld_kh; }
+    }
+  };
+  auto store_rows = [&](int buf, int lo, int hi) {       // passes lo..hi-1 of the combined (A then B) row-pass list
+    unsigned char* As = As0 + buf * BMB * ROWB;
+    unsigned char* Bs = Bs0 + buf * BN * ROWB;
+#pragma unroll
+    for (int i = 0; i < AR + BR; ++i) {
+      if (i < lo || i >= hi) continue;
+      if (i < AR) *reinterpret_cast<u32x4*>(As + (lrow + RP * i) * ROWB + lcolB) = ra[i];
+      else *reinterpret_cast<u32x4*>(Bs + (lrow + RP * (i - AR)) * ROWB + lcolB) = rb[i - AR];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  load_step();
+  store_rows(0, 0, AR + BR);
+  __syncthreads();
+  const int nsteps = a.ksteps;
+  int cur = 0;
+  for (int step = 0; step < nsteps; ++step) {
+    const unsigned char* As = As0 + cur * BMB * ROWB + (wm * TM * 32 + l31) * ROWB + half * 16;
+    const unsigned char* Bs = Bs0 + cur * BN * ROWB + (wn * TN * 32 + l31) * ROWB + half * 16;
+    load_step();                                          // step + 1 (past the end: zeros, never used)
+    bf16x8 fa[2][TM], fb[2][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const bf16x8*>(As + i * 32 * ROWB);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb[0][j] = *reinterpret_cast<const bf16x8*>(Bs + j * 32 * ROWB);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (s < 3) {                                        // fragments of the next 16-deep slice land under this slice's MFMAs
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[(s + 1) & 1][i] = *reinterpret_cast<const bf16x8*>(As + i * 32 * ROWB + (s + 1) * 32);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[(s + 1) & 1][j] = *reinterpret_cast<const bf16x8*>(Bs + j * 32 * ROWB + (s + 1) * 32);
+      }
+      // the LDS stores of step + 1 ride behind the last two slices' MFMAs
+      if (s == 2) store_rows(cur ^ 1, 0, (AR + BR) / 2);
+      if (s == 3) store_rows(cur ^ 1, (AR + BR) / 2, AR + BR);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s & 1][i], fb[s & 1][j], acc[i][j], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- epilogue: 32 rows of this wave's tile at a time through its own LDS patch
+  float* Cs = reinterpret_cast<float*>(lds) + wave * 32 * C_LD;
+  const int flags = d.flags;
+  constexpr int C8 = TN * 4;                              // 8-channel groups per patch row
+  constexpr int RPP = 64 / C8;                            // patch rows per pass of the wave
+  const int c8 = lane % C8, r0 = lane / C8;
+  const int co = tile_n * BN + wn * TN * 32 + c8 * 8;
+  float bv[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bv[e] = ((flags & FO_BIAS) && co + e < d.Cout) ? a.bias[co + e] : 0.f;
+  __bf16* out = reinterpret_cast<__bf16*>(a.out);
+  const __bf16* mask = reinterpret_cast<const __bf16*>(a.mask);
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Cs[((r & 3) + 8 * (r >> 2) + 4 * half) * C_LD + j * 32 + l31] = acc[i][j][r];
+    __builtin_amdgcn_wave_barrier();
+    const int mbase = tile_m * BMB + (wm * TM + i) * 32;
+#pragma unroll
+    for (int p = 0; p < 32 / RPP; ++p) {
+      const int row = p * RPP + r0;
+      const int m = mbase + row;
+      const float* crow = Cs + row * C_LD + c8 * 8;
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(crow);
+      const f32x4 v1 = *reinterpret_cast<const f32x4*>(crow + 4);
+      if (m >= a.M || co >= d.Cout) continue;
+      float v[8] = {v0.x + bv[0], v0.y + bv[1], v0.z + bv[2], v0.w + bv[3], v1.x + bv[4], v1.y + bv[5], v1.z + bv[6], v1.w + bv[7]};
+      if (flags & FO_MASK) {
+        const bf16x8 mk = *reinterpret_cast<const bf16x8*>(mask + (size_t)m * d.ldMask + co);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (float)mk[e] > 0.f ? v[e] : 0.f;
+      }
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (__bf16)((flags & FO_OUT_RELU) ? fmaxf(v[e], 0.f) : v[e]);
+      *reinterpret_cast<bf16x8*>(out + (size_t)m * d.ldOut + co) = o;
+    }
+  }
+}
+
+template <int BN, int WAVES_M, int WAVES_N, int TM, int TN>
+int launch_big(const ConvArgsH& a, hipStream_t s) {
+  constexpr int ldsBytes = 2 * (256 + BN) * ROWB;
+  static bool attr_set = false;                            // > 64 KB of dynamic LDS needs the opt-in once per process
+  auto kern = conv_bf16_big_kernel<BN, WAVES_M, WAVES_N, TM, TN>;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, ldsBytes) != hipSuccess) {
+      fo_set_error("conv_bf16: cannot reserve %d bytes of LDS", ldsBytes);
+      return FO_E_HIP;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(a.tilesM * a.tilesN), dim3(64 * WAVES_M * WAVES_N), ldsBytes, s, a);
+  FO_CHECK_LAUNCH();
+  return FO_OK;
+}
+
 template <int BN, int WAVES_M, int WAVES_N, int TM, int TN>
 int launch(const ConvArgsH& a, bool smallc, hipStream_t s) {
   const int grid = a.tilesM * a.tilesN;
@@ -369,6 +564,28 @@ int fo_conv_igemm_bf16(const fo_conv_desc* d, const void* in, const void* wp, co
   a.inBytes = (unsigned)inBytes;
   a.wpBytes = (unsigned)wpBytes;
   hipStream_t s = (hipStream_t)stream;
+  // big tiles (one workgroup per CU) where the launch still fills the chip for a few rounds: stride-1 same-size convs
+  const bool same = d->stride == 1 && d->ostride == 1 && d->Hm == d->Hout && d->Wm == d->Wout && d->Hin == d->Hm && d->Win == d->Wm;
+  const char* nobig = getenv("FACEOFF_BF16_SMALL_TILES");
+  if (!smallc && same && !(nobig && atoi(nobig)) && d->Cout >= 64 && d->Cout % 64 == 0) {
+    const int tilesM256 = (a.M + 255) / 256;
+    const char* force = getenv("FACEOFF_BF16_BIG_TILES");          // tests: big tiles at any size
+    const int cus = (force && atoi(force)) ? 0 : fo_cu_count();
+    const char* var = getenv("FACEOFF_BF16_VARIANT");               // diagnostics: 4 = four-wave variants
+    const int v4 = var && atoi(var) == 4;
+    if (d->Cout % 256 == 0 && (long long)tilesM256 * (d->Cout / 256) >= 3ll * cus) {
+      a.tilesM = tilesM256; a.tilesN = d->Cout / 256;
+      return v4 ? launch_big<256, 2, 2, 4, 4>(a, s) : launch_big<256, 2, 4, 4, 2>(a, s);
+    }
+    if (d->Cout % 128 == 0 && d->Cout % 256 != 0 && (long long)tilesM256 * (d->Cout / 128) >= 3ll * cus) {
+      a.tilesM = tilesM256; a.tilesN = d->Cout / 128;
+      return v4 ? launch_big<128, 2, 2, 4, 2>(a, s) : launch_big<128, 4, 2, 2, 2>(a, s);
+    }
+    if (d->Cout == 64 && (long long)tilesM256 >= 3ll * cus) {
+      a.tilesM = tilesM256; a.tilesN = 1;
+      return v4 ? launch_big<64, 4, 1, 2, 2>(a, s) : launch_big<64, 8, 1, 1, 2>(a, s);
+    }
+  }
   if (d->Cout > 64) {
     a.tilesN = (d->Cout + 127) / 128;
     return launch<128, 2, 2, 2, 2>(a, smallc, s);
