@@ -277,7 +277,8 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvArgsH a) {
 
 // ------------------------------------------------------------------------------------------------ big tiles
 // 256 x BN tile, ONE workgroup per CU with 8 waves (two per SIMD), each wave (TM x TN) 32x32 accumulators (128 x 64 for the
-// 256 x 256 tile).  Why: at the bf16 rate a 128 x 128 tile with 2 x 2 accumulators per wave asks for ~39 TB/s from L2 (32 KB
+// 256 x 256 tile; a four-wave 128 x 128-per-wave form measured 15 % slower: one wave per SIMD leaves nobody to cover its
+// fragment reads and barrier waits).  Why: at the bf16 rate a 128 x 128 tile with 2 x 2 accumulators per wave asks for ~39 TB/s from L2 (32 KB
 // per 2.1 MFLOP K-step) and ~190 B/clk from LDS (every fragment feeds only 2 MFMAs) -- both beyond the hardware.  256 x 256
 // halves the L2 bytes per FLOP, 4 x 2 accumulators per wave cut the LDS reads per MFMA by a third, and a K-step becomes
 // 64 MFMAs per wave x 2 waves per SIMD = ~4000 cycles -- longer than an HBM miss -- so a one-deep prefetch (loads of step
@@ -571,19 +572,22 @@ int fo_conv_igemm_bf16(const fo_conv_desc* d, const void* in, const void* wp, co
     const int tilesM256 = (a.M + 255) / 256;
     const char* force = getenv("FACEOFF_BF16_BIG_TILES");          // tests: big tiles at any size
     const int cus = (force && atoi(force)) ? 0 : fo_cu_count();
-    const char* var = getenv("FACEOFF_BF16_VARIANT");               // diagnostics: 4 = four-wave variants
-    const int v4 = var && atoi(var) == 4;
+    // measured at the C3 shapes (tools/bench_bf16.py): 256-column tiles win everywhere they apply (conv3_x / conv4_x forward
+    // 820-860 -> 1000-1050 TFLOP/s, masked data gradients 775-845 -> 860-990); the 128- and 64-column variants lose to
+    // the two-workgroups-per-CU kernel on their short-K layers (K = 576 / 1152: the unoverlapped prologue and epilogue of a
+    // lone workgroup) and are only taken when forced (tests)
+    const bool forced = force && atoi(force);
     if (d->Cout % 256 == 0 && (long long)tilesM256 * (d->Cout / 256) >= 3ll * cus) {
       a.tilesM = tilesM256; a.tilesN = d->Cout / 256;
-      return v4 ? launch_big<256, 2, 2, 4, 4>(a, s) : launch_big<256, 2, 4, 4, 2>(a, s);
+      return launch_big<256, 2, 4, 4, 2>(a, s);
     }
-    if (d->Cout % 128 == 0 && d->Cout % 256 != 0 && (long long)tilesM256 * (d->Cout / 128) >= 3ll * cus) {
+    if (forced && d->Cout % 128 == 0) {
       a.tilesM = tilesM256; a.tilesN = d->Cout / 128;
-      return v4 ? launch_big<128, 2, 2, 4, 2>(a, s) : launch_big<128, 4, 2, 2, 2>(a, s);
+      return launch_big<128, 4, 2, 2, 2>(a, s);
     }
-    if (d->Cout == 64 && (long long)tilesM256 >= 3ll * cus) {
+    if (forced && d->Cout == 64) {
       a.tilesM = tilesM256; a.tilesN = 1;
-      return v4 ? launch_big<64, 4, 1, 2, 2>(a, s) : launch_big<64, 8, 1, 1, 2>(a, s);
+      return launch_big<64, 8, 1, 1, 2>(a, s);
     }
   }
   if (d->Cout > 64) {
