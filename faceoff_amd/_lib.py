@@ -47,6 +47,7 @@ SIGNATURES = {
     "fo_pack_convT_k4s2_fused": (_I, [_P, _P, _I, _I, _I, _P]),
     "fo_conv_igemm": (_I, [_D, _P, _P, _P, _P, _P, _P, _P]),
     "fo_conv_igemm_variant": (_I, [_D]),
+    "fo_resblock_fwd": (_I, [_D, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "fo_conv_igemm_banked": (_I, [_D, _P, _P, _P, _I, _P]),
     "fo_wino_gemm": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "fo_wgrad_banked_ws_bytes": (_L, [_D, _I]),

@@ -54,6 +54,12 @@ struct ConvArgs {
   int margin;        // bytes the input descriptor starts below `in`, so that per-row base offsets are never negative
   unsigned inBytes;  // addressable extent behind `in` (buffer descriptor bound)
   unsigned wpBytes;
+  // fused ResBlock tail (FUSE instantiation): out2 = [relu]( h * wp2^T + bias2 + add ), h = this conv's 32-channel result
+  const float* wp2;   // [128][32] packed 1x1 filter
+  const float* bias2;
+  float* out2;
+  int ldOut2;
+  int relu2;
 };
 
 constexpr int BM = 128;
@@ -159,8 +165,9 @@ __device__ __forceinline__ void store_tile(const ConvArgs& a, const float* Cs, i
   else rows(std::false_type{});
 }
 
-template <int BN, int WAVES_M, int WAVES_N, int TM, int TN, bool SMALLC, bool INRELU>
+template <int BN, int WAVES_M, int WAVES_N, int TM, int TN, bool SMALLC, bool INRELU, bool FUSE = false>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
+  static_assert(!FUSE || (BN == 32 && WAVES_M == 4 && TM == 1 && TN == 1), "the fused ResBlock tail is built on the 32-column tile");
   static_assert(WAVES_M * WAVES_N == 4, "4 waves");
   static_assert(WAVES_M * TM * 32 == BM && WAVES_N * TN * 32 == BN, "tile");
   constexpr int BROWS = BN / 32;  // B-tile row passes per thread
@@ -382,6 +389,64 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     cur ^= 1;
   }
 
+  if constexpr (FUSE) {
+    // ---- ResBlock tail (reference models/vqvae_conv3d_latent.py:90-99): this tile's h = relu(conv3x3(relu(x)) + b1) never
+    // leaves the CU before the 1x1 conv consumes it: it goes to LDS in the A-operand layout (and from there to memory once,
+    // 16 B per lane: the backward needs it), the 128 x 32 filter of the 1x1 conv joins it, each wave contracts its 32 rows
+    // against all 128 output columns (64 MFMAs), and the residual `out += input` (+ the encoder's / decoder's ReLU) is the
+    // epilogue, straight from the accumulators (one dword per lane = whole 128-byte lines).
+    float* Hs = lds;                       // [128][36]
+    float* W3s = lds + BM * LDS_LD;        // [128][36]
+    __syncthreads();
+    {
+      const float b1 = a.bias[l31];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Hs[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * LDS_LD + l31] = fmaxf(acc[0][0][r] + b1, 0.f);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        *reinterpret_cast<f32x4*>(W3s + (lrow + 32 * i) * LDS_LD + lcol) = *reinterpret_cast<const f32x4*>(a.wp2 + (lrow + 32 * i) * 32 + lcol);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {          // h -> memory (hidden activation, kept for the backward)
+      const int row = lrow + 32 * i;
+      const long long m = (long long)tile_m * BM + row;
+      if (m < a.M) *reinterpret_cast<f32x4*>(a.out + m * d.ldOut + lcol) = *reinterpret_cast<const f32x4*>(Hs + row * LDS_LD + lcol);
+    }
+    f32x16 acc2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2[j][r] = 0.f;
+    const float* Ha = Hs + (wm * 32 + l31) * LDS_LD + half * 4;
+    const float* Wb = W3s + l31 * LDS_LD + half * 4;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const f32x4 fa = *reinterpret_cast<const f32x4*>(Ha + kk * 8);
+      f32x4 fb[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const f32x4*>(Wb + j * 32 * LDS_LD + kk * 8);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc2[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s], fb[j][s], acc2[j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = j * 32 + l31;
+      const float b3 = a.bias2[col];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long long m = (long long)tile_m * BM + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (m >= a.M) continue;
+        float v = acc2[j][r] + b3 + a.add[m * d.ldAdd + col];
+        if (a.relu2) v = fmaxf(v, 0.f);
+        a.out2[m * a.ldOut2 + col] = v;
+      }
+    }
+    return;
+  }
+
   // ---- epilogue.  An MFMA accumulator holds one output column per lane, so storing it directly means
   // 4-byte stores in 128-B pieces (and as many scalar loads for the mask / residual operands).  The tile
   // is transposed through LDS instead (the staging buffers are free now): every thread then owns float4
@@ -471,10 +536,10 @@ static int pick_variant(const fo_conv_desc* d) {
 
 extern "C" int fo_conv_igemm_variant(const fo_conv_desc* d) { return d ? pick_variant(d) : FO_E_SHAPE; }
 
-static int conv_igemm_impl(const fo_conv_desc* d, const float* in, const float* wp, const float* bias, const float* mask,
-                           const float* add, float* out, void* stream, int bank_frames) {
-  ConvArgs a;
+static int fill_args(const fo_conv_desc* d, const float* in, const float* wp, const float* bias, const float* mask,
+                     const float* add, float* out, int bank_frames, ConvArgs& a) {
   a.d = *d;
+  a.wp2 = nullptr; a.bias2 = nullptr; a.out2 = nullptr; a.ldOut2 = 0; a.relu2 = 0;
   a.in = in; a.wp = wp; a.bias = bias; a.mask = mask; a.add = add; a.out = out;
   FO_REQUIRE(d->N > 0 && d->T > 0 && d->N % d->T == 0, FO_E_SHAPE, "conv: N=%d not a multiple of T=%d", d->N, d->T);
   FO_REQUIRE(d->Cin % 4 == 0 && d->ldIn % 4 == 0, FO_E_ALIGN, "conv: Cin/ldIn must be multiples of 4");
@@ -536,6 +601,14 @@ static int conv_igemm_impl(const fo_conv_desc* d, const float* in, const float* 
     FO_REQUIRE(allBanks < (1ull << 31), FO_E_SHAPE, "conv: filter banks exceed the 2 GiB window");
     a.wpBytes = (unsigned)allBanks;
   }
+  return FO_OK;
+}
+
+static int conv_igemm_impl(const fo_conv_desc* d, const float* in, const float* wp, const float* bias, const float* mask,
+                           const float* add, float* out, void* stream, int bank_frames) {
+  ConvArgs a;
+  if (int rc = fill_args(d, in, wp, bias, mask, add, out, bank_frames, a)) return rc;
+  const bool smallc = d->Cin < 32;
   hipStream_t s = (hipStream_t)stream;
   // BN by output channels (filters are packed with Cout rounded up to the same BN)
   if (d->Cout > 64) {
@@ -559,6 +632,29 @@ static int conv_igemm_impl(const fo_conv_desc* d, const float* in, const float* 
 extern "C" int fo_conv_igemm(const fo_conv_desc* d, const float* in, const float* wp, const float* bias,
                              const float* mask, const float* add, float* out, void* stream) {
   return conv_igemm_impl(d, in, wp, bias, mask, add, out, stream, 0);
+}
+
+// ResBlock forward in ONE launch (reference models/vqvae_conv3d_latent.py:86-101): h = relu(conv3x3(relu(x)) + b1) is written
+// to `hbuf` (the backward needs it) and out = [relu](conv1x1(h) + b3 + x) to `out`.  d describes the 3x3 conv (Cin = C,
+// Cout = 32, k 1x3x3 p1 s1 on a same-size grid; ldOut = pixel stride of hbuf, ldAdd = pixel stride of x); wp1 / wp3 are the
+// fo_pack_conv packs of the 3x3 (32 rows) and 1x1 (128 rows x 32) filters.  C must be 128.
+extern "C" int fo_resblock_fwd(const fo_conv_desc* d, const float* x, const float* wp1, const float* b1, const float* wp3,
+                               const float* b3, float* hbuf, float* out, int ldOut2, int out_relu, void* stream) {
+  FO_REQUIRE(d && x && wp1 && b1 && wp3 && b3 && hbuf && out, FO_E_SHAPE, "resblock_fwd: null pointer");
+  FO_REQUIRE(d->Cout == 32 && d->Cin == 128 && d->KD == 1 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->ostride == 1 && d->padH == 1 &&
+                 d->padW == 1 && d->Hm == d->Hin && d->Wm == d->Win && d->Hout == d->Hin && d->Wout == d->Win && d->T >= 1,
+             FO_E_SHAPE, "resblock_fwd: a 3x3 pad-1 stride-1 conv 128 -> 32 on a same-size grid is required");
+  FO_REQUIRE(d->ldAdd >= 128 && d->ldAdd % 4 == 0 && ldOut2 >= 128 && ldOut2 % 4 == 0 && d->ldOut >= 32 && d->ldOut % 4 == 0 &&
+                 fo_aligned16(hbuf) && fo_aligned16(out) && fo_aligned16(wp3), FO_E_ALIGN, "resblock_fwd: strides / alignment");
+  fo_conv_desc dd = *d;
+  dd.flags = FO_IN_RELU | FO_BIAS | FO_OUT_RELU;
+  ConvArgs a;
+  if (int rc = fill_args(&dd, x, wp1, b1, nullptr, x, hbuf, 0, a)) return rc;
+  a.wp2 = wp3; a.bias2 = b3; a.out2 = out; a.ldOut2 = ldOut2; a.relu2 = out_relu;
+  a.tilesN = 1;
+  hipLaunchKernelGGL((conv_igemm_kernel<32, 4, 1, 1, 1, false, true, true>), dim3(a.tilesM * a.tilesN), dim3(256), 0, (hipStream_t)stream, a);
+  FO_CHECK_LAUNCH();
+  return FO_OK;
 }
 
 // The same contraction with the filter chosen per frame: frames [b*bank_frames, (b+1)*bank_frames) use the b-th filter

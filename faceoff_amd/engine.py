@@ -242,6 +242,7 @@ class VQVAEEngine:
         # Conv3d forward / data gradient as Winograd F(2x2,3x3) + a (3,1,1) implicit GEMM (FACEOFF_NO_WINOGRAD=1: direct)
         self.winograd = not _os.environ.get("FACEOFF_NO_WINOGRAD")
         self.winograd_max_tile = int(_os.environ.get("FACEOFF_WINOGRAD_TILE", "4"))   # 2: F(2x2,3x3) everywhere
+        self.fused_resblock = not _os.environ.get("FACEOFF_NO_FUSED_RESBLOCK")
         self.keep_wino_v = False      # training forward: keep each Conv3d's transformed input for its filter gradient
         self._keepalive = []
         self._cur_S = None            # state dict of the forward / backward in flight (kept Winograd planes live in it)
@@ -288,8 +289,12 @@ class VQVAEEngine:
         L = self.layers
         n, h, w, _ = x.shape
         hbuf = self._new(n, h, w, 32)
-        L[prefix + ".conv.1"].fwd(x, hbuf, flags=FO_IN_RELU | FO_OUT_RELU)
-        L[prefix + ".conv.3"].fwd(hbuf, out, flags=FO_OUT_RELU if out_relu else 0, add=x)
+        c1, c3 = L[prefix + ".conv.1"], L[prefix + ".conv.3"]
+        if self.fused_resblock and x.shape[-1] == 128:        # one launch: the hidden tile never leaves the CU between the convs
+            ops.resblock_fwd(x, c1.wp, c1.b, c3.wp, c3.b, hbuf, out, out_relu)
+            return hbuf
+        c1.fwd(x, hbuf, flags=FO_IN_RELU | FO_OUT_RELU)
+        c3.fwd(hbuf, out, flags=FO_OUT_RELU if out_relu else 0, add=x)
         return hbuf
 
     def _resblock_bwd(self, prefix, g_out, x, hbuf, g_x):

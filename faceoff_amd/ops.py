@@ -182,6 +182,20 @@ def conv_igemm(x, wp, bias, out, *, T=1, k=(1, 3, 3), stride=1, pad=(0, 1, 1), c
         prof.end()
 
 
+def resblock_fwd(x, wp1, b1, wp3, b3, hbuf, out, out_relu):
+    """One fo_resblock_fwd launch: hbuf = relu(conv3x3(relu(x)) + b1), out = [relu](conv1x1(hbuf) + b3 + x)."""
+    N, H, W, Cc = x.shape
+    d = _desc(N=N, T=1, Hin=H, Win=W, Hm=H, Wm=W, Hout=H, Wout=W, Cin=Cc, Cout=32, KD=1, KH=3, KW=3, stride=1, padD=0, padH=1, padW=1,
+              ostride=1, ophH=0, ophW=0, ldIn=ld_of(x), ldOut=ld_of(hbuf), ldMask=0, ldAdd=ld_of(x), flags=0)
+    prof = PROFILER
+    if prof is not None:
+        prof.begin("resblock_fwd" + (f" [{N}x{H}x{W} {Cc}->32->{Cc}]" if prof.detail else ""), 2.0 * N * H * W * 32 * (9 * Cc + Cc))
+    _lib.call("fo_resblock_fwd", C.byref(d), _ptr(x), _ptr(wp1), _ptr(b1), _ptr(wp3), _ptr(b3), _ptr(hbuf), _ptr(out), ld_of(out),
+              int(bool(out_relu)), _stream())
+    if prof is not None:
+        prof.end()
+
+
 # ------------------------------------------------------------------ Winograd F(m x m, 3x3) Conv3d, m = 2 or 4
 def wino_tile(H, W, N=None):
     """Output-tile size for a Conv3d on HxW frames: 4 (4x fewer MFMA FLOP, fp32 error ~3e-6 of scale) when the plane

@@ -101,6 +101,14 @@ typedef struct fo_conv_desc {
 int fo_conv_igemm(const fo_conv_desc* d, const float* in, const float* wp, const float* bias,
                   const float* mask, const float* add, float* out, void* stream);
 
+/* ResBlock.forward in ONE launch (models/vqvae_conv3d_latent.py:86-101: ReLU -> Conv 3x3 C->32 -> ReLU -> Conv 1x1 32->C ->
+ * `out += input`): hbuf = relu(conv3x3(relu(x)) + b1) [N,H,W,ldOut of d] (kept for the backward), out = conv1x1(hbuf) + b3 + x,
+ * ReLU'd when out_relu != 0 (the encoder's / decoder's trailing nn.ReLU, :126,145).  The 32-channel tile goes from the 3x3
+ * conv's accumulators through LDS into the 1x1 contraction without a round trip to memory.  d = the 3x3 conv (Cin = C = 128,
+ * Cout = 32, same-size grid; ldIn = ldAdd = pixel stride of x); wp1 / wp3 = fo_pack_conv of the two filters. */
+int fo_resblock_fwd(const fo_conv_desc* d, const float* x, const float* wp1, const float* b1, const float* wp3, const float* b3,
+                    float* hbuf, float* out, int ldOut2, int out_relu, void* stream);
+
 /* fo_conv_igemm with the filter chosen per frame: frames [b*bank_frames, (b+1)*bank_frames) use the b-th of the
  * consecutive packed filter banks behind `wp`.  No bias / mask / residual.  Needs bank_frames*Hm*Wm % 128 == 0. */
 int fo_conv_igemm_banked(const fo_conv_desc* d, const float* in, const float* wp, float* out, int bank_frames, void* stream);

@@ -412,3 +412,30 @@ def test_wino_gemm_equals_the_banked_implicit_gemm(N, T, Ht, Wt, kd, ci, co):
                 ref[:, t] += v[:, t + dt] @ u[:, k].T
     got = M1.view(planes, N // T, T, Ht * Wt, co)[p].double()
     assert (got - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("N,H,W,out_relu", [(3, 16, 16, False), (2, 20, 12, True), (1, 7, 9, False)])
+def test_fused_resblock_forward_equals_the_two_launch_form(N, H, W, out_relu):
+    """fo_resblock_fwd (3x3 -> ReLU -> 1x1 -> + input in one launch, hidden tile through LDS) against torch-CPU ResBlock
+    arithmetic (reference models/vqvae_conv3d_latent.py:86-101) and against the engine's two-launch form."""
+    from faceoff_amd import ops
+    g = torch.Generator().manual_seed(N * 100 + H)
+    x = torch.randn((N, 128, H, W), generator=g)
+    w1, b1 = torch.randn((32, 128, 3, 3), generator=g) * 0.05, torch.randn(32, generator=g) * 0.1
+    w3, b3 = torch.randn((128, 32, 1, 1), generator=g) * 0.1, torch.randn(128, generator=g) * 0.1
+    h_ref = torch.relu(torch.nn.functional.conv2d(torch.relu(x), w1, b1, padding=1))
+    o_ref = torch.nn.functional.conv2d(h_ref, w3, b3) + x
+    if out_relu:
+        o_ref = torch.relu(o_ref)
+    xc = x.permute(0, 2, 3, 1).contiguous().cuda()
+    wp1, wp3 = ops.pack_conv(w1.cuda()), ops.pack_conv(w3.cuda())
+    hb = torch.full((N, H, W, 32), 5.0, device="cuda")
+    out = torch.full((N, H, W, 128), -7.0, device="cuda")
+    ops.resblock_fwd(xc, wp1, b1.cuda(), wp3, b3.cuda(), hb, out, out_relu)
+    assert (hb.permute(0, 3, 1, 2).cpu() - h_ref).abs().max().item() <= 2e-5 * h_ref.abs().max().item()
+    assert (out.permute(0, 3, 1, 2).cpu() - o_ref).abs().max().item() <= 2e-5 * o_ref.abs().max().item()
+    hb2, out2 = torch.empty_like(hb), torch.empty_like(out)
+    ops.conv_igemm(xc, wp1, b1.cuda(), hb2, cin=128, cout=32, flags=ops.FO_IN_RELU | ops.FO_OUT_RELU)
+    ops.conv_igemm(hb2, wp3, b3.cuda(), out2, k=(1, 1, 1), pad=(0, 0, 0), cin=32, cout=128, flags=ops.FO_OUT_RELU if out_relu else 0, add=xc)
+    assert torch.equal(hb, hb2)                                   # same k-ordered MFMA chain for the 3x3 half
+    assert (out - out2).abs().max().item() <= 1e-6 * out2.abs().max().item()
