@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""GAN iteration (BASELINE config 5) on one 30-frame clip at 256x256:  python tools/bench_gan.py [iterations]"""
+import os, sys, time, random
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from faceoff_amd.disc import DiscEngine
+from faceoff_amd.engine import VQVAEEngine
+from faceoff_amd.gan_trainer import GANTrainer
+from faceoff_amd.synth import make_state_dict, make_disc_state
+dev = torch.device("cuda:0")
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+gen = torch.Generator(device=dev).manual_seed(1)
+img = torch.rand((30, 6, 256, 256), device=dev, generator=gen) * 2 - 1
+gt = torch.rand((30, 3, 256, 256), device=dev, generator=gen) * 2 - 1
+tr = GANTrainer(VQVAEEngine(make_state_dict(0, codebook_scale=0.3, gain=2.0), dev), DiscEngine(make_disc_state(1, 3), dev, dims=3, n_frames=15),
+                DiscEngine(make_disc_state(2, 2), dev, dims=2), rng=random.Random(3))
+for _ in range(2):
+    tr.step(img, gt)
+torch.cuda.synchronize()
+for kind in ("generator", "discriminator"):
+    ts = []
+    for _ in range(iters // 2):
+        if (tr.iteration % 2 == 0) != (kind == "generator"):
+            tr.step(img, gt)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        tr.step(img, gt)
+        torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
+    print(f"{kind} iteration: {min(ts):.2f} ms (min of {len(ts)})")
