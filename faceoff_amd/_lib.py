@@ -98,7 +98,7 @@ class ConvNdDesc(C.Structure):
 
 
 _ND = C.POINTER(ConvNdDesc)
-FO_OUT_LRELU, FO_MASK_LRELU = 64, 128
+FO_OUT_LRELU, FO_MASK_LRELU, FO_KSPLIT = 64, 128, 256
 SIGNATURES.update({
     "fo_pack_convnd": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "fo_convnd": (_I, [_ND, _I, _P, _P, _P, _P, _P, _P]),
@@ -112,6 +112,8 @@ SIGNATURES.update({
     "fo_disc_pairs_bwd": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _F, _P]),
     "fo_affine_warp": (_I, [_P, _P, _I, _I, _I, _I, C.POINTER(C.c_float), _I, _P]),
     "fo_denorm_u8": (_I, [_P, _I, _I, _I, _P, _I, _I, _I, _I, _P]),
+    "fo_space_to_depth2": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "fo_s2d_filter": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "fo_ralsgan": (_I, [_P, _I, _P, _I, _I, _F, _F, _F, _P, _P, _P, _P, _P]),
 })
 

@@ -36,6 +36,7 @@ struct GenArgs {
   int tilesPerPhase, tilesN, taps;
   unsigned srcBytes, wpBytes;
   int margin;
+  int ksplit;           // > 1: the K-steps of a tile are cut into this many slices, one workgroup each, combined with float atomics
 };
 
 __device__ __forceinline__ f32x4 bufload(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
@@ -53,8 +54,9 @@ __global__ __launch_bounds__(256, 2) void conv_gen_kernel(const GenArgs a) {
   const int wm = wave >> 1, wn = wave & 1;
   const int lrow = tid >> 3, lcol = (tid & 7) * 4;
 
-  const int tile_n = blockIdx.x % a.tilesN;
-  const int tile_m = blockIdx.x / a.tilesN;
+  const int slice = blockIdx.x % a.ksplit;
+  const int tile_n = (blockIdx.x / a.ksplit) % a.tilesN;
+  const int tile_m = (blockIdx.x / a.ksplit) / a.tilesN;
   const int phase = tile_m / a.tilesPerPhase;
   const int mt = tile_m - phase * a.tilesPerPhase;
   int phD = 0, phH = 0, phW = 0;
@@ -114,9 +116,19 @@ __global__ __launch_bounds__(256, 2) void conv_gen_kernel(const GenArgs a) {
   for (int i = 0; i < 2; ++i) wrow[i] = (unsigned)(((size_t)(tile_n * BN + lrow + 32 * i) * Ktot + lcol) * 4);
 
   const int chunks = d.Cs / BK;
-  const int nsteps = nD * nH * nW * chunks;
-
+  const int allsteps = nD * nH * nW * chunks;
+  // this workgroup's slice [s0, s1) of the K-steps, and the (tap, chunk) its walk starts at
+  const int per_slice = (allsteps + a.ksplit - 1) / a.ksplit;
+  const int s0 = min(allsteps, slice * per_slice), s1 = min(allsteps, s0 + per_slice);
+  const int nsteps = s1 - s0;
   int ld_kd = k0D, ld_kh = k0H, ld_kw = k0W, ld_chunk = 0;
+  if (s0 > 0) {
+    int t = s0 / chunks;
+    ld_chunk = s0 - t * chunks;
+    ld_kw = k0W + (t % nW) * stW; t /= nW;
+    ld_kh = k0H + (t % nH) * stH; t /= nH;
+    ld_kd = k0D + t * stD;
+  }
   unsigned ld_bad[2] = {0, 0};     // bit 31 set: this row reads padding at the current tap
   int ld_soffA = 0, ld_soffB = 0;
   auto tap_setup = [&]() {
@@ -189,13 +201,14 @@ __global__ __launch_bounds__(256, 2) void conv_gen_kernel(const GenArgs a) {
   // ---- epilogue: register r of the accumulator = tile row (r&3) + 8(r>>2) + 4*half, column l31 (32 consecutive channels)
   const int co = tile_n * BN + wn * 32 + l31;
   if (co >= d.Cd) return;
-  const float bv = (d.flags & FO_BIAS) ? a.bias[co] : 0.f;
+  const float bv = ((d.flags & FO_BIAS) && slice == 0) ? a.bias[co] : 0.f;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
     const long long pix = rowdst[row];
     if (pix < 0) continue;
     float v = acc[r] + bv;
+    if (a.ksplit > 1) { atomicAdd(a.dst + pix * d.ldD + co, v); continue; }   // dst was zeroed by the caller
     if (d.flags & FO_OUT_LRELU) v = v > 0.f ? v : v * d.slope;
     if (d.flags & FO_MASK_LRELU) v = a.mask[pix * d.ldMask + co] > 0.f ? v : v * d.slope;
     float* o = a.dst + pix * d.ldD + co;
@@ -337,7 +350,7 @@ int fo_convnd(const fo_convnd_desc* d, int transposed, const float* src, const f
   FO_REQUIRE(src && wp && dst && fo_aligned16(src) && fo_aligned16(wp), FO_E_ALIGN, "convnd: pointers");
   FO_REQUIRE(!(d->flags & FO_BIAS) || bias, FO_E_SHAPE, "convnd: FO_BIAS without bias");
   FO_REQUIRE(!(d->flags & FO_MASK_LRELU) || (mask && d->ldMask >= d->Cd), FO_E_SHAPE, "convnd: FO_MASK_LRELU without mask");
-  FO_REQUIRE(!(d->flags & ~(FO_BIAS | FO_OUT_LRELU | FO_MASK_LRELU | FO_ADD)), FO_E_SHAPE, "convnd: unsupported flag");
+  FO_REQUIRE(!(d->flags & ~(FO_BIAS | FO_OUT_LRELU | FO_MASK_LRELU | FO_ADD | FO_KSPLIT)), FO_E_SHAPE, "convnd: unsupported flag");
   GenArgs a;
   a.d = *d; a.src = src; a.wp = wp; a.bias = bias; a.mask = mask; a.dst = dst; a.transposed = transposed;
   a.taps = d->KD * d->KH * d->KW;
@@ -358,7 +371,19 @@ int fo_convnd(const fo_convnd_desc* d, int transposed, const float* src, const f
                                       : ((((long long)d->pD * d->Hs + d->pH) * d->Ws + d->pW) * d->ldS) * 4ll;
   FO_REQUIRE(srcBytes + (unsigned long long)margin < (1ull << 31) && wpBytes < (1ull << 31), FO_E_SHAPE, "convnd: tensor exceeds the 2 GiB window");
   a.srcBytes = (unsigned)srcBytes; a.wpBytes = (unsigned)wpBytes; a.margin = (int)margin;
-  const long long grid = (long long)phases * a.tilesPerPhase * a.tilesN;
+  // few tiles but a long contraction (the 1-channel patch head: 192 tiles x 1024 K-steps): slice K over workgroups
+  a.ksplit = 1;
+  {
+    const long long tiles = (long long)phases * a.tilesPerPhase * a.tilesN;
+    const int steps = a.taps * (d->Cs / 32) / phases;
+    if ((d->flags & FO_KSPLIT) && tiles < 2048 && steps >= 32) {
+      long long k = (2048 + tiles - 1) / tiles;
+      if (k > steps / 16) k = steps / 16;
+      if (k > 1) a.ksplit = (int)k;
+    }
+    FO_REQUIRE(a.ksplit == 1 || !(d->flags & (FO_OUT_LRELU | FO_MASK_LRELU | FO_ADD)), FO_E_SHAPE, "convnd: FO_KSPLIT with a non-linear epilogue");
+  }
+  const long long grid = (long long)phases * a.tilesPerPhase * a.tilesN * a.ksplit;
   FO_REQUIRE(grid < (1ll << 31), FO_E_SHAPE, "convnd: grid");
   hipLaunchKernelGGL(conv_gen_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
   FO_CHECK_LAUNCH();

@@ -196,6 +196,45 @@ __global__ void disc_pairs_bwd_kernel(const float* __restrict__ gout, int ldOut,
   }
 }
 
+// Space-to-depth by 2 in (depth,) height, width: out[n][d'][h'][w'][((bd*2+bh)*2+bw)*C + c] = x[n][2d'+bd][2h'+bh][2w'+bw][c]
+// (zero past the end of an odd axis and in the channel padding).  inverse: the gradient's way back (gx is WRITTEN).
+// A k4 s2 p2 convolution of x is a k2 s1 p1 convolution of the result: tap k = 2a + b reads block (o + a - 1), phase b.
+__global__ void s2d_kernel(const float* __restrict__ x, int ldx, float* __restrict__ xs, int ldxs, int N, int D, int H, int W, int C,
+                           int pd, int inverse) {
+  const int Dp = (D + pd - 1) / pd, Hp = (H + 1) / 2, Wp = (W + 1) / 2;
+  const long long total = (long long)N * Dp * Hp * Wp * ldxs;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int ch = (int)(e % ldxs);
+    long long q = e / ldxs;
+    const int wp = (int)(q % Wp); q /= Wp;
+    const int hp = (int)(q % Hp); q /= Hp;
+    const int dp = (int)(q % Dp);
+    const long long n = q / Dp;
+    const int c = ch % C, ph = ch / C;
+    const int bw = ph & 1, bh = (ph >> 1) & 1, bd = ph >> 2;
+    const bool real = ph < pd * 4;
+    const int d = dp * pd + bd, h = hp * 2 + bh, w = wp * 2 + bw;
+    const bool in = real && d < D && h < H && w < W;
+    if (!inverse) xs[e] = in ? x[(((n * D + d) * H + h) * (long long)W + w) * ldx + c] : 0.f;
+    else if (in) const_cast<float*>(x)[(((n * D + d) * H + h) * (long long)W + w) * ldx + c] = xs[e];
+  }
+}
+
+// w[O][C][KD][4][4] (KD = 4 or 1) <-> w2[O][phases*C][taps2]: w2[o][((bd*2+bh)*2+bw)*C + c][(ad*2+ah)*2+aw] = w[o][c][2ad+bd][2ah+bh][2aw+bw]
+__global__ void s2d_filter_kernel(float* __restrict__ w, float* __restrict__ w2, int O, int C, int KD, int inverse) {
+  const int taps = KD * 16, total = O * C * taps;
+  const int pd = KD == 4 ? 2 : 1, taps2 = pd * 4, C2 = pd * 4 * C;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    const int kw = e % 4, kh = (e / 4) % 4, kd = (e / 16) % KD;
+    const int c = (e / taps) % C, o = e / (taps * C);
+    const int ad = kd >> 1, bd = kd & 1, ah = kh >> 1, bh = kh & 1, aw = kw >> 1, bw = kw & 1;
+    const int ch = ((bd * 2 + bh) * 2 + bw) * C + c, t2 = (ad * 2 + ah) * 2 + aw;
+    const int e2 = (o * C2 + ch) * taps2 + (KD == 4 ? t2 : (ah * 2 + aw));
+    if (!inverse) w2[e2] = w[e];
+    else w[e] = w2[e2];
+  }
+}
+
 __device__ __forceinline__ float block_sum(float v, float* sh) {
   const int tid = threadIdx.x;
   sh[tid] = v;
@@ -297,6 +336,22 @@ int fo_disc_pairs_bwd(const float* gout, int ldOut, int H, int W, int f0, int fi
   const int F = std::max(std::max(first, last), f0) + 1;
   hipLaunchKernelGGL(disc_pairs_bwd_kernel, dim3(grid_for((long long)F * H * W)), dim3(256), 0, (hipStream_t)stream, gout, ldOut, H, W, F,
                      f0, first, step, n, gsrc, ldG, scale);
+  FO_CHECK_LAUNCH();
+  return FO_OK;
+}
+
+int fo_space_to_depth2(float* x, int ldx, float* xs, int ldxs, int N, int D, int H, int W, int C, int depth_too, int inverse, void* stream) {
+  const int pd = depth_too ? 2 : 1;
+  FO_REQUIRE(x && xs && N > 0 && C > 0 && ldx >= C && ldxs >= pd * 4 * C, FO_E_SHAPE, "space_to_depth2: bad arguments");
+  const long long total = (long long)N * ((D + pd - 1) / pd) * ((H + 1) / 2) * ((W + 1) / 2) * ldxs;
+  hipLaunchKernelGGL(s2d_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, ldx, xs, ldxs, N, D, H, W, C, pd, inverse);
+  FO_CHECK_LAUNCH();
+  return FO_OK;
+}
+
+int fo_s2d_filter(float* w, float* w2, int O, int C, int KD, int inverse, void* stream) {
+  FO_REQUIRE(w && w2 && O > 0 && C > 0 && (KD == 4 || KD == 1), FO_E_SHAPE, "s2d_filter: bad arguments");
+  hipLaunchKernelGGL(s2d_filter_kernel, dim3(grid_for((long long)O * C * KD * 16)), dim3(256), 0, (hipStream_t)stream, w, w2, O, C, KD, inverse);
   FO_CHECK_LAUNCH();
   return FO_OK;
 }

@@ -21,7 +21,7 @@ from collections import OrderedDict
 import torch
 
 from . import _lib, ops
-from ._lib import ConvNdDesc, FO_BIAS, FO_ADD, FO_OUT_LRELU, FO_MASK_LRELU
+from ._lib import ConvNdDesc, FO_BIAS, FO_ADD, FO_OUT_LRELU, FO_MASK_LRELU, FO_KSPLIT
 from .synth import disc_param_specs, DISC_CHANNELS
 
 STRIDES = (2, 2, 2, 1, 1)
@@ -61,7 +61,7 @@ class DiscEngine:
         self.m = torch.zeros_like(self.flat_params)
         self.v = torch.zeros_like(self.flat_params)
         self.t = 0
-        self._wp, self._wpt = {}, {}
+        self._wp, self._wpt, self._w2 = {}, {}, {}
         if state_dict is not None:
             self.load_state_dict(state_dict)
 
@@ -102,6 +102,27 @@ class DiscEngine:
         d.ldMask, d.flags, d.slope = ld_mask, flags, SLOPE
         return d
 
+    def _desc0(self, N, src_dims, cs, ld_s, dst_dims, cd, ld_d, flags=0, ld_mask=0):
+        """The first layer on the space-to-depth image: kernel 2, stride 1, padding 1."""
+        d = self._desc(N, src_dims, cs, ld_s, dst_dims, cd, ld_d, 1, flags, ld_mask)
+        three = self.dims == 3
+        d.KD, d.KH, d.KW = (2 if three else 1), 2, 2
+        d.pD, d.pH, d.pW = (1 if three else 0), 1, 1
+        return d
+
+    def _s2d(self, x, inverse_into=None):
+        """x [N][D][H][W][32] (nc real channels) -> xs [N][D'][H'][W'][64 | 32]; inverse_into: scatter a gradient xs back into it."""
+        N, D, H, W, ld = (inverse_into if inverse_into is not None else x).shape
+        three = self.dims == 3
+        Dp = (D + 1) // 2 if three else D
+        ldxs = 64 if three else 32
+        if inverse_into is None:
+            xs = torch.empty((N, Dp, (H + 1) // 2, (W + 1) // 2, ldxs), device=self.device)
+            _lib.call("fo_space_to_depth2", ops._ptr(x), ld, ops._ptr(xs), ldxs, N, D, H, W, self.nc, int(three), 0, ops._stream())
+            return xs
+        _lib.call("fo_space_to_depth2", ops._ptr(inverse_into), ld, ops._ptr(x), ldxs, N, D, H, W, self.nc, int(three), 1, ops._stream())
+        return inverse_into
+
     def pack_filters(self):
         """Checkpoint-layout filters -> forward and data-gradient packs (every step: the optimiser rewrites the weights)."""
         taps = K ** self.dims
@@ -109,6 +130,19 @@ class DiscEngine:
             if not k.endswith(".weight"):
                 continue
             O, I = w.shape[:2]
+            if k.endswith("_layer0.0.weight"):
+                # first layer (nc = 6 input channels): k4 s2 p2 over x == k2 s1 p1 over the space-to-depth image (8 | 4 phases
+                # x 6 channels = 48 | 24 -> one or two 32-channel K chunks instead of 64 | 16 taps of a 6-in-32 padded pixel)
+                ph, taps2 = (8, 8) if self.dims == 3 else (4, 4)
+                w2 = self._w2.setdefault(k, torch.empty((O, ph * I, taps2), device=self.device))
+                _lib.call("fo_s2d_filter", ops._ptr(w), ops._ptr(w2), O, I, K if self.dims == 3 else 1, 0, ops._stream())
+                for store, tr in ((self._wp, 0), (self._wpt, 1)):
+                    rows, cols = (ph * I, O) if tr else (O, ph * I)
+                    n = ((rows + 63) // 64 * 64) * taps2 * ((cols + 31) // 32 * 32)
+                    if k not in store or store[k].numel() != n:
+                        store[k] = torch.empty(n, device=self.device)
+                    _lib.call("fo_pack_convnd", ops._ptr(w2), ops._ptr(store[k]), O, ph * I, taps2, tr, ops._stream())
+                continue
             for store, tr in ((self._wp, 0), (self._wpt, 1)):
                 rows, cols = (I, O) if tr else (O, I)
                 n = ((rows + 63) // 64 * 64) * taps * ((cols + 31) // 32 * 32)
@@ -155,16 +189,27 @@ class DiscEngine:
 
     def _scale_fwd(self, x, prefix, training, order):
         N = x.shape[0]
-        feat, stats, inp = [], [None] * 5, [x]
+        feat, stats, inp = [], [None] * 5, []
         h, cin = x, 32
         for j, (co, s) in enumerate(zip(DISC_CHANNELS, STRIDES)):
             key = f"{prefix}_layer{j}"
             sd = self._dims_of(h)
             dd = tuple((_out(n, s) if (self.dims == 3 or a > 0) else 1) for a, n in enumerate(sd))
+            if j == 0:
+                xs = self._s2d(x)
+                y = torch.empty((N,) + dd + (co,), device=self.device)
+                d = self._desc0(N, self._dims_of(xs), xs.shape[-1], xs.shape[-1], dd, co, co, FO_BIAS | FO_OUT_LRELU)
+                _lib.call("fo_convnd", C.byref(d), 0, ops._ptr(xs), ops._ptr(self._wp[key + ".0.weight"]), ops._ptr(self.params[key + ".0.bias"]),
+                          None, ops._ptr(y), ops._stream())
+                feat.append(y)
+                inp += [xs, y]
+                h, cin = y, co
+                continue
             ld_out = max(32, co)
             # the 1-channel head is written into a zeroed 32-float pixel
             y = (torch.zeros if co < 32 else torch.empty)((N,) + dd + (ld_out,), device=self.device)
-            flags = FO_BIAS | (FO_OUT_LRELU if j == 0 else 0)
+            # the head (1 channel, K = 64 taps x 512): 192 tiles x 1024 K-steps -> the launch may slice K (y is zeroed above)
+            flags = FO_BIAS | (FO_OUT_LRELU if j == 0 else 0) | (FO_KSPLIT if co < 32 else 0)
             d = self._desc(N, sd, cin, h.shape[-1], dd, co, ld_out, s, flags)
             _lib.call("fo_convnd", C.byref(d), 0, ops._ptr(h), ops._ptr(self._wp[key + ".0.weight"]), ops._ptr(self.params[key + ".0.bias"]),
                       None, ops._ptr(y), ops._stream())
@@ -181,7 +226,7 @@ class DiscEngine:
             feat.append(y)
             inp.append(y)
             h, cin = y, max(32, co)
-        return {"feat": feat, "stats": stats, "inp": inp[:5], "prefix": prefix}
+        return {"feat": feat, "stats": stats, "inp": inp[:5], "prefix": prefix, "x_shape": tuple(x.shape)}
 
     # ------------------------------------------------------------------ backward
     def backward(self, S, g_logits, param_grads=True, input_grad=False):
@@ -228,11 +273,27 @@ class DiscEngine:
                     _lib.call("fo_instnorm_lrelu_bwd", ops._ptr(g[n]), g.shape[-1], ops._ptr(feat[j][n]), feat[j].shape[-1],
                               ops._ptr(stats[j][n]), ops._ptr(gc[n]), gc.shape[-1], C.c_int64(rows), co, C.c_float(SLOPE), ops._stream())
                 g = gc
+            if j == 0:
+                # first layer on the space-to-depth image (x_in = xs): filter gradient in the k2 layout, mapped back to k4
+                ph = 8 if self.dims == 3 else 4
+                if param_grads:
+                    d = self._desc0(N, sd, cin_pad, cin_pad, dd, co, g.shape[-1])
+                    dw2 = torch.zeros_like(self._w2[key + ".0.weight"])
+                    _lib.call("fo_wgradnd", C.byref(d), ops._ptr(g), ops._ptr(x_in), ops._ptr(dw2), ph * self.nc, ops._stream())
+                    _lib.call("fo_s2d_filter", ops._ptr(self.grads[key + ".0.weight"]), ops._ptr(dw2), co, self.nc,
+                              K if self.dims == 3 else 1, 1, ops._stream())
+                    rows = g.numel() // g.shape[-1]
+                    ops.bias_grad(g.view(rows, 1, 1, g.shape[-1]), self.grads[key + ".0.bias"], co)
+                if not input_grad:
+                    return None
+                gxs = torch.empty_like(x_in)
+                d = self._desc0(N, dd, co, g.shape[-1], sd, ph * self.nc, cin_pad)
+                _lib.call("fo_convnd", C.byref(d), 1, ops._ptr(g), ops._ptr(self._wpt[key + ".0.weight"]), None, None, ops._ptr(gxs), ops._stream())
+                gx = torch.zeros(sc["x_shape"], device=self.device)
+                return self._s2d(gxs, inverse_into=gx)
             if param_grads:
                 d = self._desc(N, sd, cin_pad, cin_pad, dd, co, g.shape[-1], s)
                 self._wgrad(d, g, x_in, key, cin_real)
-            if j == 0 and not input_grad:
-                return None
             # data gradient: source = g on the conv's output grid (channels padded to 32), destination = the conv's input
             cs = max(32, co)
             gin = torch.empty_like(x_in) if j > 0 else torch.zeros_like(x_in)

@@ -236,13 +236,15 @@ int fo_denorm_u8(const float* src, int ld, int C, int c0, uint8_t* out, int N, i
  * (a 2-D tensor has D = 1). */
 #define FO_OUT_LRELU 64   /* fo_convnd: LeakyReLU(slope) on the result */
 #define FO_MASK_LRELU 128 /* fo_convnd: result *= (mask[pixel][c] > 0 ? 1 : slope)  (LeakyReLU backward fused into a data gradient) */
+#define FO_KSPLIT 256     /* fo_convnd: the launch MAY cut the contraction into slices combined with float atomics (few tiles, long K:
+                             the 1-channel patch head); dst must be ZERO on entry; only with FO_BIAS */
 typedef struct fo_convnd_desc {
   int32_t N;
   int32_t Ds, Hs, Ws, Cs, ldS; /* SOURCE tensor of the launch (forward: the conv's input; transposed: the output gradient) */
   int32_t Dd, Hd, Wd, Cd, ldD; /* DESTINATION tensor (forward: the conv's output; transposed: the input gradient) */
   int32_t KD, KH, KW, sD, sH, sW, pD, pH, pW; /* the CONVOLUTION's kernel / stride / padding in either direction */
   int32_t ldMask;              /* pixel stride of `mask` (FO_MASK_LRELU), on the destination grid */
-  int32_t flags;               /* FO_BIAS | FO_OUT_LRELU | FO_MASK_LRELU | FO_ADD (accumulate into dst) */
+  int32_t flags;               /* FO_BIAS | FO_OUT_LRELU | FO_MASK_LRELU | FO_ADD (accumulate into dst) | FO_KSPLIT */
   float slope;                 /* LeakyReLU negative slope */
 } fo_convnd_desc;
 /* w[O][I][taps] (checkpoint OIDHW / OIHW) -> forward pack [O pad 64][taps][I pad 32] (transposed = 0) or the data-gradient
@@ -279,6 +281,13 @@ int fo_disc_pairs(const float* src, int nchw, int ldSrc, int H, int W, int f0, i
                   void* stream);
 int fo_disc_pairs_bwd(const float* gout, int ldOut, int H, int W, int f0, int first, int step, int n, float* gsrc, int ldG, float scale,
                       void* stream);
+/* The 6-channel first layer of a discriminator (Conv k4 s2 p2, :133-136) as a k2 s1 p1 conv over the space-to-depth image:
+ * xs[n][d'][h'][w'][((bd*2+bh)*2+bw)*C + c] = x[n][2d'+bd][2h'+bh][2w'+bw][c] (zero past an odd axis' end / in the channel padding;
+ * depth_too = 0: 2-D, phases (bh, bw) only).  inverse != 0 scatters xs back into x (the input gradient's way back).
+ * fo_s2d_filter maps the checkpoint filter w[O][C][KD][4][4] to w2[O][phases*C][taps2] (tap k = 2a + b) and back (inverse: the
+ * filter gradient's way back). */
+int fo_space_to_depth2(float* x, int ldx, float* xs, int ldxs, int N, int D, int H, int W, int C, int depth_too, int inverse, void* stream);
+int fo_s2d_filter(float* w, float* w2, int O, int C, int KD, int inverse, void* stream);
 /* Relativistic average LSGAN (mocoganhd_losses.py:108-126) on one scale's patch logits a[na], b[nb] (pixel stride ld):
  *   loss = w * ( mean((a - mean(b) - ta)^2) + mean((b - mean(a) - tb)^2) )       accumulated into *loss_acc;
  * ga / gb (either may be NULL) receive d loss / d a, d loss / d b times gscale[0] (stride ld, written not added). */
