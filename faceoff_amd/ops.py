@@ -233,7 +233,59 @@ def _wino_buffers(nfloats, device):
     return buf
 
 
+WINO_SPLIT = bool(_os.environ.get("FACEOFF_WINO_SPLIT"))    # off: measured null (see conv3d_winograd)
+_side_streams = {}
+
+
+def _side_stream(device):
+    """A helper stream per (device, current stream): the second half-batch of a Winograd convolution runs on it."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    s = _side_streams.get(key)
+    if s is None:
+        s = _side_streams[key] = torch.cuda.Stream(device=device)
+    return s
+
+
+def _halves_ok(N, T, Ht, Wt):
+    h = N // 2
+    return WINO_SPLIT and PROFILER is None and N % (2 * T) == 0 and (h * Ht * Wt) % 128 == 0 and 36 * h * Ht * Wt >= 128 * 1024   # >= 2 rounds of tiles per half
+
+
 def conv3d_winograd(x, U, bias, out, *, T, cin, cout, flags=0, mask=None, add=None, keep_v=False, m=2, kd=3):
+    """Conv3d k3 p1 s1 (kd=3; or Conv2d 3x3 p1 s1, kd=1, T=1), or its data gradient with the dgrad filter banks, on
+    [N,H,W,C] frames, clips of T frames.
+    keep_v: return the transformed input planes (the filter gradient of the same layer needs exactly them:
+    conv3d_wgrad_winograd(V=...)) instead of using the per-stream scratch.
+
+    The three kernels of one convolution are a chain -- HBM-bound transform, matrix-bound GEMM, HBM-bound transform -- so
+    alone they can only run one after the other.  Large batches are therefore cut into two halves of whole clips that run
+    on two streams, the second started when the first half's input transform is done: its transforms then run beside the
+    first half's GEMM and vice versa.  MEASURED (tools/split_probe.py, tools/ab.sh): a free-running transform beside the
+    GEMM costs 0.01 ms instead of 0.2 (tools/coexist_probe.py), but inside the dependent chain the six shorter launches and
+    two cross-stream hand-offs give most of it back: 1.498 -> 1.468 ms per 64^2 Conv3d, +6 % on the filter-gradient form,
+    nothing on the whole step.  Hence opt-in only (FACEOFF_WINO_SPLIT=1)."""
+    N, H, W, _ = x.shape
+    if not _halves_ok(N, T if kd > 1 else 1, H // m, W // m) or m != 4:
+        return _conv3d_winograd_one(x, U, bias, out, T=T, cin=cin, cout=cout, flags=flags, mask=mask, add=add, keep_v=keep_v, m=m, kd=kd)
+    h = N // 2
+    main, side = torch.cuda.current_stream(), _side_stream(x.device)
+    sl = lambda t, a, b: None if t is None else t[a:b]
+    res = [None, None]
+
+    def second_half():
+        ev = torch.cuda.Event()
+        ev.record(main)
+        side.wait_event(ev)
+        with torch.cuda.stream(side):
+            res[1] = _conv3d_winograd_one(x[h:], U, bias, out[h:], T=T, cin=cin, cout=cout, flags=flags, mask=sl(mask, h, N), add=sl(add, h, N),
+                                          keep_v=keep_v, m=m, kd=kd)
+    res[0] = _conv3d_winograd_one(x[:h], U, bias, out[:h], T=T, cin=cin, cout=cout, flags=flags, mask=sl(mask, 0, h), add=sl(add, 0, h),
+                                  keep_v=keep_v, m=m, kd=kd, after_input=second_half)
+    main.wait_stream(side)
+    return res if keep_v else None
+
+
+def _conv3d_winograd_one(x, U, bias, out, *, T, cin, cout, flags=0, mask=None, add=None, keep_v=False, m=2, kd=3, after_input=None):
     """Conv3d k3 p1 s1 (kd=3; or Conv2d 3x3 p1 s1, kd=1, T=1), or its data gradient with the dgrad filter banks, on
     [N,H,W,C] frames, clips of T frames.
     keep_v: return the transformed input planes in their own tensor (the filter gradient of the same layer needs exactly
@@ -252,6 +304,8 @@ def conv3d_winograd(x, U, bias, out, *, T, cin, cout, flags=0, mask=None, add=No
     if keep_v:
         V = torch.empty(P * plane_v, device=x.device, dtype=torch.float32)
     _lib.call("fo_wino_input", _ptr(x), ld_of(x), _ptr(V), N, H, W, cin, m, _stream())
+    if after_input is not None:
+        after_input()                 # (the batch-halves pipeline starts its second half here)
     bank = pad_out(cout) * kd * cin                                 # floats per filter bank
     banked = (N * Ht * Wt) % 128 == 0
     per = max(1, min(P, ((1 << 31) - 1) // max(plane_v * 4, plane_m * 4))) if banked else 1   # planes per launch (2 GiB window)
@@ -298,10 +352,9 @@ def wino_wgrad_ok(H, W, N, T, m=2, kd=3):
             and (m + 2) ** 2 * N * (H // m) * (W // m) * 128 * 4 < (1 << 31))
 
 
-def conv3d_wgrad_winograd(g, x, dw, dbias, *, T, a_real, b_real, V=None, m=2, kd=3):
-    """Filter gradient of a Conv3d k3 p1 in the Winograd domain: dU[xi] = sum dM[xi] (x) V[xi] ((m+2)^2 banked wgrad
-    GEMMs with a (3,1,1) geometry), dW = G^T dU G; 2.25x (m=2) / 4x (m=4) fewer MFMA FLOP than the direct form.
-    dbias = column sums of g."""
+def _wgrad_winograd_dU(g, x, *, T, a_real, b_real, V=None, m=2, kd=3, after_gradout=None):
+    """dU[xi][co][ci][kd] = sum over the frames of g / x of dM[xi] (x) V[xi]  (one banked wgrad GEMM launch); returns dU
+    (a slice of this stream's workspace)."""
     N, H, W, _ = x.shape
     Ht, Wt, P = H // m, W // m, (m + 2) ** 2
     cin, cout = b_real, a_real
@@ -313,6 +366,8 @@ def conv3d_wgrad_winograd(g, x, dw, dbias, *, T, a_real, b_real, V=None, m=2, kd
         V, dM = _wino_buffers((P * plane_v, P * plane_m), x.device)
         _lib.call("fo_wino_input", _ptr(x), ld_of(x), _ptr(V), N, H, W, cin, m, _stream())
     _lib.call("fo_wino_gradout", _ptr(g), ld_of(g), _ptr(dM), N, H, W, cout, m, _stream())
+    if after_gradout is not None:
+        after_gradout()
     d = _desc(N=P * N, T=T if kd > 1 else 1, Hin=1, Win=Ht * Wt, Hm=1, Wm=Ht * Wt, Hout=1, Wout=Ht * Wt, Cin=cin, Cout=cout, KD=kd,
               KH=1, KW=1, stride=1, padD=kd // 2, padH=0, padW=0, ostride=1, ophH=0, ophW=0, ldIn=cin, ldOut=cout, ldMask=0, ldAdd=0,
               flags=0)
@@ -329,6 +384,35 @@ def conv3d_wgrad_winograd(g, x, dw, dbias, *, T, a_real, b_real, V=None, m=2, kd
     _lib.call("fo_conv_wgrad_banked", C.byref(d), _ptr(dM), _ptr(V), _ptr(dU), cout, cin, _ptr(ws), C.c_int64(nbytes), P, _stream())
     if prof is not None:
         prof.end()
+    return dU
+
+
+def conv3d_wgrad_winograd(g, x, dw, dbias, *, T, a_real, b_real, V=None, m=2, kd=3):
+    """Filter gradient of a Conv3d k3 p1 in the Winograd domain: dU[xi] = sum dM[xi] (x) V[xi] ((m+2)^2 banked wgrad
+    GEMMs with a (3,1,1) geometry), dW = G^T dU G; 2.25x (m=2) / 4x (m=4) fewer MFMA FLOP than the direct form.
+    dbias = column sums of g.  V: the forward's transformed input (a tensor, or the two half-batch tensors the batch-halves
+    pipeline of conv3d_winograd kept: the halves' dU are then computed on two streams and added)."""
+    N = x.shape[0]
+    cin, cout = b_real, a_real
+    P = (m + 2) ** 2
+    if isinstance(V, (list, tuple)):
+        h = N // 2
+        main, side = torch.cuda.current_stream(), _side_stream(x.device)
+        res = [None, None]
+
+        def second_half():
+            ev = torch.cuda.Event()
+            ev.record(main)
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                res[1] = _wgrad_winograd_dU(g[h:], x[h:], T=T, a_real=a_real, b_real=b_real, V=V[1], m=m, kd=kd)
+        res[0] = _wgrad_winograd_dU(g[:h], x[:h], T=T, a_real=a_real, b_real=b_real, V=V[0], m=m, kd=kd, after_gradout=second_half)
+        main.wait_stream(side)
+        dU = res[0]
+        n = dU.numel()
+        _lib.call("fo_add", _ptr(dU), n, _ptr(res[1]), n, _ptr(dU), n, C.c_int64(1), n, _stream())
+    else:
+        dU = _wgrad_winograd_dU(g, x, T=T, a_real=a_real, b_real=b_real, V=V, m=m, kd=kd)
     _lib.call("fo_wino_wgrad_out", _ptr(dU), _ptr(dw), cout, cin, kd, m, _stream())
     if dbias is not None:
         bias_grad(g, dbias, cout)
