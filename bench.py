@@ -137,6 +137,12 @@ def main():
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    # FACEOFF_BENCH_SHARE_GPU=1 + FACEOFF_BENCH_BACKEND=gloo (tests on a one-GPU box): every rank on device 0, collectives over
+    # gloo -- the multi-rank control flow of this script (barriers, max over ranks, the legs, rank 0's JSON line) without RCCL
+    share_gpu = bool(os.environ.get("FACEOFF_BENCH_SHARE_GPU"))
+    backend = os.environ.get("FACEOFF_BENCH_BACKEND", "nccl")
+    if share_gpu:
+        local_rank = 0
     if torch.cuda.device_count() <= local_rank:
         raise SystemExit(f"bench.py: LOCAL_RANK={local_rank} but {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local_rank)
@@ -156,7 +162,10 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.distributed.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=dev)
+        else:
+            torch.distributed.init_process_group(backend)
 
     from faceoff_amd import ops
     from faceoff_amd.engine import VQVAEEngine
@@ -255,14 +264,14 @@ def main():
     fps = world * frames * args.steps / dt
     out = {
         "metric": "train frames/sec (256x256, T=5, bs=32/GPU)", "value": round(fps, 2), "unit": "frames/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+        "n_gpus": world if not share_gpu else 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
         "ms_per_step_hip_events": round(ms_events, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic U(-1,1) inputs resident in HBM; random-init weights (kaiming-uniform x2 gain, codebook N(0,0.3^2))",
         "config": {"workload": (f"C2: VQ-VAE-2 + Conv3d latent, {H}x{H}, T={T}, {B} clips/GPU, recon+VQ loss, fwd+bwd+Adam"
                                 if not args.perceptual else
                                 f"C3: C2 (fp32) + LPIPS/VGG-16 perceptual loss in {args.lpips_dtype} (seeded VGG weights), {H}x{H}, T={T}, {B} clips/GPU"),
-                   "global_clips": B * world, "frames_per_step": frames * world, "parallelism": f"dp{world}",
+                   "global_clips": B * world, "frames_per_step": frames * world, "parallelism": f"dp{world}" + (" (ranks sharing one GPU over gloo: a control-flow test, not a measurement)" if share_gpu else ""),
                    "conv3d_algorithm": ("winograd (fwd, dgrad, wgrad), F(4x4,3x3) where a plane is whole GEMM tiles else F(2x2,3x3)"
                                         if winograd_on else "direct")},
         "loss": {"recon": round(recon.item(), 6), "latent": round(latent.item(), 6)},

@@ -43,3 +43,26 @@ def test_bench_multi_gpu_code_path_with_one_rank():
     assert len(lines) == 1, lines
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["parallelism"] == "dp1"
+
+
+def test_bench_two_rank_control_flow_on_one_gpu():
+    """The multi-rank flow of bench.py -- process group, barriers, max over ranks, every leg (direct-conv, c3, c5) run by
+    every rank, rank 0 alone printing the JSON line, clean exits -- with two ranks sharing device 0 over gloo (the box has one
+    GPU; RCCL refuses two ranks on one device).  Small clip count: this checks the flow, not the speed."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   FACEOFF_BENCH_SHARE_GPU="1", FACEOFF_BENCH_BACKEND="gloo")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--clips", "8",
+                                       "--no-cpu-baseline"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT, env=env))
+    outs = [p.communicate(timeout=900) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-1500:] for o in outs]
+    lines0 = [l for l in outs[0][0].splitlines() if l.strip()]
+    assert len(lines0) == 1 and not outs[1][0].strip(), (lines0, outs[1][0][-300:])
+    d = json.loads(lines0[0])
+    assert d["config"]["global_clips"] == 16 and d["config"]["frames_per_step"] == 80 and "c3" in d and "c5" in d and "direct_conv" in d["roofline"]
+    assert abs(d["value"] - 80 / (d["ms_per_step"] * 1e-3)) < 1e-2 * d["value"]
