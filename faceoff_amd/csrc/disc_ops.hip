@@ -10,26 +10,31 @@ namespace {
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
-// sum over the 64 row slots of each of the 4 channel groups of a 256-thread workgroup (thread = slot * 4 + group)
+constexpr int IN_G = 2;                 // float4 channel groups per workgroup (8 channels)
+constexpr int IN_SLOTS = 256 / IN_G;    // row slots
+// sum over the row slots of each channel group of a 256-thread workgroup (thread = slot * IN_G + group)
 __device__ __forceinline__ f32x4 reduce_slots(f32x4 v, f32x4* sh, int tid) {
   sh[tid] = v;
   __syncthreads();
-  for (int s = 128; s >= 4; s >>= 1) {
+  for (int s = 128; s >= IN_G; s >>= 1) {
     if (tid < s) sh[tid] += sh[tid + s];
     __syncthreads();
   }
-  const f32x4 r = sh[tid & 3];
+  const f32x4 r = sh[tid % IN_G];
   __syncthreads();
   return r;
 }
 
-// One workgroup = 16 channels x all rows of the sample (the normed layers have <= 21k positions x 128..512 channels).
+// One workgroup = 8 channels x all rows of one sample (blockIdx.y): the normed layers have <= 21k positions x 128..512 channels.
 __global__ __launch_bounds__(256) void instnorm_lrelu_fwd_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy,
                                                                  long long rows, int C, float eps, float slope, float* __restrict__ stats,
                                                                  float* __restrict__ running, float momentum, int use_running) {
   __shared__ f32x4 sh[256];
-  const int tid = threadIdx.x, grp = tid & 3, slot = tid >> 2;
-  const int c = blockIdx.x * 16 + grp * 4;
+  const int tid = threadIdx.x, grp = tid % IN_G, slot = tid / IN_G;
+  const int c = blockIdx.x * (4 * IN_G) + grp * 4;
+  x += (long long)blockIdx.y * rows * ldx;            // samples are consecutive [rows][ld] blocks
+  y += (long long)blockIdx.y * rows * ldy;
+  stats += (long long)blockIdx.y * 2 * C;
   f32x4 mean, rstd;
   if (use_running) {
     mean = ld4(running + c);
@@ -37,10 +42,10 @@ __global__ __launch_bounds__(256) void instnorm_lrelu_fwd_kernel(const float* __
     for (int e = 0; e < 4; ++e) rstd[e] = 1.f / sqrtf(v[e] + eps);
   } else {
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    for (long long r = slot; r < rows; r += 64) s += ld4(x + r * ldx + c);
+    for (long long r = slot; r < rows; r += IN_SLOTS) s += ld4(x + r * ldx + c);
     mean = reduce_slots(s, sh, tid) * (1.f / (float)rows);
     f32x4 q = {0.f, 0.f, 0.f, 0.f};
-    for (long long r = slot; r < rows; r += 64) { const f32x4 dlt = ld4(x + r * ldx + c) - mean; q += dlt * dlt; }
+    for (long long r = slot; r < rows; r += IN_SLOTS) { const f32x4 dlt = ld4(x + r * ldx + c) - mean; q += dlt * dlt; }
     const f32x4 var = reduce_slots(q, sh, tid) * (1.f / (float)rows);       // biased, as F.instance_norm normalises
     for (int e = 0; e < 4; ++e) rstd[e] = 1.f / sqrtf(var[e] + eps);
     if (running && slot == 0) {          // running statistics: momentum update with the UNBIASED variance
@@ -50,7 +55,7 @@ __global__ __launch_bounds__(256) void instnorm_lrelu_fwd_kernel(const float* __
     }
   }
   if (slot == 0) { st4(stats + c, mean); st4(stats + C + c, rstd); }
-  for (long long r = slot; r < rows; r += 64) {
+  for (long long r = slot; r < rows; r += IN_SLOTS) {
     f32x4 z = (ld4(x + r * ldx + c) - mean) * rstd;
     for (int e = 0; e < 4; ++e) z[e] = z[e] > 0.f ? z[e] : z[e] * slope;
     st4(y + r * ldy + c, z);
@@ -62,11 +67,15 @@ __global__ __launch_bounds__(256) void instnorm_lrelu_bwd_kernel(const float* __
                                                                  const float* __restrict__ stats, float* __restrict__ gx, int ldgx,
                                                                  long long rows, int C, float slope) {
   __shared__ f32x4 sh[256];
-  const int tid = threadIdx.x, grp = tid & 3, slot = tid >> 2;
-  const int c = blockIdx.x * 16 + grp * 4;
+  const int tid = threadIdx.x, grp = tid % IN_G, slot = tid / IN_G;
+  const int c = blockIdx.x * (4 * IN_G) + grp * 4;
+  gy += (long long)blockIdx.y * rows * ldg;
+  y += (long long)blockIdx.y * rows * ldy;
+  gx += (long long)blockIdx.y * rows * ldgx;
+  stats += (long long)blockIdx.y * 2 * C;
   const float inv_slope = 1.f / slope;
   f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
-  for (long long r = slot; r < rows; r += 64) {
+  for (long long r = slot; r < rows; r += IN_SLOTS) {
     const f32x4 yv = ld4(y + r * ldy + c);
     f32x4 g = ld4(gy + r * ldg + c);
     for (int e = 0; e < 4; ++e) {
@@ -80,7 +89,7 @@ __global__ __launch_bounds__(256) void instnorm_lrelu_bwd_kernel(const float* __
   const float inv = 1.f / (float)rows;
   const f32x4 m1 = reduce_slots(s1, sh, tid) * inv, m2 = reduce_slots(s2, sh, tid) * inv;
   const f32x4 rstd = ld4(stats + C + c);
-  for (long long r = slot; r < rows; r += 64) {
+  for (long long r = slot; r < rows; r += IN_SLOTS) {
     const f32x4 yv = ld4(y + r * ldy + c);
     f32x4 g = ld4(gy + r * ldg + c), o;
     for (int e = 0; e < 4; ++e) {
@@ -91,6 +100,25 @@ __global__ __launch_bounds__(256) void instnorm_lrelu_bwd_kernel(const float* __
     }
     st4(gx + r * ldgx + c, o);
   }
+}
+
+// running statistics of a batch of samples normalised in one launch: the reference calls the module once per sample, in
+// `order`, and each call moves running_mean / running_var by `momentum` (unbiased variance) -- applied here in that order
+__global__ void instnorm_running_kernel(const float* __restrict__ stats, int N, const int* __restrict__ order, int C, float rows, float eps,
+                                        float momentum, float* __restrict__ running) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float rm = running[c], rv = running[C + c];
+  const float unb = rows > 1.f ? rows / (rows - 1.f) : 1.f;
+  for (int i = 0; i < N; ++i) {
+    const float* st = stats + (long long)order[i] * 2 * C;
+    const float rstd = st[C + c];
+    const float var = 1.f / (rstd * rstd) - eps;
+    rm = rm * (1.f - momentum) + st[c] * momentum;
+    rv = rv * (1.f - momentum) + var * unb * momentum;
+  }
+  running[c] = rm;
+  running[C + c] = rv;
 }
 
 // window of output o along one dimension: inputs [o*s - 1, o*s + 1] clipped to [0, n) (k = 3, pad = 1); k = 1: just o*s
@@ -281,20 +309,47 @@ extern "C" {
 
 int fo_instnorm_lrelu_fwd(const float* x, int ldx, float* y, int ldy, int64_t rows, int C, float eps, float slope, float* stats,
                           float* running, float momentum, int use_running, void* stream) {
-  FO_REQUIRE(x && y && stats && rows > 0 && C > 0 && C % 16 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && fo_aligned16(x) && fo_aligned16(y),
-             FO_E_SHAPE, "instnorm: C %% 16 == 0, ld %% 4 == 0, 16-byte alignment");
+  FO_REQUIRE(x && y && stats && rows > 0 && C > 0 && C % 8 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && fo_aligned16(x) && fo_aligned16(y),
+             FO_E_SHAPE, "instnorm: C %% 8 == 0, ld %% 4 == 0, 16-byte alignment");
   FO_REQUIRE(!use_running || running, FO_E_SHAPE, "instnorm: eval mode needs the running statistics");
-  hipLaunchKernelGGL(instnorm_lrelu_fwd_kernel, dim3(C / 16), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, (long long)rows, C, eps,
+  hipLaunchKernelGGL(instnorm_lrelu_fwd_kernel, dim3(C / 8, 1), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, (long long)rows, C, eps,
                      slope, stats, running, momentum, use_running);
+  FO_CHECK_LAUNCH();
+  return FO_OK;
+}
+
+int fo_instnorm_lrelu_fwd_batch(const float* x, int ldx, float* y, int ldy, int N, int64_t rows, int C, float eps, float slope,
+                                float* stats, float* running, const int32_t* order, float momentum, int use_running, void* stream) {
+  FO_REQUIRE(x && y && stats && N > 0 && rows > 0 && C > 0 && C % 8 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && fo_aligned16(x) && fo_aligned16(y),
+             FO_E_SHAPE, "instnorm_batch: C %% 8 == 0, ld %% 4 == 0, 16-byte alignment");
+  FO_REQUIRE(!use_running || running, FO_E_SHAPE, "instnorm_batch: eval mode needs the running statistics");
+  hipLaunchKernelGGL(instnorm_lrelu_fwd_kernel, dim3(C / 8, N), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, (long long)rows, C, eps,
+                     slope, stats, use_running ? running : nullptr, momentum, use_running);
+  FO_CHECK_LAUNCH();
+  if (!use_running && running) {
+    FO_REQUIRE(order, FO_E_SHAPE, "instnorm_batch: the sample order of the running-statistics updates is required");
+    hipLaunchKernelGGL(instnorm_running_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats, N, order, C, (float)rows, eps,
+                       momentum, running);
+    FO_CHECK_LAUNCH();
+  }
+  return FO_OK;
+}
+
+int fo_instnorm_lrelu_bwd_batch(const float* gy, int ldg, const float* y, int ldy, const float* stats, float* gx, int ldgx, int N,
+                                int64_t rows, int C, float slope, void* stream) {
+  FO_REQUIRE(gy && y && stats && gx && N > 0 && rows > 0 && C % 8 == 0 && ldg % 4 == 0 && ldy % 4 == 0 && ldgx % 4 == 0 && slope != 0.f, FO_E_SHAPE,
+             "instnorm_bwd_batch: C %% 8 == 0, ld %% 4 == 0, slope != 0");
+  hipLaunchKernelGGL(instnorm_lrelu_bwd_kernel, dim3(C / 8, N), dim3(256), 0, (hipStream_t)stream, gy, ldg, y, ldy, stats, gx, ldgx,
+                     (long long)rows, C, slope);
   FO_CHECK_LAUNCH();
   return FO_OK;
 }
 
 int fo_instnorm_lrelu_bwd(const float* gy, int ldg, const float* y, int ldy, const float* stats, float* gx, int ldgx, int64_t rows,
                           int C, float slope, void* stream) {
-  FO_REQUIRE(gy && y && stats && gx && rows > 0 && C % 16 == 0 && ldg % 4 == 0 && ldy % 4 == 0 && ldgx % 4 == 0 && slope != 0.f, FO_E_SHAPE,
-             "instnorm_bwd: C %% 16 == 0, ld %% 4 == 0, slope != 0");
-  hipLaunchKernelGGL(instnorm_lrelu_bwd_kernel, dim3(C / 16), dim3(256), 0, (hipStream_t)stream, gy, ldg, y, ldy, stats, gx, ldgx,
+  FO_REQUIRE(gy && y && stats && gx && rows > 0 && C % 8 == 0 && ldg % 4 == 0 && ldy % 4 == 0 && ldgx % 4 == 0 && slope != 0.f, FO_E_SHAPE,
+             "instnorm_bwd: C %% 8 == 0, ld %% 4 == 0, slope != 0");
+  hipLaunchKernelGGL(instnorm_lrelu_bwd_kernel, dim3(C / 8, 1), dim3(256), 0, (hipStream_t)stream, gy, ldg, y, ldy, stats, gx, ldgx,
                      (long long)rows, C, slope);
   FO_CHECK_LAUNCH();
   return FO_OK;

@@ -189,6 +189,7 @@ class DiscEngine:
 
     def _scale_fwd(self, x, prefix, training, order):
         N = x.shape[0]
+        order_t = torch.tensor(order, dtype=torch.int32, device=self.device)
         feat, stats, inp = [], [None] * 5, []
         h, cin = x, 32
         for j, (co, s) in enumerate(zip(DISC_CHANNELS, STRIDES)):
@@ -218,9 +219,8 @@ class DiscEngine:
                 st = torch.empty((N, 2 * co), device=self.device)
                 z = torch.empty_like(y)
                 run = self.buffers[key + ".1._both"]
-                for n in order:
-                    _lib.call("fo_instnorm_lrelu_fwd", ops._ptr(y[n]), ld_out, ops._ptr(z[n]), ld_out, C.c_int64(rows), co, C.c_float(IN_EPS),
-                              C.c_float(SLOPE), ops._ptr(st[n]), ops._ptr(run), C.c_float(IN_MOMENTUM), int(not training), ops._stream())
+                _lib.call("fo_instnorm_lrelu_fwd_batch", ops._ptr(y), ld_out, ops._ptr(z), ld_out, N, C.c_int64(rows), co, C.c_float(IN_EPS),
+                          C.c_float(SLOPE), ops._ptr(st), ops._ptr(run), ops._ptr(order_t), C.c_float(IN_MOMENTUM), int(not training), ops._stream())
                 stats[j] = st
                 y = z
             feat.append(y)
@@ -269,9 +269,8 @@ class DiscEngine:
             if 1 <= j <= 3:              # g is wrt the post-activation output: through LeakyReLU and InstanceNorm
                 rows = dd[0] * dd[1] * dd[2]
                 gc = torch.empty_like(g)
-                for n in range(N):
-                    _lib.call("fo_instnorm_lrelu_bwd", ops._ptr(g[n]), g.shape[-1], ops._ptr(feat[j][n]), feat[j].shape[-1],
-                              ops._ptr(stats[j][n]), ops._ptr(gc[n]), gc.shape[-1], C.c_int64(rows), co, C.c_float(SLOPE), ops._stream())
+                _lib.call("fo_instnorm_lrelu_bwd_batch", ops._ptr(g), g.shape[-1], ops._ptr(feat[j]), feat[j].shape[-1], ops._ptr(stats[j]),
+                          ops._ptr(gc), gc.shape[-1], N, C.c_int64(rows), co, C.c_float(SLOPE), ops._stream())
                 g = gc
             if j == 0:
                 # first layer on the space-to-depth image (x_in = xs): filter gradient in the k2 layout, mapped back to k4

@@ -268,6 +268,13 @@ int fo_instnorm_lrelu_fwd(const float* x, int ldx, float* y, int ldy, int64_t ro
 /* gx = d loss / d x given gy = d loss / d y and the saved y, stats (training-mode statistics). */
 int fo_instnorm_lrelu_bwd(const float* gy, int ldg, const float* y, int ldy, const float* stats, float* gx, int ldgx, int64_t rows,
                           int C, float slope, void* stream);
+/* The same for N samples stored one after the other ([N][rows][ld]) in ONE launch; stats [N][2C].  Training mode moves the
+ * running statistics once per sample in the order given by `order` (device int32[N]: the reference calls the module sample by
+ * sample). */
+int fo_instnorm_lrelu_fwd_batch(const float* x, int ldx, float* y, int ldy, int N, int64_t rows, int C, float eps, float slope,
+                                float* stats, float* running, const int32_t* order, float momentum, int use_running, void* stream);
+int fo_instnorm_lrelu_bwd_batch(const float* gy, int ldg, const float* y, int ldy, const float* stats, float* gx, int ldgx, int N,
+                                int64_t rows, int C, float slope, void* stream);
 /* AvgPool(k = 3 in every pooled dimension, padding 1, count_include_pad = False) of [D][H][W][C] with strides (sD, sH, sW);
  * kD = 1 leaves the depth axis alone (2-D pooling).  _bwd ADDS the gradient into gx (zero it first). */
 int fo_avgpool3_fwd(const float* x, float* y, int D, int H, int W, int C, int ld, int kD, int sD, int sH, int sW, void* stream);
