@@ -454,6 +454,190 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 1) void conv_bf16_big_kerne
   }
 }
 
+// ------------------------------------------------------------------------------------------------ big tiles, LDS-DMA staging
+// The 256 x 256 tile again, with the operands going global -> LDS directly (buffer_load_dwordx4 ... lds): no staging VGPRs,
+// no ds_write pass.  An LDS-DMA writes 64 lanes x 16 B LINEARLY from a wave-uniform base, so rows cannot be padded; the
+// bank-conflict fix moves to a swizzle instead: LDS rows are 128 B (one 64-deep K-step of one GEMM row = eight 16-B chunks)
+// and chunk c of row r lives at chunk position c ^ ((r >> 1) & 7).  The swizzle is applied on the SOURCE side (lane l of a
+// DMA instruction = row l / 8, LDS chunk position l % 8 fetches source chunk (l % 8) ^ ((row >> 1) & 7)) and again on the
+// fragment read (same involution), never on the LDS destination.  With it the 16 lanes of a ds_read_b128 group (rows r..r+15
+// at one logical chunk) cover all 16 sixteen-byte bank groups.  Two LDS stages: the DMAs of step n+1 are issued at the top
+// of step n (the stage they fill was last read in step n-1, behind that step's barrier) and retired by the vmcnt(0) that
+// __syncthreads() implies at the bottom -- a K-step is ~4000 cycles for the two waves of a SIMD, longer than an HBM miss.
+template <int TM, int TN>
+__global__ __launch_bounds__(512, 1) void conv_bf16_dma_kernel(const ConvArgsH a) {
+  constexpr int BMB = 256, BNB = 256, WAVES_N = 4;
+  static_assert(TM == 4 && TN == 2, "2 x 4 waves of 128 x 64");
+  constexpr int STAGE = (BMB + BNB) * 128;                // bytes per stage
+  constexpr int C_LD = TN * 32 + 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const fo_conv_desc& d = a.d;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int logical = fo_xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_n = logical % a.tilesN;
+  const int tile_m = logical / a.tilesN;
+  const int ntaps = d.KH * d.KW;
+
+  // ---- DMA roles: instruction i (0..3) of wave w stages tile rows (i*8 + w)*8 .. +7, lane = (row % 8, chunk position)
+  const int drow = lane >> 3, dpos = lane & 7;
+  int rowoffA[4];
+  unsigned tapmaskA[4], woffB[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (i * 8 + wave) * 8 + drow;            // row of the tile (A: pixel, B: output channel)
+    const int chunk = dpos ^ ((row >> 1) & 7);            // source chunk this lane fetches
+    const int m = tile_m * BMB + row;
+    const bool pv = m < a.M;
+    const int mm = pv ? m : 0;
+    const int n = mm / a.HWm;
+    const int rem = mm - n * a.HWm;
+    const int y = rem / d.Wm;
+    const int x = rem - y * d.Wm;
+    const int py = y - d.padH, px = x - d.padW;
+    rowoffA[i] = ((n * d.Hin + py) * d.Win + px) * d.ldIn * 2 + chunk * 16;
+    unsigned mk = 0;
+    for (int tp = 0; tp < ntaps; ++tp) {
+      const int kh = tp / d.KW, kw = tp - kh * d.KW;
+      const bool ok = pv & ((unsigned)(py + kh) < (unsigned)d.Hin) & ((unsigned)(px + kw) < (unsigned)d.Win);
+      mk |= (ok ? 1u : 0u) << tp;
+    }
+    tapmaskA[i] = mk;
+    woffB[i] = (unsigned)(((size_t)(tile_n * BNB + row) * a.Ktot) * 2 + chunk * 16);
+  }
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in), 0, a.inBytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rwp = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wp), 0, a.wpBytes, 0x00020000);
+  typedef __attribute__((address_space(3))) unsigned char lds_byte;
+  lds_byte* const lds3 = (lds_byte*)lds;
+
+  int ld_step = 0, ld_tap = 0, ld_kh = 0, ld_kw = 0, ld_chunk = 0;
+  auto dma_step = [&](int stage) {
+    const int stepoff = ((ld_kh * d.Win + ld_kw) * d.ldIn + ld_chunk * 64) * 2;
+    lds_byte* const sa = lds3 + stage * STAGE;
+    lds_byte* const sb = sa + BMB * 128;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const unsigned pad = (((tapmaskA[i] >> ld_tap) & 1u) - 1u) & OOB;       // padding tap / row past M -> zeros
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void*)(sa + (i * 8 + wave) * 1024), 16,
+                                               (unsigned)(rowoffA[i] + stepoff) | pad, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rwp, (__attribute__((address_space(3))) void*)(sb + (i * 8 + wave) * 1024), 16,
+                                               ld_step < a.ksteps ? woffB[i] + ld_step * 128 : OOB, 0, 0, 0);
+    ++ld_step;
+    if (++ld_chunk == a.cinChunks) {
+      ld_chunk = 0;
+      ++ld_tap;
+      if (++ld_kw == d.KW) { ld_kw = 0; ++ld_kh; }
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragment addressing: row = block row + l31 (blocks are multiples of 32: (row >> 1) & 7 = (l31 >> 1) & 7), logical chunk 2s + half
+  const int xr = (l31 >> 1) & 7;
+  int swz[4];
+#pragma unroll
+  for (int sidx = 0; sidx < 4; ++sidx) swz[sidx] = ((2 * sidx + half) ^ xr) * 16;
+
+  dma_step(0);
+  __syncthreads();
+  const int nsteps = a.ksteps;
+  for (int step = 0; step < nsteps; ++step) {
+    const int cur = step & 1;
+    dma_step(cur ^ 1);                                    // step + 1 (past the end: zeros, never read)
+    const unsigned char* As = lds + cur * STAGE + (wm * TM * 32 + l31) * 128;
+    const unsigned char* Bs = lds + cur * STAGE + BMB * 128 + (wn * TN * 32 + l31) * 128;
+    bf16x8 fa[2][TM], fb[2][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const bf16x8*>(As + i * 32 * 128 + swz[0]);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb[0][j] = *reinterpret_cast<const bf16x8*>(Bs + j * 32 * 128 + swz[0]);
+#pragma unroll
+    for (int sidx = 0; sidx < 4; ++sidx) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (sidx < 3) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[(sidx + 1) & 1][i] = *reinterpret_cast<const bf16x8*>(As + i * 32 * 128 + swz[sidx + 1]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[(sidx + 1) & 1][j] = *reinterpret_cast<const bf16x8*>(Bs + j * 32 * 128 + swz[sidx + 1]);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[sidx & 1][i], fb[sidx & 1][j], acc[i][j], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();                                      // (implies vmcnt(0): this wave's DMAs of step + 1 have landed)
+  }
+
+  // ---- epilogue: as conv_bf16_big_kernel
+  float* Cs = reinterpret_cast<float*>(lds) + wave * 32 * C_LD;
+  const int flags = d.flags;
+  constexpr int C8 = TN * 4, RPP = 64 / C8;
+  const int c8 = lane % C8, r0 = lane / C8;
+  const int co = tile_n * BNB + wn * TN * 32 + c8 * 8;
+  float bv[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bv[e] = ((flags & FO_BIAS) && co + e < d.Cout) ? a.bias[co + e] : 0.f;
+  __bf16* out = reinterpret_cast<__bf16*>(a.out);
+  const __bf16* mask = reinterpret_cast<const __bf16*>(a.mask);
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Cs[((r & 3) + 8 * (r >> 2) + 4 * half) * C_LD + j * 32 + l31] = acc[i][j][r];
+    __builtin_amdgcn_wave_barrier();
+    const int mbase = tile_m * BMB + (wm * TM + i) * 32;
+#pragma unroll
+    for (int p = 0; p < 32 / RPP; ++p) {
+      const int row = p * RPP + r0;
+      const int m = mbase + row;
+      const float* crow = Cs + row * C_LD + c8 * 8;
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(crow);
+      const f32x4 v1 = *reinterpret_cast<const f32x4*>(crow + 4);
+      if (m >= a.M || co >= d.Cout) continue;
+      float v[8] = {v0.x + bv[0], v0.y + bv[1], v0.z + bv[2], v0.w + bv[3], v1.x + bv[4], v1.y + bv[5], v1.z + bv[6], v1.w + bv[7]};
+      if (flags & FO_MASK) {
+        const bf16x8 mk = *reinterpret_cast<const bf16x8*>(mask + (size_t)m * d.ldMask + co);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (float)mk[e] > 0.f ? v[e] : 0.f;
+      }
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (__bf16)((flags & FO_OUT_RELU) ? fmaxf(v[e], 0.f) : v[e]);
+      *reinterpret_cast<bf16x8*>(out + (size_t)m * d.ldOut + co) = o;
+    }
+  }
+}
+
+int launch_dma(const ConvArgsH& a, hipStream_t s) {
+  constexpr int ldsBytes = 2 * (256 + 256) * 128;
+  static bool attr_set = false;
+  auto kern = conv_bf16_dma_kernel<4, 2>;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, ldsBytes) != hipSuccess) {
+      fo_set_error("conv_bf16: cannot reserve %d bytes of LDS", ldsBytes);
+      return FO_E_HIP;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(a.tilesM * a.tilesN), dim3(512), ldsBytes, s, a);
+  FO_CHECK_LAUNCH();
+  return FO_OK;
+}
+
 template <int BN, int WAVES_M, int WAVES_N, int TM, int TN>
 int launch_big(const ConvArgsH& a, hipStream_t s) {
   constexpr int ldsBytes = 2 * (256 + BN) * ROWB;
@@ -579,6 +763,8 @@ int fo_conv_igemm_bf16(const fo_conv_desc* d, const void* in, const void* wp, co
     const bool forced = force && atoi(force);
     if (d->Cout % 256 == 0 && (long long)tilesM256 * (d->Cout / 256) >= 3ll * cus) {
       a.tilesM = tilesM256; a.tilesN = d->Cout / 256;
+      const char* nodma = getenv("FACEOFF_BF16_NO_DMA");              // diagnostics: register-staged form of the same tile
+      if (!(nodma && atoi(nodma))) return launch_dma(a, s);
       return launch_big<256, 2, 4, 4, 2>(a, s);
     }
     if (forced && d->Cout % 128 == 0) {
