@@ -275,220 +275,79 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvArgsH a) {
   }
 }
 
-// ------------------------------------------------------------------------------------------------ big tiles
-// 256 x BN tile, ONE workgroup per CU with 8 waves (two per SIMD), each wave (TM x TN) 32x32 accumulators (128 x 64 for the
-// 256 x 256 tile; a four-wave 128 x 128-per-wave form measured 15 % slower: one wave per SIMD leaves nobody to cover its
-// fragment reads and barrier waits).  Why: at the bf16 rate a 128 x 128 tile with 2 x 2 accumulators per wave asks for ~39 TB/s from L2 (32 KB
-// per 2.1 MFLOP K-step) and ~190 B/clk from LDS (every fragment feeds only 2 MFMAs) -- both beyond the hardware.  256 x 256
-// halves the L2 bytes per FLOP, 4 x 2 accumulators per wave cut the LDS reads per MFMA by a third, and a K-step becomes
-// 64 MFMAs per wave x 2 waves per SIMD = ~4000 cycles -- longer than an HBM miss -- so a one-deep prefetch (loads of step
-// n+1 issued before step n's MFMAs, stored to the other LDS buffer behind them) covers the memory latency, while the two
-// waves of a SIMD cover each other's fragment reads and barrier waits.  Epilogue: each wave transposes its accumulators 32
-// rows at a time through its own LDS patch (wave-local) so that bias / ReLU / mask / rounding / stores are 16 B per lane.
-// Stride-1, same-size convolutions with Cin % 64 == 0 (every LPIPS layer but the RGB one).
-template <int BN, int WAVES_M, int WAVES_N, int TM, int TN>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 1) void conv_bf16_big_kernel(const ConvArgsH a) {
-  constexpr int NT = 64 * WAVES_M * WAVES_N;              // threads
-  constexpr int BMB = WAVES_M * TM * 32;
-  static_assert(WAVES_N * TN * 32 == BN && BMB == 256, "tile");
-  constexpr int RP = NT / 8;                              // rows per loader pass (8 threads x 16 B per 128-B row)
-  constexpr int AR = BMB / RP, BR = BN / RP;
-  static_assert(AR >= 1 && BR >= 1, "loader passes");
-  constexpr int C_LD = TN * 32 + 4;                       // floats per row of a wave's epilogue patch
-  static_assert(WAVES_M * WAVES_N * 32 * C_LD * 4 <= 2 * (BMB + BN) * ROWB, "epilogue patches must fit the staging LDS");
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  unsigned char* As0 = lds;
-  unsigned char* Bs0 = lds + 2 * BMB * ROWB;
-
-  const fo_conv_desc& d = a.d;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int l31 = lane & 31, half = lane >> 5;
-  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-  const int logical = fo_xcd_remap(blockIdx.x, gridDim.x);
-  const int tile_n = logical % a.tilesN;
-  const int tile_m = logical / a.tilesN;
-  const int ntaps = d.KH * d.KW;
-
-  const int lrow = tid >> 3;
-  const int lcolB = (tid & 7) * 16;
-  int rowoff[AR];
-  unsigned tapmask[AR];
-#pragma unroll
-  for (int i = 0; i < AR; ++i) {
-    const int m = tile_m * BMB + lrow + RP * i;
-    const bool pv = m < a.M;
-    const int mm = pv ? m : 0;
-    const int n = mm / a.HWm;
-    const int rem = mm - n * a.HWm;
-    const int y = rem / d.Wm;
-    const int x = rem - y * d.Wm;
-    const int py = y - d.padH, px = x - d.padW;
-    rowoff[i] = ((n * d.Hin + py) * d.Win + px) * d.ldIn * 2 + lcolB;
-    unsigned mk = 0;
-    for (int tp = 0; tp < ntaps; ++tp) {
-      const int kh = tp / d.KW, kw = tp - kh * d.KW;
-      const bool ok = pv & ((unsigned)(py + kh) < (unsigned)d.Hin) & ((unsigned)(px + kw) < (unsigned)d.Win);
-      mk |= (ok ? 1u : 0u) << tp;
-    }
-    tapmask[i] = mk;
-  }
-  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in), 0, a.inBytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rwp = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wp), 0, a.wpBytes, 0x00020000);
-  const unsigned wrow = (unsigned)(((size_t)(tile_n * BN + lrow) * a.Ktot) * 2 + lcolB);
-  const unsigned wstrideRP = (unsigned)((size_t)RP * a.Ktot * 2);
-
-  int ld_step = 0, ld_tap = 0, ld_kh = 0, ld_kw = 0, ld_chunk = 0;
-  u32x4 ra[AR], rb[BR];
-  auto load_step = [&]() {
-    const int stepoff = ((ld_kh * d.Win + ld_kw) * d.ldIn + ld_chunk * 64) * 2;
-#pragma unroll
-    for (int i = 0; i < AR; ++i) {
-      const unsigned pad = (((tapmask[i] >> ld_tap) & 1u) - 1u) & OOB;
-      ra[i] = bufload16(rin, (unsigned)(rowoff[i] + stepoff) | pad);
-    }
-#pragma unroll
-    for (int i = 0; i < BR; ++i) rb[i] = bufload16(rwp, ld_step < a.ksteps ? wrow + i * wstrideRP + ld_step * 128 : OOB);
-    ++ld_step;
-    if (++ld_chunk == a.cinChunks) {
-      ld_chunk = 0;
-      ++ld_tap;
-      if (++ld_kw == d.KW) { ld_kw = 0; ++ld_kh; }
-    }
-  };
-  auto store_rows = [&](int buf, int lo, int hi) {       // passes lo..hi-1 of the combined (A then B) row-pass list
-    unsigned char* As = As0 + buf * BMB * ROWB;
-    unsigned char* Bs = Bs0 + buf * BN * ROWB;
-#pragma unroll
-    for (int i = 0; i < AR + BR; ++i) {
-      if (i < lo || i >= hi) continue;
-      if (i < AR) *reinterpret_cast<u32x4*>(As + (lrow + RP * i) * ROWB + lcolB) = ra[i];
-      else *reinterpret_cast<u32x4*>(Bs + (lrow + RP * (i - AR)) * ROWB + lcolB) = rb[i - AR];
-    }
-  };
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  load_step();
-  store_rows(0, 0, AR + BR);
-  __syncthreads();
-  const int nsteps = a.ksteps;
-  int cur = 0;
-  for (int step = 0; step < nsteps; ++step) {
-    const unsigned char* As = As0 + cur * BMB * ROWB + (wm * TM * 32 + l31) * ROWB + half * 16;
-    const unsigned char* Bs = Bs0 + cur * BN * ROWB + (wn * TN * 32 + l31) * ROWB + half * 16;
-    load_step();                                          // step + 1 (past the end: zeros, never used)
-    bf16x8 fa[2][TM], fb[2][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const bf16x8*>(As + i * 32 * ROWB);
-#pragma unroll
-    for (int j = 0; j < TN; ++j) fb[0][j] = *reinterpret_cast<const bf16x8*>(Bs + j * 32 * ROWB);
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      __builtin_amdgcn_sched_barrier(0);
-      if (s < 3) {                                        // fragments of the next 16-deep slice land under this slice's MFMAs
-#pragma unroll
-        for (int i = 0; i < TM; ++i) fa[(s + 1) & 1][i] = *reinterpret_cast<const bf16x8*>(As + i * 32 * ROWB + (s + 1) * 32);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) fb[(s + 1) & 1][j] = *reinterpret_cast<const bf16x8*>(Bs + j * 32 * ROWB + (s + 1) * 32);
-      }
-      // the LDS stores of step + 1 ride behind the last two slices' MFMAs
-      if (s == 2) store_rows(cur ^ 1, 0, (AR + BR) / 2);
-      if (s == 3) store_rows(cur ^ 1, (AR + BR) / 2, AR + BR);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s & 1][i], fb[s & 1][j], acc[i][j], 0, 0, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();
-    cur ^= 1;
-  }
-
-  // ---- epilogue: 32 rows of this wave's tile at a time through its own LDS patch
-  float* Cs = reinterpret_cast<float*>(lds) + wave * 32 * C_LD;
-  const int flags = d.flags;
-  constexpr int C8 = TN * 4;                              // 8-channel groups per patch row
-  constexpr int RPP = 64 / C8;                            // patch rows per pass of the wave
-  const int c8 = lane % C8, r0 = lane / C8;
-  const int co = tile_n * BN + wn * TN * 32 + c8 * 8;
-  float bv[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) bv[e] = ((flags & FO_BIAS) && co + e < d.Cout) ? a.bias[co + e] : 0.f;
-  __bf16* out = reinterpret_cast<__bf16*>(a.out);
-  const __bf16* mask = reinterpret_cast<const __bf16*>(a.mask);
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) Cs[((r & 3) + 8 * (r >> 2) + 4 * half) * C_LD + j * 32 + l31] = acc[i][j][r];
-    __builtin_amdgcn_wave_barrier();
-    const int mbase = tile_m * BMB + (wm * TM + i) * 32;
-#pragma unroll
-    for (int p = 0; p < 32 / RPP; ++p) {
-      const int row = p * RPP + r0;
-      const int m = mbase + row;
-      const float* crow = Cs + row * C_LD + c8 * 8;
-      const f32x4 v0 = *reinterpret_cast<const f32x4*>(crow);
-      const f32x4 v1 = *reinterpret_cast<const f32x4*>(crow + 4);
-      if (m >= a.M || co >= d.Cout) continue;
-      float v[8] = {v0.x + bv[0], v0.y + bv[1], v0.z + bv[2], v0.w + bv[3], v1.x + bv[4], v1.y + bv[5], v1.z + bv[6], v1.w + bv[7]};
-      if (flags & FO_MASK) {
-        const bf16x8 mk = *reinterpret_cast<const bf16x8*>(mask + (size_t)m * d.ldMask + co);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (float)mk[e] > 0.f ? v[e] : 0.f;
-      }
-      bf16x8 o;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = (__bf16)((flags & FO_OUT_RELU) ? fmaxf(v[e], 0.f) : v[e]);
-      *reinterpret_cast<bf16x8*>(out + (size_t)m * d.ldOut + co) = o;
-    }
-  }
+// ------------------------------------------------------------------------------------------------ big tiles: LDS-DMA ring + ping-pong
+// 256 x BN output tile (BN = 256 or 128), 8 waves, one workgroup per CU, for the layers with >= 128 output channels and a
+// launch of >= 2-3 rounds of tiles.  What it changes against conv_bf16_kernel above, each measured in one process on one device
+// (tools/ab_bf16.py, conv4_2 forward, 160 frames): 256 x 256 register-staged tiles 0.710 ms -> operands DMA'd global -> LDS
+// (buffer_load_dwordx4 ... lds: no staging VGPRs, no ds_write pass) 0.671 -> two wave groups in ping-pong 0.609 ->
+// v_mfma_f32_16x16x32_bf16 instead of 32x32x16 0.576 ms (the kernel is power-bound: MFMA-busy 0.55 -> 0.70 took the clock from
+// 1.65 to 1.49 GHz; the 16x16x32 shape holds 1.63 GHz at 0.66 busy).
+//
+// Structure: the K loop runs in 32-deep tiles ("phases"), each phase = { TM + TN ds_read_b128 | barrier | TM x TN MFMA | barrier },
+// and the two wave groups (G0 = waves 0-3, G1 = waves 4-7: one wave of each per SIMD) run ONE BARRIER APART -- G1 executes one
+// extra s_barrier up front -- so in every inter-barrier segment one group issues MFMAs while the other does its fragment reads
+// and its DMA issue.  Operands sit in a ring of four slots (tile p in slot p % 4).  An LDS-DMA writes 64 lanes x 16 B LINEARLY
+// from a wave-uniform base (16 rows x 64 B per instruction), so rows cannot be padded; the bank-conflict fix is a swizzle
+// applied on the SOURCE side (lane = row l / 4, LDS chunk position l % 4 fetches source chunk (l % 4) ^ SWZ(row)) and again on
+// the fragment read, never on the LDS destination.  A lane's A/B fragment is row (lane & 15), 16-B chunk (lane >> 4) of the
+// 64-B tile row: one ds_read_b128 per 16-row block and phase; with SWZ(row) = {0, 2, 3, 1}[(row >> 2) & 3] the ds_read_b128 lane
+// groups ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32) cover all sixteen 16-B slots of the 256-B bank row once.
+//
+// Staging protocol, with global segments numbered s = 0, 1, ... (G0: phase p reads in s = 2p, MFMAs in 2p+1; G1: reads in 2p+1,
+// MFMAs in 2p+2); NP = DMA instructions per wave and tile; every DMA sits in its wave's READ segment (its issue cost, ~100
+// cycles per 1-KB piece, is then in the shadow of the other group's MFMAs):
+//     G1, segment 2p+1: issue its rows of tile p+3 (slot of tile p-1: the last reads of that slot, G1's own in segment 2p-1,
+//       were retired by the lgkmcnt(0) in front of its MFMAs in segment 2p, before the barrier that opens 2p+1), then
+//       s_waitcnt vmcnt(2 NP): only tiles p+2, p+3 may still fly, so its rows of tile p+1 have landed;
+//     G0, segment 2p: issue its rows of tile p+2 (slot of tile p-2, last read in segment 2p-3, retired in 2p-2); after its
+//       MFMAs, at the end of segment 2p+1, s_waitcnt vmcnt(NP): tile p+2 may fly, its rows of tile p+1 have landed
+// -- both before the barrier that opens segment 2p+2, where G0 reads tile p+1 first.  A tile is in flight for four to five
+// segments (2000-2500 cycles) and nothing is drained to vmcnt(0) inside the loop; raw s_barrier only (__syncthreads() would
+// drain).  Tiles past the end are DMA'd as zeros (out-of-range offsets) so the counts stay constant.  Barrier counts: G0
+// 1 + 2 nt + 2, G1 2 + 2 nt + 1.
+typedef __attribute__((address_space(3))) unsigned char lds_byte;
+// (kept out of the kernel template: hipcc's host pass drops a kernel template whose value-dependent body holds this builtin)
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, lds_byte* dst, unsigned voffset) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)dst, 16, voffset, 0, 0, 0);
 }
+__device__ __forceinline__ int swz(int row) { return (0x1320 >> (((row >> 2) & 3) * 4)) & 3; }
+template <int N> __device__ __forceinline__ void wait_vmcnt();              // s_waitcnt takes an immediate
+template <> __device__ __forceinline__ void wait_vmcnt<3>() { asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
+template <> __device__ __forceinline__ void wait_vmcnt<4>() { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+template <> __device__ __forceinline__ void wait_vmcnt<6>() { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+template <> __device__ __forceinline__ void wait_vmcnt<8>() { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
 
-// ------------------------------------------------------------------------------------------------ big tiles, LDS-DMA staging
-// The 256 x 256 tile again, with the operands going global -> LDS directly (buffer_load_dwordx4 ... lds): no staging VGPRs,
-// no ds_write pass.  An LDS-DMA writes 64 lanes x 16 B LINEARLY from a wave-uniform base, so rows cannot be padded; the
-// bank-conflict fix moves to a swizzle instead: LDS rows are 128 B (one 64-deep K-step of one GEMM row = eight 16-B chunks)
-// and chunk c of row r lives at chunk position c ^ ((r >> 1) & 7).  The swizzle is applied on the SOURCE side (lane l of a
-// DMA instruction = row l / 8, LDS chunk position l % 8 fetches source chunk (l % 8) ^ ((row >> 1) & 7)) and again on the
-// fragment read (same involution), never on the LDS destination.  With it the 16 lanes of a ds_read_b128 group (rows r..r+15
-// at one logical chunk) cover all 16 sixteen-byte bank groups.  Two LDS stages: the DMAs of step n+1 are issued at the top
-// of step n (the stage they fill was last read in step n-1, behind that step's barrier) and retired by the vmcnt(0) that
-// __syncthreads() implies at the bottom -- a K-step is ~4000 cycles for the two waves of a SIMD, longer than an HBM miss.
-template <int TM, int TN>
-__global__ __launch_bounds__(512, 1) void conv_bf16_dma_kernel(const ConvArgsH a) {
-  constexpr int BMB = 256, BNB = 256, WAVES_N = 4;
-  static_assert(TM == 4 && TN == 2, "2 x 4 waves of 128 x 64");
-  constexpr int STAGE = (BMB + BNB) * 128;                // bytes per stage
-  constexpr int C_LD = TN * 32 + 4;
+template <int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(512, 1) void conv_bf16_pp16_kernel(const ConvArgsH a) {
+  constexpr int BMB = 256;
+  static_assert(WAVES_M * WAVES_N == 8 && (BN == 256 || BN == 128), "8 waves");
+  constexpr int TM = BMB / WAVES_M / 16, TN = BN / WAVES_N / 16;     // 16 x 16 blocks per wave
+  constexpr int WCOLS = TN * 16;
+  static_assert(WCOLS == 64, "the epilogue stores 64-column wave tiles");
+  constexpr int SLOT = (BMB + BN) * 64;                   // bytes per ring slot
+  constexpr int NPB = BN / 128;                           // B pieces per wave and tile
+  constexpr int NP = 2 + NPB;
+  constexpr int C_LD = WCOLS + 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const fo_conv_desc& d = a.d;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int l31 = lane & 31, half = lane >> 5;
+  const int l15 = lane & 15, quad = lane >> 4;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const bool g1 = __builtin_amdgcn_readfirstlane(wave >> 2) != 0;
   const int logical = fo_xcd_remap(blockIdx.x, gridDim.x);
   const int tile_n = logical % a.tilesN;
   const int tile_m = logical / a.tilesN;
   const int ntaps = d.KH * d.KW;
-
-  // ---- DMA roles: instruction i (0..3) of wave w stages tile rows (i*8 + w)*8 .. +7, lane = (row % 8, chunk position)
-  const int drow = lane >> 3, dpos = lane & 7;
-  int rowoffA[4];
-  unsigned tapmaskA[4], woffB[4];
+  const int chunks32 = a.cinChunks * 2;
+  const int nt = a.ksteps * 2;
+  const int drow = lane >> 2, dpos = lane & 3;
+  int rowoffA[2];
+  unsigned tapmaskA[2], woffB[NPB];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = (i * 8 + wave) * 8 + drow;            // row of the tile (A: pixel, B: output channel)
-    const int chunk = dpos ^ ((row >> 1) & 7);            // source chunk this lane fetches
+  for (int i = 0; i < 2; ++i) {
+    const int row = (i * 8 + wave) * 16 + drow;
+    const int chunk = dpos ^ swz(row);
     const int m = tile_m * BMB + row;
     const bool pv = m < a.M;
     const int mm = pv ? m : 0;
@@ -505,127 +364,142 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_dma_kernel(const ConvArgsH a
       mk |= (ok ? 1u : 0u) << tp;
     }
     tapmaskA[i] = mk;
-    woffB[i] = (unsigned)(((size_t)(tile_n * BNB + row) * a.Ktot) * 2 + chunk * 16);
+  }
+#pragma unroll
+  for (int i = 0; i < NPB; ++i) {
+    const int row = (i * 8 + wave) * 16 + drow;
+    woffB[i] = (unsigned)(((size_t)(tile_n * BN + row) * a.Ktot) * 2 + (dpos ^ swz(row)) * 16);
   }
   const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in), 0, a.inBytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rwp = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wp), 0, a.wpBytes, 0x00020000);
-  typedef __attribute__((address_space(3))) unsigned char lds_byte;
   lds_byte* const lds3 = (lds_byte*)lds;
 
-  int ld_step = 0, ld_tap = 0, ld_kh = 0, ld_kw = 0, ld_chunk = 0;
-  auto dma_step = [&](int stage) {
-    const int stepoff = ((ld_kh * d.Win + ld_kw) * d.ldIn + ld_chunk * 64) * 2;
-    lds_byte* const sa = lds3 + stage * STAGE;
-    lds_byte* const sb = sa + BMB * 128;
+  int ld_q = 0, ld_tap = 0, ld_kh = 0, ld_kw = 0, ld_chunk = 0;
+  auto dma_tile = [&]() {
+    const int stepoff = ((ld_kh * d.Win + ld_kw) * d.ldIn + ld_chunk * 32) * 2;
+    lds_byte* const sa = lds3 + (ld_q & 3) * SLOT;
+    lds_byte* const sb = sa + BMB * 64;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const unsigned pad = (((tapmaskA[i] >> ld_tap) & 1u) - 1u) & OOB;       // padding tap / row past M -> zeros
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void*)(sa + (i * 8 + wave) * 1024), 16,
-                                               (unsigned)(rowoffA[i] + stepoff) | pad, 0, 0, 0);
+    for (int i = 0; i < 2; ++i) {
+      const unsigned pad = (((tapmaskA[i] >> ld_tap) & 1u) - 1u) & OOB;       // padding tap / row past M / tile past the end -> zeros
+      dma16(rin, sa + (i * 8 + wave) * 1024, (unsigned)(rowoffA[i] + stepoff) | pad);
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rwp, (__attribute__((address_space(3))) void*)(sb + (i * 8 + wave) * 1024), 16,
-                                               ld_step < a.ksteps ? woffB[i] + ld_step * 128 : OOB, 0, 0, 0);
-    ++ld_step;
-    if (++ld_chunk == a.cinChunks) {
+    for (int i = 0; i < NPB; ++i)
+      dma16(rwp, sb + (i * 8 + wave) * 1024, ld_q < nt ? woffB[i] + ld_q * 64 : OOB);
+    ++ld_q;
+    if (++ld_chunk == chunks32) {
       ld_chunk = 0;
-      ++ld_tap;
+      if (ld_tap < 31) ++ld_tap;
       if (++ld_kw == d.KW) { ld_kw = 0; ++ld_kh; }
     }
   };
 
-  f32x16 acc[TM][TN];
+  f32x4 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // fragment addressing: row = block row + l31 (blocks are multiples of 32: (row >> 1) & 7 = (l31 >> 1) & 7), logical chunk 2s + half
-  const int xr = (l31 >> 1) & 7;
-  int swz[4];
-#pragma unroll
-  for (int sidx = 0; sidx < 4; ++sidx) swz[sidx] = ((2 * sidx + half) ^ xr) * 16;
+  const int fpos = (quad ^ swz(l15)) * 16;                // (block bases are multiples of 16 rows: the swizzle sees lane & 15 only)
+  const int aoff = (wm * TM * 16 + l15) * 64 + fpos, boff = BMB * 64 + (wn * TN * 16 + l15) * 64 + fpos;
 
-  dma_step(0);
-  __syncthreads();
-  const int nsteps = a.ksteps;
-  for (int step = 0; step < nsteps; ++step) {
-    const int cur = step & 1;
-    dma_step(cur ^ 1);                                    // step + 1 (past the end: zeros, never read)
-    const unsigned char* As = lds + cur * STAGE + (wm * TM * 32 + l31) * 128;
-    const unsigned char* Bs = lds + cur * STAGE + BMB * 128 + (wn * TN * 32 + l31) * 128;
-    bf16x8 fa[2][TM], fb[2][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const bf16x8*>(As + i * 32 * 128 + swz[0]);
-#pragma unroll
-    for (int j = 0; j < TN; ++j) fb[0][j] = *reinterpret_cast<const bf16x8*>(Bs + j * 32 * 128 + swz[0]);
-#pragma unroll
-    for (int sidx = 0; sidx < 4; ++sidx) {
-      __builtin_amdgcn_sched_barrier(0);
-      if (sidx < 3) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) fa[(sidx + 1) & 1][i] = *reinterpret_cast<const bf16x8*>(As + i * 32 * 128 + swz[sidx + 1]);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) fb[(sidx + 1) & 1][j] = *reinterpret_cast<const bf16x8*>(Bs + j * 32 * 128 + swz[sidx + 1]);
-      }
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[sidx & 1][i], fb[sidx & 1][j], acc[i][j], 0, 0, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();                                      // (implies vmcnt(0): this wave's DMAs of step + 1 have landed)
+  dma_tile();
+  dma_tile();
+  if (g1) {
+    dma_tile();
+    wait_vmcnt<2 * NP>();                              // tile 0 of this wave has landed
+  } else {
+    wait_vmcnt<NP>();
   }
+  __builtin_amdgcn_s_barrier();
+  if (g1) __builtin_amdgcn_s_barrier();                   // G1 runs one segment behind G0 from here on
+  __builtin_amdgcn_sched_barrier(0);
 
-  // ---- epilogue: as conv_bf16_big_kernel
+  for (int p = 0; p < nt; ++p) {
+    const unsigned char* As = lds + (p & 3) * SLOT + aoff;
+    const unsigned char* Bs = lds + (p & 3) * SLOT + boff;
+    bf16x8 fa[TM], fb[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(Bs + j * 16 * 64);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(As + i * 16 * 64);
+    dma_tile();                                           // G0: tile p+2, G1: tile p+3
+    if (g1) wait_vmcnt<2 * NP>();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    if (!g1) wait_vmcnt<NP>();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (!g1) __builtin_amdgcn_s_barrier();                  // G0 waits out G1's last segment
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the zero-fill DMAs of tiles past the end
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+
+  // ---- epilogue: 32 rows of the wave tile at a time through a wave-local LDS patch, then 16-byte bf16 stores
   float* Cs = reinterpret_cast<float*>(lds) + wave * 32 * C_LD;
   const int flags = d.flags;
-  constexpr int C8 = TN * 4, RPP = 64 / C8;
+  constexpr int C8 = WCOLS / 8, RPP = 64 / C8;
   const int c8 = lane % C8, r0 = lane / C8;
-  const int co = tile_n * BNB + wn * TN * 32 + c8 * 8;
+  const int co = tile_n * BN + wn * WCOLS + c8 * 8;
   float bv[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) bv[e] = ((flags & FO_BIAS) && co + e < d.Cout) ? a.bias[co + e] : 0.f;
   __bf16* out = reinterpret_cast<__bf16*>(a.out);
   const __bf16* mask = reinterpret_cast<const __bf16*>(a.mask);
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
+  for (int i2 = 0; i2 < TM / 2; ++i2) {
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+    for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) Cs[((r & 3) + 8 * (r >> 2) + 4 * half) * C_LD + j * 32 + l31] = acc[i][j][r];
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Cs[(ii * 16 + quad * 4 + r) * C_LD + j * 16 + l15] = acc[i2 * 2 + ii][j][r];
     __builtin_amdgcn_wave_barrier();
-    const int mbase = tile_m * BMB + (wm * TM + i) * 32;
+    const int mbase = tile_m * BMB + wm * TM * 16 + i2 * 32;
+    bf16x8 mk[32 / RPP];                                  // all mask loads of the round in flight before the first use
+    if (flags & FO_MASK) {
 #pragma unroll
-    for (int p = 0; p < 32 / RPP; ++p) {
-      const int row = p * RPP + r0;
+      for (int pp = 0; pp < 32 / RPP; ++pp) {
+        const int m = mbase + pp * RPP + r0;
+        mk[pp] = *reinterpret_cast<const bf16x8*>(mask + (size_t)(m < a.M ? m : 0) * d.ldMask + co);
+      }
+    }
+#pragma unroll
+    for (int pp = 0; pp < 32 / RPP; ++pp) {
+      const int row = pp * RPP + r0;
       const int m = mbase + row;
       const float* crow = Cs + row * C_LD + c8 * 8;
       const f32x4 v0 = *reinterpret_cast<const f32x4*>(crow);
       const f32x4 v1 = *reinterpret_cast<const f32x4*>(crow + 4);
-      if (m >= a.M || co >= d.Cout) continue;
       float v[8] = {v0.x + bv[0], v0.y + bv[1], v0.z + bv[2], v0.w + bv[3], v1.x + bv[4], v1.y + bv[5], v1.z + bv[6], v1.w + bv[7]};
       if (flags & FO_MASK) {
-        const bf16x8 mk = *reinterpret_cast<const bf16x8*>(mask + (size_t)m * d.ldMask + co);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (float)mk[e] > 0.f ? v[e] : 0.f;
+        for (int e = 0; e < 8; ++e) v[e] = (float)mk[pp][e] > 0.f ? v[e] : 0.f;
       }
       bf16x8 o;
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] = (__bf16)((flags & FO_OUT_RELU) ? fmaxf(v[e], 0.f) : v[e]);
-      *reinterpret_cast<bf16x8*>(out + (size_t)m * d.ldOut + co) = o;
+      if (m < a.M) *reinterpret_cast<bf16x8*>(out + (size_t)m * d.ldOut + co) = o;
     }
   }
 }
 
-int launch_dma(const ConvArgsH& a, hipStream_t s) {
-  constexpr int ldsBytes = 2 * (256 + 256) * 128;
+template <int BN, int WAVES_M, int WAVES_N>
+int launch_pp16(const ConvArgsH& a, hipStream_t s) {
+  constexpr int ldsBytes = 4 * (256 + BN) * 64;
   static bool attr_set = false;
-  auto kern = conv_bf16_dma_kernel<4, 2>;
+  void (*kern)(const ConvArgsH) = conv_bf16_pp16_kernel<BN, WAVES_M, WAVES_N>;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, ldsBytes) != hipSuccess) {
       fo_set_error("conv_bf16: cannot reserve %d bytes of LDS", ldsBytes);
@@ -634,23 +508,6 @@ int launch_dma(const ConvArgsH& a, hipStream_t s) {
     attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3(a.tilesM * a.tilesN), dim3(512), ldsBytes, s, a);
-  FO_CHECK_LAUNCH();
-  return FO_OK;
-}
-
-template <int BN, int WAVES_M, int WAVES_N, int TM, int TN>
-int launch_big(const ConvArgsH& a, hipStream_t s) {
-  constexpr int ldsBytes = 2 * (256 + BN) * ROWB;
-  static bool attr_set = false;                            // > 64 KB of dynamic LDS needs the opt-in once per process
-  auto kern = conv_bf16_big_kernel<BN, WAVES_M, WAVES_N, TM, TN>;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, ldsBytes) != hipSuccess) {
-      fo_set_error("conv_bf16: cannot reserve %d bytes of LDS", ldsBytes);
-      return FO_E_HIP;
-    }
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(kern, dim3(a.tilesM * a.tilesN), dim3(64 * WAVES_M * WAVES_N), ldsBytes, s, a);
   FO_CHECK_LAUNCH();
   return FO_OK;
 }
@@ -749,31 +606,23 @@ int fo_conv_igemm_bf16(const fo_conv_desc* d, const void* in, const void* wp, co
   a.inBytes = (unsigned)inBytes;
   a.wpBytes = (unsigned)wpBytes;
   hipStream_t s = (hipStream_t)stream;
-  // big tiles (one workgroup per CU) where the launch still fills the chip for a few rounds: stride-1 same-size convs
+  // big tiles (one workgroup per CU) where the launch still fills the chip for a few rounds: stride-1 same-size convs.
+  // Measured at the C3 shapes and at a fifth of them (tools/ab_bf16.py): 256-column tiles +22...30 % over conv_bf16_kernel
+  // on conv3_x / conv4_x, 128-column tiles +5...10 % on conv2_x and +12...15 % on 2-round launches; 64-column layers
+  // (K = 576: 18 phases) stay on conv_bf16_kernel, whose second workgroup hides the prologue and epilogue
   const bool same = d->stride == 1 && d->ostride == 1 && d->Hm == d->Hout && d->Wm == d->Wout && d->Hin == d->Hm && d->Win == d->Wm;
-  const char* nobig = getenv("FACEOFF_BF16_SMALL_TILES");
-  if (!smallc && same && !(nobig && atoi(nobig)) && d->Cout >= 64 && d->Cout % 64 == 0) {
-    const int tilesM256 = (a.M + 255) / 256;
-    const char* force = getenv("FACEOFF_BF16_BIG_TILES");          // tests: big tiles at any size
-    const int cus = (force && atoi(force)) ? 0 : fo_cu_count();
-    // measured at the C3 shapes (tools/bench_bf16.py): 256-column tiles win everywhere they apply (conv3_x / conv4_x forward
-    // 820-860 -> 1000-1050 TFLOP/s, masked data gradients 775-845 -> 860-990); the 128- and 64-column variants lose to
-    // the two-workgroups-per-CU kernel on their short-K layers (K = 576 / 1152: the unoverlapped prologue and epilogue of a
-    // lone workgroup) and are only taken when forced (tests)
-    const bool forced = force && atoi(force);
-    if (d->Cout % 256 == 0 && (long long)tilesM256 * (d->Cout / 256) >= 3ll * cus) {
-      a.tilesM = tilesM256; a.tilesN = d->Cout / 256;
-      const char* nodma = getenv("FACEOFF_BF16_NO_DMA");              // diagnostics: register-staged form of the same tile
-      if (!(nodma && atoi(nodma))) return launch_dma(a, s);
-      return launch_big<256, 2, 4, 4, 2>(a, s);
+  const char* nobig = getenv("FACEOFF_BF16_SMALL_TILES");            // diagnostics / tests: never
+  const char* force = getenv("FACEOFF_BF16_BIG_TILES");              // tests: at any size
+  if (!smallc && same && !(nobig && atoi(nobig)) && d->Cout % 128 == 0) {
+    const long long tilesM256 = (a.M + 255) / 256;
+    const long long cus = (force && atoi(force)) ? 0 : fo_cu_count();
+    if (d->Cout % 256 == 0 && tilesM256 * (d->Cout / 256) >= 3 * cus) {
+      a.tilesM = (int)tilesM256; a.tilesN = d->Cout / 256;
+      return launch_pp16<256, 2, 4>(a, s);
     }
-    if (forced && d->Cout % 128 == 0) {
-      a.tilesM = tilesM256; a.tilesN = d->Cout / 128;
-      return launch_big<128, 4, 2, 2, 2>(a, s);
-    }
-    if (forced && d->Cout == 64) {
-      a.tilesM = tilesM256; a.tilesN = 1;
-      return launch_big<64, 8, 1, 1, 2>(a, s);
+    if (tilesM256 * (d->Cout / 128) >= 2 * cus) {
+      a.tilesM = (int)tilesM256; a.tilesN = d->Cout / 128;
+      return launch_pp16<128, 4, 2>(a, s);
     }
   }
   if (d->Cout > 64) {
