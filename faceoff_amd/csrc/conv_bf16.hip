@@ -51,6 +51,67 @@ __device__ __forceinline__ u32x4 bufload16(__amdgpu_buffer_rsrc_t r, unsigned of
   return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
 }
 
+// fp32 C tile in LDS (BM x (BN + 4)) -> bias / ReLU mask / ReLU -> bf16, 8 channels = 16 B per lane
+template <int BN>
+__device__ __forceinline__ void store_c_tile(const ConvArgsH& a, const float* Cs, int tile_m, int tile_n, int tid) {
+  constexpr int C_LD = BN + 4;
+  const fo_conv_desc& d = a.d;
+  const int flags = d.flags;
+  constexpr int C8 = BN / 8;
+  constexpr int RPP = 256 / C8;
+  const int c8 = tid % C8;
+  const int co = tile_n * BN + c8 * 8;
+  if (co >= d.Cout) return;
+  float bv[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bv[e] = ((flags & FO_BIAS) && co + e < d.Cout) ? a.bias[co + e] : 0.f;
+  const bool identity_pix = (d.ostride == 1) & (d.Hm == d.Hout) & (d.Wm == d.Wout);
+  __bf16* out = reinterpret_cast<__bf16*>(a.out);
+  const __bf16* mask = reinterpret_cast<const __bf16*>(a.mask);
+  // rows in batches: all mask loads of a batch are in flight before the first is used (see conv_igemm.hip store_tile)
+  constexpr int ROWS = BM / RPP, R = ROWS < 8 ? ROWS : 8;
+  const int r0 = tid / C8;
+#pragma unroll
+  for (int b = 0; b < ROWS; b += R) {
+    size_t opix[R];
+    bool ok[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      int m = tile_m * BM + r0 + (b + r) * RPP;
+      ok[r] = m < a.M;
+      m = min(m, a.M - 1);
+      opix[r] = m;
+      if (!identity_pix) {
+        const int n = m / a.HWm;
+        const int rem = m - n * a.HWm;
+        const int y = rem / d.Wm;
+        const int x = rem - y * d.Wm;
+        opix[r] = ((size_t)n * d.Hout + (y * d.ostride + d.ophH)) * d.Wout + (x * d.ostride + d.ophW);
+      }
+    }
+    bf16x8 mk[R];
+    if (flags & FO_MASK) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) mk[r] = *reinterpret_cast<const bf16x8*>(mask + opix[r] * d.ldMask + co);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const float* crow = Cs + (r0 + (b + r) * RPP) * C_LD + c8 * 8;
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(crow);
+      const f32x4 v1 = *reinterpret_cast<const f32x4*>(crow + 4);
+      float v[8] = {v0.x + bv[0], v0.y + bv[1], v0.z + bv[2], v0.w + bv[3], v1.x + bv[4], v1.y + bv[5], v1.z + bv[6], v1.w + bv[7]};
+      if (flags & FO_MASK) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (float)mk[r][e] > 0.f ? v[e] : 0.f;
+      }
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (__bf16)((flags & FO_OUT_RELU) ? fmaxf(v[e], 0.f) : v[e]);
+      if (ok[r]) *reinterpret_cast<bf16x8*>(out + opix[r] * d.ldOut + co) = o;
+    }
+  }
+}
+
 template <int BN, int WAVES_M, int WAVES_N, int TM, int TN, bool SMALLC>
 __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvArgsH a) {
   static_assert(WAVES_M * WAVES_N == 4, "4 waves");
@@ -219,60 +280,144 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvArgsH a) {
         Cs[row * C_LD + (wn * TN + j) * 32 + l31] = acc[i][j][r];
       }
   __syncthreads();
-  const int flags = d.flags;
-  constexpr int C8 = BN / 8;
-  constexpr int RPP = 256 / C8;
-  const int c8 = tid % C8;
-  const int co = tile_n * BN + c8 * 8;
-  if (co >= d.Cout) return;
-  float bv[8];
+  store_c_tile<BN>(a, Cs, tile_m, tile_n, tid);
+}
+
+// ------------------------------------------------------------------------------------------------ 128-row tiles, LDS-DMA staging
+// conv_bf16_kernel's tile (128 x BN, 4 waves, 2-3 workgroups per CU) with the operands DMA'd global -> LDS instead of staged
+// through registers: at BN = 64 the register form spends 311 LDS cycles per K-step on its ds_write_b128 (24 KB at ~79 B/clk)
+// against 256 cycles of MFMA -- LDS-store-bound; a DMA has no VGPR -> LDS transfer at all.  LDS rows are unpadded 128 B (one
+// 64-deep K-step of one GEMM row = eight 16-B chunks), chunk c of row r at position c ^ ((r >> 1) & 7), applied on the DMA
+// source address and on the fragment read.  One barrier per K-step (the DMA of step n+1 is issued before the MFMAs of step n
+// and drained by the vmcnt(0) of __syncthreads()): the other workgroups on the CU cover the drain.
+typedef __attribute__((address_space(3))) unsigned char lds_byte;
+// (kept out of the kernel templates: hipcc's host pass drops a kernel template whose value-dependent body holds this builtin)
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, lds_byte* dst, unsigned voffset) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)dst, 16, voffset, 0, 0, 0);
+}
+
+template <int BN, int WAVES_M, int WAVES_N, int TM, int TN>
+__global__ __launch_bounds__(256, 2) void conv_bf16_dma_kernel(const ConvArgsH a) {
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+  static_assert(WAVES_M * TM * 32 == BM && WAVES_N * TN * 32 == BN, "tile");
+  constexpr int STAGE = (BM + BN) * 128;
+  constexpr int NPB = BN / 32;                            // B pieces (8 rows x 128 B) per wave and K-step
+  constexpr int C_LD = BN + 4;
+  constexpr int LDSB = 2 * STAGE > BM * C_LD * 4 ? 2 * STAGE : BM * C_LD * 4;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[LDSB];
+  const fo_conv_desc& d = a.d;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int logical = fo_xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_n = logical % a.tilesN;
+  const int tile_m = logical / a.tilesN;
+  const int ntaps = d.KH * d.KW;
+
+  // ---- DMA roles: piece i of wave w = tile rows (i*4 + w)*8 .. +7, lane = (row % 8, chunk position)
+  const int drow = lane >> 3, dpos = lane & 7;
+  int rowoffA[4];
+  unsigned tapmaskA[4], woffB[NPB];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) bv[e] = ((flags & FO_BIAS) && co + e < d.Cout) ? a.bias[co + e] : 0.f;
-  const bool identity_pix = (d.ostride == 1) & (d.Hm == d.Hout) & (d.Wm == d.Wout);
-  __bf16* out = reinterpret_cast<__bf16*>(a.out);
-  const __bf16* mask = reinterpret_cast<const __bf16*>(a.mask);
-  // rows in batches: all mask loads of a batch are in flight before the first is used (see conv_igemm.hip store_tile)
-  constexpr int ROWS = BM / RPP, R = ROWS < 8 ? ROWS : 8;
-  const int r0 = tid / C8;
-#pragma unroll
-  for (int b = 0; b < ROWS; b += R) {
-    size_t opix[R];
-    bool ok[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      int m = tile_m * BM + r0 + (b + r) * RPP;
-      ok[r] = m < a.M;
-      m = min(m, a.M - 1);
-      opix[r] = m;
-      if (!identity_pix) {
-        const int n = m / a.HWm;
-        const int rem = m - n * a.HWm;
-        const int y = rem / d.Wm;
-        const int x = rem - y * d.Wm;
-        opix[r] = ((size_t)n * d.Hout + (y * d.ostride + d.ophH)) * d.Wout + (x * d.ostride + d.ophW);
-      }
+  for (int i = 0; i < 4; ++i) {
+    const int row = (i * 4 + wave) * 8 + drow;
+    const int chunk = dpos ^ ((row >> 1) & 7);
+    const int m = tile_m * BM + row;
+    const bool pv = m < a.M;
+    const int mm = pv ? m : 0;
+    const int n = mm / a.HWm;
+    const int rem = mm - n * a.HWm;
+    const int y = rem / d.Wm;
+    const int x = rem - y * d.Wm;
+    const int py = y * d.stride - d.padH, px = x * d.stride - d.padW;
+    rowoffA[i] = ((n * d.Hin + py) * d.Win + px) * d.ldIn * 2 + chunk * 16;
+    unsigned mk = 0;
+    for (int tp = 0; tp < ntaps; ++tp) {
+      const int kh = tp / d.KW, kw = tp - kh * d.KW;
+      const bool ok = pv & ((unsigned)(py + kh) < (unsigned)d.Hin) & ((unsigned)(px + kw) < (unsigned)d.Win);
+      mk |= (ok ? 1u : 0u) << tp;
     }
-    bf16x8 mk[R];
-    if (flags & FO_MASK) {
-#pragma unroll
-      for (int r = 0; r < R; ++r) mk[r] = *reinterpret_cast<const bf16x8*>(mask + opix[r] * d.ldMask + co);
-    }
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const float* crow = Cs + (r0 + (b + r) * RPP) * C_LD + c8 * 8;
-      const f32x4 v0 = *reinterpret_cast<const f32x4*>(crow);
-      const f32x4 v1 = *reinterpret_cast<const f32x4*>(crow + 4);
-      float v[8] = {v0.x + bv[0], v0.y + bv[1], v0.z + bv[2], v0.w + bv[3], v1.x + bv[4], v1.y + bv[5], v1.z + bv[6], v1.w + bv[7]};
-      if (flags & FO_MASK) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (float)mk[r][e] > 0.f ? v[e] : 0.f;
-      }
-      bf16x8 o;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = (__bf16)((flags & FO_OUT_RELU) ? fmaxf(v[e], 0.f) : v[e]);
-      if (ok[r]) *reinterpret_cast<bf16x8*>(out + opix[r] * d.ldOut + co) = o;
-    }
+    tapmaskA[i] = mk;
   }
+#pragma unroll
+  for (int i = 0; i < NPB; ++i) {
+    const int row = (i * 4 + wave) * 8 + drow;
+    woffB[i] = (unsigned)(((size_t)(tile_n * BN + row) * a.Ktot) * 2 + (dpos ^ ((row >> 1) & 7)) * 16);
+  }
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in), 0, a.inBytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rwp = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wp), 0, a.wpBytes, 0x00020000);
+  lds_byte* const lds3 = (lds_byte*)lds;
+
+  int ld_step = 0, ld_tap = 0, ld_kh = 0, ld_kw = 0, ld_chunk = 0;
+  auto dma_step = [&](int stage) {
+    const int stepoff = ((ld_kh * d.Win + ld_kw) * d.ldIn + ld_chunk * 64) * 2;
+    lds_byte* const sa = lds3 + stage * STAGE;
+    lds_byte* const sb = sa + BM * 128;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const unsigned pad = (((tapmaskA[i] >> ld_tap) & 1u) - 1u) & OOB;       // padding tap / row past M -> zeros
+      dma16(rin, sa + (i * 4 + wave) * 1024, (unsigned)(rowoffA[i] + stepoff) | pad);
+    }
+#pragma unroll
+    for (int i = 0; i < NPB; ++i) dma16(rwp, sb + (i * 4 + wave) * 1024, ld_step < a.ksteps ? woffB[i] + ld_step * 128 : OOB);
+    ++ld_step;
+    if (++ld_chunk == a.cinChunks) {
+      ld_chunk = 0;
+      if (ld_tap < 31) ++ld_tap;
+      if (++ld_kw == d.KW) { ld_kw = 0; ++ld_kh; }
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragment addressing: row = block row + l31 (blocks are multiples of 32 rows), logical chunk 2s + half
+  const int xr = (l31 >> 1) & 7;
+  int fpos[4];
+#pragma unroll
+  for (int sidx = 0; sidx < 4; ++sidx) fpos[sidx] = ((2 * sidx + half) ^ xr) * 16;
+
+  dma_step(0);
+  __syncthreads();
+  const int nsteps = a.ksteps;
+  for (int step = 0; step < nsteps; ++step) {
+    const int cur = step & 1;
+    dma_step(cur ^ 1);                                    // step + 1 (past the end: zeros, never read)
+    const unsigned char* As = lds + cur * STAGE + (wm * TM * 32 + l31) * 128;
+    const unsigned char* Bs = lds + cur * STAGE + BM * 128 + (wn * TN * 32 + l31) * 128;
+#pragma unroll
+    for (int sidx = 0; sidx < 4; ++sidx) {
+      bf16x8 fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(As + i * 32 * 128 + fpos[sidx]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(Bs + j * 32 * 128 + fpos[sidx]);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();                                      // (implies vmcnt(0): this wave's DMAs of step + 1 have landed)
+  }
+
+  float* Cs = reinterpret_cast<float*>(lds);
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        Cs[row * C_LD + (wn * TN + j) * 32 + l31] = acc[i][j][r];
+      }
+  __syncthreads();
+  store_c_tile<BN>(a, Cs, tile_m, tile_n, tid);
 }
 
 // ------------------------------------------------------------------------------------------------ big tiles: LDS-DMA ring + ping-pong
@@ -305,11 +450,6 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvArgsH a) {
 // segments (2000-2500 cycles) and nothing is drained to vmcnt(0) inside the loop; raw s_barrier only (__syncthreads() would
 // drain).  Tiles past the end are DMA'd as zeros (out-of-range offsets) so the counts stay constant.  Barrier counts: G0
 // 1 + 2 nt + 2, G1 2 + 2 nt + 1.
-typedef __attribute__((address_space(3))) unsigned char lds_byte;
-// (kept out of the kernel template: hipcc's host pass drops a kernel template whose value-dependent body holds this builtin)
-__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, lds_byte* dst, unsigned voffset) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)dst, 16, voffset, 0, 0, 0);
-}
 __device__ __forceinline__ int swz(int row) { return (0x1320 >> (((row >> 2) & 3) * 4)) & 3; }
 template <int N> __device__ __forceinline__ void wait_vmcnt();              // s_waitcnt takes an immediate
 template <> __device__ __forceinline__ void wait_vmcnt<3>() { asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
@@ -513,6 +653,13 @@ int launch_pp16(const ConvArgsH& a, hipStream_t s) {
 }
 
 template <int BN, int WAVES_M, int WAVES_N, int TM, int TN>
+int launch_dma(const ConvArgsH& a, hipStream_t s) {
+  hipLaunchKernelGGL((conv_bf16_dma_kernel<BN, WAVES_M, WAVES_N, TM, TN>), dim3(a.tilesM * a.tilesN), dim3(256), 0, s, a);
+  FO_CHECK_LAUNCH();
+  return FO_OK;
+}
+
+template <int BN, int WAVES_M, int WAVES_N, int TM, int TN>
 int launch(const ConvArgsH& a, bool smallc, hipStream_t s) {
   const int grid = a.tilesM * a.tilesN;
   if (smallc)
@@ -625,12 +772,14 @@ int fo_conv_igemm_bf16(const fo_conv_desc* d, const void* in, const void* wp, co
       return launch_pp16<128, 4, 2>(a, s);
     }
   }
+  const char* nodma = getenv("FACEOFF_BF16_NO_DMA");                // diagnostics: the register-staged kernel everywhere
+  const bool dma = !smallc && !(nodma && atoi(nodma));
   if (d->Cout > 64) {
     a.tilesN = (d->Cout + 127) / 128;
-    return launch<128, 2, 2, 2, 2>(a, smallc, s);
+    return dma ? launch_dma<128, 2, 2, 2, 2>(a, s) : launch<128, 2, 2, 2, 2>(a, smallc, s);
   } else if (d->Cout > 32) {
     a.tilesN = 1;
-    return launch<64, 2, 2, 2, 1>(a, smallc, s);
+    return dma ? launch_dma<64, 2, 2, 2, 1>(a, s) : launch<64, 2, 2, 2, 1>(a, smallc, s);
   } else {
     a.tilesN = 1;
     return launch<32, 4, 1, 1, 1>(a, smallc, s);
