@@ -37,6 +37,7 @@ class DiscEngine:
         assert dims in (2, 3)
         self.device, self.dims, self.nc, self.num_D, self.n_frames = torch.device(device), dims, nc, num_D, n_frames
         self.specs = disc_param_specs(dims, nc, num_D)
+        self._order_cache = {}
         sizes = [(k, s, int(torch.tensor(s).prod()) if len(s) else 1) for k, s in self.specs if k.endswith((".weight", ".bias"))]
         total = sum((n + 3) // 4 * 4 for _, _, n in sizes)
         self.flat_params = torch.zeros(total, device=self.device)
@@ -189,7 +190,10 @@ class DiscEngine:
 
     def _scale_fwd(self, x, prefix, training, order):
         N = x.shape[0]
-        order_t = torch.tensor(order, dtype=torch.int32, device=self.device)
+        # (cached: a host list -> device tensor copy is a synchronous H2D transfer that drains the stream -- 3 ms per call here)
+        order_t = self._order_cache.get(tuple(order))
+        if order_t is None:
+            order_t = self._order_cache[tuple(order)] = torch.tensor(order, dtype=torch.int32, device=self.device)
         feat, stats, inp = [], [None] * 5, []
         h, cin = x, 32
         for j, (co, s) in enumerate(zip(DISC_CHANNELS, STRIDES)):

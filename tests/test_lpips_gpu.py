@@ -82,7 +82,7 @@ def _bf16_round(a):
     return torch.from_numpy(a).bfloat16().float()
 
 
-@pytest.mark.parametrize("big", [False, True])
+@pytest.mark.parametrize("big", [False, True, "staged"])
 @pytest.mark.parametrize("cin,cout,hw,flags", [(64, 64, (20, 28), "relu"), (128, 256, (9, 13), "relu"), (256, 128, (16, 16), "mask"),
                                                (64, 3, (12, 20), "none"), (8, 64, (18, 22), "relu"), (512, 512, (6, 10), "mask"),
                                                (64, 128, (17, 23), "mask")])
@@ -92,8 +92,13 @@ def test_conv_bf16_vs_torch(cin, cout, hw, flags, big, monkeypatch):
     summation order, i.e. within one bf16 ulp (2^-8 relative) of it."""
     import zlib
     from faceoff_amd import ops
-    # big = the 256-row tiles (one workgroup per CU) the C3-size launches take, forced on at this small size
-    monkeypatch.setenv("FACEOFF_BF16_BIG_TILES" if big else "FACEOFF_BF16_SMALL_TILES", "1")
+    # big = the 256-row ping-pong tiles (one workgroup per CU) the C3-size launches take, forced on at this small size;
+    # False = the 128-row LDS-DMA tiles; "staged" = the register-staged kernel (diagnostic switch; the RGB layers always use it)
+    if big == "staged":
+        monkeypatch.setenv("FACEOFF_BF16_SMALL_TILES", "1")
+        monkeypatch.setenv("FACEOFF_BF16_NO_DMA", "1")
+    else:
+        monkeypatch.setenv("FACEOFF_BF16_BIG_TILES" if big else "FACEOFF_BF16_SMALL_TILES", "1")
     rng = np.random.default_rng(zlib.crc32(f"{cin}-{cout}-{hw}-{flags}".encode()))
     N, (H, W) = 2, hw
     ci_real = 3 if cin == 8 else cin
