@@ -204,3 +204,38 @@ def test_lpips_bf16_frame_chunking_and_precomputed_target_taps():
     np.testing.assert_allclose([l2.item(), l3.item()], l1.item(), rtol=1e-5)
     assert torch.equal(g1, g3)
     assert (g1 - g2).abs().max().item() <= 1e-6 * g1.abs().max().item()
+
+
+@pytest.mark.parametrize("cin,cout", [(256, 256), (128, 128), (64, 64)])
+def test_conv_bf16_dma_kernels_are_deterministic(cin, cout, monkeypatch):
+    """Race screen (tools/race_screen_bf16.py runs it at the config-3 sizes): the LDS-DMA kernels -- the ping-pong tiles for
+    >= 128 output channels, the 128-row tiles for 64 -- launched 30 times on the same operands with a bandwidth-heavy kernel
+    beside them on a second stream must return bit-identical outputs (a misplaced vmcnt / barrier shows up as rare wrong
+    tiles), and the first must equal the register-staged kernel's to one bf16 rounding."""
+    from faceoff_amd import ops
+    torch.manual_seed(cin)
+    N, H = 24, 32
+    x = (torch.randn((N, H, H, cin), device="cuda") * 0.5).bfloat16()
+    wp = ops.pack_conv_bf16(torch.randn((cout, cin, 3, 3), device="cuda") * 0.05)
+    b = torch.randn(cout, device="cuda")
+
+    def run():
+        out = torch.empty((N, H, H, cout), device="cuda", dtype=torch.bfloat16)
+        ops.conv_bf16(x, wp, b, out, cin=cin, cout=cout, flags=ops.FO_OUT_RELU)
+        return out
+    monkeypatch.setenv("FACEOFF_BF16_SMALL_TILES", "1")
+    monkeypatch.setenv("FACEOFF_BF16_NO_DMA", "1")
+    ref = run()
+    monkeypatch.delenv("FACEOFF_BF16_SMALL_TILES")
+    monkeypatch.delenv("FACEOFF_BF16_NO_DMA")
+    monkeypatch.setenv("FACEOFF_BF16_BIG_TILES", "1")
+    first = run()
+    assert ((first.float() - ref.float()).abs() <= 2.0 ** -7 * ref.float().abs() + 1e-6).all()
+    side, noise = torch.cuda.Stream(), torch.empty(64 << 20, device="cuda")
+    for r in range(30):
+        if r & 1:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                noise.mul_(1.0001)
+        assert torch.equal(run(), first), r
+    torch.cuda.synchronize()

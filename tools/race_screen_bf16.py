@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Race screen for the LDS-DMA / ping-pong bf16 conv kernels: a kernel with a misplaced vmcnt or barrier produces rare wrong
+tiles that come and go with machine load.  Every layer shape of config 3 is launched REPS times on the same operands at full
+size (all CUs busy), with a bandwidth-heavy kernel running beside it on a second stream half of the time; every output must be
+bit-identical to the first, and the first must match the register-staged kernel to bf16 rounding.
+    python tools/race_screen_bf16.py [REPS]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from faceoff_amd import ops  # noqa: E402
+
+dev = torch.device("cuda:0")
+REPS = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+N = int(os.environ.get("FRAMES", "160"))
+bf = torch.bfloat16
+shapes = [("conv1_2", 256, 64, 64), ("conv2_1", 128, 64, 128), ("conv2_2", 128, 128, 128), ("conv3_1", 64, 128, 256),
+          ("conv3_2", 64, 256, 256), ("conv4_1", 32, 256, 512), ("conv4_2", 32, 512, 512), ("conv5_x", 16, 512, 512)]
+side = torch.cuda.Stream()
+noise = torch.empty(256 << 20, device=dev)
+bad = 0
+for name, H, ci, co in shapes:
+    for kind in ("fwd", "dgrad"):
+        cin, cout = (co, ci) if kind == "dgrad" else (ci, co)
+        x = (torch.randn((N, H, H, cin), device=dev) * 0.5).to(bf)
+        wp = ops.pack_conv_bf16(torch.randn((cout, cin, 3, 3), device=dev) * 0.05)
+        b = torch.randn(cout, device=dev)
+        mask = torch.randn((N, H, H, cout), device=dev).clamp_min(0).to(bf) if kind == "dgrad" else None
+
+        def run():
+            out = torch.empty((N, H, H, cout), device=dev, dtype=bf)
+            ops.conv_bf16(x, wp, b if kind == "fwd" else None, out, cin=cin, cout=cout, flags=ops.FO_OUT_RELU if kind == "fwd" else 0, mask=mask)
+            return out
+        os.environ["FACEOFF_BF16_SMALL_TILES"] = "1"
+        os.environ["FACEOFF_BF16_NO_DMA"] = "1"
+        ref = run()
+        os.environ.pop("FACEOFF_BF16_SMALL_TILES")
+        os.environ.pop("FACEOFF_BF16_NO_DMA")
+        first = run()
+        torch.cuda.synchronize()
+        dev_max = (first.float() - ref.float()).abs().max().item() / ref.float().abs().max().item()
+        diffs = 0
+        for r in range(REPS):
+            if r & 1:
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    noise.mul_(1.0001)
+            o = run()
+            diffs += int(not torch.equal(o, first))
+        torch.cuda.synchronize()
+        bad += diffs + int(dev_max > 2.0 ** -7)
+        print(f"{name} {kind:5s}: {REPS} launches, {diffs} differ from the first; first vs register-staged kernel: max |diff| / max |ref| = {dev_max:.2e}", flush=True)
+print("RACE SCREEN", "FAILED" if bad else "clean")
+sys.exit(1 if bad else 0)
