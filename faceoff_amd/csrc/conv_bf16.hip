@@ -420,6 +420,110 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_dma_kernel(const ConvArgsH a
   store_c_tile<BN>(a, Cs, tile_m, tile_n, tid);
 }
 
+// ------------------------------------------------------------------------------------------------ RGB layer (8 -> 64 channels, 3x3)
+// VGG's first conv has K = 9 taps x 8 padded channels = 72: as a tiled GEMM it is two K-steps per tile, i.e. all prologue and
+// epilogue (0.89 ms for 1.34 GB of output).  Here nothing is staged: with K ordered (tap, channel) one MFMA operand fragment of
+// v_mfma_f32_32x32x16_bf16 (8 consecutive k per lane) IS one pixel's 16-byte channel vector at one tap, so a lane loads its
+// fragment straight from global memory (padding: out-of-range offset -> zeros); the 64 x 72 filter lives in 40 VGPRs per
+// lane for the whole kernel; a wave walks blocks of 32 consecutive pixels (persistent grid), 5 loads and 10 MFMAs per block.
+// Operands are swapped (C^T = W X^T: rows = output channels, columns = pixels) so that a lane's accumulator holds 4 consecutive
+// channels of ONE pixel: bias + ReLU + bf16 pack per lane, a wave-local 4.5 KB LDS patch turns that into 16-byte stores of
+// whole 128-byte pixel lines.  0.92 -> 0.44 ms.  (The same trick does NOT carry to the layer's 64 -> 3 data gradient: there a
+// pixel is 128 B, adjacent lanes of a fragment load are 128 B apart, and the L1 serves one line per lane: 1.28 vs 1.18 ms tiled.)
+__global__ __launch_bounds__(256) void conv_rgb_bf16_kernel(const ConvArgsH a, int nblocks) {
+  constexpr int PITCH = 128 + 16;                         // patch row: one pixel's 64 bf16 + pad
+  __shared__ __attribute__((aligned(16))) unsigned char patch_all[4][32 * PITCH];
+  __shared__ __attribute__((aligned(16))) float bias_s[64];
+  const fo_conv_desc& d = a.d;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  unsigned char* patch = patch_all[wave];
+  if (tid < 64) bias_s[tid] = (d.flags & FO_BIAS) ? a.bias[tid] : 0.f;
+  __syncthreads();
+
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in), 0, a.inBytes, 0x00020000);
+  // filter fragments: row (output channel) i*32 + l31, k = s*16 + half*8 .. +8  (taps 2s + half; tap 9 = zeros in the pack)
+  bf16x8 wf[2][5];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int s = 0; s < 5; ++s)
+      wf[i][s] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(a.wp) + (size_t)(i * 32 + l31) * a.Ktot + s * 16 + half * 8);
+  // this lane's taps
+  int tdy[5], tdx[5], toff[5];
+#pragma unroll
+  for (int s = 0; s < 5; ++s) {
+    const int t = 2 * s + half;
+    tdy[s] = t / 3 - 1;
+    tdx[s] = t % 3 - 1;
+    toff[s] = t < 9 ? (tdy[s] * d.Win + tdx[s]) * 16 : (int)OOB;
+  }
+  const bool relu = d.flags & FO_OUT_RELU;
+  __bf16* out = reinterpret_cast<__bf16*>(a.out);
+  const int gw = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
+
+  auto load_block = [&](int blk, bf16x8 (&xf)[5]) {
+    const int m = blk * 32 + l31;
+    const bool pv = m < a.M;
+    const int mm = pv ? m : 0;
+    const int n = mm / a.HWm;
+    const int rem = mm - n * a.HWm;
+    const int y = rem / d.Wm;
+    const int x = rem - y * d.Wm;
+    const int base = mm * 16;
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+      const bool ok = pv & ((unsigned)(y + tdy[s]) < (unsigned)d.Hin) & ((unsigned)(x + tdx[s]) < (unsigned)d.Win) & (toff[s] != (int)OOB);
+      xf[s] = __builtin_bit_cast(bf16x8, bufload16(rin, ok ? (unsigned)(base + toff[s]) : OOB));
+    }
+  };
+
+  bf16x8 xa[5], xb[5];
+  if (gw < nblocks) load_block(gw, xa);
+  for (int blk = gw; blk < nblocks; blk += 2 * nw) {
+#pragma unroll
+    for (int phase = 0; phase < 2; ++phase) {
+      const int cur = blk + phase * nw;
+      if (cur >= nblocks) break;
+      bf16x8 (&xc)[5] = phase ? xb : xa;
+      bf16x8 (&xn)[5] = phase ? xa : xb;
+      if (cur + nw < nblocks) load_block(cur + nw, xn);   // next block's fragments fly during this block's MFMAs and stores
+      f32x16 acc[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 5; ++s)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i][s], xc[s], acc[i], 0, 0, 0);
+      // rows of acc[i] = channels i*32 + (r & 3) + 8 (r >> 2) + 4 half, column = pixel l31
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int c0 = i * 32 + 8 * g + 4 * half;
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias_s + c0);
+          float v0 = acc[i][4 * g + 0] + b4.x, v1 = acc[i][4 * g + 1] + b4.y, v2 = acc[i][4 * g + 2] + b4.z, v3 = acc[i][4 * g + 3] + b4.w;
+          if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+          typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+          bf16x4 o = {(__bf16)v0, (__bf16)v1, (__bf16)v2, (__bf16)v3};
+          *reinterpret_cast<bf16x4*>(patch + l31 * PITCH + c0 * 2) = o;
+        }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int pix = it * 8 + (lane >> 3), piece = lane & 7;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(patch + pix * PITCH + piece * 16);
+        const long long m = (long long)cur * 32 + pix;
+        if (m < a.M) *reinterpret_cast<u32x4*>(out + m * d.ldOut + piece * 8) = v;
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ big tiles: LDS-DMA ring + ping-pong
 // 256 x BN output tile (BN = 256 or 128), 8 waves, one workgroup per CU, for the layers with >= 128 output channels and a
 // launch of >= 2-3 rounds of tiles.  What it changes against conv_bf16_kernel above, each measured in one process on one device
@@ -753,6 +857,16 @@ int fo_conv_igemm_bf16(const fo_conv_desc* d, const void* in, const void* wp, co
   a.inBytes = (unsigned)inBytes;
   a.wpBytes = (unsigned)wpBytes;
   hipStream_t s = (hipStream_t)stream;
+  const char* norgb = getenv("FACEOFF_BF16_NO_RGB");                 // diagnostics: the tiled kernel for the RGB layer too
+  if (smallc && d->Cout == 64 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->ostride == 1 && d->padH == 1 && d->padW == 1 &&
+      d->Hin == d->Hm && d->Win == d->Wm && d->Hm == d->Hout && d->Wm == d->Wout && d->ldOut == 64 && !(d->flags & FO_MASK) &&
+      a.Ktot == 128 && inBytes < (1ull << 31) && !(norgb && atoi(norgb))) {
+    const int nblocks = (a.M + 31) / 32;
+    const int grid = std::min((nblocks + 3) / 4, fo_cu_count() * 3);
+    hipLaunchKernelGGL(conv_rgb_bf16_kernel, dim3(grid), dim3(256), 0, s, a, nblocks);
+    FO_CHECK_LAUNCH();
+    return FO_OK;
+  }
   // big tiles (one workgroup per CU) where the launch still fills the chip for a few rounds: stride-1 same-size convs.
   // Measured at the C3 shapes and at a fifth of them (tools/ab_bf16.py): 256-column tiles +22...30 % over conv_bf16_kernel
   // on conv3_x / conv4_x, 128-column tiles +5...10 % on conv2_x and +12...15 % on 2-round launches; 64-column layers
