@@ -53,6 +53,13 @@ SIGNATURES = {
     "fo_wgrad_banked_ws_bytes": (_L, [_D, _I]),
     "fo_conv_wgrad_banked": (_I, [_D, _P, _P, _P, _I, _I, _P, _L, _I, _P]),
     "fo_wino_gradout": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P]),
+    "fo_w42_filter": (_I, [_P, _P, _I, _I, _I, _P]),
+    "fo_w42_input_cells": (_I, [_P, _I, _P, _I, _I, _I, _I, _L, _P]),
+    "fo_w42_input_full": (_I, [_P, _I, _P, _I, _I, _I, _I, _L, _P]),
+    "fo_w42_output": (_I, [_P, _L, _P, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "fo_w42_output_cells": (_I, [_P, _L, _P, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "fo_w42_gradout": (_I, [_P, _I, _P, _I, _I, _I, _I, _L, _P]),
+    "fo_w42_wgrad_out": (_I, [_P, _P, _I, _I, _P]),
     "fo_wino_wgrad_out": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "fo_wino_filter": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "fo_wino_input": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P]),

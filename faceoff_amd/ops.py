@@ -345,6 +345,121 @@ def _conv3d_winograd_one(x, U, bias, out, *, T, cin, cout, flags=0, mask=None, a
     return V if keep_v else None
 
 
+# ---------------------------------------------------------------- Winograd F(4x4, 2x2) for the k4 s2 p1 stems (csrc/wino42.hip)
+W42 = not _os.environ.get("FACEOFF_NO_W42")
+
+
+def _rows128(n):
+    return (n + 127) // 128 * 128
+
+
+def w42_filter(w, transposed):
+    """w [O][I][4][4] (Conv2d; or ConvTranspose2d [I_T][O_T][4][4] read as O := I_T, I := O_T) -> U [25][O][4I] (conv form) or
+    [25][4I][O] (transposed form)."""
+    O, I = w.shape[:2]
+    U = torch.empty(25 * O * 4 * I, device=w.device, dtype=torch.float32)
+    _lib.call("fo_w42_filter", _ptr(w), _ptr(U), O, I, int(bool(transposed)), _stream())
+    return U
+
+
+def w42_conv_ok(N, H, W, cin, cout):
+    """conv form (Conv2d k4 s2 p1 forward; data gradient of ConvTranspose2d k4 s2 p1) on [N,H,W,cin] -> [N,H/2,W/2,cout]"""
+    rows = N * (H // 8) * (W // 8)
+    return (W42 and H % 8 == 0 and W % 8 == 0 and cin % 16 == 0 and 4 * cin >= 64 and cout % 128 == 0 and rows >= 1024
+            and 25 * _rows128(rows) * max(4 * cin, cout) * 4 < (1 << 31))
+
+
+def w42_convT_ok(N, h, w, cin, cout):
+    """transposed form (ConvTranspose2d k4 s2 p1 forward; data gradient of Conv2d k4 s2 p1) on [N,h,w,cin] -> [N,2h,2w,cout]"""
+    rows = N * ((h + 4) // 4) * ((w + 4) // 4)
+    return (W42 and cin % 32 == 0 and cin >= 64 and (4 * cout) % 128 == 0 and rows >= 1024
+            and 25 * _rows128(rows) * max(cin, 4 * cout) * 4 < (1 << 31))
+
+
+def _w42_gemm(V, U, M, rows, K, Nc, label):
+    prof = PROFILER
+    if prof is not None:
+        nominal = 2.0 * 25 * rows * K * Nc
+        prof.begin("wino_gemm" + (f" [F(4,2) 25x{rows} {K}->{Nc} {label}]" if prof.detail else ""), nominal, nominal)
+    _lib.call("fo_wino_gemm", _ptr(V), _ptr(U), _ptr(M), 25, 1, 1, rows, K, Nc, 1, _stream())
+    if prof is not None:
+        prof.end()
+
+
+def _epi(bias, mask, add, flags):
+    return flags | (FO_BIAS if bias is not None else 0) | (FO_MASK if mask is not None else 0) | (FO_ADD if add is not None else 0)
+
+
+def conv_k4s2_winograd(x, U, bias, out, *, cin, cout, flags=0, mask=None, add=None, keep_v=False):
+    """Conv2d k4 s2 p1 (cin -> cout) on x [N,H,W,>=cin] into out [N,H/2,W/2,>=cout] as F(4x4, 2x2) over 2x2 pixel cells.
+    U = w42_filter(w, False).  keep_v: return the transformed input (the layer's filter gradient needs exactly it)."""
+    N, H, W, _ = x.shape
+    rows = _rows128(N * (H // 8) * (W // 8))
+    K = 4 * cin
+    V, M = _wino_buffers((0 if keep_v else 25 * rows * K, 25 * rows * cout), x.device)
+    if keep_v:
+        V = torch.empty(25 * rows * K, device=x.device, dtype=torch.float32)
+    _lib.call("fo_w42_input_cells", _ptr(x), ld_of(x), _ptr(V), N, H, W, cin, C.c_int64(rows), _stream())
+    _w42_gemm(V, U, M, rows, K, cout, "conv")
+    _lib.call("fo_w42_output", _ptr(M), C.c_int64(rows), _ptr(bias), _ptr(mask), ld_of(mask) if mask is not None else 0, _ptr(add),
+              ld_of(add) if add is not None else 0, _ptr(out), ld_of(out), N, H // 2, W // 2, cout, _epi(bias, mask, add, flags), _stream())
+    return V if keep_v else None
+
+
+def convT_k4s2_winograd(g, U, bias, out, *, cin, cout, flags=0, mask=None, add=None):
+    """ConvTranspose2d k4 s2 p1 (cin -> cout) on g [N,h,w,>=cin] into out [N,2h,2w,>=cout] -- equally the data gradient of a
+    Conv2d k4 s2 p1 (cout -> cin).  U = w42_filter(w, True) with w read as [cin][cout][4][4]."""
+    N, h, w, _ = g.shape
+    rows = _rows128(N * ((h + 4) // 4) * ((w + 4) // 4))
+    V, M = _wino_buffers((25 * rows * cin, 25 * rows * 4 * cout), g.device)
+    _lib.call("fo_w42_input_full", _ptr(g), ld_of(g), _ptr(V), N, h, w, cin, C.c_int64(rows), _stream())
+    _w42_gemm(V, U, M, rows, cin, 4 * cout, "convT")
+    _lib.call("fo_w42_output_cells", _ptr(M), C.c_int64(rows), _ptr(bias), _ptr(mask), ld_of(mask) if mask is not None else 0, _ptr(add),
+              ld_of(add) if add is not None else 0, _ptr(out), ld_of(out), N, h, w, cout, _epi(bias, mask, add, flags), _stream())
+
+
+def w42_wgrad_ok(N, H, W, cin, cout):
+    """filter gradient of the conv form: x [N,H,W,cin] (cells), g [N,H/2,W/2,cout]"""
+    rows = N * (H // 8) * (W // 8)
+    return (W42 and H % 8 == 0 and W % 8 == 0 and cin % 16 == 0 and cout % 32 == 0 and ((H // 8) * (W // 8)) % 32 == 0
+            and 25 * rows * max(4 * cin, cout) * 4 < (1 << 31))
+
+
+def conv_k4s2_wgrad_winograd(x, g, dw, *, cin, cout, V=None):
+    """dw [cout][cin][4][4] = filter gradient of Conv2d k4 s2 p1 from its input x [N,H,W,>=cin] and output gradient
+    g [N,H/2,W/2,>=cout] (for a ConvTranspose2d: x := its output gradient, g := its input, dw its [I_T][O_T][4][4] weight).
+    V: the forward's transformed input (conv_k4s2_winograd(keep_v=True)), rows padded to 128."""
+    N, H, W, _ = x.shape
+    tiles = N * (H // 8) * (W // 8)
+    K = 4 * cin
+    if V is not None:
+        rows = V.numel() // (25 * K)
+        _, dM = _wino_buffers((0, 25 * rows * cout), x.device)
+    else:
+        rows = tiles
+        V, dM = _wino_buffers((25 * rows * K, 25 * rows * cout), x.device)
+        _lib.call("fo_w42_input_cells", _ptr(x), ld_of(x), _ptr(V), N, H, W, cin, C.c_int64(rows), _stream())
+    if rows != tiles:
+        dM[:25 * rows * cout].zero_()                                  # the padding rows of a plane contribute nothing
+    _lib.call("fo_w42_gradout", _ptr(g), ld_of(g), _ptr(dM), N, H // 2, W // 2, cout, C.c_int64(rows), _stream())
+    # planes as frames of a (1,1,1) wgrad: one "frame" per plane with `rows` positions
+    d = _desc(N=25, T=1, Hin=1, Win=rows, Hm=1, Wm=rows, Hout=1, Wout=rows, Cin=K, Cout=cout, KD=1, KH=1, KW=1, stride=1, padD=0, padH=0,
+              padW=0, ostride=1, ophH=0, ophW=0, ldIn=K, ldOut=cout, ldMask=0, ldAdd=0, flags=0)
+    nbytes = _lib.load().fo_wgrad_banked_ws_bytes(C.byref(d), 25)
+    if nbytes < 0:
+        _lib.check(-1, "fo_wgrad_banked_ws_bytes")
+    ws = _workspace(nbytes + 25 * cout * K * 4 + 64, x.device)
+    dU = ws[(nbytes + 3) // 4 // 4 * 4 + 4:][:25 * cout * K]
+    prof = PROFILER
+    if prof is not None:
+        nominal = 2.0 * 25 * rows * cout * K
+        prof.begin("conv_wgrad_%dx%d" % (cout, K) + (f" [F(4,2) GEMM 25x{rows}]" if prof.detail else ""), nominal, nominal)
+    _lib.call("fo_conv_wgrad_banked", C.byref(d), _ptr(dM), _ptr(V), _ptr(dU), cout, K, _ptr(ws), C.c_int64(nbytes), 25, _stream())
+    if prof is not None:
+        prof.end()
+    _lib.call("fo_w42_wgrad_out", _ptr(dU), _ptr(dw), cout, cin, _stream())
+
+
 def wino_wgrad_ok(H, W, N, T, m=2, kd=3):
     """The Winograd filter-gradient form needs frames that are multiples of m, (H/m * W/m) % 32 == 0 (the wgrad kernel's
     row-run walk over a plane flattened to one row per frame) and plane stacks inside the 2 GiB buffer window."""

@@ -216,6 +216,29 @@ int fo_wino_output(const float* M, const float* bias, const float* mask, int ldM
 int fo_wino_gradout(const float* g, int ldg, float* dM, int N, int H, int W, int C, int m, void* stream);
 int fo_wino_wgrad_out(const float* dU /* [(m+2)^2][O][I][KD] */, float* dW, int O, int I, int KD, int m, void* stream);
 
+/* ---------------------------------------------------------------- Winograd F(4x4, 2x2) for the k4 s2 p1 stems (csrc/wino42.hip)
+ * A Conv2d k4 s2 p1 (reference models/vqvae_conv3d_latent.py:108,110,117) is a k2 s1 convolution over 2x2 pixel cells of the
+ * padded input; its adjoint -- its data gradient, and the forward of ConvTranspose2d k4 s2 p1 (:157,160,215) -- a full k2
+ * correlation that produces cells.  Both run as 25 Winograd-domain GEMMs (fo_wino_gemm, KD = 1) between these transforms.
+ * w: [O][I][4][4] (Conv2d) or, same memory, [I_T][O_T][4][4] (ConvTranspose2d with O := I_T, I := O_T).
+ *   conv form        rows = tiles of 4x4 outputs, K = 4 I:  V = input_cells(x),  U = filter(transposed = 0) [25][O][4 I],
+ *                    M [25][rows][O] -> fo_w42_output -> y [N][H/2][W/2][O]
+ *   transposed form  rows = tiles of 4x4 cells over the (h+1) x (w+1) cell grid, K = O:  V = input_full(g),
+ *                    U = filter(transposed = 1) [25][4 I][O],  M [25][rows][4 I] -> fo_w42_output_cells -> [N][2h][2w][I]
+ *   filter gradient  dM = fo_w42_gradout(dy) [25][rows][O], V = input_cells(x): dU [25][O][4 I] by fo_conv_wgrad_banked,
+ *                    dW = fo_w42_wgrad_out(dU)
+ * planeRows: rows per plane of V / M / dM (>= the tile count; the GEMM wants a multiple of 128).  Epilogue flags as
+ * fo_wino_output (FO_BIAS | FO_MASK | FO_ADD | FO_OUT_RELU). */
+int fo_w42_filter(const float* w, float* U, int O, int I, int transposed, void* stream);
+int fo_w42_input_cells(const float* x, int ldx, float* V, int N, int H, int W, int C, long long planeRows, void* stream);
+int fo_w42_input_full(const float* g, int ldg, float* V, int N, int h, int w, int C, long long planeRows, void* stream);
+int fo_w42_output(const float* M, long long planeRows, const float* bias, const float* mask, int ldMask, const float* add, int ldAdd,
+                  float* out, int ldOut, int N, int h, int w, int C, int flags, void* stream);
+int fo_w42_output_cells(const float* M, long long planeRows, const float* bias, const float* mask, int ldMask, const float* add, int ldAdd,
+                        float* out, int ldOut, int N, int h, int w, int C, int flags, void* stream);
+int fo_w42_gradout(const float* g, int ldg, float* dM, int N, int h, int w, int C, long long planeRows, void* stream);
+int fo_w42_wgrad_out(const float* dU /* [25][O][4 I] */, float* dW, int O, int I, void* stream);
+
 /* ---------------------------------------------------------------- input pipeline / validation helpers on the device
  * dst[n][c] = warp of src[n][c] ([N][C][H][W] frames) by the affine map M (6 floats, HOST pointer, row-major 2x3) taking
  * DESTINATION pixel (x, y) to its SOURCE position -- what cv2.warpAffine applies after inverting its argument
