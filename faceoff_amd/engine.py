@@ -56,6 +56,7 @@ class _Layer:
 
     # -- filter packing (every step: the optimiser rewrites the checkpoint-layout weights)
     def pack(self):
+        self._w42_u = {}           # Winograd F(4x4, 2x2) filter banks of this step (k4 s2 stems), made on first use
         if self.kind == "convT":
             if self.co <= 8:                         # few output channels: all 4 phases as one 3x3 filter bank
                 self.wp = ops.pack_convT_fused(self.w, self.wp)
@@ -86,8 +87,16 @@ class _Layer:
         if self.kind == "convT" and self.co <= 8:
             assert add is None
             ops.convT_fused(x, self.wp, self.b, out, cin=self.cip, cout=self.co, flags=flags)
+        elif self.kind == "convT" and self._w42("convT", x.shape[0], x.shape[1], x.shape[2], self.ci, self.co):
+            ops.convT_k4s2_winograd(x, self._w42_filter(True), self.b, out, cin=self.ci, cout=self.co, flags=flags, add=add)
         elif self.kind == "convT":
             ops.convT_phases(x, self.wp, self.b, out, cin=self.cip, cout=self.co, flags=flags, add=add)
+        elif self.k[-1] == 4 and self._w42("conv", x.shape[0], x.shape[1], x.shape[2], self.ci, self.co):
+            S = self.engine._cur_S
+            keep = S is not None and self.engine.keep_wino_v and ops.w42_wgrad_ok(x.shape[0], x.shape[1], x.shape[2], self.ci, self.co)
+            V = ops.conv_k4s2_winograd(x, self._w42_filter(False), self.b, out, cin=self.ci, cout=self.co, flags=flags, add=add, keep_v=keep)
+            if keep:
+                S.setdefault("_wino_v", {})[self.name] = V
         elif self._winograd_m(x):
             m = self._winograd_m(x)
             kd = self._wino_kd
@@ -119,6 +128,22 @@ class _Layer:
             return 4
         return 0
 
+    def _w42(self, form, N, H, W, cin, cout):
+        """Winograd F(4x4, 2x2) form of a k4 s2 p1 stem pass (2.56x fewer MFMA FLOP): `form` = "conv" (Conv2d forward, ConvTranspose2d
+        data gradient: [N,H,W,cin] -> [N,H/2,W/2,cout]), "convT" ([N,H,W,cin] -> [N,2H,2W,cout]) or "wgrad" (conv-form geometry).
+        Measured per layer (tools/bench_w42.py): pays on enc_b.2, dec.4 and dec_t.4 (128 channels on the pixel-grid side: -20 % forward / data
+        gradient, -25...-48 % filter gradient), not on upsample_t (64 -> 64) or enc_t.0 (64 channels on that side)."""
+        eng = self.engine
+        wide, narrow = (self.ci, self.co) if self.kind == "convT" else (self.co, self.ci)     # the cell side has 4 x narrow channels
+        if eng is None or not eng.winograd or not eng.w42 or wide < 128 or narrow < 64:
+            return False
+        return {"conv": ops.w42_conv_ok, "convT": ops.w42_convT_ok, "wgrad": ops.w42_wgrad_ok}[form](N, H, W, cin, cout)
+
+    def _w42_filter(self, transposed):
+        if transposed not in self._w42_u:
+            self._w42_u[transposed] = ops.w42_filter(self.w, transposed)
+        return self._w42_u[transposed]
+
     @property
     def _wino_kd(self):
         return 3 if self.kind == "conv3d" else 1
@@ -131,9 +156,13 @@ class _Layer:
 
     # -- data gradient: gin = dgrad(g) [* (mask > 0)] [+ add]
     def dgrad(self, g, gin, T=1, mask=None, add=None):
-        if self.kind == "convT":                     # conv k4 s2 p1 over g
+        if self.kind == "convT" and self._w42("conv", g.shape[0], g.shape[1], g.shape[2], self.co, self.ci):
+            ops.conv_k4s2_winograd(g, self._w42_filter(False), None, gin, cin=self.co, cout=self.ci, mask=mask, add=add)
+        elif self.kind == "convT":                   # conv k4 s2 p1 over g
             ops.conv_igemm(g, self.wpd, None, gin, k=(1, 4, 4), stride=2, pad=(0, 1, 1), cin=ops.pad_in(self.co),
                            cout=self.ci, mask=mask, add=add)
+        elif self.k[-1] == 4 and self._w42("convT", g.shape[0], g.shape[1], g.shape[2], self.co, self.ci):
+            ops.convT_k4s2_winograd(g, self._w42_filter(True), None, gin, cin=self.co, cout=self.ci, mask=mask, add=add)
         elif self.k[-1] == 4:                        # transposed conv over g
             ops.convT_phases(g, self.wpd, None, gin, cin=self.co, cout=self.ci, mask=mask, add=add)
         elif self._winograd_m(g):
@@ -167,9 +196,20 @@ class _Layer:
 
     def _wgrad(self, x, g, T, in_relu):
         geo = self._geom()
-        if self.kind == "convT":
+        if self.kind == "convT" and self._w42("wgrad", g.shape[0], g.shape[1], g.shape[2], self.co, self.ci):
+            # the adjoint convolution's filter gradient: its input is this layer's output gradient, its output gradient this layer's input
+            ops.conv_k4s2_wgrad_winograd(g, x, self.gw, cin=self.co, cout=self.ci)
+            ops.bias_grad(g, self.gb, self.co)
+        elif self.kind == "convT":
             ops.conv_wgrad(x, g, self.gw, None, k=(1, 4, 4), stride=2, pad=(0, 1, 1), a_real=self.ci, b_real=self.co,
                            in_relu=False)
+            ops.bias_grad(g, self.gb, self.co)
+        elif self.k[-1] == 4 and not in_relu and self._w42("wgrad", x.shape[0], x.shape[1], x.shape[2], self.ci, self.co):
+            S = self.engine._cur_S
+            V = S.get("_wino_v", {}).pop(self.name, None) if S is not None else None
+            if V is not None and self.engine.wgrad_stream is not None:
+                self.engine._keepalive.append(V)
+            ops.conv_k4s2_wgrad_winograd(x, g, self.gw, cin=self.ci, cout=self.co, V=V)
             ops.bias_grad(g, self.gb, self.co)
         elif (self._winograd_m(x) and not in_relu and self.ci == self.cip
               and ops.wino_wgrad_ok(x.shape[1], x.shape[2], x.shape[0], T, self._winograd_m(x), self._wino_kd)):
@@ -242,6 +282,7 @@ class VQVAEEngine:
         # Conv3d forward / data gradient as Winograd F(2x2,3x3) + a (3,1,1) implicit GEMM (FACEOFF_NO_WINOGRAD=1: direct)
         self.winograd = not _os.environ.get("FACEOFF_NO_WINOGRAD")
         self.winograd_max_tile = int(_os.environ.get("FACEOFF_WINOGRAD_TILE", "4"))   # 2: F(2x2,3x3) everywhere
+        self.w42 = not _os.environ.get("FACEOFF_NO_W42")       # k4 s2 stems as Winograd F(4x4, 2x2) (needs self.winograd too)
         self.fused_resblock = not _os.environ.get("FACEOFF_NO_FUSED_RESBLOCK")
         self.keep_wino_v = False      # training forward: keep each Conv3d's transformed input for its filter gradient
         self._keepalive = []

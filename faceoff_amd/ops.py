@@ -347,6 +347,7 @@ def _conv3d_winograd_one(x, U, bias, out, *, T, cin, cout, flags=0, mask=None, a
 
 # ---------------------------------------------------------------- Winograd F(4x4, 2x2) for the k4 s2 p1 stems (csrc/wino42.hip)
 W42 = not _os.environ.get("FACEOFF_NO_W42")
+W42_MIN_ROWS = 1024          # tiles per plane below which the direct kernels are used (tests lower it to reach this path at small sizes)
 
 
 def _rows128(n):
@@ -365,14 +366,14 @@ def w42_filter(w, transposed):
 def w42_conv_ok(N, H, W, cin, cout):
     """conv form (Conv2d k4 s2 p1 forward; data gradient of ConvTranspose2d k4 s2 p1) on [N,H,W,cin] -> [N,H/2,W/2,cout]"""
     rows = N * (H // 8) * (W // 8)
-    return (W42 and H % 8 == 0 and W % 8 == 0 and cin % 16 == 0 and 4 * cin >= 64 and cout % 128 == 0 and rows >= 1024
+    return (W42 and H % 8 == 0 and W % 8 == 0 and cin % 16 == 0 and 4 * cin >= 64 and cout % 128 == 0 and rows >= W42_MIN_ROWS
             and 25 * _rows128(rows) * max(4 * cin, cout) * 4 < (1 << 31))
 
 
 def w42_convT_ok(N, h, w, cin, cout):
     """transposed form (ConvTranspose2d k4 s2 p1 forward; data gradient of Conv2d k4 s2 p1) on [N,h,w,cin] -> [N,2h,2w,cout]"""
     rows = N * ((h + 4) // 4) * ((w + 4) // 4)
-    return (W42 and cin % 32 == 0 and cin >= 64 and (4 * cout) % 128 == 0 and rows >= 1024
+    return (W42 and cin % 32 == 0 and cin >= 64 and (4 * cout) % 128 == 0 and rows >= W42_MIN_ROWS
             and 25 * _rows128(rows) * max(cin, 4 * cout) * 4 < (1 << 31))
 
 
@@ -421,8 +422,8 @@ def convT_k4s2_winograd(g, U, bias, out, *, cin, cout, flags=0, mask=None, add=N
 def w42_wgrad_ok(N, H, W, cin, cout):
     """filter gradient of the conv form: x [N,H,W,cin] (cells), g [N,H/2,W/2,cout]"""
     rows = N * (H // 8) * (W // 8)
-    return (W42 and H % 8 == 0 and W % 8 == 0 and cin % 16 == 0 and cout % 32 == 0 and ((H // 8) * (W // 8)) % 32 == 0
-            and 25 * rows * max(4 * cin, cout) * 4 < (1 << 31))
+    return (W42 and H % 8 == 0 and W % 8 == 0 and cin % 16 == 0 and cout % 32 == 0 and rows % 32 == 0 and rows >= W42_MIN_ROWS
+            and 25 * _rows128(rows) * max(4 * cin, cout) * 4 < (1 << 31))
 
 
 def conv_k4s2_wgrad_winograd(x, g, dw, *, cin, cout, V=None):
