@@ -16,6 +16,8 @@ from __future__ import annotations
 
 from collections import OrderedDict
 
+import os as _os
+
 import torch
 
 from . import ops
@@ -35,6 +37,9 @@ BACKWARD_ORDER = (
     + _rb("enc_t.blocks.3") + ["enc_t.blocks.2", "enc_t.blocks.0"]
     + [f"conv3d_encoded_b.conv3d.{i}.0" for i in (2, 1, 0)] + _rb("enc_b.blocks.6") + _rb("enc_b.blocks.5")
     + ["enc_b.blocks.4", "enc_b.blocks.2", "enc_b.blocks.0"])
+
+
+WINO2D_MIN_CIN = int(_os.environ.get("FACEOFF_WINO2D_MIN_CIN", "64"))    # 3x3 Conv2d with >= this many input channels: F(4x4,3x3) (64: enc_t.2, dec_t.0; -0.13 ms per step)
 
 
 class _Layer:
@@ -114,7 +119,7 @@ class _Layer:
             ops.conv_igemm(x, self.wp, self.b, out, T=T if self.kind == "conv3d" else 1, cin=self.cip, cout=self.co,
                            flags=flags, add=add, **g)
 
-    def _winograd_m(self, x):
+    def _winograd_m(self, x, dgrad=False):
         """Output-tile size of the Winograd form for a Conv3d k3 p1 on frames like x: 4 (64x64 latents: 4x fewer MFMA
         FLOP), 2 (other even sizes: 2.25x fewer) or 0 = direct kernel (odd sizes, other layer kinds, FACEOFF_NO_WINOGRAD)."""
         eng = self.engine
@@ -124,8 +129,9 @@ class _Layer:
         if self.kind == "conv3d":
             return m
         # Conv2d 3x3 s1 128->128 (enc_b.blocks.4, dec.blocks.0): one depth tap, K = Cin only -- pays with F(4x4) alone
-        if self.kind == "conv" and self.k == (3, 3) and self.ci >= 128 and self.co >= 128 and m == 4:
-            return 4
+        if self.kind == "conv" and self.k == (3, 3) and self.ci >= WINO2D_MIN_CIN and self.co >= 128 and m == 4:
+            # (the data gradient's GEMM has Cout := ci columns: the plane-stack GEMM kernel wants whole 128-column tiles)
+            return 4 if (not dgrad or self.ci % 128 == 0) else 0
         return 0
 
     def _w42(self, form, N, H, W, cin, cout):
@@ -165,8 +171,8 @@ class _Layer:
             ops.convT_k4s2_winograd(g, self._w42_filter(True), None, gin, cin=self.co, cout=self.ci, mask=mask, add=add)
         elif self.k[-1] == 4:                        # transposed conv over g
             ops.convT_phases(g, self.wpd, None, gin, cin=self.co, cout=self.ci, mask=mask, add=add)
-        elif self._winograd_m(g):
-            m = self._winograd_m(g)
+        elif self._winograd_m(g, dgrad=True):
+            m = self._winograd_m(g, dgrad=True)
             ops.conv3d_winograd(g, self._wino_filter(m, True), None, gin, T=T, cin=self.co, cout=self.ci, mask=mask, add=add, m=m,
                                 kd=self._wino_kd)
         else:
