@@ -155,7 +155,8 @@ __global__ void vq_stats_reduce_kernel(const float* __restrict__ ws, int nblk, f
   else counts[e - VQ_K * VQ_D] = s;
 }
 
-inline int stats_blocks(int64_t nvec) { return (int)std::max<int64_t>(1, std::min<int64_t>(128, nvec / 512)); }
+// one workgroup per CU (the 131 KB table allows no more); the slab count is part of the workspace contract (fo_vq_stats_ws_bytes)
+inline int stats_blocks(int64_t nvec) { return (int)std::max<int64_t>(1, std::min<int64_t>(fo_cu_count(), nvec / 512)); }
 
 // EMA update (:66-75).  One workgroup, one thread per code.
 __global__ __launch_bounds__(VQ_K) void vq_ema_kernel(float* embed, float* cluster_size, float* embed_avg,
