@@ -277,14 +277,20 @@ class VQVAEEngine:
         import os as _os
         self.wgrad_stream = None
         if self.device.type == "cuda" and not _os.environ.get("FACEOFF_NO_WGRAD_OVERLAP"):
-            self.wgrad_stream = torch.cuda.Stream(device=self.device)
+            self.wgrad_stream = torch.cuda.Stream(device=self.device, priority=int(_os.environ.get("FACEOFF_WGRAD_PRIO", "0")))
         # second side stream: the bottom Conv3d chain (forward and backward) is independent of the top-level chain
         # (enc_t / quantize_t / dec_t), whose launches are small (1280 tiles); run side by side, each fills the
         # other's tails -- two igemm workgroups per CU fit whichever kernel they come from.
         self.aux_stream = None
         if self.device.type == "cuda" and not _os.environ.get("FACEOFF_NO_CHAIN_OVERLAP"):
-            self.aux_stream = torch.cuda.Stream(device=self.device)
-        self._streams = (self.wgrad_stream, self.aux_stream)
+            self.aux_stream = torch.cuda.Stream(device=self.device, priority=int(_os.environ.get("FACEOFF_AUX_PRIO", "0")))
+        # third side stream: the ~60 filter-packing launches of a step (tiny, latency-bound) beside the input layout kernel and
+        # the first two layers instead of in front of them (tools/timeline.py: they were 1.3 ms of nothing-but-small-kernels)
+        self.pack_stream = None
+        if self.device.type == "cuda" and not _os.environ.get("FACEOFF_NO_PACK_OVERLAP"):
+            self.pack_stream = torch.cuda.Stream(device=self.device)
+        self._streams = (self.wgrad_stream, self.aux_stream, self.pack_stream)
+        self._pack_events = None
         # Conv3d forward / data gradient as Winograd F(2x2,3x3) + a (3,1,1) implicit GEMM (FACEOFF_NO_WINOGRAD=1: direct)
         self.winograd = not _os.environ.get("FACEOFF_NO_WINOGRAD")
         self.winograd_max_tile = int(_os.environ.get("FACEOFF_WINOGRAD_TILE", "4"))   # 2: F(2x2,3x3) everywhere
@@ -304,7 +310,7 @@ class VQVAEEngine:
         ``on=False``, everything in program order on the current stream (each kernel then has the GPU to itself --
         what per-kernel timing needs)."""
         torch.cuda.synchronize(self.device)
-        self.wgrad_stream, self.aux_stream = self._streams if on else (None, None)
+        self.wgrad_stream, self.aux_stream, self.pack_stream = self._streams if on else (None, None, None)
 
     def load_state_dict(self, sd):
         for k, v in sd.items():
@@ -360,9 +366,38 @@ class VQVAEEngine:
 
     # ------------------------------------------------------------------ forward (staged so the reference's
     # only_encode / encode_quantized / decode entry points can run the same launches)
-    def pack_filters(self):
-        for layer in self.layers.values():
-            layer.pack()
+    _PACK_FIRST = ("enc_b.blocks.0", "enc_b.blocks.2")
+
+    def pack_filters(self, defer=False):
+        """Every layer's packed filters for this step (the optimiser rewrote the checkpoint-layout weights).  With a pack stream:
+        the first two layers' filters, an event, the rest, a second event; with defer=True (forward()) the caller's stream waits
+        for the first before enc_b.blocks.0 and for the second before enc_b.blocks.4 (stage_encode), otherwise right here."""
+        self._pack_events = None
+        ps = self.pack_stream
+        if ps is None:
+            for layer in self.layers.values():
+                layer.pack()
+            return
+        ps.wait_stream(torch.cuda.current_stream())        # the weights of this step (previous Adam launch) are final
+        with torch.cuda.stream(ps):
+            for name in self._PACK_FIRST:
+                self.layers[name].pack()
+            early = torch.cuda.Event()
+            early.record(ps)
+            for name, layer in self.layers.items():
+                if name not in self._PACK_FIRST:
+                    layer.pack()
+            late = torch.cuda.Event()
+            late.record(ps)
+        self._pack_events = [early, late]
+        if not defer:
+            self._await_pack(1)
+            self._pack_events = None
+
+    def _await_pack(self, which):
+        if self._pack_events is not None and self._pack_events[which] is not None:
+            torch.cuda.current_stream().wait_event(self._pack_events[which])
+            self._pack_events[which] = None
 
     def stage_encode(self, S):
         """only_encode (:237-241): enc_b = Encoder(stride 4), enc_t = Encoder(stride 2)."""
@@ -370,8 +405,10 @@ class VQVAEEngine:
         L, x8 = self.layers, S["x8"]
         N, H, W, _ = x8.shape
         h2, w2, h4, w4, h8, w8 = H // 2, W // 2, H // 4, W // 4, H // 8, W // 8
+        self._await_pack(0)
         a0 = self._new(N, h2, w2, 64); L["enc_b.blocks.0"].fwd(x8, a0, flags=FO_OUT_RELU)
         a1 = self._new(N, h4, w4, 128); L["enc_b.blocks.2"].fwd(a0, a1, flags=FO_OUT_RELU)
+        self._await_pack(1)
         a2 = self._new(N, h4, w4, 128); L["enc_b.blocks.4"].fwd(a1, a2)
         a3 = self._new(N, h4, w4, 128); S["h_eb5"] = self._resblock_fwd("enc_b.blocks.5", a2, a3, False)
         eb = self._new(N, h4, w4, 128); S["h_eb6"] = self._resblock_fwd("enc_b.blocks.6", a3, eb, True)
@@ -465,7 +502,7 @@ class VQVAEEngine:
         T = T or self.clip_len or N
         assert N % T == 0, f"N={N} frames is not a whole number of clips of T={T}"
         assert H % 8 == 0 and W % 8 == 0, "spatial size must be a multiple of 8"
-        self.pack_filters()
+        self.pack_filters(defer=True)
         self.keep_wino_v = bool(training)
         assert Cin <= 8
         S = {"T": T, "x8": ops.cat_nchw_to_nhwc8(*parts) if parts is not None else ops.nchw_to_nhwc(img_nchw, cpad=ops.pad_in(Cin))}
