@@ -277,13 +277,13 @@ class VQVAEEngine:
         import os as _os
         self.wgrad_stream = None
         if self.device.type == "cuda" and not _os.environ.get("FACEOFF_NO_WGRAD_OVERLAP"):
-            self.wgrad_stream = torch.cuda.Stream(device=self.device, priority=int(_os.environ.get("FACEOFF_WGRAD_PRIO", "0")))
+            self.wgrad_stream = torch.cuda.Stream(device=self.device)
         # second side stream: the bottom Conv3d chain (forward and backward) is independent of the top-level chain
         # (enc_t / quantize_t / dec_t), whose launches are small (1280 tiles); run side by side, each fills the
         # other's tails -- two igemm workgroups per CU fit whichever kernel they come from.
         self.aux_stream = None
         if self.device.type == "cuda" and not _os.environ.get("FACEOFF_NO_CHAIN_OVERLAP"):
-            self.aux_stream = torch.cuda.Stream(device=self.device, priority=int(_os.environ.get("FACEOFF_AUX_PRIO", "0")))
+            self.aux_stream = torch.cuda.Stream(device=self.device)
         # third side stream: the ~60 filter-packing launches of a step (tiny, latency-bound) beside the input layout kernel and
         # the first two layers instead of in front of them (tools/timeline.py: they were 1.3 ms of nothing-but-small-kernels)
         self.pack_stream = None
