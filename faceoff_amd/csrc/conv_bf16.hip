@@ -560,17 +560,20 @@ template <> __device__ __forceinline__ void wait_vmcnt<3>() { asm volatile("s_wa
 template <> __device__ __forceinline__ void wait_vmcnt<4>() { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
 template <> __device__ __forceinline__ void wait_vmcnt<6>() { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
 template <> __device__ __forceinline__ void wait_vmcnt<8>() { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+template <> __device__ __forceinline__ void wait_vmcnt<5>() { asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); }
+template <> __device__ __forceinline__ void wait_vmcnt<10>() { asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); }
 
-template <int BN, int WAVES_M, int WAVES_N>
+template <int BMB, int BN, int WAVES_M, int WAVES_N>
 __global__ __launch_bounds__(512, 1) void conv_bf16_pp16_kernel(const ConvArgsH a) {
-  constexpr int BMB = 256;
-  static_assert(WAVES_M * WAVES_N == 8 && (BN == 256 || BN == 128), "8 waves");
+  static_assert(WAVES_M * WAVES_N == 8 && (BMB == 256 || BMB == 512) && (BN == 256 || BN == 128), "8 waves");
   constexpr int TM = BMB / WAVES_M / 16, TN = BN / WAVES_N / 16;     // 16 x 16 blocks per wave
   constexpr int WCOLS = TN * 16;
-  static_assert(WCOLS == 64, "the epilogue stores 64-column wave tiles");
+  static_assert(WCOLS == 64 || WCOLS == 128, "the epilogue stores 64- or 128-column wave tiles");
+  static_assert(TM % 2 == 0, "the epilogue walks pairs of 16-row blocks");
   constexpr int SLOT = (BMB + BN) * 64;                   // bytes per ring slot
   constexpr int NPB = BN / 128;                           // B pieces per wave and tile
-  constexpr int NP = 2 + NPB;
+  constexpr int NPA = BMB / 128;                          // A pieces (16 rows x 64 B) per wave and tile
+  constexpr int NP = NPA + NPB;
   constexpr int C_LD = WCOLS + 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const fo_conv_desc& d = a.d;
@@ -586,10 +589,10 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_pp16_kernel(const ConvArgsH 
   const int chunks32 = a.cinChunks * 2;
   const int nt = a.ksteps * 2;
   const int drow = lane >> 2, dpos = lane & 3;
-  int rowoffA[2];
-  unsigned tapmaskA[2], woffB[NPB];
+  int rowoffA[NPA];
+  unsigned tapmaskA[NPA], woffB[NPB];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < NPA; ++i) {
     const int row = (i * 8 + wave) * 16 + drow;
     const int chunk = dpos ^ swz(row);
     const int m = tile_m * BMB + row;
@@ -624,7 +627,7 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_pp16_kernel(const ConvArgsH 
     lds_byte* const sa = lds3 + (ld_q & 3) * SLOT;
     lds_byte* const sb = sa + BMB * 64;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NPA; ++i) {
       const unsigned pad = (((tapmaskA[i] >> ld_tap) & 1u) - 1u) & OOB;       // padding tap / row past M / tile past the end -> zeros
       dma16(rin, sa + (i * 8 + wave) * 1024, (unsigned)(rowoffA[i] + stepoff) | pad);
     }
@@ -739,11 +742,11 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_pp16_kernel(const ConvArgsH 
   }
 }
 
-template <int BN, int WAVES_M, int WAVES_N>
+template <int BMB, int BN, int WAVES_M, int WAVES_N>
 int launch_pp16(const ConvArgsH& a, hipStream_t s) {
-  constexpr int ldsBytes = 4 * (256 + BN) * 64;
+  constexpr int ldsBytes = 4 * (BMB + BN) * 64;
   static bool attr_set = false;
-  void (*kern)(const ConvArgsH) = conv_bf16_pp16_kernel<BN, WAVES_M, WAVES_N>;
+  void (*kern)(const ConvArgsH) = conv_bf16_pp16_kernel<BMB, BN, WAVES_M, WAVES_N>;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, ldsBytes) != hipSuccess) {
       fo_set_error("conv_bf16: cannot reserve %d bytes of LDS", ldsBytes);
@@ -869,7 +872,8 @@ int fo_conv_igemm_bf16(const fo_conv_desc* d, const void* in, const void* wp, co
   }
   // big tiles (one workgroup per CU) where the launch still fills the chip for a few rounds: stride-1 same-size convs.
   // Measured at the C3 shapes and at a fifth of them (tools/ab_bf16.py): 256-column tiles +22...30 % over conv_bf16_kernel
-  // on conv3_x / conv4_x, 128-column tiles +5...10 % on conv2_x and +12...15 % on 2-round launches; 64-column layers
+  // on conv3_x / conv4_x, 128-column tiles +5...10 % on conv2_x and +12...15 % on 2-round launches, the 512 x 128 tile (32 MFMAs per
+  // phase and wave instead of 16: half the barriers per FLOP) another +14...17 % where there are >= 8 rounds of them; 64-column layers
   // (K = 576: 18 phases) stay on conv_bf16_kernel, whose second workgroup hides the prologue and epilogue
   const bool same = d->stride == 1 && d->ostride == 1 && d->Hm == d->Hout && d->Wm == d->Wout && d->Hin == d->Hm && d->Win == d->Wm;
   const char* nobig = getenv("FACEOFF_BF16_SMALL_TILES");            // diagnostics / tests: never
@@ -879,11 +883,17 @@ int fo_conv_igemm_bf16(const fo_conv_desc* d, const void* in, const void* wp, co
     const long long cus = (force && atoi(force)) ? 0 : fo_cu_count();
     if (d->Cout % 256 == 0 && tilesM256 * (d->Cout / 256) >= 3 * cus) {
       a.tilesM = (int)tilesM256; a.tilesN = d->Cout / 256;
-      return launch_pp16<256, 2, 4>(a, s);
+      return launch_pp16<256, 256, 2, 4>(a, s);
+    }
+    const char* t512 = getenv("FACEOFF_BF16_TILE512");               // 0: never the 512-row tile (diagnostics)
+    const long long tilesM512 = (a.M + 511) / 512;
+    if (!(t512 && !atoi(t512)) && tilesM512 * (d->Cout / 128) >= 8 * cus && (cus > 0 || (t512 && atoi(t512)))) {
+      a.tilesM = (int)tilesM512; a.tilesN = d->Cout / 128;
+      return launch_pp16<512, 128, 8, 1>(a, s);
     }
     if (tilesM256 * (d->Cout / 128) >= 2 * cus) {
       a.tilesM = (int)tilesM256; a.tilesN = d->Cout / 128;
-      return launch_pp16<128, 4, 2>(a, s);
+      return launch_pp16<256, 128, 4, 2>(a, s);
     }
   }
   const char* nodma = getenv("FACEOFF_BF16_NO_DMA");                // diagnostics: the register-staged kernel everywhere

@@ -82,7 +82,7 @@ def _bf16_round(a):
     return torch.from_numpy(a).bfloat16().float()
 
 
-@pytest.mark.parametrize("big", [False, True, "staged"])
+@pytest.mark.parametrize("big", [False, True, "staged", "tile512"])
 @pytest.mark.parametrize("cin,cout,hw,flags", [(64, 64, (20, 28), "relu"), (128, 256, (9, 13), "relu"), (256, 128, (16, 16), "mask"),
                                                (64, 3, (12, 20), "none"), (8, 64, (18, 22), "relu"), (512, 512, (6, 10), "mask"),
                                                (64, 128, (17, 23), "mask")])
@@ -94,7 +94,10 @@ def test_conv_bf16_vs_torch(cin, cout, hw, flags, big, monkeypatch):
     from faceoff_amd import ops
     # big = the 256-row ping-pong tiles (one workgroup per CU) the C3-size launches take, forced on at this small size;
     # False = the 128-row LDS-DMA tiles; "staged" = the register-staged kernel (diagnostic switch; the RGB layers always use it)
-    if big == "staged":
+    if big == "tile512":           # the 512 x 128 ping-pong tile (layers with 128 output channels and >= 4 rounds of tiles)
+        monkeypatch.setenv("FACEOFF_BF16_BIG_TILES", "1")
+        monkeypatch.setenv("FACEOFF_BF16_TILE512", "1")
+    elif big == "staged":
         monkeypatch.setenv("FACEOFF_BF16_SMALL_TILES", "1")
         monkeypatch.setenv("FACEOFF_BF16_NO_DMA", "1")
     else:
