@@ -873,7 +873,7 @@ int fo_conv_igemm_bf16(const fo_conv_desc* d, const void* in, const void* wp, co
   // big tiles (one workgroup per CU) where the launch still fills the chip for a few rounds: stride-1 same-size convs.
   // Measured at the C3 shapes and at a fifth of them (tools/ab_bf16.py): 256-column tiles +22...30 % over conv_bf16_kernel
   // on conv3_x / conv4_x, 128-column tiles +5...10 % on conv2_x and +12...15 % on 2-round launches, the 512 x 128 tile (32 MFMAs per
-  // phase and wave instead of 16: half the barriers per FLOP) another +14...17 % where there are >= 8 rounds of them; 64-column layers
+  // phase and wave instead of 16: half the barriers per FLOP) another +14...17 % where there are >= 8 rounds of them (a 512 x 64 tile for the 64-column layers measured -8 %); 64-column layers
   // (K = 576: 18 phases) stay on conv_bf16_kernel, whose second workgroup hides the prologue and epilogue
   const bool same = d->stride == 1 && d->ostride == 1 && d->Hm == d->Hout && d->Wm == d->Wout && d->Hin == d->Hm && d->Win == d->Wm;
   const char* nobig = getenv("FACEOFF_BF16_SMALL_TILES");            // diagnostics / tests: never
