@@ -187,7 +187,12 @@ class _Layer:
         gradient both depend only on g, and an igemm workgroup (73 KB LDS) and a wgrad workgroup (64 KB) fit one CU
         together, so each kernel's tail and prologue are filled by the other's workgroups."""
         eng = self.engine
-        if eng is not None and eng.wgrad_stream is not None:
+        if eng is not None and eng.wgrad_stream is not None and eng.defer_wgrad:
+            # deferred: launched behind the NEXT Winograd-domain GEMM of the calling stream (ops.AFTER_GEMM), so that it starts
+            # when that GEMM ends -- beside the HBM-bound output / input transforms that follow -- instead of beside the GEMM
+            eng._keepalive.append((x, g))
+            eng._pending_wgrad.setdefault(torch.cuda.current_stream().cuda_stream, []).append((self, x, g, T, in_relu))
+        elif eng is not None and eng.wgrad_stream is not None:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
             eng.wgrad_stream.wait_event(ev)
@@ -297,6 +302,10 @@ class VQVAEEngine:
         self.w42 = not _os.environ.get("FACEOFF_NO_W42")       # k4 s2 stems as Winograd F(4x4, 2x2) (needs self.winograd too)
         self.fused_resblock = not _os.environ.get("FACEOFF_NO_FUSED_RESBLOCK")
         self.keep_wino_v = False      # training forward: keep each Conv3d's transformed input for its filter gradient
+        # filter gradients start when the next Winograd-domain GEMM of their stream ENDS (beside the HBM-bound transforms that
+        # follow it) rather than beside that GEMM: -0.33 ms per step (tools/ab.sh; holding one or three more back: +0.2...0.3)
+        self.defer_wgrad = not _os.environ.get("FACEOFF_NO_DEFER_WGRAD")
+        self._pending_wgrad = {}
         self._keepalive = []
         self._cur_S = None            # state dict of the forward / backward in flight (kept Winograd planes live in it)
         if state_dict is not None:
@@ -359,6 +368,24 @@ class VQVAEEngine:
         c3.dgrad(g_out, g_h, mask=hbuf)
         c1.wgrad(x, g_h, in_relu=True)
         c1.dgrad(g_h, g_x, mask=x, add=g_out)
+
+    def _flush_wgrad(self, everything=False):
+        """Launch the deferred filter gradients that were queued from the current stream (all streams: everything=True) on the
+        filter-gradient stream, behind an event recorded now."""
+        cur = torch.cuda.current_stream()
+        keys = list(self._pending_wgrad) if everything else [cur.cuda_stream]
+        items = [it for k in keys for it in self._pending_wgrad.pop(k, [])]
+        if not items:
+            return
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        self.wgrad_stream.wait_event(ev)
+        hook, ops.AFTER_GEMM = ops.AFTER_GEMM, None          # (the filter-gradient kernels' own GEMMs must not re-enter)
+        with torch.cuda.stream(self.wgrad_stream):
+            for layer, x, g, T, in_relu in items:
+                layer._wgrad(x, g, T, in_relu)
+                self._ready(layer.name)
+        ops.AFTER_GEMM = hook
 
     def _ready(self, name):
         if self.grad_ready_hook is not None:
@@ -526,6 +553,8 @@ class VQVAEEngine:
         T = S["T"]
         self._cur_S = S
         new_like = torch.empty_like
+        if self.defer_wgrad and self.wgrad_stream is not None:
+            ops.AFTER_GEMM = self._flush_wgrad
         # ---- dec (Decoder stride 4)
         l6, l4 = L["dec.blocks.6"], L["dec.blocks.4"]
         l6.wgrad(S["w1"], g_dec)
@@ -610,6 +639,9 @@ class VQVAEEngine:
         b2.wgrad(S["a0"], g_a1)
         g_a0 = new_like(S["a0"]); b2.dgrad(g_a1, g_a0, mask=S["a0"])
         b0.wgrad(S["x8"], g_a0)
+        ops.AFTER_GEMM = None
+        if self.wgrad_stream is not None and self._pending_wgrad:
+            self._flush_wgrad(everything=True)
         if self.wgrad_stream is not None:          # join: every filter gradient is in the arena after this
             torch.cuda.current_stream().wait_stream(self.wgrad_stream)
             self._keepalive.clear()

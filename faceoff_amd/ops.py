@@ -233,6 +233,7 @@ def _wino_buffers(nfloats, device):
     return buf
 
 
+AFTER_GEMM = None      # hook called right after a Winograd-domain GEMM launch of a forward / data-gradient pass (engine: deferred wgrads)
 WINO_SPLIT = bool(_os.environ.get("FACEOFF_WINO_SPLIT"))    # off: measured null (see conv3d_winograd)
 _side_streams = {}
 
@@ -317,6 +318,8 @@ def _conv3d_winograd_one(x, U, bias, out, *, T, cin, cout, flags=0, mask=None, a
             prof.begin("wino_gemm" + (f" [F{m} {P}x{N}x{Ht}x{Wt} {cin}->{cout} k{kd}11]" if prof.detail else ""),
                        nominal * (temporal_share(T) if kd > 1 else 1.0), nominal)
         _lib.call("fo_wino_gemm", _ptr(V), _ptr(U), _ptr(M), P, N, T if kd > 1 else 1, Ht * Wt, cin, cout, kd, _stream())
+        if AFTER_GEMM is not None:
+            AFTER_GEMM()
         if prof is not None:
             prof.end()
         per = 0
@@ -383,6 +386,8 @@ def _w42_gemm(V, U, M, rows, K, Nc, label):
         nominal = 2.0 * 25 * rows * K * Nc
         prof.begin("wino_gemm" + (f" [F(4,2) 25x{rows} {K}->{Nc} {label}]" if prof.detail else ""), nominal, nominal)
     _lib.call("fo_wino_gemm", _ptr(V), _ptr(U), _ptr(M), 25, 1, 1, rows, K, Nc, 1, _stream())
+    if AFTER_GEMM is not None:
+        AFTER_GEMM()
     if prof is not None:
         prof.end()
 
