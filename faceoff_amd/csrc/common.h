@@ -10,6 +10,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 void fo_set_error(const char* fmt, ...);
 int fo_cu_count();  // compute units of the current device (cached; 256 on MI355X)
+// conv_img.hip: the 8 -> 64 channel k4 s2 p1 image layer without LDS staging; 0 = launched, 1 = geometry not applicable
+int fo_conv_img_try(const fo_conv_desc* d, const float* in, const float* wp, const float* bias, const float* mask, const float* add,
+                    float* out, hipStream_t stream);
 
 #define FO_CHECK_LAUNCH()                                                     \
   do {                                                                        \

@@ -109,3 +109,31 @@ def test_engine_with_the_stems_on_winograd_equals_the_direct_engine(fixture, gol
     worst = max(((e1.grads[k] - v).abs().max().item() / (v.abs().max().item() + 1e-30), k) for k, v in e0.grads.items())
     print(f"[{fixture}: stems on F(4x4,2x2) vs direct] ReLU-mask flips {flips}, worst gradient rel diff {worst}")
     assert worst[0] <= tol, (worst, flips)
+
+
+@pytest.mark.parametrize("mode", ["forward", "dgrad"])
+def test_image_layer_kernel_vs_torch(mode):
+    """conv_img_kernel (csrc/conv_img.hip: the 8 -> 64 channel k4 s2 p1 layer without LDS staging, taken from 32 768 output
+    pixels up) against torch-CPU, as enc_b.blocks.0 forward (bias + ReLU) and as the data gradient of dec.blocks.6 (ReLU mask +
+    residual)."""
+    from faceoff_amd import ops
+    g = torch.Generator().manual_seed(5)
+    N, H = 3, 256
+    x = torch.zeros((N, 8, H, H))
+    x[:, :6] = torch.randn((N, 6, H, H), generator=g)
+    w = torch.randn((64, 6, 4, 4), generator=g) / np.sqrt(96)
+    b = torch.randn(64, generator=g)
+    ref = torch.nn.functional.conv2d(x[:, :6], w, b if mode == "forward" else None, stride=2, padding=1)
+    mask = add = None
+    if mode == "forward":
+        ref = torch.relu(ref)
+    else:
+        mask = torch.randn(ref.shape, generator=g)
+        add = torch.randn(ref.shape, generator=g)
+        ref = ref * (mask > 0) + add
+    wp = ops.pack_conv(w.cuda())
+    out = torch.empty((N, H // 2, H // 2, 64), device="cuda")
+    ops.conv_igemm(_nhwc(x), wp, b.cuda() if mode == "forward" else None, out, k=(1, 4, 4), stride=2, pad=(0, 1, 1), cin=8, cout=64,
+                   flags=ops.FO_OUT_RELU if mode == "forward" else 0, mask=None if mask is None else _nhwc(mask),
+                   add=None if add is None else _nhwc(add))
+    _close(out.cpu().permute(0, 3, 1, 2), ref, 2e-6)
