@@ -479,16 +479,20 @@ __global__ __launch_bounds__(256) void conv_rgb_bf16_kernel(const ConvArgsH a, i
     }
   };
 
+  // No data-dependent branch in the loop (hipcc otherwise drains every outstanding load, vmcnt(0), in front of each store): blocks
+  // past the end load zeros through out-of-range offsets (load_block's pv) and their stores are dropped the same way.
+  const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (unsigned)(((size_t)(a.M - 1) * d.ldOut + 64) * 2), 0x00020000);
+  const float lo = relu ? 0.f : -__builtin_inff();
   bf16x8 xa[5], xb[5];
-  if (gw < nblocks) load_block(gw, xa);
-  for (int blk = gw; blk < nblocks; blk += 2 * nw) {
+  load_block(gw, xa);
+  const int iters = (nblocks - gw + 2 * nw - 1) / (2 * nw);          // (uniform per wave)
+  for (int itn = 0, blk = gw; itn < iters; ++itn, blk += 2 * nw) {
 #pragma unroll
     for (int phase = 0; phase < 2; ++phase) {
       const int cur = blk + phase * nw;
-      if (cur >= nblocks) break;
       bf16x8 (&xc)[5] = phase ? xb : xa;
       bf16x8 (&xn)[5] = phase ? xa : xb;
-      if (cur + nw < nblocks) load_block(cur + nw, xn);   // next block's fragments fly during this block's MFMAs and stores
+      load_block(cur + nw, xn);                            // next block's fragments fly during this block's MFMAs and stores
       f32x16 acc[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -506,8 +510,8 @@ __global__ __launch_bounds__(256) void conv_rgb_bf16_kernel(const ConvArgsH a, i
         for (int g = 0; g < 4; ++g) {
           const int c0 = i * 32 + 8 * g + 4 * half;
           const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias_s + c0);
-          float v0 = acc[i][4 * g + 0] + b4.x, v1 = acc[i][4 * g + 1] + b4.y, v2 = acc[i][4 * g + 2] + b4.z, v3 = acc[i][4 * g + 3] + b4.w;
-          if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+          const float v0 = fmaxf(acc[i][4 * g + 0] + b4.x, lo), v1 = fmaxf(acc[i][4 * g + 1] + b4.y, lo);
+          const float v2 = fmaxf(acc[i][4 * g + 2] + b4.z, lo), v3 = fmaxf(acc[i][4 * g + 3] + b4.w, lo);
           typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
           bf16x4 o = {(__bf16)v0, (__bf16)v1, (__bf16)v2, (__bf16)v3};
           *reinterpret_cast<bf16x4*>(patch + l31 * PITCH + c0 * 2) = o;
@@ -518,7 +522,7 @@ __global__ __launch_bounds__(256) void conv_rgb_bf16_kernel(const ConvArgsH a, i
         const int pix = it * 8 + (lane >> 3), piece = lane & 7;
         const u32x4 v = *reinterpret_cast<const u32x4*>(patch + pix * PITCH + piece * 16);
         const long long m = (long long)cur * 32 + pix;
-        if (m < a.M) *reinterpret_cast<u32x4*>(out + m * d.ldOut + piece * 8) = v;
+        __builtin_amdgcn_raw_buffer_store_b128(v, rout, m < a.M ? (unsigned)((m * d.ldOut + piece * 8) * 2) : OOB, 0, 0);
       }
     }
   }
