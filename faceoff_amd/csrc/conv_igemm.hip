@@ -485,7 +485,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
       if (m >= a.M) break;
       int n, y, x;
       decode_pixel(a, m, n, y, x);
-      const size_t opix = ((size_t)n * d.Hout + (2 * y + py)) * d.Wout + (2 * x + px);
+      // ophH = 1: cell form (k2 full correlation over an (Hin+1) x (Win+1) grid): the cell's pixels sit one row / column up-left
+      const int oy = 2 * y + py - d.ophH, ox = 2 * x + px - d.ophH;
+      if ((unsigned)oy >= (unsigned)d.Hout || (unsigned)ox >= (unsigned)d.Wout) continue;
+      const size_t opix = ((size_t)n * d.Hout + oy) * d.Wout + ox;
       f32x4 v = *reinterpret_cast<const f32x4*>(Cs + row * C_LD + c4 * 4) + bv;
       if (flags & FO_OUT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
       *reinterpret_cast<f32x4*>(a.out + opix * d.ldOut + c) = v;
@@ -545,8 +548,9 @@ static int fill_args(const fo_conv_desc* d, const float* in, const float* wp, co
   FO_REQUIRE(d->Cin % 4 == 0 && d->ldIn % 4 == 0, FO_E_ALIGN, "conv: Cin/ldIn must be multiples of 4");
   FO_REQUIRE(fo_aligned16(in) && fo_aligned16(wp), FO_E_ALIGN, "conv: in/wp must be 16-byte aligned");
   if (d->flags & FO_DEPTH2SPACE) {
-    FO_REQUIRE(d->Cout == 32 && d->ldOut >= 8 && d->ldOut % 4 == 0 && fo_aligned16(out) && d->Hout == 2 * d->Hm &&
-                   d->Wout == 2 * d->Wm && !(d->flags & (FO_MASK | FO_ADD)) && d->ophW >= 1 && d->ophW <= 8,
+    FO_REQUIRE(d->Cout == 32 && d->ldOut >= 8 && d->ldOut % 4 == 0 && fo_aligned16(out) && (d->ophH == 0 || d->ophH == 1) &&
+                   d->Hout == 2 * (d->Hm - d->ophH) && d->Wout == 2 * (d->Wm - d->ophH) && !(d->flags & (FO_MASK | FO_ADD)) &&
+                   d->ophW >= 1 && d->ophW <= 8,
                FO_E_SHAPE, "conv: FO_DEPTH2SPACE needs Cout == 32 (4 phases x 8), ldOut >= 8, a 2x output grid, no mask/add");
   } else
     FO_REQUIRE(fo_aligned16(out) && d->ldOut % 4 == 0 && d->ldOut >= (d->Cout + 3) / 4 * 4, FO_E_ALIGN,

@@ -133,13 +133,18 @@ def pack_convT(w, out=None):
     return out
 
 
+CONVT_CELLS = not _os.environ.get("FACEOFF_NO_CONVT_CELLS")     # few-channel transposed conv: k2 cell form (K = 4 Ci) instead of 3x3 (9 Ci)
+
+
 def pack_convT_fused(w, out=None):
-    """[Ci][Co<=8][4][4] -> [32 = 4 phases x 8][9][Cipad]: the transposed conv as one 3x3 filter bank (FO_DEPTH2SPACE)"""
+    """[Ci][Co<=8][4][4] -> the transposed conv as one filter bank for FO_DEPTH2SPACE: [32 = 4 phases x 8][4 taps][Cipad] (cell
+    form, default) or [32][9][Cipad] (3x3 form)"""
     Ci, Co = w.shape[:2]
     Cip = pad_in(Ci)
+    taps = 4 if CONVT_CELLS else 9
     if out is None:
-        out = torch.empty(32 * 9 * Cip, device=w.device, dtype=torch.float32)
-    _lib.call("fo_pack_convT_k4s2_fused", _ptr(w), _ptr(out), Ci, Co, Cip, _stream())
+        out = torch.empty(32 * taps * Cip, device=w.device, dtype=torch.float32)
+    _lib.call("fo_pack_convT_k4s2_cells" if CONVT_CELLS else "fo_pack_convT_k4s2_fused", _ptr(w), _ptr(out), Ci, Co, Cip, _stream())
     return out
 
 
@@ -590,6 +595,10 @@ def convT_fused(x, wpf, bias, out, *, cin, cout, flags=0):
     """k4 s2 p1 transposed conv with cout <= 8 as ONE launch: 3x3 conv over the input grid, 32 GEMM columns =
     4 sub-pixel phases x 8 channels, depth-to-space in the epilogue (out: [N, 2H, 2W, >=8])."""
     N, Hi, Wi, _ = x.shape
+    if CONVT_CELLS:      # k2 full correlation over the (Hi+1) x (Wi+1) cell grid; a cell's 4 pixels sit one row / column up-left
+        conv_igemm(x, wpf, bias, out, k=(1, 2, 2), stride=1, pad=(0, 1, 1), cin=cin, cout=32, flags=flags | FO_DEPTH2SPACE,
+                   mgrid=(Hi + 1, Wi + 1), oph=(1, cout))
+        return
     conv_igemm(x, wpf, bias, out, k=(1, 3, 3), stride=1, pad=(0, 1, 1), cin=cin, cout=32, flags=flags | FO_DEPTH2SPACE,
                mgrid=(Hi, Wi), oph=(0, cout))
 

@@ -47,7 +47,8 @@ extern "C" {
 #define FO_DEPTH2SPACE 32 /* fused k4 s2 p1 ConvTranspose2d with few output channels (dec.blocks.6, 64 -> 6, :152): one
                              3x3 conv over the INPUT grid whose 32 GEMM columns are 4 sub-pixel phases x 8 channels
                              (fo_pack_convT_k4s2_fused); column ph*8+c of input pixel (y,x) lands at output pixel
-                             (2y+ph/2, 2x+ph%2), channel c.  desc: Cout=32, Hout=2*Hm, ldOut>=8, ophW = real channels */
+                             (2y+ph/2, 2x+ph%2), channel c.  desc: Cout=32, Hout=2*Hm, ldOut>=8, ophW = real channels; ophH = 1: the cell form
+                             (fo_pack_convT_k4s2_cells), Hout = 2*(Hm-1) */
 
 int fo_version(void);
 const char* fo_last_error(void);
@@ -79,6 +80,10 @@ int fo_pack_convT_k4s2(const float* w, float* wp, int Ci, int Co, int Cipad, int
 /* Same weight, Co <= 8, as ONE 3x3 filter bank for FO_DEPTH2SPACE: wp[32 = 4 phases x 8][9 taps][Cipad], zero where
  * a tap of the 3x3 input neighbourhood does not contribute to a phase (5 of 9 per phase). */
 int fo_pack_convT_k4s2_fused(const float* w, float* wp, int Ci, int Co, int Cipad, void* stream);
+/* The cell form of the same layer (FO_DEPTH2SPACE with desc.ophH = 1): a k2 p1 conv over an (Hin+1) x (Win+1) grid of 2x2-pixel
+ * cells, wp[32 = 4 phases x 8][4 taps][Cipad]; cell (i,j), phase (a,b) lands at output pixel (2i+a-1, 2j+b-1) (the border cells'
+ * outside pixels are dropped).  K = 4 Ci instead of 9 Ci. */
+int fo_pack_convT_k4s2_cells(const float* w, float* wp, int Ci, int Co, int Cipad, void* stream);
 
 /* ---------------------------------------------------------------- convolution (implicit GEMM, fp32 MFMA) */
 typedef struct fo_conv_desc {
