@@ -10,6 +10,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 void fo_set_error(const char* fmt, ...);
 int fo_cu_count();  // compute units of the current device (cached; 256 on MI355X)
+// wgrad_img.hip: the filter gradient of the same layers (pixels as the contraction index, operands straight from global memory)
+int64_t fo_wgrad_img_ws_bytes(const fo_conv_desc* d);
+int fo_wgrad_img_try(const fo_conv_desc* d, const float* P, const float* Q, float* dw, int Areal, int Breal, float* dbias, float* ws,
+                     int64_t ws_bytes, hipStream_t stream);
 // conv_img.hip: the 8 -> 64 channel k4 s2 p1 image layer without LDS staging; 0 = launched, 1 = geometry not applicable
 int fo_conv_img_try(const fo_conv_desc* d, const float* in, const float* wp, const float* bias, const float* mask, const float* add,
                     float* out, hipStream_t stream);

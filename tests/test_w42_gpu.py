@@ -137,3 +137,28 @@ def test_image_layer_kernel_vs_torch(mode):
                    flags=ops.FO_OUT_RELU if mode == "forward" else 0, mask=None if mask is None else _nhwc(mask),
                    add=None if add is None else _nhwc(add))
     _close(out.cpu().permute(0, 3, 1, 2), ref, 2e-6)
+
+
+@pytest.mark.parametrize("kind", ["conv", "convT"])
+def test_image_layer_filter_gradient_vs_torch(kind):
+    """wgrad_img_kernel (csrc/wgrad_img.hip; taken from 262 144 pixels up) against torch-CPU: the filter (and bias) gradient of
+    enc_b.blocks.0 (Conv2d 6 -> 64 k4 s2 p1) and the filter gradient of dec.blocks.6 (ConvTranspose2d 64 -> 6)."""
+    from faceoff_amd import ops
+    g = torch.Generator().manual_seed(11)
+    N, H = 16, 256
+    img = torch.zeros((N, 8, H, H))
+    img[:, :6] = torch.randn((N, 6, H, H), generator=g)
+    feat = torch.randn((N, 64, H // 2, H // 2), generator=g)
+    if kind == "conv":
+        w = torch.zeros((64, 6, 4, 4), requires_grad=True)
+        b = torch.zeros(64, requires_grad=True)
+        torch.nn.functional.conv2d(img[:, :6], w, b, stride=2, padding=1).backward(feat)
+        dw, db = torch.empty((64, 6, 4, 4), device="cuda"), torch.empty(64, device="cuda")
+        ops.conv_wgrad(_nhwc(feat), _nhwc(img), dw, db, k=(1, 4, 4), stride=2, pad=(0, 1, 1), a_real=64, b_real=6)
+        _close(db.cpu(), b.grad, 2e-5)
+    else:
+        w = torch.zeros((64, 6, 4, 4), requires_grad=True)
+        torch.nn.functional.conv_transpose2d(feat, w, None, stride=2, padding=1).backward(img[:, :6])
+        dw = torch.empty((64, 6, 4, 4), device="cuda")
+        ops.conv_wgrad(_nhwc(feat), _nhwc(img), dw, None, k=(1, 4, 4), stride=2, pad=(0, 1, 1), a_real=64, b_real=6)
+    _close(dw.cpu(), w.grad, 2e-5)
