@@ -588,6 +588,8 @@ class VQVAEEngine:
             kb1.wgrad(S["c1"], g_c2, T=T)
             kb1.dgrad(g_c2, g_c1, T=T, mask=S["c1"])
             kb0.wgrad(S["eb"], g_c1, T=T)
+            if self.defer_wgrad and self.wgrad_stream is not None:
+                self._flush_wgrad()       # no GEMM follows on this stream: the chain's last filter gradient must not wait for the end
 
         if self.aux_stream is not None:
             self.aux_stream.wait_stream(torch.cuda.current_stream())
