@@ -56,6 +56,9 @@ __global__ __launch_bounds__(256, 1) void vq_assign_kernel(const float* __restri
     const float* xp = x + (size_t)(valid ? v : 0) * ldx + half;
 #pragma unroll
     for (int s = 0; s < 32; ++s) xr[s] = valid ? xp[2 * s] : 0.f;
+    float xg[32];                                          // the same 32 rows, lane = dimension (for the gather at the end)
+#pragma unroll
+    for (int u = 0; u < 32; ++u) xg[u] = x[(size_t)min<long long>(tile * 32 + u, nvec - 1) * ldx + lane];
     float xh = 0.f;
 #pragma unroll
     for (int s = 0; s < 32; ++s) xh = fmaf(xr[s], xr[s], xh);
@@ -82,25 +85,17 @@ __global__ __launch_bounds__(256, 1) void vq_assign_kernel(const float* __restri
     if (od < best_d || (od == best_d && oi < best_i)) { best_d = od; best_i = oi; }
     if (half == 0 && valid) ind[v] = best_i;
 
-    // gather + straight-through: the wave walks its 32 vectors, 64 lanes = 64 dims; the x rows are
-    // fetched 8 at a time so the (L2-resident) loads overlap instead of serialising on latency
+    // gather + straight-through: the wave walks its 32 vectors, 64 lanes = 64 dims.  The x rows (this layout: lane = dimension)
+    // were requested before the distance loop (xg), so nothing waits on memory here
     const int nhere = (int)min<long long>(32, nvec - tile * 32);
-    for (int j0 = 0; j0 < nhere; j0 += 8) {
-      float xv[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const size_t vj = (size_t)(tile * 32 + min(j0 + u, nhere - 1));
-        xv[u] = x[vj * ldx + lane];
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        if (j0 + u < nhere) {
-          const int idx = __shfl(best_i, j0 + u);
-          const size_t vj = (size_t)(tile * 32 + j0 + u);
-          const float diff = E[idx * VQ_LD + lane] - xv[u];
-          qout[vj * ldq + lane] = xv[u] + diff;  // input + (quantize - input).detach()   (:78)
-          sq = fmaf(diff, diff, sq);
-        }
+    for (int u = 0; u < 32; ++u) {
+      if (u < nhere) {
+        const int idx = __shfl(best_i, u);
+        const size_t vj = (size_t)(tile * 32 + u);
+        const float diff = E[idx * VQ_LD + lane] - xg[u];
+        qout[vj * ldq + lane] = xg[u] + diff;  // input + (quantize - input).detach()   (:78)
+        sq = fmaf(diff, diff, sq);
       }
     }
   }
