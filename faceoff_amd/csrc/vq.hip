@@ -31,25 +31,25 @@ __global__ void vq_prepare_kernel(const float* __restrict__ embed, float* __rest
   enorm[c] = ev + od;
 }
 
-// Persistent: one workgroup per CU keeps the whole codebook (512 x 64, rows padded to 65 floats:
+// Persistent: one workgroup (8 waves, two per SIMD) per CU keeps the whole codebook (512 x 64, rows padded to 65 floats:
 // conflict-free both for the MFMA A-fragment column reads and the row gathers) in LDS and its
-// four waves walk 32-vector tiles independently.  MFMA roles: A = codes (rows), B = vectors
+// waves walk 32-vector tiles independently.  MFMA roles: A = codes (rows), B = vectors
 // (columns), so a lane owns ONE vector and sees 16 codes per 32-code tile in its accumulator:
 // the arg-min is a per-lane scan plus one cross-half exchange.
-__global__ __launch_bounds__(256, 1) void vq_assign_kernel(const float* __restrict__ x, int ldx, long long nvec,
+__global__ __launch_bounds__(512, 1) void vq_assign_kernel(const float* __restrict__ x, int ldx, long long nvec,
                                                            const float* __restrict__ embedT,
                                                            const float* __restrict__ enorm, long long* __restrict__ ind,
                                                            float* __restrict__ qout, int ldq, float* sq_sum) {
   __shared__ float E[VQ_K * VQ_LD + VQ_K];
   float* En = E + VQ_K * VQ_LD;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
-  for (int idx = tid; idx < VQ_K * VQ_D; idx += 256) E[(idx >> 6) * VQ_LD + (idx & 63)] = embedT[idx];
-  for (int idx = tid; idx < VQ_K; idx += 256) En[idx] = enorm[idx];
+  for (int idx = tid; idx < VQ_K * VQ_D; idx += 512) E[(idx >> 6) * VQ_LD + (idx & 63)] = embedT[idx];
+  for (int idx = tid; idx < VQ_K; idx += 512) En[idx] = enorm[idx];
   __syncthreads();
 
   const long long ntiles = (nvec + 31) / 32;
   float sq = 0.f;
-  for (long long tile = (long long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long long)gridDim.x * 4) {
+  for (long long tile = (long long)blockIdx.x * 8 + wave; tile < ntiles; tile += (long long)gridDim.x * 8) {
     const long long v = tile * 32 + l31;
     const bool valid = v < nvec;
     float xr[32];
@@ -217,8 +217,8 @@ int fo_vq_assign(const float* x, int ldx, int64_t nvec, const float* embedT, con
   FO_REQUIRE(nvec > 0 && ldx >= VQ_D && ldq >= VQ_D, FO_E_SHAPE, "vq_assign: bad shape");
   const int cus = fo_cu_count();
   const int64_t ntiles = (nvec + 31) / 32;
-  const int grid = (int)std::min<int64_t>(cus, (ntiles + 3) / 4);
-  hipLaunchKernelGGL(vq_assign_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, (long long)nvec, embedT, enorm,
+  const int grid = (int)std::min<int64_t>(cus, (ntiles + 7) / 8);
+  hipLaunchKernelGGL(vq_assign_kernel, dim3(grid), dim3(512), 0, (hipStream_t)stream, x, ldx, (long long)nvec, embedT, enorm,
                      (long long*)ind, q_ste, ldq, sq_sum);
   FO_CHECK_LAUNCH();
   return FO_OK;
