@@ -409,7 +409,9 @@ def conv_k4s2_winograd(x, U, bias, out, *, cin, cout, flags=0, mask=None, add=No
     K = 4 * cin
     V, M = _wino_buffers((0 if keep_v else 25 * rows * K, 25 * rows * cout), x.device)
     if keep_v:
-        V = torch.empty(25 * rows * K, device=x.device, dtype=torch.float32)
+        # the rows that pad a plane to whole 128-row GEMM tiles must be ZERO in a kept V: the filter gradient contracts over all rows
+        # of the plane (0 x uninitialised memory can be NaN)
+        V = (torch.empty if rows == N * (H // 8) * (W // 8) else torch.zeros)(25 * rows * K, device=x.device, dtype=torch.float32)
     _lib.call("fo_w42_input_cells", _ptr(x), ld_of(x), _ptr(V), N, H, W, cin, C.c_int64(rows), _stream())
     _w42_gemm(V, U, M, rows, K, cout, "conv")
     _lib.call("fo_w42_output", _ptr(M), C.c_int64(rows), _ptr(bias), _ptr(mask), ld_of(mask) if mask is not None else 0, _ptr(add),

@@ -31,6 +31,10 @@ def test_conv_k4s2_winograd_vs_torch(cin, cout, hw, monkeypatch):
     ref = torch.relu(torch.nn.functional.conv2d(x, w, b, stride=2, padding=1))
     assert ops.w42_conv_ok(N, H, W, cin, cout)
     U = ops.w42_filter(w.cuda(), False)
+    # poison the allocator's free blocks: a plane of V is padded to whole 128-row tiles (24 x 6 x 10 = 1440 tiles -> 1536 rows in
+    # the second case) and the filter gradient contracts over the padding rows too -- they must be zero, not whatever torch.empty returns
+    junk = torch.full((96 << 20,), float("nan"), device="cuda")
+    del junk
     out = torch.full((N, H // 2, W // 2, cout + 32), 7.0, device="cuda")
     V = ops.conv_k4s2_winograd(_nhwc(x), U, b.cuda(), out[..., :cout], cin=cin, cout=cout, flags=ops.FO_OUT_RELU, keep_v=True)
     err = _close(out[..., :cout].cpu().permute(0, 3, 1, 2), ref)
