@@ -17,6 +17,8 @@ for (B, T, H, W) in [(8, 5, 256, 256), (32, 5, 128, 128), (3, 3, 256, 192), (1, 
     gt = torch.rand((B * T, 3, H, W), device=dev, generator=g) * 2 - 1
     res = []
     for direct in (False, True):
+        junk = torch.full((1 << 30,), float("nan"), device=dev)       # poison the allocator's free blocks (4 GiB of NaN)
+        del junk
         eng = VQVAEEngine(sd, dev)
         if direct:
             eng.winograd = False
