@@ -553,6 +553,7 @@ class VQVAEEngine:
         T = S["T"]
         self._cur_S = S
         new_like = torch.empty_like
+        self._pending_wgrad.clear()        # (nothing may survive an aborted backward)
         if self.defer_wgrad and self.wgrad_stream is not None:
             ops.AFTER_GEMM = self._flush_wgrad
         # ---- dec (Decoder stride 4)
