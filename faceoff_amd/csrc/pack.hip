@@ -192,6 +192,13 @@ int fo_pack_convT_k4s2_cells(const float* w, float* wp, int Ci, int Co, int Cipa
 int fo_nchw_to_nhwc(const float* x, float* y, int N, int C, int H, int W, int Cpad, int ldy, void* stream) {
   FO_REQUIRE(Cpad >= C && ldy >= Cpad, FO_E_SHAPE, "nchw_to_nhwc: bad channel padding");
   const int HW = H * W;
+  if (Cpad == 8 && ldy == 8 && C <= 8 && fo_aligned16(y)) {   // image tensors: one pixel per lane, no LDS (every access coalesced)
+    const long long npix = (long long)N * HW;
+    hipLaunchKernelGGL(nchw2_to_nhwc8_kernel, dim3(grid_for((size_t)npix)), dim3(256), 0, (hipStream_t)stream, x, (const float*)nullptr, y, C,
+                       0, HW, npix);
+    FO_CHECK_LAUNCH();
+    return FO_OK;
+  }
   hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((HW + 63) / 64, N), dim3(256), 0, (hipStream_t)stream, x, y, C, HW, Cpad, ldy);
   FO_CHECK_LAUNCH();
   return FO_OK;
