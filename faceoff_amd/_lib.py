@@ -77,6 +77,7 @@ SIGNATURES = {
     "fo_vq_gather": (_I, [_P, _P, _P, _I, _L, _P]),
     "fo_mse_slice_fwd": (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _P]),
     "fo_mse_slice_bwd": (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _F, _P, _I, _P]),
+    "fo_mse_slice_fwd_bwd": (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _F, _P, _I, _P, _P]),
     "fo_lpips_prep": (_I, [_P, _I, _I, _P, _I, _I, _I, _P, _P, _P]),
     "fo_lpips_prep_bwd": (_I, [_P, _I, _P, _I, _L, _P, _P, _F, _P]),
     "fo_maxpool2_fwd": (_I, [_P, _P, _I, _I, _I, _I, _P]),

@@ -47,6 +47,27 @@ __global__ void mse_slice_bwd_kernel(const float* __restrict__ dec, int ldd, con
   }
 }
 
+// Both at once (the training step needs the loss value AND its gradient; neither depends on the other): one pass over dec and gt.
+__global__ void mse_slice_fwd_bwd_kernel(const float* __restrict__ dec, int ldd, const float* __restrict__ gt, int HW, long long npix, int C3,
+                                         const float* __restrict__ gscale, float inv_numel, float* __restrict__ gdec, int ldg, float* sum) {
+  const float k = 2.f * inv_numel * gscale[0];
+  float s = 0.f;
+  for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < npix; p += (long long)gridDim.x * blockDim.x) {
+    const long long n = p / HW;
+    const int hw = (int)(p - n * HW);
+    const f32x4 d = *reinterpret_cast<const f32x4*>(dec + p * ldd);
+    const float* g = gt + (n * C3) * (long long)HW + hw;
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      if (c < C3) { const float e = d[c] - g[(long long)c * HW]; s = fmaf(e, e, s); o[c] = k * e; }
+    *reinterpret_cast<f32x4*>(gdec + p * ldg) = o;
+    for (int c = 4; c < ldg; c += 4) *reinterpret_cast<f32x4*>(gdec + p * ldg + c) = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) atomicAdd(sum, s);
+}
+
 // column sums of g[M][ld] (first C channels): stage 1 -> ws[block][C], stage 2 sums blocks in order
 __global__ void colsum_stage1(const float* __restrict__ g, float* __restrict__ ws, long long M, int C, int ld) {
   __shared__ f32x4 red[256];
@@ -148,6 +169,16 @@ int fo_mse_slice_bwd(const float* dec, int ldd, const float* gt_nchw, int N, int
   const long long npix = (long long)N * H * W;
   hipLaunchKernelGGL(mse_slice_bwd_kernel, dim3(grid_for(npix, 4096)), dim3(256), 0, (hipStream_t)stream, dec, ldd, gt_nchw,
                      H * W, npix, C3, gscale, inv_numel, gdec, ldg);
+  FO_CHECK_LAUNCH();
+  return FO_OK;
+}
+
+int fo_mse_slice_fwd_bwd(const float* dec, int ldd, const float* gt_nchw, int N, int H, int W, int C3, const float* gscale,
+                         float inv_numel, float* gdec, int ldg, float* sum, void* stream) {
+  FO_REQUIRE(C3 <= 3 && ldd % 4 == 0 && ldg % 4 == 0, FO_E_SHAPE, "mse: at most 3 channels, ld %% 4 == 0");
+  const long long npix = (long long)N * H * W;
+  hipLaunchKernelGGL(mse_slice_fwd_bwd_kernel, dim3(grid_for(npix, 4096)), dim3(256), 0, (hipStream_t)stream, dec, ldd, gt_nchw, H * W, npix,
+                     C3, gscale, inv_numel, gdec, ldg, sum);
   FO_CHECK_LAUNCH();
   return FO_OK;
 }

@@ -658,10 +658,9 @@ class VQVAEEngine:
         S = self.forward(img_nchw, training=True, T=T)
         dec = S["dec"]
         acc = torch.zeros(1, device=self.device)
-        ops.mse_slice_fwd(dec, gt_nchw, acc)
-        recon = acc / float(gt_nchw.numel())
         one = torch.ones(1, device=self.device)
         g_dec = torch.empty_like(dec)
-        ops.mse_slice_bwd(dec, gt_nchw, one, g_dec)
+        ops.mse_slice_fwd_bwd(dec, gt_nchw, acc, one, g_dec)       # loss value and gradient in one pass over dec and gt
+        recon = acc / float(gt_nchw.numel())
         self.backward(S, g_dec, one * latent_weight)
         return recon, S["diff"], S

@@ -748,6 +748,16 @@ def mse_slice_bwd(dec, gt_nchw, gscale, gdec):
               C.c_float(1.0 / (N * c3 * H * W)), _ptr(gdec), ld_of(gdec), _stream())
 
 
+def mse_slice_fwd_bwd(dec, gt_nchw, acc, gscale, gdec):
+    """sum of squares into acc AND the gradient into gdec, one pass (training step)"""
+    N, H, W, _ = dec.shape
+    gt_nchw = dense_f32(gt_nchw, "ground truth")
+    assert gt_nchw.shape[0] == N and gt_nchw.shape[2:] == (H, W), "ground truth must be [N,C,H,W] like the decoder output"
+    c3 = gt_nchw.shape[1]
+    _lib.call("fo_mse_slice_fwd_bwd", _ptr(dec), ld_of(dec), _ptr(gt_nchw), N, H, W, c3, _ptr(gscale), C.c_float(1.0 / (N * c3 * H * W)),
+              _ptr(gdec), ld_of(gdec), _ptr(acc), _stream())
+
+
 def adam_flat(p, g, m, v, lr, step, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0):
     b1, b2 = betas
     _lib.call("fo_adam_flat", _ptr(p), _ptr(g), _ptr(m), _ptr(v), C.c_int64(p.numel()), C.c_float(lr), C.c_float(b1),

@@ -93,11 +93,10 @@ class FaceOffTrainer:
         S = eng.forward(img, training=True, T=T)
         dec = S["dec"]
         acc = torch.zeros(1, device=eng.device)
-        ops.mse_slice_fwd(dec, ground_truth, acc)
-        recon = acc / float(ground_truth.numel())
         one = torch.ones(1, device=eng.device)
         g_dec = torch.empty_like(dec)
-        ops.mse_slice_bwd(dec, ground_truth, one, g_dec)
+        ops.mse_slice_fwd_bwd(dec, ground_truth, acc, one, g_dec)       # loss value and gradient in one pass over dec and gt
+        recon = acc / float(ground_truth.numel())
         perceptual = torch.zeros(1, device=eng.device)
         if self.vqlpips is not None:
             if taps0 is not None:

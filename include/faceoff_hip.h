@@ -179,6 +179,9 @@ int fo_mse_slice_fwd(const float* dec, int ldd, const float* gt_nchw, int N, int
 /* gdec[n][h][w][c] = c<3 ? gscale * 2 (dec-gt)/numel : 0, for c < ldg  (gscale read from device) */
 int fo_mse_slice_bwd(const float* dec, int ldd, const float* gt_nchw, int N, int H, int W, int C3,
                      const float* gscale, float inv_numel, float* gdec, int ldg, void* stream);
+/* both in one pass over dec and gt (the training step, :37-39 then :100) */
+int fo_mse_slice_fwd_bwd(const float* dec, int ldd, const float* gt_nchw, int N, int H, int W, int C3, const float* gscale,
+                         float inv_numel, float* gdec, int ldg, float* sum, void* stream);
 
 /* ---------------------------------------------------------------- LPIPS / VGG-16 (models/lpips.py:80-161, loss.py:27-33)
  * The 13 VGG convolutions (+ReLU) are fo_conv_igemm launches (first layer: Cin 3 padded to 8, KW padded
