@@ -512,7 +512,7 @@ class VQVAEEngine:
         v1 = self._new(N, h4, w4, 128); S["h_d1"] = self._resblock_fwd("dec.blocks.1", v0, v1, False)
         v2 = self._new(N, h4, w4, 128); S["h_d2"] = self._resblock_fwd("dec.blocks.2", v1, v2, True)
         w1 = self._new(N, 2 * h4, 2 * w4, 64); L["dec.blocks.4"].fwd(v2, w1, flags=FO_OUT_RELU)
-        dec = torch.zeros((N, 4 * h4, 4 * w4, 8), device=self.device); L["dec.blocks.6"].fwd(w1, dec)
+        dec = torch.empty((N, 4 * h4, 4 * w4, 8), device=self.device); L["dec.blocks.6"].fwd(w1, dec)   # (every pixel, all 8 floats, is written)
         S.update(v0=v0, v1=v1, v2=v2, w1=w1, dec=dec)
 
     def forward(self, img_nchw, training=True, T=None):
