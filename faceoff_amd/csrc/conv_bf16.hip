@@ -528,6 +528,89 @@ __global__ __launch_bounds__(256) void conv_rgb_bf16_kernel(const ConvArgsH a, i
   }
 }
 
+// The RGB layer's data gradient (VGG conv1_1 backwards: 64 -> 3 channels, padded to 8).  The tiled kernel spends a 32-column MFMA
+// on 3 columns and re-fetches every gradient pixel nine times (1.1 ms).  Here a workgroup (4 waves, two per CU) walks 64-pixel row segments: the three
+// gradient rows a segment needs (with a one-pixel halo) are DMA'd into LDS once (double-buffered: the next segment's rows fly
+// during this one's MFMAs), all nine taps read their fragments from there, and the contraction runs on v_mfma_f32_16x16x32_bf16
+// with the filter as the ROW operand (16 rows, 3 real; its 18 fragments live in registers) and 16 pixels as columns, so a lane's
+// accumulator is 4 consecutive channels of one pixel: lanes 0-31 store 8 bytes each, 256 contiguous bytes per wave.
+// LDS rows are pixels of 128 B; chunk c of pixel p sits at position c ^ ((p >> 1) & 7) (DMA source side + fragment read).
+__global__ __launch_bounds__(256, 2) void conv_rgb_dgrad_bf16_kernel(const ConvArgsH a, int nseg, int segsPerRow) {
+  constexpr int SEG = 64, PPR = 9, PIECES = 28, ROWPX = PPR * 8;   // 8-pixel pieces per stage: 3 rows x 9 (66 pixels + pad), 4 waves x 7
+  constexpr int STAGE = PIECES * 1024;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const fo_conv_desc& d = a.d;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, quad = lane >> 4;
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in), 0, a.inBytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (unsigned)(((size_t)(a.M - 1) * d.ldOut + 8) * 2), 0x00020000);
+  lds_byte* const lds3 = (lds_byte*)lds;
+  // filter fragments: row (output channel) l15, K-step st = (tap, 32-channel half): k = st*32 + quad*8
+  bf16x8 wf[18];
+#pragma unroll
+  for (int st = 0; st < 18; ++st)
+    wf[st] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(a.wp) + (size_t)l15 * a.Ktot + st * 32 + quad * 8);
+  // DMA roles: piece id = i*8 + wave (i < 7) = LDS row id / 17, pixels 8*(id % 17) .. +7; lane = (pixel % 8, chunk position)
+  int prow[7], ppix[7];
+  unsigned pchunk[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    const int id = i * 4 + wave;
+    prow[i] = id < 3 * PPR ? id / PPR : -1000000;         // the piece past the third row: always out of range (zeros into the padding)
+    ppix[i] = (id % PPR) * 8 + (lane >> 3);
+    pchunk[i] = (unsigned)(((lane & 7) ^ ((ppix[i] >> 1) & 7)) * 16);
+  }
+  auto dma_segment = [&](int seg, int stage) {
+    const int rowid = seg / segsPerRow;                    // (frame, image row), uniform
+    const int xs = (seg - rowid * segsPerRow) * SEG;
+    const int n = rowid / d.Hin, y = rowid - n * d.Hin;
+    const bool sv = seg < nseg;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      const int iy = y - 1 + prow[i], ix = xs - 1 + ppix[i];
+      const bool ok = sv & ((unsigned)iy < (unsigned)d.Hin) & ((unsigned)ix < (unsigned)d.Win);
+      dma16(rin, lds3 + stage * STAGE + (i * 4 + wave) * 1024, ok ? (unsigned)(((n * d.Hin + iy) * d.Win + ix) * 128) + pchunk[i] : OOB);
+    }
+  };
+  // fragment addressing: output pixel of this lane = wave*16 + l15; tap (kh, kw) reads LDS row kh, pixel + kw; chunk h*4 + quad
+  const int px = wave * 16 + l15;
+  int foff[3][2];
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int p = px + kw;
+      foff[kw][h] = p * 128 + (((h * 4 + quad) ^ ((p >> 1) & 7)) * 16);
+    }
+  int seg = blockIdx.x;
+  dma_segment(seg, 0);
+  __syncthreads();
+  for (int it = 0; seg < nseg; seg += gridDim.x, ++it) {
+    const int cur = it & 1;
+    dma_segment(seg + gridDim.x, cur ^ 1);
+    const unsigned char* S = lds + cur * STAGE;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const bf16x8 xf = *reinterpret_cast<const bf16x8*>(S + kh * (ROWPX * 128) + foff[kw][h]);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[(kh * 3 + kw) * 2 + h], xf, acc, 0, 0, 0);
+        }
+    // acc[r] = channel quad*4 + r of pixel px
+    const int rowid = seg / segsPerRow;
+    const long long m = (long long)rowid * d.Win + (seg - rowid * segsPerRow) * SEG + px;
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const bf16x4 o = {(__bf16)acc[0], (__bf16)acc[1], (__bf16)acc[2], (__bf16)acc[3]};
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rout, quad < 2 ? (unsigned)((m * d.ldOut + quad * 4) * 2) : OOB, 0, 0);
+    __syncthreads();                                      // (vmcnt(0): the next segment's rows have landed; this stage is free again)
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ big tiles: LDS-DMA ring + ping-pong
 // 256 x BN output tile (BN = 256 or 128), 8 waves, one workgroup per CU, for the layers with >= 128 output channels and a
 // launch of >= 2-3 rounds of tiles.  What it changes against conv_bf16_kernel above, each measured in one process on one device
@@ -871,6 +954,24 @@ int fo_conv_igemm_bf16(const fo_conv_desc* d, const void* in, const void* wp, co
     const int nblocks = (a.M + 31) / 32;
     const int grid = std::min((nblocks + 3) / 4, fo_cu_count() * 3);
     hipLaunchKernelGGL(conv_rgb_bf16_kernel, dim3(grid), dim3(256), 0, s, a, nblocks);
+    FO_CHECK_LAUNCH();
+    return FO_OK;
+  }
+  if (!smallc && d->Cin == 64 && d->ldIn == 64 && d->Cout <= 8 && d->ldOut == 8 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->ostride == 1 &&
+      d->padH == 1 && d->padW == 1 && d->Hin == d->Hm && d->Win == d->Wm && d->Hm == d->Hout && d->Wm == d->Wout && d->flags == 0 &&
+      d->Win % 64 == 0 && a.M >= 64 * 1024 && !(norgb && atoi(norgb))) {
+    constexpr int ldsBytes = 2 * 28 * 1024;
+    static bool attr_set = false;
+    if (!attr_set) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_rgb_dgrad_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, ldsBytes) !=
+          hipSuccess) {
+        fo_set_error("conv_bf16: cannot reserve %d bytes of LDS", ldsBytes);
+        return FO_E_HIP;
+      }
+      attr_set = true;
+    }
+    const int segsPerRow = d->Win / 64, nseg = d->N * d->Hin * segsPerRow;
+    hipLaunchKernelGGL(conv_rgb_dgrad_bf16_kernel, dim3(std::min(nseg, 2 * fo_cu_count())), dim3(256), ldsBytes, s, a, nseg, segsPerRow);
     FO_CHECK_LAUNCH();
     return FO_OK;
   }

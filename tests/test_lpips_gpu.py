@@ -242,3 +242,28 @@ def test_conv_bf16_dma_kernels_are_deterministic(cin, cout, monkeypatch):
                 noise.mul_(1.0001)
         assert torch.equal(run(), first), r
     torch.cuda.synchronize()
+
+
+def test_rgb_layer_data_gradient_kernel_vs_torch(monkeypatch):
+    """conv_rgb_dgrad_bf16_kernel (VGG conv1_1 backwards, 64 -> 3 channels: gradient rows staged once in LDS for the nine taps;
+    taken from 65 536 pixels and widths that are multiples of 64) against the fp32 convolution of the same bf16 operands and
+    against the tiled kernel it replaces (bit for bit: the same k-ordered MFMA chains)."""
+    from faceoff_amd import ops
+    g = torch.Generator().manual_seed(3)
+    N, H, W = 3, 96, 256
+    gy = torch.randn((N, 64, H, W), generator=g).bfloat16().float()
+    w = (torch.randn((64, 3, 3, 3), generator=g) / 24).bfloat16().float()    # conv1_1 weight [O=64][I=3]
+    ref = torch.nn.functional.conv_transpose2d(gy, w, padding=1)              # d/dx of conv2d(x, w, padding=1)
+    wpd = ops.pack_conv_dgrad_bf16(w.cuda())
+    outs = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("FACEOFF_BF16_NO_RGB", "1")
+        out = torch.full((N, H, W, 8), 7.0, dtype=torch.bfloat16, device="cuda")
+        ops.conv_bf16(gy.permute(0, 2, 3, 1).contiguous().cuda().bfloat16(), wpd, None, out, cin=64, cout=3)
+        outs.append(out)
+    got = outs[0][..., :3].float().cpu().permute(0, 3, 1, 2)
+    tol = 2.0 ** -8 * ref.abs() + 2e-3 * ref.abs().max() / 24 + 1e-6
+    assert ((got - ref).abs() <= tol).all()
+    assert (outs[0][..., 3:] == 0).all()
+    assert torch.equal(outs[0], outs[1])
