@@ -238,6 +238,15 @@ def _wino_buffers(nfloats, device):
     return buf
 
 
+# The Winograd-domain GEMMs on the bf16 matrix pipe (csrc/wino_gemm_split.hip: exact three-way bf16 split of both fp32 operands,
+# six partial products, fp32 accumulation -- fp32 results to the last bit or two at 6/16 of the matrix time) or on the fp32 MFMA.
+BF16X6 = bool(_os.environ.get("FACEOFF_BF16X6"))
+
+
+def wino_gemm_symbol():
+    return "fo_wino_gemm_split" if BF16X6 else "fo_wino_gemm"
+
+
 AFTER_GEMM = None      # hook called right after a Winograd-domain GEMM launch of a forward / data-gradient pass (engine: deferred wgrads)
 WINO_SPLIT = bool(_os.environ.get("FACEOFF_WINO_SPLIT"))    # off: measured null (see conv3d_winograd)
 _side_streams = {}
@@ -322,7 +331,7 @@ def _conv3d_winograd_one(x, U, bias, out, *, T, cin, cout, flags=0, mask=None, a
             nominal = 2.0 * P * N * Ht * Wt * cout * kd * cin
             prof.begin("wino_gemm" + (f" [F{m} {P}x{N}x{Ht}x{Wt} {cin}->{cout} k{kd}11]" if prof.detail else ""),
                        nominal * (temporal_share(T) if kd > 1 else 1.0), nominal)
-        _lib.call("fo_wino_gemm", _ptr(V), _ptr(U), _ptr(M), P, N, T if kd > 1 else 1, Ht * Wt, cin, cout, kd, _stream())
+        _lib.call(wino_gemm_symbol(), _ptr(V), _ptr(U), _ptr(M), P, N, T if kd > 1 else 1, Ht * Wt, cin, cout, kd, _stream())
         if AFTER_GEMM is not None:
             AFTER_GEMM()
         if prof is not None:
@@ -390,7 +399,7 @@ def _w42_gemm(V, U, M, rows, K, Nc, label):
     if prof is not None:
         nominal = 2.0 * 25 * rows * K * Nc
         prof.begin("wino_gemm" + (f" [F(4,2) 25x{rows} {K}->{Nc} {label}]" if prof.detail else ""), nominal, nominal)
-    _lib.call("fo_wino_gemm", _ptr(V), _ptr(U), _ptr(M), 25, 1, 1, rows, K, Nc, 1, _stream())
+    _lib.call(wino_gemm_symbol(), _ptr(V), _ptr(U), _ptr(M), 25, 1, 1, rows, K, Nc, 1, _stream())
     if AFTER_GEMM is not None:
         AFTER_GEMM()
     if prof is not None:

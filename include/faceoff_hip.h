@@ -123,6 +123,11 @@ int fo_conv_igemm_banked(const fo_conv_desc* d, const float* in, const float* wp
  *   M[xi][r][co] = sum_{kd,ci} V[xi][r + (kd - KD/2)*P][ci] * U[xi][co][kd][ci]      r < N*P rows per plane, P rows per frame,
  * depth taps outside a clip of T frames skipped.  V [planes][N*P][Cin], U [planes][Cout][KD][Cin], M [planes][N*P][Cout]. */
 int fo_wino_gemm(const float* V, const float* U, float* M, int planes, int N, int T, int P, int Cin, int Cout, int KD, void* stream);
+/* The same GEMM with every fp32 product formed on the bf16 matrix pipe (csrc/wino_gemm_split.hip): each operand is split
+ * exactly into three bf16 pieces in registers and the six partial products of weight >= 2^-16 are accumulated in fp32 --
+ * relative error 2^-23 per product, i.e. fp32 arithmetic to the last bit or two, at 6/16 of the fp32 MFMA's matrix time.
+ * Same arguments, same constraints, same layouts (all fp32 in memory). */
+int fo_wino_gemm_split(const float* V, const float* U, float* M, int planes, int N, int T, int P, int Cin, int Cout, int KD, void* stream);
 
 /* fo_conv_wgrad for `banks` independent planes of N/banks frames (whole clips each) in one launch: dw receives `banks`
  * consecutive [Areal][Breal][taps] tensors.  Conv3d geometry (KD > 1) only; no bias sum. */
