@@ -74,6 +74,7 @@ def parse_args(argv=None):
                          "the headline metric is config 2, which reports config 3 under the key `c3` anyway")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-c3", action="store_true", help="skip the short config-3 leg")
+    ap.add_argument("--no-x6-leg", action="store_true", help="skip the leg with the Winograd-domain GEMMs on the bf16 matrix pipe")
     ap.add_argument("--no-direct-leg", action="store_true", help="skip the short direct-convolution leg")
     ap.add_argument("--no-c5", action="store_true", help="skip the short config-5 (GAN iteration) leg")
     ap.add_argument("--lpips-dtype", choices=("bf16", "fp32"), default="bf16",
@@ -325,6 +326,23 @@ def main():
                   note="Conv3d and 3x3 128->128 layers on conv_igemm3 / conv_igemm instead of Winograd, same process")
         out["roofline"]["direct_conv"] = dd
         del eng_d, tr_d
+        torch.cuda.empty_cache()
+
+    # ------------------------------------------------------------------ the same step, fp32 products on the bf16 matrix pipe
+    # (opt-in FACEOFF_BF16X6=1; `value` above is the fp32-MFMA path unless that variable is set for the whole run)
+    if winograd_on and not args.no_x6_leg and not args.perceptual and not ops.BF16X6:
+        ops.BF16X6 = True
+        eng_x, tr_x = make_trainer(winograd=True)
+        k_x = max(2, min(args.steps, 5))
+        dt_x, _, (r_x, l_x, _) = timed(tr_x, k_x, 2)
+        ops.BF16X6 = False
+        out["bf16x6"] = {
+            "what": ("the Winograd-domain GEMMs (csrc/wino_gemm_split.hip) form each fp32 product as six bf16 MFMA partial products of "
+                     "an exact three-way bf16 split of both operands, accumulated in fp32: relative error 2^-23 per product "
+                     "(tests/test_split_gpu.py: closer to an fp64 product than the fp32 MFMA kernel). Everything else unchanged."),
+            "value": round(world * frames * k_x / dt_x, 2), "unit": "frames/s", "ms_per_step": round(dt_x / k_x * 1e3, 3), "steps": k_x, "warmup": 2,
+            "loss": {"recon": round(r_x.item(), 6), "latent": round(l_x.item(), 6)}}
+        del eng_x, tr_x
         torch.cuda.empty_cache()
 
     # ------------------------------------------------------------------ BASELINE config 3: + LPIPS in bf16

@@ -51,7 +51,8 @@ SIGNATURES = {
     "fo_resblock_fwd": (_I, [_D, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "fo_conv_igemm_banked": (_I, [_D, _P, _P, _P, _I, _P]),
     "fo_wino_gemm": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
-    "fo_wino_gemm_split": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "fo_wino_gemm_split": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "fo_wino_gemm_split_ws_bytes": (_L, [_I, _I, _I, _I]),
     "fo_wgrad_banked_ws_bytes": (_L, [_D, _I]),
     "fo_conv_wgrad_banked": (_I, [_D, _P, _P, _P, _I, _I, _P, _L, _I, _P]),
     "fo_wino_gradout": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P]),

@@ -243,8 +243,21 @@ def _wino_buffers(nfloats, device):
 BF16X6 = bool(_os.environ.get("FACEOFF_BF16X6"))
 
 
-def wino_gemm_symbol():
-    return "fo_wino_gemm_split" if BF16X6 else "fo_wino_gemm"
+_split_ws = {}
+
+
+def wino_gemm(V, U, M, planes, N, T, P, cin, cout, kd):
+    """The plane-stack GEMM M[xi] = V[xi] (x) U[xi] (csrc/wino_gemm.hip; csrc/wino_gemm_split.hip when BF16X6)."""
+    if not BF16X6:
+        _lib.call("fo_wino_gemm", _ptr(V), _ptr(U), _ptr(M), planes, N, T, P, cin, cout, kd, _stream())
+        return
+    need = 3 * planes * cout * kd * cin                       # bf16 elements: the filter banks as three planes
+    key = (V.device, torch.cuda.current_stream(V.device).cuda_stream)
+    ws = _split_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, device=V.device, dtype=torch.bfloat16)
+        _split_ws[key] = ws
+    _lib.call("fo_wino_gemm_split", _ptr(V), _ptr(U), _ptr(ws), _ptr(M), planes, N, T, P, cin, cout, kd, _stream())
 
 
 AFTER_GEMM = None      # hook called right after a Winograd-domain GEMM launch of a forward / data-gradient pass (engine: deferred wgrads)
@@ -331,7 +344,7 @@ def _conv3d_winograd_one(x, U, bias, out, *, T, cin, cout, flags=0, mask=None, a
             nominal = 2.0 * P * N * Ht * Wt * cout * kd * cin
             prof.begin("wino_gemm" + (f" [F{m} {P}x{N}x{Ht}x{Wt} {cin}->{cout} k{kd}11]" if prof.detail else ""),
                        nominal * (temporal_share(T) if kd > 1 else 1.0), nominal)
-        _lib.call(wino_gemm_symbol(), _ptr(V), _ptr(U), _ptr(M), P, N, T if kd > 1 else 1, Ht * Wt, cin, cout, kd, _stream())
+        wino_gemm(V, U, M, P, N, T if kd > 1 else 1, Ht * Wt, cin, cout, kd)
         if AFTER_GEMM is not None:
             AFTER_GEMM()
         if prof is not None:
@@ -399,7 +412,7 @@ def _w42_gemm(V, U, M, rows, K, Nc, label):
     if prof is not None:
         nominal = 2.0 * 25 * rows * K * Nc
         prof.begin("wino_gemm" + (f" [F(4,2) 25x{rows} {K}->{Nc} {label}]" if prof.detail else ""), nominal, nominal)
-    _lib.call(wino_gemm_symbol(), _ptr(V), _ptr(U), _ptr(M), 25, 1, 1, rows, K, Nc, 1, _stream())
+    wino_gemm(V, U, M, 25, 1, 1, rows, K, Nc, 1)
     if AFTER_GEMM is not None:
         AFTER_GEMM()
     if prof is not None:

@@ -124,10 +124,13 @@ int fo_conv_igemm_banked(const fo_conv_desc* d, const float* in, const float* wp
  * depth taps outside a clip of T frames skipped.  V [planes][N*P][Cin], U [planes][Cout][KD][Cin], M [planes][N*P][Cout]. */
 int fo_wino_gemm(const float* V, const float* U, float* M, int planes, int N, int T, int P, int Cin, int Cout, int KD, void* stream);
 /* The same GEMM with every fp32 product formed on the bf16 matrix pipe (csrc/wino_gemm_split.hip): each operand is split
- * exactly into three bf16 pieces in registers and the six partial products of weight >= 2^-16 are accumulated in fp32 --
- * relative error 2^-23 per product, i.e. fp32 arithmetic to the last bit or two, at 6/16 of the fp32 MFMA's matrix time.
- * Same arguments, same constraints, same layouts (all fp32 in memory). */
-int fo_wino_gemm_split(const float* V, const float* U, float* M, int planes, int N, int T, int P, int Cin, int Cout, int KD, void* stream);
+ * exactly into three bf16 pieces (V in registers, U by a small kernel into the scratch U3) and the six partial products of
+ * weight >= 2^-16 are accumulated in fp32 -- relative error 2^-23 per product, i.e. fp32 arithmetic to the last bit, at 6/16
+ * of the fp32 MFMA's matrix time.  Same arguments, constraints and layouts (all fp32 in memory) plus the scratch:
+ * fo_wino_gemm_split_ws_bytes(planes, Cin, Cout, KD) bytes, 16-byte aligned, private to the stream until the GEMM ends. */
+int64_t fo_wino_gemm_split_ws_bytes(int planes, int Cin, int Cout, int KD);
+int fo_wino_gemm_split(const float* V, const float* U, void* U3, float* M, int planes, int N, int T, int P, int Cin, int Cout, int KD,
+                       void* stream);
 
 /* fo_conv_wgrad for `banks` independent planes of N/banks frames (whole clips each) in one launch: dw receives `banks`
  * consecutive [Areal][Breal][taps] tensors.  Conv3d geometry (KD > 1) only; no bias sum. */

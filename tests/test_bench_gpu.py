@@ -30,6 +30,11 @@ def test_bench_emits_one_valid_json_line():
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     # achieved = algorithmic FLOP per launch / average launch duration
     assert abs(r["achieved"] - r["algorithmic_gflop_per_launch"] / r["avg_launch_ms"]) < 0.02 * r["achieved"]
+    # the opt-in leg with fp32 products on the bf16 matrix pipe: its own step time (its losses are those of its own, fresh
+    # trainer after its own number of steps; tests/test_split_gpu.py compares the two paths on equal inputs)
+    x = d["bf16x6"]
+    assert x["value"] > 0 and abs(x["value"] - 160 / (x["ms_per_step"] * 1e-3)) < 1e-2 * x["value"]
+    assert 0 < x["loss"]["recon"] < 1 and 0 < x["loss"]["latent"] < 1
 
 
 def test_bench_multi_gpu_code_path_with_one_rank():

@@ -5,7 +5,7 @@ mkdir -p gpurun_out/$TAG
 for rep in 1 2; do
   for v in A B; do
     if [ $v = A ]; then E="$A"; else E="$B"; fi
-    env $E python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-c3 --no-c5 --no-direct-leg "$@" > gpurun_out/$TAG/$v$rep.json 2> gpurun_out/$TAG/$v$rep.err
+    env $E python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-c3 --no-c5 --no-direct-leg --no-x6-leg "$@" > gpurun_out/$TAG/$v$rep.json 2> gpurun_out/$TAG/$v$rep.err
     python - gpurun_out/$TAG/$v$rep.json "$v$rep [$E]" <<'PY'
 import json,sys
 d=json.load(open(sys.argv[1]))
