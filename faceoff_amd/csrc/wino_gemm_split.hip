@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_split_kernel(const WGArgs a)
   // ---- loader state (one K-step ahead of the matrix pipe), as in wino_gemm_kernel.  The U planes: 24 wave-DMAs of 16 rows
   // x 64 B per K-step, six per wave -- DMA d = wave * 6 + q is piece d / 8, rows (d % 8) * 16 .. + 15; lane = (row % 16, position)
   unsigned ld_rowoff[4], ld_mask[4], ld_woff[6];
-  int ld_kd = 0, ld_kd_hi = 0, ld_chunk = 0;
+  int ld_kd = 0, ld_seq = 0, ld_left = 0, ld_chunk = 0;   // this depth tap, the taps after it (2 bits each), how many in all
   int fifo_w = 0, fifo_r = 0;
   bool ld_live = true;
 
@@ -162,7 +162,21 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_split_kernel(const WGArgs a)
     int klo = 0, khi = a.KD;
     while (klo < a.KD - 1 && !((any >> klo) & 1)) ++klo;
     while (khi > klo + 1 && !((any >> (khi - 1)) & 1)) --khi;
-    ld_kd = klo; ld_kd_hi = khi; ld_chunk = 0;
+    // The taps in the order kd = (2 - frame + i) mod 3: workgroups on neighbouring frames start together, and in this order
+    // the three of them that read a frame's rows (as its tap 0, 1, 2) do so in the same third of their tiles -- one fetch
+    // from HBM serves all three out of L2 instead of three fetches a third of a tile (~4 MB of traffic per XCD) apart.
+    {
+      const unsigned F0 = a.pShift >= 0 ? (unsigned)row0 >> a.pShift : udiv((unsigned)row0, a.P, a.pMagic);
+      const int c = (a.diag & 16) ? 0 : (int)((5u - (F0 - __umulhi(F0, 0x55555556u) * 3u)) % 3u);
+      int seq = 0, n = 0;
+      for (int i = 0; i < a.KD; ++i) {
+        int kd = c + i;
+        if (kd >= a.KD) kd -= a.KD;
+        if (a.KD == 1) kd = 0;
+        if (kd >= klo && kd < khi) { seq |= kd << (2 * n); ++n; }
+      }
+      ld_kd = seq & 3; ld_seq = seq >> 2; ld_left = n; ld_chunk = 0;
+    }
     if (tid == 0) { fifo[fifo_w & 3][0] = row0; fifo[fifo_w & 3][1] = tile_n; fifo[fifo_w & 3][2] = (khi - klo) * a.cinChunks; }
     ++fifo_w;
   };
@@ -190,12 +204,13 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_split_kernel(const WGArgs a)
     for (int s = 0; s < 4; ++s) ra[set][s] = bufload(rin, (a.diag & 1) ? OOB : (a.diag & 8) ? (a.margin + (ld_rowoff[s] & 0xFFFF0u)) : (((ld_mask[s] >> ld_kd) << 31) | ld_rowoff[s]), (a.diag & 8) ? (soffA & 0xFFF0) : soffA);
     if (++ld_chunk == a.cinChunks) {
       ld_chunk = 0;
-      if (++ld_kd == ld_kd_hi) {
+      if (--ld_left != 0) { ld_kd = ld_seq & 3; ld_seq >>= 2; }
+      else {
         ld_tile += per;
         if (ld_live && ld_tile < hi) setup(ld_tile);
         else {
           ld_live = false;
-          ld_kd = 0; ld_kd_hi = 1 << 30;
+          ld_kd = 0; ld_seq = 0; ld_left = 1 << 30;
 #pragma unroll
           for (int i = 0; i < 4; ++i) { ld_rowoff[i] = OOB; ld_mask[i] = 0; }
 #pragma unroll
@@ -306,6 +321,228 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_split_kernel(const WGArgs a)
   }
 }
 
+// ---------------------------------------------------------------------------------------------------- 256 x 128 tiles
+// One workgroup of eight waves per CU on a 256 x 128 tile (planes that are whole 256-row tiles: every C2 shape).  Against the
+// kernel above: a K-step's U planes serve twice the rows (the L2 -> LDS traffic of the filter banks, the larger of the two
+// operand streams at 6 B per element, halves); V's LDS planes are double-buffered too (144 KB in all), so the split's LDS
+// writes go into the other stage during the MFMAs and a K-step has ONE barrier.
+__global__ __launch_bounds__(512, 1) void wino_gemm_split256_kernel(const WGArgs a) {
+  // two stages of V planes (256 rows), then two stages of U planes (128 rows)
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  __shared__ int fifo[4][4];                 // tiles the loader has entered and the matrix side has not: row0, tile_n, K-steps
+  unsigned char* As0 = lds;
+  constexpr int ASTAGE = 6 * PIECE, BSTAGE = 3 * PIECE, APIECE = 2 * PIECE;
+  unsigned char* Bs0 = lds + 2 * ASTAGE;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, quad = lane >> 4;
+  const int wm = wave >> 1, wn = wave & 1;             // 4 x 2 waves of 64 x 64
+  const int lrow = tid >> 3, lcol = (tid & 7) * 4;      // rows lrow + 64 s
+
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(reinterpret_cast<const char*>(a.V) - a.margin), 0, a.vBytes + a.margin, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rwp = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.U3), 0, a.uBytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(a.M, 0, a.mBytes, 0x00020000);
+
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per = gridDim.x >> 3;
+  const int lo = (int)(((long long)a.tiles * xcd) >> 3), hi = (int)(((long long)a.tiles * (xcd + 1)) >> 3);
+  int ld_tile = lo + slot;
+  if (ld_tile >= hi) return;
+
+  // ---- loader state (one K-step ahead of the matrix pipe), as in wino_gemm_kernel.  The U planes: 24 wave-DMAs of 16 rows
+  // x 64 B per K-step, six per wave -- DMA d = wave * 6 + q is piece d / 8, rows (d % 8) * 16 .. + 15; lane = (row % 16, position)
+  unsigned ld_rowoff[4], ld_mask[4], ld_woff[3];
+  int ld_kd = 0, ld_seq = 0, ld_left = 0, ld_chunk = 0;   // this depth tap, the taps after it (2 bits each), how many in all
+  int fifo_w = 0, fifo_r = 0;
+  bool ld_live = true;
+
+  auto setup = [&](int tile) {
+    const int tile_n = tile % a.tilesN, tile_m = tile / a.tilesN;
+    const int row0 = tile_m * 256;
+    const int plane = (int)udiv((unsigned)tile_m, a.tilesPerPlane, a.planeMagic);
+    const unsigned boff = (unsigned)plane * a.bankBytes;
+    unsigned any = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = row0 + lrow + 64 * i;
+      const unsigned F = a.pShift >= 0 ? (unsigned)r >> a.pShift : udiv((unsigned)r, a.P, a.pMagic);
+      const int t = (int)(F - udiv(F, a.T, a.tMagic) * (unsigned)a.T);
+      unsigned bad = 0;
+      for (int kd = 0; kd < a.KD; ++kd) bad |= ((unsigned)(t + kd - a.padD) < (unsigned)a.T ? 0u : 1u) << kd;
+      ld_mask[i] = bad;
+      ld_rowoff[i] = (unsigned)(r * a.ldV + lcol) * 4u;
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int d = wave * 3 + q, piece = d >> 3, row = (d & 7) * 16 + (lane >> 2);
+      ld_woff[q] = boff + (unsigned)piece * a.pieceBytes + (unsigned)((tile_n * BN + row) * a.Ktot) * 2u + (unsigned)(((lane & 3) ^ swz(row)) << 4);
+    }
+    {
+      const unsigned F0 = a.pShift >= 0 ? (unsigned)row0 >> a.pShift : udiv((unsigned)row0, a.P, a.pMagic);
+      const unsigned F1 = a.pShift >= 0 ? (unsigned)(row0 + 255) >> a.pShift : udiv((unsigned)(row0 + 255), a.P, a.pMagic);
+      if (F1 - F0 > 1) any = (1u << a.KD) - 1;
+      else {
+        const int t0 = (int)(F0 - udiv(F0, a.T, a.tMagic) * (unsigned)a.T), t1 = (int)(F1 - udiv(F1, a.T, a.tMagic) * (unsigned)a.T);
+        for (int kd = 0; kd < a.KD; ++kd)
+          any |= ((((unsigned)(t0 + kd - a.padD) < (unsigned)a.T) | ((unsigned)(t1 + kd - a.padD) < (unsigned)a.T)) ? 1u : 0u) << kd;
+      }
+    }
+    int klo = 0, khi = a.KD;
+    while (klo < a.KD - 1 && !((any >> klo) & 1)) ++klo;
+    while (khi > klo + 1 && !((any >> (khi - 1)) & 1)) --khi;
+    // The taps in the order kd = (2 - frame + i) mod 3: workgroups on neighbouring frames start together, and in this order
+    // the three of them that read a frame's rows (as its tap 0, 1, 2) do so in the same third of their tiles -- one fetch
+    // from HBM serves all three out of L2 instead of three fetches a third of a tile (~4 MB of traffic per XCD) apart.
+    {
+      const unsigned F0 = a.pShift >= 0 ? (unsigned)row0 >> a.pShift : udiv((unsigned)row0, a.P, a.pMagic);
+      const int c = (a.diag & 16) ? 0 : (int)((5u - (F0 - __umulhi(F0, 0x55555556u) * 3u)) % 3u);
+      int seq = 0, n = 0;
+      for (int i = 0; i < a.KD; ++i) {
+        int kd = c + i;
+        if (kd >= a.KD) kd -= a.KD;
+        if (a.KD == 1) kd = 0;
+        if (kd >= klo && kd < khi) { seq |= kd << (2 * n); ++n; }
+      }
+      ld_kd = seq & 3; ld_seq = seq >> 2; ld_left = n; ld_chunk = 0;
+    }
+    if (tid == 0) { fifo[fifo_w & 3][0] = row0; fifo[fifo_w & 3][1] = tile_n; fifo[fifo_w & 3][2] = (khi - klo) * a.cinChunks; }
+    ++fifo_w;
+  };
+
+  // V rows run two K-steps ahead in registers (split during the MFMAs of the step before they are needed), the U planes one
+  // step ahead by DMA: the loader walks at V's pace and hands each step's U offsets to the next call
+  f32x4 ra[2][4];
+  unsigned pb_woff[3];
+  int pb_soff = 0;
+#pragma unroll
+  for (int q = 0; q < 3; ++q) pb_woff[q] = OOB;
+  auto load_step = [&](int set, int stage, bool dma) {
+    if (dma) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const int d = wave * 3 + q;            // (wave-uniform: the LDS address stays scalar)
+        dma16(rwp, (lds_byte*)(Bs0) + stage * BSTAGE + (d >> 3) * PIECE + (d & 7) * (16 * 64), (a.diag & 2) ? OOB : pb_woff[q], pb_soff);
+      }
+    }
+    const int soffA = (ld_kd * a.P * a.ldV + ld_chunk * BK) * 4;
+    pb_soff = (ld_kd * a.cinChunks + ld_chunk) * (BK * 2);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) pb_woff[q] = ld_woff[q];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) ra[set][s] = bufload(rin, (a.diag & 1) ? OOB : (a.diag & 8) ? (a.margin + (ld_rowoff[s] & 0xFFFF0u)) : (((ld_mask[s] >> ld_kd) << 31) | ld_rowoff[s]), (a.diag & 8) ? (soffA & 0xFFF0) : soffA);
+    if (++ld_chunk == a.cinChunks) {
+      ld_chunk = 0;
+      if (--ld_left != 0) { ld_kd = ld_seq & 3; ld_seq >>= 2; }
+      else {
+        ld_tile += per;
+        if (ld_live && ld_tile < hi) setup(ld_tile);
+        else {
+          ld_live = false;
+          ld_kd = 0; ld_seq = 0; ld_left = 1 << 30;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { ld_rowoff[i] = OOB; ld_mask[i] = 0; }
+#pragma unroll
+          for (int q = 0; q < 3; ++q) ld_woff[q] = OOB;
+        }
+      }
+    }
+  };
+  // this thread's 8 bytes (4 k) of rows lrow + 32 s in each plane
+  unsigned wr_off[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int row = lrow + 64 * s;
+    wr_off[s] = (unsigned)(row * 64 + ((((tid & 7) >> 1) ^ swz(row)) << 4) + (tid & 1) * 8);
+  }
+  unsigned pc[4][6];                           // the split of one K-step's rows, waiting for the LDS planes to be free
+  auto split_rows = [&](int set, int s) {
+    split2(ra[set][s][0], ra[set][s][1], pc[s][0], pc[s][2], pc[s][4]);
+    split2(ra[set][s][2], ra[set][s][3], pc[s][1], pc[s][3], pc[s][5]);
+  };
+  auto store_rows = [&](int s, int astage) {
+    unsigned char* A = As0 + astage * ASTAGE + wr_off[s];
+    *reinterpret_cast<u32x2*>(A) = u32x2{pc[s][0], pc[s][1]};
+    *reinterpret_cast<u32x2*>(A + APIECE) = u32x2{pc[s][2], pc[s][3]};
+    *reinterpret_cast<u32x2*>(A + 2 * APIECE) = u32x2{pc[s][4], pc[s][5]};
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment addresses: row (block base + l15), chunk quad
+  const unsigned fr = (unsigned)(l15 * 64 + ((quad ^ swz(l15)) << 4));     // block bases are multiples of 16 rows
+  const unsigned char* Af = As0 + (wm * 64) * 64 + fr;
+  const unsigned char* Bf = Bs0 + (wn * 64) * 64 + fr;
+
+  setup(ld_tile);
+  load_step(0, 0, false);                      // V(0); U(0)'s offsets noted
+  load_step(1, 0, true);                       // U(0) -> stage 0; V(1)
+  __syncthreads();                             // the first tile's FIFO entry; everything above has landed
+  int cur_row0 = fifo[0][0], cur_tn = fifo[0][1], cur_left = fifo[0][2];
+  fifo_r = 1;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) { split_rows(0, s); store_rows(s, 0); }
+  __syncthreads();
+  // one K-step n: `set` = the register set V(n+2) is loaded into (V(n+1) sits in the other), `stage` = the LDS stage of V(n), U(n)
+  auto body = [&](int set, int stage) -> bool {
+    load_step(set, stage ^ 1, true);           // U(n+1) by DMA, then V(n+2)
+    const unsigned char* Aq = Af + stage * ASTAGE;
+    const unsigned char* Bq = Bf + stage * BSTAGE;
+    bf16x8 fa[4][3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) fa[i][p] = *reinterpret_cast<const bf16x8*>(Aq + p * APIECE + i * (16 * 64));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      bf16x8 fb[3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) fb[p] = *reinterpret_cast<const bf16x8*>(Bq + p * PIECE + j * (16 * 64));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[2], fa[i][0], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[0], fa[i][2], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[1], fa[i][1], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[1], fa[i][0], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[0], fa[i][1], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[0], fa[i][0], acc[i][j], 0, 0, 0);
+      split_rows(set ^ 1, j);                  // a quarter of V(n+1): split, and straight into the other stage
+      store_rows(j, stage ^ 1);
+    }
+    const bool tile_end = --cur_left == 0;
+    if (tile_end) {
+      const unsigned voff = (unsigned)((cur_row0 + wm * 64 + l15) * a.ldM + cur_tn * BN + wn * 64 + quad * 4) * 4u;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rout, (a.diag & 4) ? OOB : voff + j * 64, i * 16 * a.ldM * 4, 0);
+          acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      if (fifo_r == fifo_w) return false;      // the loader entered no further tile: that was this workgroup's last
+      cur_row0 = fifo[fifo_r & 3][0]; cur_tn = fifo[fifo_r & 3][1]; cur_left = fifo[fifo_r & 3][2];
+      ++fifo_r;
+      // U(n+1)'s DMAs were issued before V(n+2)'s four loads and the tile's 16 stores: all older than those have landed
+      asm volatile("s_waitcnt vmcnt(20) lgkmcnt(0)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();              // K-step n read by every wave; V(n+1), U(n+1) in place
+    return true;
+  };
+  while (true) {
+    if (!body(0, 0)) break;
+    if (!body(1, 1)) break;
+  }
+}
+
 static unsigned magic_of(unsigned d) { return d <= 1 ? 0u : (unsigned)(((1ull << 32) + d - 1) / d); }
 
 }  // namespace
@@ -352,6 +589,28 @@ extern "C" int fo_wino_gemm_split(const float* V, const float* U, void* U3, floa
   a.vBytes = (unsigned)vBytes; a.uBytes = (unsigned)uBytes; a.mBytes = (unsigned)mBytes;
   a.margin = (unsigned)margin;
   a.diag = getenv("FACEOFF_SPLIT_DIAG") ? atoi(getenv("FACEOFF_SPLIT_DIAG")) : 0;
+  static const bool no256 = getenv("FACEOFF_SPLIT_NO256") != nullptr;
+  if (((long long)N * P) % 256 == 0 && !no256) {           // 256-row tiles, one workgroup of eight waves per CU
+    a.tilesPerPlane = (int)(((long long)N * P) / 256);
+    a.tiles = (int)(rows / 256) * a.tilesN;
+    a.planeMagic = magic_of((unsigned)a.tilesPerPlane);
+    int grid = (fo_cu_count() + 7) / 8 * 8;
+    const int maxUseful = ((a.tiles + 7) / 8) * 8;
+    if (grid > maxUseful) grid = maxUseful;
+    constexpr int ldsBytes = 18 * PIECE;
+    static bool attr256 = false;
+    if (!attr256) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(wino_gemm_split256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, ldsBytes) !=
+          hipSuccess) {
+        fo_set_error("wino_gemm_split: cannot reserve %d bytes of LDS", ldsBytes);
+        return FO_E_HIP;
+      }
+      attr256 = true;
+    }
+    hipLaunchKernelGGL(wino_gemm_split256_kernel, dim3(grid), dim3(512), ldsBytes, (hipStream_t)stream, a);
+    FO_CHECK_LAUNCH();
+    return FO_OK;
+  }
   int grid = 2 * fo_cu_count();
   grid = (grid + 7) / 8 * 8;
   const int maxUseful = ((a.tiles + 7) / 8) * 8;
