@@ -48,7 +48,6 @@ struct WGArgs {
   unsigned pieceBytes;  // bytes of one bf16 bank
   unsigned vBytes, uBytes, mBytes;
   unsigned margin;
-  int diag;
 };
 
 constexpr int BM = 128, BN = 128, BK = 32;
@@ -167,7 +166,7 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_split_kernel(const WGArgs a)
     // from HBM serves all three out of L2 instead of three fetches a third of a tile (~4 MB of traffic per XCD) apart.
     {
       const unsigned F0 = a.pShift >= 0 ? (unsigned)row0 >> a.pShift : udiv((unsigned)row0, a.P, a.pMagic);
-      const int c = (a.diag & 16) ? 0 : (int)((5u - (F0 - __umulhi(F0, 0x55555556u) * 3u)) % 3u);
+      const int c = (int)((5u - (F0 - __umulhi(F0, 0x55555556u) * 3u)) % 3u);
       int seq = 0, n = 0;
       for (int i = 0; i < a.KD; ++i) {
         int kd = c + i;
@@ -193,7 +192,7 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_split_kernel(const WGArgs a)
 #pragma unroll
       for (int q = 0; q < 6; ++q) {
         const int d = wave * 6 + q;            // (wave-uniform: the LDS address stays scalar)
-        dma16(rwp, (lds_byte*)(Bs0) + stage * (3 * PIECE) + (d >> 3) * PIECE + (d & 7) * (16 * 64), (a.diag & 2) ? OOB : pb_woff[q], pb_soff);
+        dma16(rwp, (lds_byte*)(Bs0) + stage * (3 * PIECE) + (d >> 3) * PIECE + (d & 7) * (16 * 64), pb_woff[q], pb_soff);
       }
     }
     const int soffA = (ld_kd * a.P * a.ldV + ld_chunk * BK) * 4;
@@ -201,7 +200,7 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_split_kernel(const WGArgs a)
 #pragma unroll
     for (int q = 0; q < 6; ++q) pb_woff[q] = ld_woff[q];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) ra[set][s] = bufload(rin, (a.diag & 1) ? OOB : (a.diag & 8) ? (a.margin + (ld_rowoff[s] & 0xFFFF0u)) : (((ld_mask[s] >> ld_kd) << 31) | ld_rowoff[s]), (a.diag & 8) ? (soffA & 0xFFF0) : soffA);
+    for (int s = 0; s < 4; ++s) ra[set][s] = bufload(rin, ((ld_mask[s] >> ld_kd) << 31) | ld_rowoff[s], soffA);
     if (++ld_chunk == a.cinChunks) {
       ld_chunk = 0;
       if (--ld_left != 0) { ld_kd = ld_seq & 3; ld_seq >>= 2; }
@@ -299,7 +298,7 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_split_kernel(const WGArgs a)
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rout, (a.diag & 4) ? OOB : voff + j * 64, i * 16 * a.ldM * 4, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rout, voff + j * 64, i * 16 * a.ldM * 4, 0);
           acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
       if (fifo_r == fifo_w) return false;      // the loader entered no further tile: that was this workgroup's last
@@ -395,7 +394,7 @@ __global__ __launch_bounds__(512, 1) void wino_gemm_split256_kernel(const WGArgs
     // from HBM serves all three out of L2 instead of three fetches a third of a tile (~4 MB of traffic per XCD) apart.
     {
       const unsigned F0 = a.pShift >= 0 ? (unsigned)row0 >> a.pShift : udiv((unsigned)row0, a.P, a.pMagic);
-      const int c = (a.diag & 16) ? 0 : (int)((5u - (F0 - __umulhi(F0, 0x55555556u) * 3u)) % 3u);
+      const int c = (int)((5u - (F0 - __umulhi(F0, 0x55555556u) * 3u)) % 3u);
       int seq = 0, n = 0;
       for (int i = 0; i < a.KD; ++i) {
         int kd = c + i;
@@ -421,7 +420,7 @@ __global__ __launch_bounds__(512, 1) void wino_gemm_split256_kernel(const WGArgs
 #pragma unroll
       for (int q = 0; q < 3; ++q) {
         const int d = wave * 3 + q;            // (wave-uniform: the LDS address stays scalar)
-        dma16(rwp, (lds_byte*)(Bs0) + stage * BSTAGE + (d >> 3) * PIECE + (d & 7) * (16 * 64), (a.diag & 2) ? OOB : pb_woff[q], pb_soff);
+        dma16(rwp, (lds_byte*)(Bs0) + stage * BSTAGE + (d >> 3) * PIECE + (d & 7) * (16 * 64), pb_woff[q], pb_soff);
       }
     }
     const int soffA = (ld_kd * a.P * a.ldV + ld_chunk * BK) * 4;
@@ -429,7 +428,7 @@ __global__ __launch_bounds__(512, 1) void wino_gemm_split256_kernel(const WGArgs
 #pragma unroll
     for (int q = 0; q < 3; ++q) pb_woff[q] = ld_woff[q];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) ra[set][s] = bufload(rin, (a.diag & 1) ? OOB : (a.diag & 8) ? (a.margin + (ld_rowoff[s] & 0xFFFF0u)) : (((ld_mask[s] >> ld_kd) << 31) | ld_rowoff[s]), (a.diag & 8) ? (soffA & 0xFFF0) : soffA);
+    for (int s = 0; s < 4; ++s) ra[set][s] = bufload(rin, ((ld_mask[s] >> ld_kd) << 31) | ld_rowoff[s], soffA);
     if (++ld_chunk == a.cinChunks) {
       ld_chunk = 0;
       if (--ld_left != 0) { ld_kd = ld_seq & 3; ld_seq >>= 2; }
@@ -523,7 +522,7 @@ __global__ __launch_bounds__(512, 1) void wino_gemm_split256_kernel(const WGArgs
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rout, (a.diag & 4) ? OOB : voff + j * 64, i * 16 * a.ldM * 4, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rout, voff + j * 64, i * 16 * a.ldM * 4, 0);
           acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
       if (fifo_r == fifo_w) return false;      // the loader entered no further tile: that was this workgroup's last
@@ -588,7 +587,6 @@ extern "C" int fo_wino_gemm_split(const float* V, const float* U, void* U3, floa
   a.bankBytes = (unsigned)bankBytes; a.pieceBytes = (unsigned)pieceBytes;
   a.vBytes = (unsigned)vBytes; a.uBytes = (unsigned)uBytes; a.mBytes = (unsigned)mBytes;
   a.margin = (unsigned)margin;
-  a.diag = getenv("FACEOFF_SPLIT_DIAG") ? atoi(getenv("FACEOFF_SPLIT_DIAG")) : 0;
   static const bool no256 = getenv("FACEOFF_SPLIT_NO256") != nullptr;
   if (((long long)N * P) % 256 == 0 && !no256) {           // 256-row tiles, one workgroup of eight waves per CU
     a.tilesPerPlane = (int)(((long long)N * P) / 256);
