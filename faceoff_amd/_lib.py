@@ -53,6 +53,8 @@ SIGNATURES = {
     "fo_wino_gemm": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "fo_wino_gemm_split": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "fo_wino_gemm_split_ws_bytes": (_L, [_I, _I, _I, _I]),
+    "fo_wino_wgrad_split_ws_bytes": (_L, [_I, _I, _I, _I, _I, _I]),
+    "fo_wino_wgrad_split": (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _P]),
     "fo_wgrad_banked_ws_bytes": (_L, [_D, _I]),
     "fo_conv_wgrad_banked": (_I, [_D, _P, _P, _P, _I, _I, _P, _L, _I, _P]),
     "fo_wino_gradout": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P]),

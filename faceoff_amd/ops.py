@@ -260,6 +260,19 @@ def wino_gemm(V, U, M, planes, N, T, P, cin, cout, kd):
     _lib.call("fo_wino_gemm_split", _ptr(V), _ptr(U), _ptr(ws), _ptr(M), planes, N, T, P, cin, cout, kd, _stream())
 
 
+def wino_wgrad_gemm_split(dM, V, planes, N, T, P, cin, cout, kd):
+    """dU [planes][cout][cin][kd] by csrc/wino_wgrad_split.hip, or None where its shapes do not apply (BF16X6 only)."""
+    if not BF16X6 or _os.environ.get("FACEOFF_NO_WGRAD_SPLIT") or cin % 128 or cout % 128 or (N * P) % 32 or (kd == 3 and P % 32):
+        return None
+    nbytes = _lib.load().fo_wino_wgrad_split_ws_bytes(planes, N, P, cin, cout, kd)
+    if nbytes < 0:
+        return None
+    ws = _workspace(nbytes + planes * cout * cin * kd * 4 + 64, dM.device)
+    dU = ws[(nbytes + 3) // 4 // 4 * 4 + 4:][:planes * cout * cin * kd]
+    _lib.call("fo_wino_wgrad_split", _ptr(dM), _ptr(V), _ptr(dU), _ptr(ws), C.c_int64(nbytes), planes, N, T, P, cin, cout, kd, _stream())
+    return dU
+
+
 AFTER_GEMM = None      # hook called right after a Winograd-domain GEMM launch of a forward / data-gradient pass (engine: deferred wgrads)
 WINO_SPLIT = bool(_os.environ.get("FACEOFF_WINO_SPLIT"))    # off: measured null (see conv3d_winograd)
 _side_streams = {}
@@ -489,7 +502,11 @@ def conv_k4s2_wgrad_winograd(x, g, dw, *, cin, cout, V=None):
     if prof is not None:
         nominal = 2.0 * 25 * rows * cout * K
         prof.begin("conv_wgrad_%dx%d" % (cout, K) + (f" [F(4,2) GEMM 25x{rows}]" if prof.detail else ""), nominal, nominal)
-    _lib.call("fo_conv_wgrad_banked", C.byref(d), _ptr(dM), _ptr(V), _ptr(dU), cout, K, _ptr(ws), C.c_int64(nbytes), 25, _stream())
+    dUs = wino_wgrad_gemm_split(dM, V, 25, 1, 1, rows, K, cout, 1)
+    if dUs is not None:
+        dU = dUs
+    else:
+        _lib.call("fo_conv_wgrad_banked", C.byref(d), _ptr(dM), _ptr(V), _ptr(dU), cout, K, _ptr(ws), C.c_int64(nbytes), 25, _stream())
     if prof is not None:
         prof.end()
     _lib.call("fo_w42_wgrad_out", _ptr(dU), _ptr(dw), cout, cin, _stream())
@@ -531,7 +548,11 @@ def _wgrad_winograd_dU(g, x, *, T, a_real, b_real, V=None, m=2, kd=3, after_grad
         nominal = 2.0 * P * N * Ht * Wt * cout * cin * kd
         prof.begin("conv_wgrad_%dx%d" % (cout, cin) + (f" [winograd F{m} GEMM {P}x{N}x{Ht}x{Wt} k{kd}11]" if prof.detail else ""),
                    nominal * (temporal_share(T) if kd > 1 else 1.0), nominal)
-    _lib.call("fo_conv_wgrad_banked", C.byref(d), _ptr(dM), _ptr(V), _ptr(dU), cout, cin, _ptr(ws), C.c_int64(nbytes), P, _stream())
+    dUs = wino_wgrad_gemm_split(dM, V, P, N, T if kd > 1 else 1, Ht * Wt, cin, cout, kd)
+    if dUs is not None:
+        dU = dUs
+    else:
+        _lib.call("fo_conv_wgrad_banked", C.byref(d), _ptr(dM), _ptr(V), _ptr(dU), cout, cin, _ptr(ws), C.c_int64(nbytes), P, _stream())
     if prof is not None:
         prof.end()
     return dU

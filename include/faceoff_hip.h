@@ -230,6 +230,13 @@ int fo_wino_output(const float* M, const float* bias, const float* mask, int ldM
  * gradient g [N,H,W,ldg]; then dU[xi] = sum_pixels dM[xi] (x) V[xi] shifted by the depth tap -- (m+2)^2 wgrad GEMMs in one
  * fo_conv_wgrad_banked launch ((3,1,1) geometry, planes as banks); then dW[O][I][KD][3][3] = G^T dU G. */
 int fo_wino_gradout(const float* g, int ldg, float* dM, int N, int H, int W, int C, int m, void* stream);
+/* The dU GEMMs above with the fp32 products on the bf16 matrix pipe (csrc/wino_wgrad_split.hip; the arithmetic of
+ * fo_wino_gemm_split): dU[xi][co][ci][kd] = sum_r dM[xi][r][co] * V[xi][r + (kd - KD/2) * P][ci] over the N * P rows of each of
+ * `planes` planes, frames in clips of T.  dM [planes][N*P][Cout], V [planes][N*P][Cin] (dense), dU [planes][Cout][Cin][KD].
+ * Cin % 128 == 0, Cout % 128 == 0, N*P % 32 == 0 (P % 32 == 0 when KD == 3).  ws: fo_wino_wgrad_split_ws_bytes(...) bytes. */
+int64_t fo_wino_wgrad_split_ws_bytes(int planes, int N, int P, int Cin, int Cout, int KD);
+int fo_wino_wgrad_split(const float* dM, const float* V, float* dU, float* ws, int64_t ws_bytes, int planes, int N, int T, int P, int Cin,
+                        int Cout, int KD, void* stream);
 int fo_wino_wgrad_out(const float* dU /* [(m+2)^2][O][I][KD] */, float* dW, int O, int I, int KD, int m, void* stream);
 
 /* ---------------------------------------------------------------- Winograd F(4x4, 2x2) for the k4 s2 p1 stems (csrc/wino42.hip)

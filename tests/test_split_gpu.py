@@ -81,6 +81,8 @@ def split_gemms(monkeypatch):
     def spy(name, *a):
         if name == "fo_wino_gemm_split":
             calls["n"] += 1
+        if name == "fo_wino_wgrad_split":
+            calls["wgrad"] = calls.get("wgrad", 0) + 1
         assert name != "fo_wino_gemm", "the fp32-MFMA GEMM ran although BF16X6 is set"
         return real(name, *a)
     monkeypatch.setattr(_lib, "call", spy)
@@ -139,7 +141,7 @@ def test_c2_step_with_split_gemms_equals_direct_engine_and_is_reproducible(split
     import test_fullsize_gpu as F
     F.test_c2_step_winograd_engine_equals_direct_engine()
     F.test_c2_training_step_is_finite_reproducible_and_updates_everything()
-    assert split_gemms["n"] > 20
+    assert split_gemms["n"] > 20 and split_gemms.get("wgrad", 0) >= 11        # 6 Conv3d + 2 Conv2d 3x3 + 3 stems per backward
 
 
 @pytest.mark.parametrize("cin,cout,hw", [(64, 128, (64, 64)), (32, 128, (48, 80))])
@@ -147,3 +149,48 @@ def test_stem_winograd_vs_torch_with_split_gemms(cin, cout, hw, split_gemms, mon
     import test_w42_gpu as W
     W.test_conv_k4s2_winograd_vs_torch(cin, cout, hw, monkeypatch)
     assert split_gemms["n"] > 0
+
+
+# ---------------------------------------------------------------- the filter-gradient GEMMs (csrc/wino_wgrad_split.hip)
+def _wgrad_ref64(dM, V, planes, N, T, P, cin, cout, kd):
+    A = dM.double().view(planes, N, P, cout)
+    B = V.double().view(planes, N, P, cin)
+    dU = torch.zeros((planes, cout, cin, kd), dtype=torch.float64, device=dM.device)
+    for k in range(kd):
+        s = k - kd // 2
+        for n in range(N):
+            if 0 <= n % T + s < T:
+                dU[..., k] += torch.einsum("xpo,xpc->xoc", A[:, n], B[:, n + s])
+    return dU
+
+
+@pytest.mark.parametrize("planes,N,T,P,cin,cout,kd", [(36, 10, 5, 64, 128, 128, 3), (25, 1, 1, 1152, 256, 128, 1), (5, 6, 3, 32, 128, 256, 3),
+                                                      (4, 7, 1, 96, 128, 128, 1), (2, 160, 5, 256, 128, 128, 3)])      # the last: C2's K
+def test_split_wgrad_gemm_vs_fp64_and_the_fp32_kernel(planes, N, T, P, cin, cout, kd):
+    from faceoff_amd import _lib
+    from faceoff_amd.ops import _desc
+    import ctypes as C
+    g = torch.Generator().manual_seed(planes * 7 + cin)
+    dM = (torch.randn((planes, N * P, cout), generator=g) * torch.exp(2 * torch.randn((planes, N * P, 1), generator=g))).cuda()
+    V = (torch.randn((planes, N * P, cin), generator=g) * torch.exp(torch.randn((planes, N * P, 1), generator=g))).cuda()
+    s = torch.cuda.current_stream().cuda_stream
+    nb = _lib.load().fo_wino_wgrad_split_ws_bytes(planes, N, P, cin, cout, kd)
+    assert nb > 0
+    ws = torch.full((nb // 4,), float("nan"), device="cuda")
+    dU = torch.full((planes, cout, cin, kd), float("nan"), device="cuda")
+    _lib.call("fo_wino_wgrad_split", dM.data_ptr(), V.data_ptr(), dU.data_ptr(), ws.data_ptr(), C.c_int64(nb), planes, N, T, P, cin, cout, kd, s)
+    # the fp32-MFMA kernel on the same operands (the call of ops._wgrad_winograd_dU)
+    d = _desc(N=planes * N, T=T if kd > 1 else 1, Hin=1, Win=P, Hm=1, Wm=P, Hout=1, Wout=P, Cin=cin, Cout=cout, KD=kd, KH=1, KW=1, stride=1,
+              padD=kd // 2, padH=0, padW=0, ostride=1, ophH=0, ophW=0, ldIn=cin, ldOut=cout, ldMask=0, ldAdd=0, flags=0)
+    nb2 = _lib.load().fo_wgrad_banked_ws_bytes(C.byref(d), planes)
+    ws2 = torch.empty(nb2 // 4 + 16, device="cuda")
+    dU2 = torch.full((planes, cout, cin, kd), float("nan"), device="cuda")
+    _lib.call("fo_conv_wgrad_banked", C.byref(d), dM.data_ptr(), V.data_ptr(), dU2.data_ptr(), cout, cin, ws2.data_ptr(), C.c_int64(nb2), planes, s)
+    torch.cuda.synchronize()
+    ref = _wgrad_ref64(dM, V, planes, N, T, P, cin, cout, kd)
+    mag = _wgrad_ref64(dM.abs(), V.abs(), planes, N, T, P, cin, cout, kd) + 1e-300
+    e_split = ((dU.double() - ref).abs() / mag).max().item()
+    e_native = ((dU2.double() - ref).abs() / mag).max().item()
+    print(f"[split wgrad gemm {planes}x{N * P} rows {cout}x{kd * cin}] max err / sum|a||b|: fp32 MFMA {e_native:.2e}, bf16x6 {e_split:.2e}")
+    assert torch.isfinite(dU).all()
+    assert e_split <= 2 * e_native + 1e-9          # (K = N * P rows: the fp32 accumulation error grows with it in both)
