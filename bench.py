@@ -337,9 +337,10 @@ def main():
         dt_x, _, (r_x, l_x, _) = timed(tr_x, k_x, 2)
         ops.BF16X6 = False
         out["bf16x6"] = {
-            "what": ("the Winograd-domain GEMMs (csrc/wino_gemm_split.hip) form each fp32 product as six bf16 MFMA partial products of "
-                     "an exact three-way bf16 split of both operands, accumulated in fp32: relative error 2^-23 per product "
-                     "(tests/test_split_gpu.py: closer to an fp64 product than the fp32 MFMA kernel). Everything else unchanged."),
+            "what": ("the Winograd-domain GEMMs -- forward, data gradient (csrc/wino_gemm_split.hip) and filter gradient "
+                     "(csrc/wino_wgrad_split.hip) -- form each fp32 product as six bf16 MFMA partial products of an exact three-way "
+                     "bf16 split of both operands, accumulated in fp32: relative error 2^-23 per product (tests/test_split_gpu.py: "
+                     "closer to an fp64 product than the fp32 MFMA kernels). Everything else unchanged."),
             "value": round(world * frames * k_x / dt_x, 2), "unit": "frames/s", "ms_per_step": round(dt_x / k_x * 1e3, 3), "steps": k_x, "warmup": 2,
             "loss": {"recon": round(r_x.item(), 6), "latent": round(l_x.item(), 6)}}
         del eng_x, tr_x
