@@ -22,6 +22,7 @@
 //   * frames whose shifted neighbour is outside the clip are skipped whole (a K-step never straddles a frame: P % 32 == 0).
 #include "common.h"
 #include <algorithm>
+#include <stdlib.h>
 
 namespace {
 
@@ -182,6 +183,161 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_split_kernel(const WSArgs a
       for (int r = 0; r < 4; ++r) o[(long long)(i * 16 + kg * 4 + r) * a.Cin + j * 16 + l15] = acc[i][j][r];
 }
 
+// ---------------------------------------------------------------------------------------------------- KD = 3: one pass for the three taps
+// The kernel above run once per depth tap reads every dM row three times and every V row three times (3.4 GB per 64^2 launch at
+// 3.1 TB/s: it is HBM-bound).  Here a workgroup (8 waves: 2 x 4 of 64 x 32) owns the 128 x 128 blocks of ALL THREE taps (96
+// accumulator registers per lane) and walks a clip frame by frame at a fixed 32-row position: step t loads ONE dM tile (frame t)
+// and ONE V tile (frame t + 1), keeps the V tiles of frames t-1, t, t+1 in a ring of three LDS slots, and does the (up to) three
+// products dM[t]^T V[t + kd - 1] -- 10 tile loads per clip position for 13 products instead of 26, three times the MFMAs per split
+// value.  The V tiles form one linear stream over (clip position, frame): tile m lives in slot m % 3, step n reads tiles n-1, n, n+1
+// and prefetches tile n+2 (stored after the step's barrier, into the slot tile n-1 leaves).  120 KB of LDS, one workgroup per CU.
+struct WS3Args {
+  const float* dM;
+  const float* V;
+  float* ws;            // [slabs][planes][3][Cout][Cin]
+  int planes, tilesA, tilesB, slabs;
+  int T, P, chunks;     // clip length, rows per frame, P / 32
+  int units;            // clips * chunks: (clip, 32-row position) pairs per plane
+  int Cin, Cout;
+  long long planeRows;
+};
+
+__global__ __launch_bounds__(512, 1) void wino_wgrad_split3_kernel(const WS3Args a) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[12 * PLANE];    // dM pieces 0..2, then three slots of V pieces 0..2
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wa = wave >> 2, wb = wave & 3;
+  int w = blockIdx.x;
+  const int slab = w % a.slabs; w /= a.slabs;
+  const int tb = w % a.tilesB; w /= a.tilesB;
+  const int ta = w % a.tilesA;
+  const int plane = w / a.tilesA;
+  const int u0 = (int)((long long)a.units * slab / a.slabs), u1 = (int)((long long)a.units * (slab + 1) / a.slabs);
+  const int nsteps = (u1 - u0) * a.T;
+
+  // ---- loader: thread = (row tid >> 4, 4 channels (tid & 15) * 4 + 64 s); linear tile m -> unit u0 + m / T, frame m % T
+  const int lrow = tid >> 4, lcol = (tid & 15) * 4;
+  const float* pA = a.dM + ((long long)plane * a.planeRows + lrow) * a.Cout + ta * 128 + lcol;
+  const float* pB = a.V + ((long long)plane * a.planeRows + lrow) * a.Cin + tb * 128 + lcol;
+  // two cursors over the linear tile stream (unit, frame) -> first row of the tile; advanced one tile at a time (no divisions)
+  struct Cursor { int t, chunk, clip; long long row; };
+  auto cursor_at = [&](int m) {
+    Cursor c;
+    const int u = u0 + m / a.T;
+    c.t = m - (m / a.T) * a.T; c.clip = u / a.chunks; c.chunk = u - c.clip * a.chunks;
+    c.row = (long long)(c.clip * a.T + c.t) * a.P + c.chunk * 32;
+    return c;
+  };
+  auto advance = [&](Cursor& c) {
+    c.row += a.P;
+    if (++c.t == a.T) {
+      c.t = 0;
+      if (++c.chunk == a.chunks) { c.chunk = 0; ++c.clip; }
+      c.row = (long long)c.clip * a.T * a.P + c.chunk * 32;
+    }
+  };
+  f32x4 ra[2], rb[2];
+  auto load_a = [&](const Cursor& c) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) ra[s] = *reinterpret_cast<const f32x4*>(pA + c.row * a.Cout + 64 * s);
+  };
+  auto load_b = [&](const Cursor& c) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) rb[s] = *reinterpret_cast<const f32x4*>(pB + c.row * a.Cin + 64 * s);
+  };
+  const unsigned wr = (unsigned)(lrow * ROWB + ((lcol * 2) ^ (((lrow >> 3) & 1) << 5)));
+  auto store_tile = [&](const f32x4* r, unsigned char* base) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      unsigned q[6];
+      split2(r[s][0], r[s][1], q[0], q[2], q[4]);
+      split2(r[s][2], r[s][3], q[1], q[3], q[5]);
+      unsigned char* d = base + wr + s * 128;
+      *reinterpret_cast<u32x2*>(d) = u32x2{q[0], q[1]};
+      *reinterpret_cast<u32x2*>(d + PLANE) = u32x2{q[2], q[3]};
+      *reinterpret_cast<u32x2*>(d + 2 * PLANE) = u32x2{q[4], q[5]};
+    }
+  };
+  unsigned char* const Bs = lds + 3 * PLANE;
+
+  f32x4 acc[3][4][2];
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[k][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int l15 = lane & 15, kg = lane >> 4;
+  const unsigned fr = (unsigned)((kg * 8 + (l15 >> 2)) * ROWB + (l15 & 3) * 8);
+  const int sw = (kg & 1) << 5;
+  const unsigned char* Af = lds + fr + (wa * 64) * 2;
+  const unsigned char* Bf = Bs + fr + (wb * 32) * 2;
+
+  if (nsteps > 0) {
+    // prologue: dM tile 0, V tiles 0 and 1
+    Cursor ca = cursor_at(0), cb = cursor_at(0);
+    load_a(ca); load_b(cb);
+    store_tile(ra, lds); store_tile(rb, Bs);
+    advance(ca); advance(cb);                              // ca: dM tile 1, cb: V tile 1
+    if (nsteps > 1) { load_b(cb); store_tile(rb, Bs + 3 * PLANE); }
+    advance(cb);                                           // cb: V tile 2
+    __syncthreads();
+    int t = 0, slot = 0;                                   // frame of step n within its clip; n % 3
+    for (int n = 0; n < nsteps; ++n) {
+      if (n + 1 < nsteps) load_a(ca);                      // dM tile n+1, V tile n+2: in flight during the MFMAs
+      if (n + 2 < nsteps) load_b(cb);
+      advance(ca); advance(cb);
+      bf16x8 fa[4][3];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) fa[i][p] = frag_tr(Af + p * PLANE + ((i * 32) ^ sw));
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        if ((unsigned)(t + k - 1) >= (unsigned)a.T) continue;              // the neighbour frame lies outside the clip
+        int sl = slot + k - 1;                                             // slot of V tile n + k - 1
+        sl = sl < 0 ? 2 : (sl > 2 ? 0 : sl);
+        const unsigned char* Bq = Bf + sl * (3 * PLANE);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          bf16x8 fb[3];
+#pragma unroll
+          for (int p = 0; p < 3; ++p) fb[p] = frag_tr(Bq + p * PLANE + ((j * 32) ^ sw));
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[k][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][2], fb[0], acc[k][i][j], 0, 0, 0);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[k][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][0], fb[2], acc[k][i][j], 0, 0, 0);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[k][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][1], fb[1], acc[k][i][j], 0, 0, 0);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[k][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][1], fb[0], acc[k][i][j], 0, 0, 0);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[k][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][0], fb[1], acc[k][i][j], 0, 0, 0);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[k][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][0], fb[0], acc[k][i][j], 0, 0, 0);
+        }
+      }
+      __syncthreads();                                     // every wave has read dM tile n and V tile n-1
+      if (n + 1 < nsteps) store_tile(ra, lds);             // dM tile n+1
+      if (n + 2 < nsteps) store_tile(rb, Bs + (slot == 0 ? 2 : slot - 1) * (3 * PLANE));     // V tile n+2 -> slot (n+2) % 3 = (n-1) % 3
+      __syncthreads();
+      if (++t == a.T) t = 0;
+      slot = slot == 2 ? 0 : slot + 1;
+    }
+  }
+  // ---- partial blocks -> ws[slab][plane][kd][co][ci]
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    float* o = a.ws + ((((long long)slab * a.planes + plane) * 3 + k) * a.Cout + ta * 128 + wa * 64) * a.Cin + tb * 128 + wb * 32;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[(long long)(i * 16 + kg * 4 + r) * a.Cin + j * 16 + l15] = acc[k][i][j][r];
+  }
+}
+
 // dU[plane][co][ci][kd] = sum over the slabs (fixed order) of ws[slab][plane][kd][co][ci]
 __global__ __launch_bounds__(256) void wgrad_split_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dU, int slabs, int planes, int KD,
                                                                  long long cc /* Cout * Cin */) {
@@ -197,17 +353,30 @@ __global__ __launch_bounds__(256) void wgrad_split_reduce_kernel(const float* __
 }
 
 int pick_slabs(int blocks, long long steps) {
-  int s = (2 * fo_cu_count() + blocks - 1) / blocks;
+  int s = 2 * fo_cu_count() / blocks;                      // (one round of workgroups, two per CU)
   const long long cap = std::max<long long>(1, steps / 16);      // at least 16 K-steps per slab
   return (int)std::max<long long>(1, std::min<long long>(s, cap));
 }
 
 }  // namespace
 
+// the one-pass KD = 3 kernel: one workgroup per CU; a slab is a run of (clip, 32-row position) units
+static int pick_slabs3(int blocks, int units) {
+  const int s = fo_cu_count() / blocks;                    // one round of workgroups: a second, nearly empty round would double the time
+  return std::max(1, std::min(s, units));
+}
+static bool use_pass3(int N, int T, int P, int KD) {
+  static const bool off = getenv("FACEOFF_WGRAD_SPLIT_PER_TAP") != nullptr;
+  return KD == 3 && P % 32 == 0 && N % T == 0 && !off;
+}
+
 extern "C" int64_t fo_wino_wgrad_split_ws_bytes(int planes, int N, int P, int Cin, int Cout, int KD) {
   if (planes <= 0 || Cin % 128 || Cout % 128 || ((long long)N * P) % 32) return -1;
   const int blocks = planes * KD * (Cout / 128) * (Cin / 128);
-  return (int64_t)pick_slabs(blocks, (long long)N * P / 32) * planes * KD * Cout * Cin * 4;
+  // (either kernel's slab count: the larger)
+  const int s1 = pick_slabs(blocks, (long long)N * P / 32);
+  const int s3 = KD == 3 && P % 32 == 0 ? pick_slabs3(blocks / KD, (int)((long long)N * P / 32)) : 0;
+  return (int64_t)std::max(s1, s3) * planes * KD * Cout * Cin * 4;
 }
 
 extern "C" int fo_wino_wgrad_split(const float* dM, const float* V, float* dU, float* ws, int64_t ws_bytes, int planes, int N, int T, int P,
@@ -220,6 +389,22 @@ extern "C" int fo_wino_wgrad_split(const float* dM, const float* V, float* dU, f
   FO_REQUIRE(fo_aligned16(dM) && fo_aligned16(V) && fo_aligned16(dU) && fo_aligned16(ws), FO_E_ALIGN, "wino_wgrad_split: 16-byte alignment");
   const int64_t need = fo_wino_wgrad_split_ws_bytes(planes, N, P, Cin, Cout, KD);
   FO_REQUIRE(ws_bytes >= need, FO_E_SHAPE, "wino_wgrad_split: workspace of %lld bytes, %lld needed", (long long)ws_bytes, (long long)need);
+  if (use_pass3(N, T, P, KD)) {
+    WS3Args b;
+    b.dM = dM; b.V = V; b.ws = ws;
+    b.planes = planes; b.tilesA = Cout / 128; b.tilesB = Cin / 128;
+    b.T = T; b.P = P; b.chunks = P / 32; b.units = (N / T) * b.chunks;
+    b.Cin = Cin; b.Cout = Cout; b.planeRows = (long long)N * P;
+    const int blocks3 = planes * b.tilesA * b.tilesB;
+    b.slabs = pick_slabs3(blocks3, b.units);
+    hipLaunchKernelGGL(wino_wgrad_split3_kernel, dim3(blocks3 * b.slabs), dim3(512), 0, (hipStream_t)stream, b);
+    FO_CHECK_LAUNCH();
+    const long long total3 = (long long)planes * KD * Cout * Cin;
+    const int rb3 = (int)std::min<long long>((total3 + 255) / 256, 8LL * fo_cu_count());
+    hipLaunchKernelGGL(wgrad_split_reduce_kernel, dim3(rb3), dim3(256), 0, (hipStream_t)stream, ws, dU, b.slabs, planes, KD, (long long)Cout * Cin);
+    FO_CHECK_LAUNCH();
+    return FO_OK;
+  }
   WSArgs a;
   a.dM = dM; a.V = V; a.ws = ws;
   a.planes = planes; a.KD = KD; a.tilesA = Cout / 128; a.tilesB = Cin / 128;
