@@ -36,7 +36,9 @@ def _ref64(V, U, planes, N, T, P, cin, cout, kd):
 
 
 @pytest.mark.parametrize("planes,N,T,P,cin,cout,kd", [(36, 10, 5, 64, 128, 128, 3), (25, 1, 1, 1152, 256, 128, 1), (36, 6, 3, 64, 64, 256, 3),
-                                                      (4, 8, 1, 16, 96, 128, 1)])
+                                                      (4, 8, 1, 16, 96, 128, 1),
+                                                      (6, 10, 5, 128, 128, 128, 3), (4, 6, 3, 256, 64, 256, 3), (3, 4, 2, 384, 96, 128, 3),
+                                                      (300, 5, 5, 128, 128, 128, 3)])
 def test_split_gemm_is_fp32_accurate(planes, N, T, P, cin, cout, kd):
     g = torch.Generator().manual_seed(planes + cin)
     # wide dynamic range inside a row (Winograd-domain planes differ by orders of magnitude)
@@ -54,8 +56,8 @@ def test_split_gemm_is_fp32_accurate(planes, N, T, P, cin, cout, kd):
     r_split = ((split - ref).abs() / mag).pow(2).mean().sqrt().item()
     print(f"[split gemm {planes}x{N * P}x{kd * cin}->{cout}] max err / sum|v||u|: fp32 MFMA {e_native:.2e}, bf16x6 {e_split:.2e};"
           f" rms {r_native:.2e} vs {r_split:.2e}")
-    assert e_split <= 2.0 ** -21          # a few fp32 roundings (2^-24 each)
-    assert r_split <= 4 * r_native + 1e-9
+    assert e_split <= 1.5 * e_native + 1e-9 and e_split <= 2.0 ** -20          # a few fp32 roundings (2^-24 each)
+    assert r_split <= 1.5 * r_native + 1e-9
 
 
 def test_split_gemm_exact_on_bf16_representable_inputs():
