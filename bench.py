@@ -279,6 +279,9 @@ def main():
     }
     if args.perceptual:
         out["dtype"] = "f32 (VQ-VAE) + %s (LPIPS)" % ("bf16" if args.lpips_dtype == "bf16" else "f32")
+    if ops.BF16X6:       # FACEOFF_BF16X6=1 for the whole run: say so in the line (the default run reports this path as the `bf16x6` leg)
+        out["dtype"] += " [Winograd-domain GEMMs: each fp32 product as 6 bf16 MFMA partial products of an exact 3-way split, fp32 accumulate]"
+        out["config"]["winograd_gemm_arithmetic"] = "bf16x6 (FACEOFF_BF16X6=1)"
     # Speed against an IDEAL direct-convolution implementation (SURVEY 8(d)'s FLOP count at the dense MFMA peak of the
     # type each part runs in).  NOT a roofline fraction: Winograd executes 2.25-4x fewer multiplies on the Conv3d and
     # 3x3 128->128 layers, so this ratio exceeds 1 when the step is faster than any direct convolution could be.
