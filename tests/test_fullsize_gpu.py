@@ -181,13 +181,21 @@ def test_c2_step_winograd_engine_equals_direct_engine():
     flips = 0
     for lvl in "tb":
         bad = (w["id_" + lvl] != d["id_" + lvl]).reshape(-1)
+        if lvl == "b" and flips:
+            # a flipped TOP code (a near-tie, gated above) is decoded into the bottom quantizer's input: around it that input differs
+            # by O(1) between the two engines and the bottom codes with it.  Those positions are not compared (at most a 24 x 24
+            # neighbourhood per flipped top code: dec_t's three 3x3 stages and its stride-2 stem); every other mismatch is gated.
+            moved = (w["qb_in"] - d["qb_in"]).abs().reshape(-1, 64).max(1).values > 1e-3
+            assert int(moved.sum()) <= 24 * 24 * flips, (int(moved.sum()), flips)
+            bad = bad & ~moved
         nbad = int(bad.sum())
         if nbad:
             x = d[f"q{lvl}_in"].reshape(-1, 64)[bad].double()
             e = torch.from_numpy(sd[f"quantize_{lvl}.embed"]).cuda().double()
             dist = x.pow(2).sum(1, keepdim=True) - 2 * x @ e + e.pow(2).sum(0, keepdim=True)
             top2 = torch.topk(-dist, 2, dim=1).values
-            assert ((top2[:, 0] - top2[:, 1]) < 1e-4).all(), f"id_{lvl}: mismatch outside the near-tie gate"
+            margin = (top2[:, 0] - top2[:, 1]).max().item()
+            assert margin < 1e-4, f"id_{lvl}: {nbad} mismatches, one with a top-2 margin of {margin:.3e} (outside the near-tie gate)"
             assert nbad <= 1e-5 * bad.numel() + 2
         flips += nbad
     np.testing.assert_allclose([w["recon"], w["diff"]], [d["recon"], d["diff"]], rtol=1e-5)
