@@ -124,7 +124,6 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_split_kernel(const WGArgs a)
   // x 64 B per K-step, six per wave -- DMA d = wave * 6 + q is piece d / 8, rows (d % 8) * 16 .. + 15; lane = (row % 16, position)
   unsigned ld_rowoff[4], ld_mask[4], ld_woff[6];
   int ld_kd = 0, ld_seq = 0, ld_left = 0, ld_chunk = 0;   // this depth tap, the taps after it (2 bits each), how many in all
-  int ld_c0 = 0;                                           // the K chunk a segment starts at (rotated per tile, see setup)
   int fifo_w = 0, fifo_r = 0;
   bool ld_live = true;
 
@@ -176,9 +175,6 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_split_kernel(const WGArgs a)
         if (kd >= klo && kd < khi) { seq |= kd << (2 * n); ++n; }
       }
       ld_kd = seq & 3; ld_seq = seq >> 2; ld_left = n; ld_chunk = 0;
-      // Neighbouring tiles -- the workgroups of an XCD at any moment -- start their K segments at different 32-channel chunks, so
-      // that they do not all pull the same lines of the filter bank out of L2 at the same time (a line lives in one channel).
-      ld_c0 = tile_m % a.cinChunks;
     }
     if (tid == 0) { fifo[fifo_w & 3][0] = row0; fifo[fifo_w & 3][1] = tile_n; fifo[fifo_w & 3][2] = (khi - klo) * a.cinChunks; }
     ++fifo_w;
@@ -199,10 +195,8 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_split_kernel(const WGArgs a)
         dma16(rwp, (lds_byte*)(Bs0) + stage * (3 * PIECE) + (d >> 3) * PIECE + (d & 7) * (16 * 64), pb_woff[q], pb_soff);
       }
     }
-    int cc = ld_chunk + ld_c0;
-    if (cc >= a.cinChunks) cc -= a.cinChunks;
-    const int soffA = (ld_kd * a.P * a.ldV + cc * BK) * 4;
-    pb_soff = (ld_kd * a.cinChunks + cc) * (BK * 2);
+    const int soffA = (ld_kd * a.P * a.ldV + ld_chunk * BK) * 4;
+    pb_soff = (ld_kd * a.cinChunks + ld_chunk) * (BK * 2);
 #pragma unroll
     for (int q = 0; q < 6; ++q) pb_woff[q] = ld_woff[q];
 #pragma unroll
@@ -358,7 +352,6 @@ __global__ __launch_bounds__(512, 1) void wino_gemm_split256_kernel(const WGArgs
   // x 64 B per K-step, six per wave -- DMA d = wave * 6 + q is piece d / 8, rows (d % 8) * 16 .. + 15; lane = (row % 16, position)
   unsigned ld_rowoff[4], ld_mask[4], ld_woff[3];
   int ld_kd = 0, ld_seq = 0, ld_left = 0, ld_chunk = 0;   // this depth tap, the taps after it (2 bits each), how many in all
-  int ld_c0 = 0;                                           // the K chunk a segment starts at (rotated per tile, see setup)
   int fifo_w = 0, fifo_r = 0;
   bool ld_live = true;
 
@@ -410,9 +403,6 @@ __global__ __launch_bounds__(512, 1) void wino_gemm_split256_kernel(const WGArgs
         if (kd >= klo && kd < khi) { seq |= kd << (2 * n); ++n; }
       }
       ld_kd = seq & 3; ld_seq = seq >> 2; ld_left = n; ld_chunk = 0;
-      // Neighbouring tiles -- the workgroups of an XCD at any moment -- start their K segments at different 32-channel chunks, so
-      // that they do not all pull the same lines of the filter bank out of L2 at the same time (a line lives in one channel).
-      ld_c0 = tile_m % a.cinChunks;
     }
     if (tid == 0) { fifo[fifo_w & 3][0] = row0; fifo[fifo_w & 3][1] = tile_n; fifo[fifo_w & 3][2] = (khi - klo) * a.cinChunks; }
     ++fifo_w;
@@ -433,10 +423,8 @@ __global__ __launch_bounds__(512, 1) void wino_gemm_split256_kernel(const WGArgs
         dma16(rwp, (lds_byte*)(Bs0) + stage * BSTAGE + (d >> 3) * PIECE + (d & 7) * (16 * 64), pb_woff[q], pb_soff);
       }
     }
-    int cc = ld_chunk + ld_c0;
-    if (cc >= a.cinChunks) cc -= a.cinChunks;
-    const int soffA = (ld_kd * a.P * a.ldV + cc * BK) * 4;
-    pb_soff = (ld_kd * a.cinChunks + cc) * (BK * 2);
+    const int soffA = (ld_kd * a.P * a.ldV + ld_chunk * BK) * 4;
+    pb_soff = (ld_kd * a.cinChunks + ld_chunk) * (BK * 2);
 #pragma unroll
     for (int q = 0; q < 3; ++q) pb_woff[q] = ld_woff[q];
 #pragma unroll
