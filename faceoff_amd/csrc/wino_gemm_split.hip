@@ -15,8 +15,8 @@
 //   * the filter banks U are split once per call by a small kernel into three bf16 planes (caller's scratch) and reach LDS by
 //     LDS-DMA, double-buffered: no registers, no vector-ALU work in the GEMM;
 //   * the planes V stay fp32 in HBM (traffic unchanged; the filter-gradient path reads the same tensor): a K-step's rows are
-//     loaded one step ahead into registers, split there (11 VALU instructions per pair of values: 3 packed converts, 4
-//     re-expansions, 4 subtractions) and written to LDS as three bf16 planes.  tools/ubench/mfma_valu_overlap.hip: on gfx950 a
+//     loaded two steps ahead into registers, split there (9 VALU instructions per pair of values: 3 packed converts, 4
+//     re-expansions, 2 packed subtractions) and written to LDS as three bf16 planes.  tools/ubench/mfma_valu_overlap.hip: on gfx950 a
 //     vector-ALU instruction and a bf16 MFMA of the same SIMD never overlap, not even from different waves, so the split is
 //     paid in matrix time (352 cycles against 1536 of MFMA per wave and K-step) -- half of what splitting both operands cost;
 //   * LDS rows are 64 bytes ([piece][row][32 k]), chunk c (8 k) of row r at position c ^ swz(r): conflict-free for the
