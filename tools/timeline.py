@@ -12,7 +12,7 @@ for f in glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
 rows.sort()
-MATRIX = ("wino_gemm", "conv_igemm", "conv_wgrad_kernel", "vq_assign", "conv_gen_kernel", "wgrad_gen_kernel", "conv_bf16", "conv_img_kernel",
+MATRIX = ("wino_gemm", "wino_wgrad_split", "conv_igemm", "conv_wgrad_kernel", "vq_assign", "conv_gen_kernel", "wgrad_gen_kernel", "conv_bf16", "conv_img_kernel",
           "wgrad_img_kernel", "conv_rgb")
 # the last full step: find adam kernels
 adam = [i for i, r in enumerate(rows) if "adam_kernel" in r[2]]
