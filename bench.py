@@ -338,6 +338,18 @@ def main():
         eng_x, tr_x = make_trainer(winograd=True)
         k_x = max(2, min(args.steps, 5))
         dt_x, _, (r_x, l_x, _) = timed(tr_x, k_x, 2)
+        kern_x = None
+        if not args.no_kernel_events:
+            summ_x, _ = per_kernel(eng_x, tr_x, k_x)
+            kern_x = {}
+            for name in ("wino_gemm", "conv_wgrad_128x128"):
+                if name in summ_x:
+                    v = summ_x[name]
+                    # 6 bf16 MFMA FLOP are executed per algorithmic fp32 FLOP: the matrix-pipe roofline of these launches is the bf16 peak
+                    kern_x[name] = {"launches_per_step": v["launches"] / k_x, "avg_ms": round(v["avg_ms"], 4),
+                                    "fp32_equivalent_tflops": round(v["tflops"], 2), "executed_bf16_tflops": round(6 * v["tflops"], 1),
+                                    "peak_bf16_tflops": BF16_MFMA_PEAK_TFLOPS, "frac_of_bf16_peak": round(6 * v["tflops"] / BF16_MFMA_PEAK_TFLOPS, 4),
+                                    "ms_per_step": round(v["total_ms"] / k_x, 3)}
         ops.BF16X6 = False
         out["bf16x6"] = {
             "what": ("the Winograd-domain GEMMs -- forward, data gradient (csrc/wino_gemm_split.hip) and filter gradient "
@@ -346,6 +358,8 @@ def main():
                      "closer to an fp64 product than the fp32 MFMA kernels). Everything else unchanged."),
             "value": round(world * frames * k_x / dt_x, 2), "unit": "frames/s", "ms_per_step": round(dt_x / k_x * 1e3, 3), "steps": k_x, "warmup": 2,
             "loss": {"recon": round(r_x.item(), 6), "latent": round(l_x.item(), 6)}}
+        if kern_x:
+            out["bf16x6"]["kernels"] = kern_x
         del eng_x, tr_x
         torch.cuda.empty_cache()
 
