@@ -57,7 +57,7 @@ def cpu_baseline(T, H, W, steps=20):
     for _ in range(steps):
         O.train_step(img, gt, p, adam_state=st)
     dt = (time.perf_counter() - t0) / steps
-    return {"value": round(T / dt, 3), "unit": "frames/s", "cores": cores, "kind": "port",
+    return {"value": round(T / dt, 3), "unit": "frames/s", "cores": cores, "host_cores": os.cpu_count(), "kind": "port",
             "sample": f"1 clip x {T} frames {H}x{W}, fwd+bwd+Adam, {steps} timed steps (~{dt * steps:.0f} s) after 2 warm-ups, torch-CPU oracle"}
 
 
@@ -191,6 +191,9 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         return t.item()
 
+    def min_over_ranks(x):
+        return -max_over_ranks(-x)
+
     def make_trainer(winograd=True, perceptual=False):
         eng = VQVAEEngine(make_state_dict(0, codebook_scale=0.3, gain=2.0), dev)
         if not winograd:
@@ -210,6 +213,8 @@ def main():
         Returns (seconds for the K steps, HIP-event ms per step on this rank, last losses)."""
         for _ in range(warmup):
             tr.step(img, gt, T=T)
+        if tr.reducer is not None:
+            tr.reducer.time_exposed = True
         sync()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
@@ -219,6 +224,9 @@ def main():
         ev1.record()                      # every side stream is joined into this one at the end of a step
         sync()
         dt = time.perf_counter() - t0
+        if tr.reducer is not None:
+            tr.reducer.time_exposed = False
+        timed.last_dt_this_rank = dt
         return max_over_ranks(dt), ev0.elapsed_time(ev1) / steps, losses
 
     def per_kernel(eng, tr, steps):
@@ -253,6 +261,28 @@ def main():
     # ------------------------------------------------------------------ the timed workload
     eng, trainer = make_trainer(winograd=not args.direct_conv, perceptual=args.perceptual)
     dt, ms_events, (recon, latent, _) = timed(trainer, args.steps, args.warmup)
+    comm = None
+    if ddp:
+        # Self-proving multi-GPU line: how many ranks the process group REALLY had (max-reduced over it), what moved per step,
+        # how much of the gradient all-reduce was left exposed behind backward, and the slowest / fastest rank's step time.
+        red = trainer.reducer
+        ranks = int(max_over_ranks(float(torch.distributed.get_world_size())))
+        exposed = red.exposed_ms() if red is not None else None
+        my_ms = timed.last_dt_this_rank / args.steps * 1e3
+        try:
+            rccl = ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None
+        except Exception:
+            rccl = None
+        desc = red.describe() if red is not None else {"buckets": 0, "bucket_bytes": [], "grad_bytes_per_step": 0}
+        vq_bytes = 2 * (512 + 512 * 64) * 4                       # one fused [512] + [64,512] message per quantiser (:63-64)
+        comm = {"ranks_in_group": ranks, "backend": torch.distributed.get_backend(), "rccl_version": rccl,
+                "collectives_forced_in_one_rank_group": bool(world == 1),
+                "allreduce_bytes_per_step": desc["grad_bytes_per_step"] + vq_bytes,
+                "grad_allreduce_bytes_per_step": desc["grad_bytes_per_step"], "vq_stats_allreduce_bytes_per_step": vq_bytes,
+                "buckets": desc["buckets"], "bucket_bytes": desc["bucket_bytes"],
+                "exposed_ms": None if exposed is None else round(max_over_ranks(exposed), 4),
+                "exposed_ms_what": "HIP events on the compute stream around its wait for the all-reduce side stream in reducer.finish(), mean over the timed steps, max over ranks",
+                "ms_per_step_min_rank": round(min_over_ranks(my_ms), 3), "ms_per_step_max_rank": round(max_over_ranks(my_ms), 3)}
     summ = ms_serial = None
     if not args.no_kernel_events:
         summ, ms_serial = per_kernel(eng, trainer, args.steps)
@@ -277,6 +307,8 @@ def main():
                                         if winograd_on else "direct")},
         "loss": {"recon": round(recon.item(), 6), "latent": round(latent.item(), 6)},
     }
+    if comm is not None:
+        out["comm"] = comm
     if args.perceptual:
         out["dtype"] = "f32 (VQ-VAE) + %s (LPIPS)" % ("bf16" if args.lpips_dtype == "bf16" else "f32")
     if ops.BF16X6:       # FACEOFF_BF16X6=1 for the whole run: say so in the line (the default run reports this path as the `bf16x6` leg)
@@ -310,8 +342,12 @@ def main():
             try:
                 tr_json = json.load(open(pmc))
                 out["roofline"]["traffic"] = tr_json.get(out["roofline"]["kernel"])
+                from faceoff_amd._lib import kernel_source_sha16
+                stamp = tr_json.get("_kernel_source_sha16")
                 out["roofline"]["traffic_source"] = ("HBM bytes per launch from the committed rocprofv3 --pmc passes "
-                                                     f"({tr_json.get('_source', 'profiles/pmc_traffic.json')}), not re-measured in this run")
+                                                     f"({tr_json.get('_source', 'profiles/pmc_traffic.json')}), not re-measured in this run; "
+                                                     f"measured on kernel sources {stamp or 'unstamped (round 2)'}" +
+                                                     (f", this run's sources {kernel_source_sha16()}" if stamp != kernel_source_sha16() else " = this run's sources"))
             except Exception:
                 pass
 

@@ -19,6 +19,20 @@ class FaceoffHipError(RuntimeError):
     pass
 
 
+def kernel_source_sha16():
+    """sha256 (first 16 hex digits) over the kernel sources (csrc/*.hip, *.inc, *.h, *.cpp, sorted by name): what profiles/ stamps
+    a measurement with, so that a committed per-kernel number (profiles/pmc_traffic.json) can be tied to the code it was measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(_HERE, "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".inc", ".h", ".cpp")):
+            h.update(name.encode())
+            with open(os.path.join(d, name), "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 class ConvDesc(C.Structure):
     """Mirror of `fo_conv_desc` (include/faceoff_hip.h)."""
     _fields_ = [(n, C.c_int32) for n in (

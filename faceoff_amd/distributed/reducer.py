@@ -47,6 +47,11 @@ class GradBucketReducer:
         self.cuda = flat_grads.is_cuda
         self.side = torch.cuda.Stream(device=flat_grads.device) if self.cuda and self.active else None
         self.launched = []         # bucket indices in launch order (tests)
+        # bench.py's `comm` block: with time_exposed = True, finish() brackets the main stream's wait for the side stream with HIP
+        # events; their distance is the all-reduce time that backward did NOT cover (from "compute stream reached the join" to "last
+        # bucket summed")
+        self.time_exposed = False
+        self._exposed = []
 
     def layer_done(self, name):
         """grad_ready_hook of the engine: fire the bucket whose last layer just completed."""
@@ -80,7 +85,15 @@ class GradBucketReducer:
             with torch.cuda.stream(self.side):
                 for w in self._works:
                     w.wait()
-            torch.cuda.current_stream().wait_stream(self.side)
+            main = torch.cuda.current_stream()
+            if self.time_exposed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(main)
+                main.wait_stream(self.side)
+                e1.record(main)
+                self._exposed.append((e0, e1))
+            else:
+                main.wait_stream(self.side)
         else:
             for w in self._works:
                 w.wait()
@@ -88,6 +101,23 @@ class GradBucketReducer:
         self.launched = []
         self._pending = [set(ms) for ms in self.members]
         self._events = [[] for _ in self.members]
+
+
+    def exposed_ms(self, reset=True):
+        """Mean per step of the time the compute stream spent waiting for the gradient all-reduces (synchronises); None if
+        nothing was timed."""
+        if not self._exposed:
+            return None
+        torch.cuda.synchronize(self.flat.device)
+        ms = sum(a.elapsed_time(b) for a, b in self._exposed) / len(self._exposed)
+        if reset:
+            self._exposed = []
+        return ms
+
+    def describe(self):
+        """Static facts for bench.py's `comm` block."""
+        return {"buckets": len(self.buckets), "bucket_bytes": [(hi - lo) * 4 for lo, hi, _ in self.buckets],
+                "grad_bytes_per_step": int(self.flat.numel()) * 4}
 
 
 def fused_vq_allreduce(group=None):

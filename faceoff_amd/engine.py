@@ -549,13 +549,25 @@ class VQVAEEngine:
     def backward(self, S, g_dec, g_diff):
         """S: the dict forward() returned.  g_dec NHWC [N,H,W,8] grad wrt dec; g_diff float32[1] device tensor.
         Fills self.grads (flat arena).  Order = reverse forward, so arena slices complete back-to-front."""
+        self._pending_wgrad.clear()        # (nothing may survive an aborted backward)
+        if self.defer_wgrad and self.wgrad_stream is not None:
+            ops.AFTER_GEMM = self._flush_wgrad
+        try:
+            self._backward(S, g_dec, g_diff)
+        finally:
+            # also after an exception: a hook left installed would launch this backward's stale filter gradients from the
+            # next forward's Winograd GEMMs (into the gradient arena, popping from a dead S, firing the DDP hook out of turn)
+            ops.AFTER_GEMM = None
+            self._pending_wgrad.clear()
+            self._keepalive.clear()
+            S.pop("_wino_v", None)
+            self._cur_S = None
+
+    def _backward(self, S, g_dec, g_diff):
         L = self.layers
         T = S["T"]
         self._cur_S = S
         new_like = torch.empty_like
-        self._pending_wgrad.clear()        # (nothing may survive an aborted backward)
-        if self.defer_wgrad and self.wgrad_stream is not None:
-            ops.AFTER_GEMM = self._flush_wgrad
         # ---- dec (Decoder stride 4)
         l6, l4 = L["dec.blocks.6"], L["dec.blocks.4"]
         l6.wgrad(S["w1"], g_dec)
@@ -647,9 +659,6 @@ class VQVAEEngine:
             self._flush_wgrad(everything=True)
         if self.wgrad_stream is not None:          # join: every filter gradient is in the arena after this
             torch.cuda.current_stream().wait_stream(self.wgrad_stream)
-            self._keepalive.clear()
-        S.pop("_wino_v", None)
-        self._cur_S = None
 
     # ------------------------------------------------------------------ fused train step (bench / trainer fast path)
     def loss_and_backward(self, img_nchw, gt_nchw, T=None, latent_weight=1.0):

@@ -89,6 +89,11 @@ class GANTrainer:
         gen_iter = self.iteration % 2 == 0                                    # :338-341
         self.iteration += 1
         N = img.shape[0]
+        # the pairing kernel reads the ground truth through a raw pointer as dense [F,3,H,W] fp32: validate it ONCE here (a strided or
+        # 4-channel tensor would pass the MSE ops, which densify their own copy, and then feed garbage 'real' pairs to both discriminators)
+        ground_truth = ops.dense_f32(ground_truth, "ground truth")
+        if ground_truth.dim() != 4 or ground_truth.shape[1] != 3 or ground_truth.shape[0] != N:
+            raise ValueError(f"ground truth must be [N={N},3,H,W], got {tuple(ground_truth.shape)}")
         c = choices if choices is not None else self.draw(N, gen_iter)
         w, r = self.window, c["random_idx"]
         assert N >= w and 0 <= r <= N - w

@@ -54,6 +54,17 @@ class KernelProfiler:
 PROFILER = None   # set to a KernelProfiler to time conv launches
 
 
+_logged = set()
+
+
+def _log_once(key, msg):
+    """One line on stderr the first time a size-dependent downgrade is taken (never silent, never per step)."""
+    if key not in _logged:
+        _logged.add(key)
+        import sys
+        sys.stderr.write(msg + "\n")
+
+
 def temporal_share(T, kd=3, pad=1):
     """Fraction of a Conv3d's (frame, depth tap) pairs that read a real frame of the clip: (3T-2)/3T for k=3, p=1."""
     valid = sum(1 for t in range(T) for k in range(kd) if 0 <= t + k - pad < T)
@@ -206,8 +217,13 @@ def wino_tile(H, W, N=None):
     """Output-tile size for a Conv3d on HxW frames: 4 (4x fewer MFMA FLOP, fp32 error ~3e-6 of scale) when the plane
     stack can run as ONE banked GEMM launch (a plane's N * H/4 * W/4 rows are whole 128-row GEMM tiles and the 36 planes
     fit the 2 GiB buffer window), else 2 (2.25x fewer, error as the direct convolution), else 0 (odd sizes: direct)."""
-    if H % 4 == 0 and W % 4 == 0 and N is not None and (N * (H // 4) * (W // 4)) % 128 == 0 and 36 * N * (H // 4) * (W // 4) * 128 * 4 < (1 << 31):
-        return 4
+    if H % 4 == 0 and W % 4 == 0 and N is not None and (N * (H // 4) * (W // 4)) % 128 == 0:
+        if 36 * N * (H // 4) * (W // 4) * 128 * 4 < (1 << 31):
+            return 4
+        _log_once(("wino_tile", H, W),
+                  f"faceoff_amd: {N} frames of {H}x{W} latents put the 36 F(4x4,3x3) planes past the 2 GiB buffer-descriptor window; "
+                  f"these layers run as F(2x2,3x3) (2.25x instead of 4x fewer multiplies). Use at most "
+                  f"{((1 << 31) - 1) // (36 * (H // 4) * (W // 4) * 128 * 4)} frames per step at this size to keep F(4x4).")
     return 2 if H % 2 == 0 and W % 2 == 0 else 0
 
 
@@ -274,59 +290,9 @@ def wino_wgrad_gemm_split(dM, V, planes, N, T, P, cin, cout, kd):
 
 
 AFTER_GEMM = None      # hook called right after a Winograd-domain GEMM launch of a forward / data-gradient pass (engine: deferred wgrads)
-WINO_SPLIT = bool(_os.environ.get("FACEOFF_WINO_SPLIT"))    # off: measured null (see conv3d_winograd)
-_side_streams = {}
-
-
-def _side_stream(device):
-    """A helper stream per (device, current stream): the second half-batch of a Winograd convolution runs on it."""
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
-    s = _side_streams.get(key)
-    if s is None:
-        s = _side_streams[key] = torch.cuda.Stream(device=device)
-    return s
-
-
-def _halves_ok(N, T, Ht, Wt):
-    h = N // 2
-    return WINO_SPLIT and PROFILER is None and N % (2 * T) == 0 and (h * Ht * Wt) % 128 == 0 and 36 * h * Ht * Wt >= 128 * 1024   # >= 2 rounds of tiles per half
 
 
 def conv3d_winograd(x, U, bias, out, *, T, cin, cout, flags=0, mask=None, add=None, keep_v=False, m=2, kd=3):
-    """Conv3d k3 p1 s1 (kd=3; or Conv2d 3x3 p1 s1, kd=1, T=1), or its data gradient with the dgrad filter banks, on
-    [N,H,W,C] frames, clips of T frames.
-    keep_v: return the transformed input planes (the filter gradient of the same layer needs exactly them:
-    conv3d_wgrad_winograd(V=...)) instead of using the per-stream scratch.
-
-    The three kernels of one convolution are a chain -- HBM-bound transform, matrix-bound GEMM, HBM-bound transform -- so
-    alone they can only run one after the other.  Large batches are therefore cut into two halves of whole clips that run
-    on two streams, the second started when the first half's input transform is done: its transforms then run beside the
-    first half's GEMM and vice versa.  MEASURED (tools/split_probe.py, tools/ab.sh): a free-running transform beside the
-    GEMM costs 0.01 ms instead of 0.2 (tools/coexist_probe.py), but inside the dependent chain the six shorter launches and
-    two cross-stream hand-offs give most of it back: 1.498 -> 1.468 ms per 64^2 Conv3d, +6 % on the filter-gradient form,
-    nothing on the whole step.  Hence opt-in only (FACEOFF_WINO_SPLIT=1)."""
-    N, H, W, _ = x.shape
-    if not _halves_ok(N, T if kd > 1 else 1, H // m, W // m) or m != 4:
-        return _conv3d_winograd_one(x, U, bias, out, T=T, cin=cin, cout=cout, flags=flags, mask=mask, add=add, keep_v=keep_v, m=m, kd=kd)
-    h = N // 2
-    main, side = torch.cuda.current_stream(), _side_stream(x.device)
-    sl = lambda t, a, b: None if t is None else t[a:b]
-    res = [None, None]
-
-    def second_half():
-        ev = torch.cuda.Event()
-        ev.record(main)
-        side.wait_event(ev)
-        with torch.cuda.stream(side):
-            res[1] = _conv3d_winograd_one(x[h:], U, bias, out[h:], T=T, cin=cin, cout=cout, flags=flags, mask=sl(mask, h, N), add=sl(add, h, N),
-                                          keep_v=keep_v, m=m, kd=kd)
-    res[0] = _conv3d_winograd_one(x[:h], U, bias, out[:h], T=T, cin=cin, cout=cout, flags=flags, mask=sl(mask, 0, h), add=sl(add, 0, h),
-                                  keep_v=keep_v, m=m, kd=kd, after_input=second_half)
-    main.wait_stream(side)
-    return res if keep_v else None
-
-
-def _conv3d_winograd_one(x, U, bias, out, *, T, cin, cout, flags=0, mask=None, add=None, keep_v=False, m=2, kd=3, after_input=None):
     """Conv3d k3 p1 s1 (kd=3; or Conv2d 3x3 p1 s1, kd=1, T=1), or its data gradient with the dgrad filter banks, on
     [N,H,W,C] frames, clips of T frames.
     keep_v: return the transformed input planes in their own tensor (the filter gradient of the same layer needs exactly
@@ -345,14 +311,17 @@ def _conv3d_winograd_one(x, U, bias, out, *, T, cin, cout, flags=0, mask=None, a
     if keep_v:
         V = torch.empty(P * plane_v, device=x.device, dtype=torch.float32)
     _lib.call("fo_wino_input", _ptr(x), ld_of(x), _ptr(V), N, H, W, cin, m, _stream())
-    if after_input is not None:
-        after_input()                 # (the batch-halves pipeline starts its second half here)
     bank = pad_out(cout) * kd * cin                                 # floats per filter bank
     banked = (N * Ht * Wt) % 128 == 0
     per = max(1, min(P, ((1 << 31) - 1) // max(plane_v * 4, plane_m * 4))) if banked else 1   # planes per launch (2 GiB window)
+    # fo_wino_gemm addresses the whole V stack through one buffer descriptor and reaches kd/2 frames past either end of it (those
+    # offsets must still be below 2^31), and the split variant also needs the three bf16 filter-bank pieces inside one window:
+    # the same predicate as the C side (csrc/wino_gemm.hip), so a stack just under 2 GiB takes the banked loop instead of FO_E_SHAPE
+    one_launch = (banked and per == P and P * plane_v * 4 + 2 * (kd // 2) * Ht * Wt * cin * 4 < (1 << 31) and P * plane_m * 4 < (1 << 31)
+                  and (not BF16X6 or 3 * P * pad_out(cout) * kd * cin * 2 < (1 << 31)))
     prof = PROFILER
     # every C2 shape: the whole plane stack as ONE launch of the persistent plane-stack GEMM kernel
-    if banked and per == P and cin >= 64 and cout % 128 == 0 and not _os.environ.get("FACEOFF_NO_WINO_GEMM"):
+    if one_launch and cin >= 64 and cout % 128 == 0 and not _os.environ.get("FACEOFF_NO_WINO_GEMM"):
         if prof is not None:
             nominal = 2.0 * P * N * Ht * Wt * cout * kd * cin
             prof.begin("wino_gemm" + (f" [F{m} {P}x{N}x{Ht}x{Wt} {cin}->{cout} k{kd}11]" if prof.detail else ""),
@@ -519,7 +488,7 @@ def wino_wgrad_ok(H, W, N, T, m=2, kd=3):
             and (m + 2) ** 2 * N * (H // m) * (W // m) * 128 * 4 < (1 << 31))
 
 
-def _wgrad_winograd_dU(g, x, *, T, a_real, b_real, V=None, m=2, kd=3, after_gradout=None):
+def _wgrad_winograd_dU(g, x, *, T, a_real, b_real, V=None, m=2, kd=3):
     """dU[xi][co][ci][kd] = sum over the frames of g / x of dM[xi] (x) V[xi]  (one banked wgrad GEMM launch); returns dU
     (a slice of this stream's workspace)."""
     N, H, W, _ = x.shape
@@ -533,8 +502,6 @@ def _wgrad_winograd_dU(g, x, *, T, a_real, b_real, V=None, m=2, kd=3, after_grad
         V, dM = _wino_buffers((P * plane_v, P * plane_m), x.device)
         _lib.call("fo_wino_input", _ptr(x), ld_of(x), _ptr(V), N, H, W, cin, m, _stream())
     _lib.call("fo_wino_gradout", _ptr(g), ld_of(g), _ptr(dM), N, H, W, cout, m, _stream())
-    if after_gradout is not None:
-        after_gradout()
     d = _desc(N=P * N, T=T if kd > 1 else 1, Hin=1, Win=Ht * Wt, Hm=1, Wm=Ht * Wt, Hout=1, Wout=Ht * Wt, Cin=cin, Cout=cout, KD=kd,
               KH=1, KW=1, stride=1, padD=kd // 2, padH=0, padW=0, ostride=1, ophH=0, ophW=0, ldIn=cin, ldOut=cout, ldMask=0, ldAdd=0,
               flags=0)
@@ -561,29 +528,11 @@ def _wgrad_winograd_dU(g, x, *, T, a_real, b_real, V=None, m=2, kd=3, after_grad
 def conv3d_wgrad_winograd(g, x, dw, dbias, *, T, a_real, b_real, V=None, m=2, kd=3):
     """Filter gradient of a Conv3d k3 p1 in the Winograd domain: dU[xi] = sum dM[xi] (x) V[xi] ((m+2)^2 banked wgrad
     GEMMs with a (3,1,1) geometry), dW = G^T dU G; 2.25x (m=2) / 4x (m=4) fewer MFMA FLOP than the direct form.
-    dbias = column sums of g.  V: the forward's transformed input (a tensor, or the two half-batch tensors the batch-halves
-    pipeline of conv3d_winograd kept: the halves' dU are then computed on two streams and added)."""
+    dbias = column sums of g.  V: the forward's transformed input, if it was kept."""
     N = x.shape[0]
     cin, cout = b_real, a_real
     P = (m + 2) ** 2
-    if isinstance(V, (list, tuple)):
-        h = N // 2
-        main, side = torch.cuda.current_stream(), _side_stream(x.device)
-        res = [None, None]
-
-        def second_half():
-            ev = torch.cuda.Event()
-            ev.record(main)
-            side.wait_event(ev)
-            with torch.cuda.stream(side):
-                res[1] = _wgrad_winograd_dU(g[h:], x[h:], T=T, a_real=a_real, b_real=b_real, V=V[1], m=m, kd=kd)
-        res[0] = _wgrad_winograd_dU(g[:h], x[:h], T=T, a_real=a_real, b_real=b_real, V=V[0], m=m, kd=kd, after_gradout=second_half)
-        main.wait_stream(side)
-        dU = res[0]
-        n = dU.numel()
-        _lib.call("fo_add", _ptr(dU), n, _ptr(res[1]), n, _ptr(dU), n, C.c_int64(1), n, _stream())
-    else:
-        dU = _wgrad_winograd_dU(g, x, T=T, a_real=a_real, b_real=b_real, V=V, m=m, kd=kd)
+    dU = _wgrad_winograd_dU(g, x, T=T, a_real=a_real, b_real=b_real, V=V, m=m, kd=kd)
     _lib.call("fo_wino_wgrad_out", _ptr(dU), _ptr(dw), cout, cin, kd, m, _stream())
     if dbias is not None:
         bias_grad(g, dbias, cout)

@@ -122,6 +122,10 @@ def main():
                          f"{fmt(rd/1e6 if rd is not None else None, '{:.1f}')} | {fmt(wrb/1e6 if wrb is not None else None, '{:.1f}')} | "
                          f"{fmt(hit/(hit+miss) if hit is not None and miss is not None and hit+miss > 0 else None)} |\n")
         traffic["_source"] = f"profiles/{tag}_pmc.md"
+        # tie the numbers to the kernel sources they were measured on (the GPU box has no .git): bench.py compares this with the tree it runs
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from faceoff_amd._lib import kernel_source_sha16
+        traffic["_kernel_source_sha16"] = kernel_source_sha16()
         with open(os.path.join(out, "pmc_traffic.json"), "w") as fh:
             json.dump(traffic, fh, indent=1)
     print("summaries written to", out)

@@ -48,6 +48,14 @@ def test_bench_multi_gpu_code_path_with_one_rank():
     assert len(lines) == 1, lines
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["parallelism"] == "dp1"
+    # the self-proving `comm` block: ranks the group really had, bytes moved, buckets, exposed all-reduce time, per-rank spread
+    c = d["comm"]
+    assert c["ranks_in_group"] == 1 and c["backend"] == "nccl" and c["rccl_version"] and c["collectives_forced_in_one_rank_group"] is True
+    assert c["grad_allreduce_bytes_per_step"] == 4 * 4050040 and c["vq_stats_allreduce_bytes_per_step"] == 2 * (512 + 512 * 64) * 4
+    assert c["allreduce_bytes_per_step"] == c["grad_allreduce_bytes_per_step"] + c["vq_stats_allreduce_bytes_per_step"]
+    assert c["buckets"] == len(c["bucket_bytes"]) >= 3 and sum(c["bucket_bytes"]) == c["grad_allreduce_bytes_per_step"]
+    assert c["exposed_ms"] is not None and 0 <= c["exposed_ms"] < d["ms_per_step"]
+    assert c["ms_per_step_min_rank"] <= c["ms_per_step_max_rank"] and abs(c["ms_per_step_max_rank"] - d["ms_per_step"]) < 1e-2 * d["ms_per_step"]
 
 
 def test_bench_two_rank_control_flow_on_one_gpu():
@@ -70,4 +78,6 @@ def test_bench_two_rank_control_flow_on_one_gpu():
     assert len(lines0) == 1 and not outs[1][0].strip(), (lines0, outs[1][0][-300:])
     d = json.loads(lines0[0])
     assert d["config"]["global_clips"] == 16 and d["config"]["frames_per_step"] == 80 and "c3" in d and "c5" in d and "direct_conv" in d["roofline"]
+    assert d["comm"]["ranks_in_group"] == 2 and d["comm"]["backend"] == "gloo" and d["comm"]["collectives_forced_in_one_rank_group"] is False
+    assert d["comm"]["exposed_ms"] is not None and d["comm"]["ms_per_step_min_rank"] <= d["comm"]["ms_per_step_max_rank"]
     assert abs(d["value"] - 80 / (d["ms_per_step"] * 1e-3)) < 1e-2 * d["value"]

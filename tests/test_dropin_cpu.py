@@ -35,3 +35,36 @@ print("IMPORTS_OK")
     # a fresh interpreter started OUTSIDE the repository, so only the sys.path line makes the names resolvable
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd="/tmp")
     assert out.returncode == 0 and "IMPORTS_OK" in out.stdout, out.stderr[-2000:]
+
+
+def test_utils_shim_exports_every_name_the_reference_utils_defines(tmp_path):
+    """`from utils import *` (train_faceoff_perceptual.py:17) must hand the trainers every function utils.py defines:
+    validation() calls save_frames_as_video at its first clip (:79), the disc trainers call save_image."""
+    names = ["save_frames_as_video", "save_image", "process_data", "get_facetranslation_latent_conv_perceptual", "get_loaders_and_models"]
+    ref = "/root/reference/utils.py"
+    if os.path.exists(ref):                       # live where the reference exists: its own list of top-level functions
+        import ast
+        names = [n.name for n in ast.parse(open(ref).read()).body if isinstance(n, ast.FunctionDef)]
+        assert "save_frames_as_video" in names and "save_image" in names
+    code = r"""
+import sys
+sys.path.insert(0, %r)
+ns = {}
+exec("from utils import *", ns)
+missing = [n for n in %r if not callable(ns.get(n))]
+assert not missing, missing
+import numpy as np, torch
+ns["save_frames_as_video"]([np.full((4, 6, 3), 0.5, np.float32)] * 3, %r, fps=25)
+ns["save_image"](torch.zeros(4, 3, 5, 5), %r)
+print("UTILS_OK")
+""" % (ROOT, names, str(tmp_path / "clip.mp4"), str(tmp_path / "grid.png"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd="/tmp")
+    assert out.returncode == 0 and "UTILS_OK" in out.stdout, out.stderr[-2000:]
+    import numpy as np
+    try:
+        import cv2  # noqa: F401
+        assert (tmp_path / "clip.mp4").exists()
+    except ImportError:
+        clip = np.load(tmp_path / "clip.npy")
+        assert clip.shape == (3, 4, 6, 3) and clip.dtype == np.uint8 and int(clip[0, 0, 0, 0]) == 127
+    assert (tmp_path / "grid.png").exists()

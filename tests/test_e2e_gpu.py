@@ -41,7 +41,7 @@ def _engine_step(g, T=None):
     return eng, recon, diff, S, img, gt
 
 
-def _check_against_golden(g, eng, recon, diff, S, literal=False, what=""):
+def _check_against_golden(g, eng, recon, diff, S, literal=False, what="", expect_flips=None, tol0=1e-3):
     """Bounds: 1e-3 of each tensor's scale (BASELINE.json north_star) whenever every code index equals the reference's.
     An index may differ only where the REFERENCE's own top-2 distance margin is below 1e-4 (an fp32 near-tie: any
     summation order may flip it); a flipped code changes `dec` locally by O(1), so only then the bounds widen."""
@@ -54,11 +54,15 @@ def _check_against_golden(g, eng, recon, diff, S, literal=False, what=""):
         assert np.all(g["margin_" + lvl][bad] < 1e-4), f"id_{lvl}: {int(bad.sum())} mismatches outside the near-tie gate"
         assert bad.mean() < 2e-3
         flips += int(bad.sum())
-    tol = 1e-3 if flips == 0 else 1e-1           # one flipped code moves a first-layer gradient by a few per cent
+    # the fixtures whose reference margins leave no near-tie (b1_literal, c1, c1w: smallest top-2 margin >> fp32 error) must
+    # reproduce EVERY index: a flip there is a bug, not rounding, and the widened bounds below must never apply to them
+    if expect_flips is not None:
+        assert flips == expect_flips, f"{what}: {flips} code-index flips, expected {expect_flips}"
+    tol = tol0 if flips == 0 else 1e-1           # one flipped code moves a first-layer gradient by a few per cent
     got_dec = dec.cpu().numpy() if g["dec"].ndim == 4 else _sub(dec)
     obs = {"dec": _rel(got_dec, g["dec"])}
     if flips == 0:
-        assert obs["dec"] < 1e-3
+        assert obs["dec"] < tol0
     else:   # a flipped top-level code reaches a 40x40-pixel patch of one 64x64 frame through dec_t + dec
         frac_bad = (np.abs(got_dec - g["dec"]) > 1e-3 * np.abs(g["dec"]).max()).mean()
         assert frac_bad < 0.12 * flips, (flips, frac_bad)
@@ -83,17 +87,18 @@ def _check_against_golden(g, eng, recon, diff, S, literal=False, what=""):
     obs["grad_sub"] = worst
     for n in names:
         if "grad_full." + n in g.files:
-            assert _rel(eng.grads[n].cpu().numpy(), g["grad_full." + n]) < (1e-3 if flips == 0 else 0.1), n
+            assert _rel(eng.grads[n].cpu().numpy(), g["grad_full." + n]) < (tol0 if flips == 0 else 0.1), n
     for k, b in eng.buffers.items():
         np.testing.assert_allclose(_stats(b)[1], g["buf_stats." + k][1], rtol=1e-3 if flips == 0 else 2e-3)
     print(f"[parity {what}] index flips {flips}; observed max rel err: {obs}")
+    return flips, obs
 
 
 def test_c1_e2e_vs_reference_golden(golden_dir):
     """BASELINE config 1 (64x64, T=2, bs=2): forward, losses, indices, all 70 gradients, EMA buffers."""
     g = np.load(os.path.join(golden_dir, "c1_e2e.npz"))
     eng, recon, diff, S, img, gt = _engine_step(g)
-    _check_against_golden(g, eng, recon, diff, S, what="c1")
+    _check_against_golden(g, eng, recon, diff, S, what="c1", expect_flips=0)
     # Adam step (train_faceoff_perceptual.py:107) then an eval forward pins the whole state update
     from faceoff_amd import ops
     m, v = torch.zeros_like(eng.flat_params), torch.zeros_like(eng.flat_params)
@@ -112,14 +117,14 @@ def test_c1w_e2e_many_codes_vs_reference_golden(golden_dir):
     g = np.load(os.path.join(golden_dir, "c1w_e2e.npz"))
     assert len(np.unique(g["id_t"])) > 100 and len(np.unique(g["id_b"])) > 100
     eng, recon, diff, S, img, gt = _engine_step(g)
-    _check_against_golden(g, eng, recon, diff, S, what="c1w")
+    _check_against_golden(g, eng, recon, diff, S, what="c1w", expect_flips=0)
 
 
 def test_b1_literal_reference_forward(golden_dir):
     """One clip of 4 frames (T = N): equals the reference's VQVAE.forward itself."""
     g = np.load(os.path.join(golden_dir, "b1_literal.npz"))
     eng, recon, diff, S, img, gt = _engine_step(g)
-    _check_against_golden(g, eng, recon, diff, S, literal=True, what="b1 literal")
+    _check_against_golden(g, eng, recon, diff, S, literal=True, what="b1 literal", expect_flips=0)
 
 
 def test_c2_oneclip_vs_reference_golden(golden_dir):
@@ -127,6 +132,38 @@ def test_c2_oneclip_vs_reference_golden(golden_dir):
     g = np.load(os.path.join(golden_dir, "c2_oneclip.npz"))
     eng, recon, diff, S, img, gt = _engine_step(g)
     _check_against_golden(g, eng, recon, diff, S, what="c2 one clip")
+
+
+def test_c2_oneclip_on_f2x2_winograd_is_tight_and_the_f4x4_engine_differs_by_relu_near_ties_only(golden_dir, monkeypatch):
+    """The default engine's F(4x4,3x3) layers carry 1.5-2e-5 of forward error per layer, which at 256x256 moves a
+    few pre-activations across zero; a ReLU's derivative jumps there and the FIRST layer's filter gradient, which sums the whole
+    backward chain, then sits close to the 1e-3 parity bound (0.5-1.0e-3 observed).  Two checks make that margin explicit:
+      (1) the same fixture on FACEOFF_WINOGRAD_TILE=2 (F(2x2,3x3): the direct kernels' error level) must be well inside the
+          bound -- so the engine's arithmetic is right and the F(4x4) excess is the transform's rounding, nothing else;
+      (2) the F(4x4) engine's saved activations differ from that run's by <= 2e-5 of scale, and every ReLU mask that differs
+          does so on an element within 1e-4 of zero in both (a near-tie, gated exactly like the VQ near-ties); the count is printed."""
+    g = np.load(os.path.join(golden_dir, "c2_oneclip.npz"))
+    e4, r4, d4, S4, *_ = _engine_step(g)
+    assert e4.winograd and e4.winograd_max_tile == 4
+    monkeypatch.setenv("FACEOFF_WINOGRAD_TILE", "2")
+    e2, r2, d2, S2, *_ = _engine_step(g)
+    assert e2.winograd_max_tile == 2
+    flips2, obs2 = _check_against_golden(g, e2, r2, d2, S2, what="c2 one clip, F(2x2)", tol0=5e-4)
+    relu_flips, worst_at_flip = 0, 0.0
+    for k, a in S4.items():
+        b = S2.get(k)
+        if torch.is_tensor(a) and torch.is_tensor(b) and a.is_floating_point() and a.shape == b.shape and a.dim() == 4:
+            scale = b.abs().max().item() + 1e-30
+            assert (a - b).abs().max().item() <= 1e-4 * scale, k
+            diff_mask = (a > 0) != (b > 0)
+            n = int(diff_mask.sum().item())
+            if n:
+                relu_flips += n
+                worst_at_flip = max(worst_at_flip, torch.maximum(a.abs(), b.abs())[diff_mask].max().item() / scale)
+    print(f"[c2 one clip] F(4x4) vs F(2x2) engine: {relu_flips} ReLU-mask differences, largest |activation| at one {worst_at_flip:.2e} of scale; "
+          f"F(2x2) engine vs golden: {obs2}")
+    assert worst_at_flip <= 1e-4, worst_at_flip
+    assert relu_flips <= 2000, relu_flips
 
 
 def test_e2e_vs_oracle_ragged():

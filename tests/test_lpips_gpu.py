@@ -267,3 +267,44 @@ def test_rgb_layer_data_gradient_kernel_vs_torch(monkeypatch):
     assert ((got - ref).abs() <= tol).all()
     assert (outs[0][..., 3:] == 0).all()
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_lpips_all_zero_feature_vectors_give_zero_gradient_like_the_reference(dtype):
+    """normalize_tensor (lpips.py:155-157) divides by sqrt(sum x^2) + eps; where a pixel's feature vector is entirely zero the
+    backward of that sqrt is inf * 0 = NaN INSIDE autograd -- but every tap is a ReLU output, an all-zero vector means every
+    pre-activation was <= 0, and ReLU's backward selects 0 there, so the reference's image gradient is finite (checked on the
+    oracle below, which runs the reference's own torch ops).  The kernels emit 0 for such pixels directly: same result, no NaN
+    anywhere.  conv1_2's bias is pushed down so that a large share of relu1_2 pixels are all-zero vectors (fp32: compared with
+    the oracle; bf16: finite and close to the fp32 engine)."""
+    from faceoff_amd.lpips import LPIPSEngine
+    from oracle import faceoff_oracle as O
+    sd = make_vgg_lpips_state(3)
+    sd["net.slice1.2.bias"][:] = -5.0                            # ~49 % of the relu1_2 pixels become all-zero vectors
+    rng = np.random.default_rng(8)
+    tgt = rng.uniform(-1, 1, (2, 3, 32, 48)).astype(np.float32)
+    rec = (tgt + 0.4 * rng.standard_normal(tgt.shape)).astype(np.float32)
+    lp = {k: torch.from_numpy(v) for k, v in sd.items()}
+    r = torch.from_numpy(rec).requires_grad_(True)
+    shift = torch.tensor(O.LPIPS_SHIFT).view(1, 3, 1, 1)
+    scale = torch.tensor(O.LPIPS_SCALE).view(1, 3, 1, 1)
+    tap1 = O.vgg16_taps((r.detach() - shift) / scale, lp, False)[0]
+    zero_share = (tap1.abs().sum(1) == 0).float().mean().item()
+    assert 0.02 < zero_share < 0.98, zero_share                  # the case is really exercised, and not everywhere
+    ref = O.lpips_forward(torch.from_numpy(tgt), r, lp).mean()
+    ref.backward()
+    assert torch.isfinite(r.grad).all() and torch.isfinite(ref)
+    eng = LPIPSEngine(sd, "cuda:0", dtype=dtype)
+    dec = torch.zeros((2, 32, 48, 8), device="cuda")
+    dec[..., :3] = torch.from_numpy(rec).permute(0, 2, 3, 1).cuda()
+    g_dec = torch.zeros_like(dec)
+    loss = eng.loss_and_grad(torch.from_numpy(tgt).cuda(), dec, g_dec, weight=1.0)
+    got = g_dec[..., :3].permute(0, 3, 1, 2).cpu()
+    assert torch.isfinite(loss).all() and torch.isfinite(got).all()
+    want = r.grad
+    if dtype == "fp32":
+        np.testing.assert_allclose(loss.item(), ref.item(), rtol=1e-3)
+        assert (got - want).abs().max().item() <= 2e-3 * want.abs().max().item()
+    else:
+        np.testing.assert_allclose(loss.item(), ref.item(), rtol=5e-2)
+        assert (got - want).norm().item() <= 0.15 * want.norm().item()
