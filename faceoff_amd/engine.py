@@ -134,14 +134,14 @@ class _Layer:
             return 4 if (not dgrad or self.ci % 128 == 0) else 0
         return 0
 
-    def _w42(self, form, N, H, W, cin, cout):
+    def _w42(self, form, N, H, W, cin, cout, which="fwd"):
         """Winograd F(4x4, 2x2) form of a k4 s2 p1 stem pass (2.56x fewer MFMA FLOP): `form` = "conv" (Conv2d forward, ConvTranspose2d
         data gradient: [N,H,W,cin] -> [N,H/2,W/2,cout]), "convT" ([N,H,W,cin] -> [N,2H,2W,cout]) or "wgrad" (conv-form geometry).
         Measured per layer (tools/bench_w42.py): pays on enc_b.2, dec.4 and dec_t.4 (128 channels on the pixel-grid side: -20 % forward / data
         gradient, -25...-48 % filter gradient), not on upsample_t (64 -> 64) or enc_t.0 (64 channels on that side)."""
         eng = self.engine
         wide, narrow = (self.ci, self.co) if self.kind == "convT" else (self.co, self.ci)     # the cell side has 4 x narrow channels
-        if eng is None or not eng.winograd or not eng.w42 or wide < 128 or narrow < 64:
+        if eng is None or not eng.winograd or not eng.w42 or wide < 128 or narrow < 64 or (self.name, which) in eng.w42_skip:
             return False
         return {"conv": ops.w42_conv_ok, "convT": ops.w42_convT_ok, "wgrad": ops.w42_wgrad_ok}[form](N, H, W, cin, cout)
 
@@ -162,12 +162,12 @@ class _Layer:
 
     # -- data gradient: gin = dgrad(g) [* (mask > 0)] [+ add]
     def dgrad(self, g, gin, T=1, mask=None, add=None):
-        if self.kind == "convT" and self._w42("conv", g.shape[0], g.shape[1], g.shape[2], self.co, self.ci):
+        if self.kind == "convT" and self._w42("conv", g.shape[0], g.shape[1], g.shape[2], self.co, self.ci, "dgrad"):
             ops.conv_k4s2_winograd(g, self._w42_filter(False), None, gin, cin=self.co, cout=self.ci, mask=mask, add=add)
         elif self.kind == "convT":                   # conv k4 s2 p1 over g
             ops.conv_igemm(g, self.wpd, None, gin, k=(1, 4, 4), stride=2, pad=(0, 1, 1), cin=ops.pad_in(self.co),
                            cout=self.ci, mask=mask, add=add)
-        elif self.k[-1] == 4 and self._w42("convT", g.shape[0], g.shape[1], g.shape[2], self.co, self.ci):
+        elif self.k[-1] == 4 and self._w42("convT", g.shape[0], g.shape[1], g.shape[2], self.co, self.ci, "dgrad"):
             ops.convT_k4s2_winograd(g, self._w42_filter(True), None, gin, cin=self.co, cout=self.ci, mask=mask, add=add)
         elif self.k[-1] == 4:                        # transposed conv over g
             ops.convT_phases(g, self.wpd, None, gin, cin=self.co, cout=self.ci, mask=mask, add=add)
@@ -207,7 +207,7 @@ class _Layer:
 
     def _wgrad(self, x, g, T, in_relu):
         geo = self._geom()
-        if self.kind == "convT" and self._w42("wgrad", g.shape[0], g.shape[1], g.shape[2], self.co, self.ci):
+        if self.kind == "convT" and self._w42("wgrad", g.shape[0], g.shape[1], g.shape[2], self.co, self.ci, "wgrad"):
             # the adjoint convolution's filter gradient: its input is this layer's output gradient, its output gradient this layer's input
             ops.conv_k4s2_wgrad_winograd(g, x, self.gw, cin=self.co, cout=self.ci)
             ops.bias_grad(g, self.gb, self.co)
@@ -215,7 +215,7 @@ class _Layer:
             ops.conv_wgrad(x, g, self.gw, None, k=(1, 4, 4), stride=2, pad=(0, 1, 1), a_real=self.ci, b_real=self.co,
                            in_relu=False)
             ops.bias_grad(g, self.gb, self.co)
-        elif self.k[-1] == 4 and not in_relu and self._w42("wgrad", x.shape[0], x.shape[1], x.shape[2], self.ci, self.co):
+        elif self.k[-1] == 4 and not in_relu and self._w42("wgrad", x.shape[0], x.shape[1], x.shape[2], self.ci, self.co, "wgrad"):
             S = self.engine._cur_S
             V = S.get("_wino_v", {}).pop(self.name, None) if S is not None else None
             if V is not None and self.engine.wgrad_stream is not None:
@@ -300,6 +300,8 @@ class VQVAEEngine:
         self.winograd = not _os.environ.get("FACEOFF_NO_WINOGRAD")
         self.winograd_max_tile = int(_os.environ.get("FACEOFF_WINOGRAD_TILE", "4"))   # 2: F(2x2,3x3) everywhere
         self.w42 = not _os.environ.get("FACEOFF_NO_W42")       # k4 s2 stems as Winograd F(4x4, 2x2) (needs self.winograd too)
+        # (layer, pass) pairs kept OFF the F(4x4,2x2) form, pass in {"fwd", "dgrad", "wgrad"}
+        self.w42_skip = {tuple(it.split(":")) for it in _os.environ.get("FACEOFF_W42_SKIP", "").split(",") if it}
         self.fused_resblock = not _os.environ.get("FACEOFF_NO_FUSED_RESBLOCK")
         self.keep_wino_v = False      # training forward: keep each Conv3d's transformed input for its filter gradient
         # filter gradients start when the next Winograd-domain GEMM of their stream ENDS (beside the HBM-bound transforms that

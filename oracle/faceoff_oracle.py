@@ -90,58 +90,117 @@ def vq_margin(x, embed):
     return (top2[:, 0] - top2[:, 1]).float()
 
 
-# --------------------------------------------------------------------------- conv stacks
-def _res_block(x, p, prefix):
-    """ResBlock.forward (:97-101): ReLU -> Conv3x3 -> ReLU -> Conv1x1, out += input."""
-    h = F.relu(x)
-    h = F.conv2d(h, p[prefix + ".conv.1.weight"], p[prefix + ".conv.1.bias"], padding=1)
-    h = F.relu(h)
-    h = F.conv2d(h, p[prefix + ".conv.3.weight"], p[prefix + ".conv.3.bias"])
-    return h + x
+class _RoundBF16(torch.autograd.Function):
+    """Storage rounding of the bf16 configuration (BASELINE config 3): the value is rounded to bfloat16 on the way
+    forward and its gradient is rounded to bfloat16 on the way back (what a bf16 tensor and its bf16 .grad hold);
+    all arithmetic around it stays fp32 (= bf16 operands, fp32 accumulate)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.bfloat16().float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.bfloat16().float()
 
 
-def encoder(x, p, prefix, stride, n_res_block=2):
-    """Encoder (:103-131)."""
-    b = prefix + ".blocks."
-    if stride == 4:
-        x = F.relu(F.conv2d(x, p[b + "0.weight"], p[b + "0.bias"], stride=2, padding=1))
-        x = F.relu(F.conv2d(x, p[b + "2.weight"], p[b + "2.bias"], stride=2, padding=1))
-        x = F.conv2d(x, p[b + "4.weight"], p[b + "4.bias"], padding=1)
-        first = 5
-    else:
-        x = F.relu(F.conv2d(x, p[b + "0.weight"], p[b + "0.bias"], stride=2, padding=1))
-        x = F.conv2d(x, p[b + "2.weight"], p[b + "2.bias"], padding=1)
-        first = 3
-    for i in range(n_res_block):
-        x = _res_block(x, p, f"{b}{first + i}")
-    return F.relu(x)
-
-
-def decoder(x, p, prefix, stride, n_res_block=2):
-    """Decoder (:134-166)."""
-    b = prefix + ".blocks."
-    x = F.conv2d(x, p[b + "0.weight"], p[b + "0.bias"], padding=1)
-    for i in range(n_res_block):
-        x = _res_block(x, p, f"{b}{1 + i}")
-    x = F.relu(x)
-    k = 1 + n_res_block + 1
-    x = F.conv_transpose2d(x, p[f"{b}{k}.weight"], p[f"{b}{k}.bias"], stride=2, padding=1)
-    if stride == 4:
-        x = F.relu(x)
-        x = F.conv_transpose2d(x, p[f"{b}{k + 2}.weight"], p[f"{b}{k + 2}.bias"], stride=2, padding=1)
+def _identity(x):
     return x
 
 
-def conv3d_postnet(x5, p, prefix):
+class _RoundGradBF16(torch.autograd.Function):
+    """A tensor that stays fp32 on the way forward (the quantiser's input, the decoder output) but whose GRADIENT is stored as
+    bfloat16 (it is an operand of the next bf16 data- / filter-gradient GEMM)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.bfloat16().float()
+
+
+def _round_weight(w):
+    """bf16 operand copy of an fp32 master filter: value rounded (exactly: the difference is representable), gradient passed
+    through unrounded (filter gradients are accumulated and kept in fp32)."""
+    return w + (w.bfloat16().float() - w).detach()
+
+
+class _BF16Sim:
+    """Rounding points of the bf16-operand VQ-VAE step (BASELINE config 3 as SURVEY.md section 8(d) defines it: bf16 MFMA
+    operands, fp32 accumulation, fp32 master weights, fp32 VQ), shared with faceoff_amd.engine (dtype="bf16"):
+      act(x)   every activation a conv kernel stores -- after bias, residual add and ReLU, all done in fp32 on the accumulator --
+               is rounded to bf16 ONCE, and so is its gradient (after the ReLU mask and the fan-in add, done in fp32);
+      grad(x)  the quantisers' inputs and the decoder output stay fp32 (VQ distances / arg-min / commitment loss and the image
+               losses run in fp32 on unrounded values), their gradients are stored as bf16;
+      w(w)     filters are rounded to bf16 from the fp32 master copy each step; their gradients stay fp32;
+      biases, codebooks, EMA buffers, loss scalars and the optimiser are fp32."""
+    act = staticmethod(_RoundBF16.apply)
+    grad = staticmethod(_RoundGradBF16.apply)
+    w = staticmethod(_round_weight)
+
+
+class _NoSim:
+    act = grad = w = staticmethod(_identity)
+
+
+# --------------------------------------------------------------------------- conv stacks
+def _res_block(x, p, prefix, r=_NoSim, out_relu=False):
+    """ResBlock.forward (:97-101): ReLU -> Conv3x3 -> ReLU -> Conv1x1, out += input.  (out_relu: the Encoder's / Decoder's
+    trailing ReLU (:126,145), which the engine applies before the block's output is stored -- the same values either way.)"""
+    h = F.relu(x)
+    h = F.conv2d(h, r.w(p[prefix + ".conv.1.weight"]), p[prefix + ".conv.1.bias"], padding=1)
+    h = r.act(F.relu(h))
+    h = F.conv2d(h, r.w(p[prefix + ".conv.3.weight"]), p[prefix + ".conv.3.bias"])
+    h = h + x
+    return r.act(F.relu(h) if out_relu else h)
+
+
+def encoder(x, p, prefix, stride, n_res_block=2, r=_NoSim):
+    """Encoder (:103-131)."""
+    b = prefix + ".blocks."
+    if stride == 4:
+        x = r.act(F.relu(F.conv2d(x, r.w(p[b + "0.weight"]), p[b + "0.bias"], stride=2, padding=1)))
+        x = r.act(F.relu(F.conv2d(x, r.w(p[b + "2.weight"]), p[b + "2.bias"], stride=2, padding=1)))
+        x = r.act(F.conv2d(x, r.w(p[b + "4.weight"]), p[b + "4.bias"], padding=1))
+        first = 5
+    else:
+        x = r.act(F.relu(F.conv2d(x, r.w(p[b + "0.weight"]), p[b + "0.bias"], stride=2, padding=1)))
+        x = r.act(F.conv2d(x, r.w(p[b + "2.weight"]), p[b + "2.bias"], padding=1))
+        first = 3
+    for i in range(n_res_block):
+        x = _res_block(x, p, f"{b}{first + i}", r, out_relu=(i == n_res_block - 1))
+    return x if n_res_block else F.relu(x)
+
+
+def decoder(x, p, prefix, stride, n_res_block=2, r=_NoSim):
+    """Decoder (:134-166).  (bf16 policy: the last layer's output is left to the caller -- `dec` itself stays fp32.)"""
+    b = prefix + ".blocks."
+    x = r.act(F.conv2d(x, r.w(p[b + "0.weight"]), p[b + "0.bias"], padding=1))
+    for i in range(n_res_block):
+        x = _res_block(x, p, f"{b}{1 + i}", r, out_relu=(i == n_res_block - 1))
+    if not n_res_block:
+        x = F.relu(x)
+    k = 1 + n_res_block + 1
+    x = F.conv_transpose2d(x, r.w(p[f"{b}{k}.weight"]), p[f"{b}{k}.bias"], stride=2, padding=1)
+    if stride == 4:
+        x = r.act(F.relu(x))
+        x = F.conv_transpose2d(x, r.w(p[f"{b}{k + 2}.weight"]), p[f"{b}{k + 2}.bias"], stride=2, padding=1)
+    return x
+
+
+def conv3d_postnet(x5, p, prefix, r=_NoSim):
     """Conv3dLatentPostnet (:169-190) on [B,C,T,H,W]."""
     for i in range(3):
-        x5 = F.conv3d(x5, p[f"{prefix}.conv3d.{i}.0.weight"], p[f"{prefix}.conv3d.{i}.0.bias"], padding=1)
+        x5 = F.conv3d(x5, r.w(p[f"{prefix}.conv3d.{i}.0.weight"]), p[f"{prefix}.conv3d.{i}.0.bias"], padding=1)
         if i < 2:
             x5 = F.relu(x5)
+        x5 = r.act(x5)
     return x5
 
 
-def vqvae_forward(x, p, training=True, all_reduce=None, T=None):
+def vqvae_forward(x, p, training=True, all_reduce=None, T=None, bf16sim=False):
     """VQVAE.forward (:243-259) generalised to clips.
 
     x: [B,T,6,H,W] (or [N,6,H,W] with T=None => one clip of N frames, the literal reference).
@@ -154,8 +213,9 @@ def vqvae_forward(x, p, training=True, all_reduce=None, T=None):
         frames = x
         T_ = T if T is not None else x.shape[0]
         B = x.shape[0] // T_
-    enc_b = encoder(frames, p, "enc_b", 4)                    # :237-241
-    enc_t = encoder(enc_b, p, "enc_t", 2)
+    r = _BF16Sim if bf16sim else _NoSim      # (bf16sim: the rounding points of the bf16-operand engine, see _BF16Sim)
+    enc_b = encoder(r.act(frames) if bf16sim else frames, p, "enc_b", 4, r=r)                    # :237-241
+    enc_t = encoder(r.act(enc_b), p, "enc_t", 2, r=r)        # (r.act on a stored tensor: a no-op forward; backward it rounds THIS consumer's gradient, which the engine stores before the fan-in add)
 
     def clips(t):   # :247  [N,C,h,w] -> [B,C,T,h,w]
         n, c, h, w = t.shape
@@ -165,27 +225,27 @@ def vqvae_forward(x, p, training=True, all_reduce=None, T=None):
         b, c, tt, h, w = t5.shape
         return t5.permute(0, 2, 1, 3, 4).reshape(b * tt, c, h, w)
 
-    enc_b_conv = frames_of(conv3d_postnet(clips(enc_b), p, "conv3d_encoded_b"))   # :250
-    enc_t_conv = frames_of(conv3d_postnet(clips(enc_t), p, "conv3d_encoded_t"))
+    enc_b_conv = frames_of(conv3d_postnet(clips(enc_b), p, "conv3d_encoded_b", r))   # :250
+    enc_t_conv = frames_of(conv3d_postnet(clips(enc_t), p, "conv3d_encoded_t", r))
 
     # encode_quantized (:261-278)
-    qt_in = F.conv2d(enc_t_conv, p["quantize_conv_t.weight"], p["quantize_conv_t.bias"]).permute(0, 2, 3, 1)
+    qt_in = r.grad(F.conv2d(enc_t_conv, r.w(p["quantize_conv_t.weight"]), p["quantize_conv_t.bias"]).permute(0, 2, 3, 1))
     quant_t, diff_t, id_t, new_t = quantize_forward(
         qt_in, p["quantize_t.embed"], p["quantize_t.cluster_size"], p["quantize_t.embed_avg"],
         training, all_reduce)
-    quant_t = quant_t.permute(0, 3, 1, 2)
-    dec_t = decoder(quant_t, p, "dec_t", 2)
+    quant_t = r.act(quant_t.permute(0, 3, 1, 2))
+    dec_t = r.act(decoder(quant_t, p, "dec_t", 2, r=r))
     cat_b = torch.cat([dec_t, enc_b_conv], 1)
-    qb_in = F.conv2d(cat_b, p["quantize_conv_b.weight"], p["quantize_conv_b.bias"]).permute(0, 2, 3, 1)
+    qb_in = r.grad(F.conv2d(cat_b, r.w(p["quantize_conv_b.weight"]), p["quantize_conv_b.bias"]).permute(0, 2, 3, 1))
     quant_b, diff_b, id_b, new_b = quantize_forward(
         qb_in, p["quantize_b.embed"], p["quantize_b.cluster_size"], p["quantize_b.embed_avg"],
         training, all_reduce)
-    quant_b = quant_b.permute(0, 3, 1, 2)
+    quant_b = r.act(quant_b.permute(0, 3, 1, 2))
     diff = diff_t.unsqueeze(0) + diff_b.unsqueeze(0)
 
     # decode (:280-285)
-    upsample_t = F.conv_transpose2d(quant_t, p["upsample_t.weight"], p["upsample_t.bias"], stride=2, padding=1)
-    dec = decoder(torch.cat([upsample_t, quant_b], 1), p, "dec", 4)
+    upsample_t = r.act(F.conv_transpose2d(r.act(quant_t), r.w(p["upsample_t.weight"]), p["upsample_t.bias"], stride=2, padding=1))
+    dec = r.grad(decoder(torch.cat([upsample_t, quant_b], 1), p, "dec", 4, r=r))
     new_buffers = None
     if training:
         new_buffers = {f"quantize_t.{k}": v for k, v in new_t.items()}
@@ -203,24 +263,6 @@ for _s, (_a, _b) in enumerate([(0, 4), (4, 9), (9, 16), (16, 23), (23, 30)], sta
         _VGG_SLICE_OF[_i] = _s
 LPIPS_SHIFT = (-.030, -.088, -.188)   # lpips.py:99
 LPIPS_SCALE = (.458, .448, .450)      # lpips.py:100
-
-
-class _RoundBF16(torch.autograd.Function):
-    """Storage rounding of the bf16 configuration (BASELINE config 3): the value is rounded to bfloat16 on the way
-    forward and its gradient is rounded to bfloat16 on the way back (what a bf16 tensor and its bf16 .grad hold);
-    all arithmetic around it stays fp32 (= bf16 operands, fp32 accumulate)."""
-
-    @staticmethod
-    def forward(ctx, x):
-        return x.bfloat16().float()
-
-    @staticmethod
-    def backward(ctx, g):
-        return g.bfloat16().float()
-
-
-def _identity(x):
-    return x
 
 
 def vgg16_taps(x, lp, bf16sim=False):
@@ -265,13 +307,13 @@ def lpips_forward(inp, target, lp, per_tap=False, bf16sim=False):
 
 
 # --------------------------------------------------------------------------- the step
-def run_step(x, ground_truth, p, lpips_state=None, training=True, all_reduce=None, lpips_bf16sim=False):
+def run_step(x, ground_truth, p, lpips_state=None, training=True, all_reduce=None, lpips_bf16sim=False, bf16sim=False):
     """run_step + loss composition (train_faceoff_perceptual.py:32-47,97-98).
 
     x[B,T,6,H,W], ground_truth[B,T,3,H,W].  Returns dict with recon/latent/perceptual/loss
     and the forward dict.  perceptual is 0 when lpips_state is None (BASELINE config 2).
     """
-    fw = vqvae_forward(x, p, training=training, all_reduce=all_reduce)
+    fw = vqvae_forward(x, p, training=training, all_reduce=all_reduce, bf16sim=bf16sim)
     gt = ground_truth.reshape(-1, *ground_truth.shape[-3:])
     out = fw["dec"][:, :3]                                   # :37
     recon = F.mse_loss(out, gt)                              # :21,39
@@ -299,12 +341,12 @@ def adam_step(p, grads, state, lr=3e-4, betas=(0.9, 0.999), eps=1e-8):
             p[k].addcdiv_(m, denom, value=-lr / (1 - b1 ** t))
 
 
-def train_step(x, ground_truth, p, lpips_state=None, adam_state=None, lr=3e-4, lpips_bf16sim=False):
+def train_step(x, ground_truth, p, lpips_state=None, adam_state=None, lr=3e-4, lpips_bf16sim=False, bf16sim=False):
     """One iteration of train() (:93-107): zero_grad, run_step, backward, (Adam), EMA buffers."""
     params = {k: v for k, v in p.items() if v.requires_grad}
     for v in params.values():
         v.grad = None
-    r = run_step(x, ground_truth, p, lpips_state, training=True, lpips_bf16sim=lpips_bf16sim)
+    r = run_step(x, ground_truth, p, lpips_state, training=True, lpips_bf16sim=lpips_bf16sim, bf16sim=bf16sim)
     r["loss"].backward()
     grads = {k: v.grad.detach().clone() for k, v in params.items()}
     with torch.no_grad():

@@ -134,21 +134,23 @@ def test_c2_oneclip_vs_reference_golden(golden_dir):
     _check_against_golden(g, eng, recon, diff, S, what="c2 one clip")
 
 
-def test_c2_oneclip_on_f2x2_winograd_is_tight_and_the_f4x4_engine_differs_by_relu_near_ties_only(golden_dir, monkeypatch):
-    """The default engine's F(4x4,3x3) layers carry 1.5-2e-5 of forward error per layer, which at 256x256 moves a
-    few pre-activations across zero; a ReLU's derivative jumps there and the FIRST layer's filter gradient, which sums the whole
-    backward chain, then sits close to the 1e-3 parity bound (0.5-1.0e-3 observed).  Two checks make that margin explicit:
-      (1) the same fixture on FACEOFF_WINOGRAD_TILE=2 (F(2x2,3x3): the direct kernels' error level) must be well inside the
-          bound -- so the engine's arithmetic is right and the F(4x4) excess is the transform's rounding, nothing else;
-      (2) the F(4x4) engine's saved activations differ from that run's by <= 2e-5 of scale, and every ReLU mask that differs
-          does so on an element within 1e-4 of zero in both (a near-tie, gated exactly like the VQ near-ties); the count is printed."""
+def test_c2_oneclip_direct_engine_is_tight_and_the_default_engine_differs_by_relu_near_ties_only(golden_dir, monkeypatch):
+    """Where the 256x256 clip's first-layer filter gradient gets its 0.9e-3 (bound 1e-3) from -- measured (tools/scratch/
+    c2clip_probe.py): NOT from the arithmetic of any backward kernel (switching single data- / filter-gradient passes between
+    their Winograd and direct forms moves it in the 4th digit) but from ~25 ReLU masks that the Winograd FORWARD passes'
+    2e-5 of rounding flip on pre-activations within rounding of zero (enc_b.blocks.2 on F(4x4,2x2) alone accounts for half).  The inputs
+    are noise, so that gradient is a sum of 82 000 terms of random sign (|sum| ~ 300 sigma) and one flipped mask moves it by a few sigma:
+    any two fp32 implementations differ like this, the direct engine against torch-CPU by 2.5e-4.  So the margin is made explicit:
+      (1) the engine on the direct kernels (5 such flips) must be within 5e-4 of the reference's golden on every tensor;
+      (2) the default engine's saved activations equal the direct engine's to 1e-4 of scale, and every ReLU mask that differs does
+          so on an element below 1e-4 of scale in both (a near-tie, gated exactly like the VQ near-ties); the count is bounded."""
     g = np.load(os.path.join(golden_dir, "c2_oneclip.npz"))
     e4, r4, d4, S4, *_ = _engine_step(g)
     assert e4.winograd and e4.winograd_max_tile == 4
-    monkeypatch.setenv("FACEOFF_WINOGRAD_TILE", "2")
+    monkeypatch.setenv("FACEOFF_NO_WINOGRAD", "1")
     e2, r2, d2, S2, *_ = _engine_step(g)
-    assert e2.winograd_max_tile == 2
-    flips2, obs2 = _check_against_golden(g, e2, r2, d2, S2, what="c2 one clip, F(2x2)", tol0=5e-4)
+    assert not e2.winograd
+    flips2, obs2 = _check_against_golden(g, e2, r2, d2, S2, what="c2 one clip, direct kernels", tol0=5e-4)
     relu_flips, worst_at_flip = 0, 0.0
     for k, a in S4.items():
         b = S2.get(k)
@@ -160,10 +162,10 @@ def test_c2_oneclip_on_f2x2_winograd_is_tight_and_the_f4x4_engine_differs_by_rel
             if n:
                 relu_flips += n
                 worst_at_flip = max(worst_at_flip, torch.maximum(a.abs(), b.abs())[diff_mask].max().item() / scale)
-    print(f"[c2 one clip] F(4x4) vs F(2x2) engine: {relu_flips} ReLU-mask differences, largest |activation| at one {worst_at_flip:.2e} of scale; "
-          f"F(2x2) engine vs golden: {obs2}")
+    print(f"[c2 one clip] default (Winograd) vs direct engine: {relu_flips} ReLU-mask differences, largest |activation| at one "
+          f"{worst_at_flip:.2e} of scale; direct engine vs golden: {obs2}")
     assert worst_at_flip <= 1e-4, worst_at_flip
-    assert relu_flips <= 2000, relu_flips
+    assert relu_flips <= 200, relu_flips
 
 
 def test_e2e_vs_oracle_ragged():
