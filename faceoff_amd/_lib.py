@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FACEOFF_HIP_LIB", os.path.join(_HERE, "libfaceoff_hip.so"))   # override: A/B kernel builds
 
-FO_IN_RELU, FO_BIAS, FO_MASK, FO_ADD, FO_OUT_RELU, FO_DEPTH2SPACE = 1, 2, 4, 8, 16, 32
+FO_IN_RELU, FO_BIAS, FO_MASK, FO_ADD, FO_OUT_RELU, FO_DEPTH2SPACE, FO_OUT_F32 = 1, 2, 4, 8, 16, 32, 64
 
 
 class FaceoffHipError(RuntimeError):
@@ -105,6 +105,16 @@ SIGNATURES = {
     "fo_pack_conv_bf16": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "fo_pack_conv_dgrad_bf16": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "fo_conv_igemm_bf16": (_I, [_D, _P, _P, _P, _P, _P, _P]),
+    "fo_conv_bf16": (_I, [_D, _P, _P, _P, _P, _P, _P, _P]),
+    "fo_wgrad_bf16_ws_bytes": (_L, [_D]),
+    "fo_conv_wgrad_bf16": (_I, [_D, _P, _P, _P, _I, _I, _P, _L, _P]),
+    "fo_bias_grad_bf16_ws_bytes": (_L, [_I]),
+    "fo_bias_grad_bf16": (_I, [_P, _P, _L, _I, _I, _I, _P, _P]),
+    "fo_f32_to_bf16": (_I, [_P, _L, _P, _L, _L, _I, _P]),
+    "fo_bf16_to_f32": (_I, [_P, _L, _P, _L, _L, _I, _P]),
+    "fo_nchw2_to_nhwc8_bf16": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _P]),
+    "fo_vq_assign2": (_I, [_P, _I, _L, _P, _P, _P, _P, _I, _P, _P, _I, _P]),
+    "fo_vq_bwd_bf16": (_I, [_P, _I, _P, _I, _P, _I, _P, _F, _P, _I, _L, _P]),
     "fo_lpips_prep_bf16": (_I, [_P, _I, _I, _P, _I, _I, _I, _P, _P, _P]),
     "fo_lpips_prep_bwd_bf16": (_I, [_P, _P, _I, _L, _P, _P, _F, _P]),
     "fo_maxpool2_fwd_bf16": (_I, [_P, _P, _I, _I, _I, _I, _P]),

@@ -32,13 +32,62 @@ struct ConvArgsH {
   const void* wp;
   const float* bias;
   const void* mask;
+  const void* add;
   void* out;
   int M, HWm, tilesM, tilesN;
-  int cinChunks;   // Cin/64 ; SMALLC: unused
-  int Ktot;        // elements per filter row (multiple of 64)
-  int ksteps;      // Ktot/64
+  int cinChunks;   // K chunks per tap: Cin/64 (128-row kernels), Cin/32 (256-row kernels); SMALLC: unused
+  int Ktot;        // elements per filter row (multiple of 64; 256-row kernels: of 32)
+  int ksteps;      // Ktot/64 (256-row kernels: Ktot/32)
+  int frameTiles;  // 1: a row tile never straddles a frame (HWm % tile rows == 0): depth taps that fall into clip padding are skipped whole
   unsigned inBytes, wpBytes;
 };
+
+// Walk of the contraction index in (depth tap, row tap, column tap, channel chunk) order.  Depth taps outside [kd0, kd1) are never
+// visited: for a row tile inside ONE frame at position t of its clip these are the taps that see nothing but clip padding
+// (reference Conv3d padding=1, models/vqvae_conv3d_latent.py:181: 2 of the 15 (frame, tap) pairs at T = 5).
+struct KWalk {
+  int q, tap, kd, kh, kw, chunk;      // q: K-steps issued so far
+};
+__device__ __forceinline__ void kwalk_range(const ConvArgsH& a, int tile_row0, int& kd0, int& kd1) {
+  const fo_conv_desc& d = a.d;
+  kd0 = 0; kd1 = d.KD;
+  if (d.KD > 1 && a.frameTiles) {
+    const int t = (tile_row0 / a.HWm) % d.T;
+    kd0 = max(0, d.padD - t);
+    kd1 = min(d.KD, d.T + d.padD - t);
+  }
+}
+__device__ __forceinline__ KWalk kwalk_begin(const fo_conv_desc& d, int kd0) {
+  KWalk w;
+  w.q = 0; w.kd = kd0; w.kh = 0; w.kw = 0; w.chunk = 0; w.tap = kd0 * d.KH * d.KW;
+  return w;
+}
+__device__ __forceinline__ void kwalk_next(KWalk& w, const fo_conv_desc& d, int chunks) {
+  ++w.q;
+  if (++w.chunk == chunks) {
+    w.chunk = 0;
+    if (w.tap < 31) ++w.tap;
+    if (++w.kw == d.KW) {
+      w.kw = 0;
+      if (++w.kh == d.KH) { w.kh = 0; ++w.kd; }
+    }
+  }
+}
+// bit tp of the result: tap tp of output row (frame n at clip position t, tap-(0,0,0) input coordinates py, px) reads a real pixel
+__device__ __forceinline__ unsigned tap_mask(const fo_conv_desc& d, bool pv, int t, int py, int px) {
+  unsigned mk = 0;
+  int tp = 0;
+  for (int kd = 0; kd < d.KD; ++kd) {
+    const bool okd = pv & ((unsigned)(t + kd - d.padD) < (unsigned)d.T);
+    for (int kh = 0; kh < d.KH; ++kh) {
+      const bool okh = okd & ((unsigned)(py + kh) < (unsigned)d.Hin);
+      for (int kw = 0; kw < d.KW; ++kw, ++tp) mk |= ((okh & ((unsigned)(px + kw) < (unsigned)d.Win)) ? 1u : 0u) << tp;
+    }
+  }
+  return mk;
+}
+// relu() of two packed bf16
+__device__ __forceinline__ unsigned relu_pk(unsigned w) { return w & ~(((w & 0x80008000u) >> 15) * 0xffffu); }
 
 #ifndef FO_ABLATE_H   // diagnostic builds (tools/ablate_bf16.sh): bit 0 drop the loop's global loads, 1 its LDS stores,
 #define FO_ABLATE_H 0 // 2 its fragment reads (results are wrong, only the timing is of interest)
@@ -51,7 +100,35 @@ __device__ __forceinline__ u32x4 bufload16(__amdgpu_buffer_rsrc_t r, unsigned of
   return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
 }
 
-// fp32 C tile in LDS (BM x (BN + 4)) -> bias / ReLU mask / ReLU -> bf16, 8 channels = 16 B per lane
+// One output row's 8 consecutive channels: v = fp32 accumulators + bias -> ReLU-backward mask -> + add (residual / gradient fan-in)
+// -> ReLU -> ONE rounding to bf16 (or kept fp32: FO_OUT_F32, the quantisers' inputs and the decoder output)
+__device__ __forceinline__ void emit8(const ConvArgsH& a, int flags, float (&v)[8], const bf16x8& mk, const bf16x8& ad, size_t opix, int co, bool ok) {
+  if (flags & FO_MASK) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (float)mk[e] > 0.f ? v[e] : 0.f;
+  }
+  if (flags & FO_ADD) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += (float)ad[e];
+  }
+  if (flags & FO_OUT_RELU) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+  }
+  if (!ok) return;
+  if (flags & FO_OUT_F32) {
+    float* o = reinterpret_cast<float*>(a.out) + opix * a.d.ldOut + co;
+    *reinterpret_cast<f32x4*>(o) = f32x4{v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(o + 4) = f32x4{v[4], v[5], v[6], v[7]};
+  } else {
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e];
+    *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(a.out) + opix * a.d.ldOut + co) = o;
+  }
+}
+
+// fp32 C tile in LDS (BM x (BN + 4)) -> epilogue, 8 channels per lane
 template <int BN>
 __device__ __forceinline__ void store_c_tile(const ConvArgsH& a, const float* Cs, int tile_m, int tile_n, int tid) {
   constexpr int C_LD = BN + 4;
@@ -62,13 +139,21 @@ __device__ __forceinline__ void store_c_tile(const ConvArgsH& a, const float* Cs
   const int c8 = tid % C8;
   const int co = tile_n * BN + c8 * 8;
   if (co >= d.Cout) return;
+  // FO_DEPTH2SPACE (the k4 s2 p1 transposed conv with <= 8 output channels as ONE GEMM, reference :152): GEMM column = phase * 8 +
+  // channel, so a lane's 8 columns are ONE output pixel's 8 channels: pixel (2y + ph/2 - ophH, 2x + ph%2 - ophH), d.ophW real channels
+  const bool d2s = flags & FO_DEPTH2SPACE;
+  const int ph = co >> 3;
   float bv[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) bv[e] = ((flags & FO_BIAS) && co + e < d.Cout) ? a.bias[co + e] : 0.f;
-  const bool identity_pix = (d.ostride == 1) & (d.Hm == d.Hout) & (d.Wm == d.Wout);
-  __bf16* out = reinterpret_cast<__bf16*>(a.out);
+  for (int e = 0; e < 8; ++e) {
+    const int cb = d2s ? e : co + e;
+    bv[e] = ((flags & FO_BIAS) && cb < (d2s ? d.ophW : d.Cout)) ? a.bias[cb] : 0.f;
+  }
+  const bool identity_pix = (d.ostride == 1) & (d.Hm == d.Hout) & (d.Wm == d.Wout) & !d2s;
   const __bf16* mask = reinterpret_cast<const __bf16*>(a.mask);
-  // rows in batches: all mask loads of a batch are in flight before the first is used (see conv_igemm.hip store_tile)
+  const __bf16* addp = reinterpret_cast<const __bf16*>(a.add);
+  const int cst = d2s ? 0 : co;               // channel offset of the store
+  // rows in batches: all mask / add loads of a batch are in flight before the first is used (see conv_igemm.hip store_tile)
   constexpr int ROWS = BM / RPP, R = ROWS < 8 ? ROWS : 8;
   const int r0 = tid / C8;
 #pragma unroll
@@ -86,13 +171,25 @@ __device__ __forceinline__ void store_c_tile(const ConvArgsH& a, const float* Cs
         const int rem = m - n * a.HWm;
         const int y = rem / d.Wm;
         const int x = rem - y * d.Wm;
-        opix[r] = ((size_t)n * d.Hout + (y * d.ostride + d.ophH)) * d.Wout + (x * d.ostride + d.ophW);
+        int oy = y * d.ostride + d.ophH, ox = x * d.ostride + d.ophW;
+        if (d2s) {
+          oy = 2 * y + (ph >> 1) - d.ophH;
+          ox = 2 * x + (ph & 1) - d.ophH;
+          ok[r] = ok[r] & ((unsigned)oy < (unsigned)d.Hout) & ((unsigned)ox < (unsigned)d.Wout);
+          oy = min(max(oy, 0), d.Hout - 1);
+          ox = min(max(ox, 0), d.Wout - 1);
+        }
+        opix[r] = ((size_t)n * d.Hout + oy) * d.Wout + ox;
       }
     }
-    bf16x8 mk[R];
+    bf16x8 mk[R], ad[R];
     if (flags & FO_MASK) {
 #pragma unroll
       for (int r = 0; r < R; ++r) mk[r] = *reinterpret_cast<const bf16x8*>(mask + opix[r] * d.ldMask + co);
+    }
+    if (flags & FO_ADD) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) ad[r] = *reinterpret_cast<const bf16x8*>(addp + opix[r] * d.ldAdd + co);
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -100,19 +197,12 @@ __device__ __forceinline__ void store_c_tile(const ConvArgsH& a, const float* Cs
       const f32x4 v0 = *reinterpret_cast<const f32x4*>(crow);
       const f32x4 v1 = *reinterpret_cast<const f32x4*>(crow + 4);
       float v[8] = {v0.x + bv[0], v0.y + bv[1], v0.z + bv[2], v0.w + bv[3], v1.x + bv[4], v1.y + bv[5], v1.z + bv[6], v1.w + bv[7]};
-      if (flags & FO_MASK) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (float)mk[r][e] > 0.f ? v[e] : 0.f;
-      }
-      bf16x8 o;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = (__bf16)((flags & FO_OUT_RELU) ? fmaxf(v[e], 0.f) : v[e]);
-      if (ok[r]) *reinterpret_cast<bf16x8*>(out + opix[r] * d.ldOut + co) = o;
+      emit8(a, flags, v, mk[r], ad[r], opix[r], cst, ok[r]);
     }
   }
 }
 
-template <int BN, int WAVES_M, int WAVES_N, int TM, int TN, bool SMALLC>
+template <int BN, int WAVES_M, int WAVES_N, int TM, int TN, bool SMALLC, bool INRELU>
 __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvArgsH a) {
   static_assert(WAVES_M * WAVES_N == 4, "4 waves");
   static_assert(WAVES_M * TM * 32 == BM && WAVES_N * TN * 32 == BN, "tile");
@@ -130,7 +220,10 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvArgsH a) {
   const int logical = fo_xcd_remap(blockIdx.x, gridDim.x);
   const int tile_n = logical % a.tilesN;
   const int tile_m = logical / a.tilesN;
-  const int ntaps = d.KH * d.KW;
+  const int ntaps = d.KD * d.KH * d.KW;
+  int kd0, kd1;
+  kwalk_range(a, tile_m * BM, kd0, kd1);
+  const int nsteps = SMALLC ? a.ksteps : (kd1 - kd0) * d.KH * d.KW * a.cinChunks;
 
   // ---- loader coordinates: thread covers rows lrow + 32*i, 16 bytes (8 elements) at byte column lcolB
   const int lrow = tid >> 3;
@@ -150,17 +243,9 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvArgsH a) {
     const int x = rem - y * d.Wm;
     py[i] = y * d.stride - d.padH;
     px[i] = x * d.stride - d.padW;
-    pbase[i] = (n * d.Hin + py[i]) * d.Win + px[i];      // pixel index of tap (0,0)
+    pbase[i] = ((n - d.padD) * d.Hin + py[i]) * d.Win + px[i];      // pixel index of tap (0,0,0)
     rowoff[i] = pbase[i] * d.ldIn * 2 + lcolB;
-    unsigned mk = 0;
-    if (!SMALLC) {
-      for (int tp = 0; tp < ntaps; ++tp) {
-        const int kh = tp / d.KW, kw = tp - kh * d.KW;
-        const bool ok = pv[i] & ((unsigned)(py[i] + kh) < (unsigned)d.Hin) & ((unsigned)(px[i] + kw) < (unsigned)d.Win);
-        mk |= (ok ? 1u : 0u) << tp;
-      }
-    }
-    tapmask[i] = mk;
+    tapmask[i] = SMALLC ? 0u : tap_mask(d, pv[i], n % d.T, py[i], px[i]);
   }
 
   const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in), 0, a.inBytes, 0x00020000);
@@ -169,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvArgsH a) {
   const unsigned wstride32 = (unsigned)((size_t)32 * a.Ktot * 2);
 
   // incremental (tap, chunk) walk of the next step to load (wave-uniform scalars)
-  int ld_step = 0, ld_tap = 0, ld_kh = 0, ld_kw = 0, ld_chunk = 0;
+  KWalk kw_ = kwalk_begin(d, kd0);
   // SMALLC: this thread's tap of the step being loaded
   int sc_off = 0, sc_kh = 0, sc_kw = 0;
   bool sc_ok = false;
@@ -178,36 +263,36 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvArgsH a) {
 
   auto load_step = [&](int slot) {
     if (SMALLC) {
-      const int tap = ld_step * 8 + (tid & 7);
+      const int tap = kw_.q * 8 + (tid & 7);
       sc_kh = tap / d.KW;
       sc_kw = tap - sc_kh * d.KW;
       sc_ok = tap < ntaps;
       sc_off = (sc_kh * d.Win + sc_kw) * d.ldIn * 2;
     }
-    const int stepoff = ((ld_kh * d.Win + ld_kw) * d.ldIn + ld_chunk * 64) * 2;
+    const int stepoff = ((((kw_.kd * d.Hin) + kw_.kh) * d.Win + kw_.kw) * d.ldIn + kw_.chunk * 64) * 2;
+    const int kpos = SMALLC ? kw_.q : kw_.tap * a.cinChunks + kw_.chunk;      // 64-element position inside a filter row
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       if (SMALLC) {
         const bool ok = sc_ok & pv[s] & ((unsigned)(py[s] + sc_kh) < (unsigned)d.Hin) & ((unsigned)(px[s] + sc_kw) < (unsigned)d.Win);
         ra[slot][s] = bufload16(rin, ok ? (unsigned)(pbase[s] * d.ldIn * 2 + sc_off) : OOB);
       } else {
-        const unsigned pad = (((tapmask[s] >> ld_tap) & 1u) - 1u) & OOB;     // padding tap -> beyond the descriptor -> zeros
+        const unsigned pad = (((tapmask[s] >> kw_.tap) & 1u) - 1u) & OOB;     // padding tap -> beyond the descriptor -> zeros
         ra[slot][s] = bufload16(rin, (unsigned)(rowoff[s] + stepoff) | pad);
       }
-      if (s < BROWS) rb[slot][s < BROWS ? s : 0] = bufload16(rwp, ld_step < a.ksteps ? wrow + s * wstride32 + ld_step * 128 : OOB);
+      if (s < BROWS) rb[slot][s < BROWS ? s : 0] = bufload16(rwp, kw_.q < nsteps ? wrow + s * wstride32 + kpos * 128 : OOB);
     }
-    ++ld_step;
-    if (!SMALLC && ++ld_chunk == a.cinChunks) {
-      ld_chunk = 0;
-      ++ld_tap;
-      if (++ld_kw == d.KW) { ld_kw = 0; ++ld_kh; }
-    }
+    if (SMALLC) ++kw_.q; else kwalk_next(kw_, d, a.cinChunks);
   };
   auto store_step = [&](int slot, int buf, int s_lo = 0, int s_hi = 4) {
     unsigned char* As = As0 + buf * BM * ROWB;
     unsigned char* Bs = Bs0 + buf * BN * ROWB;
 #pragma unroll
     for (int s = s_lo; s < s_hi; ++s) {
+      if (INRELU) {                   // the leading ReLU of a ResBlock (reference :91), applied as the operand is staged
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ra[slot][s][e] = relu_pk(ra[slot][s][e]);
+      }
       *reinterpret_cast<u32x4*>(As + (lrow + 32 * s) * ROWB + lcolB) = ra[slot][s];
       if (s < BROWS) *reinterpret_cast<u32x4*>(Bs + (lrow + 32 * s) * ROWB + lcolB) = rb[slot][s < BROWS ? s : 0];
     }
@@ -254,7 +339,6 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvArgsH a) {
   load_step(1);
   store_step(0, 0);
   __syncthreads();
-  const int nsteps = a.ksteps;
   for (int step = 0; step < nsteps; step += 2) {
     if (!(FO_ABLATE_H & 1)) load_step(0);                 // step + 2
     compute(0, 1, 1);             // step; stores step + 1
@@ -313,7 +397,9 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_dma_kernel(const ConvArgsH a
   const int logical = fo_xcd_remap(blockIdx.x, gridDim.x);
   const int tile_n = logical % a.tilesN;
   const int tile_m = logical / a.tilesN;
-  const int ntaps = d.KH * d.KW;
+  int kd0, kd1;
+  kwalk_range(a, tile_m * BM, kd0, kd1);
+  const int nsteps = (kd1 - kd0) * d.KH * d.KW * a.cinChunks;
 
   // ---- DMA roles: piece i of wave w = tile rows (i*4 + w)*8 .. +7, lane = (row % 8, chunk position)
   const int drow = lane >> 3, dpos = lane & 7;
@@ -331,14 +417,8 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_dma_kernel(const ConvArgsH a
     const int y = rem / d.Wm;
     const int x = rem - y * d.Wm;
     const int py = y * d.stride - d.padH, px = x * d.stride - d.padW;
-    rowoffA[i] = ((n * d.Hin + py) * d.Win + px) * d.ldIn * 2 + chunk * 16;
-    unsigned mk = 0;
-    for (int tp = 0; tp < ntaps; ++tp) {
-      const int kh = tp / d.KW, kw = tp - kh * d.KW;
-      const bool ok = pv & ((unsigned)(py + kh) < (unsigned)d.Hin) & ((unsigned)(px + kw) < (unsigned)d.Win);
-      mk |= (ok ? 1u : 0u) << tp;
-    }
-    tapmaskA[i] = mk;
+    rowoffA[i] = (((n - d.padD) * d.Hin + py) * d.Win + px) * d.ldIn * 2 + chunk * 16;
+    tapmaskA[i] = tap_mask(d, pv, n % d.T, py, px);
   }
 #pragma unroll
   for (int i = 0; i < NPB; ++i) {
@@ -349,24 +429,20 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_dma_kernel(const ConvArgsH a
   const __amdgpu_buffer_rsrc_t rwp = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wp), 0, a.wpBytes, 0x00020000);
   lds_byte* const lds3 = (lds_byte*)lds;
 
-  int ld_step = 0, ld_tap = 0, ld_kh = 0, ld_kw = 0, ld_chunk = 0;
+  KWalk kw_ = kwalk_begin(d, kd0);
   auto dma_step = [&](int stage) {
-    const int stepoff = ((ld_kh * d.Win + ld_kw) * d.ldIn + ld_chunk * 64) * 2;
+    const int stepoff = ((((kw_.kd * d.Hin) + kw_.kh) * d.Win + kw_.kw) * d.ldIn + kw_.chunk * 64) * 2;
+    const int kpos = kw_.tap * a.cinChunks + kw_.chunk;
     lds_byte* const sa = lds3 + stage * STAGE;
     lds_byte* const sb = sa + BM * 128;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const unsigned pad = (((tapmaskA[i] >> ld_tap) & 1u) - 1u) & OOB;       // padding tap / row past M -> zeros
+      const unsigned pad = (((tapmaskA[i] >> kw_.tap) & 1u) - 1u) & OOB;      // padding tap / row past M -> zeros
       dma16(rin, sa + (i * 4 + wave) * 1024, (unsigned)(rowoffA[i] + stepoff) | pad);
     }
 #pragma unroll
-    for (int i = 0; i < NPB; ++i) dma16(rwp, sb + (i * 4 + wave) * 1024, ld_step < a.ksteps ? woffB[i] + ld_step * 128 : OOB);
-    ++ld_step;
-    if (++ld_chunk == a.cinChunks) {
-      ld_chunk = 0;
-      if (ld_tap < 31) ++ld_tap;
-      if (++ld_kw == d.KW) { ld_kw = 0; ++ld_kh; }
-    }
+    for (int i = 0; i < NPB; ++i) dma16(rwp, sb + (i * 4 + wave) * 1024, kw_.q < nsteps ? woffB[i] + kpos * 128 : OOB);
+    kwalk_next(kw_, d, a.cinChunks);
   };
 
   f32x16 acc[TM][TN];
@@ -385,7 +461,6 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_dma_kernel(const ConvArgsH a
 
   dma_step(0);
   __syncthreads();
-  const int nsteps = a.ksteps;
   for (int step = 0; step < nsteps; ++step) {
     const int cur = step & 1;
     dma_step(cur ^ 1);                                    // step + 1 (past the end: zeros, never read)
@@ -672,9 +747,10 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_pp16_kernel(const ConvArgsH 
   const int logical = fo_xcd_remap(blockIdx.x, gridDim.x);
   const int tile_n = logical % a.tilesN;
   const int tile_m = logical / a.tilesN;
-  const int ntaps = d.KH * d.KW;
-  const int chunks32 = a.cinChunks * 2;
-  const int nt = a.ksteps * 2;
+  const int chunks32 = a.cinChunks;                        // (32-deep chunks per tap)
+  int kd0, kd1;
+  kwalk_range(a, tile_m * BMB, kd0, kd1);
+  const int nt = (kd1 - kd0) * d.KH * d.KW * chunks32;    // 32-deep K tiles of this row tile
   const int drow = lane >> 2, dpos = lane & 3;
   int rowoffA[NPA];
   unsigned tapmaskA[NPA], woffB[NPB];
@@ -690,14 +766,8 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_pp16_kernel(const ConvArgsH 
     const int y = rem / d.Wm;
     const int x = rem - y * d.Wm;
     const int py = y - d.padH, px = x - d.padW;
-    rowoffA[i] = ((n * d.Hin + py) * d.Win + px) * d.ldIn * 2 + chunk * 16;
-    unsigned mk = 0;
-    for (int tp = 0; tp < ntaps; ++tp) {
-      const int kh = tp / d.KW, kw = tp - kh * d.KW;
-      const bool ok = pv & ((unsigned)(py + kh) < (unsigned)d.Hin) & ((unsigned)(px + kw) < (unsigned)d.Win);
-      mk |= (ok ? 1u : 0u) << tp;
-    }
-    tapmaskA[i] = mk;
+    rowoffA[i] = (((n - d.padD) * d.Hin + py) * d.Win + px) * d.ldIn * 2 + chunk * 16;
+    tapmaskA[i] = tap_mask(d, pv, n % d.T, py, px);
   }
 #pragma unroll
   for (int i = 0; i < NPB; ++i) {
@@ -708,25 +778,22 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_pp16_kernel(const ConvArgsH 
   const __amdgpu_buffer_rsrc_t rwp = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wp), 0, a.wpBytes, 0x00020000);
   lds_byte* const lds3 = (lds_byte*)lds;
 
-  int ld_q = 0, ld_tap = 0, ld_kh = 0, ld_kw = 0, ld_chunk = 0;
+  KWalk kw_ = kwalk_begin(d, kd0);
   auto dma_tile = [&]() {
-    const int stepoff = ((ld_kh * d.Win + ld_kw) * d.ldIn + ld_chunk * 32) * 2;
-    lds_byte* const sa = lds3 + (ld_q & 3) * SLOT;
+    const int stepoff = ((((kw_.kd * d.Hin) + kw_.kh) * d.Win + kw_.kw) * d.ldIn + kw_.chunk * 32) * 2;
+    const int kpos = kw_.tap * chunks32 + kw_.chunk;       // 32-element position inside a filter row
+    lds_byte* const sa = lds3 + (kw_.q & 3) * SLOT;
     lds_byte* const sb = sa + BMB * 64;
 #pragma unroll
     for (int i = 0; i < NPA; ++i) {
-      const unsigned pad = (((tapmaskA[i] >> ld_tap) & 1u) - 1u) & OOB;       // padding tap / row past M / tile past the end -> zeros
+      // padding tap / row past M -> zeros; K tiles past the end: whatever the walk points at (never multiplied in: the loop ends first)
+      const unsigned pad = (((tapmaskA[i] >> kw_.tap) & 1u) - 1u) & OOB;
       dma16(rin, sa + (i * 8 + wave) * 1024, (unsigned)(rowoffA[i] + stepoff) | pad);
     }
 #pragma unroll
     for (int i = 0; i < NPB; ++i)
-      dma16(rwp, sb + (i * 8 + wave) * 1024, ld_q < nt ? woffB[i] + ld_q * 64 : OOB);
-    ++ld_q;
-    if (++ld_chunk == chunks32) {
-      ld_chunk = 0;
-      if (ld_tap < 31) ++ld_tap;
-      if (++ld_kw == d.KW) { ld_kw = 0; ++ld_kh; }
-    }
+      dma16(rwp, sb + (i * 8 + wave) * 1024, kw_.q < nt ? woffB[i] + kpos * 64 : OOB);
+    kwalk_next(kw_, d, chunks32);
   };
 
   f32x4 acc[TM][TN];
@@ -779,7 +846,7 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_pp16_kernel(const ConvArgsH 
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
 
-  // ---- epilogue: 32 rows of the wave tile at a time through a wave-local LDS patch, then 16-byte bf16 stores
+  // ---- epilogue: 32 rows of the wave tile at a time through a wave-local LDS patch, then 8 channels per lane (emit8)
   float* Cs = reinterpret_cast<float*>(lds) + wave * 32 * C_LD;
   const int flags = d.flags;
   constexpr int C8 = WCOLS / 8, RPP = 64 / C8;
@@ -788,8 +855,8 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_pp16_kernel(const ConvArgsH 
   float bv[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) bv[e] = ((flags & FO_BIAS) && co + e < d.Cout) ? a.bias[co + e] : 0.f;
-  __bf16* out = reinterpret_cast<__bf16*>(a.out);
   const __bf16* mask = reinterpret_cast<const __bf16*>(a.mask);
+  const __bf16* addp = reinterpret_cast<const __bf16*>(a.add);
 #pragma unroll
   for (int i2 = 0; i2 < TM / 2; ++i2) {
     __builtin_amdgcn_wave_barrier();
@@ -801,12 +868,19 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_pp16_kernel(const ConvArgsH 
         for (int r = 0; r < 4; ++r) Cs[(ii * 16 + quad * 4 + r) * C_LD + j * 16 + l15] = acc[i2 * 2 + ii][j][r];
     __builtin_amdgcn_wave_barrier();
     const int mbase = tile_m * BMB + wm * TM * 16 + i2 * 32;
-    bf16x8 mk[32 / RPP];                                  // all mask loads of the round in flight before the first use
+    bf16x8 mk[32 / RPP], ad[32 / RPP];                    // all mask / add loads of the round in flight before the first use
     if (flags & FO_MASK) {
 #pragma unroll
       for (int pp = 0; pp < 32 / RPP; ++pp) {
         const int m = mbase + pp * RPP + r0;
         mk[pp] = *reinterpret_cast<const bf16x8*>(mask + (size_t)(m < a.M ? m : 0) * d.ldMask + co);
+      }
+    }
+    if (flags & FO_ADD) {
+#pragma unroll
+      for (int pp = 0; pp < 32 / RPP; ++pp) {
+        const int m = mbase + pp * RPP + r0;
+        ad[pp] = *reinterpret_cast<const bf16x8*>(addp + (size_t)(m < a.M ? m : 0) * d.ldAdd + co);
       }
     }
 #pragma unroll
@@ -817,14 +891,7 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_pp16_kernel(const ConvArgsH 
       const f32x4 v0 = *reinterpret_cast<const f32x4*>(crow);
       const f32x4 v1 = *reinterpret_cast<const f32x4*>(crow + 4);
       float v[8] = {v0.x + bv[0], v0.y + bv[1], v0.z + bv[2], v0.w + bv[3], v1.x + bv[4], v1.y + bv[5], v1.z + bv[6], v1.w + bv[7]};
-      if (flags & FO_MASK) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (float)mk[pp][e] > 0.f ? v[e] : 0.f;
-      }
-      bf16x8 o;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = (__bf16)((flags & FO_OUT_RELU) ? fmaxf(v[e], 0.f) : v[e]);
-      if (m < a.M) *reinterpret_cast<bf16x8*>(out + (size_t)m * d.ldOut + co) = o;
+      emit8(a, flags, v, mk[pp], ad[pp], (size_t)(m < a.M ? m : 0), co, m < a.M);
     }
   }
 }
@@ -857,9 +924,11 @@ template <int BN, int WAVES_M, int WAVES_N, int TM, int TN>
 int launch(const ConvArgsH& a, bool smallc, hipStream_t s) {
   const int grid = a.tilesM * a.tilesN;
   if (smallc)
-    hipLaunchKernelGGL((conv_bf16_kernel<BN, WAVES_M, WAVES_N, TM, TN, true>), dim3(grid), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv_bf16_kernel<BN, WAVES_M, WAVES_N, TM, TN, true, false>), dim3(grid), dim3(256), 0, s, a);
+  else if (a.d.flags & FO_IN_RELU)
+    hipLaunchKernelGGL((conv_bf16_kernel<BN, WAVES_M, WAVES_N, TM, TN, false, true>), dim3(grid), dim3(256), 0, s, a);
   else
-    hipLaunchKernelGGL((conv_bf16_kernel<BN, WAVES_M, WAVES_N, TM, TN, false>), dim3(grid), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv_bf16_kernel<BN, WAVES_M, WAVES_N, TM, TN, false, false>), dim3(grid), dim3(256), 0, s, a);
   FO_CHECK_LAUNCH();
   return FO_OK;
 }
@@ -910,31 +979,39 @@ int fo_pack_conv_dgrad_bf16(const float* w, void* wp, int O, int I, int taps, in
   return FO_OK;
 }
 
-int fo_conv_igemm_bf16(const fo_conv_desc* d, const void* in, const void* wp, const float* bias, const void* mask, void* out,
-                       void* stream) {
+static int conv_bf16_impl(const fo_conv_desc* d, const void* in, const void* wp, const float* bias, const void* mask, const void* add,
+                          void* out, void* stream) {
   ConvArgsH a;
   a.d = *d;
-  a.in = in; a.wp = wp; a.bias = bias; a.mask = mask; a.out = out;
-  FO_REQUIRE(d->N > 0 && d->KD == 1 && d->padD == 0, FO_E_SHAPE, "conv_bf16: 2-D only (KD == 1)");
-  FO_REQUIRE(!(d->flags & ~(FO_BIAS | FO_MASK | FO_OUT_RELU)), FO_E_SHAPE, "conv_bf16: flags other than BIAS|MASK|OUT_RELU");
-  FO_REQUIRE(d->ldIn % 8 == 0 && d->ldOut % 8 == 0 && fo_aligned16(in) && fo_aligned16(wp) && fo_aligned16(out), FO_E_ALIGN,
-             "conv_bf16: 16-byte alignment (ld %% 8 == 0)");
-  FO_REQUIRE(d->ldOut >= (d->Cout + 7) / 8 * 8, FO_E_ALIGN, "conv_bf16: ldOut must hold Cout rounded up to 8");
-  FO_REQUIRE(!(d->flags & FO_MASK) || (mask && fo_aligned16(mask) && d->ldMask % 8 == 0), FO_E_ALIGN, "conv_bf16: mask alignment");
-  FO_REQUIRE(!(d->flags & FO_BIAS) || bias, FO_E_SHAPE, "conv_bf16: FO_BIAS without bias");
-  const int taps = d->KH * d->KW;
-  FO_REQUIRE(taps >= 1 && taps <= 31, FO_E_SHAPE, "conv_bf16: at most 31 taps (got %d)", taps);
-  const bool smallc = d->Cin < 64;
-  if (smallc) {
-    FO_REQUIRE(d->Cin == 8 && d->ldIn == 8, FO_E_SHAPE, "conv_bf16: small Cin must be 8 with 16-byte pixels (got %d)", d->Cin);
-    a.Ktot = (taps + 7) / 8 * 64;
-    a.cinChunks = 1;
+  a.in = in; a.wp = wp; a.bias = bias; a.mask = mask; a.add = add; a.out = out;
+  const int flags = d->flags;
+  const bool f32out = flags & FO_OUT_F32, d2s = flags & FO_DEPTH2SPACE;
+  FO_REQUIRE(d->N > 0 && d->T > 0 && d->N % d->T == 0 && d->KD >= 1 && (d->KD == 1 || d->stride == 1), FO_E_SHAPE,
+             "conv_bf16: N=%d must be whole clips of T=%d; depth taps need stride 1", d->N, d->T);
+  FO_REQUIRE(!(flags & ~(FO_IN_RELU | FO_BIAS | FO_MASK | FO_ADD | FO_OUT_RELU | FO_DEPTH2SPACE | FO_OUT_F32)), FO_E_SHAPE, "conv_bf16: unknown flag");
+  FO_REQUIRE(d->ldIn % 8 == 0 && fo_aligned16(in) && fo_aligned16(wp) && fo_aligned16(out) && d->ldOut % (f32out ? 4 : 8) == 0, FO_E_ALIGN,
+             "conv_bf16: 16-byte alignment (bf16 ld %% 8 == 0, fp32 ld %% 4 == 0)");
+  if (d2s) {
+    FO_REQUIRE(d->Cout == 32 && d->ldOut >= 8 && (d->ophH == 0 || d->ophH == 1) && d->Hout == 2 * (d->Hm - d->ophH) && d->Wout == 2 * (d->Wm - d->ophH) &&
+                   !(flags & (FO_MASK | FO_ADD)) && d->ophW >= 1 && d->ophW <= 8,
+               FO_E_SHAPE, "conv_bf16: FO_DEPTH2SPACE needs Cout == 32 (4 phases x 8), ldOut >= 8, a 2x output grid, no mask/add");
   } else {
-    FO_REQUIRE(d->Cin % 64 == 0, FO_E_SHAPE, "conv_bf16: Cin=%d must be a multiple of 64 (or 8)", d->Cin);
-    a.Ktot = taps * d->Cin;
-    a.cinChunks = d->Cin / 64;
+    FO_REQUIRE(d->ldOut >= (d->Cout + 7) / 8 * 8, FO_E_ALIGN, "conv_bf16: ldOut must hold Cout rounded up to 8");
   }
-  a.ksteps = a.Ktot / 64;
+  FO_REQUIRE(!(flags & FO_MASK) || (mask && fo_aligned16(mask) && d->ldMask % 8 == 0), FO_E_ALIGN, "conv_bf16: mask alignment");
+  FO_REQUIRE(!(flags & FO_ADD) || (add && fo_aligned16(add) && d->ldAdd % 8 == 0), FO_E_ALIGN, "conv_bf16: add alignment");
+  FO_REQUIRE(!(flags & FO_BIAS) || bias, FO_E_SHAPE, "conv_bf16: FO_BIAS without bias");
+  const int taps = d->KD * d->KH * d->KW;
+  FO_REQUIRE(taps >= 1 && taps <= 31, FO_E_SHAPE, "conv_bf16: at most 31 taps (got %d)", taps);
+  const bool smallc = d->Cin < 32;
+  if (smallc) {
+    FO_REQUIRE(d->Cin == 8 && d->ldIn == 8 && d->KD == 1 && !(flags & FO_IN_RELU), FO_E_SHAPE,
+               "conv_bf16: small Cin must be 8 with 16-byte pixels, 2-D, no input ReLU (got %d)", d->Cin);
+    a.Ktot = (taps + 7) / 8 * 64;
+  } else {
+    FO_REQUIRE(d->Cin % 32 == 0, FO_E_SHAPE, "conv_bf16: Cin=%d must be a multiple of 32 (or 8)", d->Cin);
+    a.Ktot = taps * d->Cin;
+  }
   a.HWm = d->Hm * d->Wm;
   const long long M = (long long)d->N * a.HWm;
   FO_REQUIRE(M > 0 && M < (1ll << 31), FO_E_SHAPE, "conv_bf16: M out of range");
@@ -943,13 +1020,16 @@ int fo_conv_igemm_bf16(const fo_conv_desc* d, const void* in, const void* wp, co
   const unsigned long long inBytes = (((unsigned long long)d->N * d->Hin * d->Win - 1) * d->ldIn + d->Cin) * 2ull;
   const int opad = d->Cout > 64 ? (d->Cout + 127) / 128 * 128 : (d->Cout > 32 ? 64 : 32);
   const unsigned long long wpBytes = (unsigned long long)opad * a.Ktot * 2ull;
-  FO_REQUIRE(inBytes < (1ull << 31) && wpBytes < (1ull << 31), FO_E_SHAPE, "conv_bf16: tensor exceeds the 2 GiB buffer-descriptor window");
+  // (the offset arithmetic is 32-bit and starts up to one padding frame + row + column below the tensor)
+  const unsigned long long margin = ((((unsigned long long)d->padD * d->Hin + d->padH) * d->Win + d->padW) * d->ldIn + 64) * 2ull;
+  FO_REQUIRE(inBytes + margin < (1ull << 31) && wpBytes < (1ull << 31), FO_E_SHAPE, "conv_bf16: tensor exceeds the 2 GiB buffer-descriptor window");
   a.inBytes = (unsigned)inBytes;
   a.wpBytes = (unsigned)wpBytes;
   hipStream_t s = (hipStream_t)stream;
+  const bool plain_epi = !(flags & (FO_ADD | FO_OUT_F32 | FO_DEPTH2SPACE | FO_IN_RELU));
   const char* norgb = getenv("FACEOFF_BF16_NO_RGB");                 // diagnostics: the tiled kernel for the RGB layer too
-  if (smallc && d->Cout == 64 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->ostride == 1 && d->padH == 1 && d->padW == 1 &&
-      d->Hin == d->Hm && d->Win == d->Wm && d->Hm == d->Hout && d->Wm == d->Wout && d->ldOut == 64 && !(d->flags & FO_MASK) &&
+  if (smallc && plain_epi && d->Cout == 64 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->ostride == 1 && d->padH == 1 && d->padW == 1 &&
+      d->Hin == d->Hm && d->Win == d->Wm && d->Hm == d->Hout && d->Wm == d->Wout && d->ldOut == 64 && !(flags & FO_MASK) &&
       a.Ktot == 128 && inBytes < (1ull << 31) && !(norgb && atoi(norgb))) {
     const int nblocks = (a.M + 31) / 32;
     const int grid = std::min((nblocks + 3) / 4, fo_cu_count() * 3);
@@ -957,8 +1037,8 @@ int fo_conv_igemm_bf16(const fo_conv_desc* d, const void* in, const void* wp, co
     FO_CHECK_LAUNCH();
     return FO_OK;
   }
-  if (!smallc && d->Cin == 64 && d->ldIn == 64 && d->Cout <= 8 && d->ldOut == 8 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->ostride == 1 &&
-      d->padH == 1 && d->padW == 1 && d->Hin == d->Hm && d->Win == d->Wm && d->Hm == d->Hout && d->Wm == d->Wout && d->flags == 0 &&
+  if (!smallc && d->KD == 1 && d->Cin == 64 && d->ldIn == 64 && d->Cout <= 8 && d->ldOut == 8 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->ostride == 1 &&
+      d->padH == 1 && d->padW == 1 && d->Hin == d->Hm && d->Win == d->Wm && d->Hm == d->Hout && d->Wm == d->Wout && flags == 0 &&
       d->Win % 64 == 0 && a.M >= 64 * 1024 && !(norgb && atoi(norgb))) {
     constexpr int ldsBytes = 2 * 28 * 1024;
     static bool attr_set = false;
@@ -980,29 +1060,40 @@ int fo_conv_igemm_bf16(const fo_conv_desc* d, const void* in, const void* wp, co
   // on conv3_x / conv4_x, 128-column tiles +5...10 % on conv2_x and +12...15 % on 2-round launches, the 512 x 128 tile (32 MFMAs per
   // phase and wave instead of 16: half the barriers per FLOP) another +14...17 % where there are >= 8 rounds of them (a 512 x 64 tile for the 64-column layers measured -8 %); 64-column layers
   // (K = 576: 18 phases) stay on conv_bf16_kernel, whose second workgroup hides the prologue and epilogue
-  const bool same = d->stride == 1 && d->ostride == 1 && d->Hm == d->Hout && d->Wm == d->Wout && d->Hin == d->Hm && d->Win == d->Wm;
+  const bool same = d->stride == 1 && d->ostride == 1 && d->Hm == d->Hout && d->Wm == d->Wout && d->Hin == d->Hm && d->Win == d->Wm && !d2s;
   const char* nobig = getenv("FACEOFF_BF16_SMALL_TILES");            // diagnostics / tests: never
   const char* force = getenv("FACEOFF_BF16_BIG_TILES");              // tests: at any size
-  if (!smallc && same && !(nobig && atoi(nobig)) && d->Cout % 128 == 0) {
+  const bool odd32 = !smallc && d->Cin % 64 != 0;                    // 32-channel inputs (the ResBlocks' hidden tensor): only the 256-row kernels walk K in 32-deep tiles
+  if (!smallc && same && !(flags & FO_IN_RELU) && (!(nobig && atoi(nobig)) || odd32) && d->Cout % 128 == 0) {
+    a.cinChunks = d->Cin / 32;
+    a.ksteps = a.Ktot / 32;
     const long long tilesM256 = (a.M + 255) / 256;
-    const long long cus = (force && atoi(force)) ? 0 : fo_cu_count();
+    const long long cus = ((force && atoi(force)) || odd32) ? 0 : fo_cu_count();
     if (d->Cout % 256 == 0 && tilesM256 * (d->Cout / 256) >= 3 * cus) {
       a.tilesM = (int)tilesM256; a.tilesN = d->Cout / 256;
+      a.frameTiles = a.HWm % 256 == 0;
       return launch_pp16<256, 256, 2, 4>(a, s);
     }
     const char* t512 = getenv("FACEOFF_BF16_TILE512");               // 0: never the 512-row tile (diagnostics)
     const long long tilesM512 = (a.M + 511) / 512;
     if (!(t512 && !atoi(t512)) && tilesM512 * (d->Cout / 128) >= 8 * cus && (cus > 0 || (t512 && atoi(t512)))) {
       a.tilesM = (int)tilesM512; a.tilesN = d->Cout / 128;
+      a.frameTiles = a.HWm % 512 == 0;
       return launch_pp16<512, 128, 8, 1>(a, s);
     }
     if (tilesM256 * (d->Cout / 128) >= 2 * cus) {
       a.tilesM = (int)tilesM256; a.tilesN = d->Cout / 128;
+      a.frameTiles = a.HWm % 256 == 0;
       return launch_pp16<256, 128, 4, 2>(a, s);
     }
   }
+  FO_REQUIRE(smallc || d->Cin % 64 == 0, FO_E_SHAPE,
+             "conv_bf16: Cin=%d (a multiple of 32 but not of 64) is only taken by the same-size stride-1 kernels with Cout %% 128 == 0", d->Cin);
+  a.cinChunks = smallc ? 1 : d->Cin / 64;
+  a.ksteps = a.Ktot / 64;
+  a.frameTiles = a.HWm % BM == 0;
   const char* nodma = getenv("FACEOFF_BF16_NO_DMA");                // diagnostics: the register-staged kernel everywhere
-  const bool dma = !smallc && !(nodma && atoi(nodma));
+  const bool dma = !smallc && !(flags & FO_IN_RELU) && !(nodma && atoi(nodma));
   if (d->Cout > 64) {
     a.tilesN = (d->Cout + 127) / 128;
     return dma ? launch_dma<128, 2, 2, 2, 2>(a, s) : launch<128, 2, 2, 2, 2>(a, smallc, s);
@@ -1013,5 +1104,19 @@ int fo_conv_igemm_bf16(const fo_conv_desc* d, const void* in, const void* wp, co
     a.tilesN = 1;
     return launch<32, 4, 1, 1, 1>(a, smallc, s);
   }
+}
+
+int fo_conv_igemm_bf16(const fo_conv_desc* d, const void* in, const void* wp, const float* bias, const void* mask, void* out,
+                       void* stream) {
+  FO_REQUIRE(d->KD == 1 && d->padD == 0, FO_E_SHAPE, "conv_igemm_bf16: 2-D only (fo_conv_bf16 takes depth taps)");
+  FO_REQUIRE(!(d->flags & ~(FO_BIAS | FO_MASK | FO_OUT_RELU)), FO_E_SHAPE, "conv_igemm_bf16: flags other than BIAS|MASK|OUT_RELU");
+  fo_conv_desc e = *d;
+  e.T = 1;
+  return conv_bf16_impl(&e, in, wp, bias, mask, nullptr, out, stream);
+}
+
+int fo_conv_bf16(const fo_conv_desc* d, const void* in, const void* wp, const float* bias, const void* mask, const void* add, void* out,
+                 void* stream) {
+  return conv_bf16_impl(d, in, wp, bias, mask, add, out, stream);
 }
 }

@@ -39,7 +39,8 @@ __global__ void vq_prepare_kernel(const float* __restrict__ embed, float* __rest
 __global__ __launch_bounds__(512, 1) void vq_assign_kernel(const float* __restrict__ x, int ldx, long long nvec,
                                                            const float* __restrict__ embedT,
                                                            const float* __restrict__ enorm, long long* __restrict__ ind,
-                                                           float* __restrict__ qout, int ldq, float* sq_sum) {
+                                                           float* __restrict__ qout, int ldq, float* sq_sum,
+                                                           __bf16* __restrict__ qb16, int ldqb) {
   __shared__ float E[VQ_K * VQ_LD + VQ_K];
   float* En = E + VQ_K * VQ_LD;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
@@ -94,7 +95,9 @@ __global__ __launch_bounds__(512, 1) void vq_assign_kernel(const float* __restri
         const int idx = __shfl(best_i, u);
         const size_t vj = (size_t)(tile * 32 + u);
         const float diff = E[idx * VQ_LD + lane] - xg[u];
-        qout[vj * ldq + lane] = xg[u] + diff;  // input + (quantize - input).detach()   (:78)
+        const float ste = xg[u] + diff;        // input + (quantize - input).detach()   (:78)
+        qout[vj * ldq + lane] = ste;
+        if (qb16) qb16[vj * ldqb + lane] = (__bf16)ste;     // the bf16-operand engine's copy for the next conv (rounded once)
         sq = fmaf(diff, diff, sq);
       }
     }
@@ -212,16 +215,21 @@ int fo_vq_prepare(const float* embed, float* embedT, float* enorm, void* stream)
   return FO_OK;
 }
 
-int fo_vq_assign(const float* x, int ldx, int64_t nvec, const float* embedT, const float* enorm, int64_t* ind,
-                 float* q_ste, int ldq, float* sq_sum, void* stream) {
-  FO_REQUIRE(nvec > 0 && ldx >= VQ_D && ldq >= VQ_D, FO_E_SHAPE, "vq_assign: bad shape");
+int fo_vq_assign2(const float* x, int ldx, int64_t nvec, const float* embedT, const float* enorm, int64_t* ind,
+                  float* q_ste, int ldq, float* sq_sum, void* q_bf16, int ldqb, void* stream) {
+  FO_REQUIRE(nvec > 0 && ldx >= VQ_D && ldq >= VQ_D && (!q_bf16 || ldqb >= VQ_D), FO_E_SHAPE, "vq_assign: bad shape");
   const int cus = fo_cu_count();
   const int64_t ntiles = (nvec + 31) / 32;
   const int grid = (int)std::min<int64_t>(cus, (ntiles + 7) / 8);
   hipLaunchKernelGGL(vq_assign_kernel, dim3(grid), dim3(512), 0, (hipStream_t)stream, x, ldx, (long long)nvec, embedT, enorm,
-                     (long long*)ind, q_ste, ldq, sq_sum);
+                     (long long*)ind, q_ste, ldq, sq_sum, reinterpret_cast<__bf16*>(q_bf16), ldqb);
   FO_CHECK_LAUNCH();
   return FO_OK;
+}
+
+int fo_vq_assign(const float* x, int ldx, int64_t nvec, const float* embedT, const float* enorm, int64_t* ind,
+                 float* q_ste, int ldq, float* sq_sum, void* stream) {
+  return fo_vq_assign2(x, ldx, nvec, embedT, enorm, ind, q_ste, ldq, sq_sum, nullptr, 0, stream);
 }
 
 int64_t fo_vq_stats_ws_bytes(int64_t nvec) { return (int64_t)stats_blocks(nvec) * (VQ_K * VQ_D + VQ_K) * 4; }

@@ -1,0 +1,431 @@
+// Filter gradients of the bf16-operand VQ-VAE step on the gfx950 bf16 MFMA (v_mfma_f32_16x16x32_bf16): bf16 activations and bf16
+// activation gradients in, fp32 accumulation, fp32 filter gradient out in the checkpoint layout.  Replaces the cuDNN wgrad kernels
+// torch.autocast(bfloat16) would run under loss.backward() (reference train_faceoff_perceptual.py:100) for every conv of
+// models/vqvae_conv3d_latent.py:92-190.
+//
+//   dW[a][b][tap] = sum_m P[m][a] * Q[qpix(m, tap)][b]        m over the N * Hm * Wm positions of P (the tensor on the conv's OUTPUT
+//                                                             grid), qpix = (frame + kd - padD, y*stride + kh - padH, x*stride + kw - padW)
+//
+// A TN GEMM: the contraction index is the ROW of both channels-last operands, while the MFMA wants eight consecutive k per lane.
+// As in wino_wgrad_split.hip the K-step's rows are stored in LDS as they arrive, [k][channel], and gfx950's transposing LDS read
+// (ds_read_b64_tr_b16: lane i of a 16-lane block receives element i & 3 of the 8-byte chunk lane 4e + (i >> 2) addressed, e = 0..3)
+// hands each lane its fragment -- no register transposes, no 2-byte stores.
+//
+// Two forms of one kernel template:
+//  * ROW RUNS (Wm % 32 == 0: every C2 shape).  A K-step is a run of 32 consecutive output pixels of one image row; the pixels of Q
+//    that ALL the kw taps of one (kd, kh) need for it are consecutive too (32 stride + KW - stride of them), so they are staged
+//    ONCE and tap kw reads its fragments at a row offset: a workgroup owns the NKW = KW blocks dW[.][.][kd][kh][0..KW) (3 x 128 x 128
+//    for a 3x3 / 3x3x3 conv, 4 x 128 x 64 for the k4 s2 stems) over a slab of the runs.  Runs whose (frame, row) of Q is padding
+//    for this (kd, kh) are skipped whole.
+//  * GATHER (any other geometry): a K-step is 32 consecutive positions m, each row's source pixel is decoded on its own, one tap
+//    per workgroup.
+// The 8-channel image layers (enc_b.blocks.0, dec.blocks.6: Cb = 8, KW = 4) run the row-run form with the FOUR kw taps as the
+// b index: the 4 pixels x 8 channels a tap row needs are 64 contiguous bytes of the input row (b' = kw * 8 + c, "SMALLC").
+// Slabs are summed in a fixed order by wgrad_bf16_reduce_kernel (bitwise reproducible, no atomics), which also clips to the real
+// channel counts and writes [a][b][taps].
+#include <stdlib.h>
+#include <algorithm>
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+struct WArgs {
+  fo_conv_desc d;            // Cout = channels of P (a), Cin = channels of Q (b); ldOut = ldP, ldIn = ldQ; Hm/Wm = grid of P
+  const __bf16* P;
+  const __bf16* Q;
+  float* ws;                 // [slabs][taps][Apad][Bpad]
+  int tilesA, tilesB, slabs, tapRows, taps;
+  int Apad, Bpad;
+  int units;                 // row runs (or 32-position steps) in all
+  int runsPerRow;            // Wm / 32 (row-run form)
+  int inrelu;
+};
+
+__device__ __forceinline__ unsigned relu_pk(unsigned w) { return w & ~(((w & 0x80008000u) >> 15) * 0xffffu); }
+
+__device__ __forceinline__ bf16x4 tr_read(const unsigned char* p) {
+  typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+  return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p);
+}
+
+// LDS row pitch for C channels whose rows are read at a row stride S (1, or 2 for the k4 s2 stems' Q): the four rows a 16-lane
+// block reads (k, k+1, k+2, k+3 times S) must sit in four different 64-byte bank groups: pitch * S = 64 (mod 256).
+constexpr int row_pitch(int C, int S) { return S == 2 ? (2 * C + 255) / 256 * 256 + 32 : (2 * C + 255) / 256 * 256 + 64; }
+
+// TA x TB block, WA x (8 / WA) waves, NKW taps per workgroup (1, 3 or 4).  FAST: row-run form.  SMALLC: FAST with Cb = 8, KW = 4.
+template <int TA, int TB, int WA, int NKW, bool FAST, bool SMALLC>
+__global__ __launch_bounds__(512, 1) void wgrad_bf16_kernel(const WArgs a) {
+  constexpr int WB = 8 / WA;
+  constexpr int MA = TA / WA / 16, MB = TB / WB / 16;                // 16 x 16 tiles per wave
+  static_assert(MA >= 1 && MB >= 1 && TA % (WA * 16) == 0 && TB % (WB * 16) == 0, "wave tiling");
+  constexpr int S = (NKW == 4 && !SMALLC) ? 2 : 1;                   // row stride of Q in LDS (k4 s2)
+  constexpr int NQ = FAST && !SMALLC ? 32 * S + NKW - S : 32;        // rows of Q staged per K-step
+  constexpr int PA = row_pitch(TA, 1), PB = row_pitch(TB, S);
+  constexpr int SWB = S == 2 ? 4 : 3;                                // granule-swap parity bit of a Q row: (row >> SWB) & 1
+  constexpr int CA = TA / 8, CB = TB / 8;                            // 16-byte chunks per row
+  constexpr int NPA = (32 * CA + 511) / 512, NPB = (NQ * CB + 511) / 512;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[32 * PA + NQ * PB];
+  unsigned char* const As = lds;
+  unsigned char* const Bs = lds + 32 * PA;
+  const fo_conv_desc& d = a.d;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wa = wave / WB, wb = wave % WB;
+  const int l15 = lane & 15, kg = lane >> 4;
+
+  // ---- this workgroup: (slab, tap row, tile a, tile b); slabs of one (tile, tap row) are neighbours in the grid
+  int w = blockIdx.x;
+  const int tr = w % a.tapRows; w /= a.tapRows;                      // the tap rows of a slab walk the same positions together (L2)
+  const int tb = w % a.tilesB; w /= a.tilesB;
+  const int ta = w % a.tilesA;
+  const int slab = w / a.tilesA;
+  // tap row -> (kd, kh) [row-run form: all kw] or one tap (kd, kh, kw) [gather form]
+  int kd, kh, kw0;
+  if (FAST) { kd = tr / d.KH; kh = tr - kd * d.KH; kw0 = 0; }
+  else { kd = tr / (d.KH * d.KW); const int r = tr - kd * d.KH * d.KW; kh = r / d.KW; kw0 = r - kh * d.KW; }
+  const int u0 = (int)((long long)a.units * slab / a.slabs), u1 = (int)((long long)a.units * (slab + 1) / a.slabs);
+  const int HWm = d.Hm * d.Wm;
+  const int M = d.N * HWm;
+
+  // ---- loader roles: chunk id = tid + 512 i -> (row, 16-byte chunk)
+  int prow[NPA], pcol[NPA], qrow[NPB], qcol[NPB];
+#pragma unroll
+  for (int i = 0; i < NPA; ++i) { const int id = tid + 512 * i; prow[i] = id / CA; pcol[i] = id - prow[i] * CA; }
+#pragma unroll
+  for (int i = 0; i < NPB; ++i) { const int id = tid + 512 * i; qrow[i] = id / CB; qcol[i] = id - qrow[i] * CB; }
+  const int a0 = ta * TA, b0 = tb * TB;
+  u32x4 rp[NPA], rq[NPB];
+
+  // a unit's validity and its loads
+  auto unit_valid = [&](int u) -> bool {
+    if (!FAST) return true;
+    const int rowid = u / a.runsPerRow;                              // (frame, output row)
+    const int n = rowid / d.Hm, y = rowid - n * d.Hm;
+    const int t = n % d.T;
+    return ((unsigned)(t + kd - d.padD) < (unsigned)d.T) & ((unsigned)(y * d.stride + kh - d.padH) < (unsigned)d.Hin);
+  };
+  auto load = [&](int u) {
+    if (FAST) {
+      const int rowid = u / a.runsPerRow;
+      const int x0 = (u - rowid * a.runsPerRow) * 32;
+      const int n = rowid / d.Hm, y = rowid - n * d.Hm;
+      const long long pbase = ((long long)rowid * d.Wm + x0) * d.ldOut;
+      const int qy = y * d.stride + kh - d.padH, qx0 = x0 * d.stride - d.padW;
+      const long long qbase = (((long long)(n + kd - d.padD) * d.Hin + qy) * d.Win + qx0) * d.ldIn;
+#pragma unroll
+      for (int i = 0; i < NPA; ++i) {
+        const bool ok = prow[i] < 32 && a0 + pcol[i] * 8 < d.Cout;
+        rp[i] = ok ? *reinterpret_cast<const u32x4*>(a.P + pbase + (long long)prow[i] * d.ldOut + a0 + pcol[i] * 8) : u32x4{0, 0, 0, 0};
+      }
+#pragma unroll
+      for (int i = 0; i < NPB; ++i) {
+        if (SMALLC) {        // row r = output pixel x0 + r, chunk c = tap kw: input pixel 2 (x0 + r) - padW + c, its 8 channels
+          const int dx = qrow[i] * d.stride + qcol[i];               // pixels to the right of qx0
+          const bool ok = qrow[i] < 32 && (unsigned)(qx0 + dx) < (unsigned)d.Win;
+          rq[i] = ok ? *reinterpret_cast<const u32x4*>(a.Q + qbase + (long long)dx * d.ldIn) : u32x4{0, 0, 0, 0};
+        } else {
+          const int qx = qx0 + qrow[i];
+          const bool ok = qrow[i] < NQ && (unsigned)qx < (unsigned)d.Win && b0 + qcol[i] * 8 < d.Cin;
+          rq[i] = ok ? *reinterpret_cast<const u32x4*>(a.Q + qbase + (long long)qrow[i] * d.ldIn + b0 + qcol[i] * 8) : u32x4{0, 0, 0, 0};
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NPA; ++i) {
+        const int m = u * 32 + prow[i];
+        const bool ok = prow[i] < 32 && m < M && a0 + pcol[i] * 8 < d.Cout;
+        rp[i] = ok ? *reinterpret_cast<const u32x4*>(a.P + (long long)m * d.ldOut + a0 + pcol[i] * 8) : u32x4{0, 0, 0, 0};
+      }
+#pragma unroll
+      for (int i = 0; i < NPB; ++i) {
+        const int m = u * 32 + qrow[i];
+        const int mm = m < M ? m : 0;
+        const int n = mm / HWm, rem = mm - n * HWm, y = rem / d.Wm, x = rem - y * d.Wm;
+        const int t = n % d.T;
+        const int qy = y * d.stride + kh - d.padH, qx = x * d.stride + kw0 - d.padW;
+        const bool ok = qrow[i] < 32 && m < M && ((unsigned)(t + kd - d.padD) < (unsigned)d.T) && ((unsigned)qy < (unsigned)d.Hin) &&
+                        ((unsigned)qx < (unsigned)d.Win) && b0 + qcol[i] * 8 < d.Cin;
+        rq[i] = ok ? *reinterpret_cast<const u32x4*>(a.Q + (((long long)(n + kd - d.padD) * d.Hin + qy) * d.Win + qx) * d.ldIn + b0 + qcol[i] * 8)
+                   : u32x4{0, 0, 0, 0};
+      }
+    }
+  };
+  auto store = [&]() {
+#pragma unroll
+    for (int i = 0; i < NPA; ++i)
+      if (prow[i] < 32) *reinterpret_cast<u32x4*>(As + prow[i] * PA + ((pcol[i] * 16) ^ (((prow[i] >> 3) & 1) << 5))) = rp[i];
+#pragma unroll
+    for (int i = 0; i < NPB; ++i)
+      if (qrow[i] < NQ) {
+        u32x4 v = rq[i];
+        if (a.inrelu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = relu_pk(v[e]);
+        }
+        *reinterpret_cast<u32x4*>(Bs + qrow[i] * PB + ((qcol[i] * 16) ^ (((qrow[i] >> SWB) & 1) << 5))) = v;
+      }
+  };
+
+  f32x4 acc[NKW][MA][MB];
+#pragma unroll
+  for (int k = 0; k < NKW; ++k)
+#pragma unroll
+    for (int i = 0; i < MA; ++i)
+#pragma unroll
+      for (int j = 0; j < MB; ++j) acc[k][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- fragment addressing.  A: rows k = 8 kg + (l15 >> 2) (+4), channels 16 i + 4 (l15 & 3); a 16-channel tile is 32 bytes, and the
+  // granule swap of a row (XOR 32 of the byte column) exchanges neighbouring tiles: byte column = ((i ^ parity) * 32) + 8 (l15 & 3)
+  const int krow = kg * 8 + (l15 >> 2);
+  const int parA = kg & 1;                                           // ((krow) >> 3) & 1 == ((krow + 4) >> 3) & 1
+  const unsigned char* const Af = As + krow * PA + (l15 & 3) * 8;
+  const int colA = (wa * (TA / WA)) * 2, colB = (wb * (TB / WB)) * 2;     // byte column of the wave's first tile (the swap applies to the WHOLE column)
+  // B: row of LDS = k * S + kw
+  int rowB[NKW][2], parB[NKW][2];
+#pragma unroll
+  for (int k = 0; k < NKW; ++k)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int r = SMALLC ? (krow + 4 * h) : (krow + 4 * h) * S + (FAST ? k : 0);
+      rowB[k][h] = r * PB + (l15 & 3) * 8;
+      parB[k][h] = (r >> SWB) & 1;
+    }
+
+  auto compute = [&]() {
+    bf16x8 fa[MA];
+#pragma unroll
+    for (int i = 0; i < MA; ++i) {
+      const bf16x4 lo = tr_read(Af + ((colA + i * 32) ^ (parA << 5)));
+      const bf16x4 hi = tr_read(Af + 4 * PA + ((colA + i * 32) ^ (parA << 5)));
+      fa[i] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+#pragma unroll
+    for (int k = 0; k < NKW; ++k)
+#pragma unroll
+      for (int j = 0; j < MB; ++j) {
+        const bf16x4 lo = tr_read(Bs + rowB[k][0] + ((colB + j * 32) ^ (parB[k][0] << 5)));
+        const bf16x4 hi = tr_read(Bs + rowB[k][1] + ((colB + j * 32) ^ (parB[k][1] << 5)));
+        const bf16x8 fb = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+        for (int i = 0; i < MA; ++i) acc[k][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb, acc[k][i][j], 0, 0, 0);
+      }
+  };
+
+  int u = u0;
+  while (u < u1 && !unit_valid(u)) ++u;
+  if (u < u1) load(u);
+  while (u < u1) {
+    store();
+    __syncthreads();
+    int nx = u + 1;
+    while (nx < u1 && !unit_valid(nx)) ++nx;
+    if (nx < u1) load(nx);                                            // the next K-step's rows fly during the MFMAs
+    compute();
+    __syncthreads();
+    u = nx;
+  }
+
+  // ---- partial blocks -> ws[slab][tap][a][b]: accumulator register r of lane l = (a = 4 (l >> 4) + r, b = l & 15)
+#pragma unroll
+  for (int k = 0; k < NKW; ++k) {
+    const int tap = FAST ? (SMALLC ? tr : tr * NKW + k) : tr;
+    float* o = a.ws + (((long long)slab * (SMALLC ? a.tapRows : a.taps) + tap) * a.Apad + a0 + wa * (TA / WA)) * a.Bpad + b0 + wb * (TB / WB);
+#pragma unroll
+    for (int i = 0; i < MA; ++i)
+#pragma unroll
+      for (int j = 0; j < MB; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[(long long)(i * 16 + kg * 4 + r) * a.Bpad + j * 16 + l15] = acc[k][i][j][r];
+  }
+}
+
+// dw[a][b][tap] = sum over the slabs (fixed order) of ws[slab][tap][a][b], a < Areal, b < Breal.
+// smallc: ws[slab][kh][a][kw * 8 + c] -> dw[a][c][kh * 4 + kw]
+__global__ __launch_bounds__(256) void wgrad_bf16_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int slabs, int taps, int Apad, int Bpad,
+                                                               int Areal, int Breal, int smallc) {
+  const long long total = (long long)Areal * Breal * taps;
+  const long long slabStride = (long long)(smallc ? taps / 4 : taps) * Apad * Bpad;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int tap = (int)(i % taps);
+    const int b = (int)((i / taps) % Breal);
+    const int aa = (int)(i / ((long long)taps * Breal));
+    const long long src = smallc ? (((long long)(tap >> 2) * Apad + aa) * Bpad + (tap & 3) * 8 + b) : (((long long)tap * Apad + aa) * Bpad + b);
+    float s = 0.f;
+    for (int k = 0; k < slabs; ++k) s += ws[k * slabStride + src];
+    dw[i] = s;
+  }
+}
+
+// column sums of a bf16 [rows][ld] tensor (bias gradients): one workgroup per 64 channels x slab of rows, then a fixed-order reduce
+__global__ __launch_bounds__(256) void colsum_bf16_kernel(const __bf16* __restrict__ g, long long rows, int C, int ld, float* __restrict__ ws, int slabs) {
+  __shared__ float red[4][64];
+  const int c8 = threadIdx.x & 7, r0 = threadIdx.x >> 3;               // 8 lanes x 8 channels = 64 channels, 32 rows per pass
+  const int cblk = blockIdx.x % ((C + 63) / 64), slab = blockIdx.x / ((C + 63) / 64);
+  const int c = cblk * 64 + c8 * 8;
+  const long long ra = rows * slab / slabs, rb = rows * (slab + 1) / slabs;
+  float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (c < C)
+    for (long long r = ra + r0; r < rb; r += 32) {
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(g + r * ld + c);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[e] += (float)v[e];
+    }
+  // reduce the 32 row-lanes of each channel group: within a wave (8 rows) by shuffles, across the 4 waves through LDS
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    float v = s[e];
+    v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+    if ((threadIdx.x & 63) < 8) red[threadIdx.x >> 6][c8 * 8 + e] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    ws[(long long)slab * ((C + 63) / 64 * 64) + cblk * 64 + threadIdx.x] = v;
+  }
+}
+__global__ void colsum_reduce_kernel(const float* __restrict__ ws, float* __restrict__ db, int slabs, int Cpad, int Creal) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= Creal) return;
+  float s = 0.f;
+  for (int k = 0; k < slabs; ++k) s += ws[(long long)k * Cpad + c];
+  db[c] = s;
+}
+
+struct WPlan {
+  int TA, TB, NKW;
+  bool fast, smallc;
+  int tilesA, tilesB, tapRows, taps, units, slabs, Apad, Bpad;
+};
+
+int make_plan(const fo_conv_desc* d, WPlan* p) {
+  const int A = d->Cout, B = d->Cin;
+  p->taps = d->KD * d->KH * d->KW;
+  p->smallc = B == 8;
+  FO_REQUIRE(A % 8 == 0 && B % 8 == 0 && d->ldIn % 8 == 0 && d->ldOut % 8 == 0, FO_E_ALIGN, "wgrad_bf16: channel counts / strides must be multiples of 8");
+  FO_REQUIRE(d->N > 0 && d->T > 0 && d->N % d->T == 0, FO_E_SHAPE, "wgrad_bf16: N must be whole clips");
+  FO_REQUIRE((long long)d->N * d->Hm * d->Wm < (1ll << 31) && (long long)d->N * d->Hin * d->Win < (1ll << 31), FO_E_SHAPE, "wgrad_bf16: too many positions");
+  if (p->smallc) {
+    FO_REQUIRE(d->KW == 4 && d->KD == 1 && d->stride == 2 && d->ldIn == 8 && d->Wm % 32 == 0 && A % 64 == 0, FO_E_SHAPE,
+               "wgrad_bf16: 8-channel Q needs the k4 s2 image-layer geometry (KW = 4, stride 2, 16-byte pixels, Wm %% 32 == 0, Ca %% 64 == 0)");
+    p->TA = 64; p->TB = 32; p->NKW = 1; p->fast = true;
+    p->tapRows = d->KH;
+  } else {
+    p->fast = d->Wm % 32 == 0 && ((d->KW == 4 && d->stride == 2) || ((d->KW == 3 || d->KW == 1) && d->stride == 1));
+    p->NKW = p->fast ? d->KW : 1;
+    p->TA = A >= 128 ? 128 : (A > 32 ? 64 : 32);
+    p->TB = B >= 128 ? 128 : (B > 32 ? 64 : 32);
+    if (p->NKW == 4 && p->TA == 128 && p->TB == 128) p->TB = 64;      // (accumulator budget: 4 x 128 x 64)
+    if (p->TA == 32 && p->TB == 32) p->TB = 64;                       // (eight waves need eight 16 x 16 tiles)
+    p->tapRows = p->fast ? d->KD * d->KH : p->taps;
+  }
+  p->tilesA = (A + p->TA - 1) / p->TA;
+  p->tilesB = p->smallc ? 1 : (B + p->TB - 1) / p->TB;
+  p->Apad = p->tilesA * p->TA;
+  p->Bpad = p->tilesB * p->TB;
+  p->units = p->fast ? d->N * d->Hm * (d->Wm / 32) : (int)(((long long)d->N * d->Hm * d->Wm + 31) / 32);
+  const int blocks = p->tilesA * p->tilesB * p->tapRows;
+  const int cus = fo_cu_count();
+  int s = std::max(1, cus / blocks);                                  // one round of workgroups (one per CU)
+  s = std::min(s, std::max(1, p->units / 4));                         // at least 4 K-steps per slab
+  p->slabs = s;
+  return FO_OK;
+}
+
+template <int TA, int TB, int WA, int NKW, bool FAST, bool SMALLC>
+void launch_w(const WArgs& a, int grid, hipStream_t s) {
+  hipLaunchKernelGGL((wgrad_bf16_kernel<TA, TB, WA, NKW, FAST, SMALLC>), dim3(grid), dim3(512), 0, s, a);
+}
+
+}  // namespace
+
+extern "C" int64_t fo_wgrad_bf16_ws_bytes(const fo_conv_desc* d) {
+  WPlan p;
+  if (make_plan(d, &p) != FO_OK) return -1;
+  return (int64_t)p.slabs * (p.smallc ? p.tapRows : p.taps) * p.Apad * p.Bpad * 4;
+}
+
+extern "C" int fo_conv_wgrad_bf16(const fo_conv_desc* d, const void* P, const void* Q, float* dw, int Areal, int Breal, float* ws, int64_t ws_bytes,
+                                  void* stream) {
+  WPlan p;
+  const int rc = make_plan(d, &p);
+  if (rc != FO_OK) return rc;
+  FO_REQUIRE(P && Q && dw && ws && fo_aligned16(P) && fo_aligned16(Q) && fo_aligned16(ws), FO_E_ALIGN, "wgrad_bf16: 16-byte alignment");
+  FO_REQUIRE(Areal >= 1 && Areal <= d->Cout && Breal >= 1 && Breal <= d->Cin, FO_E_SHAPE, "wgrad_bf16: real channel counts out of range");
+  const int64_t need = fo_wgrad_bf16_ws_bytes(d);
+  FO_REQUIRE(ws_bytes >= need, FO_E_WORKSPACE, "wgrad_bf16: workspace of %lld bytes, %lld needed", (long long)ws_bytes, (long long)need);
+  WArgs a;
+  a.d = *d;
+  a.P = reinterpret_cast<const __bf16*>(P); a.Q = reinterpret_cast<const __bf16*>(Q); a.ws = ws;
+  a.tilesA = p.tilesA; a.tilesB = p.tilesB; a.slabs = p.slabs; a.tapRows = p.tapRows; a.taps = p.taps;
+  a.Apad = p.Apad; a.Bpad = p.Bpad; a.units = p.units; a.runsPerRow = p.fast ? d->Wm / 32 : 1;
+  a.inrelu = (d->flags & FO_IN_RELU) ? 1 : 0;
+  const int grid = p.tilesA * p.tilesB * p.tapRows * p.slabs;
+  hipStream_t s = (hipStream_t)stream;
+  const int key = p.TA * 1000 + p.TB;
+  bool ok = true;
+  if (p.smallc) launch_w<64, 32, 4, 1, true, true>(a, grid, s);
+  else if (p.fast && p.NKW == 3) {
+    if (key == 128128) launch_w<128, 128, 2, 3, true, false>(a, grid, s);
+    else if (key == 128064) launch_w<128, 64, 4, 3, true, false>(a, grid, s);
+    else if (key == 128032) launch_w<128, 32, 4, 3, true, false>(a, grid, s);
+    else if (key == 64128) launch_w<64, 128, 2, 3, true, false>(a, grid, s);
+    else if (key == 64064) launch_w<64, 64, 2, 3, true, false>(a, grid, s);
+    else if (key == 64032) launch_w<64, 32, 4, 3, true, false>(a, grid, s);
+    else if (key == 32128) launch_w<32, 128, 1, 3, true, false>(a, grid, s);
+    else if (key == 32064) launch_w<32, 64, 2, 3, true, false>(a, grid, s);
+    else ok = false;
+  } else if (p.fast && p.NKW == 4) {
+    if (key == 128064) launch_w<128, 64, 4, 4, true, false>(a, grid, s);
+    else if (key == 128032) launch_w<128, 32, 4, 4, true, false>(a, grid, s);
+    else if (key == 64128) launch_w<64, 128, 2, 4, true, false>(a, grid, s);
+    else if (key == 64064) launch_w<64, 64, 2, 4, true, false>(a, grid, s);
+    else if (key == 64032) launch_w<64, 32, 4, 4, true, false>(a, grid, s);
+    else if (key == 32128) launch_w<32, 128, 1, 4, true, false>(a, grid, s);
+    else if (key == 32064) launch_w<32, 64, 2, 4, true, false>(a, grid, s);
+    else ok = false;
+  } else if (p.fast) {                                                // NKW == 1 (1x1 convs)
+    if (key == 128128) launch_w<128, 128, 2, 1, true, false>(a, grid, s);
+    else if (key == 128064) launch_w<128, 64, 4, 1, true, false>(a, grid, s);
+    else if (key == 128032) launch_w<128, 32, 4, 1, true, false>(a, grid, s);
+    else if (key == 64128) launch_w<64, 128, 2, 1, true, false>(a, grid, s);
+    else if (key == 64064) launch_w<64, 64, 2, 1, true, false>(a, grid, s);
+    else if (key == 64032) launch_w<64, 32, 4, 1, true, false>(a, grid, s);
+    else if (key == 32128) launch_w<32, 128, 1, 1, true, false>(a, grid, s);
+    else if (key == 32064) launch_w<32, 64, 2, 1, true, false>(a, grid, s);
+    else ok = false;
+  } else {
+    if (key == 128128) launch_w<128, 128, 2, 1, false, false>(a, grid, s);
+    else if (key == 128064) launch_w<128, 64, 4, 1, false, false>(a, grid, s);
+    else if (key == 128032) launch_w<128, 32, 4, 1, false, false>(a, grid, s);
+    else if (key == 64128) launch_w<64, 128, 2, 1, false, false>(a, grid, s);
+    else if (key == 64064) launch_w<64, 64, 2, 1, false, false>(a, grid, s);
+    else if (key == 64032) launch_w<64, 32, 4, 1, false, false>(a, grid, s);
+    else if (key == 32128) launch_w<32, 128, 1, 1, false, false>(a, grid, s);
+    else if (key == 32064) launch_w<32, 64, 2, 1, false, false>(a, grid, s);
+    else ok = false;
+  }
+  FO_REQUIRE(ok, FO_E_SHAPE, "wgrad_bf16: no kernel for a %d x %d block with %d taps per workgroup", p.TA, p.TB, p.NKW);
+  FO_CHECK_LAUNCH();
+  const long long total = (long long)Areal * Breal * p.taps;
+  const int rblocks = (int)std::min<long long>((total + 255) / 256, 8LL * fo_cu_count());
+  hipLaunchKernelGGL(wgrad_bf16_reduce_kernel, dim3(rblocks), dim3(256), 0, s, ws, dw, p.slabs, p.taps, p.Apad, p.Bpad, Areal, Breal, p.smallc ? 1 : 0);
+  FO_CHECK_LAUNCH();
+  return FO_OK;
+}
+
+// db[c] = sum over the rows of g[row][c] (c < Creal), g bf16 [rows][ld]; ws: at least fo_bias_grad_bf16_ws_bytes(C) bytes
+extern "C" int64_t fo_bias_grad_bf16_ws_bytes(int C) { return (int64_t)256 * ((C + 63) / 64 * 64) * 4; }
+extern "C" int fo_bias_grad_bf16(const void* g, float* db, int64_t rows, int C, int Creal, int ld, float* ws, void* stream) {
+  FO_REQUIRE(g && db && ws && rows > 0 && C % 8 == 0 && ld % 8 == 0 && Creal <= C && fo_aligned16(g), FO_E_SHAPE, "bias_grad_bf16: bad arguments");
+  const int cblks = (C + 63) / 64;
+  const int slabs = (int)std::max<int64_t>(1, std::min<int64_t>(256, std::min<int64_t>(rows / 64, 4 * (int64_t)fo_cu_count() / cblks)));
+  hipLaunchKernelGGL(colsum_bf16_kernel, dim3(cblks * slabs), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const __bf16*>(g), (long long)rows, C, ld, ws,
+                     slabs);
+  FO_CHECK_LAUNCH();
+  hipLaunchKernelGGL(colsum_reduce_kernel, dim3((Creal + 63) / 64), dim3(64), 0, (hipStream_t)stream, ws, db, slabs, cblks * 64, Creal);
+  FO_CHECK_LAUNCH();
+  return FO_OK;
+}

@@ -12,7 +12,7 @@ import os as _os
 import torch
 
 from . import _lib
-from ._lib import ConvDesc, FO_IN_RELU, FO_BIAS, FO_MASK, FO_ADD, FO_OUT_RELU, FO_DEPTH2SPACE  # noqa: F401
+from ._lib import ConvDesc, FO_IN_RELU, FO_BIAS, FO_MASK, FO_ADD, FO_OUT_RELU, FO_DEPTH2SPACE, FO_OUT_F32  # noqa: F401
 
 
 class KernelProfiler:
@@ -583,6 +583,146 @@ def conv_bf16(x, wp, bias, out, *, k=(3, 3), stride=1, pad=(1, 1), cin=None, cou
     _lib.call("fo_conv_igemm_bf16", C.byref(d), _ptr(x), _ptr(wp), _ptr(bias), _ptr(mask), _ptr(out), _stream())
     if prof is not None:
         prof.end()
+
+
+# ------------------------------------------------------------------ bf16-operand VQ-VAE step (csrc/conv_bf16.hip, wgrad_bf16.hip, bf16_ops.hip)
+BF = torch.bfloat16
+
+
+def to_bf16(x, out=None):
+    """fp32 -> bf16 (round to nearest even) of a dense tensor or a channels-last view (last dim % 8 == 0)."""
+    Cc = x.shape[-1]
+    if out is None:
+        out = torch.empty(x.shape, device=x.device, dtype=BF)
+    if x.dim() == 1:
+        _lib.call("fo_f32_to_bf16", _ptr(x), C.c_int64(Cc), _ptr(out), C.c_int64(Cc), C.c_int64(1), Cc, _stream())
+        return out
+    rows = x.numel() // Cc
+    _lib.call("fo_f32_to_bf16", _ptr(x), C.c_int64(ld_of(x)), _ptr(out), C.c_int64(ld_of(out, BF)), C.c_int64(rows), Cc, _stream())
+    return out
+
+
+def to_f32(x, out=None):
+    Cc = x.shape[-1]
+    if out is None:
+        out = torch.empty(x.shape, device=x.device, dtype=torch.float32)
+    rows = x.numel() // Cc
+    _lib.call("fo_bf16_to_f32", _ptr(x), C.c_int64(ld_of(x, BF)), _ptr(out), C.c_int64(ld_of(out)), C.c_int64(rows), Cc, _stream())
+    return out
+
+
+def cat_nchw_to_nhwc8_bf16(a, b=None):
+    """process_data's channel concatenation + layout change + rounding of the network input: [N,Ca,H,W] (+ [N,Cb,H,W]) fp32 -> bf16 [N,H,W,8]"""
+    N, Ca, H, W = a.shape
+    Cb = 0 if b is None else b.shape[1]
+    assert Ca + Cb <= 8 and (b is None or b.shape == (N, Cb, H, W))
+    y = torch.empty((N, H, W, 8), device=a.device, dtype=BF)
+    _lib.call("fo_nchw2_to_nhwc8_bf16", _ptr(dense_f32(a, "source frames")), Ca, _ptr(None if b is None else dense_f32(b, "background frames")), Cb, _ptr(y),
+              N, H, W, _stream())
+    return y
+
+
+def conv_bf16g(x, wp, bias, out, *, T=1, k=(1, 3, 3), stride=1, pad=(0, 1, 1), cin=None, cout=None, flags=0, mask=None, add=None, ostride=1,
+               oph=(0, 0), mgrid=None):
+    """One fo_conv_bf16 launch: bf16 x / wp / mask / add (channels-last views), fp32 bias; out bf16, or fp32 (FO_OUT_F32 is set from its dtype)."""
+    N, Hin, Win, _ = x.shape
+    _, Hout, Wout, _ = out.shape
+    Hm, Wm = mgrid if mgrid is not None else (Hout, Wout)
+    if bias is not None:
+        flags |= FO_BIAS
+    if mask is not None:
+        flags |= FO_MASK
+    if add is not None:
+        flags |= FO_ADD
+    if out.dtype == torch.float32:
+        flags |= FO_OUT_F32
+    d = _desc(N=N, T=T, Hin=Hin, Win=Win, Hm=Hm, Wm=Wm, Hout=Hout, Wout=Wout,
+              Cin=cin if cin is not None else x.shape[-1], Cout=cout if cout is not None else out.shape[-1],
+              KD=k[0], KH=k[1], KW=k[2], stride=stride, padD=pad[0], padH=pad[1], padW=pad[2], ostride=ostride, ophH=oph[0], ophW=oph[1],
+              ldIn=ld_of(x, BF), ldOut=ld_of(out, out.dtype), ldMask=ld_of(mask, BF) if mask is not None else 0,
+              ldAdd=ld_of(add, BF) if add is not None else 0, flags=flags)
+    prof = PROFILER
+    if prof is not None:
+        nominal = 2.0 * N * Hm * Wm * d.Cout * (k[0] * k[1] * k[2] * d.Cin)
+        same = stride == 1 and ostride == 1 and (Hm, Wm) == (Hout, Wout) == (Hin, Win) and not (flags & FO_DEPTH2SPACE)
+        kname = "conv_bf16_big" if (same and d.Cout % 128 == 0 and d.Cin >= 32 and not (flags & FO_IN_RELU)) else (
+            "conv_bf16_bn%d%s" % (128 if d.Cout > 64 else (64 if d.Cout > 32 else 32), "_c8" if d.Cin < 32 else ""))
+        if prof.detail:
+            kname += f" [{N}x{Hm}x{Wm} {d.Cin}->{d.Cout} k{k[0]}{k[1]}{k[2]} s{stride} f{flags}]"
+        prof.begin(kname, nominal * (temporal_share(T, k[0], pad[0]) if k[0] > 1 else 1.0), nominal)
+    _lib.call("fo_conv_bf16", C.byref(d), _ptr(x), _ptr(wp), _ptr(bias), _ptr(mask), _ptr(add), _ptr(out), _stream())
+    if prof is not None:
+        prof.end()
+
+
+def convT_fused_bf16(x, wpf, bias, out, *, cin, cout, flags=0):
+    """k4 s2 p1 transposed conv with cout <= 8 as ONE launch (cell form, see convT_fused): out [N, 2H, 2W, >= 8], fp32 or bf16."""
+    N, Hi, Wi, _ = x.shape
+    conv_bf16g(x, wpf, bias, out, k=(1, 2, 2), stride=1, pad=(0, 1, 1), cin=cin, cout=32, flags=flags | FO_DEPTH2SPACE, mgrid=(Hi + 1, Wi + 1),
+               oph=(1, cout))
+
+
+def convT_phases_bf16(x, wp4, bias, out, *, cin, cout, flags=0, mask=None, add=None):
+    """k4 s2 p1 transposed conv (or the dgrad of a k4 s2 p1 conv) as 4 sub-pixel launches (bf16 operands)."""
+    N, Hi, Wi, _ = x.shape
+    per_phase = pad_out(cout) * 4 * cin
+    for ph in range(4):
+        py, px = ph >> 1, ph & 1
+        conv_bf16g(x, wp4[ph * per_phase:(ph + 1) * per_phase], bias, out, k=(1, 2, 2), stride=1, pad=(0, 1 - py, 1 - px), cin=cin, cout=cout,
+                   flags=flags, mask=mask, add=add, ostride=2, oph=(py, px), mgrid=(Hi, Wi))
+
+
+def conv_wgrad_bf16(P, Q, dw, dbias, *, T=1, k=(1, 3, 3), stride=1, pad=(0, 1, 1), a_real, b_real, in_relu=False):
+    """dW[a][b][tap] (fp32) = sum_m P[m][a] Q[qpix(m,tap)][b] from bf16 P, Q; dbias (optional, fp32) = colsum(P)."""
+    N, Hm, Wm, Ca = P.shape
+    _, Hq, Wq, Cb = Q.shape
+    d = _desc(N=N, T=T, Hin=Hq, Win=Wq, Hm=Hm, Wm=Wm, Hout=Hm, Wout=Wm, Cin=Cb, Cout=Ca, KD=k[0], KH=k[1], KW=k[2], stride=stride,
+              padD=pad[0], padH=pad[1], padW=pad[2], ostride=1, ophH=0, ophW=0, ldIn=ld_of(Q, BF), ldOut=ld_of(P, BF), ldMask=0, ldAdd=0,
+              flags=FO_IN_RELU if in_relu else 0)
+    nbytes = _lib.load().fo_wgrad_bf16_ws_bytes(C.byref(d))
+    if nbytes < 0:
+        _lib.check(-1, "fo_wgrad_bf16_ws_bytes")
+    ws = _workspace(nbytes, P.device)
+    prof = PROFILER
+    if prof is not None:
+        wname = "wgrad_bf16_%dx%d" % (Ca, Cb)
+        if prof.detail:
+            wname += f" [{N}x{Hm}x{Wm} k{k[0]}{k[1]}{k[2]} s{stride}]"
+        nominal = 2.0 * N * Hm * Wm * Ca * Cb * k[0] * k[1] * k[2]
+        prof.begin(wname, nominal * (temporal_share(T, k[0], pad[0]) if k[0] > 1 else 1.0), nominal)
+    _lib.call("fo_conv_wgrad_bf16", C.byref(d), _ptr(P), _ptr(Q), _ptr(dw), a_real, b_real, _ptr(ws), C.c_int64(ws.numel() * 4), _stream())
+    if prof is not None:
+        prof.end()
+    if dbias is not None:
+        bias_grad_bf16(P, dbias, a_real)
+
+
+def bias_grad_bf16(g, dbias, c_real):
+    rows = g.shape[0] * g.shape[1] * g.shape[2]
+    Cc = g.shape[-1]
+    ws = _workspace(_lib.load().fo_bias_grad_bf16_ws_bytes(Cc), g.device)
+    _lib.call("fo_bias_grad_bf16", _ptr(g), _ptr(dbias), C.c_int64(rows), Cc, c_real, ld_of(g, BF), _ptr(ws), _stream())
+
+
+def vq_assign_bf16out(x, embedT, enorm, q_f32, q_bf16, stats, train):
+    """vq_assign on the fp32 input x, writing the straight-through output both as fp32 (q_f32, kept for the backward) and as bf16
+    (q_bf16: the operand of the next convolution; may be a channel slice)."""
+    nvec = x.shape[0] * x.shape[1] * x.shape[2]
+    ind = torch.empty(x.shape[:-1], device=x.device, dtype=torch.int64)
+    _lib.call("fo_vq_assign2", _ptr(x), ld_of(x), C.c_int64(nvec), _ptr(embedT), _ptr(enorm), _ptr(ind), _ptr(q_f32), ld_of(q_f32), _ptr(stats[0:1]),
+              _ptr(q_bf16), ld_of(q_bf16, BF), _stream())
+    if train:
+        nbytes = _lib.load().fo_vq_stats_ws_bytes(C.c_int64(nvec))
+        ws = _workspace(nbytes, x.device)
+        _lib.call("fo_vq_stats", _ptr(x), ld_of(x), C.c_int64(nvec), _ptr(ind), _ptr(stats[1:513]), _ptr(stats[513:]), _ptr(ws), _stream())
+    return ind
+
+
+def vq_bwd_bf16(gq, x, q, gdiff, gx):
+    """gx (bf16) = bf16(gq (bf16) + gdiff * 2 / numel * (x - q)), x and q fp32"""
+    nvec = x.shape[0] * x.shape[1] * x.shape[2]
+    _lib.call("fo_vq_bwd_bf16", _ptr(gq), ld_of(gq, BF), _ptr(x), ld_of(x), _ptr(q), ld_of(q), _ptr(gdiff), C.c_float(2.0 / (nvec * 64)), _ptr(gx),
+              ld_of(gx, BF), C.c_int64(nvec), _stream())
 
 
 def convT_fused(x, wpf, bias, out, *, cin, cout, flags=0):

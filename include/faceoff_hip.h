@@ -49,6 +49,8 @@ extern "C" {
                              (fo_pack_convT_k4s2_fused); column ph*8+c of input pixel (y,x) lands at output pixel
                              (2y+ph/2, 2x+ph%2), channel c.  desc: Cout=32, Hout=2*Hm, ldOut>=8, ophW = real channels; ophH = 1: the cell form
                              (fo_pack_convT_k4s2_cells), Hout = 2*(Hm-1) */
+#define FO_OUT_F32 64  /* fo_conv_bf16 only: the result is stored as fp32 (ldOut in floats) instead of being rounded to bf16 -- the
+                          quantisers' inputs (quantize_conv_t / _b, :208,213: VQ distances and arg-min stay fp32) and the decoder output */
 
 int fo_version(void);
 const char* fo_last_error(void);
@@ -361,6 +363,42 @@ int fo_pack_conv_dgrad_bf16(const float* w, void* wp, int O, int I, int taps, in
  * to 128 (Cout > 64), 64 (Cout > 32) or 32.  flags: FO_BIAS | FO_MASK (mask = bf16 activation, > 0) | FO_OUT_RELU. */
 int fo_conv_igemm_bf16(const fo_conv_desc* d, const void* in, const void* wp, const float* bias, const void* mask, void* out,
                        void* stream);
+/* ---------------------------------------------------------------- bf16-operand VQ-VAE step (BASELINE config 3 as SURVEY 8(d) defines it)
+ * The VQ-VAE's own convolutions with bf16 MFMA operands, fp32 accumulation, fp32 master weights and fp32 VQ: activations and
+ * activation gradients are STORED as bf16 (rounded once, after bias / ReLU mask / residual or fan-in add / ReLU were applied in
+ * fp32 to the accumulator), filters are rounded from the fp32 master copy every step, filter and bias gradients stay fp32.
+ *
+ * fo_conv_bf16 = fo_conv_igemm_bf16 with the whole fo_conv_desc honoured: depth taps (KD = 3, clips of d->T frames: reference
+ * nn.Conv3d :181,185; the taps of a row tile that see nothing but clip padding are skipped), stride 2, sub-pixel phases
+ * (ostride / oph*), Cin % 32 == 0 for the same-size stride-1 forms with Cout % 128 == 0 (else Cin % 64 == 0, or 8), and the flags
+ * FO_IN_RELU (Cout <= 32 forms only: the operand is staged through registers), FO_BIAS, FO_MASK, FO_ADD (bf16 tensor, ldAdd),
+ * FO_OUT_RELU, FO_DEPTH2SPACE (Cout == 32) and FO_OUT_F32.  Replaces the cuDNN kernels torch.autocast(bfloat16) would pick for
+ * models/vqvae_conv3d_latent.py:92-190 and their autograd data gradients. */
+int fo_conv_bf16(const fo_conv_desc* d, const void* in, const void* wp, const float* bias, const void* mask, const void* add, void* out,
+                 void* stream);
+/* Filter gradient of the same convolutions: dw[a][b][taps] (fp32, the checkpoint layout; a < Areal, b < Breal) =
+ * sum_m P[m][a] * Q[qpix(m,tap)][b] with bf16 P (the tensor on the conv's output grid: d->Cout channels, row stride d->ldOut, grid
+ * d->Hm x d->Wm) and bf16 Q (d->Cin channels, d->ldIn, d->Hin x d->Win), fp32 accumulation (csrc/wgrad_bf16.hip).  Same descriptor
+ * convention as fo_conv_wgrad; FO_IN_RELU applies relu() to Q as it is staged.  Channel counts are multiples of 8; an 8-channel Q
+ * (the image layers) needs the k4 s2 geometry.  ws: fo_wgrad_bf16_ws_bytes(d) bytes of scratch, private to the stream. */
+int64_t fo_wgrad_bf16_ws_bytes(const fo_conv_desc* d);
+int fo_conv_wgrad_bf16(const fo_conv_desc* d, const void* P, const void* Q, float* dw, int Areal, int Breal, float* ws, int64_t ws_bytes,
+                       void* stream);
+/* db[c] = sum over the rows of the bf16 tensor g[rows][ld] (bias gradients), c < Creal <= C. */
+int64_t fo_bias_grad_bf16_ws_bytes(int C);
+int fo_bias_grad_bf16(const void* g, float* db, int64_t rows, int C, int Creal, int ld, float* ws, void* stream);
+/* Row-strided conversions, C % 8 == 0 (strides in elements of the respective type). */
+int fo_f32_to_bf16(const float* x, int64_t ldx, void* y, int64_t ldy, int64_t rows, int C, void* stream);
+int fo_bf16_to_f32(const void* x, int64_t ldx, float* y, int64_t ldy, int64_t rows, int C, void* stream);
+/* fo_nchw2_to_nhwc8 with the result rounded to bf16 (the network input of the bf16-operand engine; utils.py:32). */
+int fo_nchw2_to_nhwc8_bf16(const float* a, int Ca, const float* b, int Cb, void* y, int N, int H, int W, void* stream);
+/* fo_vq_assign that also writes a bf16 copy of the straight-through output (q_bf16 [nvec][ldqb], may be NULL): the quantiser itself
+ * -- distances, arg-min, gather, commitment sum -- runs in fp32 on the fp32 input exactly as fo_vq_assign. */
+int fo_vq_assign2(const float* x, int ldx, int64_t nvec, const float* embedT, const float* enorm, int64_t* ind, float* q_ste, int ldq,
+                  float* sq_sum, void* q_bf16, int ldqb, void* stream);
+/* fo_vq_bwd with bf16 gradients: gx = bf16(gq + gdiff[0] * scale * (x - q)); gq, gx bf16, x and q fp32. */
+int fo_vq_bwd_bf16(const void* gq, int ldg, const float* x, int ldx, const float* q, int ldq, const float* gdiff, float scale, void* gx,
+                   int ldgx, int64_t nvec, void* stream);
 int fo_lpips_prep_bf16(const float* src, int src_is_nhwc, int ld, void* y, int N, int H, int W, const float* shift3,
                        const float* scale3, void* stream);
 int fo_lpips_prep_bwd_bf16(const void* g /* [npix][8] */, float* gdec, int ldd, int64_t npix, const float* scale3,

@@ -1,0 +1,283 @@
+"""The kernels of the bf16-operand VQ-VAE step (BASELINE config 3 as SURVEY.md 8(d) defines it), each through the C ABI against torch-CPU
+fp32 convolutions of the SAME bf16-rounded operands (products of bf16 numbers are exact in fp32, so what differs is the fp32 summation
+order and the one final rounding of a stored bf16 result):
+  * bf16 outputs: within one bf16 ulp of the fp32 reference (2^-8 relative) + 1e-3 of the tensor's scale for cancelling sums;
+  * fp32 outputs (quantiser inputs, decoder output, filter / bias gradients): 2e-5 of the tensor's scale.
+Geometries: every conv form of models/vqvae_conv3d_latent.py:92-190 -- Conv3d k3 (T = 1, 2, 3, 5), k3 s1, k4 s2, 1x1 (32, 128 and 192 input
+channels), the 8-channel image layer, transposed k4 s2 as four phases and as the one-launch cell form -- forward, data gradient with ReLU
+mask / fan-in add, and filter gradient in both its forms (row runs; gather for widths that are not multiples of 32)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+def rb(t):
+    return t.bfloat16().float()
+
+
+def nhwc(t):            # [N,C,H,W] fp32 (bf16-representable) -> bf16 channels-last on the GPU
+    return t.permute(0, 2, 3, 1).contiguous().to(BF).cuda()
+
+
+def back(t):            # channels-last GPU tensor -> [N,C,H,W] fp32 on the CPU
+    return t.float().cpu().permute(0, 3, 1, 2)
+
+
+def close_bf16(got, ref, what=""):
+    got, ref = got.float(), ref.float()
+    tol = ref.abs() * 2.0 ** -8 + 1e-3 * ref.abs().max()
+    bad = (got - ref).abs() > tol
+    assert not bad.any(), f"{what}: {int(bad.sum())} of {bad.numel()} off, worst {((got - ref).abs() / tol).max().item():.2f} x tol"
+
+
+def close_f32(got, ref, tol=2e-5, what=""):
+    err = (got.float() - ref.float()).abs().max().item() / (ref.abs().max().item() + 1e-30)
+    assert err <= tol, f"{what}: rel err {err:.2e}"
+
+
+def gen(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def packed_bf16(w_packed_f32):
+    from faceoff_amd import ops
+    return ops.to_bf16(w_packed_f32)
+
+
+# ------------------------------------------------------------------------------------------------ forward / data gradient
+@pytest.mark.parametrize("T", [1, 2, 3, 5])
+@pytest.mark.parametrize("big", [False, True])
+def test_conv3d_forward_and_data_gradient(T, big, monkeypatch):
+    """nn.Conv3d(128, 128, 3, padding=1) (:181) on clips of T frames: forward with bias + ReLU, data gradient with ReLU mask + fan-in add,
+    on the 128-row tiles and (FACEOFF_BF16_BIG_TILES) on the 256-row ping-pong kernel that the C2 shapes take (both skip the depth taps
+    that only see clip padding)."""
+    from faceoff_amd import ops
+    if big:
+        monkeypatch.setenv("FACEOFF_BF16_BIG_TILES", "1")
+    g = gen(10 + T)
+    B, H, W, Cc = 2, 16, 16, 128
+    N = B * T
+    x = rb(torch.randn((N, Cc, H, W), generator=g))
+    w = rb(torch.randn((Cc, Cc, 3, 3, 3), generator=g) / np.sqrt(27 * Cc))
+    b = torch.randn(Cc, generator=g)
+    x5 = x.reshape(B, T, Cc, H, W).permute(0, 2, 1, 3, 4)
+    ref = F.relu(F.conv3d(x5, w, b, padding=1)).permute(0, 2, 1, 3, 4).reshape(N, Cc, H, W)
+    wp = packed_bf16(ops.pack_conv(w.reshape(Cc, Cc, 27).cuda()))
+    out = torch.empty((N, H, W, Cc), device="cuda", dtype=BF)
+    ops.conv_bf16g(nhwc(x), wp, b.cuda(), out, T=T, k=(3, 3, 3), pad=(1, 1, 1), cin=Cc, cout=Cc, flags=ops.FO_OUT_RELU)
+    close_bf16(back(out), ref, "conv3d forward")
+    # data gradient: conv of the output gradient with the flipped, transposed filter; * (mask > 0) + add
+    gy = rb(torch.randn((N, Cc, H, W), generator=g))
+    mask = rb(torch.randn((N, Cc, H, W), generator=g))
+    add = rb(torch.randn((N, Cc, H, W), generator=g))
+    gy5 = gy.reshape(B, T, Cc, H, W).permute(0, 2, 1, 3, 4)
+    gref = F.conv_transpose3d(gy5, w, padding=1).permute(0, 2, 1, 3, 4).reshape(N, Cc, H, W) * (mask > 0) + add
+    wpd = packed_bf16(ops.pack_conv_dgrad(w.reshape(Cc, Cc, 27).cuda()))
+    gin = torch.empty((N, H, W, Cc), device="cuda", dtype=BF)
+    ops.conv_bf16g(nhwc(gy), wpd, None, gin, T=T, k=(3, 3, 3), pad=(1, 1, 1), cin=Cc, cout=Cc, mask=nhwc(mask), add=nhwc(add))
+    close_bf16(back(gin), gref, "conv3d data gradient")
+
+
+@pytest.mark.parametrize("cin,cout,H", [(64, 128, 32), (128, 64, 16), (8, 64, 64)])
+def test_conv_k4s2_forward(cin, cout, H):
+    """nn.Conv2d(k=4, s=2, p=1) (:109,111,118): the stems, incl. the 8-channel image layer"""
+    from faceoff_amd import ops
+    g = gen(cin + cout)
+    N, creal = 3, (6 if cin == 8 else cin)
+    x = torch.zeros((N, cin, H, H))
+    x[:, :creal] = rb(torch.randn((N, creal, H, H), generator=g))
+    w = rb(torch.randn((cout, creal, 4, 4), generator=g) / np.sqrt(16 * creal))
+    b = torch.randn(cout, generator=g)
+    ref = F.relu(F.conv2d(x[:, :creal], w, b, stride=2, padding=1))
+    wp = packed_bf16(ops.pack_conv(w.cuda()))
+    out = torch.empty((N, H // 2, H // 2, cout), device="cuda", dtype=BF)
+    ops.conv_bf16g(nhwc(x), wp, b.cuda(), out, k=(1, 4, 4), stride=2, pad=(0, 1, 1), cin=cin, cout=cout, flags=ops.FO_OUT_RELU)
+    close_bf16(back(out), ref, f"k4s2 {cin}->{cout}")
+
+
+def test_transposed_conv_phases_into_a_channel_slice_and_its_data_gradient():
+    """nn.ConvTranspose2d(128, 64, 4, stride=2, padding=1) (:157) as four sub-pixel launches writing channels 0..63 of a 192-channel
+    buffer (torch.cat([dec_t, enc_b], 1), :271); and its data gradient = a k4 s2 conv of the output gradient slice, with ReLU mask."""
+    from faceoff_amd import ops
+    g = gen(3)
+    N, ci, co, h = 2, 128, 64, 16
+    x = rb(torch.randn((N, ci, h, h), generator=g))
+    w = rb(torch.randn((ci, co, 4, 4), generator=g) / np.sqrt(4 * ci))
+    b = torch.randn(co, generator=g)
+    ref = F.conv_transpose2d(x, w, b, stride=2, padding=1)
+    cat = torch.full((N, 2 * h, 2 * h, 192), 7.0, device="cuda", dtype=BF)
+    ops.convT_phases_bf16(nhwc(x), packed_bf16(ops.pack_convT(w.cuda())), b.cuda(), cat[..., 0:64], cin=ci, cout=co)
+    close_bf16(back(cat[..., 0:64]), ref, "convT phases")
+    assert bool((cat[..., 64:] == 7.0).all())
+    gy = rb(torch.randn((N, 192, 2 * h, 2 * h), generator=g))
+    mask = rb(torch.randn((N, ci, h, h), generator=g))
+    gref = F.conv2d(gy[:, :64], w, stride=2, padding=1) * (mask > 0)
+    gin = torch.empty((N, h, h, ci), device="cuda", dtype=BF)
+    ops.conv_bf16g(nhwc(gy)[..., 0:64], packed_bf16(ops.pack_conv(w.cuda())), None, gin, k=(1, 4, 4), stride=2, pad=(0, 1, 1), cin=co, cout=ci,
+                   mask=nhwc(mask))
+    close_bf16(back(gin), gref, "convT data gradient")
+
+
+def test_resblock_pair_of_launches():
+    """ResBlock (:86-101): h = relu(conv3x3(relu(x)) + b1) with the leading ReLU applied as the operand is staged (FO_IN_RELU, 128 -> 32),
+    out = relu(conv1x1(h) + b3 + x) (32 input channels: the 256-row kernel's 32-deep K tiles; residual add + trailing ReLU in the epilogue)."""
+    from faceoff_amd import ops
+    g = gen(4)
+    N, Cc, H = 2, 128, 16
+    x = rb(torch.randn((N, Cc, H, H), generator=g))
+    w1 = rb(torch.randn((32, Cc, 3, 3), generator=g) / np.sqrt(9 * Cc))
+    b1 = torch.randn(32, generator=g) * 0.1
+    w3 = rb(torch.randn((Cc, 32, 1, 1), generator=g) / np.sqrt(32))
+    b3 = torch.randn(Cc, generator=g) * 0.1
+    h_ref = F.relu(F.conv2d(F.relu(x), w1, b1, padding=1))
+    hb = torch.empty((N, H, H, 32), device="cuda", dtype=BF)
+    ops.conv_bf16g(nhwc(x), packed_bf16(ops.pack_conv(w1.cuda())), b1.cuda(), hb, cin=Cc, cout=32, flags=ops.FO_IN_RELU | ops.FO_OUT_RELU)
+    close_bf16(back(hb), h_ref, "resblock 3x3")
+    out_ref = F.relu(F.conv2d(hb.float().cpu().permute(0, 3, 1, 2), w3, b3) + x)
+    out = torch.empty((N, H, H, Cc), device="cuda", dtype=BF)
+    ops.conv_bf16g(hb, packed_bf16(ops.pack_conv(w3.cuda())), b3.cuda(), out, k=(1, 1, 1), pad=(0, 0, 0), cin=32, cout=Cc, flags=ops.FO_OUT_RELU,
+                   add=nhwc(x))
+    close_bf16(back(out), out_ref, "resblock 1x1 + residual")
+    # data gradients of the pair: 1x1 128 -> 32 with the hidden ReLU's mask, 3x3 32 -> 128 with the input ReLU's mask + the residual's gradient
+    gy = rb(torch.randn((N, Cc, H, H), generator=g))
+    gh_ref = F.conv_transpose2d(gy, w3) * (hb.float().cpu().permute(0, 3, 1, 2) > 0)
+    gh = torch.empty((N, H, H, 32), device="cuda", dtype=BF)
+    ops.conv_bf16g(nhwc(gy), packed_bf16(ops.pack_conv_dgrad(w3.reshape(Cc, 32, 1).cuda())), None, gh, k=(1, 1, 1), pad=(0, 0, 0), cin=Cc, cout=32, mask=hb)
+    close_bf16(back(gh), gh_ref, "resblock 1x1 data gradient")
+    gx_ref = F.conv_transpose2d(gh.float().cpu().permute(0, 3, 1, 2), w1, padding=1) * (x > 0) + gy
+    gx = torch.empty((N, H, H, Cc), device="cuda", dtype=BF)
+    ops.conv_bf16g(gh, packed_bf16(ops.pack_conv_dgrad(w1.reshape(32, Cc, 9).cuda())), None, gx, cin=32, cout=Cc, mask=nhwc(x), add=nhwc(gy))
+    close_bf16(back(gx), gx_ref, "resblock 3x3 data gradient")
+
+
+def test_quantize_conv_1x1_192_channels_fp32_output():
+    """quantize_conv_b (:213): 1x1, 192 -> 64 on the concatenated buffer, result kept in fp32 (FO_OUT_F32) for the quantiser"""
+    from faceoff_amd import ops
+    g = gen(5)
+    N, H = 2, 24
+    x = rb(torch.randn((N, 192, H, H), generator=g))
+    w = rb(torch.randn((64, 192, 1, 1), generator=g) / np.sqrt(192))
+    b = torch.randn(64, generator=g)
+    ref = F.conv2d(x, w, b)
+    out = torch.empty((N, H, H, 64), device="cuda", dtype=torch.float32)
+    ops.conv_bf16g(nhwc(x), packed_bf16(ops.pack_conv(w.cuda())), b.cuda(), out, k=(1, 1, 1), pad=(0, 0, 0), cin=192, cout=64)
+    close_f32(back(out), ref, 2e-5, "quantize_conv_b")
+
+
+def test_last_transposed_conv_as_one_cell_form_launch_fp32_output():
+    """dec.blocks.6 (:152): ConvTranspose2d(64, 6, 4, 2, 1) as ONE launch (k2 conv over the cell grid, depth-to-space epilogue), fp32 result"""
+    from faceoff_amd import ops
+    g = gen(6)
+    N, h = 2, 24
+    x = rb(torch.randn((N, 64, h, h), generator=g))
+    w = rb(torch.randn((64, 6, 4, 4), generator=g) / 16)
+    b = torch.randn(6, generator=g)
+    ref = F.conv_transpose2d(x, w, b, stride=2, padding=1)
+    out = torch.full((N, 2 * h, 2 * h, 8), 5.0, device="cuda", dtype=torch.float32)
+    ops.convT_fused_bf16(nhwc(x), packed_bf16(ops.pack_convT_fused(w.cuda())), b.cuda(), out, cin=64, cout=6)
+    close_f32(back(out)[:, :6], ref, 2e-5, "dec.blocks.6")
+    assert bool((out[..., 6:] == 0).all())                  # the two padding channels are written as zeros
+    # its data gradient: k4 s2 conv over the 8-channel gradient (16-byte pixels), 8 -> 64 with ReLU mask
+    gy = torch.zeros((N, 8, 2 * h, 2 * h))
+    gy[:, :6] = rb(torch.randn((N, 6, 2 * h, 2 * h), generator=g))
+    mask = rb(torch.randn((N, 64, h, h), generator=g))
+    gref = F.conv2d(gy[:, :6], w, stride=2, padding=1) * (mask > 0)
+    gin = torch.empty((N, h, h, 64), device="cuda", dtype=BF)
+    ops.conv_bf16g(nhwc(gy), packed_bf16(ops.pack_conv(w.cuda())), None, gin, k=(1, 4, 4), stride=2, pad=(0, 1, 1), cin=8, cout=64, mask=nhwc(mask))
+    close_bf16(back(gin), gref, "dec.blocks.6 data gradient")
+
+
+# ------------------------------------------------------------------------------------------------ filter gradients
+def _wgrad_case(seed, N, T, ca, cb, k, stride, pad, Hm, Wm, in_relu=False, ca_real=None, cb_real=None):
+    from faceoff_amd import ops
+    g = gen(seed)
+    kd, kh, kw = k
+    Hq, Wq = (Hm - 1) * stride + kh - 2 * pad[1], (Wm - 1) * stride + kw - 2 * pad[2]
+    if stride == 2:
+        Hq, Wq = 2 * Hm, 2 * Wm
+    ca_real, cb_real = ca_real or ca, cb_real or cb
+    P = torch.zeros((N, ca, Hm, Wm))
+    P[:, :ca_real] = rb(torch.randn((N, ca_real, Hm, Wm), generator=g))
+    Q = torch.zeros((N, cb, Hq, Wq))
+    Q[:, :cb_real] = rb(torch.randn((N, cb_real, Hq, Wq), generator=g))
+    Qe = F.relu(Q) if in_relu else Q
+    w = torch.zeros((ca_real, cb_real, kd, kh, kw), requires_grad=True)
+    B = N // T
+    y = F.conv3d(Qe[:, :cb_real].reshape(B, T, cb_real, Hq, Wq).permute(0, 2, 1, 3, 4), w, stride=(1, stride, stride), padding=pad)
+    y.backward(P[:, :ca_real].reshape(B, T, ca_real, Hm, Wm).permute(0, 2, 1, 3, 4))
+    dw = torch.empty((ca_real, cb_real, kd * kh * kw), device="cuda")
+    db = torch.empty(ca_real, device="cuda")
+    ops.conv_wgrad_bf16(nhwc(P), nhwc(Q), dw, db, T=T, k=k, stride=stride, pad=pad, a_real=ca_real, b_real=cb_real, in_relu=in_relu)
+    close_f32(dw.cpu().reshape(w.shape), w.grad, 2e-5, f"wgrad {ca}x{cb} k{k} s{stride} {Hm}x{Wm}")
+    close_f32(db.cpu(), P[:, :ca_real].sum((0, 2, 3)), 2e-5, "bias gradient")
+
+
+@pytest.mark.parametrize("T", [1, 2, 5])
+def test_wgrad_conv3d_row_runs(T):
+    _wgrad_case(20 + T, 2 * T, T, 128, 128, (3, 3, 3), 1, (1, 1, 1), 8, 32)
+
+
+@pytest.mark.parametrize("ca,cb,in_relu", [(128, 128, False), (32, 128, True), (128, 64, False), (64, 128, False)])
+def test_wgrad_3x3_row_runs(ca, cb, in_relu):
+    """3x3 s1 layers: 128 -> 128, the ResBlocks' 128 -> 32 (its input ReLU applied as Q is staged), 64 -> 128 and its transpose"""
+    _wgrad_case(30 + ca + cb, 3, 1, ca, cb, (1, 3, 3), 1, (0, 1, 1), 12, 64, in_relu=in_relu)
+
+
+@pytest.mark.parametrize("ca,cb", [(128, 32), (64, 128), (64, 192)])
+def test_wgrad_1x1(ca, cb):
+    _wgrad_case(40 + ca + cb, 2, 1, ca, cb, (1, 1, 1), 1, (0, 0, 0), 16, 32)
+
+
+@pytest.mark.parametrize("ca,cb", [(128, 64), (64, 128), (64, 64)])
+def test_wgrad_k4s2_row_runs(ca, cb):
+    """k4 s2 stems (and, with the roles of input and output gradient swapped, the transposed convs): four kw taps per staged row"""
+    _wgrad_case(50 + ca + cb, 2, 1, ca, cb, (1, 4, 4), 2, (0, 1, 1), 10, 32)
+
+
+def test_wgrad_image_layers_8_channels():
+    """enc_b.blocks.0 / dec.blocks.6: Q is the 8-channel (6 real) image-side tensor, k4 s2; the four kw taps are the b index"""
+    _wgrad_case(60, 2, 1, 64, 8, (1, 4, 4), 2, (0, 1, 1), 16, 64, cb_real=6)
+
+
+@pytest.mark.parametrize("k,stride,pad,ca,cb,T", [((1, 3, 3), 1, (0, 1, 1), 128, 128, 1), ((3, 3, 3), 1, (1, 1, 1), 128, 128, 3), ((1, 4, 4), 2, (0, 1, 1), 128, 64, 1),
+                                                    ((1, 1, 1), 1, (0, 0, 0), 128, 32, 1), ((1, 3, 3), 1, (0, 1, 1), 32, 128, 1)])
+def test_wgrad_gather_form_for_other_widths(k, stride, pad, ca, cb, T):
+    """widths that are not multiples of 32 (40 x 24 frames and the like): one tap per workgroup, every row's source pixel decoded on its own"""
+    _wgrad_case(70 + ca + cb + k[2], 2 * T, T, ca, cb, k, stride, pad, 10, 12, in_relu=(ca == 32))
+
+
+# ------------------------------------------------------------------------------------------------ element-wise
+def test_conversions_input_layout_and_vq_glue():
+    from faceoff_amd import ops
+    g = gen(9)
+    x = torch.randn((3, 5, 7, 64), generator=g).cuda()
+    wide = torch.zeros((3, 5, 7, 192), device="cuda", dtype=BF)
+    ops.to_bf16(x, wide[..., 64:128])
+    assert torch.equal(wide[..., 64:128], x.to(BF)) and bool((wide[..., :64] == 0).all()) and bool((wide[..., 128:] == 0).all())
+    assert torch.equal(ops.to_f32(wide[..., 64:128]), x.to(BF).float())
+    a, b = torch.randn((2, 3, 6, 10), generator=g).cuda(), torch.randn((2, 3, 6, 10), generator=g).cuda()
+    y = ops.cat_nchw_to_nhwc8_bf16(a, b)
+    want = torch.zeros((2, 6, 10, 8), device="cuda")
+    want[..., :3], want[..., 3:6] = a.permute(0, 2, 3, 1), b.permute(0, 2, 3, 1)
+    assert torch.equal(y, want.to(BF))
+    # quantiser glue: fo_vq_assign2 = fo_vq_assign + a bf16 copy; fo_vq_bwd_bf16 = bf16(gq + gdiff * 2/numel * (x - q))
+    xin = (torch.randn((2, 4, 4, 64), generator=g) * 0.3).cuda()
+    embed = (torch.randn((64, 512), generator=g) * 0.3).cuda()
+    eT, en = ops.vq_prepare(embed)
+    q1, st1 = torch.empty_like(xin), torch.zeros(1 + 512 + 512 * 64, device="cuda")
+    i1 = ops.vq_assign(xin, eT, en, q1, st1, True)
+    q2, st2 = torch.empty_like(xin), torch.zeros(1 + 512 + 512 * 64, device="cuda")
+    qb = torch.zeros((2, 4, 4, 128), device="cuda", dtype=BF)
+    i2 = ops.vq_assign_bf16out(xin, eT, en, q2, qb[..., 64:], st2, True)
+    assert torch.equal(i1, i2) and torch.equal(q1, q2) and torch.equal(st1[1:], st2[1:]) and torch.equal(qb[..., 64:], q1.to(BF)) and bool((qb[..., :64] == 0).all())
+    np.testing.assert_allclose(st1[0].item(), st2[0].item(), rtol=1e-6)
+    gq = torch.randn((2, 4, 4, 64), generator=g).cuda().to(BF)
+    gd = torch.tensor([0.7], device="cuda")
+    gx = torch.empty((2, 4, 4, 64), device="cuda", dtype=BF)
+    ops.vq_bwd_bf16(gq, xin, q1, gd, gx)
+    want = (gq.float() + 0.7 * (2.0 / xin.numel()) * (xin - q1)).to(BF)
+    assert (gx.float() - want.float()).abs().max().item() <= 2.0 ** -7 * want.float().abs().max().item()
