@@ -194,8 +194,8 @@ def main():
     def min_over_ranks(x):
         return -max_over_ranks(-x)
 
-    def make_trainer(winograd=True, perceptual=False):
-        eng = VQVAEEngine(make_state_dict(0, codebook_scale=0.3, gain=2.0), dev)
+    def make_trainer(winograd=True, perceptual=False, dtype="fp32"):
+        eng = VQVAEEngine(make_state_dict(0, codebook_scale=0.3, gain=2.0), dev, dtype=dtype)
         if not winograd:
             eng.winograd = False
         vqlpips = None
@@ -247,10 +247,13 @@ def main():
         eng.set_stream_overlap(not args.serial_streams)
         return prof.summary(), ms_serial
 
+    def is_bf16_kernel(name):
+        return name.startswith(("conv_bf16", "wgrad_bf16"))
+
     def dominant(summ, steps, ms_serial):
         dom = max(summ, key=lambda k: summ[k]["total_ms"])
         d = summ[dom]
-        peak = BF16_MFMA_PEAK_TFLOPS if dom.startswith("conv_bf16") else FP32_MFMA_PEAK_TFLOPS
+        peak = BF16_MFMA_PEAK_TFLOPS if is_bf16_kernel(dom) else FP32_MFMA_PEAK_TFLOPS
         return {"bound": "mfma", "kernel": dom, "achieved": round(d["tflops"], 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(d["tflops"] / peak, 4), "traffic": None,
                 "achieved_padded_taps_counted": round(d["tflops_nominal"], 2),
@@ -332,7 +335,7 @@ def main():
                           for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["total_ms"])}
         # whole-step matrix-pipe fraction from what the launches really execute: sum of every profiled launch's FLOP
         # (Winograd-domain GEMMs counted as the GEMMs they are, clip-padding taps excluded) + the VQ distance GEMM
-        fp32_flop = sum(v["flops_per_launch"] * v["launches"] for k, v in summ.items() if not k.startswith("conv_bf16")) / args.steps
+        fp32_flop = sum(v["flops_per_launch"] * v["launches"] for k, v in summ.items() if not is_bf16_kernel(k)) / args.steps
         fp32_flop += VQ_FLOP_PER_FRAME * frames
         out["executed_matrix_tflop_per_step"] = round(fp32_flop / 1e12, 4)
         if not args.perceptual:
@@ -399,20 +402,52 @@ def main():
         del eng_x, tr_x
         torch.cuda.empty_cache()
 
-    # ------------------------------------------------------------------ BASELINE config 3: + LPIPS in bf16
+    # ------------------------------------------------------------------ BASELINE config 3: + LPIPS, bf16 MFMA operands throughout
+    # ("C3: + LPIPS, bf16 MFMA inputs / fp32 accumulate & master weights": the VQ-VAE's own convolutions on the bf16 matrix
+    # pipe as well -- engine dtype="bf16": fp32 master weights, fp32 accumulation, fp32 VQ; parity against the oracle with the same
+    # rounding points, tests/test_bf16_engine_gpu.py -- next to the same step with the VQ-VAE left in fp32, `c3.fp32_vqvae`)
     if not args.no_c3 and not args.perceptual and not args.direct_conv:
-        eng_c, tr_c = make_trainer(winograd=True, perceptual=True)
+        ideal_c = lambda vq_peak: FLOP_PER_FRAME / (vq_peak * 1e12) + LPIPS_FLOP_PER_FRAME / (
+            (BF16_MFMA_PEAK_TFLOPS if args.lpips_dtype == "bf16" else FP32_MFMA_PEAK_TFLOPS) * 1e12)
         k_c = max(2, min(args.steps, 5))
+        eng_c, tr_c = make_trainer(perceptual=True, dtype="bf16")
         dt_c, _, (r_c, l_c, p_c) = timed(tr_c, k_c, 2)
         fps_c = world * frames * k_c / dt_c
-        ideal_c = FLOP_PER_FRAME / (FP32_MFMA_PEAK_TFLOPS * 1e12) + LPIPS_FLOP_PER_FRAME / (
-            (BF16_MFMA_PEAK_TFLOPS if args.lpips_dtype == "bf16" else FP32_MFMA_PEAK_TFLOPS) * 1e12)
-        out["c3"] = {"workload": f"C3: C2 (fp32 VQ-VAE) + LPIPS/VGG-16 perceptual loss in {args.lpips_dtype} (seeded VGG weights)",
+        out["c3"] = {"workload": f"C3: C2 + LPIPS/VGG-16 perceptual loss, bf16 MFMA operands / fp32 accumulate & master weights for the VQ-VAE and the LPIPS "
+                                 f"branch alike (fp32 VQ, losses, Adam; seeded VGG weights), {H}x{H}, T={T}, {B} clips/GPU",
                      "value": round(fps_c, 2), "unit": "frames/s", "ms_per_step": round(dt_c / k_c * 1e3, 3), "steps": k_c, "warmup": 2,
-                     "dtype": "f32 (VQ-VAE) + %s (LPIPS)" % args.lpips_dtype,
-                     "speed_vs_ideal_direct_conv": round(ideal_c * fps_c / world, 4),
+                     "dtype": "bf16 (VQ-VAE convolutions and LPIPS: bf16 operands, fp32 accumulate; VQ, losses, master weights, Adam fp32)",
+                     "speed_vs_ideal_direct_conv": round(ideal_c(BF16_MFMA_PEAK_TFLOPS) * fps_c / world, 4),
                      "loss": {"recon": round(r_c.item(), 6), "latent": round(l_c.item(), 6), "perceptual": round(p_c.item(), 6)}}
+        if not args.no_kernel_events:
+            summ_c, ms_serial_c = per_kernel(eng_c, tr_c, k_c)
+            rc = dominant(summ_c, k_c, ms_serial_c)
+            rc["measured"] = "HIP events per launch, side streams joined (as `roofline`); algorithmic FLOP of the launches (clip-padding taps excluded) against the dense bf16 MFMA peak"
+            rc["ms_per_step_serial"] = round(ms_serial_c, 3)
+            out["c3"]["roofline"] = rc
+            out["c3"]["kernels"] = {k: {"launches_per_step": v["launches"] / k_c, "avg_ms": round(v["avg_ms"], 4), "tflops": round(v["tflops"], 1),
+                                        "frac_of_bf16_peak": round(v["tflops"] / BF16_MFMA_PEAK_TFLOPS, 4), "ms_per_step": round(v["total_ms"] / k_c, 3)}
+                                    for k, v in sorted(summ_c.items(), key=lambda kv: -kv[1]["total_ms"])[:12]}
+            bf16_flop = sum(v["flops_per_launch"] * v["launches"] for k, v in summ_c.items()) / k_c
+            out["c3"]["executed_matrix_tflop_per_step"] = round(bf16_flop / 1e12, 3)
+            out["c3"]["step_frac_executed_flop_of_bf16_peak"] = round(bf16_flop / (dt_c / k_c) / (BF16_MFMA_PEAK_TFLOPS * 1e12), 4)
         del eng_c, tr_c
+        torch.cuda.empty_cache()
+        # the bf16 VQ-VAE step alone (recon + VQ loss, no LPIPS): what the bf16 matrix pipe does to config 2's workload
+        eng_b, tr_b = make_trainer(dtype="bf16")
+        dt_b, _, (r_b, l_b, _) = timed(tr_b, k_c, 2)
+        out["c3"]["vqvae_only_bf16"] = {"value": round(world * frames * k_c / dt_b, 2), "unit": "frames/s", "ms_per_step": round(dt_b / k_c * 1e3, 3),
+                                        "loss": {"recon": round(r_b.item(), 6), "latent": round(l_b.item(), 6)},
+                                        "note": "config 2's step with bf16 MFMA operands (no LPIPS); `value` of this line stays the fp32 step"}
+        del eng_b, tr_b
+        torch.cuda.empty_cache()
+        # round 2's form of config 3: fp32 VQ-VAE + bf16 LPIPS
+        eng_f, tr_f = make_trainer(winograd=True, perceptual=True)
+        dt_f, _, (r_f, l_f, p_f) = timed(tr_f, k_c, 2)
+        out["c3"]["fp32_vqvae"] = {"value": round(world * frames * k_c / dt_f, 2), "unit": "frames/s", "ms_per_step": round(dt_f / k_c * 1e3, 3),
+                                   "dtype": "f32 (VQ-VAE) + %s (LPIPS)" % args.lpips_dtype,
+                                   "loss": {"recon": round(r_f.item(), 6), "latent": round(l_f.item(), 6), "perceptual": round(p_f.item(), 6)}}
+        del eng_f, tr_f
         torch.cuda.empty_cache()
 
     # ------------------------------------------------------------------ BASELINE config 5: the two-optimiser GAN iteration

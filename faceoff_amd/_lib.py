@@ -107,7 +107,7 @@ SIGNATURES = {
     "fo_conv_igemm_bf16": (_I, [_D, _P, _P, _P, _P, _P, _P]),
     "fo_conv_bf16": (_I, [_D, _P, _P, _P, _P, _P, _P, _P]),
     "fo_wgrad_bf16_ws_bytes": (_L, [_D]),
-    "fo_conv_wgrad_bf16": (_I, [_D, _P, _P, _P, _I, _I, _P, _L, _P]),
+    "fo_conv_wgrad_bf16": (_I, [_D, _P, _P, _P, _I, _I, _P, _P, _L, _P]),
     "fo_bias_grad_bf16_ws_bytes": (_L, [_I]),
     "fo_bias_grad_bf16": (_I, [_P, _P, _L, _I, _I, _I, _P, _P]),
     "fo_f32_to_bf16": (_I, [_P, _L, _P, _L, _L, _I, _P]),

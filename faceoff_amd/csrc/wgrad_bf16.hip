@@ -43,6 +43,8 @@ struct WArgs {
   int units;                 // row runs (or 32-position steps) in all
   int runsPerRow;            // Wm / 32 (row-run form)
   int inrelu;
+  int biasTapRow;            // the tap row whose workgroups also sum the columns of P (it visits every position), -1: no bias gradient
+  float* wsBias;             // [slabs][Apad]
 };
 
 __device__ __forceinline__ unsigned relu_pk(unsigned w) { return w & ~(((w & 0x80008000u) >> 15) * 0xffffu); }
@@ -54,41 +56,47 @@ __device__ __forceinline__ bf16x4 tr_read(const unsigned char* p) {
 
 // LDS row pitch for C channels whose rows are read at a row stride S (1, or 2 for the k4 s2 stems' Q): the four rows a 16-lane
 // block reads (k, k+1, k+2, k+3 times S) must sit in four different 64-byte bank groups: pitch * S = 64 (mod 256).
-constexpr int row_pitch(int C, int S) { return S == 2 ? (2 * C + 255) / 256 * 256 + 32 : (2 * C + 255) / 256 * 256 + 64; }
+constexpr int row_pitch(int C, int S) { return S == 2 ? (C <= 64 ? 160 : 288) : (C == 32 ? 64 : 320); }
 
-// TA x TB block, WA x (8 / WA) waves, NKW taps per workgroup (1, 3 or 4).  FAST: row-run form.  SMALLC: FAST with Cb = 8, KW = 4.
-template <int TA, int TB, int WA, int NKW, bool FAST, bool SMALLC>
+// TA x TB block, WA x (8 / WA) waves, NKW taps per workgroup (1, 3 or 4), KR runs per barrier pair (thin blocks: more MFMAs per step).
+// FAST: row-run form.  SMALLC: the image layers (Cb = 8, k4 s2): b' = kw * 8 + c, and the NKW = 4 taps of the workgroup are the four kh.
+template <int TA, int TB, int WA, int NKW, int KR, bool FAST, bool SMALLC>
 __global__ __launch_bounds__(512, 1) void wgrad_bf16_kernel(const WArgs a) {
   constexpr int WB = 8 / WA;
   constexpr int MA = TA / WA / 16, MB = TB / WB / 16;                // 16 x 16 tiles per wave
   static_assert(MA >= 1 && MB >= 1 && TA % (WA * 16) == 0 && TB % (WB * 16) == 0, "wave tiling");
+  static_assert(!SMALLC || (FAST && NKW == 4 && TB == 32), "image-layer form");
   constexpr int S = (NKW == 4 && !SMALLC) ? 2 : 1;                   // row stride of Q in LDS (k4 s2)
-  constexpr int NQ = FAST && !SMALLC ? 32 * S + NKW - S : 32;        // rows of Q staged per K-step
+  constexpr int NQ = SMALLC ? 128 : (FAST ? 32 * S + NKW - S : 32);  // rows of Q staged per run
   constexpr int PA = row_pitch(TA, 1), PB = row_pitch(TB, S);
   constexpr int SWB = S == 2 ? 4 : 3;                                // granule-swap parity bit of a Q row: (row >> SWB) & 1
   constexpr int CA = TA / 8, CB = TB / 8;                            // 16-byte chunks per row
   constexpr int NPA = (32 * CA + 511) / 512, NPB = (NQ * CB + 511) / 512;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[32 * PA + NQ * PB];
+  constexpr int SA = 32 * PA, SB = NQ * PB;                          // bytes per run
+  static_assert(KR * (SA + SB) <= 65536, "static LDS");
+  __shared__ __attribute__((aligned(16))) unsigned char lds[KR * (SA + SB)];
   unsigned char* const As = lds;
-  unsigned char* const Bs = lds + 32 * PA;
+  unsigned char* const Bs = lds + KR * SA;
   const fo_conv_desc& d = a.d;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wa = wave / WB, wb = wave % WB;
   const int l15 = lane & 15, kg = lane >> 4;
 
-  // ---- this workgroup: (slab, tap row, tile a, tile b); slabs of one (tile, tap row) are neighbours in the grid
+  // ---- this workgroup: (slab, tap row, tile a, tile b); the tap rows of a slab are neighbours in the grid (they walk the same positions: L2)
   int w = blockIdx.x;
-  const int tr = w % a.tapRows; w /= a.tapRows;                      // the tap rows of a slab walk the same positions together (L2)
+  const int tr = w % a.tapRows; w /= a.tapRows;
   const int tb = w % a.tilesB; w /= a.tilesB;
   const int ta = w % a.tilesA;
   const int slab = w / a.tilesA;
-  // tap row -> (kd, kh) [row-run form: all kw] or one tap (kd, kh, kw) [gather form]
+  // tap row -> (kd, kh) [row-run form: all kw] or one tap (kd, kh, kw) [gather form]; image layers: all of kh, kw
   int kd, kh, kw0;
-  if (FAST) { kd = tr / d.KH; kh = tr - kd * d.KH; kw0 = 0; }
+  if (SMALLC) { kd = 0; kh = 0; kw0 = 0; }
+  else if (FAST) { kd = tr / d.KH; kh = tr - kd * d.KH; kw0 = 0; }
   else { kd = tr / (d.KH * d.KW); const int r = tr - kd * d.KH * d.KW; kh = r / d.KW; kw0 = r - kh * d.KW; }
   const int u0 = (int)((long long)a.units * slab / a.slabs), u1 = (int)((long long)a.units * (slab + 1) / a.slabs);
   const int HWm = d.Hm * d.Wm;
   const int M = d.N * HWm;
+  const bool bias_wg = tb == 0 && tr == a.biasTapRow;                // this workgroup also sums the columns of P (the bias gradient)
 
   // ---- loader roles: chunk id = tid + 512 i -> (row, 16-byte chunk)
   int prow[NPA], pcol[NPA], qrow[NPB], qcol[NPB];
@@ -97,142 +105,175 @@ __global__ __launch_bounds__(512, 1) void wgrad_bf16_kernel(const WArgs a) {
 #pragma unroll
   for (int i = 0; i < NPB; ++i) { const int id = tid + 512 * i; qrow[i] = id / CB; qcol[i] = id - qrow[i] * CB; }
   const int a0 = ta * TA, b0 = tb * TB;
-  u32x4 rp[NPA], rq[NPB];
+  u32x4 rp[KR][NPA], rq[KR][NPB];
 
-  // a unit's validity and its loads
+  // a unit's validity (row-run form: the (frame, row) of Q this tap row reads is not padding) and its loads
   auto unit_valid = [&](int u) -> bool {
-    if (!FAST) return true;
+    if (!FAST || SMALLC) return true;
     const int rowid = u / a.runsPerRow;                              // (frame, output row)
     const int n = rowid / d.Hm, y = rowid - n * d.Hm;
     const int t = n % d.T;
     return ((unsigned)(t + kd - d.padD) < (unsigned)d.T) & ((unsigned)(y * d.stride + kh - d.padH) < (unsigned)d.Hin);
   };
-  auto load = [&](int u) {
+  auto next_valid = [&](int u) -> int {
+    while (u < u1 && !unit_valid(u)) ++u;
+    return u;
+  };
+  auto load = [&](int u, u32x4 (&xp)[NPA], u32x4 (&xq)[NPB]) {       // u >= u1: zeros (a K-step's unused run)
+    const bool live = u < u1;
     if (FAST) {
       const int rowid = u / a.runsPerRow;
       const int x0 = (u - rowid * a.runsPerRow) * 32;
       const int n = rowid / d.Hm, y = rowid - n * d.Hm;
       const long long pbase = ((long long)rowid * d.Wm + x0) * d.ldOut;
-      const int qy = y * d.stride + kh - d.padH, qx0 = x0 * d.stride - d.padW;
-      const long long qbase = (((long long)(n + kd - d.padD) * d.Hin + qy) * d.Win + qx0) * d.ldIn;
+      const int qx0 = x0 * d.stride - d.padW;
 #pragma unroll
       for (int i = 0; i < NPA; ++i) {
-        const bool ok = prow[i] < 32 && a0 + pcol[i] * 8 < d.Cout;
-        rp[i] = ok ? *reinterpret_cast<const u32x4*>(a.P + pbase + (long long)prow[i] * d.ldOut + a0 + pcol[i] * 8) : u32x4{0, 0, 0, 0};
+        const bool ok = live && prow[i] < 32 && a0 + pcol[i] * 8 < d.Cout;
+        xp[i] = ok ? *reinterpret_cast<const u32x4*>(a.P + pbase + (long long)prow[i] * d.ldOut + a0 + pcol[i] * 8) : u32x4{0, 0, 0, 0};
       }
 #pragma unroll
       for (int i = 0; i < NPB; ++i) {
-        if (SMALLC) {        // row r = output pixel x0 + r, chunk c = tap kw: input pixel 2 (x0 + r) - padW + c, its 8 channels
-          const int dx = qrow[i] * d.stride + qcol[i];               // pixels to the right of qx0
-          const bool ok = qrow[i] < 32 && (unsigned)(qx0 + dx) < (unsigned)d.Win;
-          rq[i] = ok ? *reinterpret_cast<const u32x4*>(a.Q + qbase + (long long)dx * d.ldIn) : u32x4{0, 0, 0, 0};
+        if (SMALLC) {        // LDS row = kh * 32 + r (output pixel x0 + r), chunk c = tap kw: input pixel (2 y + kh - padH, 2 (x0 + r) - padW + c)
+          const int khq = qrow[i] >> 5, r = qrow[i] & 31;
+          const int qy = y * d.stride + khq - d.padH, dx = r * d.stride + qcol[i];
+          const bool ok = live && qrow[i] < NQ && (unsigned)qy < (unsigned)d.Hin && (unsigned)(qx0 + dx) < (unsigned)d.Win;
+          xq[i] = ok ? *reinterpret_cast<const u32x4*>(a.Q + (((long long)n * d.Hin + qy) * d.Win + qx0 + dx) * d.ldIn) : u32x4{0, 0, 0, 0};
         } else {
+          const int qy = y * d.stride + kh - d.padH;
+          const long long qbase = (((long long)(n + kd - d.padD) * d.Hin + qy) * d.Win + qx0) * d.ldIn;
           const int qx = qx0 + qrow[i];
-          const bool ok = qrow[i] < NQ && (unsigned)qx < (unsigned)d.Win && b0 + qcol[i] * 8 < d.Cin;
-          rq[i] = ok ? *reinterpret_cast<const u32x4*>(a.Q + qbase + (long long)qrow[i] * d.ldIn + b0 + qcol[i] * 8) : u32x4{0, 0, 0, 0};
+          const bool ok = live && qrow[i] < NQ && (unsigned)qx < (unsigned)d.Win && b0 + qcol[i] * 8 < d.Cin;
+          xq[i] = ok ? *reinterpret_cast<const u32x4*>(a.Q + qbase + (long long)qrow[i] * d.ldIn + b0 + qcol[i] * 8) : u32x4{0, 0, 0, 0};
         }
       }
     } else {
 #pragma unroll
       for (int i = 0; i < NPA; ++i) {
         const int m = u * 32 + prow[i];
-        const bool ok = prow[i] < 32 && m < M && a0 + pcol[i] * 8 < d.Cout;
-        rp[i] = ok ? *reinterpret_cast<const u32x4*>(a.P + (long long)m * d.ldOut + a0 + pcol[i] * 8) : u32x4{0, 0, 0, 0};
+        const bool ok = live && prow[i] < 32 && m < M && a0 + pcol[i] * 8 < d.Cout;
+        xp[i] = ok ? *reinterpret_cast<const u32x4*>(a.P + (long long)m * d.ldOut + a0 + pcol[i] * 8) : u32x4{0, 0, 0, 0};
       }
 #pragma unroll
       for (int i = 0; i < NPB; ++i) {
         const int m = u * 32 + qrow[i];
-        const int mm = m < M ? m : 0;
+        const int mm = (live && m < M) ? m : 0;
         const int n = mm / HWm, rem = mm - n * HWm, y = rem / d.Wm, x = rem - y * d.Wm;
         const int t = n % d.T;
         const int qy = y * d.stride + kh - d.padH, qx = x * d.stride + kw0 - d.padW;
-        const bool ok = qrow[i] < 32 && m < M && ((unsigned)(t + kd - d.padD) < (unsigned)d.T) && ((unsigned)qy < (unsigned)d.Hin) &&
+        const bool ok = live && qrow[i] < 32 && m < M && ((unsigned)(t + kd - d.padD) < (unsigned)d.T) && ((unsigned)qy < (unsigned)d.Hin) &&
                         ((unsigned)qx < (unsigned)d.Win) && b0 + qcol[i] * 8 < d.Cin;
-        rq[i] = ok ? *reinterpret_cast<const u32x4*>(a.Q + (((long long)(n + kd - d.padD) * d.Hin + qy) * d.Win + qx) * d.ldIn + b0 + qcol[i] * 8)
+        xq[i] = ok ? *reinterpret_cast<const u32x4*>(a.Q + (((long long)(n + kd - d.padD) * d.Hin + qy) * d.Win + qx) * d.ldIn + b0 + qcol[i] * 8)
                    : u32x4{0, 0, 0, 0};
       }
     }
   };
-  auto store = [&]() {
+  auto store = [&](int rr, const u32x4 (&xp)[NPA], const u32x4 (&xq)[NPB]) {
 #pragma unroll
     for (int i = 0; i < NPA; ++i)
-      if (prow[i] < 32) *reinterpret_cast<u32x4*>(As + prow[i] * PA + ((pcol[i] * 16) ^ (((prow[i] >> 3) & 1) << 5))) = rp[i];
+      if (prow[i] < 32) *reinterpret_cast<u32x4*>(As + rr * SA + prow[i] * PA + ((pcol[i] * 16) ^ (((prow[i] >> 3) & 1) << 5))) = xp[i];
 #pragma unroll
     for (int i = 0; i < NPB; ++i)
       if (qrow[i] < NQ) {
-        u32x4 v = rq[i];
+        u32x4 v = xq[i];
         if (a.inrelu) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = relu_pk(v[e]);
         }
-        *reinterpret_cast<u32x4*>(Bs + qrow[i] * PB + ((qcol[i] * 16) ^ (((qrow[i] >> SWB) & 1) << 5))) = v;
+        *reinterpret_cast<u32x4*>(Bs + rr * SB + qrow[i] * PB + ((qcol[i] * 16) ^ (((qrow[i] >> SWB) & 1) << 5))) = v;
       }
   };
 
-  f32x4 acc[NKW][MA][MB];
+  f32x4 acc[NKW][MA][MB], accb[MA];
 #pragma unroll
   for (int k = 0; k < NKW; ++k)
 #pragma unroll
     for (int i = 0; i < MA; ++i)
 #pragma unroll
       for (int j = 0; j < MB; ++j) acc[k][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < MA; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bf16x8 ones = {(__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f};
 
   // ---- fragment addressing.  A: rows k = 8 kg + (l15 >> 2) (+4), channels 16 i + 4 (l15 & 3); a 16-channel tile is 32 bytes, and the
-  // granule swap of a row (XOR 32 of the byte column) exchanges neighbouring tiles: byte column = ((i ^ parity) * 32) + 8 (l15 & 3)
+  // granule swap of a row (XOR 32 of the byte column, applied to the WHOLE column) exchanges neighbouring tiles
   const int krow = kg * 8 + (l15 >> 2);
   const int parA = kg & 1;                                           // ((krow) >> 3) & 1 == ((krow + 4) >> 3) & 1
   const unsigned char* const Af = As + krow * PA + (l15 & 3) * 8;
-  const int colA = (wa * (TA / WA)) * 2, colB = (wb * (TB / WB)) * 2;     // byte column of the wave's first tile (the swap applies to the WHOLE column)
-  // B: row of LDS = k * S + kw
+  const int colA = (wa * (TA / WA)) * 2, colB = (wb * (TB / WB)) * 2;
+  // B: row of LDS = k * S + kw  (image layers: kh * 32 + k)
   int rowB[NKW][2], parB[NKW][2];
 #pragma unroll
   for (int k = 0; k < NKW; ++k)
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const int r = SMALLC ? (krow + 4 * h) : (krow + 4 * h) * S + (FAST ? k : 0);
+      const int r = SMALLC ? k * 32 + krow + 4 * h : (krow + 4 * h) * S + (FAST ? k : 0);
       rowB[k][h] = r * PB + (l15 & 3) * 8;
       parB[k][h] = (r >> SWB) & 1;
     }
 
-  auto compute = [&]() {
+  auto compute = [&](int rr) {
     bf16x8 fa[MA];
 #pragma unroll
     for (int i = 0; i < MA; ++i) {
-      const bf16x4 lo = tr_read(Af + ((colA + i * 32) ^ (parA << 5)));
-      const bf16x4 hi = tr_read(Af + 4 * PA + ((colA + i * 32) ^ (parA << 5)));
+      const bf16x4 lo = tr_read(Af + rr * SA + ((colA + i * 32) ^ (parA << 5)));
+      const bf16x4 hi = tr_read(Af + rr * SA + 4 * PA + ((colA + i * 32) ^ (parA << 5)));
       fa[i] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+    if (bias_wg) {       // column sums of P: an MFMA against a fragment of ones, the MA tiles dealt over the WB waves that hold the same rows
+#pragma unroll
+      for (int i = 0; i < MA; ++i)
+        if (i % WB == wb % (MA < WB ? MA : WB) && wb < (MA < WB ? MA : WB)) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], ones, accb[i], 0, 0, 0);
     }
 #pragma unroll
     for (int k = 0; k < NKW; ++k)
 #pragma unroll
       for (int j = 0; j < MB; ++j) {
-        const bf16x4 lo = tr_read(Bs + rowB[k][0] + ((colB + j * 32) ^ (parB[k][0] << 5)));
-        const bf16x4 hi = tr_read(Bs + rowB[k][1] + ((colB + j * 32) ^ (parB[k][1] << 5)));
+        const bf16x4 lo = tr_read(Bs + rr * SB + rowB[k][0] + ((colB + j * 32) ^ (parB[k][0] << 5)));
+        const bf16x4 hi = tr_read(Bs + rr * SB + rowB[k][1] + ((colB + j * 32) ^ (parB[k][1] << 5)));
         const bf16x8 fb = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 #pragma unroll
         for (int i = 0; i < MA; ++i) acc[k][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb, acc[k][i][j], 0, 0, 0);
       }
   };
 
-  int u = u0;
-  while (u < u1 && !unit_valid(u)) ++u;
-  if (u < u1) load(u);
-  while (u < u1) {
-    store();
+  // K-steps of KR valid runs each (a step's unused runs are zeros); the next step's rows fly during the MFMAs
+  int cur[KR], nxt[KR];
+  {
+    int u = next_valid(u0);
+#pragma unroll
+    for (int rr = 0; rr < KR; ++rr) { cur[rr] = u; u = u < u1 ? next_valid(u + 1) : u1; }
+  }
+  if (cur[0] < u1) {
+#pragma unroll
+    for (int rr = 0; rr < KR; ++rr) load(cur[rr], rp[rr], rq[rr]);
+  }
+  while (cur[0] < u1) {
+#pragma unroll
+    for (int rr = 0; rr < KR; ++rr) store(rr, rp[rr], rq[rr]);
     __syncthreads();
-    int nx = u + 1;
-    while (nx < u1 && !unit_valid(nx)) ++nx;
-    if (nx < u1) load(nx);                                            // the next K-step's rows fly during the MFMAs
-    compute();
+    {
+      int u = cur[KR - 1] < u1 ? next_valid(cur[KR - 1] + 1) : u1;
+#pragma unroll
+      for (int rr = 0; rr < KR; ++rr) { nxt[rr] = u; u = u < u1 ? next_valid(u + 1) : u1; }
+    }
+    if (nxt[0] < u1) {
+#pragma unroll
+      for (int rr = 0; rr < KR; ++rr) load(nxt[rr], rp[rr], rq[rr]);
+    }
+#pragma unroll
+    for (int rr = 0; rr < KR; ++rr)
+      if (cur[rr] < u1) compute(rr);
     __syncthreads();
-    u = nx;
+#pragma unroll
+    for (int rr = 0; rr < KR; ++rr) cur[rr] = nxt[rr];
   }
 
   // ---- partial blocks -> ws[slab][tap][a][b]: accumulator register r of lane l = (a = 4 (l >> 4) + r, b = l & 15)
 #pragma unroll
   for (int k = 0; k < NKW; ++k) {
-    const int tap = FAST ? (SMALLC ? tr : tr * NKW + k) : tr;
-    float* o = a.ws + (((long long)slab * (SMALLC ? a.tapRows : a.taps) + tap) * a.Apad + a0 + wa * (TA / WA)) * a.Bpad + b0 + wb * (TB / WB);
+    const int tap = SMALLC ? k : (FAST ? tr * NKW + k : tr);
+    float* o = a.ws + (((long long)slab * (SMALLC ? 4 : a.taps) + tap) * a.Apad + a0 + wa * (TA / WA)) * a.Bpad + b0 + wb * (TB / WB);
 #pragma unroll
     for (int i = 0; i < MA; ++i)
 #pragma unroll
@@ -240,22 +281,58 @@ __global__ __launch_bounds__(512, 1) void wgrad_bf16_kernel(const WArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[(long long)(i * 16 + kg * 4 + r) * a.Bpad + j * 16 + l15] = acc[k][i][j][r];
   }
+  if (bias_wg && l15 == 0) {
+    float* ob = a.wsBias + (long long)slab * a.Apad + a0 + wa * (TA / WA);
+#pragma unroll
+    for (int i = 0; i < MA; ++i)
+      if (i % WB == wb % (MA < WB ? MA : WB) && wb < (MA < WB ? MA : WB)) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ob[i * 16 + kg * 4 + r] = accb[i][r];
+      }
+  }
 }
 
-// dw[a][b][tap] = sum over the slabs (fixed order) of ws[slab][tap][a][b], a < Areal, b < Breal.
-// smallc: ws[slab][kh][a][kw * 8 + c] -> dw[a][c][kh * 4 + kw]
+// dw[a][b][tap] = sum over the slabs (fixed order) of ws[slab][tap][a][b], a < Areal, b < Breal; work items in ws order (coalesced
+// reads of the slabs, one scattered 4-byte store each); a block = 64 consecutive outputs x 4 groups of lanes that each take every
+// fourth slab, two loads in flight per lane (thin layers have up to 256 slabs of a few KB: a serial walk would be latency-bound).
+// smallc: ws[slab][kh][a][kw * 8 + c] -> dw[a][c][kh * 4 + kw].
+// The tail of the index space sums the bias-gradient slabs: db[a] = sum_slab wsBias[slab][a].
 __global__ __launch_bounds__(256) void wgrad_bf16_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int slabs, int taps, int Apad, int Bpad,
-                                                               int Areal, int Breal, int smallc) {
+                                                               int Areal, int Breal, int smallc, const float* __restrict__ wsBias, float* __restrict__ db) {
+  __shared__ float red[4][64];
   const long long total = (long long)Areal * Breal * taps;
-  const long long slabStride = (long long)(smallc ? taps / 4 : taps) * Apad * Bpad;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int tap = (int)(i % taps);
-    const int b = (int)((i / taps) % Breal);
-    const int aa = (int)(i / ((long long)taps * Breal));
-    const long long src = smallc ? (((long long)(tap >> 2) * Apad + aa) * Bpad + (tap & 3) * 8 + b) : (((long long)tap * Apad + aa) * Bpad + b);
-    float s = 0.f;
-    for (int k = 0; k < slabs; ++k) s += ws[k * slabStride + src];
-    dw[i] = s;
+  const long long slabStride = (long long)(smallc ? 4 : taps) * Apad * Bpad;
+  const long long all = total + (db ? Areal : 0);
+  const int li = threadIdx.x & 63, part = threadIdx.x >> 6;
+  for (long long i0 = (long long)blockIdx.x * 64; i0 < all; i0 += (long long)gridDim.x * 64) {
+    const long long i = i0 + li;
+    const float* src = ws;
+    long long stride = slabStride, dst = 0;
+    bool ok = i < all, isb = false;
+    if (ok && i >= total) {
+      isb = true;
+      src = wsBias + (i - total);
+      stride = Apad;
+    } else if (ok) {
+      const int b = (int)(i % Breal);
+      const int aa = (int)((i / Breal) % Areal);
+      const int tap = (int)(i / ((long long)Breal * Areal));
+      src = ws + (smallc ? (((long long)(tap >> 2) * Apad + aa) * Bpad + (tap & 3) * 8 + b) : (((long long)tap * Apad + aa) * Bpad + b));
+      dst = ((long long)aa * Breal + b) * taps + tap;
+    }
+    float s0 = 0.f, s1 = 0.f;
+    if (ok) {
+      int k = part;
+      for (; k + 4 < slabs; k += 8) { s0 += src[k * stride]; s1 += src[(k + 4) * stride]; }
+      if (k < slabs) s0 += src[k * stride];
+    }
+    red[part][li] = s0 + s1;
+    __syncthreads();
+    if (part == 0 && ok) {
+      const float v = (red[0][li] + red[1][li]) + (red[2][li] + red[3][li]);
+      if (isb) db[i - total] = v; else dw[dst] = v;
+    }
+    __syncthreads();
   }
 }
 
@@ -286,41 +363,52 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const __bf16* __restri
     ws[(long long)slab * ((C + 63) / 64 * 64) + cblk * 64 + threadIdx.x] = v;
   }
 }
-__global__ void colsum_reduce_kernel(const float* __restrict__ ws, float* __restrict__ db, int slabs, int Cpad, int Creal) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= Creal) return;
-  float s = 0.f;
-  for (int k = 0; k < slabs; ++k) s += ws[(long long)k * Cpad + c];
-  db[c] = s;
+// db[c] = sum over the slabs of ws[slab][c]: one block per 64 channels, four groups of lanes each take every fourth slab
+__global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restrict__ ws, float* __restrict__ db, int slabs, int Cpad, int Creal) {
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+  float s0 = 0.f, s1 = 0.f;
+  int k = part;
+  for (; k + 4 < slabs; k += 8) { s0 += ws[(long long)k * Cpad + c]; s1 += ws[(long long)(k + 4) * Cpad + c]; }
+  if (k < slabs) s0 += ws[(long long)k * Cpad + c];
+  red[part][threadIdx.x & 63] = s0 + s1;
+  __syncthreads();
+  if (part == 0 && c < Creal) db[c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
 struct WPlan {
-  int TA, TB, NKW;
+  int TA, TB, WA, NKW, KR;
   bool fast, smallc;
-  int tilesA, tilesB, tapRows, taps, units, slabs, Apad, Bpad;
+  int tilesA, tilesB, tapRows, taps, units, slabs, Apad, Bpad, biasTapRow;
 };
 
 int make_plan(const fo_conv_desc* d, WPlan* p) {
   const int A = d->Cout, B = d->Cin;
   p->taps = d->KD * d->KH * d->KW;
-  p->smallc = B == 8;
   FO_REQUIRE(A % 8 == 0 && B % 8 == 0 && d->ldIn % 8 == 0 && d->ldOut % 8 == 0, FO_E_ALIGN, "wgrad_bf16: channel counts / strides must be multiples of 8");
   FO_REQUIRE(d->N > 0 && d->T > 0 && d->N % d->T == 0, FO_E_SHAPE, "wgrad_bf16: N must be whole clips");
   FO_REQUIRE((long long)d->N * d->Hm * d->Wm < (1ll << 31) && (long long)d->N * d->Hin * d->Win < (1ll << 31), FO_E_SHAPE, "wgrad_bf16: too many positions");
+  // the image layers' 8-channel Q takes its own form where the geometry allows (else the gather form with 24 of 32 columns masked)
+  p->smallc = B == 8 && d->KW == 4 && d->KH == 4 && d->KD == 1 && d->stride == 2 && d->ldIn == 8 && d->Wm % 32 == 0 && A % 64 == 0;
   if (p->smallc) {
-    FO_REQUIRE(d->KW == 4 && d->KD == 1 && d->stride == 2 && d->ldIn == 8 && d->Wm % 32 == 0 && A % 64 == 0, FO_E_SHAPE,
-               "wgrad_bf16: 8-channel Q needs the k4 s2 image-layer geometry (KW = 4, stride 2, 16-byte pixels, Wm %% 32 == 0, Ca %% 64 == 0)");
-    p->TA = 64; p->TB = 32; p->NKW = 1; p->fast = true;
-    p->tapRows = d->KH;
+    p->TA = 64; p->TB = 32; p->NKW = 4; p->fast = true;
+    p->tapRows = 1;
+    p->biasTapRow = 0;
   } else {
-    p->fast = d->Wm % 32 == 0 && ((d->KW == 4 && d->stride == 2) || ((d->KW == 3 || d->KW == 1) && d->stride == 1));
+    p->fast = B >= 32 && d->Wm % 32 == 0 && ((d->KW == 4 && d->stride == 2) || ((d->KW == 3 || d->KW == 1) && d->stride == 1));
     p->NKW = p->fast ? d->KW : 1;
     p->TA = A >= 128 ? 128 : (A > 32 ? 64 : 32);
     p->TB = B >= 128 ? 128 : (B > 32 ? 64 : 32);
     if (p->NKW == 4 && p->TA == 128 && p->TB == 128) p->TB = 64;      // (accumulator budget: 4 x 128 x 64)
     if (p->TA == 32 && p->TB == 32) p->TB = 64;                       // (eight waves need eight 16 x 16 tiles)
     p->tapRows = p->fast ? d->KD * d->KH : p->taps;
+    // the centre tap's row reads a real pixel of Q for EVERY position of P: its workgroups see every row of P
+    p->biasTapRow = p->fast ? d->padD * d->KH + d->padH : (d->padD * d->KH + d->padH) * d->KW + d->padW;
   }
+  // waves: WA x (8 / WA) with at least one 16 x 16 tile per wave in either direction
+  p->WA = (p->TA == 128 && p->TB == 128) ? 2 : (p->TA == 128 ? 4 : (p->TA == 64 ? (p->TB == 32 ? 4 : 2) : (p->TB == 128 ? 1 : 2)));
+  const int perRun = p->NKW * (p->TA / p->WA / 16) * (p->TB / (8 / p->WA) / 16);      // MFMAs per wave and run
+  p->KR = perRun <= 6 ? 2 : 1;                                       // thin blocks: two runs per barrier pair
   p->tilesA = (A + p->TA - 1) / p->TA;
   p->tilesB = p->smallc ? 1 : (B + p->TB - 1) / p->TB;
   p->Apad = p->tilesA * p->TA;
@@ -329,26 +417,46 @@ int make_plan(const fo_conv_desc* d, WPlan* p) {
   const int blocks = p->tilesA * p->tilesB * p->tapRows;
   const int cus = fo_cu_count();
   int s = std::max(1, cus / blocks);                                  // one round of workgroups (one per CU)
-  s = std::min(s, std::max(1, p->units / 4));                         // at least 4 K-steps per slab
+  s = std::min(s, std::max(1, p->units / (4 * p->KR)));               // at least 4 K-steps per slab
   p->slabs = s;
   return FO_OK;
 }
 
-template <int TA, int TB, int WA, int NKW, bool FAST, bool SMALLC>
+template <int TA, int TB, int WA, int NKW, int KR, bool FAST, bool SMALLC>
 void launch_w(const WArgs& a, int grid, hipStream_t s) {
-  hipLaunchKernelGGL((wgrad_bf16_kernel<TA, TB, WA, NKW, FAST, SMALLC>), dim3(grid), dim3(512), 0, s, a);
+  hipLaunchKernelGGL((wgrad_bf16_kernel<TA, TB, WA, NKW, KR, FAST, SMALLC>), dim3(grid), dim3(512), 0, s, a);
+}
+
+// (block shape, taps per workgroup) -> instantiation; KR and WA follow from them (make_plan)
+template <int NKW, bool FAST>
+bool dispatch(const WPlan& p, const WArgs& a, int grid, hipStream_t s) {
+  const int key = p.TA * 1000 + p.TB;
+  constexpr int K2 = 2;
+  if (key == 128128) { if (NKW == 1) launch_w<128, 128, 2, NKW, (NKW * 4 * 2 <= 6 ? K2 : 1), FAST, false>(a, grid, s); else launch_w<128, 128, 2, NKW, 1, FAST, false>(a, grid, s); }
+  else if (key == 128064) launch_w<128, 64, 4, NKW, (NKW * 2 * 2 <= 6 ? K2 : 1), FAST, false>(a, grid, s);
+  else if (key == 128032) launch_w<128, 32, 4, NKW, (NKW * 2 * 1 <= 6 ? K2 : 1), FAST, false>(a, grid, s);
+  else if (key == 64128) launch_w<64, 128, 2, NKW, (NKW * 2 * 2 <= 6 ? K2 : 1), FAST, false>(a, grid, s);
+  else if (key == 64064) launch_w<64, 64, 2, NKW, (NKW * 2 * 1 <= 6 ? K2 : 1), FAST, false>(a, grid, s);
+  else if (key == 64032) launch_w<64, 32, 4, NKW, (NKW * 1 * 1 <= 6 ? K2 : 1), FAST, false>(a, grid, s);
+  else if (key == 32128) launch_w<32, 128, 1, NKW, (NKW * 2 * 1 <= 6 ? K2 : 1), FAST, false>(a, grid, s);
+  else if (key == 32064) launch_w<32, 64, 2, NKW, (NKW * 1 * 1 <= 6 ? K2 : 1), FAST, false>(a, grid, s);
+  else return false;
+  return true;
 }
 
 }  // namespace
 
+// scratch: the slabs of partial filter gradients, then the slabs of partial bias gradients
+static int64_t ws_floats_main(const WPlan& p) { return (int64_t)p.slabs * (p.smallc ? 4 : p.taps) * p.Apad * p.Bpad; }
+
 extern "C" int64_t fo_wgrad_bf16_ws_bytes(const fo_conv_desc* d) {
   WPlan p;
   if (make_plan(d, &p) != FO_OK) return -1;
-  return (int64_t)p.slabs * (p.smallc ? p.tapRows : p.taps) * p.Apad * p.Bpad * 4;
+  return (ws_floats_main(p) + (int64_t)p.slabs * p.Apad) * 4;
 }
 
-extern "C" int fo_conv_wgrad_bf16(const fo_conv_desc* d, const void* P, const void* Q, float* dw, int Areal, int Breal, float* ws, int64_t ws_bytes,
-                                  void* stream) {
+extern "C" int fo_conv_wgrad_bf16(const fo_conv_desc* d, const void* P, const void* Q, float* dw, int Areal, int Breal, float* dbias, float* ws,
+                                  int64_t ws_bytes, void* stream) {
   WPlan p;
   const int rc = make_plan(d, &p);
   if (rc != FO_OK) return rc;
@@ -362,70 +470,37 @@ extern "C" int fo_conv_wgrad_bf16(const fo_conv_desc* d, const void* P, const vo
   a.tilesA = p.tilesA; a.tilesB = p.tilesB; a.slabs = p.slabs; a.tapRows = p.tapRows; a.taps = p.taps;
   a.Apad = p.Apad; a.Bpad = p.Bpad; a.units = p.units; a.runsPerRow = p.fast ? d->Wm / 32 : 1;
   a.inrelu = (d->flags & FO_IN_RELU) ? 1 : 0;
+  a.biasTapRow = dbias ? p.biasTapRow : -1;
+  a.wsBias = ws + ws_floats_main(p);
   const int grid = p.tilesA * p.tilesB * p.tapRows * p.slabs;
   hipStream_t s = (hipStream_t)stream;
-  const int key = p.TA * 1000 + p.TB;
-  bool ok = true;
-  if (p.smallc) launch_w<64, 32, 4, 1, true, true>(a, grid, s);
-  else if (p.fast && p.NKW == 3) {
-    if (key == 128128) launch_w<128, 128, 2, 3, true, false>(a, grid, s);
-    else if (key == 128064) launch_w<128, 64, 4, 3, true, false>(a, grid, s);
-    else if (key == 128032) launch_w<128, 32, 4, 3, true, false>(a, grid, s);
-    else if (key == 64128) launch_w<64, 128, 2, 3, true, false>(a, grid, s);
-    else if (key == 64064) launch_w<64, 64, 2, 3, true, false>(a, grid, s);
-    else if (key == 64032) launch_w<64, 32, 4, 3, true, false>(a, grid, s);
-    else if (key == 32128) launch_w<32, 128, 1, 3, true, false>(a, grid, s);
-    else if (key == 32064) launch_w<32, 64, 2, 3, true, false>(a, grid, s);
-    else ok = false;
-  } else if (p.fast && p.NKW == 4) {
-    if (key == 128064) launch_w<128, 64, 4, 4, true, false>(a, grid, s);
-    else if (key == 128032) launch_w<128, 32, 4, 4, true, false>(a, grid, s);
-    else if (key == 64128) launch_w<64, 128, 2, 4, true, false>(a, grid, s);
-    else if (key == 64064) launch_w<64, 64, 2, 4, true, false>(a, grid, s);
-    else if (key == 64032) launch_w<64, 32, 4, 4, true, false>(a, grid, s);
-    else if (key == 32128) launch_w<32, 128, 1, 4, true, false>(a, grid, s);
-    else if (key == 32064) launch_w<32, 64, 2, 4, true, false>(a, grid, s);
-    else ok = false;
-  } else if (p.fast) {                                                // NKW == 1 (1x1 convs)
-    if (key == 128128) launch_w<128, 128, 2, 1, true, false>(a, grid, s);
-    else if (key == 128064) launch_w<128, 64, 4, 1, true, false>(a, grid, s);
-    else if (key == 128032) launch_w<128, 32, 4, 1, true, false>(a, grid, s);
-    else if (key == 64128) launch_w<64, 128, 2, 1, true, false>(a, grid, s);
-    else if (key == 64064) launch_w<64, 64, 2, 1, true, false>(a, grid, s);
-    else if (key == 64032) launch_w<64, 32, 4, 1, true, false>(a, grid, s);
-    else if (key == 32128) launch_w<32, 128, 1, 1, true, false>(a, grid, s);
-    else if (key == 32064) launch_w<32, 64, 2, 1, true, false>(a, grid, s);
-    else ok = false;
-  } else {
-    if (key == 128128) launch_w<128, 128, 2, 1, false, false>(a, grid, s);
-    else if (key == 128064) launch_w<128, 64, 4, 1, false, false>(a, grid, s);
-    else if (key == 128032) launch_w<128, 32, 4, 1, false, false>(a, grid, s);
-    else if (key == 64128) launch_w<64, 128, 2, 1, false, false>(a, grid, s);
-    else if (key == 64064) launch_w<64, 64, 2, 1, false, false>(a, grid, s);
-    else if (key == 64032) launch_w<64, 32, 4, 1, false, false>(a, grid, s);
-    else if (key == 32128) launch_w<32, 128, 1, 1, false, false>(a, grid, s);
-    else if (key == 32064) launch_w<32, 64, 2, 1, false, false>(a, grid, s);
-    else ok = false;
-  }
+  bool ok;
+  if (p.smallc) { launch_w<64, 32, 4, 4, 2, true, true>(a, grid, s); ok = true; }
+  else if (p.fast && p.NKW == 3) ok = dispatch<3, true>(p, a, grid, s);
+  else if (p.fast && p.NKW == 4) ok = dispatch<4, true>(p, a, grid, s);
+  else if (p.fast) ok = dispatch<1, true>(p, a, grid, s);
+  else ok = dispatch<1, false>(p, a, grid, s);
   FO_REQUIRE(ok, FO_E_SHAPE, "wgrad_bf16: no kernel for a %d x %d block with %d taps per workgroup", p.TA, p.TB, p.NKW);
   FO_CHECK_LAUNCH();
-  const long long total = (long long)Areal * Breal * p.taps;
-  const int rblocks = (int)std::min<long long>((total + 255) / 256, 8LL * fo_cu_count());
-  hipLaunchKernelGGL(wgrad_bf16_reduce_kernel, dim3(rblocks), dim3(256), 0, s, ws, dw, p.slabs, p.taps, p.Apad, p.Bpad, Areal, Breal, p.smallc ? 1 : 0);
+  const long long total = (long long)Areal * Breal * p.taps + (dbias ? Areal : 0);
+  const int rblocks = (int)std::min<long long>((total + 63) / 64, 16LL * fo_cu_count());
+  hipLaunchKernelGGL(wgrad_bf16_reduce_kernel, dim3(rblocks), dim3(256), 0, s, ws, dw, p.slabs, p.taps, p.Apad, p.Bpad, Areal, Breal, p.smallc ? 1 : 0,
+                     a.wsBias, dbias);
   FO_CHECK_LAUNCH();
   return FO_OK;
 }
 
 // db[c] = sum over the rows of g[row][c] (c < Creal), g bf16 [rows][ld]; ws: at least fo_bias_grad_bf16_ws_bytes(C) bytes
-extern "C" int64_t fo_bias_grad_bf16_ws_bytes(int C) { return (int64_t)256 * ((C + 63) / 64 * 64) * 4; }
+extern "C" int64_t fo_bias_grad_bf16_ws_bytes(int C) { return (int64_t)1024 * ((C + 63) / 64 * 64) * 4; }
 extern "C" int fo_bias_grad_bf16(const void* g, float* db, int64_t rows, int C, int Creal, int ld, float* ws, void* stream) {
   FO_REQUIRE(g && db && ws && rows > 0 && C % 8 == 0 && ld % 8 == 0 && Creal <= C && fo_aligned16(g), FO_E_SHAPE, "bias_grad_bf16: bad arguments");
   const int cblks = (C + 63) / 64;
-  const int slabs = (int)std::max<int64_t>(1, std::min<int64_t>(256, std::min<int64_t>(rows / 64, 4 * (int64_t)fo_cu_count() / cblks)));
+  // enough workgroups to stream at full rate (4 per CU), each with at least 64 rows
+  const int slabs = (int)std::max<int64_t>(1, std::min<int64_t>(1024, std::min<int64_t>(rows / 64, 4 * (int64_t)fo_cu_count() / cblks)));
   hipLaunchKernelGGL(colsum_bf16_kernel, dim3(cblks * slabs), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const __bf16*>(g), (long long)rows, C, ld, ws,
                      slabs);
   FO_CHECK_LAUNCH();
-  hipLaunchKernelGGL(colsum_reduce_kernel, dim3((Creal + 63) / 64), dim3(64), 0, (hipStream_t)stream, ws, db, slabs, cblks * 64, Creal);
+  hipLaunchKernelGGL(colsum_reduce_kernel, dim3(cblks), dim3(256), 0, (hipStream_t)stream, ws, db, slabs, cblks * 64, Creal);
   FO_CHECK_LAUNCH();
   return FO_OK;
 }

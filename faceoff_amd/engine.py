@@ -235,13 +235,78 @@ class _Layer:
                            in_relu=in_relu, **geo)
 
 
+class _LayerBF16(_Layer):
+    """The same layer with bf16 MFMA operands (BASELINE config 3 as SURVEY.md section 8(d) defines it): the fp32 master filter is packed
+    and rounded to bf16 every step, activations and their gradients are bf16 tensors, accumulation, bias, filter / bias gradients fp32.
+    Direct convolutions only (the bf16 matrix pipe is 16x the fp32 one: transforms would cost more than they save, and F(4x4) is not
+    safe at 8 significand bits)."""
+
+    def pack(self):
+        def r16(f32, key):
+            buf = getattr(self, key, None)
+            out = ops.to_bf16(f32, buf)
+            setattr(self, key, out)
+            return out
+        if self.kind == "convT":
+            self._p32 = (ops.pack_convT_fused if self.co <= 8 else ops.pack_convT)(self.w, getattr(self, "_p32", None))
+            self.wp = r16(self._p32, "_wp16")
+            if self.need_dgrad:                      # dgrad = conv k4s2p1 with O:=ci, I:=co
+                self._pd32 = ops.pack_conv(self.w, getattr(self, "_pd32", None))
+                self.wpd = r16(self._pd32, "_wpd16")
+        else:
+            self._p32 = ops.pack_conv(self.w, getattr(self, "_p32", None))
+            self.wp = r16(self._p32, "_wp16")
+            if not self.need_dgrad:
+                return
+            if self.k[-1] == 4:                      # dgrad of k4s2p1 conv = transposed conv, Ci_T:=co, Co_T:=ci
+                self._pd32 = ops.pack_convT(self.w, getattr(self, "_pd32", None))
+            else:
+                self._pd32 = ops.pack_conv_dgrad(self.w.reshape(self.co, self.ci, -1), getattr(self, "_pd32", None))
+            self.wpd = r16(self._pd32, "_wpd16")
+
+    def fwd(self, x, out, T=1, flags=0, add=None):
+        if self.kind == "convT" and self.co <= 8:
+            assert add is None
+            ops.convT_fused_bf16(x, self.wp, self.b, out, cin=self.cip, cout=self.co, flags=flags)
+        elif self.kind == "convT":
+            ops.convT_phases_bf16(x, self.wp, self.b, out, cin=self.cip, cout=self.co, flags=flags, add=add)
+        else:
+            ops.conv_bf16g(x, self.wp, self.b, out, T=T if self.kind == "conv3d" else 1, cin=self.cip, cout=self.co, flags=flags, add=add,
+                           **self._geom())
+
+    def dgrad(self, g, gin, T=1, mask=None, add=None):
+        if self.kind == "convT":                     # conv k4 s2 p1 over g
+            ops.conv_bf16g(g, self.wpd, None, gin, k=(1, 4, 4), stride=2, pad=(0, 1, 1), cin=ops.pad_in(self.co), cout=self.ci, mask=mask, add=add)
+        elif self.k[-1] == 4:                        # transposed conv over g
+            ops.convT_phases_bf16(g, self.wpd, None, gin, cin=self.co, cout=self.ci, mask=mask, add=add)
+        else:
+            geo = self._geom()
+            pad = tuple(kk - 1 - p for kk, p in zip(geo["k"], geo["pad"]))
+            ops.conv_bf16g(g, self.wpd, None, gin, T=T if self.kind == "conv3d" else 1, k=geo["k"], stride=1, pad=pad, cin=self.co, cout=self.ci,
+                           mask=mask, add=add)
+
+    def _wgrad(self, x, g, T, in_relu):
+        if self.kind == "convT":                     # the adjoint convolution's filter gradient: P = this layer's input, Q = its output gradient
+            ops.conv_wgrad_bf16(x, g, self.gw, None, k=(1, 4, 4), stride=2, pad=(0, 1, 1), a_real=self.ci, b_real=self.co)
+            ops.bias_grad_bf16(g, self.gb, self.co)
+        else:
+            ops.conv_wgrad_bf16(g, x, self.gw, self.gb, T=T if self.kind == "conv3d" else 1, a_real=self.co, b_real=self.ci, in_relu=in_relu,
+                                **self._geom())
+
+
 class VQVAEEngine:
     """Owns the flat parameter / gradient arenas and runs forward / backward on `device`."""
 
-    def __init__(self, state_dict, device, in_channel=6, clip_len=None):
+    def __init__(self, state_dict, device, in_channel=6, clip_len=None, dtype=None):
+        """dtype: "fp32" (BASELINE config 2: fp32 MFMA, the reference's arithmetic) or "bf16" (config 3: bf16 MFMA operands, fp32 accumulation,
+        fp32 master weights, fp32 VQ; rounding points = oracle.faceoff_oracle._BF16Sim).  Default: $FACEOFF_DTYPE, else fp32."""
         self.device = torch.device(device)
         self.in_channel = in_channel
         self.clip_len = clip_len
+        self.dtype = dtype or _os.environ.get("FACEOFF_DTYPE", "fp32")
+        assert self.dtype in ("fp32", "bf16"), self.dtype
+        self.bf16 = self.dtype == "bf16"
+        self.act_dtype = torch.bfloat16 if self.bf16 else torch.float32
         specs = vqvae_param_specs(in_channel=in_channel)
         # ---- flat arenas.  Arena order = REVERSE of the order in which backward() completes layers, so
         # the gradient arena fills from its end towards its start and every data-parallel bucket is one
@@ -274,12 +339,11 @@ class VQVAEEngine:
         for name, kind, shape in specs:
             if kind == "vq":
                 continue
-            self.layers[name] = _Layer(name, kind, self.params[name + ".weight"], self.params[name + ".bias"],
-                                       self.grads[name + ".weight"], self.grads[name + ".bias"])
+            self.layers[name] = (_LayerBF16 if self.bf16 else _Layer)(name, kind, self.params[name + ".weight"], self.params[name + ".bias"],
+                                                                      self.grads[name + ".weight"], self.grads[name + ".bias"])
         self.layers["enc_b.blocks.0"].need_dgrad = False   # the input image needs no gradient
         for layer in self.layers.values():
             layer.engine = self
-        import os as _os
         self.wgrad_stream = None
         if self.device.type == "cuda" and not _os.environ.get("FACEOFF_NO_WGRAD_OVERLAP"):
             self.wgrad_stream = torch.cuda.Stream(device=self.device)
@@ -306,7 +370,9 @@ class VQVAEEngine:
         self.keep_wino_v = False      # training forward: keep each Conv3d's transformed input for its filter gradient
         # filter gradients start when the next Winograd-domain GEMM of their stream ENDS (beside the HBM-bound transforms that
         # follow it) rather than beside that GEMM: -0.33 ms per step (tools/ab.sh; holding one or three more back: +0.2...0.3)
-        self.defer_wgrad = not _os.environ.get("FACEOFF_NO_DEFER_WGRAD")
+        self.defer_wgrad = not _os.environ.get("FACEOFF_NO_DEFER_WGRAD") and not self.bf16     # (the hook is a Winograd-domain GEMM launch: fp32 engine only)
+        if self.bf16:
+            self.winograd = self.w42 = self.fused_resblock = False
         self._pending_wgrad = {}
         self._keepalive = []
         self._cur_S = None            # state dict of the forward / backward in flight (kept Winograd planes live in it)
@@ -345,8 +411,8 @@ class VQVAEEngine:
         return out
 
     # ------------------------------------------------------------------ helpers
-    def _new(self, n, h, w, c):
-        return torch.empty((n, h, w, c), device=self.device, dtype=torch.float32)
+    def _new(self, n, h, w, c, dtype=None):
+        return torch.empty((n, h, w, c), device=self.device, dtype=dtype or self.act_dtype)
 
     def _resblock_fwd(self, prefix, x, out, out_relu):
         """ResBlock.forward (:97-101): h = relu(conv3x3(relu(x))); out = conv1x1(h) + x  [optionally relu'd]."""
@@ -481,18 +547,19 @@ class VQVAEEngine:
         L, d3, cat_b = self.layers, S["d3"], S["cat_b"]
         N, h8, w8, _ = d3.shape
         _, h4, w4, _ = cat_b.shape
-        qt_in = self._new(N, h8, w8, 64); L["quantize_conv_t"].fwd(d3, qt_in)
+        f32 = torch.float32        # the quantisers' inputs stay fp32 in either engine (VQ distances, arg-min and commitment loss are fp32)
+        qt_in = self._new(N, h8, w8, 64, f32); L["quantize_conv_t"].fwd(d3, qt_in)
         quant_t = self._new(N, h8, w8, 64)
-        id_t, stats_t = self._quantize("quantize_t", qt_in, quant_t, training)
+        id_t, stats_t, S["quant_t_f32"] = self._quantize("quantize_t", qt_in, quant_t, training)
         u0 = self._new(N, h8, w8, 128); L["dec_t.blocks.0"].fwd(quant_t, u0)
         u1 = self._new(N, h8, w8, 128); S["h_dt1"] = self._resblock_fwd("dec_t.blocks.1", u0, u1, False)
         u2 = self._new(N, h8, w8, 128); S["h_dt2"] = self._resblock_fwd("dec_t.blocks.2", u1, u2, True)
         L["dec_t.blocks.4"].fwd(u2, cat_b[..., 0:64])                      # torch.cat([dec_t, enc_b], 1) :271
         if S.get("_join_conv3d_b") is not None:
             torch.cuda.current_stream().wait_event(S.pop("_join_conv3d_b"))
-        qb_in = self._new(N, h4, w4, 64); L["quantize_conv_b"].fwd(cat_b, qb_in)
+        qb_in = self._new(N, h4, w4, 64, f32); L["quantize_conv_b"].fwd(cat_b, qb_in)
         cat_d = self._new(N, h4, w4, 128)
-        id_b, stats_b = self._quantize("quantize_b", qb_in, cat_d[..., 64:128], training)
+        id_b, stats_b, S["quant_b_f32"] = self._quantize("quantize_b", qb_in, cat_d[..., 64:128], training)
         S.update(qt_in=qt_in, quant_t=quant_t, u0=u0, u1=u1, u2=u2, qb_in=qb_in, cat_d=cat_d, id_t=id_t, id_b=id_b)
         # diff = diff_t + diff_b, each mean((q - x)^2) (:77,268,276,278)
         S["diff"] = stats_t[0:1] / float(qt_in.numel()) + stats_b[0:1] / float(qb_in.numel())
@@ -514,7 +581,7 @@ class VQVAEEngine:
         v1 = self._new(N, h4, w4, 128); S["h_d1"] = self._resblock_fwd("dec.blocks.1", v0, v1, False)
         v2 = self._new(N, h4, w4, 128); S["h_d2"] = self._resblock_fwd("dec.blocks.2", v1, v2, True)
         w1 = self._new(N, 2 * h4, 2 * w4, 64); L["dec.blocks.4"].fwd(v2, w1, flags=FO_OUT_RELU)
-        dec = torch.empty((N, 4 * h4, 4 * w4, 8), device=self.device); L["dec.blocks.6"].fwd(w1, dec)   # (every pixel, all 8 floats, is written)
+        dec = torch.empty((N, 4 * h4, 4 * w4, 8), device=self.device); L["dec.blocks.6"].fwd(w1, dec)   # (fp32 in either engine; every pixel, all 8 floats, is written)
         S.update(v0=v0, v1=v1, v2=v2, w1=w1, dec=dec)
 
     def forward(self, img_nchw, training=True, T=None):
@@ -534,7 +601,11 @@ class VQVAEEngine:
         self.pack_filters(defer=True)
         self.keep_wino_v = bool(training)
         assert Cin <= 8
-        S = {"T": T, "x8": ops.cat_nchw_to_nhwc8(*parts) if parts is not None else ops.nchw_to_nhwc(img_nchw, cpad=ops.pad_in(Cin))}
+        if self.bf16:
+            x8 = ops.cat_nchw_to_nhwc8_bf16(*parts) if parts is not None else ops.cat_nchw_to_nhwc8_bf16(img_nchw)
+        else:
+            x8 = ops.cat_nchw_to_nhwc8(*parts) if parts is not None else ops.nchw_to_nhwc(img_nchw, cpad=ops.pad_in(Cin))
+        S = {"T": T, "x8": x8}
         self.stage_encode(S)
         self.stage_conv3d(S)
         self.stage_quantize(S, training)
@@ -544,8 +615,21 @@ class VQVAEEngine:
     def _quantize(self, name, x, q_out, training):
         embedT, enorm = ops.vq_prepare(self.buffers[name + ".embed"])
         stats = torch.zeros(1 + 512 + 512 * 64, device=self.device)
+        if self.bf16:        # the straight-through output twice: fp32 (kept for the backward's 2 (x - q) / numel term), bf16 for the next conv
+            q32 = torch.empty(x.shape, device=self.device, dtype=torch.float32)
+            ind = ops.vq_assign_bf16out(x, embedT, enorm, q32, q_out, stats, training)
+            return ind, stats, q32
         ind = ops.vq_assign(x, embedT, enorm, q_out, stats, training)
-        return ind, stats
+        return ind, stats, None
+
+    def _vq_bwd(self, gq, x, q, q32, g_diff):
+        """Quantize backward (:77-78): g_x = g_q + g_diff * 2 (x - q) / numel; returns g_x in the engine's activation dtype."""
+        gx = torch.empty(x.shape, device=self.device, dtype=self.act_dtype)
+        if self.bf16:
+            ops.vq_bwd_bf16(gq, x, q32, g_diff, gx)
+        else:
+            ops.vq_bwd(gq, x, q, g_diff, gx)
+        return gx
 
     # ------------------------------------------------------------------ backward
     def backward(self, S, g_dec, g_diff):
@@ -570,6 +654,8 @@ class VQVAEEngine:
         T = S["T"]
         self._cur_S = S
         new_like = torch.empty_like
+        if self.bf16 and g_dec.dtype != torch.bfloat16:      # the loss kernels hand over an fp32 gradient: stored as bf16 once, here
+            g_dec = ops.to_bf16(g_dec)
         # ---- dec (Decoder stride 4)
         l6, l4 = L["dec.blocks.6"], L["dec.blocks.4"]
         l6.wgrad(S["w1"], g_dec)
@@ -586,8 +672,7 @@ class VQVAEEngine:
         up.wgrad(S["quant_t"], g_cat_d[..., 0:64])
         g_quant_t = new_like(S["quant_t"]); up.dgrad(g_cat_d[..., 0:64], g_quant_t)
         # ---- quantize_b (straight-through + commitment) and quantize_conv_b
-        g_qb_in = new_like(S["qb_in"])
-        ops.vq_bwd(g_cat_d[..., 64:128], S["qb_in"], S["cat_d"][..., 64:128], g_diff, g_qb_in)
+        g_qb_in = self._vq_bwd(g_cat_d[..., 64:128], S["qb_in"], S["cat_d"][..., 64:128], S.get("quant_b_f32"), g_diff)
         qcb = L["quantize_conv_b"]
         qcb.wgrad(S["cat_b"], g_qb_in)
         g_cat_b = new_like(S["cat_b"]); qcb.dgrad(g_qb_in, g_cat_b)
@@ -620,8 +705,7 @@ class VQVAEEngine:
         dt0.wgrad(S["quant_t"], g_u0)
         g_quant_t2 = new_like(S["quant_t"]); dt0.dgrad(g_u0, g_quant_t2, add=g_quant_t)   # fan-in of quant_t's two uses
         # ---- quantize_t and quantize_conv_t
-        g_qt_in = new_like(S["qt_in"])
-        ops.vq_bwd(g_quant_t2, S["qt_in"], S["quant_t"], g_diff, g_qt_in)
+        g_qt_in = self._vq_bwd(g_quant_t2, S["qt_in"], S["quant_t"], S.get("quant_t_f32"), g_diff)
         qct = L["quantize_conv_t"]
         qct.wgrad(S["d3"], g_qt_in)
         g_d3 = new_like(S["d3"]); qct.dgrad(g_qt_in, g_d3)

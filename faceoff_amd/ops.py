@@ -690,11 +690,9 @@ def conv_wgrad_bf16(P, Q, dw, dbias, *, T=1, k=(1, 3, 3), stride=1, pad=(0, 1, 1
             wname += f" [{N}x{Hm}x{Wm} k{k[0]}{k[1]}{k[2]} s{stride}]"
         nominal = 2.0 * N * Hm * Wm * Ca * Cb * k[0] * k[1] * k[2]
         prof.begin(wname, nominal * (temporal_share(T, k[0], pad[0]) if k[0] > 1 else 1.0), nominal)
-    _lib.call("fo_conv_wgrad_bf16", C.byref(d), _ptr(P), _ptr(Q), _ptr(dw), a_real, b_real, _ptr(ws), C.c_int64(ws.numel() * 4), _stream())
+    _lib.call("fo_conv_wgrad_bf16", C.byref(d), _ptr(P), _ptr(Q), _ptr(dw), a_real, b_real, _ptr(dbias), _ptr(ws), C.c_int64(ws.numel() * 4), _stream())
     if prof is not None:
         prof.end()
-    if dbias is not None:
-        bias_grad_bf16(P, dbias, a_real)
 
 
 def bias_grad_bf16(g, dbias, c_real):

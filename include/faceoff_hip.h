@@ -380,10 +380,12 @@ int fo_conv_bf16(const fo_conv_desc* d, const void* in, const void* wp, const fl
  * sum_m P[m][a] * Q[qpix(m,tap)][b] with bf16 P (the tensor on the conv's output grid: d->Cout channels, row stride d->ldOut, grid
  * d->Hm x d->Wm) and bf16 Q (d->Cin channels, d->ldIn, d->Hin x d->Win), fp32 accumulation (csrc/wgrad_bf16.hip).  Same descriptor
  * convention as fo_conv_wgrad; FO_IN_RELU applies relu() to Q as it is staged.  Channel counts are multiples of 8; an 8-channel Q
- * (the image layers) needs the k4 s2 geometry.  ws: fo_wgrad_bf16_ws_bytes(d) bytes of scratch, private to the stream. */
+ * (the image layers) takes a form of its own at the k4 s2 geometry.  dbias (may be NULL): [Areal] column sums of P, formed by the
+ * same launch (one extra MFMA per K-step against a fragment of ones in the workgroups of the centre tap).
+ * ws: fo_wgrad_bf16_ws_bytes(d) bytes of scratch, private to the stream. */
 int64_t fo_wgrad_bf16_ws_bytes(const fo_conv_desc* d);
-int fo_conv_wgrad_bf16(const fo_conv_desc* d, const void* P, const void* Q, float* dw, int Areal, int Breal, float* ws, int64_t ws_bytes,
-                       void* stream);
+int fo_conv_wgrad_bf16(const fo_conv_desc* d, const void* P, const void* Q, float* dw, int Areal, int Breal, float* dbias, float* ws,
+                       int64_t ws_bytes, void* stream);
 /* db[c] = sum over the rows of the bf16 tensor g[rows][ld] (bias gradients), c < Creal <= C. */
 int64_t fo_bias_grad_bf16_ws_bytes(int C);
 int fo_bias_grad_bf16(const void* g, float* db, int64_t rows, int C, int Creal, int ld, float* ws, void* stream);

@@ -32,6 +32,14 @@ def test_bench_emits_one_valid_json_line():
     assert abs(r["achieved"] - r["algorithmic_gflop_per_launch"] / r["avg_launch_ms"]) < 0.02 * r["achieved"]
     # the opt-in leg with fp32 products on the bf16 matrix pipe: its own step time (its losses are those of its own, fresh
     # trainer after its own number of steps; tests/test_split_gpu.py compares the two paths on equal inputs)
+    # config 3 (bf16 MFMA operands for the VQ-VAE and the LPIPS branch): its own value, roofline block against the bf16 peak, and the two
+    # comparison steps (bf16 VQ-VAE without LPIPS; round 2's fp32 VQ-VAE + bf16 LPIPS)
+    c3 = d["c3"]
+    assert c3["value"] > 0 and abs(c3["value"] - 160 / (c3["ms_per_step"] * 1e-3)) < 1e-2 * c3["value"] and c3["dtype"].startswith("bf16")
+    r3 = c3["roofline"]
+    assert r3["peak"] == 2500.0 and r3["bound"] == "mfma" and 0 < r3["frac"] <= 1.0 and abs(r3["frac"] - r3["achieved"] / r3["peak"]) < 1e-3
+    assert c3["vqvae_only_bf16"]["value"] > c3["value"] and c3["fp32_vqvae"]["value"] > 0
+    assert 0 < c3["loss"]["perceptual"] and 0 < c3["loss"]["recon"] < 1
     x = d["bf16x6"]
     assert x["value"] > 0 and abs(x["value"] - 160 / (x["ms_per_step"] * 1e-3)) < 1e-2 * x["value"]
     assert 0 < x["loss"]["recon"] < 1 and 0 < x["loss"]["latent"] < 1
