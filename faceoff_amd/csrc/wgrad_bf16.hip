@@ -27,6 +27,10 @@
 #include <algorithm>
 #include "common.h"
 
+#ifndef FO_ABLATE_W   // diagnostic builds (tools/ablate_wgrad.sh): bit 0 no global loads, 1 no LDS stores, 2 no fragment reads / MFMAs
+#define FO_ABLATE_W 0 // (results are wrong, only the timing is of interest)
+#endif
+
 namespace {
 
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -38,13 +42,19 @@ struct WArgs {
   const __bf16* P;
   const __bf16* Q;
   float* ws;                 // [slabs][taps][Apad][Bpad]
-  int tilesA, tilesB, slabs, tapRows, taps;
+  int tilesA, tilesB, tapRows, taps;
   int Apad, Bpad;
-  int units;                 // row runs (or 32-position steps) in all
+  int units;                 // gather / image-layer forms: 32-position steps (row runs) in all
   int runsPerRow;            // Wm / 32 (row-run form)
   int inrelu;
   int biasTapRow;            // the tap row whose workgroups also sum the columns of P (it visits every position), -1: no bias gradient
-  float* wsBias;             // [slabs][Apad]
+  float* wsBias;             // [slabs of the bias tap row][Apad]
+  // Slabs: tap row tr is cut into X * mOf[tr] slabs of EQUAL WORK (X = 8: slab s runs on the XCD that holds the slabs of the other tap
+  // rows covering the same stretch of positions -- blocks b and b + 8 share an XCD's L2; X = 1 for small problems).  A tap row's work
+  // is the positions whose (frame, row) of Q is not padding for it: (T - 1) of T frames for the outer depth taps, (H - 1) of H rows
+  // for the outer kh, so the outer tap rows get fewer slabs.
+  int X, wgPerX;             // wgPerX = sum of mOf
+  short mOf[32];
 };
 
 __device__ __forceinline__ unsigned relu_pk(unsigned w) { return w & ~(((w & 0x80008000u) >> 15) * 0xffffu); }
@@ -73,8 +83,9 @@ __global__ __launch_bounds__(512, 1) void wgrad_bf16_kernel(const WArgs a) {
   constexpr int CA = TA / 8, CB = TB / 8;                            // 16-byte chunks per row
   constexpr int NPA = (32 * CA + 511) / 512, NPB = (NQ * CB + 511) / 512;
   constexpr int SA = 32 * PA, SB = NQ * PB;                          // bytes per run
-  static_assert(KR * (SA + SB) <= 65536, "static LDS");
-  __shared__ __attribute__((aligned(16))) unsigned char lds[KR * (SA + SB)];
+  constexpr int STAGE = KR * (SA + SB);                              // two stages: step n+1 is stored while step n is on the matrix pipe
+  static_assert(2 * STAGE <= 160 * 1024, "LDS");
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];      // 2 * STAGE bytes (wgrad_lds_bytes)
   unsigned char* const As = lds;
   unsigned char* const Bs = lds + KR * SA;
   const fo_conv_desc& d = a.d;
@@ -82,18 +93,30 @@ __global__ __launch_bounds__(512, 1) void wgrad_bf16_kernel(const WArgs a) {
   const int wa = wave / WB, wb = wave % WB;
   const int l15 = lane & 15, kg = lane >> 4;
 
-  // ---- this workgroup: (slab, tap row, tile a, tile b); the tap rows of a slab are neighbours in the grid (they walk the same positions: L2)
+  // ---- this workgroup: tile (a, b), then X-way interleaved (tap row, slab) pairs: see WArgs
   int w = blockIdx.x;
-  const int tr = w % a.tapRows; w /= a.tapRows;
-  const int tb = w % a.tilesB; w /= a.tilesB;
-  const int ta = w % a.tilesA;
-  const int slab = w / a.tilesA;
+  const int perTile = a.X * a.wgPerX;
+  const int tile = w / perTile; w -= tile * perTile;
+  const int tb = tile % a.tilesB, ta = tile / a.tilesB;
+  const int xcd = w % a.X;
+  int li = w / a.X, tr = 0;
+  while (li >= a.mOf[tr]) { li -= a.mOf[tr]; ++tr; }
+  const int slab = xcd * a.mOf[tr] + li, nslab = a.X * a.mOf[tr];
   // tap row -> (kd, kh) [row-run form: all kw] or one tap (kd, kh, kw) [gather form]; image layers: all of kh, kw
   int kd, kh, kw0;
   if (SMALLC) { kd = 0; kh = 0; kw0 = 0; }
   else if (FAST) { kd = tr / d.KH; kh = tr - kd * d.KH; kw0 = 0; }
   else { kd = tr / (d.KH * d.KW); const int r = tr - kd * d.KH * d.KW; kh = r / d.KW; kw0 = r - kh * d.KW; }
-  const int u0 = (int)((long long)a.units * slab / a.slabs), u1 = (int)((long long)a.units * (slab + 1) / a.slabs);
+  // the positions this tap row really visits (row-run form): frames tlo..thi of a clip, rows ylo..yhi -- "virtual units" v = (clip, t', y', run)
+  int tlo = 0, Tv = d.T, ylo = 0, Hv = d.Hm, vunits = a.units;
+  if (FAST && !SMALLC) {
+    tlo = max(0, d.padD - kd);
+    Tv = min(d.T - 1, d.T - 1 + d.padD - kd) - tlo + 1;
+    ylo = max(0, (d.padH - kh + d.stride - 1) / d.stride);
+    Hv = min(d.Hm - 1, (d.Hin - 1 + d.padH - kh) / d.stride) - ylo + 1;
+    vunits = (Tv > 0 && Hv > 0) ? (d.N / d.T) * Tv * Hv * a.runsPerRow : 0;
+  }
+  const int u0 = (int)((long long)vunits * slab / nslab), u1 = (int)((long long)vunits * (slab + 1) / nslab);
   const int HWm = d.Hm * d.Wm;
   const int M = d.N * HWm;
   const bool bias_wg = tb == 0 && tr == a.biasTapRow;                // this workgroup also sums the columns of P (the bias gradient)
@@ -105,47 +128,43 @@ __global__ __launch_bounds__(512, 1) void wgrad_bf16_kernel(const WArgs a) {
 #pragma unroll
   for (int i = 0; i < NPB; ++i) { const int id = tid + 512 * i; qrow[i] = id / CB; qcol[i] = id - qrow[i] * CB; }
   const int a0 = ta * TA, b0 = tb * TB;
-  u32x4 rp[KR][NPA], rq[KR][NPB];
+  constexpr int D = KR == 1 ? 3 : 2;                                 // K-steps of global loads in flight (register ring)
+  u32x4 rp[D][KR][NPA], rq[D][KR][NPB];
 
-  // a unit's validity (row-run form: the (frame, row) of Q this tap row reads is not padding) and its loads
-  auto unit_valid = [&](int u) -> bool {
-    if (!FAST || SMALLC) return true;
-    const int rowid = u / a.runsPerRow;                              // (frame, output row)
-    const int n = rowid / d.Hm, y = rowid - n * d.Hm;
-    const int t = n % d.T;
-    return ((unsigned)(t + kd - d.padD) < (unsigned)d.T) & ((unsigned)(y * d.stride + kh - d.padH) < (unsigned)d.Hin);
-  };
-  auto next_valid = [&](int u) -> int {
-    while (u < u1 && !unit_valid(u)) ++u;
-    return u;
-  };
-  auto load = [&](int u, u32x4 (&xp)[NPA], u32x4 (&xq)[NPB]) {       // u >= u1: zeros (a K-step's unused run)
-    const bool live = u < u1;
-    if (FAST) {
-      const int rowid = u / a.runsPerRow;
-      const int x0 = (u - rowid * a.runsPerRow) * 32;
-      const int n = rowid / d.Hm, y = rowid - n * d.Hm;
-      const long long pbase = ((long long)rowid * d.Wm + x0) * d.ldOut;
-      const int qx0 = x0 * d.stride - d.padW;
+  // Row-run form: the units are requested strictly in increasing order, so the position of the next one is a cursor advanced by
+  // increments (no divisions in the loop), and each thread's share of an address is a constant offset from a wave-uniform base.
+  int c_run = 0, c_y = 0, c_t = 0, c_clip = 0;                       // cursor = virtual unit (clip, t', y', run) of the next load
+  if (FAST) {
+    int v = u0;
+    c_run = v % a.runsPerRow; v /= a.runsPerRow;
+    c_y = v % max(Hv, 1); v /= max(Hv, 1);
+    c_t = v % max(Tv, 1); c_clip = v / max(Tv, 1);
+  }
+  int offP[NPA], offQ[NPB];
+  bool okP[NPA], okQ[NPB];
 #pragma unroll
-      for (int i = 0; i < NPA; ++i) {
-        const bool ok = live && prow[i] < 32 && a0 + pcol[i] * 8 < d.Cout;
-        xp[i] = ok ? *reinterpret_cast<const u32x4*>(a.P + pbase + (long long)prow[i] * d.ldOut + a0 + pcol[i] * 8) : u32x4{0, 0, 0, 0};
-      }
+  for (int i = 0; i < NPA; ++i) { offP[i] = prow[i] * d.ldOut + a0 + pcol[i] * 8; okP[i] = prow[i] < 32 && a0 + pcol[i] * 8 < d.Cout; }
+#pragma unroll
+  for (int i = 0; i < NPB; ++i) {
+    if (SMALLC) { offQ[i] = ((qrow[i] >> 5) * d.Win + (qrow[i] & 31) * d.stride + qcol[i]) * d.ldIn; okQ[i] = qrow[i] < NQ; }
+    else { offQ[i] = qrow[i] * d.ldIn + b0 + qcol[i] * 8; okQ[i] = qrow[i] < NQ && b0 + qcol[i] * 8 < d.Cin; }
+  }
+  auto load = [&](int u, u32x4 (&xp)[NPA], u32x4 (&xq)[NPB]) {       // u >= u1: zeros (a K-step's unused run)
+    const bool live = u < u1 && !(FO_ABLATE_W & 1);
+    if (FAST) {
+      const int n = c_clip * d.T + tlo + c_t, y = ylo + c_y, x0 = c_run * 32;
+      if (++c_run == a.runsPerRow) { c_run = 0; if (++c_y == Hv) { c_y = 0; if (++c_t == Tv) { c_t = 0; ++c_clip; } } }
+      const __bf16* const pb = a.P + (((long long)n * d.Hm + y) * d.Wm + x0) * d.ldOut;
+      const int qx0 = x0 * d.stride - d.padW, qy0 = y * d.stride + kh - d.padH;     // (image layers: kh = 0, the thread's own kh is in offQ)
+      const __bf16* const qb = a.Q + (((long long)(n + kd - d.padD) * d.Hin + qy0) * d.Win + qx0) * d.ldIn;
+#pragma unroll
+      for (int i = 0; i < NPA; ++i) xp[i] = (live && okP[i]) ? *reinterpret_cast<const u32x4*>(pb + offP[i]) : u32x4{0, 0, 0, 0};
 #pragma unroll
       for (int i = 0; i < NPB; ++i) {
-        if (SMALLC) {        // LDS row = kh * 32 + r (output pixel x0 + r), chunk c = tap kw: input pixel (2 y + kh - padH, 2 (x0 + r) - padW + c)
-          const int khq = qrow[i] >> 5, r = qrow[i] & 31;
-          const int qy = y * d.stride + khq - d.padH, dx = r * d.stride + qcol[i];
-          const bool ok = live && qrow[i] < NQ && (unsigned)qy < (unsigned)d.Hin && (unsigned)(qx0 + dx) < (unsigned)d.Win;
-          xq[i] = ok ? *reinterpret_cast<const u32x4*>(a.Q + (((long long)n * d.Hin + qy) * d.Win + qx0 + dx) * d.ldIn) : u32x4{0, 0, 0, 0};
-        } else {
-          const int qy = y * d.stride + kh - d.padH;
-          const long long qbase = (((long long)(n + kd - d.padD) * d.Hin + qy) * d.Win + qx0) * d.ldIn;
-          const int qx = qx0 + qrow[i];
-          const bool ok = live && qrow[i] < NQ && (unsigned)qx < (unsigned)d.Win && b0 + qcol[i] * 8 < d.Cin;
-          xq[i] = ok ? *reinterpret_cast<const u32x4*>(a.Q + qbase + (long long)qrow[i] * d.ldIn + b0 + qcol[i] * 8) : u32x4{0, 0, 0, 0};
-        }
+        bool ok = live && okQ[i];
+        if (SMALLC) ok = ok && (unsigned)(qy0 + (qrow[i] >> 5)) < (unsigned)d.Hin && (unsigned)(qx0 + (qrow[i] & 31) * d.stride + qcol[i]) < (unsigned)d.Win;
+        else ok = ok && (unsigned)(qx0 + qrow[i]) < (unsigned)d.Win;
+        xq[i] = ok ? *reinterpret_cast<const u32x4*>(qb + offQ[i]) : u32x4{0, 0, 0, 0};
       }
     } else {
 #pragma unroll
@@ -168,10 +187,11 @@ __global__ __launch_bounds__(512, 1) void wgrad_bf16_kernel(const WArgs a) {
       }
     }
   };
-  auto store = [&](int rr, const u32x4 (&xp)[NPA], const u32x4 (&xq)[NPB]) {
+  auto store = [&](int st, int rr, const u32x4 (&xp)[NPA], const u32x4 (&xq)[NPB]) {
+    if (FO_ABLATE_W & 2) return;
 #pragma unroll
     for (int i = 0; i < NPA; ++i)
-      if (prow[i] < 32) *reinterpret_cast<u32x4*>(As + rr * SA + prow[i] * PA + ((pcol[i] * 16) ^ (((prow[i] >> 3) & 1) << 5))) = xp[i];
+      if (prow[i] < 32) *reinterpret_cast<u32x4*>(As + st * STAGE + rr * SA + prow[i] * PA + ((pcol[i] * 16) ^ (((prow[i] >> 3) & 1) << 5))) = xp[i];
 #pragma unroll
     for (int i = 0; i < NPB; ++i)
       if (qrow[i] < NQ) {
@@ -180,7 +200,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_bf16_kernel(const WArgs a) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = relu_pk(v[e]);
         }
-        *reinterpret_cast<u32x4*>(Bs + rr * SB + qrow[i] * PB + ((qcol[i] * 16) ^ (((qrow[i] >> SWB) & 1) << 5))) = v;
+        *reinterpret_cast<u32x4*>(Bs + st * STAGE + rr * SB + qrow[i] * PB + ((qcol[i] * 16) ^ (((qrow[i] >> SWB) & 1) << 5))) = v;
       }
   };
 
@@ -212,14 +232,27 @@ __global__ __launch_bounds__(512, 1) void wgrad_bf16_kernel(const WArgs a) {
       parB[k][h] = (r >> SWB) & 1;
     }
 
-  auto compute = [&](int rr) {
-    bf16x8 fa[MA];
+  // one run on the matrix pipe: ALL of its fragments are read first (20 transposing reads in flight at once: their latency is paid once
+  // per run, not once per group of MFMAs -- the two waves of a SIMD leave the barrier together, so neither covers the other's waits),
+  // then the MFMAs issue back to back
+  auto compute = [&](int st, int rr) {
+    if (FO_ABLATE_W & 4) return;
+    bf16x8 fa[MA], fb[NKW][MB];
 #pragma unroll
     for (int i = 0; i < MA; ++i) {
-      const bf16x4 lo = tr_read(Af + rr * SA + ((colA + i * 32) ^ (parA << 5)));
-      const bf16x4 hi = tr_read(Af + rr * SA + 4 * PA + ((colA + i * 32) ^ (parA << 5)));
+      const bf16x4 lo = tr_read(Af + st * STAGE + rr * SA + ((colA + i * 32) ^ (parA << 5)));
+      const bf16x4 hi = tr_read(Af + st * STAGE + rr * SA + 4 * PA + ((colA + i * 32) ^ (parA << 5)));
       fa[i] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     }
+#pragma unroll
+    for (int k = 0; k < NKW; ++k)
+#pragma unroll
+      for (int j = 0; j < MB; ++j) {
+        const bf16x4 lo = tr_read(Bs + st * STAGE + rr * SB + rowB[k][0] + ((colB + j * 32) ^ (parB[k][0] << 5)));
+        const bf16x4 hi = tr_read(Bs + st * STAGE + rr * SB + rowB[k][1] + ((colB + j * 32) ^ (parB[k][1] << 5)));
+        fb[k][j] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+    __builtin_amdgcn_sched_barrier(0);
     if (bias_wg) {       // column sums of P: an MFMA against a fragment of ones, the MA tiles dealt over the WB waves that hold the same rows
 #pragma unroll
       for (int i = 0; i < MA; ++i)
@@ -228,52 +261,56 @@ __global__ __launch_bounds__(512, 1) void wgrad_bf16_kernel(const WArgs a) {
 #pragma unroll
     for (int k = 0; k < NKW; ++k)
 #pragma unroll
-      for (int j = 0; j < MB; ++j) {
-        const bf16x4 lo = tr_read(Bs + rr * SB + rowB[k][0] + ((colB + j * 32) ^ (parB[k][0] << 5)));
-        const bf16x4 hi = tr_read(Bs + rr * SB + rowB[k][1] + ((colB + j * 32) ^ (parB[k][1] << 5)));
-        const bf16x8 fb = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      for (int j = 0; j < MB; ++j)
 #pragma unroll
-        for (int i = 0; i < MA; ++i) acc[k][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb, acc[k][i][j], 0, 0, 0);
-      }
+        for (int i = 0; i < MA; ++i) acc[k][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[k][j], acc[k][i][j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
   };
 
-  // K-steps of KR valid runs each (a step's unused runs are zeros); the next step's rows fly during the MFMAs
-  int cur[KR], nxt[KR];
-  {
-    int u = next_valid(u0);
+  // K-steps of KR runs each (a last step's unused runs are zeros).  LDS holds two stages, registers a ring of D steps: iteration n puts
+  // stage n & 1 on the matrix pipe, then stores step n+1 (requested D compute phases ago: an HBM miss under load takes several) into the
+  // other stage and requests step n+1+D into the slot that freed.  ONE barrier per step.
+  if (u0 < u1) {
 #pragma unroll
-    for (int rr = 0; rr < KR; ++rr) { cur[rr] = u; u = u < u1 ? next_valid(u + 1) : u1; }
-  }
-  if (cur[0] < u1) {
+    for (int rr = 0; rr < KR; ++rr) load(u0 + rr, rp[0][rr], rq[0][rr]);
 #pragma unroll
-    for (int rr = 0; rr < KR; ++rr) load(cur[rr], rp[rr], rq[rr]);
-  }
-  while (cur[0] < u1) {
+    for (int rr = 0; rr < KR; ++rr) store(0, rr, rp[0][rr], rq[0][rr]);
 #pragma unroll
-    for (int rr = 0; rr < KR; ++rr) store(rr, rp[rr], rq[rr]);
+    for (int k = 1; k <= D; ++k)                                      // steps 1 .. D -> slots 1, 2, .., 0
+      if (u0 + k * KR < u1) {
+#pragma unroll
+        for (int rr = 0; rr < KR; ++rr) load(u0 + k * KR + rr, rp[k % D][rr], rq[k % D][rr]);
+      }
     __syncthreads();
-    {
-      int u = cur[KR - 1] < u1 ? next_valid(cur[KR - 1] + 1) : u1;
+    int u = u0;
+    while (u < u1) {
 #pragma unroll
-      for (int rr = 0; rr < KR; ++rr) { nxt[rr] = u; u = u < u1 ? next_valid(u + 1) : u1; }
+      for (int sl = 0; sl < 2 * D; ++sl) {     // step index n = sl (mod 2 D): LDS stage sl & 1 and register slot (sl + 1) % D are compile-time
+        if (u >= u1) break;
+        constexpr int dummy = 0; (void)dummy;
+        const int st = sl & 1;
+#pragma unroll
+        for (int rr = 0; rr < KR; ++rr)
+          if (u + rr < u1) compute(st, rr);
+        if (u + KR < u1) {
+#pragma unroll
+          for (int rr = 0; rr < KR; ++rr) store(st ^ 1, rr, rp[(sl + 1) % D][rr], rq[(sl + 1) % D][rr]);
+          if (u + (D + 1) * KR < u1) {
+#pragma unroll
+            for (int rr = 0; rr < KR; ++rr) load(u + (D + 1) * KR + rr, rp[(sl + 1) % D][rr], rq[(sl + 1) % D][rr]);
+          }
+        }
+        __syncthreads();
+        u += KR;
+      }
     }
-    if (nxt[0] < u1) {
-#pragma unroll
-      for (int rr = 0; rr < KR; ++rr) load(nxt[rr], rp[rr], rq[rr]);
-    }
-#pragma unroll
-    for (int rr = 0; rr < KR; ++rr)
-      if (cur[rr] < u1) compute(rr);
-    __syncthreads();
-#pragma unroll
-    for (int rr = 0; rr < KR; ++rr) cur[rr] = nxt[rr];
   }
 
   // ---- partial blocks -> ws[slab][tap][a][b]: accumulator register r of lane l = (a = 4 (l >> 4) + r, b = l & 15)
 #pragma unroll
   for (int k = 0; k < NKW; ++k) {
     const int tap = SMALLC ? k : (FAST ? tr * NKW + k : tr);
-    float* o = a.ws + (((long long)slab * (SMALLC ? 4 : a.taps) + tap) * a.Apad + a0 + wa * (TA / WA)) * a.Bpad + b0 + wb * (TB / WB);
+    float* o = a.ws + (((long long)slab * (SMALLC ? 4 : a.taps) + tap) * a.Apad + a0 + wa * (TA / WA)) * a.Bpad + b0 + wb * (TB / WB);   // (slab < X * mOf[tap row])
 #pragma unroll
     for (int i = 0; i < MA; ++i)
 #pragma unroll
@@ -297,8 +334,13 @@ __global__ __launch_bounds__(512, 1) void wgrad_bf16_kernel(const WArgs a) {
 // fourth slab, two loads in flight per lane (thin layers have up to 256 slabs of a few KB: a serial walk would be latency-bound).
 // smallc: ws[slab][kh][a][kw * 8 + c] -> dw[a][c][kh * 4 + kw].
 // The tail of the index space sums the bias-gradient slabs: db[a] = sum_slab wsBias[slab][a].
-__global__ __launch_bounds__(256) void wgrad_bf16_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int slabs, int taps, int Apad, int Bpad,
-                                                               int Areal, int Breal, int smallc, const float* __restrict__ wsBias, float* __restrict__ db) {
+struct RArgs {
+  int taps, Apad, Bpad, Areal, Breal, smallc, X, tapsPerRow, biasTapRow;
+  short mOf[32];             // slabs of tap row tr = X * mOf[tr]; tap row of tap t = t / tapsPerRow
+};
+__global__ __launch_bounds__(256) void wgrad_bf16_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, const RArgs q,
+                                                               const float* __restrict__ wsBias, float* __restrict__ db) {
+  const int taps = q.taps, Apad = q.Apad, Bpad = q.Bpad, Areal = q.Areal, Breal = q.Breal, smallc = q.smallc;
   __shared__ float red[4][64];
   const long long total = (long long)Areal * Breal * taps;
   const long long slabStride = (long long)(smallc ? 4 : taps) * Apad * Bpad;
@@ -309,16 +351,19 @@ __global__ __launch_bounds__(256) void wgrad_bf16_reduce_kernel(const float* __r
     const float* src = ws;
     long long stride = slabStride, dst = 0;
     bool ok = i < all, isb = false;
+    int slabs = 0;
     if (ok && i >= total) {
       isb = true;
       src = wsBias + (i - total);
       stride = Apad;
+      slabs = q.X * q.mOf[q.biasTapRow];
     } else if (ok) {
       const int b = (int)(i % Breal);
       const int aa = (int)((i / Breal) % Areal);
       const int tap = (int)(i / ((long long)Breal * Areal));
       src = ws + (smallc ? (((long long)(tap >> 2) * Apad + aa) * Bpad + (tap & 3) * 8 + b) : (((long long)tap * Apad + aa) * Bpad + b));
       dst = ((long long)aa * Breal + b) * taps + tap;
+      slabs = q.X * q.mOf[smallc ? 0 : tap / q.tapsPerRow];
     }
     float s0 = 0.f, s1 = 0.f;
     if (ok) {
@@ -379,7 +424,9 @@ __global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restr
 struct WPlan {
   int TA, TB, WA, NKW, KR;
   bool fast, smallc;
-  int tilesA, tilesB, tapRows, taps, units, slabs, Apad, Bpad, biasTapRow;
+  int tilesA, tilesB, tapRows, taps, units, Apad, Bpad, biasTapRow;
+  int X, wgPerX, maxSlabs;
+  short mOf[32];
 };
 
 int make_plan(const fo_conv_desc* d, WPlan* p) {
@@ -388,6 +435,7 @@ int make_plan(const fo_conv_desc* d, WPlan* p) {
   FO_REQUIRE(A % 8 == 0 && B % 8 == 0 && d->ldIn % 8 == 0 && d->ldOut % 8 == 0, FO_E_ALIGN, "wgrad_bf16: channel counts / strides must be multiples of 8");
   FO_REQUIRE(d->N > 0 && d->T > 0 && d->N % d->T == 0, FO_E_SHAPE, "wgrad_bf16: N must be whole clips");
   FO_REQUIRE((long long)d->N * d->Hm * d->Wm < (1ll << 31) && (long long)d->N * d->Hin * d->Win < (1ll << 31), FO_E_SHAPE, "wgrad_bf16: too many positions");
+  FO_REQUIRE(p->taps <= 32, FO_E_SHAPE, "wgrad_bf16: at most 32 taps");
   // the image layers' 8-channel Q takes its own form where the geometry allows (else the gather form with 24 of 32 columns masked)
   p->smallc = B == 8 && d->KW == 4 && d->KH == 4 && d->KD == 1 && d->stride == 2 && d->ldIn == 8 && d->Wm % 32 == 0 && A % 64 == 0;
   if (p->smallc) {
@@ -408,23 +456,67 @@ int make_plan(const fo_conv_desc* d, WPlan* p) {
   // waves: WA x (8 / WA) with at least one 16 x 16 tile per wave in either direction
   p->WA = (p->TA == 128 && p->TB == 128) ? 2 : (p->TA == 128 ? 4 : (p->TA == 64 ? (p->TB == 32 ? 4 : 2) : (p->TB == 128 ? 1 : 2)));
   const int perRun = p->NKW * (p->TA / p->WA / 16) * (p->TB / (8 / p->WA) / 16);      // MFMAs per wave and run
-  p->KR = perRun <= 6 ? 2 : 1;                                       // thin blocks: two runs per barrier pair
+  p->KR = perRun <= 8 ? 2 : 1;                                       // thin blocks: two runs per barrier
   p->tilesA = (A + p->TA - 1) / p->TA;
   p->tilesB = p->smallc ? 1 : (B + p->TB - 1) / p->TB;
   p->Apad = p->tilesA * p->TA;
   p->Bpad = p->tilesB * p->TB;
   p->units = p->fast ? d->N * d->Hm * (d->Wm / 32) : (int)(((long long)d->N * d->Hm * d->Wm + 31) / 32);
-  const int blocks = p->tilesA * p->tilesB * p->tapRows;
-  const int cus = fo_cu_count();
-  int s = std::max(1, cus / blocks);                                  // one round of workgroups (one per CU)
-  s = std::min(s, std::max(1, p->units / (4 * p->KR)));               // at least 4 K-steps per slab
-  p->slabs = s;
+  // ---- slabs per tap row, proportional to the positions the tap row really visits (see WArgs)
+  long long work[32], total = 0;
+  for (int tr = 0; tr < p->tapRows; ++tr) {
+    work[tr] = p->units;
+    if (p->fast && !p->smallc) {
+      const int kd = tr / d->KH, kh = tr % d->KH;
+      const int tlo = std::max(0, d->padD - kd), thi = std::min(d->T - 1, d->T - 1 + d->padD - kd);
+      const int ylo = std::max(0, (d->padH - kh + d->stride - 1) / d->stride), yhi = std::min(d->Hm - 1, (d->Hin - 1 + d->padH - kh) / d->stride);
+      work[tr] = (thi >= tlo && yhi >= ylo) ? (long long)(d->N / d->T) * (thi - tlo + 1) * (yhi - ylo + 1) * (d->Wm / 32) : 0;
+    }
+    total += work[tr];
+  }
+  const int tiles = p->tilesA * p->tilesB;
+  const int budget = std::max(p->tapRows, fo_cu_count() / tiles);     // workgroups per tile: one round, one workgroup per CU
+  p->X = budget >= 8 * p->tapRows ? 8 : 1;
+  int sum = 0;
+  for (int tr = 0; tr < p->tapRows; ++tr) {
+    long long m = total > 0 ? ((long long)budget * work[tr] + (long long)p->X * total / 2) / ((long long)p->X * total) : 1;   // round(budget / X * share)
+    const long long cap = work[tr] / ((long long)4 * p->KR * p->X);   // at least 4 K-steps per slab
+    m = std::max<long long>(1, std::min<long long>(m, std::max<long long>(1, cap)));
+    p->mOf[tr] = (short)std::min<long long>(m, 255);
+    sum += p->mOf[tr];
+  }
+  // never a second, nearly empty round of workgroups: trim the tap rows with the least work per slab
+  while ((long long)sum * p->X * tiles > fo_cu_count() && sum > p->tapRows) {
+    int best = -1;
+    for (int tr = 0; tr < p->tapRows; ++tr)
+      if (p->mOf[tr] > 1 && (best < 0 || work[tr] * p->mOf[best] < work[best] * p->mOf[tr])) best = tr;
+    if (best < 0) break;
+    --p->mOf[best]; --sum;
+  }
+  p->wgPerX = sum;
+  p->maxSlabs = 0;
+  for (int tr = 0; tr < p->tapRows; ++tr) p->maxSlabs = std::max(p->maxSlabs, p->X * p->mOf[tr]);
+  for (int tr = p->tapRows; tr < 32; ++tr) p->mOf[tr] = 0;
   return FO_OK;
+}
+
+template <int TA, int TB, int NKW, int KR, bool FAST, bool SMALLC>
+constexpr int wgrad_lds_bytes() {
+  constexpr int S = (NKW == 4 && !SMALLC) ? 2 : 1;
+  constexpr int NQ = SMALLC ? 128 : (FAST ? 32 * S + NKW - S : 32);
+  return 2 * KR * (32 * row_pitch(TA, 1) + NQ * row_pitch(TB, S));
 }
 
 template <int TA, int TB, int WA, int NKW, int KR, bool FAST, bool SMALLC>
 void launch_w(const WArgs& a, int grid, hipStream_t s) {
-  hipLaunchKernelGGL((wgrad_bf16_kernel<TA, TB, WA, NKW, KR, FAST, SMALLC>), dim3(grid), dim3(512), 0, s, a);
+  constexpr int ldsBytes = wgrad_lds_bytes<TA, TB, NKW, KR, FAST, SMALLC>();
+  void (*kern)(const WArgs) = wgrad_bf16_kernel<TA, TB, WA, NKW, KR, FAST, SMALLC>;
+  static bool attr_set = false;
+  if (!attr_set && ldsBytes > 48 * 1024) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, ldsBytes);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), ldsBytes, s, a);
 }
 
 // (block shape, taps per workgroup) -> instantiation; KR and WA follow from them (make_plan)
@@ -432,14 +524,14 @@ template <int NKW, bool FAST>
 bool dispatch(const WPlan& p, const WArgs& a, int grid, hipStream_t s) {
   const int key = p.TA * 1000 + p.TB;
   constexpr int K2 = 2;
-  if (key == 128128) { if (NKW == 1) launch_w<128, 128, 2, NKW, (NKW * 4 * 2 <= 6 ? K2 : 1), FAST, false>(a, grid, s); else launch_w<128, 128, 2, NKW, 1, FAST, false>(a, grid, s); }
-  else if (key == 128064) launch_w<128, 64, 4, NKW, (NKW * 2 * 2 <= 6 ? K2 : 1), FAST, false>(a, grid, s);
-  else if (key == 128032) launch_w<128, 32, 4, NKW, (NKW * 2 * 1 <= 6 ? K2 : 1), FAST, false>(a, grid, s);
-  else if (key == 64128) launch_w<64, 128, 2, NKW, (NKW * 2 * 2 <= 6 ? K2 : 1), FAST, false>(a, grid, s);
-  else if (key == 64064) launch_w<64, 64, 2, NKW, (NKW * 2 * 1 <= 6 ? K2 : 1), FAST, false>(a, grid, s);
-  else if (key == 64032) launch_w<64, 32, 4, NKW, (NKW * 1 * 1 <= 6 ? K2 : 1), FAST, false>(a, grid, s);
-  else if (key == 32128) launch_w<32, 128, 1, NKW, (NKW * 2 * 1 <= 6 ? K2 : 1), FAST, false>(a, grid, s);
-  else if (key == 32064) launch_w<32, 64, 2, NKW, (NKW * 1 * 1 <= 6 ? K2 : 1), FAST, false>(a, grid, s);
+  if (key == 128128) launch_w<128, 128, 2, NKW, (NKW * 4 * 2 <= 8 ? K2 : 1), FAST, false>(a, grid, s);
+  else if (key == 128064) launch_w<128, 64, 4, NKW, (NKW * 2 * 2 <= 8 ? K2 : 1), FAST, false>(a, grid, s);
+  else if (key == 128032) launch_w<128, 32, 4, NKW, (NKW * 2 * 1 <= 8 ? K2 : 1), FAST, false>(a, grid, s);
+  else if (key == 64128) launch_w<64, 128, 2, NKW, (NKW * 2 * 2 <= 8 ? K2 : 1), FAST, false>(a, grid, s);
+  else if (key == 64064) launch_w<64, 64, 2, NKW, (NKW * 2 * 1 <= 8 ? K2 : 1), FAST, false>(a, grid, s);
+  else if (key == 64032) launch_w<64, 32, 4, NKW, (NKW * 1 * 1 <= 8 ? K2 : 1), FAST, false>(a, grid, s);
+  else if (key == 32128) launch_w<32, 128, 1, NKW, (NKW * 2 * 1 <= 8 ? K2 : 1), FAST, false>(a, grid, s);
+  else if (key == 32064) launch_w<32, 64, 2, NKW, (NKW * 1 * 1 <= 8 ? K2 : 1), FAST, false>(a, grid, s);
   else return false;
   return true;
 }
@@ -447,12 +539,12 @@ bool dispatch(const WPlan& p, const WArgs& a, int grid, hipStream_t s) {
 }  // namespace
 
 // scratch: the slabs of partial filter gradients, then the slabs of partial bias gradients
-static int64_t ws_floats_main(const WPlan& p) { return (int64_t)p.slabs * (p.smallc ? 4 : p.taps) * p.Apad * p.Bpad; }
+static int64_t ws_floats_main(const WPlan& p) { return (int64_t)p.maxSlabs * (p.smallc ? 4 : p.taps) * p.Apad * p.Bpad; }
 
 extern "C" int64_t fo_wgrad_bf16_ws_bytes(const fo_conv_desc* d) {
   WPlan p;
   if (make_plan(d, &p) != FO_OK) return -1;
-  return (ws_floats_main(p) + (int64_t)p.slabs * p.Apad) * 4;
+  return (ws_floats_main(p) + (int64_t)p.maxSlabs * p.Apad) * 4;
 }
 
 extern "C" int fo_conv_wgrad_bf16(const fo_conv_desc* d, const void* P, const void* Q, float* dw, int Areal, int Breal, float* dbias, float* ws,
@@ -467,12 +559,14 @@ extern "C" int fo_conv_wgrad_bf16(const fo_conv_desc* d, const void* P, const vo
   WArgs a;
   a.d = *d;
   a.P = reinterpret_cast<const __bf16*>(P); a.Q = reinterpret_cast<const __bf16*>(Q); a.ws = ws;
-  a.tilesA = p.tilesA; a.tilesB = p.tilesB; a.slabs = p.slabs; a.tapRows = p.tapRows; a.taps = p.taps;
+  a.tilesA = p.tilesA; a.tilesB = p.tilesB; a.tapRows = p.tapRows; a.taps = p.taps;
+  a.X = p.X; a.wgPerX = p.wgPerX;
+  for (int i = 0; i < 32; ++i) a.mOf[i] = p.mOf[i];
   a.Apad = p.Apad; a.Bpad = p.Bpad; a.units = p.units; a.runsPerRow = p.fast ? d->Wm / 32 : 1;
   a.inrelu = (d->flags & FO_IN_RELU) ? 1 : 0;
   a.biasTapRow = dbias ? p.biasTapRow : -1;
   a.wsBias = ws + ws_floats_main(p);
-  const int grid = p.tilesA * p.tilesB * p.tapRows * p.slabs;
+  const int grid = p.tilesA * p.tilesB * p.X * p.wgPerX;
   hipStream_t s = (hipStream_t)stream;
   bool ok;
   if (p.smallc) { launch_w<64, 32, 4, 4, 2, true, true>(a, grid, s); ok = true; }
@@ -484,8 +578,11 @@ extern "C" int fo_conv_wgrad_bf16(const fo_conv_desc* d, const void* P, const vo
   FO_CHECK_LAUNCH();
   const long long total = (long long)Areal * Breal * p.taps + (dbias ? Areal : 0);
   const int rblocks = (int)std::min<long long>((total + 63) / 64, 16LL * fo_cu_count());
-  hipLaunchKernelGGL(wgrad_bf16_reduce_kernel, dim3(rblocks), dim3(256), 0, s, ws, dw, p.slabs, p.taps, p.Apad, p.Bpad, Areal, Breal, p.smallc ? 1 : 0,
-                     a.wsBias, dbias);
+  RArgs q;
+  q.taps = p.taps; q.Apad = p.Apad; q.Bpad = p.Bpad; q.Areal = Areal; q.Breal = Breal; q.smallc = p.smallc ? 1 : 0; q.X = p.X;
+  q.tapsPerRow = p.fast ? p.NKW : 1; q.biasTapRow = p.biasTapRow;
+  for (int i = 0; i < 32; ++i) q.mOf[i] = p.mOf[i];
+  hipLaunchKernelGGL(wgrad_bf16_reduce_kernel, dim3(rblocks), dim3(256), 0, s, ws, dw, q, a.wsBias, dbias);
   FO_CHECK_LAUNCH();
   return FO_OK;
 }

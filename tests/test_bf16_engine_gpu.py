@@ -82,7 +82,8 @@ def test_bf16_engine_step_vs_bf16_simulated_oracle_and_vs_fp32_oracle(B, T, H, W
     assert errs32[len(errs32) // 2][0] <= (1.25 if flips == 0 else 2.0) * sim32[len(sim32) // 2][0] + 1e-3
     # EMA codebook buffers (fp32 statistics of fp32 inputs; a flipped code moves two rows)
     for k in eng.buffers:
-        np.testing.assert_allclose(eng.buffers[k].cpu().double().norm().item(), r["fw"]["new_buffers"][k].double().norm().item(), rtol=5e-3)
+        np.testing.assert_allclose(eng.buffers[k].cpu().double().norm().item(), r["fw"]["new_buffers"][k].double().norm().item(),
+                                   rtol=5e-3 if flips == 0 else 5e-2)
 
 
 def test_bf16_engine_kernel_paths_agree(monkeypatch):
