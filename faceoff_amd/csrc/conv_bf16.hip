@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvArgsH a) {
 
   const fo_conv_desc& d = a.d;
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // (uniform: LDS-DMA destinations / wave roles must be scalar)
   const int l31 = lane & 31, half = lane >> 5;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
@@ -379,6 +379,10 @@ typedef __attribute__((address_space(3))) unsigned char lds_byte;
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, lds_byte* dst, unsigned voffset) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)dst, 16, voffset, 0, 0, 0);
 }
+// (per-lane part in a VGPR that is the same for every instruction, wave-uniform part in an SGPR: the range check sees the VGPR part only)
+__device__ __forceinline__ void dma16s(__amdgpu_buffer_rsrc_t r, lds_byte* dst, unsigned voffset, unsigned soffset) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)dst, 16, voffset, soffset, 0, 0);
+}
 
 template <int BN, int WAVES_M, int WAVES_N, int TM, int TN>
 __global__ __launch_bounds__(256, 2) void conv_bf16_dma_kernel(const ConvArgsH a) {
@@ -391,7 +395,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_dma_kernel(const ConvArgsH a
   __shared__ __attribute__((aligned(16))) unsigned char lds[LDSB];
   const fo_conv_desc& d = a.d;
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // (uniform: LDS-DMA destinations / wave roles must be scalar)
   const int l31 = lane & 31, half = lane >> 5;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int logical = fo_xcd_remap(blockIdx.x, gridDim.x);
@@ -511,7 +515,7 @@ __global__ __launch_bounds__(256) void conv_rgb_bf16_kernel(const ConvArgsH a, i
   __shared__ __attribute__((aligned(16))) float bias_s[64];
   const fo_conv_desc& d = a.d;
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // (uniform: LDS-DMA destinations / wave roles must be scalar)
   const int l31 = lane & 31, half = lane >> 5;
   unsigned char* patch = patch_all[wave];
   if (tid < 64) bias_s[tid] = (d.flags & FO_BIAS) ? a.bias[tid] : 0.f;
@@ -616,7 +620,7 @@ __global__ __launch_bounds__(256, 2) void conv_rgb_dgrad_bf16_kernel(const ConvA
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const fo_conv_desc& d = a.d;
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // (uniform: LDS-DMA destinations / wave roles must be scalar)
   const int l15 = lane & 15, quad = lane >> 4;
   const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in), 0, a.inBytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (unsigned)(((size_t)(a.M - 1) * d.ldOut + 8) * 2), 0x00020000);
@@ -740,7 +744,7 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_pp16_kernel(const ConvArgsH 
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const fo_conv_desc& d = a.d;
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // (uniform: LDS-DMA destinations / wave roles must be scalar)
   const int l15 = lane & 15, quad = lane >> 4;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const bool g1 = __builtin_amdgcn_readfirstlane(wave >> 2) != 0;
@@ -894,6 +898,175 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_pp16_kernel(const ConvArgsH 
       emit8(a, flags, v, mk[pp], ad[pp], (size_t)(m < a.M ? m : 0), co, m < a.M);
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------------ 64 input channels, 3x3: halo tiles
+// The short-K layers (VGG conv1_2 64 -> 64 at full resolution, conv2_1 64 -> 128, reference models/lpips.py:118-134, and their data
+// gradients where the gradient has 64 channels; K = 576) spend a tiled implicit GEMM mostly outside its K loop, and the tile's A operand
+// is re-fetched through L1 once per tap.  Here a workgroup of four waves walks output tiles of 4 rows x 32 pixels (persistent grid, TWO
+// workgroups per CU: one's epilogue stores and patch wait run beside the other's MFMAs -- with one workgroup per CU the store phase, 0.39 ms
+// of a 1.1 ms launch, overlapped nothing):
+//   * the tile's INPUT PATCH (6 rows x 34 pixels x 64 channels, zero halo) is DMA'd into LDS once -- as two 32-channel planes of 64-byte
+//     pixels, the 256-row kernel's layout and swizzle (conflict-free ds_read_b128), row pitch 48 pixels so that a tap's shift keeps the
+//     swizzle a per-lane constant -- and serves all nine taps; the next tile's patch flies during this tile's MFMAs (two LDS stages);
+//   * the FILTER never touches LDS: a wave owns 32 output channels of a 64-channel half and keeps their 9 x 64 x 32 fragment set in
+//     144 registers for the whole kernel (v_mfma_f32_16x16x32_bf16 with the filter as the ROW operand, 16 pixels as columns);
+//   * so a K-slice costs a wave 4 LDS reads for 8 MFMAs and nothing else; a lane's accumulator is 4 consecutive channels of one pixel
+//     (bias / ReLU mask / ReLU / bf16 rounding per lane, 8-byte stores).
+// Work item = (64-channel half of Cout, tile); a workgroup stays on one half.
+struct HaloArgs {
+  const __bf16* in;
+  const __bf16* wp;          // [Cout][9][64]
+  const float* bias;
+  const __bf16* mask;
+  __bf16* out;
+  int N, H, W, Cout, halves, tilesX, tilesY, ntiles;
+  int ldIn, ldOut, ldMask, flags;
+  unsigned inBytes;
+};
+
+__global__ __launch_bounds__(256, 2) void conv_halo64_bf16_kernel(const HaloArgs a) {
+  constexpr int PITCH = 48, ROWS = 6, PLANE = ROWS * PITCH * 64, STAGE = 2 * PLANE;     // bytes
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // (uniform: the DMA destinations and scalar offsets are derived from it)
+  const int l15 = lane & 15, quad = lane >> 4;
+  const int wm = wave >> 1, wn = wave & 1;                 // wave = rows 2 wm, 2 wm + 1 of the tile x output channels 32 wn .. + 31 of the half
+  const int half = blockIdx.x % a.halves;
+  const int wgInHalf = blockIdx.x / a.halves, wgsPerHalf = gridDim.x / a.halves;
+  // (the descriptor starts ONE PIXEL before the tensor, so that the patch's left halo column is a non-negative offset)
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.in) - a.ldIn, 0, a.inBytes + a.ldIn * 2, 0x00020000);
+  lds_byte* const lds3 = (lds_byte*)lds;
+
+  // ---- the filter fragments of this wave (wave = tile rows 2 wm, 2 wm + 1 x output channels 32 wn .. + 31 of the half):
+  // row (output channel) l15 of block j, k = tap * 64 + slice * 32 + quad * 8
+  bf16x8 wf[9][2][2];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        wf[t][sl][j] = *reinterpret_cast<const bf16x8*>(a.wp + (size_t)(half * 64 + wn * 32 + j * 16 + l15) * 576 + t * 64 + sl * 32 + quad * 8);
+
+  // ---- DMA roles: instruction id = (plane, patch row, 16-pixel group) = 36 per tile, dealt over the 4 waves; lane = (pixel l / 4, chunk
+  // position l % 4).  A lane's share of the source address is ONE constant register (pixel and swizzled chunk), the rest is scalar.
+  const int dpix = lane >> 2, dpos = lane & 3;
+  const unsigned dlane = (unsigned)(dpix * a.ldIn * 2 + ((dpos ^ swz(dpix)) * 16));
+  auto dma_tile = [&](int tile, int stage) {
+    if (FO_ABLATE_H & 8) return;
+    const bool live = tile < a.ntiles;
+    const int tx = tile % a.tilesX, r1 = tile / a.tilesX;
+    const int ty = r1 % a.tilesY, n = r1 / a.tilesY;
+    const int y0 = ty * 4 - 1, x0 = tx * 32;               // (x0: patch column 0 is image column x0 - 1 = descriptor pixel x0)
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const int id = wave + 4 * k;                         // 0 .. 35
+      const int pl = id / 18, rem = id - pl * 18, r = rem / 3, g = rem - r * 3;
+      const int iy = y0 + r;
+      const bool rowok = live & ((unsigned)iy < (unsigned)a.H);
+      const int ix = x0 - 1 + g * 16 + dpix;               // image column of this lane's pixel
+      const bool ok = rowok & ((unsigned)ix < (unsigned)a.W);
+      const unsigned soff = rowok ? (unsigned)((((size_t)n * a.H + iy) * a.W + x0 + g * 16) * a.ldIn * 2) + pl * 64 : 0u;
+      dma16s(rin, lds3 + stage * STAGE + pl * PLANE + (r * PITCH + g * 16) * 64, ok ? dlane : OOB, soff);
+    }
+  };
+
+  // ---- fragment addressing: pixel column l15 of a 16-pixel block at tap shift kw: patch pixel x16 + l15 + kw, chunk quad ^ swz
+  int cq[3];
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw) cq[kw] = (l15 + kw) * 64 + ((quad ^ swz(l15 + kw)) * 16);
+
+
+  float bv[2][4];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bv[j][r] = (a.flags & FO_BIAS) ? a.bias[half * 64 + wn * 32 + j * 16 + quad * 4 + r] : 0.f;
+
+  int tile = wgInHalf;
+  dma_tile(tile, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int it = 0; tile < a.ntiles; tile += wgsPerHalf, ++it) {
+    const int st = it & 1;
+    dma_tile(tile + wgsPerHalf, st ^ 1);                   // next tile's patch: lands during this tile's MFMAs
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const unsigned char* const base = lds + st * STAGE;
+    // 36 half-steps h = (tap, K-slice, pair of pixel blocks): two fragment reads, four MFMAs (no registers to read ahead: 144 hold the
+    // filter; the SIMD's other wave belongs to the CU's other workgroup, in another phase, and covers the wait)
+#pragma unroll
+    for (int h = 0; h < ((FO_ABLATE_H & 16) ? 0 : 36); ++h) {
+      const int tap = h >> 2, sl = (h >> 1) & 1, pr = h & 1, kh = tap / 3, kw = tap - kh * 3;
+      bf16x8 xf[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e)        // block i = 2 pr + e: tile row 2 wm + pr, pixels 16 e .. + 15
+        xf[e] = *reinterpret_cast<const bf16x8*>(base + sl * PLANE + ((2 * wm + pr + kh) * PITCH + e * 16) * 64 + cq[kw]);
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[2 * pr + e][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tap][sl][j], xf[e], acc[2 * pr + e][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- epilogue: acc[i][j][r] = channel 16 j + 4 quad + r of pixel (row 2 wm + (i >> 1), column 16 (i & 1) + l15)
+    const int tx = tile % a.tilesX, r1 = tile / a.tilesX;
+    const int ty = r1 % a.tilesY, n = r1 / a.tilesY;
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const size_t pix = ((size_t)n * a.H + ty * 4 + 2 * wm + (i >> 1)) * a.W + tx * 32 + (i & 1) * 16 + l15;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int co = half * 64 + wn * 32 + j * 16 + quad * 4;
+        float v[4] = {acc[i][j][0] + bv[j][0], acc[i][j][1] + bv[j][1], acc[i][j][2] + bv[j][2], acc[i][j][3] + bv[j][3]};
+        if (a.flags & FO_MASK) {
+          const bf16x4 mk = *reinterpret_cast<const bf16x4*>(a.mask + pix * a.ldMask + co);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = (float)mk[r] > 0.f ? v[r] : 0.f;
+        }
+        if (a.flags & FO_OUT_RELU) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
+        if (!(FO_ABLATE_H & 32)) *reinterpret_cast<bf16x4*>(a.out + pix * a.ldOut + co) = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+      }
+      __builtin_amdgcn_sched_barrier(0);                  // (one pixel block's mask loads and addresses at a time: the filter holds the registers)
+    }
+    // the next patch has landed: vmcnt retires in order and the 8 youngest operations are this tile's stores, which may keep flying
+    // (nothing reads them; the LDS stage they came from is not involved)
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+}
+
+static int launch_halo64(const ConvArgsH& c, hipStream_t s) {
+  const fo_conv_desc& d = c.d;
+  HaloArgs a;
+  a.in = reinterpret_cast<const __bf16*>(c.in); a.wp = reinterpret_cast<const __bf16*>(c.wp); a.bias = c.bias;
+  a.mask = reinterpret_cast<const __bf16*>(c.mask); a.out = reinterpret_cast<__bf16*>(c.out);
+  a.N = d.N; a.H = d.Hin; a.W = d.Win; a.Cout = d.Cout; a.halves = d.Cout / 64;
+  a.tilesX = d.Win / 32; a.tilesY = d.Hin / 4; a.ntiles = d.N * a.tilesX * a.tilesY;
+  a.ldIn = d.ldIn; a.ldOut = d.ldOut; a.ldMask = d.ldMask; a.flags = d.flags; a.inBytes = c.inBytes;
+  constexpr int ldsBytes = 2 * 2 * 6 * 48 * 64;            // two stages of two planes
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo64_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, ldsBytes) != hipSuccess) {
+      fo_set_error("conv_bf16: cannot reserve %d bytes of LDS", ldsBytes);
+      return FO_E_HIP;
+    }
+    attr_set = true;
+  }
+  const int cus = fo_cu_count();
+  int grid = std::min(2 * cus / a.halves * a.halves, a.ntiles * a.halves);          // two workgroups per CU
+  grid = std::max(a.halves, grid / a.halves * a.halves);
+  hipLaunchKernelGGL(conv_halo64_bf16_kernel, dim3(grid), dim3(256), ldsBytes, s, a);
+  FO_CHECK_LAUNCH();
+  return FO_OK;
 }
 
 template <int BMB, int BN, int WAVES_M, int WAVES_N>
@@ -1054,6 +1227,17 @@ static int conv_bf16_impl(const fo_conv_desc* d, const void* in, const void* wp,
     hipLaunchKernelGGL(conv_rgb_dgrad_bf16_kernel, dim3(std::min(nseg, 2 * fo_cu_count())), dim3(256), ldsBytes, s, a, nseg, segsPerRow);
     FO_CHECK_LAUNCH();
     return FO_OK;
+  }
+  // 64 input channels, 3x3, same size, frames of whole 4 x 32 tiles: the halo-tile kernel (filter in registers, input patch staged once)
+  {
+    const char* nohalo = getenv("FACEOFF_BF16_NO_HALO");             // diagnostics / A-B
+    const char* fhalo = getenv("FACEOFF_BF16_FORCE_HALO");           // tests: at any size
+    const long long tiles = (long long)d->N * (d->Hin / 4) * (d->Win / 32) * (d->Cout / 64);
+    if (!smallc && d->KD == 1 && d->Cin == 64 && d->Cout % 64 == 0 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->ostride == 1 && d->padH == 1 && d->padW == 1 &&
+        d->Hin == d->Hm && d->Win == d->Wm && d->Hm == d->Hout && d->Wm == d->Wout && d->Hin % 4 == 0 && d->Win % 32 == 0 &&
+        !(flags & ~(FO_BIAS | FO_MASK | FO_OUT_RELU)) && d->ldOut % 4 == 0 && (!(flags & FO_MASK) || d->ldMask % 4 == 0) &&
+        (tiles >= 8LL * fo_cu_count() || (fhalo && atoi(fhalo))) && !(nohalo && atoi(nohalo)))
+      return launch_halo64(a, s);
   }
   // big tiles (one workgroup per CU) where the launch still fills the chip for a few rounds: stride-1 same-size convs.
   // Measured at the C3 shapes and at a fifth of them (tools/ab_bf16.py): 256-column tiles +22...30 % over conv_bf16_kernel

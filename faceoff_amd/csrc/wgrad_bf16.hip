@@ -89,7 +89,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_bf16_kernel(const WArgs a) {
   unsigned char* const As = lds;
   unsigned char* const Bs = lds + KR * SA;
   const fo_conv_desc& d = a.d;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wa = wave / WB, wb = wave % WB;
   const int l15 = lane & 15, kg = lane >> 4;
 

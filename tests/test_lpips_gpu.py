@@ -135,6 +135,39 @@ def test_conv_bf16_vs_torch(cin, cout, hw, flags, big, monkeypatch):
         assert (out[..., cout:] == 0).all()
 
 
+@pytest.mark.parametrize("cout,hw,flags", [(64, (16, 32), "relu"), (128, (8, 64), "relu"), (64, (24, 96), "mask"), (192, (8, 32), "none")])
+def test_conv_bf16_halo_tile_kernel_vs_torch(cout, hw, flags, monkeypatch):
+    """conv_halo64_bf16_kernel (64 input channels, 3x3, frames of whole 8 x 32 tiles: VGG conv1_2 / conv2_1 and conv1_2's data gradient at
+    the C3 size; forced here at small sizes): input patch staged once per tile, filter fragments resident in registers.  Same contract as
+    test_conv_bf16_vs_torch; and equal to the tiled kernel's result up to summation order."""
+    from faceoff_amd import ops
+    rng = np.random.default_rng(cout + hw[0])
+    N, (H, W), cin = 3, hw, 64
+    x = _bf16_round(rng.standard_normal((N, cin, H, W)).astype(np.float32))
+    w = _bf16_round((rng.standard_normal((cout, cin, 3, 3)) / np.sqrt(9 * cin)).astype(np.float32))
+    b = torch.from_numpy(rng.standard_normal(cout).astype(np.float32)) if flags == "relu" else None
+    ref = torch.nn.functional.conv2d(x, w, b, padding=1)
+    mask = None
+    if flags == "relu":
+        ref = torch.relu(ref)
+    if flags == "mask":
+        mask = _bf16_round(rng.standard_normal((N, cout, H, W)).astype(np.float32)).clamp_min(0)
+        ref = ref * (mask > 0)
+    xg = x.permute(0, 2, 3, 1).contiguous().cuda().bfloat16()
+    wp = ops.pack_conv_bf16(w.cuda().contiguous())
+    outs = []
+    for halo in (True, False):
+        monkeypatch.setenv("FACEOFF_BF16_FORCE_HALO" if halo else "FACEOFF_BF16_NO_HALO", "1")
+        monkeypatch.delenv("FACEOFF_BF16_NO_HALO" if halo else "FACEOFF_BF16_FORCE_HALO", raising=False)
+        out = torch.full((N, H, W, cout), 7.0, dtype=torch.bfloat16, device="cuda")
+        ops.conv_bf16(xg, wp, None if b is None else b.cuda(), out, cin=cin, cout=cout, flags=ops.FO_OUT_RELU if flags == "relu" else 0,
+                      mask=None if mask is None else mask.permute(0, 2, 3, 1).contiguous().cuda().bfloat16())
+        outs.append(out.float().cpu().permute(0, 3, 1, 2))
+    tol = 2.0 ** -8 * ref.abs() + 2e-3 * ref.abs().max() / np.sqrt(9 * cin) + 1e-6
+    assert ((outs[0] - ref).abs() <= tol).all(), ((outs[0] - ref).abs() - tol).max()
+    assert ((outs[0] - outs[1]).abs() <= 2.0 ** -7 * ref.abs() + 1e-3 * ref.abs().max()).all()
+
+
 def test_pack_dgrad_bf16_is_the_conv_transpose():
     """conv_bf16 with the dgrad-packed filter == autograd's input gradient of the bf16-rounded conv."""
     from faceoff_amd import ops

@@ -15,7 +15,12 @@ from faceoff_amd.trainer import FaceOffTrainer  # noqa: E402
 dev = torch.device("cuda:0")
 B, T, H = 32, 5, 256
 eng = VQVAEEngine(make_state_dict(0, codebook_scale=0.3, gain=2.0), dev, dtype="bf16" if "--bf16" in sys.argv else "fp32")
-tr = FaceOffTrainer(eng)
+vqlpips = None
+if "--lpips" in sys.argv:
+    from faceoff_amd.loss import VQLPIPS
+    from faceoff_amd.synth import make_vgg_lpips_state
+    vqlpips = VQLPIPS(make_vgg_lpips_state(7), dtype="bf16").to(dev)
+tr = FaceOffTrainer(eng, vqlpips=vqlpips)
 if "--overlap" not in sys.argv:          # default: every kernel alone on the GPU (side streams folded into the main one)
     eng.set_stream_overlap(False)
 gen = torch.Generator(device=dev).manual_seed(1234)
