@@ -77,6 +77,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-x6-leg", action="store_true", help="skip the leg with the Winograd-domain GEMMs on the bf16 matrix pipe")
     ap.add_argument("--no-direct-leg", action="store_true", help="skip the short direct-convolution leg")
     ap.add_argument("--no-c5", action="store_true", help="skip the short config-5 (GAN iteration) leg")
+    ap.add_argument("--no-h2d-leg", action="store_true", help="skip the short host-fed leg")
     ap.add_argument("--lpips-dtype", choices=("bf16", "fp32"), default="bf16",
                     help="arithmetic of the LPIPS / VGG-16 branch (BASELINE config 3 = bf16)")
     ap.add_argument("--direct-conv", action="store_true",
@@ -448,6 +449,36 @@ def main():
                                    "dtype": "f32 (VQ-VAE) + %s (LPIPS)" % args.lpips_dtype,
                                    "loss": {"recon": round(r_f.item(), 6), "latent": round(l_f.item(), 6), "perceptual": round(p_f.item(), 6)}}
         del eng_f, tr_f
+        torch.cuda.empty_cache()
+
+    # ------------------------------------------------------------------ the headline step fed from host memory (SURVEY 8 f4 "feeding")
+    # utils.py:29-38 moves a clip to the GPU inside the step; here the loader's 5-tuples (pinned host memory, as DataLoader(pin_memory=True)
+    # yields them) are copied by faceoff_amd.feeder.HostFedBatches on a copy stream beside the previous step: 377 MB per step over PCIe
+    if not args.no_h2d_leg and not args.perceptual and not args.direct_conv:
+        eng_h, tr_h = make_trainer(winograd=True)
+        k_h = max(2, min(args.steps, 5))
+        gcpu = torch.Generator().manual_seed(4321 + rank)
+        host = [tuple((torch.rand((B, T, 3, H, H), generator=gcpu) * 2 - 1).pin_memory() if i != 4 else torch.empty(0) for i in range(5)) for _ in range(2)]
+        loader = [host[i % 2] for i in range(3 + k_h)]
+        sync()
+        it = tr_h.run_host_fed(loader)
+        for _ in range(3):
+            next(it)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(k_h):
+            r_h, l_h, _, _ = next(it)
+        sync()
+        dt_h = max_over_ranks(time.perf_counter() - t0)
+        it.close()
+        # the same trainer, same process state, with its inputs resident: the ratio of the two is the cost of feeding
+        dt_r, _, _ = timed(tr_h, k_h, 1)
+        out["h2d_fed"] = {"what": "the headline step with every batch copied from pinned host memory (source, background, source_images: "
+                                  f"{3 * frames * 3 * H * H * 4 / 1e6:.0f} MB per step) by a double-buffered copy stream beside the previous step; `value` keeps inputs resident",
+                          "value": round(world * frames * k_h / dt_h, 2), "unit": "frames/s", "ms_per_step": round(dt_h / k_h * 1e3, 3), "steps": k_h,
+                          "resident_ms_per_step_same_trainer": round(dt_r / k_h * 1e3, 3), "slowdown_vs_resident": round(dt_h / dt_r - 1.0, 4),
+                          "loss": {"recon": round(r_h.item(), 6), "latent": round(l_h.item(), 6)}}
+        del eng_h, tr_h, host, loader
         torch.cuda.empty_cache()
 
     # ------------------------------------------------------------------ BASELINE config 5: the two-optimiser GAN iteration

@@ -110,6 +110,16 @@ class FaceOffTrainer:
         self.optimizer.step(grad_scale=1.0 / self.world)   # DDP averages gradients
         return recon, S["diff"], perceptual
 
+    def run_host_fed(self, loader, max_steps=None):
+        """The training loop body over a loader of CPU 5-tuples with the host -> HBM copies double-buffered on a copy stream
+        (faceoff_amd.feeder.HostFedBatches): yields (recon, latent, perceptual, T) device scalars per step."""
+        from .feeder import HostFedBatches
+        for i, (parts, T, ground_truth) in enumerate(HostFedBatches(loader, self.engine.device)):
+            if max_steps is not None and i >= max_steps:
+                break
+            recon, latent, perceptual = self.step(parts, ground_truth, T=T)
+            yield recon, latent, perceptual, T
+
     def step_from_batch(self, data):
         """One iteration from the loader's 5-tuple (reference train loop :95 `process_data` + run_step + backward +
         optimizer): returns (recon_loss, latent_loss, perceptual_loss, S) like run_step (:32-47), losses as device scalars."""
