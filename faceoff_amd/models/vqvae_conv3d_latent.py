@@ -209,14 +209,24 @@ class VQVAE(nn.Module):
         self._last_ids = (id_t, id_b)
         return dec, diff
 
+    # (the staged entry points hand tensors in and out as fp32 NCHW like the reference; with FACEOFF_DTYPE=bf16 the engine's
+    # activations are bf16 channels-last tensors: converted at this boundary)
+    @staticmethod
+    def _act_in(eng, x_nhwc_f32):
+        return ops.to_bf16(x_nhwc_f32) if eng.bf16 else x_nhwc_f32
+
+    @staticmethod
+    def _act_out(t, c):
+        return ops.nhwc_to_nchw(ops.to_f32(t) if t.dtype == torch.bfloat16 else t, c)
+
     @torch.no_grad()
     def only_encode(self, input):
         """:237-241 -> (enc_b [N,128,H/4,W/4], enc_t [N,128,H/8,W/8])."""
         eng = self._bind(input.device)
         eng.pack_filters()
-        S = {"T": self.clip_len or input.shape[0], "x8": ops.nchw_to_nhwc(input.float().contiguous(), cpad=8)}
+        S = {"T": self.clip_len or input.shape[0], "x8": self._act_in(eng, ops.nchw_to_nhwc(input.float().contiguous(), cpad=8))}
         eng.stage_encode(S)
-        return ops.nhwc_to_nchw(S["eb"], 128), ops.nhwc_to_nchw(S["et"], 128)
+        return self._act_out(S["eb"], 128), self._act_out(S["et"], 128)
 
     @torch.no_grad()
     def encode_quantized(self, enc_b, enc_t):
@@ -224,13 +234,15 @@ class VQVAE(nn.Module):
         eng = self._bind(enc_b.device)
         eng.pack_filters()
         N, _, h4, w4 = enc_b.shape
-        S = {"T": self.clip_len or N, "d3": ops.nchw_to_nhwc(enc_t.float().contiguous())}
-        cat_b = torch.empty((N, h4, w4, 192), device=eng.device)
-        cat_b[..., 64:192] = ops.nchw_to_nhwc(enc_b.float().contiguous())
+        S = {"T": self.clip_len or N, "d3": self._act_in(eng, ops.nchw_to_nhwc(enc_t.float().contiguous()))}
+        cat_b = torch.empty((N, h4, w4, 192), device=eng.device, dtype=eng.act_dtype)
+        cat_b[..., 64:192] = self._act_in(eng, ops.nchw_to_nhwc(enc_b.float().contiguous()))
         S["cat_b"] = cat_b
         eng.stage_quantize(S, self.training)
         self._last_S = S
-        return (ops.nhwc_to_nchw(S["quant_t"], 64), ops.nhwc_to_nchw(S["cat_d"][..., 64:128], 64), S["diff"], S["id_t"], S["id_b"])
+        quant_t = S["quant_t_f32"] if eng.bf16 else S["quant_t"]          # (the quantiser's fp32 output where the engine keeps one)
+        quant_b = S["quant_b_f32"] if eng.bf16 else S["cat_d"][..., 64:128]
+        return (ops.nhwc_to_nchw(quant_t, 64), ops.nhwc_to_nchw(quant_b, 64), S["diff"], S["id_t"], S["id_b"])
 
     @torch.no_grad()
     def decode(self, quant_t, quant_b):
@@ -238,9 +250,9 @@ class VQVAE(nn.Module):
         eng = self._bind(quant_t.device)
         eng.pack_filters()
         N, _, h4, w4 = quant_b.shape
-        cat_d = torch.empty((N, h4, w4, 128), device=eng.device)
-        cat_d[..., 64:128] = ops.nchw_to_nhwc(quant_b.float().contiguous())
-        S = {"quant_t": ops.nchw_to_nhwc(quant_t.float().contiguous()), "cat_d": cat_d}
+        cat_d = torch.empty((N, h4, w4, 128), device=eng.device, dtype=eng.act_dtype)
+        cat_d[..., 64:128] = self._act_in(eng, ops.nchw_to_nhwc(quant_b.float().contiguous()))
+        S = {"quant_t": self._act_in(eng, ops.nchw_to_nhwc(quant_t.float().contiguous())), "cat_d": cat_d}
         eng.stage_decode(S)
         return ops.nhwc_to_nchw(S["dec"], self.in_channel)
 

@@ -145,3 +145,36 @@ def test_bf16_engine_at_the_timed_size_properties():
     cos = torch.nn.functional.cosine_similarity(runs[0][2].double(), e32.flat_grads.double(), dim=0).item()
     print(f"[bf16 vs fp32 engine at 160 x 256x256] losses {runs[0][:2]} vs {(r32.item(), d32.item())}; code agreement {agree}; gradient cosine {cos:.5f}")
     assert agree[0] > 0.98 and agree[1] > 0.90 and cos > 0.98, (agree, cos)
+
+
+def test_module_mirror_trains_and_infers_with_the_bf16_engine(monkeypatch):
+    """FACEOFF_DTYPE=bf16: the drop-in nn.Module (reference API, fp32 NCHW tensors in and out, fp32 nn.Parameters) on the bf16-operand
+    engine: a reference-style step (torch MSE loss, loss.backward(), torch.optim.Adam) equals the engine's fused step on the same data,
+    and the staged inference entry points (only_encode / encode_quantized / decode / decode_code) reproduce the eval forward."""
+    from faceoff_amd.models.vqvae_conv3d_latent import VQVAE
+    monkeypatch.setenv("FACEOFF_DTYPE", "bf16")
+    B, T, H, W = 2, 2, 64, 64
+    sd = make_state_dict(3, codebook_scale=0.3, gain=2.0)
+    img, gt = make_batch(41, B, T, H, W)
+    model = VQVAE(in_channel=6).to("cuda")
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    model.train()
+    x = torch.from_numpy(img).cuda()
+    y = torch.from_numpy(gt).reshape(B * T, 3, H, W).cuda()
+    out, latent = model(x)
+    assert model._engine.bf16 and out.dtype == torch.float32 and out.shape == (B * T, 6, H, W)
+    loss = torch.nn.functional.mse_loss(out[:, :3], y) + latent.mean()
+    loss.backward()
+    eng, recon, diff, S = _step(sd, img, gt, B, T, H, W)
+    np.testing.assert_allclose(loss.item(), recon.item() + diff.item(), rtol=1e-5)
+    params = dict(model.named_parameters())
+    worst = max(_rel_l2(params[k].grad, eng.grads[k]) for k in eng.grads)
+    assert worst < 1e-5, worst             # (same kernels, same inputs: only the fp32 loss gradient takes a different route into g_dec)
+    model.eval()
+    with torch.no_grad():
+        out2, _ = model(x)
+        id_t, id_b = model._last_ids
+        dec3 = model.decode_code(id_t, id_b)
+        enc_b, enc_t = model.only_encode(x.reshape(B * T, 6, H, W))
+    assert _rel_l2(dec3, out2) < 2e-2      # codes -> decode: the decoder input is the bf16-rounded codebook row in both
+    assert enc_b.shape == (B * T, 128, H // 4, W // 4) and enc_b.min().item() >= 0.0 and enc_t.shape == (B * T, 128, H // 8, W // 8)
