@@ -80,6 +80,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-h2d-leg", action="store_true", help="skip the short host-fed leg")
     ap.add_argument("--lpips-dtype", choices=("bf16", "fp32"), default="bf16",
                     help="arithmetic of the LPIPS / VGG-16 branch (BASELINE config 3 = bf16)")
+    ap.add_argument("--vqvae-dtype", choices=("fp32", "bf16"), default="fp32",
+                    help="arithmetic of the VQ-VAE convolutions in the TIMED workload (default fp32 = BASELINE config 2; with --perceptual, "
+                         "bf16 makes the timed workload config 3 as the `c3` leg runs it: what profiles/collect_extra.sh traces)")
     ap.add_argument("--direct-conv", action="store_true",
                     help="run the Conv3d / 3x3 128->128 layers on the direct implicit-GEMM kernels instead of Winograd "
                          "(the kernel-quality reference: same results to fp32 rounding, 1.5x the step time)")
@@ -263,7 +266,7 @@ def main():
                 "share_of_step_time": round(d["total_ms"] / (ms_serial * steps), 4)}
 
     # ------------------------------------------------------------------ the timed workload
-    eng, trainer = make_trainer(winograd=not args.direct_conv, perceptual=args.perceptual)
+    eng, trainer = make_trainer(winograd=not args.direct_conv, perceptual=args.perceptual, dtype=args.vqvae_dtype)
     dt, ms_events, (recon, latent, _) = timed(trainer, args.steps, args.warmup)
     comm = None
     if ddp:
@@ -315,6 +318,10 @@ def main():
         out["comm"] = comm
     if args.perceptual:
         out["dtype"] = "f32 (VQ-VAE) + %s (LPIPS)" % ("bf16" if args.lpips_dtype == "bf16" else "f32")
+    if args.vqvae_dtype == "bf16":
+        out["dtype"] = "bf16 operands / fp32 accumulate & master weights (VQ-VAE convolutions%s); VQ, losses, Adam fp32" % (
+            " and LPIPS" if args.perceptual and args.lpips_dtype == "bf16" else "")
+        out["config"]["workload"] = out["config"]["workload"].replace("C2 (fp32)", "C2").replace("C2:", "C2 on bf16 MFMA operands:")
     if ops.BF16X6:       # FACEOFF_BF16X6=1 for the whole run: say so in the line (the default run reports this path as the `bf16x6` leg)
         out["dtype"] += " [Winograd-domain GEMMs: each fp32 product as 6 bf16 MFMA partial products of an exact 3-way split, fp32 accumulate]"
         out["config"]["winograd_gemm_arithmetic"] = "bf16x6 (FACEOFF_BF16X6=1)"
@@ -356,7 +363,7 @@ def main():
                 pass
 
     # ------------------------------------------------------------------ the same step on direct convolutions
-    if winograd_on and not args.no_direct_leg and not args.no_kernel_events and not args.perceptual:
+    if winograd_on and not args.no_direct_leg and not args.no_kernel_events and not args.perceptual and args.vqvae_dtype == "fp32":
         eng_d, tr_d = make_trainer(winograd=False)
         k_d = max(2, min(args.steps, 5))
         dt_d, _, _ = timed(tr_d, k_d, 2)
@@ -373,7 +380,7 @@ def main():
 
     # ------------------------------------------------------------------ the same step, fp32 products on the bf16 matrix pipe
     # (opt-in FACEOFF_BF16X6=1; `value` above is the fp32-MFMA path unless that variable is set for the whole run)
-    if winograd_on and not args.no_x6_leg and not args.perceptual and not ops.BF16X6:
+    if winograd_on and not args.no_x6_leg and not args.perceptual and not ops.BF16X6 and args.vqvae_dtype == "fp32":
         ops.BF16X6 = True
         eng_x, tr_x = make_trainer(winograd=True)
         k_x = max(2, min(args.steps, 5))

@@ -13,7 +13,7 @@ SUM=gpurun_out/profiles_$TAG
 mkdir -p "$OUT" "$SUM"
 export TMPDIR=/tmp
 # --serial-streams: per-kernel durations need each kernel alone on the GPU (bench.py times its kernel events the same way)
-BENCH="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events --no-c3 --no-c5 --no-direct-leg --no-x6-leg --serial-streams"
+BENCH="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events --no-c3 --no-c5 --no-direct-leg --no-x6-leg --no-h2d-leg --serial-streams"
 
 if [ "$WHAT" = "trace" ] || [ "$WHAT" = "all" ]; then
   rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace -- $BENCH > "$OUT/trace.log" 2>&1

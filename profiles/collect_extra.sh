@@ -5,14 +5,14 @@ TAG=${1:-r02}
 OUT=gpurun_out/prof_${TAG}_extra
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/c3" -o c3 -- python3 bench.py --steps 2 --warmup 1 --perceptual --no-cpu-baseline --no-kernel-events --serial-streams > "$OUT/c3.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/c3" -o c3 -- python3 bench.py --steps 2 --warmup 1 --perceptual --vqvae-dtype bf16 --no-cpu-baseline --no-kernel-events --no-c5 --no-h2d-leg --serial-streams > "$OUT/c3.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/c5" -o c5 -- python3 tools/bench_gan.py 6 > "$OUT/c5.log" 2>&1
 python3 - "$OUT" "$TAG" <<'PY'
 import csv, glob, os, re, sys
 out, tag = sys.argv[1], sys.argv[2]
 def short(n):
     n = re.sub(r"\(anonymous namespace\)::", "", n); n = re.sub(r"^void ", "", n); return re.sub(r"\(.*\)$", "", n).strip()
-for leg, title in (("c3", "bench.py --perceptual --serial-streams --steps 2 --warmup 1 (C3: 3 steps traced)"), ("c5", "tools/bench_gan.py 6 (C5: 2 warm-up + 7-8 GAN iterations traced)")):
+for leg, title in (("c3", "bench.py --perceptual --vqvae-dtype bf16 --serial-streams --steps 2 --warmup 1 (C3, bf16 MFMA operands throughout: 3 steps traced)"), ("c5", "tools/bench_gan.py 6 (C5: 2 warm-up + 7-8 GAN iterations traced)")):
     rows = []
     for f in glob.glob(os.path.join(out, leg, "**", "*kernel_stats.csv"), recursive=True):
         rows += list(csv.DictReader(open(f)))
