@@ -208,6 +208,78 @@ __global__ void lpips_head_bwd_bf16_kernel(const bf16x8* __restrict__ f0, const 
   }
 }
 
+// Forward AND backward of one tap's head in ONE pass over the two feature maps (the upstream gradient of a tap's value is a known constant,
+// gscale * weight / (H W N): nothing of the backward waits for the loss): the per-frame sums of lpips_head_fwd_bf16_kernel and the gradient of
+// lpips_head_bwd_bf16_kernel from the same loads.  Saves one read of both maps per tap (2.7 GB at relu1_2).
+template <int LPP>
+__global__ void lpips_head_fwd_bwd_bf16_kernel(const bf16x8* __restrict__ f0, const bf16x8* __restrict__ f1, const float* __restrict__ lin,
+                                               float* __restrict__ val, const float* __restrict__ gscale, bf16x8* __restrict__ gf1, int HW,
+                                               long long npix, float inv_hw, float k_scale) {
+  constexpr int PPW = 64 / LPP;
+  const int lane = threadIdx.x & 63;
+  const int sub = lane % LPP, pl = lane / LPP;
+  const long long wave = (blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 6;
+  const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+  const long long per = ((npix + nwaves - 1) / nwaves + PPW - 1) / PPW * PPW;
+  const long long p_begin = wave * per, p_end = min(npix, p_begin + per);
+  const float gk = gscale[0] * k_scale;
+  float w[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) w[k] = lin[sub * 8 + k];
+  float run = 0.f;
+  long long run_n = -1;
+  for (long long p0 = p_begin; p0 < p_end; p0 += PPW) {
+    const long long p = p0 + pl;
+    const bool ok = p < p_end;
+    const long long pp = ok ? p : p_begin;
+    const bf16x8 a = f0[pp * LPP + sub], b = f1[pp * LPP + sub];
+    float sa = 0.f, sb = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { sa = fmaf((float)a[k], (float)a[k], sa); sb = fmaf((float)b[k], (float)b[k], sb); }
+    sa = group_sum<LPP>(sa); sb = group_sum<LPP>(sb);
+    const float na = sqrtf(sa), nb = sqrtf(sb);
+    const float ia = 1.f / (na + 1e-10f), ib = 1.f / (nb + 1e-10f);
+    float acc = 0.f, gn[8], dot = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float r = (float)a[k] * ia - (float)b[k] * ib;
+      acc = fmaf(w[k] * r, r, acc);
+      gn[k] = gk * 2.f * w[k] * ((float)b[k] * ib - (float)a[k] * ia);
+      dot = fmaf(gn[k], (float)b[k], dot);
+    }
+    dot = group_sum<LPP>(dot);
+    const float c2 = nb > 0.f ? dot * ib * ib / nb : 0.f;
+    bf16x8 rr;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) rr[k] = (__bf16)((float)b[k] > 0.f ? gn[k] * ib - (float)b[k] * c2 : 0.f);
+    if (ok) gf1[p * LPP + sub] = rr;
+    acc = ok ? acc : 0.f;
+    if (HW < 64) {   // tiny maps: a pass may span several frames -- one atomic per pixel (there are few)
+      acc = group_sum<LPP>(acc);
+      if (ok && sub == 0) atomicAdd(&val[p / HW], acc * inv_hw);
+      continue;
+    }
+    const long long n_first = p0 / HW;
+    const long long last = min(p0 + PPW, p_end) - 1;
+    const long long n_last = last / HW;
+    if (n_first != run_n) {
+      if (run_n >= 0) { const float t = group_sum<64>(run); if (lane == 0) atomicAdd(&val[run_n], t * inv_hw); }
+      run = 0.f; run_n = n_first;
+    }
+    if (n_last == n_first) {
+      run += acc;
+    } else {
+      const bool mine = (pp / HW) == n_first;
+      run += mine ? acc : 0.f;
+      const float t = group_sum<64>(run);
+      if (lane == 0) atomicAdd(&val[run_n], t * inv_hw);
+      run = mine ? 0.f : acc;
+      run_n = n_last;
+    }
+  }
+  if (run_n >= 0) { const float t = group_sum<64>(run); if (lane == 0) atomicAdd(&val[run_n], t * inv_hw); }
+}
+
 inline int grid_for(long long total, int cap = 4096) {
   return (int)std::max<long long>(1, std::min<long long>((total + 255) / 256, cap));
 }
@@ -269,6 +341,26 @@ int fo_lpips_tap_fwd_bf16(const void* f0, const void* f1, const float* lin, floa
   else if (C == 512) FO_HEAD_FWD(64);
   else FO_REQUIRE(false, FO_E_SHAPE, "lpips_tap_bf16: C must be 64/128/256/512 (got %d)", C);
 #undef FO_HEAD_FWD
+  FO_CHECK_LAUNCH();
+  return FO_OK;
+}
+
+int fo_lpips_tap_fwd_bwd_bf16(const void* f0, const void* f1, const float* lin, float* val, const float* gscale, void* gf1, int N, int H, int W,
+                              int C, void* stream) {
+  const long long npix = (long long)N * H * W;
+  const int grid = grid_for(npix * (C / 8), 4096);
+  const float inv = 1.f / (float)(H * W);
+  const float ks = 1.f / ((float)(H * W) * (float)N);
+#define FO_HEAD_FB(LPP_)                                                                                                 \
+  hipLaunchKernelGGL(lpips_head_fwd_bwd_bf16_kernel<LPP_>, dim3(grid), dim3(256), 0, (hipStream_t)stream,                \
+                     reinterpret_cast<const bf16x8*>(f0), reinterpret_cast<const bf16x8*>(f1), lin, val, gscale,          \
+                     reinterpret_cast<bf16x8*>(gf1), H * W, npix, inv, ks)
+  if (C == 64) FO_HEAD_FB(8);
+  else if (C == 128) FO_HEAD_FB(16);
+  else if (C == 256) FO_HEAD_FB(32);
+  else if (C == 512) FO_HEAD_FB(64);
+  else FO_REQUIRE(false, FO_E_SHAPE, "lpips_tap_bf16: C must be 64/128/256/512 (got %d)", C);
+#undef FO_HEAD_FB
   FO_CHECK_LAUNCH();
   return FO_OK;
 }

@@ -177,19 +177,26 @@ class LPIPSEngine:
             taps0, _ = self.features(self._prep(gt_nchw, nhwc=False), keep_all=False)
         taps1, acts = self.features(x1, keep_all=g_dec is not None)
         val = torch.zeros(N, device=self.device)
+        fused = self.bf16 and g_dec is not None          # training on the bf16 branch: value and gradient of a tap from ONE pass over its two maps
+        if gscale is None:
+            gscale = torch.ones(1, device=self.device)
+        head = []
         for k in range(5):
             n, h, w, c = taps1[k].shape
-            _lib.call("fo_lpips_tap_fwd_bf16" if self.bf16 else "fo_lpips_tap_fwd", ops._ptr(taps0[k]), ops._ptr(taps1[k]), ops._ptr(self.lin[k]), ops._ptr(val),
-                      n, h, w, c, ops._stream())
+            if fused:
+                g = torch.empty_like(taps1[k])
+                _lib.call("fo_lpips_tap_fwd_bwd_bf16", ops._ptr(taps0[k]), ops._ptr(taps1[k]), ops._ptr(self.lin[k]), ops._ptr(val), ops._ptr(gscale),
+                          ops._ptr(g), n, h, w, c, ops._stream())
+                head.append(g)
+            else:
+                _lib.call("fo_lpips_tap_fwd_bf16" if self.bf16 else "fo_lpips_tap_fwd", ops._ptr(taps0[k]), ops._ptr(taps1[k]), ops._ptr(self.lin[k]),
+                          ops._ptr(val), n, h, w, c, ops._stream())
         loss = val.mean().reshape(1)
         self.last_per_image = val
         if g_dec is None:
             return loss
-        if gscale is None:
-            gscale = torch.ones(1, device=self.device)
         # ---- backward, deepest stage first
-        head = []
-        for k in range(5):
+        for k in range(5 if not fused else 0):
             n, h, w, c = taps1[k].shape
             g = torch.empty_like(taps1[k])
             _lib.call("fo_lpips_tap_bwd_bf16" if self.bf16 else "fo_lpips_tap_bwd", ops._ptr(taps0[k]), ops._ptr(taps1[k]), ops._ptr(self.lin[k]), ops._ptr(gscale),

@@ -410,6 +410,10 @@ int fo_maxpool2_bwd_bf16(const void* x, const void* gy, const void* add, void* g
 int fo_lpips_tap_fwd_bf16(const void* f0, const void* f1, const float* lin, float* val, int N, int H, int W, int C, void* stream);
 int fo_lpips_tap_bwd_bf16(const void* f0, const void* f1, const float* lin, const float* gscale, void* gf1, int N, int H, int W,
                           int C, void* stream);
+/* fo_lpips_tap_fwd_bf16 and fo_lpips_tap_bwd_bf16 in ONE pass over the two feature maps (training: the tap's upstream gradient
+ * gscale[0] / (N H W) is known before its value is): val[n] += the tap's value per frame, gf1 = its gradient wrt f1. */
+int fo_lpips_tap_fwd_bwd_bf16(const void* f0, const void* f1, const float* lin, float* val, const float* gscale, void* gf1, int N, int H,
+                              int W, int C, void* stream);
 
 /* ---------------------------------------------------------------- optimiser + utilities */
 /* torch.optim.Adam defaults (train_faceoff_perceptual.py:190) over one flat parameter arena. */
