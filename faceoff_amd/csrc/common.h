@@ -18,6 +18,10 @@ int fo_wgrad_img_try(const fo_conv_desc* d, const float* P, const float* Q, floa
 int fo_conv_img_try(const fo_conv_desc* d, const float* in, const float* wp, const float* bias, const float* mask, const float* add,
                     float* out, hipStream_t stream);
 
+// resblock_halo.hip: ResBlock forward as a halo-tile kernel; 1 = launched, 0 = geometry not applicable
+int fo_resblock_halo_try(const fo_conv_desc* d, const float* x, const float* wp1, const float* b1, const float* wp3, const float* b3, float* hbuf,
+                         float* out, int ldOut2, int out_relu, hipStream_t stream);
+
 #define FO_CHECK_LAUNCH()                                                     \
   do {                                                                        \
     hipError_t e__ = hipGetLastError();                                       \

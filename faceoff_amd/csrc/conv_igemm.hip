@@ -651,6 +651,10 @@ extern "C" int fo_resblock_fwd(const fo_conv_desc* d, const float* x, const floa
              FO_E_SHAPE, "resblock_fwd: a 3x3 pad-1 stride-1 conv 128 -> 32 on a same-size grid is required");
   FO_REQUIRE(d->ldAdd >= 128 && d->ldAdd % 4 == 0 && ldOut2 >= 128 && ldOut2 % 4 == 0 && d->ldOut >= 32 && d->ldOut % 4 == 0 &&
                  fo_aligned16(hbuf) && fo_aligned16(out) && fo_aligned16(wp3), FO_E_ALIGN, "resblock_fwd: strides / alignment");
+  if (fo_resblock_halo_try(d, x, wp1, b1, wp3, b3, hbuf, out, ldOut2, out_relu, (hipStream_t)stream)) {   // widths that are multiples of 32
+    FO_CHECK_LAUNCH();
+    return FO_OK;
+  }
   fo_conv_desc dd = *d;
   dd.flags = FO_IN_RELU | FO_BIAS | FO_OUT_RELU;
   ConvArgs a;

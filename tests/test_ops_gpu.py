@@ -439,3 +439,43 @@ def test_fused_resblock_forward_equals_the_two_launch_form(N, H, W, out_relu):
     ops.conv_igemm(hb2, wp3, b3.cuda(), out2, k=(1, 1, 1), pad=(0, 0, 0), cin=32, cout=128, flags=ops.FO_OUT_RELU if out_relu else 0, add=xc)
     assert torch.equal(hb, hb2)                                   # same k-ordered MFMA chain for the 3x3 half
     assert (out - out2).abs().max().item() <= 1e-6 * out2.abs().max().item()
+
+
+@pytest.mark.parametrize("N,H,W,out_relu", [(3, 16, 32, False), (2, 6, 64, True), (1, 32, 32, False)])
+def test_resblock_halo_tile_kernel_vs_torch_and_vs_the_tiled_form(N, H, W, out_relu, monkeypatch):
+    """resblock_halo_fwd_kernel (csrc/resblock_halo.hip: input patch staged once per 2 x 32-pixel tile, contraction split over the waves with each
+    wave's filter slice resident in registers; taken at C2 sizes, forced here) against torch-CPU ResBlock arithmetic (reference
+    models/vqvae_conv3d_latent.py:86-101) and against the tiled fo_resblock_fwd: same bound, results equal up to summation order."""
+    import subprocess, sys, os, json
+    code = r"""
+import sys, json, torch
+sys.path.insert(0, %r)
+from faceoff_amd import ops
+N, H, W, out_relu = %d, %d, %d, %s
+g = torch.Generator().manual_seed(N * 100 + H)
+x = torch.randn((N, 128, H, W), generator=g)
+w1, b1 = torch.randn((32, 128, 3, 3), generator=g) * 0.05, torch.randn(32, generator=g) * 0.1
+w3, b3 = torch.randn((128, 32, 1, 1), generator=g) * 0.1, torch.randn(128, generator=g) * 0.1
+h_ref = torch.relu(torch.nn.functional.conv2d(torch.relu(x), w1, b1, padding=1))
+o_ref = torch.nn.functional.conv2d(h_ref, w3, b3) + x
+if out_relu: o_ref = torch.relu(o_ref)
+xc = x.permute(0, 2, 3, 1).contiguous().cuda()
+wide = torch.zeros((N, H, W, 192), device="cuda"); wide[..., 64:192] = xc          # also through a channel-slice view (ld = 192)
+wp1, wp3 = ops.pack_conv(w1.cuda()), ops.pack_conv(w3.cuda())
+res = {}
+for name, xin in (("dense", xc), ("slice", wide[..., 64:192])):
+    hb = torch.full((N, H, W, 32), 5.0, device="cuda"); out = torch.full((N, H, W, 128), -7.0, device="cuda")
+    ops.resblock_fwd(xin, wp1, b1.cuda(), wp3, b3.cuda(), hb, out, out_relu)
+    res[name] = ((hb.permute(0, 3, 1, 2).cpu() - h_ref).abs().max().item() / h_ref.abs().max().item(),
+                 (out.permute(0, 3, 1, 2).cpu() - o_ref).abs().max().item() / o_ref.abs().max().item())
+print(json.dumps(res))
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), N, H, W, out_relu)
+    outs = {}
+    for mode in ("halo", "tiled"):       # (the switch is read once per process)
+        env = dict(os.environ, **({"FACEOFF_FORCE_RESBLOCK_HALO": "1"} if mode == "halo" else {"FACEOFF_NO_RESBLOCK_HALO": "1"}))
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[mode] = json.loads(r.stdout.strip().splitlines()[-1])
+    for mode, res in outs.items():
+        for name, (eh, eo) in res.items():
+            assert eh <= 2e-5 and eo <= 2e-5, (mode, name, eh, eo)
