@@ -63,6 +63,8 @@ SIGNATURES = {
     "fo_conv_igemm": (_I, [_D, _P, _P, _P, _P, _P, _P, _P]),
     "fo_conv_igemm_variant": (_I, [_D]),
     "fo_resblock_fwd": (_I, [_D, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "fo_resblock_bwd_conv3_ws_bytes": (_L, [_L]),
+    "fo_resblock_bwd_conv3": (_I, [_L, _P, _I, _P, _I, _P, _P, _I, _P, _P, _P, _L, _P]),
     "fo_conv_igemm_banked": (_I, [_D, _P, _P, _P, _I, _P]),
     "fo_wino_gemm": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "fo_wino_gemm_split": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
@@ -72,6 +74,8 @@ SIGNATURES = {
     "fo_wgrad_banked_ws_bytes": (_L, [_D, _I]),
     "fo_conv_wgrad_banked": (_I, [_D, _P, _P, _P, _I, _I, _P, _L, _I, _P]),
     "fo_wino_gradout": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P]),
+    "fo_wino_gradout_bias_ws_bytes": (_L, [_I, _I, _I, _I, _I]),
+    "fo_wino_gradout_bias": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _L, _P]),
     "fo_w42_filter": (_I, [_P, _P, _I, _I, _I, _P]),
     "fo_w42_input_cells": (_I, [_P, _I, _P, _I, _I, _I, _I, _L, _P]),
     "fo_w42_input_full": (_I, [_P, _I, _P, _I, _I, _I, _I, _L, _P]),

@@ -22,6 +22,9 @@ int fo_conv_img_try(const fo_conv_desc* d, const float* in, const float* wp, con
 int fo_resblock_halo_try(const fo_conv_desc* d, const float* x, const float* wp1, const float* b1, const float* wp3, const float* b3, float* hbuf,
                          float* out, int ldOut2, int out_relu, hipStream_t stream);
 
+// elementwise.hip: out[c] = sum of the nblk partial rows ws[b][C], c < Creal (the second stage of every column sum)
+extern "C" int fo_colsum_finish(const float* ws, float* out, int nblk, int C, int Creal, void* stream);
+
 #define FO_CHECK_LAUNCH()                                                     \
   do {                                                                        \
     hipError_t e__ = hipGetLastError();                                       \

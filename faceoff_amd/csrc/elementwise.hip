@@ -86,12 +86,19 @@ __global__ void colsum_stage1(const float* __restrict__ g, float* __restrict__ w
   }
 }
 __global__ void colsum_stage2(const float* __restrict__ ws, float* __restrict__ out, int nblk, int C, int Creal) {
-  __shared__ float red[1024];   // 64 channels x 16 partial-sum lanes, combined in a fixed order
+  __shared__ float red[1024];   // 64 channels x 16 partial-sum lanes (four running sums each: four loads in flight), combined in a fixed order
   const int cl = threadIdx.x >> 6, li = threadIdx.x & 63;
   const int c = blockIdx.x * 64 + li;
   float s = 0.f;
-  if (c < Creal)
-    for (int b = cl; b < nblk; b += 16) s += ws[(size_t)b * C + c];
+  if (c < Creal) {
+    float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int b = cl;
+    for (; b + 48 < nblk; b += 64) {
+      s += ws[(size_t)b * C + c]; s1 += ws[(size_t)(b + 16) * C + c]; s2 += ws[(size_t)(b + 32) * C + c]; s3 += ws[(size_t)(b + 48) * C + c];
+    }
+    for (; b < nblk; b += 16) s += ws[(size_t)b * C + c];
+    s = (s + s1) + (s2 + s3);
+  }
   red[threadIdx.x] = s;
   __syncthreads();
   if (cl == 0 && c < Creal) {
@@ -190,6 +197,13 @@ int fo_bias_grad(const float* g, float* dbias, int64_t M, int C, int Creal, int 
   hipLaunchKernelGGL(colsum_stage1, dim3(nblk), dim3(256), 0, (hipStream_t)stream, g, ws, (long long)M, C, ld);
   FO_CHECK_LAUNCH();
   hipLaunchKernelGGL(colsum_stage2, dim3((Creal + 63) / 64), dim3(1024), 0, (hipStream_t)stream, ws, dbias, nblk, C, Creal);
+  FO_CHECK_LAUNCH();
+  return FO_OK;
+}
+
+// out[c] = sum over the nblk partial rows ws[b][C] (c < Creal): the second stage of every column-sum in this library
+int fo_colsum_finish(const float* ws, float* out, int nblk, int C, int Creal, void* stream) {
+  hipLaunchKernelGGL(colsum_stage2, dim3((Creal + 63) / 64), dim3(1024), 0, (hipStream_t)stream, ws, out, nblk, C, Creal);
   FO_CHECK_LAUNCH();
   return FO_OK;
 }

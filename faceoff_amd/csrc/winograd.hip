@@ -200,13 +200,18 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
 //   dM[xi][n][tile][co] = (A dY A^T)[xi]
 //   dU[xi][co][ci][kd]  = sum_{n,tile} dM[xi][n][tile][co] * V[xi][n + kd - 1][tile][ci]     (a*a wgrad GEMMs, banked)
 //   dW[co][ci][kd]      = G^T dU G                                    (a x a -> 3 x 3)
-template <int MT>
-__global__ __launch_bounds__(256) void wino_gradout_kernel(const float* __restrict__ g, int ldg, float* __restrict__ dM, int N, int H, int W, int C4) {
+// BIAS: the kernel reads every pixel of g exactly once, so the bias gradient (column sums of g) rides along instead of being a pass of its
+// own over g: a thread's channel group c is the same for every element it visits (C4 divides the block size), its running sum meets the
+// block's other threads of that group in LDS (fixed order) and the block's partial goes to bws[block][C] for colsum_stage2.
+template <int MT, bool BIAS>
+__global__ __launch_bounds__(256) void wino_gradout_kernel(const float* __restrict__ g, int ldg, float* __restrict__ dM, int N, int H, int W, int C4,
+                                                           float* __restrict__ bws) {
   using Wn = Wino<MT>;
   constexpr int A = Wn::A;
   const int Ht = H / MT, Wt = W / MT;
   const long long total = (long long)N * Ht * Wt * C4;
   const size_t plane = (size_t)N * Ht * Wt * C4 * 4;
+  f32x4 csum = {0.f, 0.f, 0.f, 0.f};
   for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
     const int c = (int)(e % C4);
     long long q = e / C4;
@@ -218,6 +223,12 @@ __global__ __launch_bounds__(256) void wino_gradout_kernel(const float* __restri
     for (int a = 0; a < MT; ++a)
 #pragma unroll
       for (int b = 0; b < MT; ++b) y[a][b] = ld4(g + ((n * H + MT * ty + a) * (long long)W + MT * tx + b) * ldg + c * 4);
+    if (BIAS) {
+#pragma unroll
+      for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < MT; ++b) csum += y[a][b];
+    }
     f32x4 r[A][MT];                      // r = A y   (A = (A^T)^T: r[i][b] = sum_a AT[a][i] y[a][b])
 #pragma unroll
     for (int i = 0; i < A; ++i)
@@ -238,6 +249,16 @@ __global__ __launch_bounds__(256) void wino_gradout_kernel(const float* __restri
         for (int b = 0; b < MT; ++b) axpy(acc, Wn::AT[b][j], r[i][b], first);
         st4(dst + (size_t)(A * i + j) * plane, acc);
       }
+  }
+  if (BIAS) {
+    __shared__ f32x4 red[256];
+    red[threadIdx.x] = csum;
+    __syncthreads();
+    if ((int)threadIdx.x < C4) {
+      f32x4 t = red[threadIdx.x];
+      for (int k = threadIdx.x + C4; k < 256; k += C4) t += red[k];
+      st4(bws + ((size_t)blockIdx.x * C4 + threadIdx.x) * 4, t);
+    }
   }
 }
 
@@ -330,10 +351,29 @@ int fo_wino_gradout(const float* g, int ldg, float* dM, int N, int H, int W, int
   FO_REQUIRE(H % m == 0 && W % m == 0 && C % 4 == 0 && ldg % 4 == 0 && fo_aligned16(g) && fo_aligned16(dM), FO_E_SHAPE,
              "wino_gradout: H, W multiples of m; C, ld %% 4 == 0; 16-byte alignment");
   const dim3 grid(grid_for((long long)N * (H / m) * (W / m) * (C / 4)));
-  if (m == 2) hipLaunchKernelGGL(wino_gradout_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, g, ldg, dM, N, H, W, C / 4);
-  else hipLaunchKernelGGL(wino_gradout_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, g, ldg, dM, N, H, W, C / 4);
+  if (m == 2) hipLaunchKernelGGL((wino_gradout_kernel<2, false>), grid, dim3(256), 0, (hipStream_t)stream, g, ldg, dM, N, H, W, C / 4, (float*)nullptr);
+  else hipLaunchKernelGGL((wino_gradout_kernel<4, false>), grid, dim3(256), 0, (hipStream_t)stream, g, ldg, dM, N, H, W, C / 4, (float*)nullptr);
   FO_CHECK_LAUNCH();
   return FO_OK;
+}
+
+// the same transform, with dbias[c] = column sums of g (c < C) riding along
+static int gradout_bias_grid(int N, int H, int W, int C, int m) { return grid_for((long long)N * (H / m) * (W / m) * (C / 4), 2048); }
+int64_t fo_wino_gradout_bias_ws_bytes(int N, int H, int W, int C, int m) {
+  if ((m != 2 && m != 4) || N <= 0 || C <= 0 || C % 4 != 0 || H % m != 0 || W % m != 0) return -1;
+  return (int64_t)gradout_bias_grid(N, H, W, C, m) * C * 4;
+}
+int fo_wino_gradout_bias(const float* g, int ldg, float* dM, int N, int H, int W, int C, int m, float* dbias, float* ws, int64_t ws_bytes, void* stream) {
+  FO_WINO_M(m);
+  FO_REQUIRE(H % m == 0 && W % m == 0 && C % 4 == 0 && ldg % 4 == 0 && fo_aligned16(g) && fo_aligned16(dM), FO_E_SHAPE,
+             "wino_gradout: H, W multiples of m; C, ld %% 4 == 0; 16-byte alignment");
+  FO_REQUIRE(256 % (C / 4) == 0, FO_E_SHAPE, "wino_gradout_bias: C / 4 must divide 256 (got C = %d)", C);
+  FO_REQUIRE(dbias && ws && ws_bytes >= fo_wino_gradout_bias_ws_bytes(N, H, W, C, m), FO_E_SHAPE, "wino_gradout_bias: dbias / workspace");
+  const int nblk = gradout_bias_grid(N, H, W, C, m);
+  if (m == 2) hipLaunchKernelGGL((wino_gradout_kernel<2, true>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, g, ldg, dM, N, H, W, C / 4, ws);
+  else hipLaunchKernelGGL((wino_gradout_kernel<4, true>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, g, ldg, dM, N, H, W, C / 4, ws);
+  FO_CHECK_LAUNCH();
+  return fo_colsum_finish(ws, dbias, nblk, C, C, stream);
 }
 
 int fo_wino_wgrad_out(const float* dU, float* dW, int O, int I, int KD, int m, void* stream) {

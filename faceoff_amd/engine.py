@@ -367,6 +367,7 @@ class VQVAEEngine:
         # (layer, pass) pairs kept OFF the F(4x4,2x2) form, pass in {"fwd", "dgrad", "wgrad"}
         self.w42_skip = {tuple(it.split(":")) for it in _os.environ.get("FACEOFF_W42_SKIP", "").split(",") if it}
         self.fused_resblock = not _os.environ.get("FACEOFF_NO_FUSED_RESBLOCK")
+        self.fused_resblock_bwd = self.fused_resblock and not _os.environ.get("FACEOFF_NO_FUSED_RESBLOCK_BWD")
         self.keep_wino_v = False      # training forward: keep each Conv3d's transformed input for its filter gradient
         # filter gradients start when the next Winograd-domain GEMM of their stream ENDS (beside the HBM-bound transforms that
         # follow it) rather than beside that GEMM: -0.33 ms per step (tools/ab.sh; holding one or three more back: +0.2...0.3)
@@ -431,9 +432,14 @@ class VQVAEEngine:
         """g_out: grad wrt (pre-ReLU) block output.  g_x = g_out + dgrad3x3(dgrad1x1(g_out)*(h>0))*(x>0)."""
         L = self.layers
         c3, c1 = L[prefix + ".conv.3"], L[prefix + ".conv.1"]
-        c3.wgrad(hbuf, g_out)
         g_h = torch.empty_like(hbuf)
-        c3.dgrad(g_out, g_h, mask=hbuf)
+        if self.fused_resblock_bwd and not self.bf16 and g_out.shape[-1] == 128:
+            # the 1x1's data, filter and bias gradients in one pass over g_out (three launches streamed it three times, each at the HBM roof)
+            ops.resblock_bwd_conv3(g_out, hbuf, c3.wp, g_h, c3.gw, c3.gb)
+            self._ready(c3.name)
+        else:
+            c3.wgrad(hbuf, g_out)
+            c3.dgrad(g_out, g_h, mask=hbuf)
         c1.wgrad(x, g_h, in_relu=True)
         c1.dgrad(g_h, g_x, mask=x, add=g_out)
 

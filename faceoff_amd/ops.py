@@ -212,6 +212,22 @@ def resblock_fwd(x, wp1, b1, wp3, b3, hbuf, out, out_relu):
         prof.end()
 
 
+def resblock_bwd_conv3(g, hbuf, wp3, g_h, dw3, db3):
+    """One pass over g (the ResBlock's output gradient) and hbuf (its hidden activation): g_h = (g W3) * (hbuf > 0), dw3 = g^T hbuf,
+    db3 = column sums of g (fo_resblock_bwd_conv3)."""
+    N, H, W, Cc = g.shape
+    assert Cc == 128 and hbuf.shape[-1] == 32 and g_h.shape[-1] == 32
+    M = N * H * W
+    ws = _workspace(_lib.load().fo_resblock_bwd_conv3_ws_bytes(C.c_int64(M)), g.device)
+    prof = PROFILER
+    if prof is not None:
+        prof.begin("resblock_bwd_conv3" + (f" [{N}x{H}x{W} 128->32 dgrad+wgrad+bias]" if prof.detail else ""), 2.0 * M * 128 * 32 * 2)
+    _lib.call("fo_resblock_bwd_conv3", C.c_int64(M), _ptr(g), ld_of(g), _ptr(hbuf), ld_of(hbuf), _ptr(wp3), _ptr(g_h), ld_of(g_h), _ptr(dw3), _ptr(db3),
+              _ptr(ws), C.c_int64(ws.numel() * 4), _stream())
+    if prof is not None:
+        prof.end()
+
+
 # ------------------------------------------------------------------ Winograd F(m x m, 3x3) Conv3d, m = 2 or 4
 def wino_tile(H, W, N=None):
     """Output-tile size for a Conv3d on HxW frames: 4 (4x fewer MFMA FLOP, fp32 error ~3e-6 of scale) when the plane
@@ -488,9 +504,9 @@ def wino_wgrad_ok(H, W, N, T, m=2, kd=3):
             and (m + 2) ** 2 * N * (H // m) * (W // m) * 128 * 4 < (1 << 31))
 
 
-def _wgrad_winograd_dU(g, x, *, T, a_real, b_real, V=None, m=2, kd=3):
+def _wgrad_winograd_dU(g, x, *, T, a_real, b_real, V=None, m=2, kd=3, dbias=None):
     """dU[xi][co][ci][kd] = sum over the frames of g / x of dM[xi] (x) V[xi]  (one banked wgrad GEMM launch); returns dU
-    (a slice of this stream's workspace)."""
+    (a slice of this stream's workspace).  dbias (optional): receives the column sums of g, formed inside g's transform."""
     N, H, W, _ = x.shape
     Ht, Wt, P = H // m, W // m, (m + 2) ** 2
     cin, cout = b_real, a_real
@@ -501,7 +517,13 @@ def _wgrad_winograd_dU(g, x, *, T, a_real, b_real, V=None, m=2, kd=3):
     else:
         V, dM = _wino_buffers((P * plane_v, P * plane_m), x.device)
         _lib.call("fo_wino_input", _ptr(x), ld_of(x), _ptr(V), N, H, W, cin, m, _stream())
-    _lib.call("fo_wino_gradout", _ptr(g), ld_of(g), _ptr(dM), N, H, W, cout, m, _stream())
+    if dbias is not None and 256 % (cout // 4) == 0:
+        bws = _workspace(_lib.load().fo_wino_gradout_bias_ws_bytes(N, H, W, cout, m), x.device)
+        _lib.call("fo_wino_gradout_bias", _ptr(g), ld_of(g), _ptr(dM), N, H, W, cout, m, _ptr(dbias), _ptr(bws), C.c_int64(bws.numel() * 4), _stream())
+    else:
+        _lib.call("fo_wino_gradout", _ptr(g), ld_of(g), _ptr(dM), N, H, W, cout, m, _stream())
+        if dbias is not None:
+            bias_grad(g, dbias, cout)
     d = _desc(N=P * N, T=T if kd > 1 else 1, Hin=1, Win=Ht * Wt, Hm=1, Wm=Ht * Wt, Hout=1, Wout=Ht * Wt, Cin=cin, Cout=cout, KD=kd,
               KH=1, KW=1, stride=1, padD=kd // 2, padH=0, padW=0, ostride=1, ophH=0, ophW=0, ldIn=cin, ldOut=cout, ldMask=0, ldAdd=0,
               flags=0)
@@ -532,10 +554,8 @@ def conv3d_wgrad_winograd(g, x, dw, dbias, *, T, a_real, b_real, V=None, m=2, kd
     N = x.shape[0]
     cin, cout = b_real, a_real
     P = (m + 2) ** 2
-    dU = _wgrad_winograd_dU(g, x, T=T, a_real=a_real, b_real=b_real, V=V, m=m, kd=kd)
+    dU = _wgrad_winograd_dU(g, x, T=T, a_real=a_real, b_real=b_real, V=V, m=m, kd=kd, dbias=dbias)
     _lib.call("fo_wino_wgrad_out", _ptr(dU), _ptr(dw), cout, cin, kd, m, _stream())
-    if dbias is not None:
-        bias_grad(g, dbias, cout)
 
 
 # ------------------------------------------------------------------ bf16 conv family (LPIPS branch)

@@ -116,6 +116,15 @@ int fo_conv_igemm(const fo_conv_desc* d, const float* in, const float* wp, const
 int fo_resblock_fwd(const fo_conv_desc* d, const float* x, const float* wp1, const float* b1, const float* wp3, const float* b3,
                     float* hbuf, float* out, int ldOut2, int out_relu, void* stream);
 
+/* Backward through a ResBlock's second convolution (reference models/vqvae_conv3d_latent.py:94-95,99: ReLU -> Conv2d(32, 128, 1); replaces the
+ * autograd nodes of that conv and of the ReLU in front of it) in one pass over the block's output gradient g [M][ldG] (128 channels) and the
+ * hidden activation h [M][ldH] (32 channels, post-ReLU, as fo_resblock_fwd left it):
+ *   gh [M][ldGh] = (g W3) * (h > 0),   dw3 [128][32] = g^T h,   db3 [128] (may be NULL) = column sums of g.
+ * wp3 = fo_pack_conv of the 1x1 filter.  ws: fo_resblock_bwd_conv3_ws_bytes(M) bytes.  Deterministic (fixed summation order). */
+int64_t fo_resblock_bwd_conv3_ws_bytes(int64_t M);
+int fo_resblock_bwd_conv3(int64_t M, const float* g, int ldG, const float* h, int ldH, const float* wp3, float* gh, int ldGh, float* dw3,
+                          float* db3, float* ws, int64_t ws_bytes, void* stream);
+
 /* fo_conv_igemm with the filter chosen per frame: frames [b*bank_frames, (b+1)*bank_frames) use the b-th of the
  * consecutive packed filter banks behind `wp`.  No bias / mask / residual.  Needs bank_frames*Hm*Wm % 128 == 0. */
 int fo_conv_igemm_banked(const fo_conv_desc* d, const float* in, const float* wp, float* out, int bank_frames, void* stream);
@@ -232,6 +241,11 @@ int fo_wino_output(const float* M, const float* bias, const float* mask, int ldM
  * gradient g [N,H,W,ldg]; then dU[xi] = sum_pixels dM[xi] (x) V[xi] shifted by the depth tap -- (m+2)^2 wgrad GEMMs in one
  * fo_conv_wgrad_banked launch ((3,1,1) geometry, planes as banks); then dW[O][I][KD][3][3] = G^T dU G. */
 int fo_wino_gradout(const float* g, int ldg, float* dM, int N, int H, int W, int C, int m, void* stream);
+/* The same transform with the layer's bias gradient riding along: dbias[c] = sum over the pixels of g[.][c], c < C (the transform reads every
+ * pixel of g exactly once; a separate column-sum pass would stream g again).  C / 4 must divide 256.  ws: fo_wino_gradout_bias_ws_bytes. */
+int64_t fo_wino_gradout_bias_ws_bytes(int N, int H, int W, int C, int m);
+int fo_wino_gradout_bias(const float* g, int ldg, float* dM, int N, int H, int W, int C, int m, float* dbias, float* ws, int64_t ws_bytes,
+                         void* stream);
 /* The dU GEMMs above with the fp32 products on the bf16 matrix pipe (csrc/wino_wgrad_split.hip; the arithmetic of
  * fo_wino_gemm_split): dU[xi][co][ci][kd] = sum_r dM[xi][r][co] * V[xi][r + (kd - KD/2) * P][ci] over the N * P rows of each of
  * `planes` planes, frames in clips of T.  dM [planes][N*P][Cout], V [planes][N*P][Cin] (dense), dU [planes][Cout][Cin][KD].

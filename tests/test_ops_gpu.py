@@ -479,3 +479,43 @@ print(json.dumps(res))
     for mode, res in outs.items():
         for name, (eh, eo) in res.items():
             assert eh <= 2e-5 and eo <= 2e-5, (mode, name, eh, eo)
+
+
+@pytest.mark.parametrize("N,H,W", [(2, 8, 8), (3, 7, 9), (160, 16, 16)])
+def test_resblock_bwd_conv3_one_pass_vs_torch_and_vs_the_three_launches(N, H, W):
+    """fo_resblock_bwd_conv3 (csrc/resblock_bwd.hip): the data, filter and bias gradients of a ResBlock's 1x1 convolution (reference
+    models/vqvae_conv3d_latent.py:94-95) in one pass over the output gradient -- against torch-CPU in float64 and against the three separate
+    launches it replaces; ragged pixel counts (not a multiple of the 64-pixel tile); through a channel-slice view; twice = bit-identical."""
+    from faceoff_amd import ops
+    gen = torch.Generator().manual_seed(N * 10 + W)
+    g = torch.randn((N, H, W, 128), generator=gen)
+    h = torch.relu(torch.randn((N, H, W, 32), generator=gen))          # post-ReLU hidden activation: about half zeros
+    w3 = torch.randn((128, 32, 1, 1), generator=gen) * 0.1
+    W2 = w3.reshape(128, 32).double()
+    G, Hh = g.reshape(-1, 128).double(), h.reshape(-1, 32).double()
+    gh_ref = (G @ W2) * (Hh > 0)
+    dw_ref, db_ref = G.t() @ Hh, G.sum(0)
+    gc, hc = g.cuda(), h.cuda()
+    wide = torch.zeros((N, H, W, 192), device="cuda"); wide[..., 32:160] = gc
+    wp3 = ops.pack_conv(w3.cuda())
+    outs = []
+    for gin in (gc, wide[..., 32:160], gc):
+        gh = torch.full((N, H, W, 32), 3.0, device="cuda"); dw = torch.full((128, 32), 9.0, device="cuda"); db = torch.full((128,), 9.0, device="cuda")
+        ops.resblock_bwd_conv3(gin, hc, wp3, gh, dw, db)
+        outs.append((gh.cpu(), dw.cpu(), db.cpu()))
+        scale = lambda t: t.abs().max().item()
+        assert (gh.cpu().reshape(-1, 32).double() - gh_ref).abs().max().item() <= 2e-6 * scale(gh_ref)
+        assert (dw.cpu().double() - dw_ref).abs().max().item() <= 2e-6 * max(scale(dw_ref), (G.abs().t() @ Hh).max().item())
+        assert (db.cpu().double() - db_ref).abs().max().item() <= 2e-6 * G.abs().sum(0).max().item()
+    for a, b in zip(outs[0], outs[2]):
+        assert torch.equal(a, b)                                   # fixed tile walk, fixed slab order
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)                                   # the pixel stride does not enter the arithmetic
+    # the launches it replaces
+    gh2 = torch.empty((N, H, W, 32), device="cuda"); dw2 = torch.empty((128, 32, 1, 1), device="cuda"); db2 = torch.empty((128,), device="cuda")
+    wpd = ops.pack_conv_dgrad(w3.cuda().reshape(128, 32, -1))
+    ops.conv_igemm(gc, wpd, None, gh2, k=(1, 1, 1), stride=1, pad=(0, 0, 0), cin=128, cout=32, mask=hc)
+    ops.conv_wgrad(gc, hc, dw2, db2, k=(1, 1, 1), stride=1, pad=(0, 0, 0), a_real=128, b_real=32)
+    assert (outs[0][0] - gh2.cpu()).abs().max().item() <= 2e-6 * gh2.abs().max().item()
+    assert (outs[0][1] - dw2.cpu().reshape(128, 32)).abs().max().item() <= 4e-6 * (G.abs().t() @ Hh).max().item()
+    assert (outs[0][2] - db2.cpu()).abs().max().item() <= 4e-6 * G.abs().sum(0).max().item()
