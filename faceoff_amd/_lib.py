@@ -82,6 +82,8 @@ SIGNATURES = {
     "fo_w42_output": (_I, [_P, _L, _P, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
     "fo_w42_output_cells": (_I, [_P, _L, _P, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
     "fo_w42_gradout": (_I, [_P, _I, _P, _I, _I, _I, _I, _L, _P]),
+    "fo_w42_gradout_bias_ws_bytes": (_L, [_I, _I, _I, _I]),
+    "fo_w42_gradout_bias": (_I, [_P, _I, _P, _I, _I, _I, _I, _L, _P, _P, _L, _P]),
     "fo_w42_wgrad_out": (_I, [_P, _P, _I, _I, _P]),
     "fo_wino_wgrad_out": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "fo_wino_filter": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),

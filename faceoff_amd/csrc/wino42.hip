@@ -241,10 +241,13 @@ __global__ __launch_bounds__(256) void w42_output_cells_kernel(const float* __re
 }
 
 // dM[xi][(n, ty, tx)][c] = (A dY A^T)[xi], dY = 4 x 4 tile of g[N][h][w]
+// BIAS: the bias gradient (column sums of g) rides along as in wino_gradout_kernel (winograd.hip): per-block partials to bws[block][4 C4]
+template <bool BIAS>
 __global__ __launch_bounds__(256) void w42_gradout_kernel(const float* __restrict__ g, int ldg, float* __restrict__ dM, int N, int h, int w,
-                                                          int C4, size_t plane) {
+                                                          int C4, size_t plane, float* __restrict__ bws) {
   const int Ht = h / MT, Wt = w / MT;
   const long long total = (long long)N * Ht * Wt * C4;
+  f32x4 csum = {0.f, 0.f, 0.f, 0.f};
   for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
     const int c = (int)(e % C4);
     long long q = e / C4;
@@ -256,6 +259,12 @@ __global__ __launch_bounds__(256) void w42_gradout_kernel(const float* __restric
     for (int a = 0; a < MT; ++a)
 #pragma unroll
       for (int b = 0; b < MT; ++b) y[a][b] = ld4(g + ((n * h + MT * ty + a) * (long long)w + MT * tx + b) * ldg + c * 4);
+    if (BIAS) {
+#pragma unroll
+      for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < MT; ++b) csum += y[a][b];
+    }
     f32x4 r[A][MT];
 #pragma unroll
     for (int i = 0; i < A; ++i)
@@ -276,6 +285,16 @@ __global__ __launch_bounds__(256) void w42_gradout_kernel(const float* __restric
         for (int b = 0; b < MT; ++b) axpy(acc, W42::AT[b][j], r[i][b], first);
         st4(dst + (size_t)(A * i + j) * plane, acc);
       }
+  }
+  if (BIAS) {
+    __shared__ f32x4 red[256];
+    red[threadIdx.x] = csum;
+    __syncthreads();
+    if ((int)threadIdx.x < C4) {
+      f32x4 t = red[threadIdx.x];
+      for (int k = threadIdx.x + C4; k < 256; k += C4) t += red[k];
+      st4(bws + ((size_t)blockIdx.x * C4 + threadIdx.x) * 4, t);
+    }
   }
 }
 
@@ -384,10 +403,31 @@ int fo_w42_gradout(const float* g, int ldg, float* dM, int N, int h, int w, int 
   FO_REQUIRE(h % 4 == 0 && w % 4 == 0 && C % 4 == 0 && ldg % 4 == 0 && fo_aligned16(g) && fo_aligned16(dM), FO_E_SHAPE,
              "w42_gradout: h, w multiples of 4; C, ld %% 4 == 0; 16-byte alignment");
   FO_REQUIRE(planeRows >= (long long)N * (h / 4) * (w / 4), FO_E_SHAPE, "w42_gradout: plane shorter than the tile count");
-  hipLaunchKernelGGL(w42_gradout_kernel, dim3(grid_for((long long)N * (h / 4) * (w / 4) * (C / 4))), dim3(256), 0, (hipStream_t)stream, g, ldg,
-                     dM, N, h, w, C / 4, (size_t)planeRows * C);
+  hipLaunchKernelGGL(w42_gradout_kernel<false>, dim3(grid_for((long long)N * (h / 4) * (w / 4) * (C / 4))), dim3(256), 0, (hipStream_t)stream, g, ldg,
+                     dM, N, h, w, C / 4, (size_t)planeRows * C, (float*)nullptr);
   FO_CHECK_LAUNCH();
   return FO_OK;
+}
+
+// the same transform with dbias[c] = column sums of g (c < C) riding along
+static int w42_gradout_bias_grid(int N, int h, int w, int C) {
+  return (int)std::max<long long>(1, std::min<long long>(((long long)N * (h / 4) * (w / 4) * (C / 4) + 255) / 256, 2048));
+}
+int64_t fo_w42_gradout_bias_ws_bytes(int N, int h, int w, int C) {
+  if (N <= 0 || C <= 0 || C % 4 != 0 || h % 4 != 0 || w % 4 != 0) return -1;
+  return (int64_t)w42_gradout_bias_grid(N, h, w, C) * C * 4;
+}
+int fo_w42_gradout_bias(const float* g, int ldg, float* dM, int N, int h, int w, int C, long long planeRows, float* dbias, float* ws, int64_t ws_bytes,
+                        void* stream) {
+  FO_REQUIRE(h % 4 == 0 && w % 4 == 0 && C % 4 == 0 && ldg % 4 == 0 && fo_aligned16(g) && fo_aligned16(dM), FO_E_SHAPE,
+             "w42_gradout: h, w multiples of 4; C, ld %% 4 == 0; 16-byte alignment");
+  FO_REQUIRE(planeRows >= (long long)N * (h / 4) * (w / 4), FO_E_SHAPE, "w42_gradout: plane shorter than the tile count");
+  FO_REQUIRE(256 % (C / 4) == 0, FO_E_SHAPE, "w42_gradout_bias: C / 4 must divide 256 (got C = %d)", C);
+  FO_REQUIRE(dbias && ws && ws_bytes >= fo_w42_gradout_bias_ws_bytes(N, h, w, C), FO_E_SHAPE, "w42_gradout_bias: dbias / workspace");
+  const int nblk = w42_gradout_bias_grid(N, h, w, C);
+  hipLaunchKernelGGL(w42_gradout_kernel<true>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, g, ldg, dM, N, h, w, C / 4, (size_t)planeRows * C, ws);
+  FO_CHECK_LAUNCH();
+  return fo_colsum_finish(ws, dbias, nblk, C, C, stream);
 }
 
 int fo_w42_wgrad_out(const float* dU, float* dW, int O, int I, void* stream) {

@@ -220,8 +220,7 @@ class _Layer:
             V = S.get("_wino_v", {}).pop(self.name, None) if S is not None else None
             if V is not None and self.engine.wgrad_stream is not None:
                 self.engine._keepalive.append(V)
-            ops.conv_k4s2_wgrad_winograd(x, g, self.gw, cin=self.ci, cout=self.co, V=V)
-            ops.bias_grad(g, self.gb, self.co)
+            ops.conv_k4s2_wgrad_winograd(x, g, self.gw, cin=self.ci, cout=self.co, V=V, dbias=self.gb)
         elif (self._winograd_m(x) and not in_relu and self.ci == self.cip
               and ops.wino_wgrad_ok(x.shape[1], x.shape[2], x.shape[0], T, self._winograd_m(x), self._wino_kd)):
             S = self.engine._cur_S if self.engine is not None else None

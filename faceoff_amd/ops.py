@@ -458,10 +458,11 @@ def w42_wgrad_ok(N, H, W, cin, cout):
             and 25 * _rows128(rows) * max(4 * cin, cout) * 4 < (1 << 31))
 
 
-def conv_k4s2_wgrad_winograd(x, g, dw, *, cin, cout, V=None):
+def conv_k4s2_wgrad_winograd(x, g, dw, *, cin, cout, V=None, dbias=None):
     """dw [cout][cin][4][4] = filter gradient of Conv2d k4 s2 p1 from its input x [N,H,W,>=cin] and output gradient
     g [N,H/2,W/2,>=cout] (for a ConvTranspose2d: x := its output gradient, g := its input, dw its [I_T][O_T][4][4] weight).
-    V: the forward's transformed input (conv_k4s2_winograd(keep_v=True)), rows padded to 128."""
+    V: the forward's transformed input (conv_k4s2_winograd(keep_v=True)), rows padded to 128.  dbias (optional): column sums of g, formed
+    inside g's transform."""
     N, H, W, _ = x.shape
     tiles = N * (H // 8) * (W // 8)
     K = 4 * cin
@@ -474,7 +475,14 @@ def conv_k4s2_wgrad_winograd(x, g, dw, *, cin, cout, V=None):
         _lib.call("fo_w42_input_cells", _ptr(x), ld_of(x), _ptr(V), N, H, W, cin, C.c_int64(rows), _stream())
     if rows != tiles:
         dM[:25 * rows * cout].zero_()                                  # the padding rows of a plane contribute nothing
-    _lib.call("fo_w42_gradout", _ptr(g), ld_of(g), _ptr(dM), N, H // 2, W // 2, cout, C.c_int64(rows), _stream())
+    if dbias is not None and cout % 4 == 0 and 256 % (cout // 4) == 0:
+        bws = _workspace(_lib.load().fo_w42_gradout_bias_ws_bytes(N, H // 2, W // 2, cout), x.device)
+        _lib.call("fo_w42_gradout_bias", _ptr(g), ld_of(g), _ptr(dM), N, H // 2, W // 2, cout, C.c_int64(rows), _ptr(dbias), _ptr(bws),
+                  C.c_int64(bws.numel() * 4), _stream())
+    else:
+        _lib.call("fo_w42_gradout", _ptr(g), ld_of(g), _ptr(dM), N, H // 2, W // 2, cout, C.c_int64(rows), _stream())
+        if dbias is not None:
+            bias_grad(g, dbias, cout)
     # planes as frames of a (1,1,1) wgrad: one "frame" per plane with `rows` positions
     d = _desc(N=25, T=1, Hin=1, Win=rows, Hm=1, Wm=rows, Hout=1, Wout=rows, Cin=K, Cout=cout, KD=1, KH=1, KW=1, stride=1, padD=0, padH=0,
               padW=0, ostride=1, ophH=0, ophW=0, ldIn=K, ldOut=cout, ldMask=0, ldAdd=0, flags=0)

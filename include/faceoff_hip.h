@@ -276,6 +276,10 @@ int fo_w42_output(const float* M, long long planeRows, const float* bias, const 
 int fo_w42_output_cells(const float* M, long long planeRows, const float* bias, const float* mask, int ldMask, const float* add, int ldAdd,
                         float* out, int ldOut, int N, int h, int w, int C, int flags, void* stream);
 int fo_w42_gradout(const float* g, int ldg, float* dM, int N, int h, int w, int C, long long planeRows, void* stream);
+/* ... with the layer's bias gradient (dbias[c] = column sums of g) riding along, as fo_wino_gradout_bias. */
+int64_t fo_w42_gradout_bias_ws_bytes(int N, int h, int w, int C);
+int fo_w42_gradout_bias(const float* g, int ldg, float* dM, int N, int h, int w, int C, long long planeRows, float* dbias, float* ws,
+                        int64_t ws_bytes, void* stream);
 int fo_w42_wgrad_out(const float* dU /* [25][O][4 I] */, float* dW, int O, int I, void* stream);
 
 /* ---------------------------------------------------------------- input pipeline / validation helpers on the device
