@@ -22,6 +22,10 @@ int fo_conv_img_try(const fo_conv_desc* d, const float* in, const float* wp, con
 int fo_resblock_halo_try(const fo_conv_desc* d, const float* x, const float* wp1, const float* b1, const float* wp3, const float* b3, float* hbuf,
                          float* out, int ldOut2, int out_relu, hipStream_t stream);
 
+// resblock_bwd.hip: 3x3 pad-1 stride-1 conv 32 -> 128 with mask / add epilogue (a ResBlock's first conv, backwards) as a halo-tile kernel;
+// 1 = launched, 0 = geometry not applicable
+int fo_conv3x3_c32_halo_try(const fo_conv_desc* d, const float* in, const float* wp, const float* mask, const float* add, float* out, hipStream_t stream);
+
 // elementwise.hip: out[c] = sum of the nblk partial rows ws[b][C], c < Creal (the second stage of every column sum)
 extern "C" int fo_colsum_finish(const float* ws, float* out, int nblk, int C, int Creal, void* stream);
 

@@ -615,6 +615,10 @@ static int conv_igemm_impl(const fo_conv_desc* d, const float* in, const float* 
   const bool smallc = d->Cin < 32;
   hipStream_t s = (hipStream_t)stream;
   if (smallc && bank_frames == 0 && fo_conv_img_try(d, in, wp, bias, mask, add, out, s) == 0) return FO_OK;
+  if (bank_frames == 0 && !bias && d->Cin == 32 && d->Cout == 128 && fo_conv3x3_c32_halo_try(d, in, wp, mask, add, out, s)) {
+    FO_CHECK_LAUNCH();
+    return FO_OK;
+  }
   // BN by output channels (filters are packed with Cout rounded up to the same BN)
   if (d->Cout > 64) {
     a.tilesN = (d->Cout + 127) / 128;

@@ -183,6 +183,171 @@ int grid_for(int ntiles) { return std::max(1, std::min(ntiles, 2 * fo_cu_count()
 
 }  // namespace
 
+// ------------------------------------------------------------------------------------------------------------------------------------
+// 3x3 pad-1 stride-1 convolution 32 -> 128 with the data-gradient epilogue -- the backward of a ResBlock's FIRST convolution
+// (reference models/vqvae_conv3d_latent.py:92-93: g_x = conv3x3^T(g_h) * (x > 0) + g_out) -- as a halo-tile kernel in the manner of
+// resblock_halo.hip, simpler than the forward because the 32-channel side is the INPUT:
+//   * the tile's patch (4 rows x 34 pixels x 32 channels = 17 KB, zero halo) is one slice shared by the four waves, double-buffered, the next
+//     tile's DMAs issued at the top of a tile: one barrier per tile;
+//   * the OUTPUT channels are split over the waves (wave w: 32 w .. + 31): each keeps its 9 x 32 x 32 filter block in 144 registers, contracts
+//     all of K = 288 itself -- no partial sums -- with the filter as the MFMA's row operand, so that a lane's accumulator quad is four
+//     channels of one pixel: mask, residual gradient and result move 16 bytes per lane.
+namespace {
+
+struct D3Args {
+  const float* gh;      // [N][H][W][ldGh], 32 channels
+  const float* wpd;     // [128][9][32]  (the data-gradient pack of the 3x3 filter: fo_pack_conv_dgrad)
+  const float* mask;    // [N][H][W][ldM], 128 channels, or null
+  const float* add;     // [N][H][W][ldA], 128 channels, or null
+  float* out;           // [N][H][W][ldO], 128 channels
+  int N, H, W, ldGh, ldM, ldA, ldO;
+  int tilesX, tilesY, ntiles, perXcd;
+  unsigned ghBytes, mBytes, aBytes, oBytes;
+};
+
+constexpr int PW3 = 34, PR3 = 4, PATCHB = PR3 * PW3 * 128;
+
+template <bool MASK, bool ADD>
+__global__ __launch_bounds__(256, 2) void conv3x3_c32_halo_kernel(const D3Args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];       // two patches
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  lds_byte* const lds3 = (lds_byte*)ldsb;
+  // (the descriptor starts ONE PIXEL before the tensor, so that the patch's left halo column is a non-negative offset)
+  const __amdgpu_buffer_rsrc_t rgh = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.gh) - a.ldGh, 0, a.ghBytes + a.ldGh * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.mask), 0, a.mBytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.add), 0, a.aBytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, a.oBytes, 0x00020000);
+
+  // XCD x (blockIdx % 8) owns a contiguous range of tiles, walked side by side by its workgroups (shared halo rows meet in one L2)
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
+  const int tEnd = min(a.ntiles, (xcd + 1) * a.perXcd);
+  int tile = xcd * a.perXcd + slot;
+
+  // DMA roles: 4 patch rows x 5 pieces of 8 pixels (the fifth: 2 pixels) = 20 pieces, five per wave; lane = (pixel l / 8, granule l % 8)
+  const int lp = lane >> 3, pos = lane & 7;
+  const unsigned dlane0 = (unsigned)(lp * a.ldGh * 4 + ((pos ^ (lp >> 1)) * 16));
+  const unsigned dlane1 = (unsigned)(lp * a.ldGh * 4 + ((pos ^ (lp >> 1) ^ 4) * 16));
+  auto dma_tile = [&](int t, int stage) {
+    if (t >= tEnd) return;
+    const int tx = t % a.tilesX, r1 = t / a.tilesX;
+    const int ty = r1 % a.tilesY, n = r1 / a.tilesY;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const int id = wave * 5 + k, r = id / 5, g = id - r * 5;           // (= row `wave`, piece k)
+      const int iy = ty * 2 - 1 + r;
+      const bool rowok = (unsigned)iy < (unsigned)a.H;
+      const unsigned rowoff = rowok ? (unsigned)((((size_t)n * a.H + iy) * a.W + tx * 32) * a.ldGh * 4) : 0u;
+      const bool ok = rowok & !((g == 0) & (tx == 0) & (lp == 0)) & !((g == 4) & (tx == a.tilesX - 1) & (lp == 1));
+      const unsigned vo = ok ? ((g & 1) ? dlane1 : dlane0) : OOB;
+      lds_byte* const dst = lds3 + stage * PATCHB + (r * PW3 + g * 8) * 128;
+      if (g < 4 || lane < 16)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rgh, (__attribute__((address_space(3))) void*)dst, 16, vo, rowoff + g * 8 * a.ldGh * 4, 0, 0);
+    }
+  };
+  dma_tile(tile, 0);
+
+  // filter block: row = output channel 32 wave + l31, k = tap * 32 + 8 kk + 4 half .. + 3
+  f32x4 wf[9][4];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) wf[t][kk] = *reinterpret_cast<const f32x4*>(a.wpd + (size_t)(wave * 32 + l31) * 288 + t * 32 + kk * 8 + half * 4);
+  // fragment address of (tap column kw, channel group kk) = cq[kw] ^ (kk << 5): the granule index (2 kk + half) ^ swizzle differs from
+  // kk = 0's in bits 1..2 only (12 address registers would not fit beside the filter's 144)
+  int cq[3];
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw) cq[kw] = (l31 + kw) * 128 + ((half ^ gswz(l31 + kw)) * 16);
+  const unsigned mlane = (unsigned)((l31 * a.ldM + wave * 32 + 4 * half) * 4);
+  const unsigned alane = (unsigned)((l31 * a.ldA + wave * 32 + 4 * half) * 4);
+  const unsigned olane = (unsigned)((l31 * a.ldO + wave * 32 + 4 * half) * 4);
+
+  for (int it = 0; tile < tEnd; tile += slots, ++it) {
+    const int tx = tile % a.tilesX, r1 = tile / a.tilesX;
+    const int ty = r1 % a.tilesY, n = r1 / a.tilesY;
+    const int stoff = (it & 1) * PATCHB;
+    // this wave's pieces have landed (they are older than the previous tile's epilogue loads, which its stores waited for; the 4 youngest
+    // vector-memory operations are that tile's last stores); the barrier makes the whole patch visible and tells that everyone is done with
+    // the other stage, which the next tile's DMAs refill
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __syncthreads();
+    dma_tile(tile + slots, (it & 1) ^ 1);
+
+    // one tile row (32 pixels) at a time: its mask / residual loads go out first and land under its 144 MFMAs; accumulator quad j =
+    // channels 32 wave + 8 j + 4 half .. + 3 of pixel (row mb, column l31)
+    const int pix0 = (n * a.H + ty * 2) * a.W + tx * 32;
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+      f32x4 mk[4], ad[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (MASK) mk[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rm, mlane + 32 * j, (pix0 + mb * a.W) * a.ldM * 4, 0));
+        if (ADD) ad[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, alane + 32 * j, (pix0 + mb * a.W) * a.ldA * 4, 0));
+      }
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      f32x4 fa[2];
+      auto frag = [&](int s9) {
+        const int tap = s9 >> 2, kk = s9 & 3, kh = tap / 3, kw = tap - kh * 3;
+        return *reinterpret_cast<const f32x4*>(ldsb + ((cq[kw] + stoff) ^ (kk << 5)) + (mb + kh) * PW3 * 128);
+      };
+      fa[0] = frag(0);
+#pragma unroll
+      for (int s9 = 0; s9 < 36; ++s9) {
+        const int cur = s9 & 1;
+        if (s9 + 1 < 36) fa[cur ^ 1] = frag(s9 + 1);
+        __builtin_amdgcn_sched_barrier(0);                 // (the next step's read is issued here, before this step's MFMAs)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[s9 >> 2][s9 & 3][s], fa[cur][s], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f32x4 v = {acc[4 * j], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]};
+        if (MASK) {
+          const f32x4 m = mk[j];
+          v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+        }
+        if (ADD) v += ad[j];
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, olane + 32 * j, (pix0 + mb * a.W) * a.ldO * 4, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
+}  // namespace
+
+// 1 = launched, 0 = not this kernel's geometry (the caller goes on to the tiled implicit GEMM)
+int fo_conv3x3_c32_halo_try(const fo_conv_desc* d, const float* in, const float* wp, const float* mask, const float* add, float* out, hipStream_t stream) {
+  static const bool off = getenv("FACEOFF_NO_RESBLOCK_HALO") != nullptr;
+  static const bool force = getenv("FACEOFF_FORCE_RESBLOCK_HALO") != nullptr;          // tests: at any size
+  if (off || d->Cin != 32 || d->Cout != 128 || d->KD != 1 || d->KH != 3 || d->KW != 3 || d->stride != 1 || d->ostride != 1 || d->padH != 1 ||
+      d->padW != 1 || d->Hm != d->Hin || d->Wm != d->Win || d->Hout != d->Hin || d->Wout != d->Win || d->Win % 32 != 0 || d->Hin % 2 != 0)
+    return 0;
+  if ((d->flags & ~(FO_MASK | FO_ADD)) != 0 || !!(d->flags & FO_MASK) != (mask != nullptr) || !!(d->flags & FO_ADD) != (add != nullptr)) return 0;
+  if (d->ldIn % 4 != 0 || d->ldOut % 4 != 0 || (mask && d->ldMask % 4 != 0) || (add && d->ldAdd % 4 != 0)) return 0;
+  D3Args a;
+  a.gh = in; a.wpd = wp; a.mask = mask; a.add = add; a.out = out;
+  a.N = d->N; a.H = d->Hin; a.W = d->Win; a.ldGh = d->ldIn; a.ldM = mask ? d->ldMask : 0; a.ldA = add ? d->ldAdd : 0; a.ldO = d->ldOut;
+  a.tilesX = d->Win / 32; a.tilesY = d->Hin / 2; a.ntiles = d->N * a.tilesX * a.tilesY; a.perXcd = (a.ntiles + 7) / 8;
+  const int cus = fo_cu_count();
+  if (a.ntiles < 4 * cus && !force) return 0;
+  const size_t npix = (size_t)d->N * d->Hin * d->Win;
+  const size_t ghB = (npix - 1) * d->ldIn * 4 + 128, mB = mask ? (npix - 1) * d->ldMask * 4 + 512 : 16, aB = add ? (npix - 1) * d->ldAdd * 4 + 512 : 16,
+               oB = (npix - 1) * d->ldOut * 4 + 512;
+  if (ghB >= 0x7fffffffull || mB >= 0x7fffffffull || aB >= 0x7fffffffull || oB >= 0x7fffffffull) return 0;
+  a.ghBytes = (unsigned)ghB; a.mBytes = (unsigned)mB; a.aBytes = (unsigned)aB; a.oBytes = (unsigned)oB;
+  const dim3 grid(std::max(8, std::min((a.ntiles + 7) / 8 * 8, 2 * cus) / 8 * 8));
+  if (mask && add) hipLaunchKernelGGL((conv3x3_c32_halo_kernel<true, true>), grid, dim3(256), 2 * PATCHB, stream, a);
+  else if (mask) hipLaunchKernelGGL((conv3x3_c32_halo_kernel<true, false>), grid, dim3(256), 2 * PATCHB, stream, a);
+  else if (add) hipLaunchKernelGGL((conv3x3_c32_halo_kernel<false, true>), grid, dim3(256), 2 * PATCHB, stream, a);
+  else hipLaunchKernelGGL((conv3x3_c32_halo_kernel<false, false>), grid, dim3(256), 2 * PATCHB, stream, a);
+  return 1;
+}
+
 extern "C" int64_t fo_resblock_bwd_conv3_ws_bytes(int64_t M) {
   if (M <= 0) return -1;
   const int ntiles = (int)((M + TP - 1) / TP);

@@ -468,6 +468,17 @@ for name, xin in (("dense", xc), ("slice", wide[..., 64:192])):
     ops.resblock_fwd(xin, wp1, b1.cuda(), wp3, b3.cuda(), hb, out, out_relu)
     res[name] = ((hb.permute(0, 3, 1, 2).cpu() - h_ref).abs().max().item() / h_ref.abs().max().item(),
                  (out.permute(0, 3, 1, 2).cpu() - o_ref).abs().max().item() / o_ref.abs().max().item())
+# the block's first conv backwards (conv3x3_c32_halo_kernel, csrc/resblock_bwd.hip): g_x = conv3x3^T(g_h) * (x > 0) + g_out
+gh = torch.randn((N, 32, H, W), generator=g); go = torch.randn((N, 128, H, W), generator=g)
+gx_ref = (torch.nn.functional.conv_transpose2d(gh.double(), w1.double(), padding=1) * (x > 0) + go.double())
+wpd = ops.pack_conv_dgrad(w1.cuda().reshape(32, 128, -1))
+ghc, goc = gh.permute(0, 2, 3, 1).contiguous().cuda(), go.permute(0, 2, 3, 1).contiguous().cuda()
+wide2 = torch.zeros((N, H, W, 64), device="cuda"); wide2[..., 16:48] = ghc
+for name, gin, xin in (("dgrad dense", ghc, xc), ("dgrad slice", wide2[..., 16:48], wide[..., 64:192])):
+    gx = torch.full((N, H, W, 128), 11.0, device="cuda")
+    ops.conv_igemm(gin, wpd, None, gx, k=(1, 3, 3), stride=1, pad=(0, 1, 1), cin=32, cout=128, mask=xin, add=goc)
+    e = (gx.permute(0, 3, 1, 2).cpu().double() - gx_ref).abs().max().item() / gx_ref.abs().max().item()
+    res[name] = (e, e)
 print(json.dumps(res))
 """ % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), N, H, W, out_relu)
     outs = {}
