@@ -26,6 +26,11 @@ int fo_resblock_halo_try(const fo_conv_desc* d, const float* x, const float* wp1
 // 1 = launched, 0 = geometry not applicable
 int fo_conv3x3_c32_halo_try(const fo_conv_desc* d, const float* in, const float* wp, const float* mask, const float* add, float* out, hipStream_t stream);
 
+// resblock_bwd.hip: filter + bias gradient of a ResBlock's first conv (3x3 128 -> 32, ReLU'd input) as a halo-tile kernel; 1 = launched
+int64_t fo_resblock_wgrad1_halo_ws_bytes(const fo_conv_desc* d);
+int fo_resblock_wgrad1_halo_try(const fo_conv_desc* d, const float* P, const float* Q, float* dw, int Areal, int Breal, float* dbias, float* ws,
+                                int64_t ws_bytes, hipStream_t stream);
+
 // elementwise.hip: out[c] = sum of the nblk partial rows ws[b][C], c < Creal (the second stage of every column sum)
 extern "C" int fo_colsum_finish(const float* ws, float* out, int nblk, int C, int Creal, void* stream);
 

@@ -554,7 +554,7 @@ static int64_t wgrad_ws_bytes(const fo_conv_desc* d, int banks) {
   Plan p;
   if (make_plan(d, &p, banks) != FO_OK) return -1;
   const int64_t tiled = ((int64_t)p.nchunks * p.tapsSlab * p.Apad * p.Bpad + (int64_t)p.nchunks * p.Apad) * 4 + 256;
-  return banks == 1 ? std::max(tiled, fo_wgrad_img_ws_bytes(d)) : tiled;
+  return banks == 1 ? std::max(std::max(tiled, fo_wgrad_img_ws_bytes(d)), fo_resblock_wgrad1_halo_ws_bytes(d)) : tiled;
 }
 
 extern "C" int64_t fo_wgrad_ws_bytes(const fo_conv_desc* d) { return wgrad_ws_bytes(d, 1); }
@@ -580,6 +580,10 @@ static int conv_wgrad_impl(const fo_conv_desc* d, const float* P, const float* Q
   FO_REQUIRE(fo_aligned16(P) && fo_aligned16(Q) && fo_aligned16(ws) && d->ldIn % 4 == 0 && d->ldOut % 4 == 0, FO_E_ALIGN,
              "wgrad: operands must be 16-byte aligned with ld %% 4 == 0");
   if (banks == 1 && fo_wgrad_img_try(d, P, Q, dw, Areal, Breal, dbias, ws, ws_bytes, (hipStream_t)stream) == 0) return FO_OK;
+  if (banks == 1 && fo_resblock_wgrad1_halo_try(d, P, Q, dw, Areal, Breal, dbias, ws, ws_bytes, (hipStream_t)stream)) {
+    FO_CHECK_LAUNCH();
+    return FO_OK;
+  }
   WgradArgs a;
   a.d = *d; a.P = P; a.Q = Q; a.ws = ws;
   a.HWm = d->Hm * d->Wm;

@@ -348,6 +348,187 @@ int fo_conv3x3_c32_halo_try(const fo_conv_desc* d, const float* in, const float*
   return 1;
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------------
+// Filter (and bias) gradient of a ResBlock's FIRST convolution (ReLU -> Conv2d(128, 32, 3, padding=1), reference :91-92):
+//     dW1[co][ci][kh][kw] = sum_pixels relu(x)[pixel + (kh - 1, kw - 1)][ci] * g_h[pixel][co],     db1[co] = sum_pixels g_h[pixel][co]
+// as a halo-tile kernel: the same wave-private 32-channel slices of the input patch as the forward (resblock_halo.hip), staged once for all nine
+// taps; wave w owns input channels 32 w .. + 31 and keeps its 9 x 32 x 32 block of dW1 in 144 accumulator registers over ALL its tiles
+// (rows = input channels, columns = output channels, the contraction runs over pixels, two per v_mfma_f32_32x32x2_f32); both operands are read
+// one dword per lane from [pixel][channel] images, which for this access pattern (32 consecutive channels of one pixel per half-wave) is
+// conflict-free without a swizzle; one slab per workgroup, summed in a fixed order by a second kernel which also transposes to the checkpoint
+// layout.  (The tiled conv_wgrad_kernel<32, 128> re-stages the input rows once per tap and turns its accumulators over every chunk.)
+namespace {
+
+struct W1Args {
+  const float* x;       // [N][H][W][ldX], 128 channels (the block's input; ReLU applied on the fly)
+  const float* gh;      // [N][H][W][ldGh], 32 channels
+  float* ws;            // [grid][9 * 128 * 32 + 32]
+  int N, H, W, ldX, ldGh;
+  int tilesX, tilesY, ntiles, perXcd;
+  unsigned xBytes, ghBytes;
+};
+
+constexpr int W1_SLICEB = 4 * 34 * 128;                    // a wave's 32-channel slice of the 4 x 34-pixel patch
+constexpr int W1_LDS = 4 * W1_SLICEB + 64 * 128;           // + the g_h tile: 77 824
+constexpr int W1_SLAB = 9 * 128 * 32 + 32;
+
+__global__ __launch_bounds__(256, 2) void resblock_wgrad1_halo_kernel(const W1Args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  lds_byte* const lds3 = (lds_byte*)ldsb;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x) - a.ldX, 0, a.xBytes + a.ldX * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.gh), 0, a.ghBytes, 0x00020000);
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
+  const int tEnd = min(a.ntiles, (xcd + 1) * a.perXcd);
+  int tile = xcd * a.perXcd + slot;
+
+  const int lp = lane >> 3, pos = lane & 7;
+  const unsigned xlaneD = (unsigned)(lp * a.ldX * 4 + pos * 16), glaneD = (unsigned)(lp * a.ldGh * 4 + pos * 16);
+  auto dma_tile = [&](int t) {
+    if (t >= tEnd) return;
+    const int tx = t % a.tilesX, r1 = t / a.tilesX;
+    const int ty = r1 % a.tilesY, n = r1 / a.tilesY;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int iy = ty * 2 - 1 + r;
+      const bool rowok = (unsigned)iy < (unsigned)a.H;
+      const unsigned rowoff = rowok ? (unsigned)((((size_t)n * a.H + iy) * a.W + tx * 32) * a.ldX * 4) + wave * 128 : 0u;
+#pragma unroll
+      for (int g = 0; g < 5; ++g) {
+        const bool ok = rowok & !((g == 0) & (tx == 0) & (lp == 0)) & !((g == 4) & (tx == a.tilesX - 1) & (lp == 1));
+        lds_byte* const dst = lds3 + wave * W1_SLICEB + (r * 34 + g * 8) * 128;
+        if (g < 4 || lane < 16)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)dst, 16, ok ? xlaneD : OOB, rowoff + g * 8 * a.ldX * 4, 0, 0);
+      }
+    }
+    // g_h: wave w fills tile pixels 16 w .. + 15 (tile row w / 2, columns 16 (w % 2) .. + 15)
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int p0 = wave * 16 + k * 8;
+      const unsigned so = (unsigned)((((size_t)n * a.H + ty * 2 + (p0 >> 5)) * a.W + tx * 32 + (p0 & 31)) * a.ldGh * 4);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (__attribute__((address_space(3))) void*)(lds3 + 4 * W1_SLICEB + p0 * 128), 16, glaneD, so, 0, 0);
+    }
+  };
+  dma_tile(tile);
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  float dbp = 0.f;
+  // a lane's share of both fragment addresses: pixel parity `half`, channel l31
+  const int aq = wave * W1_SLICEB + half * 128 + l31 * 4, bq = 4 * W1_SLICEB + half * 128 + l31 * 4;
+
+  for (; tile < tEnd; tile += slots) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                       // everyone's quarter of the g_h tile is visible
+    // 32 steps (tile row mb = i / 16, pixels 2 s, 2 s + 1 with s = i % 16): ten fragment reads (one per tap + g_h), issued one step ahead,
+    // nine MFMAs into nine independent accumulators
+    float av[2][9], bv[2];
+    auto load_step = [&](int i, int buf) {
+      const int mb = i >> 4, s = i & 15;
+      bv[buf] = *reinterpret_cast<const float*>(ldsb + bq + (mb * 32 + 2 * s) * 128);
+#pragma unroll
+      for (int t = 0; t < 9; ++t) av[buf][t] = *reinterpret_cast<const float*>(ldsb + aq + ((mb + t / 3) * 34 + 2 * s + t % 3) * 128);
+    };
+    load_step(0, 0);
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      const int cur = i & 1;
+      if (i + 1 < 32) load_step(i + 1, cur ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < 9; ++t) asm volatile("v_max_f32 %0, 0, %0" : "+v"(av[cur][t]));      // the block's leading ReLU (:91)
+      dbp += bv[cur];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][t], bv[cur], acc[t], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();                                       // the g_h tile is consumed (the slice is this wave's own)
+    dma_tile(tile + slots);
+  }
+
+  // slab: [tap][ci][co] (lanes along co), then db1 from wave 0 (every wave summed the same g_h tile)
+  float* const slab = a.ws + (size_t)blockIdx.x * W1_SLAB;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) slab[(t * 128 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * 32 + l31] = acc[t][r];
+  dbp += __shfl_xor(dbp, 32);
+  if (wave == 0 && half == 0) slab[9 * 128 * 32 + l31] = dbp;
+}
+
+// dW1[co][ci][tap] / db1 = the slabs summed in slab order (64 consecutive slab elements x 8 slab groups per workgroup, as the 1x1's reduce)
+__global__ __launch_bounds__(512) void resblock_wgrad1_reduce_kernel(const float* __restrict__ ws, int nslabs, float* __restrict__ dw1, float* __restrict__ db1) {
+  __shared__ float red[512];
+  const int li = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + li;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (e < W1_SLAB) {
+    const float* p = ws + e;
+    int b = grp;
+    for (; b + 24 < nslabs; b += 32) {
+      s0 += p[(size_t)b * W1_SLAB]; s1 += p[(size_t)(b + 8) * W1_SLAB]; s2 += p[(size_t)(b + 16) * W1_SLAB]; s3 += p[(size_t)(b + 24) * W1_SLAB];
+    }
+    for (; b < nslabs; b += 8) s0 += p[(size_t)b * W1_SLAB];
+  }
+  red[threadIdx.x] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (grp == 0 && e < W1_SLAB) {
+    float s = red[li];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) s += red[k * 64 + li];
+    if (e < 9 * 128 * 32) {
+      const int co = e & 31, ci = (e >> 5) & 127, t = e >> 12;
+      dw1[(co * 128 + ci) * 9 + t] = s;
+    } else if (db1) {
+      db1[e - 9 * 128 * 32] = s;
+    }
+  }
+}
+
+}  // namespace
+
+int64_t fo_resblock_wgrad1_halo_ws_bytes(const fo_conv_desc* d) {
+  if (d->Cin != 128 || d->Cout != 32 || d->KD != 1 || d->KH != 3 || d->KW != 3) return 0;
+  return (int64_t)2 * fo_cu_count() * W1_SLAB * 4;
+}
+
+// 1 = launched, 0 = not this kernel's geometry.  P = g_h [N][H][W][ldOut] (32), Q = x [N][H][W][ldIn] (128), FO_IN_RELU set.
+int fo_resblock_wgrad1_halo_try(const fo_conv_desc* d, const float* P, const float* Q, float* dw, int Areal, int Breal, float* dbias, float* ws,
+                                int64_t ws_bytes, hipStream_t stream) {
+  static const bool off = getenv("FACEOFF_NO_RESBLOCK_HALO") != nullptr;
+  static const bool force = getenv("FACEOFF_FORCE_RESBLOCK_HALO") != nullptr;
+  if (off || Areal != 32 || Breal != 128 || d->Cin != 128 || d->Cout != 32 || d->KD != 1 || d->KH != 3 || d->KW != 3 || d->stride != 1 || d->padH != 1 ||
+      d->padW != 1 || d->Hm != d->Hin || d->Wm != d->Win || d->Win % 32 != 0 || d->Hin % 2 != 0 || !(d->flags & FO_IN_RELU) || d->ldIn % 4 != 0 ||
+      d->ldOut % 4 != 0)
+    return 0;
+  W1Args a;
+  a.x = Q; a.gh = P; a.ws = ws;
+  a.N = d->N; a.H = d->Hin; a.W = d->Win; a.ldX = d->ldIn; a.ldGh = d->ldOut;
+  a.tilesX = d->Win / 32; a.tilesY = d->Hin / 2; a.ntiles = d->N * a.tilesX * a.tilesY; a.perXcd = (a.ntiles + 7) / 8;
+  const int cus = fo_cu_count();
+  if (a.ntiles < 4 * cus && !force) return 0;
+  const size_t npix = (size_t)d->N * d->Hin * d->Win;
+  const size_t xB = (npix - 1) * d->ldIn * 4 + 512, gB = (npix - 1) * d->ldOut * 4 + 128;
+  if (xB >= 0x7fffffffull || gB >= 0x7fffffffull) return 0;
+  a.xBytes = (unsigned)xB; a.ghBytes = (unsigned)gB;
+  const int grid = std::max(8, std::min((a.ntiles + 7) / 8 * 8, 2 * cus) / 8 * 8);
+  if (ws_bytes < (int64_t)grid * W1_SLAB * 4) return 0;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(resblock_wgrad1_halo_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, W1_LDS) != hipSuccess) return 0;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(resblock_wgrad1_halo_kernel, dim3(grid), dim3(256), W1_LDS, stream, a);
+  hipLaunchKernelGGL(resblock_wgrad1_reduce_kernel, dim3((W1_SLAB + 63) / 64), dim3(512), 0, stream, ws, grid, dw, dbias);
+  return 1;
+}
+
 extern "C" int64_t fo_resblock_bwd_conv3_ws_bytes(int64_t M) {
   if (M <= 0) return -1;
   const int ntiles = (int)((M + TP - 1) / TP);

@@ -479,6 +479,15 @@ for name, gin, xin in (("dgrad dense", ghc, xc), ("dgrad slice", wide2[..., 16:4
     ops.conv_igemm(gin, wpd, None, gx, k=(1, 3, 3), stride=1, pad=(0, 1, 1), cin=32, cout=128, mask=xin, add=goc)
     e = (gx.permute(0, 3, 1, 2).cpu().double() - gx_ref).abs().max().item() / gx_ref.abs().max().item()
     res[name] = (e, e)
+# ... and its filter / bias gradient (resblock_wgrad1_halo_kernel): dW1 = sum relu(x)[pixel + tap] (x) g_h[pixel], db1 = sum g_h
+xr = torch.relu(x).double()
+dw_ref = torch.nn.grad.conv2d_weight(xr, (32, 128, 3, 3), gh.double(), padding=1)
+db_ref = gh.double().sum((0, 2, 3))
+bound = torch.nn.grad.conv2d_weight(xr.abs(), (32, 128, 3, 3), gh.double().abs(), padding=1).max().item()
+for name, gin, xin in (("wgrad dense", ghc, xc), ("wgrad slice", wide2[..., 16:48], wide[..., 64:192])):
+    dw = torch.full((32, 128, 3, 3), 7.0, device="cuda"); db = torch.full((32,), 7.0, device="cuda")
+    ops.conv_wgrad(gin, xin, dw, db, k=(1, 3, 3), stride=1, pad=(0, 1, 1), a_real=32, b_real=128, in_relu=True)
+    res[name] = ((dw.cpu().double() - dw_ref).abs().max().item() / bound, (db.cpu().double() - db_ref).abs().max().item() / gh.abs().sum((0, 2, 3)).max().item())
 print(json.dumps(res))
 """ % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), N, H, W, out_relu)
     outs = {}
