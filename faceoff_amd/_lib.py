@@ -50,6 +50,14 @@ _D = C.POINTER(ConvDesc)
 # name -> (restype, argtypes); must list every symbol include/faceoff_hip.h declares
 SIGNATURES = {
     "fo_version": (_I, []),
+    "fo_comm_unique_id": (_I, [_P]),
+    "fo_comm_init": (_I, [C.POINTER(C.c_void_p), _I, _I, _P, _I]),
+    "fo_comm_rank": (_I, [_P]),
+    "fo_comm_world": (_I, [_P]),
+    "fo_comm_issued": (_L, [_P]),
+    "fo_comm_allreduce_async": (_I, [_P, _P, _L, _P]),
+    "fo_comm_wait": (_I, [_P, _P]),
+    "fo_comm_destroy": (_I, [_P]),
     "fo_last_error": (C.c_char_p, []),
     "fo_device_info": (_I, [C.POINTER(C.c_int32)]),
     "fo_nchw_to_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),

@@ -13,14 +13,21 @@ from torch import distributed as dist
 
 
 class GradBucketReducer:
-    def __init__(self, flat_grads, layer_order, offsets, bucket_bytes=4 << 20, group=None, always=False):
+    def __init__(self, flat_grads, layer_order, offsets, bucket_bytes=4 << 20, group=None, always=False, comm=None):
         """layer_order: arena order of layer names (reverse of backward completion);
-        offsets: key -> (offset, numel) for '<layer>.weight' / '<layer>.bias'."""
+        offsets: key -> (offset, numel) for '<layer>.weight' / '<layer>.bias'.
+        comm: a distributed.comm.AbiComm -- the buckets then go through the C-ABI communicator (fo_comm_allreduce_async on ITS stream,
+        fo_comm_wait) instead of torch.distributed."""
         self.flat = flat_grads
         self.group = group
-        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
-        # always=True: issue the collectives even in a one-rank group (exercises the RCCL path on a single GPU)
-        self.active = self.world > 1 or (always and dist.is_available() and dist.is_initialized())
+        self.comm = comm
+        if comm is not None:
+            self.world = comm.world
+            self.active = self.world > 1 or always
+        else:
+            self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+            # always=True: issue the collectives even in a one-rank group (exercises the RCCL path on a single GPU)
+            self.active = self.world > 1 or (always and dist.is_available() and dist.is_initialized())
         # walk the arena from the end (first-completed layer) building buckets
         self.buckets = []          # (lo, hi, last layer of the bucket in backward order)
         self.members = []          # layer names per bucket
@@ -72,6 +79,9 @@ class GradBucketReducer:
             for ev in self._events[i]:
                 self.side.wait_event(ev)
             self._events[i] = []
+            if self.comm is not None:          # the communicator's own stream runs the collective, behind the side stream's waits
+                self.comm.allreduce_async(view, after_stream=self.side)
+                return
             with torch.cuda.stream(self.side):
                 self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:
@@ -82,6 +92,8 @@ class GradBucketReducer:
         if not self.active:
             return
         if self.cuda:
+            if self.comm is not None:
+                self.comm.wait(self.side)      # (the join below then covers the collectives)
             with torch.cuda.stream(self.side):
                 for w in self._works:
                     w.wait()

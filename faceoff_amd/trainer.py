@@ -44,14 +44,15 @@ class FlatAdam:
 
 class FaceOffTrainer:
     def __init__(self, engine: VQVAEEngine, lr=3e-4, scheduler=None, vqlpips=None, bucket_bytes=4 << 20, group=None,
-                 force_collectives=False):
+                 force_collectives=False, comm=None):
         """force_collectives: run the gradient-bucket and VQ-statistics all-reduces even in a one-rank process group
-        (tests: the RCCL path on a single GPU)."""
+        (tests: the RCCL path on a single GPU).  comm: a distributed.comm.AbiComm -- gradients and VQ statistics then travel through
+        the C-ABI communicator (fo_comm_*) instead of torch.distributed."""
         self.engine = engine
         self.optimizer = FlatAdam(engine, lr=lr)
         self.scheduler = scheduler
         self.vqlpips = vqlpips
-        self.world = get_world_size()
+        self.world = comm.world if comm is not None else get_world_size()
         # the ground-truth branch of LPIPS does not depend on the model: it runs on its own stream beside the VQ-VAE
         # forward (an fp32 conv workgroup and a bf16 one fit a CU's LDS together; the bf16 convs are L2-bound,
         # the fp32 ones matrix-pipe-bound)
@@ -62,10 +63,17 @@ class FaceOffTrainer:
         self.reducer = None
         if self.world > 1 or force_collectives:
             self.reducer = GradBucketReducer(engine.flat_grads, engine.layer_order, engine.offsets, bucket_bytes, group,
-                                             always=force_collectives)
+                                             always=force_collectives, comm=comm)
             engine.grad_ready_hook = self.reducer.layer_done
-            vq_ar = fused_vq_allreduce(group)
-            engine.vq_allreduce = (lambda st: vq_ar(st, always=True)) if force_collectives else vq_ar
+            if comm is not None:
+                def vq_ar_abi(st):             # in the forward's critical path: summed behind the current stream, awaited by it
+                    comm.allreduce_async(st)
+                    comm.wait()
+                    return st
+                engine.vq_allreduce = vq_ar_abi
+            else:
+                vq_ar = fused_vq_allreduce(group)
+                engine.vq_allreduce = (lambda st: vq_ar(st, always=True)) if force_collectives else vq_ar
 
     def step(self, img, ground_truth, T=None):
         """img [B,T,6,H,W] or [N,6,H,W]; ground_truth likewise with 3 channels (utils.py:29-38).

@@ -444,6 +444,24 @@ int fo_relu(const float* x, int ldx, float* y, int ldy, int64_t rows, int C, voi
 /* y = a + b over strided [rows][C] views (gradient fan-in where no conv epilogue can take it) */
 int fo_add(const float* a, int lda, const float* b, int ldb, float* y, int ldy, int64_t rows, int C, void* stream);
 
+/* ---------------------------------------------------------------- data-parallel gradient exchange (csrc/comm.cpp)
+ * What nn.parallel.DistributedDataParallel's reducer does for the reference (train_faceoff_perceptual.py:164-169; process group:
+ * distributed/launch.py:61-66) for a host that does not go through torch.distributed: one communicator per process (= per GPU) over RCCL
+ * (opened with dlopen on first use).  Rank 0 calls fo_comm_unique_id and hands the 128 opaque bytes to every rank over the job's existing
+ * rendezvous (the reference's TCP dist_url); every rank then calls fo_comm_init.  All-reduces are in-place fp32 SUMs (averaging is folded
+ * into the optimiser's grad_scale) on the communicator's own stream, ordered by events: no call here blocks the host except destroy. */
+typedef struct fo_comm fo_comm;
+int fo_comm_unique_id(void* id128);
+int fo_comm_init(fo_comm** out, int rank, int world, const void* id128, int device);
+int fo_comm_rank(const fo_comm* c);
+int fo_comm_world(const fo_comm* c);
+int64_t fo_comm_issued(const fo_comm* c);   /* all-reduces enqueued so far */
+/* buf[0..count) := sum over ranks, enqueued BEHIND everything enqueued so far on after_stream (the stream that produced buf) */
+int fo_comm_allreduce_async(fo_comm* c, float* buf, int64_t count, void* after_stream);
+/* `stream` waits on the device for every all-reduce issued so far */
+int fo_comm_wait(fo_comm* c, void* stream);
+int fo_comm_destroy(fo_comm* c);
+
 #ifdef __cplusplus
 }
 #endif

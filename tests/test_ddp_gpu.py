@@ -144,3 +144,101 @@ def test_rccl_code_path_in_a_one_rank_group():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", _RCCL_SCRIPT, str(port)], capture_output=True, text=True, timeout=600, cwd=root)
     assert out.returncode == 0 and "RCCL_PATH_OK" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
+
+
+_ABI_COMM_SCRIPT = r"""
+import os, sys, torch
+sys.path.insert(0, os.getcwd())
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+torch.cuda.set_device(0)
+from faceoff_amd.distributed.comm import AbiComm
+from faceoff_amd.engine import VQVAEEngine
+from faceoff_amd.synth import make_state_dict, make_batch
+from faceoff_amd.trainer import FaceOffTrainer
+comm = AbiComm.create(0, 1, "cuda:0")
+# the collective itself: in place, behind the producing stream, awaited on the device
+side = torch.cuda.Stream()
+x = torch.zeros(1 << 20, device="cuda")
+with torch.cuda.stream(side):
+    x.add_(3.0)
+    comm.allreduce_async(x)                 # behind `side`
+comm.wait()                                 # the current (default) stream waits for it
+y = x * 2
+torch.cuda.synchronize()
+assert comm.issued == 1 and torch.equal(y, torch.full_like(y, 6.0))
+img, gt = make_batch(100, 2, 2, 64, 64)
+img, gt = torch.from_numpy(img).cuda(), torch.from_numpy(gt).cuda()
+out = []
+for use in (True, False):
+    eng = VQVAEEngine(make_state_dict(0, codebook_scale=0.3, gain=2.0), "cuda:0")
+    tr = FaceOffTrainer(eng, lr=3e-4, bucket_bytes=2 << 20, force_collectives=use, comm=comm if use else None)
+    assert (tr.reducer is not None) == use
+    before = comm.issued
+    recon, latent, _ = tr.step(img, gt)
+    torch.cuda.synchronize()
+    if use:
+        assert len(tr.reducer.buckets) >= 4
+        assert comm.issued - before == len(tr.reducer.buckets) + 2      # every bucket + the two quantisers' statistics
+    out.append((eng.flat_params.clone(), eng.flat_grads.clone(), eng.buffers["quantize_b.embed"].clone()))
+    tr.step(img, gt)
+    torch.cuda.synchronize()
+    assert torch.isfinite(eng.flat_params).all()
+assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1]), "one-rank all-reduce through fo_comm changed the result"
+assert (out[0][2] - out[1][2]).abs().max().item() <= 1e-5 * out[1][2].abs().max().item()
+comm.destroy()
+print("ABI_COMM_OK")
+"""
+
+
+def test_c_abi_communicator_in_a_one_rank_world():
+    """fo_comm_{unique_id,init,allreduce_async,wait,destroy} (csrc/comm.cpp: RCCL behind the C-ABI) with one rank -- all this box
+    can host: the collective is ordered behind its producer stream and awaited on the device; a training step whose gradient buckets and
+    VQ statistics travel through it gives exactly the plain step's parameters and gradients, and issues one all-reduce per bucket + two."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", _ABI_COMM_SCRIPT], capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0 and "ABI_COMM_OK" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
+
+
+_ABI_TWO_RANK_SCRIPT = r"""
+import os, sys, time, torch
+sys.path.insert(0, os.getcwd())
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+rank, idfile = int(sys.argv[1]), sys.argv[2]
+torch.cuda.set_device(rank)
+from faceoff_amd.distributed.comm import AbiComm
+def exchange(idb):                          # the "job's own rendezvous": a file rank 0 writes and rank 1 polls
+    if idb is not None:
+        with open(idfile + ".tmp", "wb") as f: f.write(idb)
+        os.replace(idfile + ".tmp", idfile)
+        return idb
+    for _ in range(600):
+        if os.path.exists(idfile):
+            return open(idfile, "rb").read()
+        time.sleep(0.1)
+    raise RuntimeError("rank 0 never published the id")
+comm = AbiComm.create(rank, 2, f"cuda:{rank}", exchange)
+x = torch.full((1 << 20,), float(rank + 1), device=f"cuda:{rank}")
+for _ in range(3):
+    comm.allreduce_async(x)                 # 1, 2 -> 3, 3 -> 6, 6 -> 12, 12
+comm.wait()
+torch.cuda.synchronize()
+assert torch.equal(x, torch.full_like(x, 12.0)), x[:4]
+comm.destroy()
+print("ABI_TWO_RANK_OK")
+"""
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: RCCL refuses two ranks on one device")
+def test_c_abi_communicator_two_ranks_on_two_gpus(tmp_path):
+    """Two processes, one GPU each, id handed over through a file: three chained in-place SUMs through fo_comm_allreduce_async."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    idfile = str(tmp_path / "fo_comm_id")
+    procs = [subprocess.Popen([sys.executable, "-c", _ABI_TWO_RANK_SCRIPT, str(r), idfile], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                              text=True, cwd=root) for r in range(2)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0 and "ABI_TWO_RANK_OK" in so, (so[-1000:], se[-3000:])
