@@ -149,7 +149,9 @@ __global__ __launch_bounds__(256, 2) void resblock_halo_fwd_kernel(const RBArgs 
   // the steady state -- the launch's 0.70 of the 2.4-GHz peak is that x the clock x ramp and tail.  Measured null, each on one box: starting
   // every second workgroup half a tile late, or at a higher s_setprio (whichever pairing of workgroups was assumed); issuing the next patch's
   // rows 0, 1 from inside the 3x3 loop (the time moves into the loop: the total is conserved); drawing tiles from a per-XCD counter instead of
-  // the fixed stride (per-wave times 0.88..1.13 of the mean became 0.95..1.07, the launch 1 % shorter).
+  // the fixed stride (per-wave times 0.88..1.13 of the mean became 0.95..1.07, the launch 1 % shorter); walking DOWN the image with the patch as
+  // a ring of four row slots, so that a tile brings in only its two new rows (half the DMA pieces and L2 traffic: the same 0.47 ms -- and the
+  // variant was not run-to-run reproducible at full size, a hazard that was not tracked down; dropped).
 #if FO_RB_STAMP
   unsigned long long ph[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
   const unsigned long long t0m = tlast, t0r = __builtin_amdgcn_s_memrealtime();
