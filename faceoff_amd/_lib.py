@@ -119,6 +119,7 @@ SIGNATURES = {
     "fo_pack_conv_bf16": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "fo_pack_conv_dgrad_bf16": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "fo_conv_igemm_bf16": (_I, [_D, _P, _P, _P, _P, _P, _P]),
+    "fo_conv_igemm_bf16_pool": (_I, [_D, _P, _P, _P, _P, _P, _I, _P]),
     "fo_conv_bf16": (_I, [_D, _P, _P, _P, _P, _P, _P, _P]),
     "fo_wgrad_bf16_ws_bytes": (_L, [_D]),
     "fo_conv_wgrad_bf16": (_I, [_D, _P, _P, _P, _I, _I, _P, _P, _L, _P]),
@@ -207,3 +208,16 @@ def call(name, *args):
     rc = getattr(lib, name)(*args)
     if rc != 0:
         check(rc, name)
+
+
+_CU = None
+
+
+def cu_count():
+    """Compute units of the current device (fo_device_info), cached."""
+    global _CU
+    if _CU is None:
+        out = (C.c_int32 * 3)()
+        call("fo_device_info", out)
+        _CU = int(out[0])
+    return _CU

@@ -920,8 +920,9 @@ struct HaloArgs {
   const float* bias;
   const __bf16* mask;
   __bf16* out;
+  __bf16* pooled;           // optional: the 2x2 max-pool of `out` ([N][H/2][W/2][ldPooled]) written from the same accumulators
   int N, H, W, Cout, halves, tilesX, tilesY, ntiles;
-  int ldIn, ldOut, ldMask, flags;
+  int ldIn, ldOut, ldMask, ldPooled, flags;
   unsigned inBytes;
 };
 
@@ -1017,6 +1018,10 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16_kernel(const HaloArgs
     const int tx = tile % a.tilesX, r1 = tile / a.tilesX;
     const int ty = r1 % a.tilesY, n = r1 / a.tilesY;
     typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    // (max-pool 2x2 riding along: a wave's two tile rows are one pooled row; the vertical partner of a pixel is the same lane's other
+    // accumulator, the horizontal one the neighbouring lane.  max commutes with the monotonic bias + ReLU + rounding, so the pooled tensor is
+    // bit for bit the pool of the stored one.)
+    float pm[2][2][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const size_t pix = ((size_t)n * a.H + ty * 4 + 2 * wm + (i >> 1)) * a.W + tx * 32 + (i & 1) * 16 + l15;
@@ -1033,20 +1038,41 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16_kernel(const HaloArgs
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
         }
-        if (!(FO_ABLATE_H & 32)) *reinterpret_cast<bf16x4*>(a.out + pix * a.ldOut + co) = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+        const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+        if (!(FO_ABLATE_H & 32)) *reinterpret_cast<bf16x4*>(a.out + pix * a.ldOut + co) = o;
+        if (a.pooled) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) pm[i & 1][j][r] = (i >> 1) ? fmaxf(pm[i & 1][j][r], (float)o[r]) : (float)o[r];
+        }
       }
       __builtin_amdgcn_sched_barrier(0);                  // (one pixel block's mask loads and addresses at a time: the filter holds the registers)
     }
+    if (a.pooled) {
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const size_t ppix = ((size_t)n * (a.H / 2) + ty * 2 + wm) * (a.W / 2) + tx * 16 + e * 8 + (l15 >> 1);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          float m[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) m[r] = fmaxf(pm[e][j][r], __shfl_xor(pm[e][j][r], 1));
+          if (!(l15 & 1))
+            *reinterpret_cast<bf16x4*>(a.pooled + ppix * a.ldPooled + half * 64 + wn * 32 + j * 16 + quad * 4) = bf16x4{(__bf16)m[0], (__bf16)m[1], (__bf16)m[2], (__bf16)m[3]};
+        }
+      }
+    }
     // the next patch has landed: vmcnt retires in order and the 8 youngest operations are this tile's stores, which may keep flying
     // (nothing reads them; the LDS stage they came from is not involved)
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if (a.pooled) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      // (+ 4 pooled stores)
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   }
 }
 
-static int launch_halo64(const ConvArgsH& c, hipStream_t s) {
+static int launch_halo64(const ConvArgsH& c, hipStream_t s, void* pooled = nullptr, int ldPooled = 0) {
   const fo_conv_desc& d = c.d;
   HaloArgs a;
+  a.pooled = reinterpret_cast<__bf16*>(pooled); a.ldPooled = ldPooled;
   a.in = reinterpret_cast<const __bf16*>(c.in); a.wp = reinterpret_cast<const __bf16*>(c.wp); a.bias = c.bias;
   a.mask = reinterpret_cast<const __bf16*>(c.mask); a.out = reinterpret_cast<__bf16*>(c.out);
   a.N = d.N; a.H = d.Hin; a.W = d.Win; a.Cout = d.Cout; a.halves = d.Cout / 64;
@@ -1153,7 +1179,7 @@ int fo_pack_conv_dgrad_bf16(const float* w, void* wp, int O, int I, int taps, in
 }
 
 static int conv_bf16_impl(const fo_conv_desc* d, const void* in, const void* wp, const float* bias, const void* mask, const void* add,
-                          void* out, void* stream) {
+                          void* out, void* stream, void* pooled = nullptr, int ldPooled = 0) {
   ConvArgsH a;
   a.d = *d;
   a.in = in; a.wp = wp; a.bias = bias; a.mask = mask; a.add = add; a.out = out;
@@ -1237,8 +1263,9 @@ static int conv_bf16_impl(const fo_conv_desc* d, const void* in, const void* wp,
         d->Hin == d->Hm && d->Win == d->Wm && d->Hm == d->Hout && d->Wm == d->Wout && d->Hin % 4 == 0 && d->Win % 32 == 0 &&
         !(flags & ~(FO_BIAS | FO_MASK | FO_OUT_RELU)) && d->ldOut % 4 == 0 && (!(flags & FO_MASK) || d->ldMask % 4 == 0) &&
         (tiles >= 8LL * fo_cu_count() || (fhalo && atoi(fhalo))) && !(nohalo && atoi(nohalo)))
-      return launch_halo64(a, s);
+      return launch_halo64(a, s, pooled, ldPooled);
   }
+  FO_REQUIRE(!pooled, FO_E_SHAPE, "conv_bf16: the pooled second output exists for the 64-input-channel halo-tile kernel only (3x3, whole 4 x 32 tiles, >= 8 tiles per CU)");
   // big tiles (one workgroup per CU) where the launch still fills the chip for a few rounds: stride-1 same-size convs.
   // Measured at the C3 shapes and at a fifth of them (tools/ab_bf16.py): 256-column tiles +22...30 % over conv_bf16_kernel
   // on conv3_x / conv4_x, 128-column tiles +5...10 % on conv2_x and +12...15 % on 2-round launches, the 512 x 128 tile (32 MFMAs per
@@ -1302,5 +1329,15 @@ int fo_conv_igemm_bf16(const fo_conv_desc* d, const void* in, const void* wp, co
 int fo_conv_bf16(const fo_conv_desc* d, const void* in, const void* wp, const float* bias, const void* mask, const void* add, void* out,
                  void* stream) {
   return conv_bf16_impl(d, in, wp, bias, mask, add, out, stream);
+}
+
+int fo_conv_igemm_bf16_pool(const fo_conv_desc* d, const void* in, const void* wp, const float* bias, void* out, void* pooled, int ldPooled,
+                            void* stream) {
+  FO_REQUIRE(d->KD == 1 && d->padD == 0 && !(d->flags & ~(FO_BIAS | FO_OUT_RELU)), FO_E_SHAPE, "conv_igemm_bf16_pool: 2-D, flags BIAS|OUT_RELU only");
+  FO_REQUIRE(pooled && fo_aligned16(pooled) && ldPooled % 4 == 0 && ldPooled >= d->Cout && d->Hout % 2 == 0 && d->Wout % 2 == 0, FO_E_SHAPE,
+             "conv_igemm_bf16_pool: pooled output [N][H/2][W/2][ldPooled >= Cout]");
+  fo_conv_desc e = *d;
+  e.T = 1;
+  return conv_bf16_impl(&e, in, wp, bias, nullptr, nullptr, out, stream, pooled, ldPooled);
 }
 }

@@ -97,12 +97,12 @@ class LPIPSEngine:
                   self.shift, self.scale, ops._stream())
         return y
 
-    def _conv(self, i, x):
+    def _conv(self, i, x, pooled=None):
         _, ci, co, _ = self.convs[i]
         N, H, W, _ = x.shape
         y = torch.empty((N, H, W, co), device=self.device, dtype=self.act_dtype)
         if self.bf16:
-            ops.conv_bf16(x, self.wp[i], self.b[i], y, cin=8 if i == 0 else ci, cout=co, flags=ops.FO_OUT_RELU)
+            ops.conv_bf16(x, self.wp[i], self.b[i], y, cin=8 if i == 0 else ci, cout=co, flags=ops.FO_OUT_RELU, pooled=pooled)
         elif i == 0:
             ops.conv_igemm(x, self.wp[0], self.b[0], y, k=(1, 3, 4), pad=(0, 1, 1), cin=8, cout=co, flags=ops.FO_OUT_RELU)
         else:
@@ -119,12 +119,19 @@ class LPIPSEngine:
         """vgg16.forward (lpips.py:139-152).  Returns (taps[5], acts) where acts[i] = ReLU output of conv i and
         acts['p<i>'] = pooled input of conv i (only when keep_all)."""
         taps, acts, x = [], {}, x8
-        for i, (_, _, _, pool) in enumerate(self.convs):
+        nxt = None                                       # the pooled input of the next conv, when the previous launch already wrote it
+        for i, (_, ci, co, pool) in enumerate(self.convs):
             if pool:
-                x = self._pool(x)
+                x = nxt if nxt is not None else self._pool(x)
                 if keep_all:
                     acts[f"p{i}"] = x
-            x = self._conv(i, x)
+            nxt = None
+            N, H, W, _ = x.shape
+            # the max-pool in front of the NEXT conv rides along in this launch where the halo-tile kernel takes it (conv1_2): the pool's own
+            # pass would read the full-resolution tap again
+            if (self.bf16 and i + 1 < len(self.convs) and self.convs[i + 1][3] and i > 0 and ops.conv_bf16_pool_ok(N, H, W, ci, co)):
+                nxt = torch.empty((N, H // 2, W // 2, co), device=self.device, dtype=self.act_dtype)
+            x = self._conv(i, x, pooled=nxt)
             if keep_all:
                 acts[i] = x
             if i in TAP_CONVS:

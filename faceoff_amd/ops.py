@@ -588,8 +588,19 @@ def pack_conv_dgrad_bf16(w):
     return out
 
 
-def conv_bf16(x, wp, bias, out, *, k=(3, 3), stride=1, pad=(1, 1), cin=None, cout=None, flags=0, mask=None):
-    """One fo_conv_igemm_bf16 launch.  x/out/mask: bf16 channels-last views; bias fp32."""
+def conv_bf16_pool_ok(N, H, W, cin, cout):
+    """Can fo_conv_igemm_bf16_pool take this 3x3 same-size layer?  (the halo-tile kernel's geometry and size gate, csrc/conv_bf16.hip)"""
+    import os
+    if os.environ.get("FACEOFF_BF16_NO_HALO", "0") not in ("", "0") or os.environ.get("FACEOFF_NO_POOL_FUSION"):
+        return False
+    tiles = N * (H // 4) * (W // 32) * (cout // 64)
+    forced = os.environ.get("FACEOFF_BF16_FORCE_HALO", "0") not in ("", "0")
+    return cin == 64 and cout % 64 == 0 and H % 4 == 0 and W % 32 == 0 and (tiles >= 8 * _lib.cu_count() or forced)
+
+
+def conv_bf16(x, wp, bias, out, *, k=(3, 3), stride=1, pad=(1, 1), cin=None, cout=None, flags=0, mask=None, pooled=None):
+    """One fo_conv_igemm_bf16 launch.  x/out/mask: bf16 channels-last views; bias fp32.  pooled (optional, only where conv_bf16_pool_ok):
+    receives the 2x2 max-pool of the result from the same launch."""
     N, Hin, Win, _ = x.shape
     _, Hout, Wout, _ = out.shape
     bf = torch.bfloat16
@@ -608,7 +619,11 @@ def conv_bf16(x, wp, bias, out, *, k=(3, 3), stride=1, pad=(1, 1), cin=None, cou
         if prof.detail:
             kname += f" [{N}x{Hout}x{Wout} {d.Cin}->{d.Cout} f{flags}]"
         prof.begin(kname, flops)
-    _lib.call("fo_conv_igemm_bf16", C.byref(d), _ptr(x), _ptr(wp), _ptr(bias), _ptr(mask), _ptr(out), _stream())
+    if pooled is not None:
+        assert mask is None
+        _lib.call("fo_conv_igemm_bf16_pool", C.byref(d), _ptr(x), _ptr(wp), _ptr(bias), _ptr(out), _ptr(pooled), ld_of(pooled, bf), _stream())
+    else:
+        _lib.call("fo_conv_igemm_bf16", C.byref(d), _ptr(x), _ptr(wp), _ptr(bias), _ptr(mask), _ptr(out), _stream())
     if prof is not None:
         prof.end()
 

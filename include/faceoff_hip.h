@@ -381,6 +381,11 @@ int fo_pack_conv_dgrad_bf16(const float* w, void* wp, int O, int I, int taps, in
  * to 128 (Cout > 64), 64 (Cout > 32) or 32.  flags: FO_BIAS | FO_MASK (mask = bf16 activation, > 0) | FO_OUT_RELU. */
 int fo_conv_igemm_bf16(const fo_conv_desc* d, const void* in, const void* wp, const float* bias, const void* mask, void* out,
                        void* stream);
+/* fo_conv_igemm_bf16 that also writes the 2x2 max-pool of its result (VGG: conv1_2 -> MaxPool2d(2), reference models/lpips.py:118-123; the
+ * full-resolution result stays a LPIPS tap): pooled [N][Hout/2][Wout/2][ldPooled], bit for bit fo_maxpool2_fwd_bf16 of `out`.  Only where the
+ * 64-input-channel halo-tile kernel applies (3x3, frames of whole 4 x 32 tiles, >= 8 tiles per CU): FO_E_SHAPE otherwise -- pool separately. */
+int fo_conv_igemm_bf16_pool(const fo_conv_desc* d, const void* in, const void* wp, const float* bias, void* out, void* pooled, int ldPooled,
+                            void* stream);
 /* ---------------------------------------------------------------- bf16-operand VQ-VAE step (BASELINE config 3 as SURVEY 8(d) defines it)
  * The VQ-VAE's own convolutions with bf16 MFMA operands, fp32 accumulation, fp32 master weights and fp32 VQ: activations and
  * activation gradients are STORED as bf16 (rounded once, after bias / ReLU mask / residual or fan-in add / ReLU were applied in

@@ -341,3 +341,34 @@ def test_lpips_all_zero_feature_vectors_give_zero_gradient_like_the_reference(dt
     else:
         np.testing.assert_allclose(loss.item(), ref.item(), rtol=5e-2)
         assert (got - want).norm().item() <= 0.15 * want.norm().item()
+
+
+def test_conv_with_the_max_pool_riding_along_equals_conv_then_pool(monkeypatch):
+    """fo_conv_igemm_bf16_pool (the 64-channel halo-tile kernel writing conv1_2's result AND its 2x2 max-pool, reference models/lpips.py:118-123):
+    both outputs bit for bit what the separate launches give; LPIPSEngine.features uses it and its taps / pooled activations do not change."""
+    import ctypes as C
+    from faceoff_amd import _lib, ops
+    monkeypatch.setenv("FACEOFF_BF16_FORCE_HALO", "1")
+    N, H, W = 3, 16, 64
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn((N, H, W, 64), generator=g).to(torch.bfloat16).cuda()
+    w = (torch.randn((64, 64, 3, 3), generator=g) * 0.06).cuda()
+    b = (torch.randn((64,), generator=g) * 0.1).cuda()
+    wp = ops.pack_conv_bf16(w)
+    y0 = torch.empty((N, H, W, 64), device="cuda", dtype=torch.bfloat16)
+    ops.conv_bf16(x, wp, b, y0, cin=64, cout=64, flags=ops.FO_OUT_RELU)
+    p0 = torch.empty((N, H // 2, W // 2, 64), device="cuda", dtype=torch.bfloat16)
+    _lib.call("fo_maxpool2_fwd_bf16", ops._ptr(y0), ops._ptr(p0), N, H, W, 64, ops._stream())
+    assert ops.conv_bf16_pool_ok(N, H, W, 64, 64)
+    y1 = torch.full_like(y0, 7.0)
+    wide = torch.full((N, H // 2, W // 2, 96), 9.0, device="cuda", dtype=torch.bfloat16)     # pooled output through a channel-slice view
+    ops.conv_bf16(x, wp, b, y1, cin=64, cout=64, flags=ops.FO_OUT_RELU, pooled=wide[..., 16:80])
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1)
+    assert torch.equal(p0, wide[..., 16:80])
+    assert (wide[..., :16] == 9.0).all() and (wide[..., 80:] == 9.0).all()
+    # a shape the halo kernel does not take: the call must refuse, not fall back silently
+    x2 = torch.randn((1, 6, 20, 64), generator=g).to(torch.bfloat16).cuda()
+    y2 = torch.empty((1, 6, 20, 64), device="cuda", dtype=torch.bfloat16); p2 = torch.empty((1, 3, 10, 64), device="cuda", dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError):
+        ops.conv_bf16(x2, wp, b, y2, cin=64, cout=64, flags=ops.FO_OUT_RELU, pooled=p2)
