@@ -183,23 +183,50 @@ class LPIPSEngine:
         if taps0 is None:
             taps0, _ = self.features(self._prep(gt_nchw, nhwc=False), keep_all=False)
         taps1, acts = self.features(x1, keep_all=g_dec is not None)
-        val = torch.zeros(N, device=self.device)
         fused = self.bf16 and g_dec is not None          # training on the bf16 branch: value and gradient of a tap from ONE pass over its two maps
         if gscale is None:
             gscale = torch.ones(1, device=self.device)
-        head = []
-        for k in range(5):
-            n, h, w, c = taps1[k].shape
-            if fused:
-                g = torch.empty_like(taps1[k])
-                _lib.call("fo_lpips_tap_fwd_bwd_bf16", ops._ptr(taps0[k]), ops._ptr(taps1[k]), ops._ptr(self.lin[k]), ops._ptr(val), ops._ptr(gscale),
-                          ops._ptr(g), n, h, w, c, ops._stream())
-                head.append(g)
+        head, head_ready = [], [None] * 5
+        if fused:
+            # The backward chain starts at the deepest tap and meets the shallower taps' gradients only in the pool backwards, much later: only
+            # tap 5's head runs in the chain's way.  The other four -- HBM-bound passes over the big feature maps, 1.5 ms at C3 -- run on a side
+            # stream beside the first (matrix-bound) data-gradient convolutions.  Each head adds into its own row of `vals`; the rows are summed
+            # in a fixed order afterwards, so the loss does not depend on how the streams interleave.
+            import os as _os
+            main = torch.cuda.current_stream(self.device)
+            overlap = not _os.environ.get("FACEOFF_NO_LPIPS_HEAD_OVERLAP")
+            if overlap and getattr(self, "_head_stream", None) is None:
+                self._head_stream = torch.cuda.Stream(device=self.device)
+            vals = torch.zeros((5, N), device=self.device)
+            head = [torch.empty_like(t) for t in taps1]
+
+            def run_head(k):
+                n, h, w, c = taps1[k].shape
+                _lib.call("fo_lpips_tap_fwd_bwd_bf16", ops._ptr(taps0[k]), ops._ptr(taps1[k]), ops._ptr(self.lin[k]), ops._ptr(vals[k]), ops._ptr(gscale),
+                          ops._ptr(head[k]), n, h, w, c, ops._stream())
+            run_head(4)
+            if overlap:
+                side = self._head_stream
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    for k in (3, 2, 1, 0):               # in the order the chain will ask for them
+                        run_head(k)
+                        head_ready[k] = torch.cuda.Event()
+                        head_ready[k].record(side)
+                for t in (*taps0, *taps1, *head, vals, gscale):
+                    t.record_stream(side)
             else:
+                for k in (3, 2, 1, 0):
+                    run_head(k)
+            val = None
+        else:
+            val = torch.zeros(N, device=self.device)
+            for k in range(5):
+                n, h, w, c = taps1[k].shape
                 _lib.call("fo_lpips_tap_fwd_bf16" if self.bf16 else "fo_lpips_tap_fwd", ops._ptr(taps0[k]), ops._ptr(taps1[k]), ops._ptr(self.lin[k]),
                           ops._ptr(val), n, h, w, c, ops._stream())
-        loss = val.mean().reshape(1)
-        self.last_per_image = val
+            loss = val.mean().reshape(1)
+            self.last_per_image = val
         if g_dec is None:
             return loss
         # ---- backward, deepest stage first
@@ -224,6 +251,8 @@ class LPIPSEngine:
                 tap = TAP_CONVS.index(i - 1)
                 gx = torch.empty_like(x)
                 n, h, w, c = x.shape
+                if head_ready[tap] is not None:
+                    torch.cuda.current_stream(self.device).wait_event(head_ready[tap])
                 _lib.call("fo_maxpool2_bwd_bf16" if self.bf16 else "fo_maxpool2_bwd", ops._ptr(x), ops._ptr(gp), ops._ptr(head[tap]), ops._ptr(gx), n, h, w, c,
                           ops._stream())
                 g = gx
@@ -238,6 +267,10 @@ class LPIPSEngine:
         else:
             _lib.call("fo_lpips_prep_bwd", ops._ptr(g), 8, ops._ptr(g_dec), ops.ld_of(g_dec), C.c_int64(N * H * W), self.scale,
                       ops._ptr(one), C.c_float(weight), ops._stream())
+        if fused:
+            val = vals.sum(0)                            # (every head has been awaited by a pool backward by now)
+            loss = val.mean().reshape(1)
+            self.last_per_image = val
         return loss
 
     def _dgrad(self, g, i, out, cin, cout, mask):
