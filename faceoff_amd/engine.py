@@ -357,7 +357,13 @@ class VQVAEEngine:
         self.pack_stream = None
         if self.device.type == "cuda" and not _os.environ.get("FACEOFF_NO_PACK_OVERLAP"):
             self.pack_stream = torch.cuda.Stream(device=self.device)
-        self._streams = (self.wgrad_stream, self.aux_stream, self.pack_stream)
+        # fourth side stream: the quantisers' EMA statistics, their cross-rank sum and the codebook update.  Nothing in the step reads them
+        # (the NEXT forward's vq_prepare does): off the forward's critical path, where they were 0.4 ms of HBM-bound work -- and, with more
+        # than one rank, a blocking all-reduce
+        self.vq_stream = None
+        if self.device.type == "cuda" and not _os.environ.get("FACEOFF_NO_VQ_OVERLAP"):
+            self.vq_stream = torch.cuda.Stream(device=self.device)
+        self._streams = (self.wgrad_stream, self.aux_stream, self.pack_stream, self.vq_stream)
         self._pack_events = None
         # Conv3d forward / data gradient as Winograd F(2x2,3x3) + a (3,1,1) implicit GEMM (FACEOFF_NO_WINOGRAD=1: direct)
         self.winograd = not _os.environ.get("FACEOFF_NO_WINOGRAD")
@@ -387,7 +393,7 @@ class VQVAEEngine:
         ``on=False``, everything in program order on the current stream (each kernel then has the GPU to itself --
         what per-kernel timing needs)."""
         torch.cuda.synchronize(self.device)
-        self.wgrad_stream, self.aux_stream, self.pack_stream = self._streams if on else (None, None, None)
+        self.wgrad_stream, self.aux_stream, self.pack_stream, self.vq_stream = self._streams if on else (None, None, None, None)
 
     def load_state_dict(self, sd):
         for k, v in sd.items():
@@ -546,8 +552,9 @@ class VQVAEEngine:
         d3 = self._new(N, h8, w8, 128); L["conv3d_encoded_t.conv3d.2.0"].fwd(d2, d3, T=T)
         S.update(c1=c1, c2=c2, d1=d1, d2=d2, d3=d3, cat_b=cat_b)
 
-    def stage_quantize(self, S, training):
-        """encode_quantized (:261-278).  Needs S[d3] and S[cat_b][..., 64:192]."""
+    def stage_quantize(self, S, training, join=True):
+        """encode_quantized (:261-278).  Needs S[d3] and S[cat_b][..., 64:192].  join=False (forward()): the codebook update is still running
+        on its side stream when this returns; forward() joins it behind the decoder."""
         self._cur_S = S
         L, d3, cat_b = self.layers, S["d3"], S["cat_b"]
         N, h8, w8, _ = d3.shape
@@ -570,11 +577,15 @@ class VQVAEEngine:
         S["diff"] = stats_t[0:1] / float(qt_in.numel()) + stats_b[0:1] / float(qb_in.numel())
         # EMA codebook update after the (optional) cross-rank sum of the statistics (:59-75)
         if training:
-            for lvl, st in (("t", stats_t), ("b", stats_b)):
-                if self.vq_allreduce is not None:
-                    self.vq_allreduce(st[1:])
-                ops.vq_ema(self.buffers[f"quantize_{lvl}.embed"], self.buffers[f"quantize_{lvl}.cluster_size"],
-                           self.buffers[f"quantize_{lvl}.embed_avg"], st)
+            import contextlib
+            with (torch.cuda.stream(self.vq_stream) if self.vq_stream is not None else contextlib.nullcontext()):
+                for lvl, st in (("t", stats_t), ("b", stats_b)):
+                    if self.vq_allreduce is not None:
+                        self.vq_allreduce(st[1:])
+                    ops.vq_ema(self.buffers[f"quantize_{lvl}.embed"], self.buffers[f"quantize_{lvl}.cluster_size"],
+                               self.buffers[f"quantize_{lvl}.embed_avg"], st)
+            if join and self.vq_stream is not None:
+                torch.cuda.current_stream().wait_stream(self.vq_stream)
 
     def stage_decode(self, S):
         """decode (:280-285).  Needs S[quant_t] and S[cat_d][..., 64:128] (= quant_b)."""
@@ -613,18 +624,22 @@ class VQVAEEngine:
         S = {"T": T, "x8": x8}
         self.stage_encode(S)
         self.stage_conv3d(S)
-        self.stage_quantize(S, training)
+        self.stage_quantize(S, training, join=False)
         self.stage_decode(S)
+        if self.vq_stream is not None and training:      # the codebook update ran beside the decoder; whoever reads the buffers next is behind it
+            torch.cuda.current_stream().wait_stream(self.vq_stream)
         return S
 
     def _quantize(self, name, x, q_out, training):
+        if self.vq_stream is not None:       # the previous step's codebook update (long finished; the join is what orders it)
+            torch.cuda.current_stream().wait_stream(self.vq_stream)
         embedT, enorm = ops.vq_prepare(self.buffers[name + ".embed"])
         stats = torch.zeros(1 + 512 + 512 * 64, device=self.device)
         if self.bf16:        # the straight-through output twice: fp32 (kept for the backward's 2 (x - q) / numel term), bf16 for the next conv
             q32 = torch.empty(x.shape, device=self.device, dtype=torch.float32)
-            ind = ops.vq_assign_bf16out(x, embedT, enorm, q32, q_out, stats, training)
+            ind = ops.vq_assign_bf16out(x, embedT, enorm, q32, q_out, stats, training, stats_stream=self.vq_stream)
             return ind, stats, q32
-        ind = ops.vq_assign(x, embedT, enorm, q_out, stats, training)
+        ind = ops.vq_assign(x, embedT, enorm, q_out, stats, training, stats_stream=self.vq_stream)
         return ind, stats, None
 
     def _vq_bwd(self, gq, x, q, q32, g_diff):

@@ -745,7 +745,23 @@ def bias_grad_bf16(g, dbias, c_real):
     _lib.call("fo_bias_grad_bf16", _ptr(g), _ptr(dbias), C.c_int64(rows), Cc, c_real, ld_of(g, BF), _ptr(ws), _stream())
 
 
-def vq_assign_bf16out(x, embedT, enorm, q_f32, q_bf16, stats, train):
+def _vq_stats(x, nvec, ind, stats, side):
+    """EMA statistics (counts, esum) of an assignment; on `side` (a stream, behind the current stream's work) when given: nothing in the
+    step waits for them -- they feed the codebook's EMA update, which the NEXT step reads."""
+    def run():
+        ws = _workspace(_lib.load().fo_vq_stats_ws_bytes(C.c_int64(nvec)), x.device)
+        _lib.call("fo_vq_stats", _ptr(x), ld_of(x), C.c_int64(nvec), _ptr(ind), _ptr(stats[1:513]), _ptr(stats[513:]), _ptr(ws), _stream())
+    if side is None:
+        run()
+        return
+    side.wait_stream(torch.cuda.current_stream(x.device))
+    with torch.cuda.stream(side):
+        run()
+    for t in (x, ind, stats):
+        t.record_stream(side)
+
+
+def vq_assign_bf16out(x, embedT, enorm, q_f32, q_bf16, stats, train, stats_stream=None):
     """vq_assign on the fp32 input x, writing the straight-through output both as fp32 (q_f32, kept for the backward) and as bf16
     (q_bf16: the operand of the next convolution; may be a channel slice)."""
     nvec = x.shape[0] * x.shape[1] * x.shape[2]
@@ -753,9 +769,7 @@ def vq_assign_bf16out(x, embedT, enorm, q_f32, q_bf16, stats, train):
     _lib.call("fo_vq_assign2", _ptr(x), ld_of(x), C.c_int64(nvec), _ptr(embedT), _ptr(enorm), _ptr(ind), _ptr(q_f32), ld_of(q_f32), _ptr(stats[0:1]),
               _ptr(q_bf16), ld_of(q_bf16, BF), _stream())
     if train:
-        nbytes = _lib.load().fo_vq_stats_ws_bytes(C.c_int64(nvec))
-        ws = _workspace(nbytes, x.device)
-        _lib.call("fo_vq_stats", _ptr(x), ld_of(x), C.c_int64(nvec), _ptr(ind), _ptr(stats[1:513]), _ptr(stats[513:]), _ptr(ws), _stream())
+        _vq_stats(x, nvec, ind, stats, stats_stream)
     return ind
 
 
@@ -874,7 +888,7 @@ def vq_prepare(embed):
     return embedT, enorm
 
 
-def vq_assign(x, embedT, enorm, q_out, stats, train):
+def vq_assign(x, embedT, enorm, q_out, stats, train, stats_stream=None):
     """x, q_out: [..., 64] views; stats: float32[1 + 512 + 512*64] = (sq_sum, counts, esum[512][64]); stats[0]
     must be zero on entry.  With train=True the EMA statistics (counts, esum) are written as well."""
     nvec = x.numel() // 64 if x.is_contiguous() else x.shape[0] * x.shape[1] * x.shape[2]
@@ -882,10 +896,7 @@ def vq_assign(x, embedT, enorm, q_out, stats, train):
     _lib.call("fo_vq_assign", _ptr(x), ld_of(x), C.c_int64(nvec), _ptr(embedT), _ptr(enorm), _ptr(ind), _ptr(q_out),
               ld_of(q_out), _ptr(stats[0:1]), _stream())
     if train:
-        nbytes = _lib.load().fo_vq_stats_ws_bytes(C.c_int64(nvec))
-        ws = _workspace(nbytes, x.device)
-        _lib.call("fo_vq_stats", _ptr(x), ld_of(x), C.c_int64(nvec), _ptr(ind), _ptr(stats[1:513]), _ptr(stats[513:]),
-                  _ptr(ws), _stream())
+        _vq_stats(x, nvec, ind, stats, stats_stream)
     return ind
 
 
