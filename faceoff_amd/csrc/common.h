@@ -31,6 +31,9 @@ int64_t fo_resblock_wgrad1_halo_ws_bytes(const fo_conv_desc* d);
 int fo_resblock_wgrad1_halo_try(const fo_conv_desc* d, const float* P, const float* Q, float* dw, int Areal, int Breal, float* dbias, float* ws,
                                 int64_t ws_bytes, hipStream_t stream);
 
+// resblock_bf16.hip: ReLU -> 3x3 conv 128 -> 32 -> bias -> ReLU on bf16 tensors as a halo-tile kernel; 1 = launched
+int fo_conv3x3_c128to32_halo_bf16_try(const fo_conv_desc* d, const void* in, const void* wp, const float* bias, void* out, hipStream_t stream);
+
 // elementwise.hip: out[c] = sum of the nblk partial rows ws[b][C], c < Creal (the second stage of every column sum)
 extern "C" int fo_colsum_finish(const float* ws, float* out, int nblk, int C, int Creal, void* stream);
 

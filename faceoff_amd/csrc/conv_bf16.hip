@@ -1254,6 +1254,11 @@ static int conv_bf16_impl(const fo_conv_desc* d, const void* in, const void* wp,
     FO_CHECK_LAUNCH();
     return FO_OK;
   }
+  // a ResBlock's 3x3 128 -> 32 (ReLU in, bias, ReLU out): its own halo-tile kernel (resblock_bf16.hip)
+  if (!mask && !add && !pooled && d->Cin == 128 && d->Cout == 32 && fo_conv3x3_c128to32_halo_bf16_try(d, in, wp, bias, out, s)) {
+    FO_CHECK_LAUNCH();
+    return FO_OK;
+  }
   // 64 input channels, 3x3, same size, frames of whole 4 x 32 tiles: the halo-tile kernel (filter in registers, input patch staged once)
   {
     const char* nohalo = getenv("FACEOFF_BF16_NO_HALO");             // diagnostics / A-B

@@ -6,6 +6,7 @@ order and the one final rounding of a stored bf16 result):
 Geometries: every conv form of models/vqvae_conv3d_latent.py:92-190 -- Conv3d k3 (T = 1, 2, 3, 5), k3 s1, k4 s2, 1x1 (32, 128 and 192 input
 channels), the 8-channel image layer, transposed k4 s2 as four phases and as the one-launch cell form -- forward, data gradient with ReLU
 mask / fan-in add, and filter gradient in both its forms (row runs; gather for widths that are not multiples of 32)."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -281,3 +282,46 @@ def test_conversions_input_layout_and_vq_glue():
     ops.vq_bwd_bf16(gq, xin, q1, gd, gx)
     want = (gq.float() + 0.7 * (2.0 / xin.numel()) * (xin - q1)).to(BF)
     assert (gx.float() - want.float()).abs().max().item() <= 2.0 ** -7 * want.float().abs().max().item()
+
+
+@pytest.mark.parametrize("N,H,W", [(3, 16, 32), (2, 6, 64), (1, 32, 32)])
+def test_resblock_conv1_halo_tile_kernel_bf16_vs_torch_and_vs_the_tiled_kernel(N, H, W):
+    """conv3x3_c128to32_halo_bf16_kernel (csrc/resblock_bf16.hip: ReLU -> Conv2d(128, 32, 3, padding=1) -> ReLU of a ResBlock, reference
+    models/vqvae_conv3d_latent.py:91-93, on bf16 operands; taken at C3 sizes, forced here) against the same arithmetic in torch (bf16-rounded
+    operands, wide accumulation, one rounding of the result) and against the tiled kernel: both within one bf16 rounding of the exact value,
+    and equal to each other except where fp32 summation order moves a result across a rounding boundary."""
+    import subprocess, sys, json
+    code = r"""
+import sys, json, torch
+sys.path.insert(0, %r)
+from faceoff_amd import ops
+N, H, W = %d, %d, %d
+g = torch.Generator().manual_seed(N * 100 + H)
+x = torch.randn((N, 128, H, W), generator=g).to(torch.bfloat16)
+w = (torch.randn((32, 128, 3, 3), generator=g) * 0.05).to(torch.bfloat16)
+b = torch.randn(32, generator=g) * 0.1
+ref = torch.relu(torch.nn.functional.conv2d(torch.relu(x.double()), w.double(), b.double(), padding=1))
+xc = x.permute(0, 2, 3, 1).contiguous().cuda()
+wide = torch.zeros((N, H, W, 192), device="cuda", dtype=torch.bfloat16); wide[..., 64:192] = xc
+wp = ops.to_bf16(ops.pack_conv(w.float().cuda()))
+res = {}
+for name, xin in (("dense", xc), ("slice", wide[..., 64:192])):
+    out = torch.full((N, H, W, 48), 5.0, device="cuda", dtype=torch.bfloat16)
+    ops.conv_bf16g(xin, wp, b.cuda(), out[..., 8:40], cin=128, cout=32, flags=ops.FO_IN_RELU | ops.FO_OUT_RELU, k=(1, 3, 3), stride=1, pad=(0, 1, 1))
+    assert (out[..., :8] == 5.0).all() and (out[..., 40:] == 5.0).all()
+    y = out[..., 8:40].permute(0, 3, 1, 2).float().cpu().double()
+    res[name] = {"err": ((y - ref).abs() / (ref.abs() + 1.0)).max().item(), "y": y.flatten()[::7].tolist()}
+print(json.dumps(res))
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), N, H, W)
+    outs = {}
+    for mode in ("halo", "tiled"):       # (the switch is read once per process)
+        env = dict(os.environ, **({"FACEOFF_FORCE_RESBLOCK_HALO": "1"} if mode == "halo" else {"FACEOFF_NO_RESBLOCK_HALO": "1"}))
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[mode] = json.loads(r.stdout.strip().splitlines()[-1])
+    for mode, res in outs.items():
+        for name, v in res.items():
+            assert v["err"] <= 2.0 ** -8, (mode, name, v["err"])          # one bf16 rounding (2^-9 relative) + accumulation noise
+    a, b = np.array(outs["halo"]["dense"]["y"]), np.array(outs["tiled"]["dense"]["y"])
+    assert np.array_equal(np.array(outs["halo"]["slice"]["y"]), a)         # the pixel stride does not enter the arithmetic
+    assert (a != b).mean() < 0.02 and np.abs(a - b).max() <= 2.0 ** -7 * (np.abs(b).max() + 1.0)
