@@ -34,6 +34,9 @@ int fo_resblock_wgrad1_halo_try(const fo_conv_desc* d, const float* P, const flo
 // resblock_bf16.hip: ReLU -> 3x3 conv 128 -> 32 -> bias -> ReLU on bf16 tensors as a halo-tile kernel; 1 = launched
 int fo_conv3x3_c128to32_halo_bf16_try(const fo_conv_desc* d, const void* in, const void* wp, const float* bias, void* out, hipStream_t stream);
 
+int fo_conv3x3_c32to128_halo_bf16_try(const fo_conv_desc* d, const void* in, const void* wp, const void* mask, const void* add, void* out,
+                                      hipStream_t stream);
+
 // elementwise.hip: out[c] = sum of the nblk partial rows ws[b][C], c < Creal (the second stage of every column sum)
 extern "C" int fo_colsum_finish(const float* ws, float* out, int nblk, int C, int Creal, void* stream);
 

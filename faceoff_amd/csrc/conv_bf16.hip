@@ -1259,6 +1259,10 @@ static int conv_bf16_impl(const fo_conv_desc* d, const void* in, const void* wp,
     FO_CHECK_LAUNCH();
     return FO_OK;
   }
+  if (!bias && !pooled && d->Cin == 32 && d->Cout == 128 && fo_conv3x3_c32to128_halo_bf16_try(d, in, wp, mask, add, out, s)) {   // ... and its data gradient
+    FO_CHECK_LAUNCH();
+    return FO_OK;
+  }
   // 64 input channels, 3x3, same size, frames of whole 4 x 32 tiles: the halo-tile kernel (filter in registers, input patch staged once)
   {
     const char* nohalo = getenv("FACEOFF_BF16_NO_HALO");             // diagnostics / A-B

@@ -150,6 +150,122 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c128to32_halo_bf16_kernel(cons
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------------
+// conv3x3_c32to128_halo_bf16_kernel: the data gradient of that convolution, g_x = conv3x3^T(g_h) * (x > 0) + g_out (:91-92 backwards), bf16 in /
+// out.  The 32-channel side is the input: ONE shared 9 KB patch per tile (two stages, one barrier per tile), OUTPUT channels split over the
+// waves (72 filter registers each, no partial sums).  48 GFLOP = 0.02 ms of MFMA against 546 MB of traffic: the kernel is a stream, and what
+// matters is that the tile's mask / residual loads are in flight before anything waits (they are issued at the top of the tile, with the next
+// patch's DMAs) and that three workgroups per CU take turns.
+struct D1Args {
+  const __bf16* gh;     // [N][H][W][ldGh], 32 channels
+  const __bf16* wpd;    // [128][9][32]  (fo_pack_conv_dgrad, rounded to bf16)
+  const __bf16* mask;   // [N][H][W][ldM], 128 channels
+  const __bf16* add;    // [N][H][W][ldA], 128 channels
+  __bf16* out;          // [N][H][W][ldO], 128 channels
+  int N, H, W, ldGh, ldM, ldA, ldO;
+  int tilesX, tilesY, ntiles, perXcd;
+  unsigned ghBytes, mBytes, aBytes, oBytes;
+};
+
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256, 3) void conv3x3_c32to128_halo_bf16_kernel(const D1Args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];       // two patches of SLB bytes
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  lds_byte* const lds3 = (lds_byte*)ldsb;
+  const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.gh) - a.ldGh, 0, a.ghBytes + a.ldGh * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.mask), 0, a.mBytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.add), 0, a.aBytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, a.oBytes, 0x00020000);
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
+  const int tEnd = min(a.ntiles, (xcd + 1) * a.perXcd);
+  int tile = xcd * a.perXcd + slot;
+
+  // DMA: 4 patch rows x 3 pieces of 16 pixels (the third: 2 pixels): wave w fills row w
+  const int lp = lane >> 2, pos = lane & 3;
+  const unsigned dlane = (unsigned)(lp * a.ldGh * 2 + ((pos ^ gsw(lp)) * 16));
+  auto dma_tile = [&](int t, int stage) {
+    if (t >= tEnd) return;
+    const int tx = t % a.tilesX, r1 = t / a.tilesX;
+    const int ty = r1 % a.tilesY, n = r1 / a.tilesY;
+    const int iy = ty * 2 - 1 + wave;
+    const bool rowok = (unsigned)iy < (unsigned)a.H;
+    const unsigned rowoff = rowok ? (unsigned)((((size_t)n * a.H + iy) * a.W + tx * 32) * a.ldGh * 2) : 0u;
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      const bool ok = rowok & !((g == 0) & (tx == 0) & (lp == 0)) & !((g == 2) & (tx == a.tilesX - 1) & (lp == 1));
+      lds_byte* const dst = lds3 + stage * SLB + (wave * PP + g * 16) * 64;
+      if (g < 2 || lane < 8)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (__attribute__((address_space(3))) void*)dst, 16, ok ? dlane : OOB, rowoff + g * 16 * a.ldGh * 2, 0, 0);
+    }
+  };
+  dma_tile(tile, 0);
+
+  // filter block: row = output channel 32 wave + l31, k = tap * 32 + 16 ks + 8 half .. + 7
+  bf16x8 wf[9][2];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) wf[t][ks] = *reinterpret_cast<const bf16x8*>(a.wpd + (size_t)((wave * 32 + l31) * 9 + t) * 32 + ks * 16 + half * 8);
+  int cq[3];
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw) cq[kw] = (l31 + kw) * 64 + ((half ^ gsw(l31 + kw)) * 16);
+  const unsigned mlane = (unsigned)((l31 * a.ldM + wave * 32 + 4 * half) * 2);
+  const unsigned alane = (unsigned)((l31 * a.ldA + wave * 32 + 4 * half) * 2);
+  const unsigned olane = (unsigned)((l31 * a.ldO + wave * 32 + 4 * half) * 2);
+
+  for (int it = 0; tile < tEnd; tile += slots, ++it) {
+    const int tx = tile % a.tilesX, r1 = tile / a.tilesX;
+    const int ty = r1 % a.tilesY, n = r1 / a.tilesY;
+    const int st = (it & 1) * SLB;
+    // this wave's row of the patch has landed (it is older than the previous tile's epilogue loads, which that epilogue waited for; the 8
+    // youngest vector-memory operations are its stores); the barrier makes the patch whole and frees the other stage
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __syncthreads();
+    dma_tile(tile + slots, (it & 1) ^ 1);
+    // the tile's mask and residual: accumulator quad j of row mb = channels 32 wave + 8 j + 4 half .. + 3 of pixel (row mb, column l31)
+    const int pix0 = (n * a.H + ty * 2) * a.W + tx * 32;
+    u32x2 mk[2][4], ad[2][4];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        mk[mb][j] = __builtin_amdgcn_raw_buffer_load_b64(rm, mlane + 16 * j, (pix0 + mb * a.W) * a.ldM * 2, 0);
+        ad[mb][j] = __builtin_amdgcn_raw_buffer_load_b64(ra, alane + 16 * j, (pix0 + mb * a.W) * a.ldA * 2, 0);
+      }
+    f32x16 acc[2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
+#pragma unroll
+    for (int s18 = 0; s18 < 18; ++s18) {
+      const int tap = s18 >> 1, ks = s18 & 1, kh = tap / 3, kw = tap - kh * 3;
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) {
+        const bf16x8 fb = *reinterpret_cast<const bf16x8*>(ldsb + st + ((cq[kw] ^ (ks << 5)) + (mb + kh) * PP * 64));
+        acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[tap][ks], fb, acc[mb], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bf16x4 m = __builtin_bit_cast(bf16x4, mk[mb][j]), ar = __builtin_bit_cast(bf16x4, ad[mb][j]);
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float c = (float)m[e] > 0.f ? acc[mb][4 * j + e] : 0.f;
+          o[e] = (__bf16)(c + (float)ar[e]);
+        }
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), ro, olane + 16 * j, (pix0 + mb * a.W) * a.ldO * 2, 0);
+      }
+  }
+}
+
 }  // namespace
 
 // 1 = launched, 0 = not this kernel's geometry.  ReLU -> 3x3 pad-1 conv 128 -> 32 -> + bias -> ReLU on bf16 tensors.
@@ -176,5 +292,29 @@ int fo_conv3x3_c128to32_halo_bf16_try(const fo_conv_desc* d, const void* in, con
     attr_set = true;
   }
   hipLaunchKernelGGL(conv3x3_c128to32_halo_bf16_kernel, dim3(std::max(8, std::min((a.ntiles + 7) / 8 * 8, 2 * cus) / 8 * 8)), dim3(256), C1_LDS, stream, a);
+  return 1;
+}
+
+// 1 = launched, 0 = not this kernel's geometry.  3x3 pad-1 conv 32 -> 128 with FO_MASK | FO_ADD on bf16 tensors (the ResBlock's data gradient).
+int fo_conv3x3_c32to128_halo_bf16_try(const fo_conv_desc* d, const void* in, const void* wp, const void* mask, const void* add, void* out,
+                                      hipStream_t stream) {
+  static const bool off = getenv("FACEOFF_NO_RESBLOCK_HALO") != nullptr;
+  static const bool force = getenv("FACEOFF_FORCE_RESBLOCK_HALO") != nullptr;
+  if (off || d->Cin != 32 || d->Cout != 128 || d->KD != 1 || d->KH != 3 || d->KW != 3 || d->stride != 1 || d->ostride != 1 || d->padH != 1 ||
+      d->padW != 1 || d->Hm != d->Hin || d->Wm != d->Win || d->Hout != d->Hin || d->Wout != d->Win || d->Win % 32 != 0 || d->Hin % 2 != 0 ||
+      d->flags != (FO_MASK | FO_ADD) || !mask || !add || d->ldIn % 8 != 0 || d->ldOut % 4 != 0 || d->ldMask % 4 != 0 || d->ldAdd % 4 != 0)
+    return 0;
+  D1Args a;
+  a.gh = reinterpret_cast<const __bf16*>(in); a.wpd = reinterpret_cast<const __bf16*>(wp); a.mask = reinterpret_cast<const __bf16*>(mask);
+  a.add = reinterpret_cast<const __bf16*>(add); a.out = reinterpret_cast<__bf16*>(out);
+  a.N = d->N; a.H = d->Hin; a.W = d->Win; a.ldGh = d->ldIn; a.ldM = d->ldMask; a.ldA = d->ldAdd; a.ldO = d->ldOut;
+  a.tilesX = d->Win / 32; a.tilesY = d->Hin / 2; a.ntiles = d->N * a.tilesX * a.tilesY; a.perXcd = (a.ntiles + 7) / 8;
+  const int cus = fo_cu_count();
+  if (a.ntiles < 4 * cus && !force) return 0;
+  const size_t npix = (size_t)d->N * d->Hin * d->Win;
+  const size_t gB = (npix - 1) * d->ldIn * 2 + 64, mB = (npix - 1) * d->ldMask * 2 + 256, aB = (npix - 1) * d->ldAdd * 2 + 256, oB = (npix - 1) * d->ldOut * 2 + 256;
+  if (gB >= 0x7fffffffull || mB >= 0x7fffffffull || aB >= 0x7fffffffull || oB >= 0x7fffffffull) return 0;
+  a.ghBytes = (unsigned)gB; a.mBytes = (unsigned)mB; a.aBytes = (unsigned)aB; a.oBytes = (unsigned)oB;
+  hipLaunchKernelGGL(conv3x3_c32to128_halo_bf16_kernel, dim3(std::max(8, std::min((a.ntiles + 7) / 8 * 8, 3 * cus) / 8 * 8)), dim3(256), 2 * SLB, stream, a);
   return 1;
 }

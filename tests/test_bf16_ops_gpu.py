@@ -311,6 +311,17 @@ for name, xin in (("dense", xc), ("slice", wide[..., 64:192])):
     assert (out[..., :8] == 5.0).all() and (out[..., 40:] == 5.0).all()
     y = out[..., 8:40].permute(0, 3, 1, 2).float().cpu().double()
     res[name] = {"err": ((y - ref).abs() / (ref.abs() + 1.0)).max().item(), "y": y.flatten()[::7].tolist()}
+# the same convolution backwards (conv3x3_c32to128_halo_bf16_kernel): g_x = conv3x3^T(g_h) * (x > 0) + g_out
+gh = torch.randn((N, 32, H, W), generator=g).to(torch.bfloat16); go = torch.randn((N, 128, H, W), generator=g).to(torch.bfloat16)
+gref = torch.nn.functional.conv_transpose2d(gh.double(), w.double(), padding=1) * (x.double() > 0) + go.double()
+wpd = ops.to_bf16(ops.pack_conv_dgrad(w.float().cuda().reshape(32, 128, -1)))
+ghc, goc = gh.permute(0, 2, 3, 1).contiguous().cuda(), go.permute(0, 2, 3, 1).contiguous().cuda()
+wg = torch.zeros((N, H, W, 64), device="cuda", dtype=torch.bfloat16); wg[..., 16:48] = ghc
+for name, gin, xin in (("dgrad dense", ghc, xc), ("dgrad slice", wg[..., 16:48], wide[..., 64:192])):
+    gx = torch.full((N, H, W, 128), 9.0, device="cuda", dtype=torch.bfloat16)
+    ops.conv_bf16g(gin, wpd, None, gx, cin=32, cout=128, mask=xin, add=goc, k=(1, 3, 3), stride=1, pad=(0, 1, 1))
+    y = gx.permute(0, 3, 1, 2).float().cpu().double()
+    res[name] = {"err": ((y - gref).abs() / (gref.abs() + 1.0)).max().item(), "y": y.flatten()[::7].tolist()}
 print(json.dumps(res))
 """ % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), N, H, W)
     outs = {}
@@ -322,6 +333,7 @@ print(json.dumps(res))
     for mode, res in outs.items():
         for name, v in res.items():
             assert v["err"] <= 2.0 ** -8, (mode, name, v["err"])          # one bf16 rounding (2^-9 relative) + accumulation noise
-    a, b = np.array(outs["halo"]["dense"]["y"]), np.array(outs["tiled"]["dense"]["y"])
-    assert np.array_equal(np.array(outs["halo"]["slice"]["y"]), a)         # the pixel stride does not enter the arithmetic
-    assert (a != b).mean() < 0.02 and np.abs(a - b).max() <= 2.0 ** -7 * (np.abs(b).max() + 1.0)
+    for key in ("dense", "dgrad dense"):
+        a, b = np.array(outs["halo"][key]["y"]), np.array(outs["tiled"][key]["y"])
+        assert np.array_equal(np.array(outs["halo"][key.replace("dense", "slice")]["y"]), a)         # the pixel stride does not enter the arithmetic
+        assert (a != b).mean() < 0.02 and np.abs(a - b).max() <= 2.0 ** -7 * (np.abs(b).max() + 1.0), key
