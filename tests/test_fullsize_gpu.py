@@ -210,3 +210,59 @@ def test_c2_step_winograd_engine_equals_direct_engine():
     print(f"[C2 step winograd vs direct engine, N={N}] index flips {flips}; dec rel err {dec_err:.2e}; worst gradient {worst}")
     if flips == 0:
         assert dec_err <= 1e-4
+
+
+def test_resblock_halo_kernels_equal_the_tiled_kernels_at_c2_size_and_are_reproducible():
+    """The ResBlock family's halo-tile kernels (csrc/resblock_halo.hip, csrc/resblock_bwd.hip) at the size they are built for -- 160 frames of
+    64 x 64 x 128, 10 240 tiles on 512 persistent workgroups, where tile walks, stage hand-overs and slab reductions run thousands of times
+    (a hazard between a DMA and a late reader shows here and not in a three-tile test) -- against the tiled kernels they replace, same inputs:
+    forward (hidden + output), the 3x3's masked data gradient with residual, its filter + bias gradient, the 1x1's one-pass backward.
+    Equal up to summation order; each halo result bit-identical between two runs."""
+    import json, os, subprocess, sys
+    code = r"""
+import sys, json, torch
+sys.path.insert(0, %r)
+from faceoff_amd import ops
+Nn, H, W = 160, 64, 64
+g = torch.Generator(device="cuda").manual_seed(7)
+def rnd(shape, s=1.0): return (torch.rand(shape, device="cuda", generator=g) * 2 - 1) * s
+x, go = rnd((Nn, H, W, 128)), rnd((Nn, H, W, 128))
+w1, b1 = rnd((32, 128, 3, 3), 0.05), rnd((32,), 0.1)
+w3, b3 = rnd((128, 32, 1, 1), 0.1), rnd((128,), 0.1)
+wp1, wp3, wpd1 = ops.pack_conv(w1), ops.pack_conv(w3), ops.pack_conv_dgrad(w1.reshape(32, 128, -1))
+h_in, gh_in = torch.relu(rnd((Nn, H, W, 32))), rnd((Nn, H, W, 32))
+def run():
+    hb = torch.empty((Nn, H, W, 32), device="cuda"); out = torch.empty((Nn, H, W, 128), device="cuda")
+    ops.resblock_fwd(x, wp1, b1, wp3, b3, hb, out, True)
+    # (the backward kernels get inputs that do not depend on the mode: a hidden value within rounding of zero would be a ReLU mask on
+    # either side of the tie, and the comparison is of kernels, not of tie-breaking)
+    gh = torch.empty_like(hb); dw3 = torch.empty((128, 32), device="cuda"); db3 = torch.empty((128,), device="cuda")
+    ops.resblock_bwd_conv3(go, h_in, wp3, gh, dw3, db3)
+    gx = torch.empty_like(x)
+    ops.conv_igemm(gh_in, wpd1, None, gx, k=(1, 3, 3), stride=1, pad=(0, 1, 1), cin=32, cout=128, mask=x, add=go)
+    dw1 = torch.empty((32, 128, 3, 3), device="cuda"); db1 = torch.empty((32,), device="cuda")
+    ops.conv_wgrad(gh_in, x, dw1, db1, k=(1, 3, 3), stride=1, pad=(0, 1, 1), a_real=32, b_real=128, in_relu=True)
+    torch.cuda.synchronize()
+    return dict(h=hb, out=out, gh=gh, dw3=dw3, db3=db3, gx=gx, dw1=dw1, db1=db1)
+r1, r2 = run(), run()
+rep = {k: bool(torch.equal(r1[k], r2[k])) for k in r1}
+torch.save({k: v.cpu() for k, v in r1.items()}, sys.argv[1])
+print(json.dumps(rep))
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),)
+    import tempfile
+    outs = {}
+    with tempfile.TemporaryDirectory() as td:
+        for mode in ("halo", "tiled"):
+            env = dict(os.environ)
+            env.pop("FACEOFF_FORCE_RESBLOCK_HALO", None)
+            if mode == "tiled":
+                env["FACEOFF_NO_RESBLOCK_HALO"] = "1"
+            path = os.path.join(td, mode + ".pt")
+            r = subprocess.run([sys.executable, "-c", code, path], capture_output=True, text=True, timeout=600, env=env)
+            assert r.returncode == 0, r.stderr[-2000:]
+            rep = json.loads(r.stdout.strip().splitlines()[-1])
+            assert all(rep.values()), (mode, rep)                       # run-to-run bit-identical (fixed tile walks, fixed slab orders)
+            outs[mode] = torch.load(path)
+    for k, tol in (("h", 2e-6), ("out", 2e-6), ("gh", 2e-6), ("gx", 4e-6), ("dw3", 2e-5), ("db3", 2e-5), ("dw1", 2e-5), ("db1", 2e-5)):
+        a, b = outs["halo"][k].double(), outs["tiled"][k].double()
+        assert (a - b).abs().max().item() <= tol * b.abs().max().item(), (k, (a - b).abs().max().item(), b.abs().max().item())
