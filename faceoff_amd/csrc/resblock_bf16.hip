@@ -154,8 +154,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c128to32_halo_bf16_kernel(cons
 // conv3x3_c32to128_halo_bf16_kernel: the data gradient of that convolution, g_x = conv3x3^T(g_h) * (x > 0) + g_out (:91-92 backwards), bf16 in /
 // out.  The 32-channel side is the input: ONE shared 9 KB patch per tile (two stages, one barrier per tile), OUTPUT channels split over the
 // waves (72 filter registers each, no partial sums).  48 GFLOP = 0.02 ms of MFMA against 546 MB of traffic: the kernel is a stream, and what
-// matters is that the tile's mask / residual loads are in flight before anything waits (they are issued at the top of the tile, with the next
-// patch's DMAs) and that three workgroups per CU take turns.
+// matters is that the mask / residual loads of a tile are issued a whole tile before they are needed (two register sets).
 struct D1Args {
   const __bf16* gh;     // [N][H][W][ldGh], 32 channels
   const __bf16* wpd;    // [128][9][32]  (fo_pack_conv_dgrad, rounded to bf16)
@@ -170,7 +169,7 @@ struct D1Args {
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256, 3) void conv3x3_c32to128_halo_bf16_kernel(const D1Args a) {
+__global__ __launch_bounds__(256, 2) void conv3x3_c32to128_halo_bf16_kernel(const D1Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];       // two patches of SLB bytes
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -217,25 +216,34 @@ __global__ __launch_bounds__(256, 3) void conv3x3_c32to128_halo_bf16_kernel(cons
   const unsigned alane = (unsigned)((l31 * a.ldA + wave * 32 + 4 * half) * 2);
   const unsigned olane = (unsigned)((l31 * a.ldO + wave * 32 + 4 * half) * 2);
 
-  for (int it = 0; tile < tEnd; tile += slots, ++it) {
-    const int tx = tile % a.tilesX, r1 = tile / a.tilesX;
+  // The tile's mask and residual (accumulator quad j of row mb = channels 32 wave + 8 j + 4 half .. + 3 of pixel (row mb, column l31)) are
+  // loaded ONE TILE AHEAD into the other of two register sets (the loop is unrolled by two so that the sets need no copies): at 3.7 TB/s of
+  // traffic a load issued at the top of its own tile came back after the tile's 36 MFMAs were long done.
+  u32x2 mk[2][2][4], ad[2][2][4];
+  auto issue_loads = [&](int t, int set) {
+    if (t >= tEnd) return;
+    const int tx = t % a.tilesX, r1 = t / a.tilesX;
     const int ty = r1 % a.tilesY, n = r1 / a.tilesY;
-    const int st = (it & 1) * SLB;
-    // this wave's row of the patch has landed (it is older than the previous tile's epilogue loads, which that epilogue waited for; the 8
-    // youngest vector-memory operations are its stores); the barrier makes the patch whole and frees the other stage
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    __syncthreads();
-    dma_tile(tile + slots, (it & 1) ^ 1);
-    // the tile's mask and residual: accumulator quad j of row mb = channels 32 wave + 8 j + 4 half .. + 3 of pixel (row mb, column l31)
     const int pix0 = (n * a.H + ty * 2) * a.W + tx * 32;
-    u32x2 mk[2][4], ad[2][4];
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        mk[mb][j] = __builtin_amdgcn_raw_buffer_load_b64(rm, mlane + 16 * j, (pix0 + mb * a.W) * a.ldM * 2, 0);
-        ad[mb][j] = __builtin_amdgcn_raw_buffer_load_b64(ra, alane + 16 * j, (pix0 + mb * a.W) * a.ldA * 2, 0);
+        mk[set][mb][j] = __builtin_amdgcn_raw_buffer_load_b64(rm, mlane + 16 * j, (pix0 + mb * a.W) * a.ldM * 2, 0);
+        ad[set][mb][j] = __builtin_amdgcn_raw_buffer_load_b64(ra, alane + 16 * j, (pix0 + mb * a.W) * a.ldA * 2, 0);
       }
+  };
+  auto step = [&](int t, int set) {                       // set = stage = parity of the tile in this workgroup's walk (a compile-time constant at both call sites)
+    const int tx = t % a.tilesX, r1 = t / a.tilesX;
+    const int ty = r1 % a.tilesY, n = r1 / a.tilesY;
+    const int st = set * SLB;
+    // this wave's row of the patch has landed: the vector-memory operations younger than its DMAs are this tile's 16 mask / residual loads
+    // and the previous tile's 8 stores; the barrier makes the patch whole and frees the other stage
+    asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    __syncthreads();
+    dma_tile(t + slots, set ^ 1);
+    issue_loads(t + slots, set ^ 1);
+    const int pix0 = (n * a.H + ty * 2) * a.W + tx * 32;
     f32x16 acc[2];
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)
@@ -254,7 +262,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_c32to128_halo_bf16_kernel(cons
     for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const bf16x4 m = __builtin_bit_cast(bf16x4, mk[mb][j]), ar = __builtin_bit_cast(bf16x4, ad[mb][j]);
+        const bf16x4 m = __builtin_bit_cast(bf16x4, mk[set][mb][j]), ar = __builtin_bit_cast(bf16x4, ad[set][mb][j]);
         bf16x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -263,6 +271,14 @@ __global__ __launch_bounds__(256, 3) void conv3x3_c32to128_halo_bf16_kernel(cons
         }
         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), ro, olane + 16 * j, (pix0 + mb * a.W) * a.ldO * 2, 0);
       }
+  };
+  issue_loads(tile, 0);
+  while (tile < tEnd) {
+    step(tile, 0);
+    tile += slots;
+    if (tile >= tEnd) break;
+    step(tile, 1);
+    tile += slots;
   }
 }
 
@@ -315,6 +331,6 @@ int fo_conv3x3_c32to128_halo_bf16_try(const fo_conv_desc* d, const void* in, con
   const size_t gB = (npix - 1) * d->ldIn * 2 + 64, mB = (npix - 1) * d->ldMask * 2 + 256, aB = (npix - 1) * d->ldAdd * 2 + 256, oB = (npix - 1) * d->ldOut * 2 + 256;
   if (gB >= 0x7fffffffull || mB >= 0x7fffffffull || aB >= 0x7fffffffull || oB >= 0x7fffffffull) return 0;
   a.ghBytes = (unsigned)gB; a.mBytes = (unsigned)mB; a.aBytes = (unsigned)aB; a.oBytes = (unsigned)oB;
-  hipLaunchKernelGGL(conv3x3_c32to128_halo_bf16_kernel, dim3(std::max(8, std::min((a.ntiles + 7) / 8 * 8, 3 * cus) / 8 * 8)), dim3(256), 2 * SLB, stream, a);
+  hipLaunchKernelGGL(conv3x3_c32to128_halo_bf16_kernel, dim3(std::max(8, std::min((a.ntiles + 7) / 8 * 8, 2 * cus) / 8 * 8)), dim3(256), 2 * SLB, stream, a);
   return 1;
 }
