@@ -21,6 +21,8 @@ from collections import OrderedDict
 import torch
 
 from . import _lib, ops
+import os as _os
+
 from ._lib import ConvNdDesc, FO_BIAS, FO_ADD, FO_OUT_LRELU, FO_MASK_LRELU, FO_KSPLIT
 from .synth import disc_param_specs, DISC_CHANNELS
 
@@ -212,9 +214,11 @@ class DiscEngine:
                 continue
             ld_out = max(32, co)
             # the 1-channel head is written into a zeroed 32-float pixel
-            y = (torch.zeros if co < 32 else torch.empty)((N,) + dd + (ld_out,), device=self.device)
-            # the head (1 channel, K = 64 taps x 512): 192 tiles x 1024 K-steps -> the launch may slice K (y is zeroed above)
-            flags = FO_BIAS | (FO_OUT_LRELU if j == 0 else 0) | (FO_KSPLIT if co < 32 else 0)
+            # few output tiles behind a long contraction -- the 1-channel head (192 tiles x 1024 K-steps) and the 256 -> 512 layer (292 tiles
+            # of a 16 384-deep contraction on 512 workgroup slots: one round, 57 % full) --: the launch may slice K (y is zeroed for it)
+            ksplit = (co < 32 or j >= 3) and not _os.environ.get("FACEOFF_NO_DISC_KSPLIT")
+            y = (torch.zeros if ksplit else torch.empty)((N,) + dd + (ld_out,), device=self.device)
+            flags = FO_BIAS | (FO_OUT_LRELU if j == 0 else 0) | (FO_KSPLIT if ksplit else 0)
             d = self._desc(N, sd, cin, h.shape[-1], dd, co, ld_out, s, flags)
             _lib.call("fo_convnd", C.byref(d), 0, ops._ptr(h), ops._ptr(self._wp[key + ".0.weight"]), ops._ptr(self.params[key + ".0.bias"]),
                       None, ops._ptr(y), ops._stream())
@@ -299,8 +303,9 @@ class DiscEngine:
                 self._wgrad(d, g, x_in, key, cin_real)
             # data gradient: source = g on the conv's output grid (channels padded to 32), destination = the conv's input
             cs = max(32, co)
-            gin = torch.empty_like(x_in) if j > 0 else torch.zeros_like(x_in)
-            flags = FO_MASK_LRELU if j == 1 else 0          # layer 0's LeakyReLU (no norm in between): mask = its output
+            ksplit = j >= 3 and not _os.environ.get("FACEOFF_NO_DISC_KSPLIT")     # (as the forward: few tiles, long contraction, linear epilogue)
+            gin = torch.empty_like(x_in) if (j > 0 and not ksplit) else torch.zeros_like(x_in)
+            flags = (FO_MASK_LRELU if j == 1 else 0) | (FO_KSPLIT if ksplit else 0)          # layer 0's LeakyReLU (no norm in between): mask = its output
             d = self._desc(N, dd, cs, g.shape[-1], sd, cin_real, cin_pad, s, flags, ld_mask=cin_pad if j == 1 else 0)
             _lib.call("fo_convnd", C.byref(d), 1, ops._ptr(g), ops._ptr(self._wpt[key + ".0.weight"]), None,
                       ops._ptr(x_in) if j == 1 else None, ops._ptr(gin), ops._stream())
