@@ -220,8 +220,12 @@ class DiscEngine:
             y = (torch.zeros if ksplit else torch.empty)((N,) + dd + (ld_out,), device=self.device)
             flags = FO_BIAS | (FO_OUT_LRELU if j == 0 else 0) | (FO_KSPLIT if ksplit else 0)
             d = self._desc(N, sd, cin, h.shape[-1], dd, co, ld_out, s, flags)
-            _lib.call("fo_convnd", C.byref(d), 0, ops._ptr(h), ops._ptr(self._wp[key + ".0.weight"]), ops._ptr(self.params[key + ".0.bias"]),
-                      None, ops._ptr(y), ops._stream())
+            if self._head_ok(co, s, cin):       # the 1-channel head: dot products, not a 64-column tile (csrc/disc_head.hip)
+                _lib.call("fo_disc_head_fwd", C.byref(d), ops._ptr(h), ops._ptr(self._wp[key + ".0.weight"]), ops._ptr(self.params[key + ".0.bias"]),
+                          ops._ptr(y), ops._stream())
+            else:
+                _lib.call("fo_convnd", C.byref(d), 0, ops._ptr(h), ops._ptr(self._wp[key + ".0.weight"]), ops._ptr(self.params[key + ".0.bias"]),
+                          None, ops._ptr(y), ops._stream())
             if 1 <= j <= 3:
                 rows = dd[0] * dd[1] * dd[2]
                 st = torch.empty((N, 2 * co), device=self.device)
@@ -255,8 +259,18 @@ class DiscEngine:
                 _lib.call("fo_avgpool3_bwd", ops._ptr(gnext[n]), ops._ptr(gx[n]), D, H, W, Cc, Cc, kD, sD, sH, sW, ops._stream())
         return gx_scale[0]
 
+    @staticmethod
+    def _head_ok(co, stride, cin):
+        return co == 1 and stride == 1 and cin in (256, 512) and not _os.environ.get("FACEOFF_NO_DISC_HEAD")
+
     def _wgrad(self, d, g, src, key, cs_real):
         dw = self.grads[key + ".0.weight"]
+        if self._head_ok(d.Cd, d.sH, d.Cs):
+            ws = ops._workspace(_lib.load().fo_disc_head_wgrad_ws_bytes(C.byref(d)), g.device)
+            _lib.call("fo_disc_head_wgrad", C.byref(d), ops._ptr(g), ops._ptr(src), ops._ptr(dw), cs_real, ops._ptr(ws), C.c_int64(ws.numel() * 4), ops._stream())
+            rows = g.numel() // g.shape[-1]
+            ops.bias_grad(g.view(rows, 1, 1, g.shape[-1]), self.grads[key + ".0.bias"], d.Cd)
+            return
         if _lib.load().fo_wgradnd_splits(C.byref(d)) > 1:
             ops.zero_(dw.view(-1))
         _lib.call("fo_wgradnd", C.byref(d), ops._ptr(g), ops._ptr(src), ops._ptr(dw), cs_real, ops._stream())
@@ -306,9 +320,13 @@ class DiscEngine:
             ksplit = j >= 3 and not _os.environ.get("FACEOFF_NO_DISC_KSPLIT")     # (as the forward: few tiles, long contraction, linear epilogue)
             gin = torch.empty_like(x_in) if (j > 0 and not ksplit) else torch.zeros_like(x_in)
             flags = (FO_MASK_LRELU if j == 1 else 0) | (FO_KSPLIT if ksplit else 0)          # layer 0's LeakyReLU (no norm in between): mask = its output
-            d = self._desc(N, dd, cs, g.shape[-1], sd, cin_real, cin_pad, s, flags, ld_mask=cin_pad if j == 1 else 0)
-            _lib.call("fo_convnd", C.byref(d), 1, ops._ptr(g), ops._ptr(self._wpt[key + ".0.weight"]), None,
-                      ops._ptr(x_in) if j == 1 else None, ops._ptr(gin), ops._stream())
+            if self._head_ok(co, s, cin_pad) and cin_real == cin_pad:
+                dfw = self._desc(N, sd, cin_pad, cin_pad, dd, co, g.shape[-1], s)       # the forward convolution's description
+                _lib.call("fo_disc_head_dgrad", C.byref(dfw), ops._ptr(g), ops._ptr(self._wp[key + ".0.weight"]), ops._ptr(gin), ops._stream())
+            else:
+                d = self._desc(N, dd, cs, g.shape[-1], sd, cin_real, cin_pad, s, flags, ld_mask=cin_pad if j == 1 else 0)
+                _lib.call("fo_convnd", C.byref(d), 1, ops._ptr(g), ops._ptr(self._wpt[key + ".0.weight"]), None,
+                          ops._ptr(x_in) if j == 1 else None, ops._ptr(gin), ops._stream())
             g = gin
         return g
 

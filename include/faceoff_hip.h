@@ -449,6 +449,15 @@ int fo_relu(const float* x, int ldx, float* y, int ldy, int64_t rows, int C, voi
 /* y = a + b over strided [rows][C] views (gradient fan-in where no conv epilogue can take it) */
 int fo_add(const float* a, int lda, const float* b, int ldb, float* y, int ldy, int64_t rows, int C, void* stream);
 
+/* The discriminators' 1-channel patch head (Conv3d / Conv2d(512 | 256, 1, k 4, s 1, p 2); reference mocoganhd_video_disc.py:150-158) as dot
+ * products instead of a 64-column GEMM tile: d describes the FORWARD convolution (Cs channels -> Cd == 1, stride 1, <= 64 taps);
+ * wp = its fo_pack_convnd forward pack (row 0 is used).  fwd writes y[position][0] only (ldD floats per position); dgrad writes every channel
+ * of gx; wgrad writes dw[0][c][tap] for c < CsReal.  Bit-reproducible (fixed summation orders). */
+int fo_disc_head_fwd(const fo_convnd_desc* d, const float* x, const float* wp, const float* bias, float* y, void* stream);
+int fo_disc_head_dgrad(const fo_convnd_desc* d, const float* g, const float* wp, float* gx, void* stream);
+int64_t fo_disc_head_wgrad_ws_bytes(const fo_convnd_desc* d);
+int fo_disc_head_wgrad(const fo_convnd_desc* d, const float* g, const float* x, float* dw, int CsReal, float* ws, int64_t ws_bytes, void* stream);
+
 /* ---------------------------------------------------------------- data-parallel gradient exchange (csrc/comm.cpp)
  * What nn.parallel.DistributedDataParallel's reducer does for the reference (train_faceoff_perceptual.py:164-169; process group:
  * distributed/launch.py:61-66) for a host that does not go through torch.distributed: one communicator per process (= per GPU) over RCCL

@@ -151,6 +151,55 @@ def test_convnd_forward_transposed_and_wgrad_vs_torch(dims, N, Cin, Cout, size, 
     assert (dw.cpu() - want).abs().max().item() <= 5e-5 * want.abs().max().item()
 
 
+@pytest.mark.parametrize("dims,N,Cin,size", [(3, 2, 512, (3, 9, 11)), (2, 2, 512, (1, 13, 12)), (3, 1, 256, (4, 6, 7)), (2, 3, 256, (1, 5, 18))])
+def test_disc_head_kernels_vs_torch(dims, N, Cin, size):
+    """fo_disc_head_{fwd,dgrad,wgrad} (csrc/disc_head.hip: the 512 -> 1 patch head, reference mocoganhd_video_disc.py:150-158, as dot products)
+    against torch-CPU conv k4 s1 p2 in float64; the pixel's other 31 floats stay untouched; every result bit-identical between two calls."""
+    from faceoff_amd import _lib, ops
+    from faceoff_amd._lib import ConvNdDesc, FO_BIAS
+    g = torch.Generator().manual_seed(dims * 1000 + Cin + N)
+    D, H, W = size
+    x = torch.randn((N, Cin, D, H, W), generator=g)
+    kshape = (4, 4, 4) if dims == 3 else (1, 4, 4)
+    w = torch.randn((1, Cin) + kshape, generator=g) * 0.05
+    b = torch.randn(1, generator=g)
+    pad = (2, 2, 2) if dims == 3 else (0, 2, 2)
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    y = torch.nn.functional.conv3d(xr, wr, b.double(), stride=1, padding=pad)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy.double())
+    Do, Ho, Wo = y.shape[2:]
+    taps = kshape[0] * 16
+    d = ConvNdDesc(N=N, Ds=D, Hs=H, Ws=W, Cs=Cin, ldS=Cin, Dd=Do, Hd=Ho, Wd=Wo, Cd=1, ldD=32, KD=kshape[0], KH=4, KW=4, sD=1, sH=1, sW=1,
+                   pD=pad[0], pH=2, pW=2, ldMask=0, flags=FO_BIAS, slope=0.2)
+    xc = x.permute(0, 2, 3, 4, 1).contiguous().cuda()
+    wc = w.reshape(1, Cin, taps).contiguous().cuda()
+    wp = torch.empty(64 * taps * Cin, device="cuda")
+    _lib.call("fo_pack_convnd", ops._ptr(wc), ops._ptr(wp), 1, Cin, taps, 0, ops._stream())
+    gc = torch.zeros((N, Do, Ho, Wo, 32), device="cuda")
+    gc[..., 0] = gy[:, 0].cuda()
+    res = []
+    for _ in range(2):
+        out = torch.full((N, Do, Ho, Wo, 32), 7.0, device="cuda")
+        _lib.call("fo_disc_head_fwd", C.byref(d), ops._ptr(xc), ops._ptr(wp), ops._ptr(b.cuda()), ops._ptr(out), ops._stream())
+        gin = torch.full((N, D, H, W, Cin), 9.0, device="cuda")
+        _lib.call("fo_disc_head_dgrad", C.byref(d), ops._ptr(gc), ops._ptr(wp), ops._ptr(gin), ops._stream())
+        dw = torch.full((1, Cin, taps), 5.0, device="cuda")
+        ws = torch.empty(_lib.load().fo_disc_head_wgrad_ws_bytes(C.byref(d)) // 4, device="cuda")
+        _lib.call("fo_disc_head_wgrad", C.byref(d), ops._ptr(gc), ops._ptr(xc), ops._ptr(dw), Cin, ops._ptr(ws), C.c_int64(ws.numel() * 4), ops._stream())
+        res.append((out.cpu(), gin.cpu(), dw.cpu()))
+    out, gin, dw = res[0]
+    for a_, b_ in zip(res[0], res[1]):
+        assert torch.equal(a_, b_)
+    assert (out[..., 1:] == 7.0).all()
+    yd = y.detach()[:, 0]
+    assert (out[..., 0].double() - yd).abs().max().item() <= 2e-6 * yd.abs().max().item()
+    assert (gin.permute(0, 4, 1, 2, 3).double() - xr.grad).abs().max().item() <= 2e-6 * xr.grad.abs().max().item()
+    want = wr.grad.reshape(1, Cin, taps)
+    bound = torch.nn.functional.conv3d(x.double().abs().transpose(0, 1), gy.double().abs().transpose(0, 1), padding=pad).max().item()
+    assert (dw.double() - want).abs().max().item() <= 2e-6 * max(bound, want.abs().max().item())
+
+
 def test_avgpool_instnorm_pairs_ralsgan_vs_torch():
     from faceoff_amd import _lib, ops
     g = torch.Generator().manual_seed(3)
