@@ -573,6 +573,7 @@ class VQVAEEngine:
         cat_d = self._new(N, h4, w4, 128)
         id_b, stats_b, S["quant_b_f32"] = self._quantize("quantize_b", qb_in, cat_d[..., 64:128], training)
         S.update(qt_in=qt_in, quant_t=quant_t, u0=u0, u1=u1, u2=u2, qb_in=qb_in, cat_d=cat_d, id_t=id_t, id_b=id_b)
+        S["_vq_stats"] = (stats_t, stats_b)      # read by the codebook update on its side stream: alive until S goes (after the join)
         # diff = diff_t + diff_b, each mean((q - x)^2) (:77,268,276,278)
         S["diff"] = stats_t[0:1] / float(qt_in.numel()) + stats_b[0:1] / float(qb_in.numel())
         # EMA codebook update after the (optional) cross-rank sum of the statistics (:59-75)

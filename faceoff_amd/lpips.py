@@ -213,8 +213,10 @@ class LPIPSEngine:
                         run_head(k)
                         head_ready[k] = torch.cuda.Event()
                         head_ready[k].record(side)
-                for t in (*taps0, *taps1, *head, vals, gscale):
-                    t.record_stream(side)
+                # (no record_stream on these tensors -- up to 1.3 GB each: it would keep the allocator from handing their blocks to the next
+                # step until the side stream's work has been observed complete, and a host that runs a few steps ahead then grows the pool by
+                # gigabytes in the middle of training.  It is not needed: every head is awaited by a pool backward on the main stream below,
+                # so by the time this function's tensors are freed, in main-stream order, the side stream is done with them.)
             else:
                 for k in (3, 2, 1, 0):
                     run_head(k)

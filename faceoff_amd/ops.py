@@ -757,8 +757,7 @@ def _vq_stats(x, nvec, ind, stats, side):
     side.wait_stream(torch.cuda.current_stream(x.device))
     with torch.cuda.stream(side):
         run()
-    for t in (x, ind, stats):
-        t.record_stream(side)
+    # (no record_stream: the caller keeps x, ind and stats alive until the stream that made them has joined `side` -- VQVAEEngine does, in S)
 
 
 def vq_assign_bf16out(x, embedT, enorm, q_f32, q_bf16, stats, train, stats_stream=None):

@@ -60,6 +60,12 @@ class FaceOffTrainer:
         self.lpips_stream = None
         if vqlpips is not None and engine.device.type == "cuda" and not _os.environ.get("FACEOFF_NO_LPIPS_OVERLAP"):
             self.lpips_stream = torch.cuda.Stream(device=engine.device)
+        # Flow control: the host may enqueue at most this many steps ahead of the GPU.  A training loop that never reads a loss lets the host
+        # run arbitrarily far ahead, and with several streams per step the caching allocator then cannot hand a step's blocks to the next
+        # one (their uses are still pending): the pool grew by 20-60 GB a few steps into a run -- device mallocs of gigabytes in the middle
+        # of training (tools/scratch/c3_steps_probe.py).  Two steps in flight keep the GPU fed; the wait costs nothing when it is the bottleneck.
+        self.max_inflight_steps = int(_os.environ.get("FACEOFF_MAX_INFLIGHT_STEPS", "2"))
+        self._inflight = []
         self.reducer = None
         if self.world > 1 or force_collectives:
             self.reducer = GradBucketReducer(engine.flat_grads, engine.layer_order, engine.offsets, bucket_bytes, group,
@@ -88,6 +94,9 @@ class FaceOffTrainer:
             img = img.reshape(-1, *img.shape[2:])
             ground_truth = ground_truth.reshape(-1, *ground_truth.shape[2:])
         eng = self.engine
+        if eng.device.type == "cuda" and self.max_inflight_steps > 0:
+            while len(self._inflight) >= self.max_inflight_steps:
+                self._inflight.pop(0).synchronize()
         taps0 = None
         if self.vqlpips is not None and self.lpips_stream is not None and eng.wgrad_stream is not None:
             main = torch.cuda.current_stream()
@@ -116,6 +125,10 @@ class FaceOffTrainer:
         if self.scheduler is not None:           # before optimizer.step(), as the reference (:104-107)
             self.scheduler.step()
         self.optimizer.step(grad_scale=1.0 / self.world)   # DDP averages gradients
+        if eng.device.type == "cuda" and self.max_inflight_steps > 0:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(eng.device))
+            self._inflight.append(ev)
         return recon, S["diff"], perceptual
 
     def run_host_fed(self, loader, max_steps=None):
