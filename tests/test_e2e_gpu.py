@@ -322,3 +322,20 @@ def test_three_training_steps_track_the_oracle():
         off += int((d > 3e-5).sum())
         tot += d.numel()
     assert off <= 0.01 * tot, (off, tot)                              # ... and that is rare
+
+
+def test_reference_goldens_with_the_resblock_halo_kernels_forced():
+    """At the goldens' sizes (1-2 clips) the ResBlock family stays on the tiled kernels -- the halo-tile kernels (csrc/resblock_halo.hip,
+    resblock_bwd.hip, resblock_bf16.hip) are taken from four tiles per CU up.  Here the same golden / oracle tests run once more in a fresh
+    process with FACEOFF_FORCE_RESBLOCK_HALO=1 (the switch is read once per process), so that the kernels the timed configuration runs are
+    held to the reference's outputs, code indices, losses and 70 gradients directly, not only through their agreement with the tiled forms."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FACEOFF_FORCE_RESBLOCK_HALO="1")
+    sel = ("tests/test_e2e_gpu.py::test_c1_e2e_vs_reference_golden", "tests/test_e2e_gpu.py::test_c2_oneclip_vs_reference_golden",
+           "tests/test_e2e_gpu.py::test_three_training_steps_track_the_oracle",
+           "tests/test_bf16_engine_gpu.py::test_bf16_engine_step_vs_bf16_simulated_oracle_and_vs_fp32_oracle")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", *sel], capture_output=True, text=True, timeout=1500, cwd=root, env=env)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-1500:])
+    assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-500:]
