@@ -58,10 +58,13 @@ class _Layer:
         self.wpd = None    # dgrad filter
         self.need_dgrad = True
         self.engine = None
+        self._w42_buf, self._wino_buf = {}, {}   # transformed filter banks: persistent buffers, refilled by pack() once a step has used them
 
     # -- filter packing (every step: the optimiser rewrites the checkpoint-layout weights)
     def pack(self):
-        self._w42_u = {}           # Winograd F(4x4, 2x2) filter banks of this step (k4 s2 stems), made on first use
+        # Winograd filter banks of this step: the forms the last step used are refilled here (on the pack stream, beside the previous
+        # launches), a form not seen before is made on first use
+        self._w42_u = {t: ops.w42_filter(self.w, t, out=U) for t, U in self._w42_buf.items()}
         if self.kind == "convT":
             if self.co <= 8:                         # few output channels: all 4 phases as one 3x3 filter bank
                 self.wp = ops.pack_convT_fused(self.w, self.wp)
@@ -71,7 +74,7 @@ class _Layer:
                 self.wpd = ops.pack_conv(self.w, self.wpd)
         else:
             self.wp = ops.pack_conv(self.w, self.wp)
-            self._wino_u = {}      # Winograd filter banks of this step, made on first use: (m, dgrad) -> U
+            self._wino_u = {key: ops.wino_filter(self.w, dgrad=key[1], m=key[0], out=U) for key, U in self._wino_buf.items()}   # (m, dgrad) -> U
             if not self.need_dgrad:
                 return
             if self.k[-1] == 4:                      # dgrad of k4s2p1 conv = transposed conv, Ci_T:=co, Co_T:=ci
@@ -147,7 +150,7 @@ class _Layer:
 
     def _w42_filter(self, transposed):
         if transposed not in self._w42_u:
-            self._w42_u[transposed] = ops.w42_filter(self.w, transposed)
+            self._w42_u[transposed] = self._w42_buf[transposed] = ops.w42_filter(self.w, transposed)
         return self._w42_u[transposed]
 
     @property
@@ -157,7 +160,7 @@ class _Layer:
     def _wino_filter(self, m, dgrad):
         key = (m, dgrad)
         if key not in self._wino_u:
-            self._wino_u[key] = ops.wino_filter(self.w, dgrad=dgrad, m=m)
+            self._wino_u[key] = self._wino_buf[key] = ops.wino_filter(self.w, dgrad=dgrad, m=m)
         return self._wino_u[key]
 
     # -- data gradient: gin = dgrad(g) [* (mask > 0)] [+ add]

@@ -243,14 +243,14 @@ def wino_tile(H, W, N=None):
     return 2 if H % 2 == 0 and W % 2 == 0 else 0
 
 
-def wino_filter(w, dgrad=False, m=2):
+def wino_filter(w, dgrad=False, m=2, out=None):
     """[O][I][KD][3][3] -> (m+2)^2 packed (3,1,1) filter banks [P][Opad][KD][Ipad] (dgrad: flipped taps, swapped channels)."""
     if w.dim() == 4:                       # Conv2d filter [O][I][3][3]: one depth tap
         w = w.unsqueeze(2)
     O, I, KD = w.shape[:3]
     rows, cols = (I, O) if dgrad else (O, I)
     Op, Ip = pad_out(rows), pad_in(cols)
-    U = torch.empty((m + 2) ** 2 * Op * KD * Ip, device=w.device, dtype=torch.float32)
+    U = out if out is not None else torch.empty((m + 2) ** 2 * Op * KD * Ip, device=w.device, dtype=torch.float32)
     _lib.call("fo_wino_filter", _ptr(w.contiguous()), _ptr(U), O, I, KD, Op, Ip, int(dgrad), m, _stream())
     return U
 
@@ -382,11 +382,11 @@ def _rows128(n):
     return (n + 127) // 128 * 128
 
 
-def w42_filter(w, transposed):
+def w42_filter(w, transposed, out=None):
     """w [O][I][4][4] (Conv2d; or ConvTranspose2d [I_T][O_T][4][4] read as O := I_T, I := O_T) -> U [25][O][4I] (conv form) or
     [25][4I][O] (transposed form)."""
     O, I = w.shape[:2]
-    U = torch.empty(25 * O * 4 * I, device=w.device, dtype=torch.float32)
+    U = out if out is not None else torch.empty(25 * O * 4 * I, device=w.device, dtype=torch.float32)
     _lib.call("fo_w42_filter", _ptr(w), _ptr(U), O, I, int(bool(transposed)), _stream())
     return U
 
