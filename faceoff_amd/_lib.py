@@ -171,6 +171,10 @@ SIGNATURES.update({
     "fo_disc_pairs_bwd": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _F, _P]),
     "fo_affine_warp": (_I, [_P, _P, _I, _I, _I, _I, C.POINTER(C.c_float), _I, _P]),
     "fo_denorm_u8": (_I, [_P, _I, _I, _I, _P, _I, _I, _I, _I, _P]),
+    "fo_warp_affine_u8": (_I, [_P, _P, _I, _I, _I, _I, C.POINTER(C.c_double), _I, _P]),
+    "fo_resize_center_u8": (_I, [_P, _P, _I, _I, _I, _I, C.POINTER(C.c_double), _I, _P]),
+    "fo_flip_u8": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "fo_u8_to_norm_nchw": (_I, [_P, _P, _I, _I, _I, _I, _I, C.c_float, C.c_float, _P]),
     "fo_space_to_depth2": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "fo_s2d_filter": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "fo_ralsgan": (_I, [_P, _I, _P, _I, _I, _F, _F, _F, _P, _P, _P, _P, _P]),

@@ -5,15 +5,21 @@ to whole clips [T,C,H,W] of float frames resident in HBM by one warp kernel (fo_
 two CPU loader workers (utils.py:73).  Same function names, argument order and parameter draws (`random.randint` in the
 reference's order, from a `random.Random`).
 
-Differences: frames are float tensors on the GPU (the reference warps uint8 numpy images before normalisation);
-interpolation is exact bilinear / bicubic -- cv2.warpAffine quantises source coordinates to 1/32 pixel, which is not
-reproduced (cv2 is not available here: parity with cv2 is unpinned, the checker is oracle/warp_oracle.py); `distort_image`
-(Wand arc / barrel distortions, :108-170) is not built."""
+Two frame formats, chosen by dtype:
+  * uint8 [N,H,W,C] (or [H,W,C]) -- what cv2 hands the reference.  These go through the kernels of csrc/warp_u8.hip, which follow
+    OpenCV 4.6.0's 8-bit arithmetic (the pinned opencv-python==4.6.0.66): 1/32-pixel source coordinates and 15-bit weights in
+    warpAffine, 11-bit cubic weights and the int / float split of the vertical pass in resize, so the perturbed frame is the
+    frame cv2 would have produced (checker: oracle/cv2_oracle.py; cv2 is not installed here, so parity with cv2 itself is
+    unpinned).  Every function also takes one parameter PER FRAME (a sequence of N values): the reference draws them per image
+    (TemporalAlignment/dataset.py:34-54).  `to_normalized` is the ToTensor + Normalize that follows (dataset.py:244-256).
+  * float32 [T,C,H,W] -- already normalised clips: exact bilinear / bicubic interpolation (checker oracle/warp_oracle.py).
+`distort_image` (Wand arc / barrel distortions, :131-168) is not built: ImageMagick is not restatable from the reference."""
 from __future__ import annotations
 
 import ctypes as C
 import math
 import random as _random
+import struct
 
 import torch
 
@@ -39,13 +45,59 @@ def _warp(frames, M, mode=0):
     return out if frames.dim() == 4 else out[0]
 
 
+def _is_u8(image):
+    return image.dtype == torch.uint8
+
+
+def _f32(v):
+    """the value after a round trip through float32 (np.float32([[1, 0, x], ...]), cv::Point2f)"""
+    return struct.unpack("f", struct.pack("f", float(v)))[0]
+
+
+def _u8_frames(image):
+    x = image if image.dim() == 4 else image.unsqueeze(0)
+    if not (x.is_cuda and x.dim() == 4 and x.shape[-1] <= 4):
+        raise ValueError(f"faceoff_amd: uint8 frames must be [N,H,W,C] (or [H,W,C]) with C <= 4 on the GPU, got {tuple(image.shape)} on {image.device}")
+    return x.contiguous()
+
+
+def _per_frame(value, N):
+    """one parameter for all N frames, or a sequence of N -> list of N"""
+    if isinstance(value, (int, float)):
+        return [value], 0
+    value = list(value)
+    if len(value) != N:
+        raise ValueError(f"faceoff_amd: {len(value)} per-frame parameters for {N} frames")
+    return value, 1
+
+
+def _warp_u8(image, matrices, per_frame):
+    """cv2.warpAffine(frame, M, (w, h)) on every frame; matrices: list of 6-tuples (forward maps)"""
+    x = _u8_frames(image)
+    N, H, W, Cc = x.shape
+    flat = [float(v) for M in matrices for v in M]
+    out = torch.empty_like(x)
+    _lib.call("fo_warp_affine_u8", ops._ptr(x), ops._ptr(out), N, H, W, Cc, (C.c_double * len(flat))(*flat), per_frame, ops._stream())
+    return out if image.dim() == 4 else out[0]
+
+
+def _hw(image):
+    return tuple(image.shape[-3:-1]) if _is_u8(image) else tuple(image.shape[-2:])
+
+
 def translate_horizontal(x, image):
-    """perturbations.py:45-52: M = [[1, 0, x], [0, 1, 0]]."""
+    """perturbations.py:45-52: M = np.float32([[1, 0, x], [0, 1, 0]])."""
+    if _is_u8(image):
+        xs, pf = _per_frame(x, _u8_frames(image).shape[0])
+        return _warp_u8(image, [(1, 0, _f32(v), 0, 1, 0) for v in xs], pf)
     return _warp(image, (1, 0, x, 0, 1, 0))
 
 
 def translate_vertical(y, image):
-    """:57-65: M = [[1, 0, 0], [0, 1, y]]."""
+    """:57-65: M = np.float32([[1, 0, 0], [0, 1, y]])."""
+    if _is_u8(image):
+        ys, pf = _per_frame(y, _u8_frames(image).shape[0])
+        return _warp_u8(image, [(1, 0, 0, 0, 1, _f32(v)) for v in ys], pf)
     return _warp(image, (1, 0, 0, 0, 1, y))
 
 
@@ -57,14 +109,31 @@ def rotation_matrix(center, angle_deg, scale=1.0):
 
 
 def rotate_image(rotation, image, center=None):
-    """:70-82: about the image centre (w // 2, h // 2) or `center`."""
-    h, w = image.shape[-2:]
+    """:70-82: about the image centre (w // 2, h // 2) or `center` (uint8 frames: one centre, or one per frame)."""
+    h, w = _hw(image)
+    if _is_u8(image):
+        N = _u8_frames(image).shape[0]
+        rs, pf = _per_frame(rotation, N)
+        cs = [(w // 2, h // 2)] if center is None else ([tuple(center)] if isinstance(center[0], (int, float)) else [tuple(c) for c in center])
+        if len(cs) > 1 or pf:
+            if len(cs) not in (1, N):
+                raise ValueError(f"faceoff_amd: {len(cs)} rotation centres for {N} frames")
+            rs, cs, pf = (rs * N if not pf else rs), (cs * N if len(cs) == 1 else cs), 1
+        return _warp_u8(image, [rotation_matrix((_f32(c[0]), _f32(c[1])), r) for r, c in zip(rs, cs)], pf)     # center is a cv::Point2f
     return _warp(image, rotation_matrix((w // 2, h // 2) if center is None else center, rotation))
 
 
 def resize_image(magnification, image):
     """:87-105: cv2.resize(fx = fy = magnification, INTER_CUBIC) then centre crop (zoom in) or centre paste onto zeros (zoom
-    out), as ONE bicubic warp: resized pixel u samples source (u + 0.5) / m - 0.5, and the crop / paste is an integer shift."""
+    out), as ONE bicubic warp: resized pixel u samples source (u + 0.5) / m - 0.5, and the crop / paste is an integer shift.
+    uint8 frames: OpenCV's fixed-point cubic resize + the crop / paste in one launch (fo_resize_center_u8)."""
+    if _is_u8(image):
+        x = _u8_frames(image)
+        N, H, W, Cc = x.shape
+        ms, pf = _per_frame(magnification, N)
+        out = torch.empty_like(x)
+        _lib.call("fo_resize_center_u8", ops._ptr(x), ops._ptr(out), N, H, W, Cc, (C.c_double * len(ms))(*[float(v) for v in ms]), pf, ops._stream())
+        return out if image.dim() == 4 else out[0]
     h, w = image.shape[-2:]
     m = float(magnification)
     ws, hs = int(round(w * m)), int(round(h * m))            # cv2.resize output size: saturate_cast<int>(size * f) = round
@@ -78,6 +147,36 @@ def resize_image(magnification, image):
     mask = torch.zeros((h, w), device=out.device)
     mask[off_y:off_y + hs, off_x:off_x + ws] = 1.0
     return out * mask
+
+
+def shear_image(shear, image):
+    """:110-119 (not in the reference's active lists): M = np.float32([[1, shear, 0], [shear, 1, 0]])."""
+    if _is_u8(image):
+        vs, pf = _per_frame(shear, _u8_frames(image).shape[0])
+        return _warp_u8(image, [(1, _f32(v), 0, _f32(v), 1, 0) for v in vs], pf)
+    return _warp(image, (1, shear, 0, shear, 1, 0))
+
+
+def image_flip(flip_code, image):
+    """:124-126 cv2.flip(image, int(flip_code)): 0 = rows reversed, > 0 = columns reversed, < 0 both."""
+    code = int(flip_code)
+    if _is_u8(image):
+        x = _u8_frames(image)
+        N, H, W, Cc = x.shape
+        out = torch.empty_like(x)
+        _lib.call("fo_flip_u8", ops._ptr(x), ops._ptr(out), N, H, W, Cc, code, ops._stream())
+        return out if image.dim() == 4 else out[0]
+    return torch.flip(image, [-2] if code == 0 else [-1] if code > 0 else [-2, -1])
+
+
+def to_normalized(frames_u8, mean=0.5, std=0.5, reverse_channels=False):
+    """transforms.ToTensor() + transforms.Normalize((mean,) * C, (std,) * C) (TemporalAlignment/dataset.py:244-256) on a stack of
+    uint8 frames [N,H,W,C] -> float32 [N,C,H,W]; reverse_channels: BGR (cv2.imread) -> RGB."""
+    x = _u8_frames(frames_u8)
+    N, H, W, Cc = x.shape
+    out = torch.empty((N, Cc, H, W), device=x.device, dtype=torch.float32)
+    _lib.call("fo_u8_to_norm_nchw", ops._ptr(x), ops._ptr(out), N, H, W, Cc, int(bool(reverse_channels)), float(mean), float(std), ops._stream())
+    return out if frames_u8.dim() == 4 else out[0]
 
 
 def perturb_image(face_image, rng=None):

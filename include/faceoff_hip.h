@@ -288,6 +288,20 @@ int fo_w42_wgrad_out(const float* dU /* [25][O][4 I] */, float* dW, int O, int I
  * (TemporalAlignment/perturbations.py:45-83) -- zero outside the image; mode 0 = bilinear, 1 = bicubic (A = -0.75, the
  * INTER_CUBIC kernel of cv2.resize, :88).  Exact arithmetic: OpenCV's 1/32-pixel coordinate quantisation is not reproduced. */
 int fo_affine_warp(const float* src, float* dst, int N, int C, int H, int W, const float* M_dst_to_src, int mode, void* stream);
+/* The same perturbations on 8-bit frames [N][H][W][C] (C <= 4, the layout cv2 hands the reference), with OpenCV 4.6.0's own
+ * fixed-point arithmetic (opencv-python==4.6.0.66, environment.yml:70; csrc/warp_u8.hip restates imgwarp.cpp / resize.cpp):
+ *   fo_warp_affine_u8    cv2.warpAffine(image, M, (w, h)) -- perturbations.py:51 :63 :80 :117.  M_fwd: HOST pointer to the 2x3
+ *                        FORWARD map(s) as doubles ([6], or [N][6] with per_frame != 0), inverted here as cv::warpAffine does;
+ *                        1/32-pixel source coordinates, 15-bit bilinear weights, BORDER_CONSTANT 0.
+ *   fo_resize_center_u8  resize_image (:87-105): cv2.resize(fx = fy = m, INTER_CUBIC) followed by the centre crop (m >= 1) or the
+ *                        centre paste onto zeros (m < 1), one launch.  magnification: HOST pointer, [1] or [N].
+ *   fo_flip_u8           cv2.flip(image, flip_code) (:125): 0 rows reversed, > 0 columns reversed, < 0 both.
+ *   fo_u8_to_norm_nchw   transforms.ToTensor() + transforms.Normalize((mean,)*C, (std,)*C) (TemporalAlignment/dataset.py:244-256):
+ *                        dst[n][c][y][x] = (float(src[n][y][x][c']) / 255 - mean) / std, c' = C-1-c with reverse_channels (BGR -> RGB). */
+int fo_warp_affine_u8(const uint8_t* src, uint8_t* dst, int N, int H, int W, int C, const double* M_fwd, int per_frame, void* stream);
+int fo_resize_center_u8(const uint8_t* src, uint8_t* dst, int N, int H, int W, int C, const double* magnification, int per_frame, void* stream);
+int fo_flip_u8(const uint8_t* src, uint8_t* dst, int N, int H, int W, int C, int flip_code, void* stream);
+int fo_u8_to_norm_nchw(const uint8_t* src, float* dst, int N, int H, int W, int C, int reverse_channels, float mean, float stdv, void* stream);
 /* out[n][y][x][3] uint8 = (uint8)(255 * (clamp(v, -1, 1) + 1) / 2) of channels c0..c0+2: `denormalize` + the uint8 cast of
  * the validation videos (train_faceoff_perceptual.py:71-77, utils.py:9-17).  src: [N][C][H][W] (ld = 0) or channels-last with
  * pixel stride ld (C unused).  bgr != 0 swaps to BGR (cv2.cvtColor(..., COLOR_RGB2BGR)). */

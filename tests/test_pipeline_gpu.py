@@ -91,3 +91,93 @@ def test_metric_accumulator_matches_the_trainer_average():
     for v, s in vals:
         m.update(torch.tensor([v], device="cuda"), s)
     assert math.isclose(m.average(), sum(v * s for v, s in vals) / sum(s for _, s in vals), rel_tol=1e-6)
+
+
+def _u8(shape, seed):
+    return np.random.default_rng(seed).integers(0, 256, shape, dtype=np.uint8)
+
+
+def test_u8_perturbations_equal_the_opencv_restatement_bit_for_bit():
+    """uint8 frames [N,H,W,C] through csrc/warp_u8.hip against oracle/cv2_oracle.py (OpenCV 4.6.0's 8-bit warpAffine / resize /
+    flip restated): every byte equal.  Covers the reference's parameter ranges (perturbations.py:271-295 and ranges.py), fractional and
+    out-of-image translations, shear, every magnification 0.90 ... 1.10 and a few outside, 1 / 3 / 4 channels, odd sizes."""
+    from faceoff_amd import perturbations as P
+    from oracle import cv2_oracle as O
+    for shape, seed in (((2, 40, 56, 3), 0), ((1, 33, 47, 4), 1), ((2, 64, 48, 1), 2)):
+        x = _u8(shape, seed)
+        xg = torch.from_numpy(x).cuda()
+        N, H, W, _ = shape
+
+        def same(got, fn):
+            got = got.cpu().numpy()
+            for n in range(N):
+                want = fn(x[n] if shape[3] > 1 else x[n, ..., 0])
+                assert np.array_equal(got[n] if shape[3] > 1 else got[n, ..., 0], want), (shape, n)
+
+        for t in (-20, -3, 0, 1, 3, 20, 0.5, -7.3, W + 5, -(W + 5)):
+            same(P.translate_horizontal(t, xg), lambda im: O.translate_horizontal(t, im))
+            same(P.translate_vertical(t, xg), lambda im: O.translate_vertical(t, im))
+        for angle in (-25, -3, -1, 0, 1, 2, 3, 7, 25, 45, 90, 180, 33.3):
+            same(P.rotate_image(angle, xg), lambda im: O.rotate_image(angle, im))
+            same(P.rotate_image(angle, xg, center=(20, 17)), lambda im: O.rotate_image(angle, im, center=(20, 17)))
+            same(P.rotate_image(angle, xg, center=(20.5, 17.25)), lambda im: O.rotate_image(angle, im, center=(20.5, 17.25)))
+        for sh in (-0.1, 0.05, 0.1):
+            same(P.shear_image(sh, xg), lambda im: O.shear_image(sh, im))
+        for k in list(range(90, 111)) + [50, 75, 150, 200]:
+            same(P.resize_image(k / 100, xg), lambda im: O.resize_image(k / 100, im))
+        for code in (0, 1, -1):
+            same(P.image_flip(code, xg), lambda im: O.image_flip(code, im))
+    # a single [H,W,C] image
+    x = _u8((40, 56, 3), 9)
+    assert np.array_equal(P.rotate_image(5, torch.from_numpy(x).cuda()).cpu().numpy(), O.rotate_image(5, x))
+
+
+def test_u8_perturbations_per_frame_parameters_at_full_size():
+    """a loader batch of 160 frames 256x256x3 (BASELINE configs[1]: bs 32 x T 5), one parameter per frame as the reference draws
+    them (TemporalAlignment/dataset.py:34-54): more frames than one launch carries, checked on sampled frames."""
+    from faceoff_amd import perturbations as P
+    from oracle import cv2_oracle as O
+    N = 160
+    x = _u8((N, 256, 256, 3), 11)
+    xg = torch.from_numpy(x).cuda()
+    r = random.Random(5)
+    tx = [r.randint(-20, 20) for _ in range(N)]
+    rot = [r.randint(-25, 25) for _ in range(N)]
+    mag = [r.randint(90, 110) / 100 for _ in range(N)]
+    centers = [(r.randint(100, 150), r.randint(90, 140)) for _ in range(N)]
+    a = P.translate_horizontal(tx, xg).cpu().numpy()
+    b = P.rotate_image(rot, xg, center=centers).cpu().numpy()
+    c = P.resize_image(mag, xg).cpu().numpy()
+    for n in (0, 15, 16, 63, 64, 65, 127, 128, 159):
+        assert np.array_equal(a[n], O.translate_horizontal(tx[n], x[n]))
+        assert np.array_equal(b[n], O.rotate_image(rot[n], x[n], center=centers[n]))
+        assert np.array_equal(c[n], O.resize_image(mag[n], x[n]))
+    with pytest.raises(ValueError):
+        P.translate_horizontal([1, 2, 3], xg)
+    # the composite on uint8 frames: same draws as on float frames, applied with the OpenCV arithmetic
+    r1, r2 = random.Random(3), random.Random(3)
+    out, gt = P.perturb_image_composite(xg[:5], (128, 110), rng=r1)
+    want = x[:5]
+    chosen = []
+    while not chosen:
+        chosen = [i for i in range(4) if r2.randint(0, 1)]
+    fns = [O.translate_horizontal, O.translate_vertical, O.rotate_image, O.resize_image]
+    ranges = [(-3, 3, 1), (-3, 3, 1), (-3, 3, 1), (90, 110, 100)]
+    for i in chosen:
+        v = r2.randint(ranges[i][0], ranges[i][1]) / ranges[i][2]
+        want = np.stack([fns[i](v, f, center=(128, 110)) if i == 2 else fns[i](v, f) for f in want])
+    assert np.array_equal(out.cpu().numpy(), want)
+
+
+def test_u8_frames_to_normalised_tensors():
+    """ToTensor + Normalize (TemporalAlignment/dataset.py:244-256): float(v) / 255, then (t - 0.5) / 0.5, bit for bit."""
+    from faceoff_amd import perturbations as P
+    x = _u8((3, 24, 40, 3), 12)
+    xg = torch.from_numpy(x).cuda()
+    t = torch.from_numpy(x).permute(0, 3, 1, 2).to(torch.float32).div(255)
+    want = t.sub(torch.tensor(0.5)).div(torch.tensor(0.5))
+    assert torch.equal(P.to_normalized(xg).cpu(), want)
+    assert torch.equal(P.to_normalized(xg, reverse_channels=True).cpu(), want.flip(1))
+    m, s = 0.485, 0.229
+    want = t.sub(torch.tensor(m)).div(torch.tensor(s))
+    assert torch.equal(P.to_normalized(xg, mean=m, std=s).cpu(), want)
