@@ -216,7 +216,9 @@ class DiscEngine:
             # the 1-channel head is written into a zeroed 32-float pixel
             # few output tiles behind a long contraction -- the 1-channel head (192 tiles x 1024 K-steps) and the 256 -> 512 layer (292 tiles
             # of a 16 384-deep contraction on 512 workgroup slots: one round, 57 % full) --: the launch may slice K (y is zeroed for it)
-            ksplit = (co < 32 or j >= 3) and not _os.environ.get("FACEOFF_NO_DISC_KSPLIT")
+            # (and every other layer whose output is fewer than 1024 tiles: the epilogue is bias only, InstanceNorm is its own launch)
+            few_tiles = (N * dd[0] * dd[1] * dd[2] + 63) // 64 * ((co + 63) // 64) < 1024
+            ksplit = (co < 32 or j >= 3 or few_tiles) and not _os.environ.get("FACEOFF_NO_DISC_KSPLIT")
             y = (torch.zeros if ksplit else torch.empty)((N,) + dd + (ld_out,), device=self.device)
             flags = FO_BIAS | (FO_OUT_LRELU if j == 0 else 0) | (FO_KSPLIT if ksplit else 0)
             d = self._desc(N, sd, cin, h.shape[-1], dd, co, ld_out, s, flags)
