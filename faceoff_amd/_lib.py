@@ -160,7 +160,8 @@ SIGNATURES.update({
     "fo_disc_head_dgrad": (_I, [_ND, _P, _P, _P, _P]),
     "fo_disc_head_wgrad_ws_bytes": (_L, [_ND]),
     "fo_disc_head_wgrad": (_I, [_ND, _P, _P, _P, _I, _P, _L, _P]),
-    "fo_wgradnd": (_I, [_ND, _P, _P, _P, _I, _P]),
+    "fo_wgradnd_ws_bytes": (C.c_int64, [_ND]),
+    "fo_wgradnd": (_I, [_ND, _P, _P, _P, _I, _P, C.c_int64, _P]),
     "fo_instnorm_lrelu_fwd": (_I, [_P, _I, _P, _I, _L, _I, _F, _F, _P, _P, _F, _I, _P]),
     "fo_instnorm_lrelu_bwd": (_I, [_P, _I, _P, _I, _P, _P, _I, _L, _I, _F, _P]),
     "fo_instnorm_lrelu_fwd_batch": (_I, [_P, _I, _P, _I, _I, _L, _I, _F, _F, _P, _P, _P, _F, _I, _P]),

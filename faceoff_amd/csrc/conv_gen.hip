@@ -258,6 +258,7 @@ struct WgArgs {
   const float* g;       // [M][ldD]   (M = N*Dd*Hd*Wd)
   const float* src;
   float* dw;            // [Cd][CsReal][taps]
+  float* ws;            // splits > 1: [split][tap][tilesCo*64][tilesCi*64] partial sums (combined by wgrad_gen_reduce_kernel)
   int M, taps, tilesCo, tilesCi, splits, CsReal;
   unsigned srcBytes, gBytes;
   int margin;
@@ -342,11 +343,24 @@ __global__ __launch_bounds__(256, 2) void wgrad_gen_kernel(const WgArgs a) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int co = tco * 64 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-    if (co < d.Cd && ci < a.CsReal) {
-      float* o = a.dw + ((size_t)co * a.CsReal + ci) * a.taps + tap;
-      if (a.splits > 1) atomicAdd(o, acc[r]);
-      else *o = acc[r];
-    }
+    if (a.splits > 1) a.ws[(((size_t)split * a.taps + tap) * (a.tilesCo * 64) + co) * (a.tilesCi * 64) + ci] = acc[r];
+    else if (co < d.Cd && ci < a.CsReal) a.dw[((size_t)co * a.CsReal + ci) * a.taps + tap] = acc[r];
+  }
+}
+
+// dw[co][ci][tap] = sum over the row slices, in slice order (bit-reproducible); one thread per (tap, co, ci), ci fastest
+__global__ void wgrad_gen_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int splits, int taps, int CoP, int CiP, int Cd,
+                                        int CsReal) {
+  const size_t total = (size_t)taps * Cd * CsReal;
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int ci = (int)(e % CsReal);
+    const int co = (int)((e / CsReal) % Cd);
+    const int tap = (int)(e / ((size_t)CsReal * Cd));
+    const float* p = ws + ((size_t)tap * CoP + co) * CiP + ci;
+    const size_t stride = (size_t)taps * CoP * CiP;
+    float sum = 0.f;
+    for (int sidx = 0; sidx < splits; ++sidx) sum += p[sidx * stride];
+    dw[((size_t)co * CsReal + ci) * taps + tap] = sum;
   }
 }
 
@@ -436,8 +450,8 @@ int fo_convnd(const fo_convnd_desc* d, int transposed, const float* src, const f
 }
 
 // dw [Cd][CsReal][taps] = filter gradient of the forward conv described by d (src = the conv's input with Cs >= CsReal
-// padded channels, g = output gradient [N*Dd*Hd*Wd][ldD]).  dw must be ZERO on entry when fo_wgradnd_splits(d) > 1
-// (row slices are combined with float atomics).
+// padded channels, g = output gradient [N*Dd*Hd*Wd][ldD]).  With fo_wgradnd_splits(d) > 1 the row slices leave their partial
+// sums in ws (fo_wgradnd_ws_bytes) and a second launch adds them in slice order.
 int fo_wgradnd_splits(const fo_convnd_desc* d) {
   if (check_desc(d)) return -1;
   const long long M = (long long)d->N * d->Dd * d->Hd * d->Wd;
@@ -447,7 +461,13 @@ int fo_wgradnd_splits(const fo_convnd_desc* d) {
   return (int)s;
 }
 
-int fo_wgradnd(const fo_convnd_desc* d, const float* g, const float* src, float* dw, int CsReal, void* stream) {
+int64_t fo_wgradnd_ws_bytes(const fo_convnd_desc* d) {
+  const int s = fo_wgradnd_splits(d);
+  if (s <= 1) return 0;
+  return (int64_t)s * d->KD * d->KH * d->KW * ((d->Cd + 63) / 64 * 64) * ((d->Cs + 63) / 64 * 64) * 4;
+}
+
+int fo_wgradnd(const fo_convnd_desc* d, const float* g, const float* src, float* dw, int CsReal, float* ws, int64_t ws_bytes, void* stream) {
   if (int rc = check_desc(d)) return rc;
   FO_REQUIRE(g && src && dw && fo_aligned16(g) && fo_aligned16(src) && d->ldD % 4 == 0, FO_E_ALIGN, "wgradnd: pointers / ldD %% 4");
   FO_REQUIRE(CsReal > 0 && CsReal <= d->Cs, FO_E_SHAPE, "wgradnd: CsReal");
@@ -460,6 +480,8 @@ int fo_wgradnd(const fo_convnd_desc* d, const float* g, const float* src, float*
   a.tilesCo = (d->Cd + 63) / 64;
   a.tilesCi = (d->Cs + 63) / 64;
   a.splits = fo_wgradnd_splits(d);
+  a.ws = ws;
+  FO_REQUIRE(a.splits == 1 || (ws && ws_bytes >= fo_wgradnd_ws_bytes(d)), FO_E_SHAPE, "wgradnd: workspace too small (fo_wgradnd_ws_bytes)");
   const unsigned long long srcBytes = (((unsigned long long)d->N * d->Ds * d->Hs * d->Ws - 1) * d->ldS + d->Cs) * 4ull;
   const unsigned long long gBytes = (((unsigned long long)M - 1) * d->ldD + (unsigned long long)((d->Cd + 3) / 4 * 4)) * 4ull;
   FO_REQUIRE(srcBytes < (1ull << 31) && gBytes < (1ull << 31), FO_E_SHAPE, "wgradnd: tensor exceeds the 2 GiB window");
@@ -467,6 +489,12 @@ int fo_wgradnd(const fo_convnd_desc* d, const float* g, const float* src, float*
   const long long grid = (long long)a.taps * a.tilesCo * a.tilesCi * a.splits;
   hipLaunchKernelGGL(wgrad_gen_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
   FO_CHECK_LAUNCH();
+  if (a.splits > 1) {
+    const size_t total = (size_t)a.taps * d->Cd * CsReal;
+    hipLaunchKernelGGL(wgrad_gen_reduce_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream, ws, dw,
+                       a.splits, a.taps, a.tilesCo * 64, a.tilesCi * 64, d->Cd, CsReal);
+    FO_CHECK_LAUNCH();
+  }
   return FO_OK;
 }
 }

@@ -265,6 +265,11 @@ class DiscEngine:
     def _head_ok(co, stride, cin):
         return co == 1 and stride == 1 and cin in (256, 512) and not _os.environ.get("FACEOFF_NO_DISC_HEAD")
 
+    @staticmethod
+    def _wgradnd(d, g, src, dw, cs_real):
+        ws = ops._workspace(_lib.load().fo_wgradnd_ws_bytes(C.byref(d)), g.device)
+        _lib.call("fo_wgradnd", C.byref(d), ops._ptr(g), ops._ptr(src), ops._ptr(dw), cs_real, ops._ptr(ws), C.c_int64(ws.numel() * 4), ops._stream())
+
     def _wgrad(self, d, g, src, key, cs_real):
         dw = self.grads[key + ".0.weight"]
         if self._head_ok(d.Cd, d.sH, d.Cs):
@@ -273,9 +278,7 @@ class DiscEngine:
             rows = g.numel() // g.shape[-1]
             ops.bias_grad(g.view(rows, 1, 1, g.shape[-1]), self.grads[key + ".0.bias"], d.Cd)
             return
-        if _lib.load().fo_wgradnd_splits(C.byref(d)) > 1:
-            ops.zero_(dw.view(-1))
-        _lib.call("fo_wgradnd", C.byref(d), ops._ptr(g), ops._ptr(src), ops._ptr(dw), cs_real, ops._stream())
+        self._wgradnd(d, g, src, dw, cs_real)
         rows = g.numel() // g.shape[-1]
         ops.bias_grad(g.view(rows, 1, 1, g.shape[-1]), self.grads[key + ".0.bias"], d.Cd)
 
@@ -301,8 +304,8 @@ class DiscEngine:
                 ph = 8 if self.dims == 3 else 4
                 if param_grads:
                     d = self._desc0(N, sd, cin_pad, cin_pad, dd, co, g.shape[-1])
-                    dw2 = torch.zeros_like(self._w2[key + ".0.weight"])
-                    _lib.call("fo_wgradnd", C.byref(d), ops._ptr(g), ops._ptr(x_in), ops._ptr(dw2), ph * self.nc, ops._stream())
+                    dw2 = torch.empty_like(self._w2[key + ".0.weight"])
+                    self._wgradnd(d, g, x_in, dw2, ph * self.nc)
                     _lib.call("fo_s2d_filter", ops._ptr(self.grads[key + ".0.weight"]), ops._ptr(dw2), co, self.nc,
                               K if self.dims == 3 else 1, 1, ops._stream())
                     rows = g.numel() // g.shape[-1]

@@ -336,9 +336,12 @@ int fo_pack_convnd(const float* w, float* wp, int O, int I, int taps, int transp
 int fo_convnd(const fo_convnd_desc* d, int transposed, const float* src, const float* wp, const float* bias, const float* mask,
               float* dst, void* stream);
 /* dw[Cd][CsReal][taps] = sum over output positions of g (x) src for the FORWARD conv d (g on the destination grid).
- * Row slices are combined with float atomics when fo_wgradnd_splits(d) > 1: dw must then be zero on entry. */
+ * Rows (and, for a depth tap, only the frames whose input is not padding) are the contraction index; when the layer needs
+ * fo_wgradnd_splits(d) > 1 row slices to fill the chip, the slices leave partial sums in ws (>= fo_wgradnd_ws_bytes(d), 0
+ * otherwise) and a second launch adds them in slice order: no atomics, bit-reproducible. */
 int fo_wgradnd_splits(const fo_convnd_desc* d);
-int fo_wgradnd(const fo_convnd_desc* d, const float* g, const float* src, float* dw, int CsReal, void* stream);
+int64_t fo_wgradnd_ws_bytes(const fo_convnd_desc* d);
+int fo_wgradnd(const fo_convnd_desc* d, const float* g, const float* src, float* dw, int CsReal, float* ws, int64_t ws_bytes, void* stream);
 /* InstanceNorm(affine=False) over the `rows` positions of one sample, per channel, then LeakyReLU:
  *   y = lrelu((x - mean_c) * rstd_c), biased variance, eps inside the sqrt.  stats = [mean(C) | rstd(C)] (kept for backward);
  * running (may be NULL) = [running_mean(C) | running_var(C)], updated with `momentum` and the UNBIASED variance, as

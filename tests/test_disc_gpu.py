@@ -99,7 +99,9 @@ def test_discriminator_engine_vs_reference_golden(golden_dir, tag, dims):
 
 
 @pytest.mark.parametrize("dims,N,Cin,Cout,size,stride", [(3, 2, 32, 64, (5, 9, 11), 2), (3, 1, 64, 128, (4, 10, 7), 1), (2, 2, 96, 64, (1, 13, 12), 2),
-                                                         (3, 1, 64, 1, (3, 6, 6), 1), (2, 1, 32, 200, (1, 17, 9), 1)])
+                                                         (3, 1, 64, 1, (3, 6, 6), 1), (2, 1, 32, 200, (1, 17, 9), 1),
+                                                         # enough rows for the filter gradient to run as row slices + the reduce launch
+                                                         (2, 2, 32, 64, (1, 40, 44), 1), (3, 1, 32, 64, (3, 20, 20), 1), (3, 2, 32, 64, (8, 21, 23), 2)])
 def test_convnd_forward_transposed_and_wgrad_vs_torch(dims, N, Cin, Cout, size, stride):
     """fo_convnd forward / transposed (gather data gradient, phase-major rows) / fo_wgradnd against torch-CPU conv k4 p2."""
     from faceoff_amd import _lib, ops
@@ -145,10 +147,15 @@ def test_convnd_forward_transposed_and_wgrad_vs_torch(dims, N, Cin, Cout, size, 
     # filter gradient
     d.flags = 0
     d.ldD = cs
-    dw = torch.zeros((Cout, Cin, taps), device="cuda")
-    _lib.call("fo_wgradnd", C.byref(d), ops._ptr(gc), ops._ptr(xc), ops._ptr(dw), Cin, ops._stream())
+    dw = torch.full((Cout, Cin, taps), 7.0, device="cuda")          # (overwritten, not accumulated into)
+    ws = ops._workspace(_lib.load().fo_wgradnd_ws_bytes(C.byref(d)), dw.device)
+    args = (C.byref(d), ops._ptr(gc), ops._ptr(xc), ops._ptr(dw), Cin, ops._ptr(ws), C.c_int64(ws.numel() * 4), ops._stream())
+    _lib.call("fo_wgradnd", *args)
     want = wr.grad.reshape(Cout, Cin, taps)
     assert (dw.cpu() - want).abs().max().item() <= 5e-5 * want.abs().max().item()
+    first = dw.clone()
+    _lib.call("fo_wgradnd", *args)                                   # row slices are added in slice order: bit-reproducible
+    assert torch.equal(first, dw)
 
 
 @pytest.mark.parametrize("dims,N,Cin,size", [(3, 2, 512, (3, 9, 11)), (2, 2, 512, (1, 13, 12)), (3, 1, 256, (4, 6, 7)), (2, 3, 256, (1, 5, 18))])

@@ -41,7 +41,9 @@ for scale, (D, H, W) in enumerate([(15, 256, 256), (15, 128, 128)]):
         flop = 2.0 * N * Do * Ho * Wo * co * cin_real * 64
         t_f = timeit(lambda: _lib.call("fo_convnd", C.byref(d), 0, ops._ptr(x), ops._ptr(wp), None, None, ops._ptr(y), ops._stream()))
         t_d = timeit(lambda: _lib.call("fo_convnd", C.byref(dt), 1, ops._ptr(g), ops._ptr(wpt), None, None, ops._ptr(gin), ops._stream()))
-        t_w = timeit(lambda: _lib.call("fo_wgradnd", C.byref(d), ops._ptr(g), ops._ptr(x), ops._ptr(dw), cin_real, ops._stream()))
+        ws = ops._workspace(_lib.load().fo_wgradnd_ws_bytes(C.byref(d)), dw.device)
+        t_w = timeit(lambda: _lib.call("fo_wgradnd", C.byref(d), ops._ptr(g), ops._ptr(x), ops._ptr(dw), cin_real, ops._ptr(ws), C.c_int64(ws.numel() * 4),
+                                       ops._stream()))
         tot += t_f + t_d + t_w
         print(f"scale {scale} layer {j}: {cin_real:3d}->{co:3d} s{s} out {Do}x{Ho}x{Wo}  {flop / 1e9:7.1f} GFLOP   fwd {t_f:7.3f} ms ({flop / t_f / 1e9:6.1f} TF)   "
               f"dgrad {t_d:7.3f} ms ({flop / t_d / 1e9:6.1f} TF)   wgrad {t_w:7.3f} ms ({flop / t_w / 1e9:6.1f} TF)")
