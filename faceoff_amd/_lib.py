@@ -154,7 +154,8 @@ _ND = C.POINTER(ConvNdDesc)
 FO_OUT_LRELU, FO_MASK_LRELU, FO_KSPLIT = 64, 128, 256
 SIGNATURES.update({
     "fo_pack_convnd": (_I, [_P, _P, _I, _I, _I, _I, _P]),
-    "fo_convnd": (_I, [_ND, _I, _P, _P, _P, _P, _P, _P]),
+    "fo_convnd_ws_bytes": (C.c_int64, [_ND, _I]),
+    "fo_convnd": (_I, [_ND, _I, _P, _P, _P, _P, _P, _P, C.c_int64, _P]),
     "fo_wgradnd_splits": (_I, [_ND]),
     "fo_disc_head_fwd": (_I, [_ND, _P, _P, _P, _P, _P]),
     "fo_disc_head_dgrad": (_I, [_ND, _P, _P, _P, _P]),

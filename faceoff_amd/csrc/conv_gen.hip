@@ -36,7 +36,9 @@ struct GenArgs {
   int tilesPerPhase, tilesN, taps;
   unsigned srcBytes, wpBytes;
   int margin;
-  int ksplit;           // > 1: the K-steps of a tile are cut into this many slices, one workgroup each, combined with float atomics
+  int ksplit;           // > 1: the K-steps of a tile are cut into this many slices, one workgroup each; the slices leave their 64 x 64
+                        // partial tiles in ws and conv_gen_reduce_kernel adds them in slice order (+ the epilogue)
+  float* ws;            // [slice][tile][64][64]
 };
 
 __device__ __forceinline__ f32x4 bufload(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
@@ -233,21 +235,64 @@ __global__ __launch_bounds__(256, 2) void conv_gen_kernel(const GenArgs a) {
   }
 
   // ---- epilogue: register r of the accumulator = tile row (r&3) + 8(r>>2) + 4*half, column l31 (32 consecutive channels)
+  if (a.ksplit > 1) {
+    float* t = a.ws + ((size_t)slice * gridDim.x / a.ksplit + blockIdx.x / a.ksplit) * (BM * BN) + wn * 32 + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * BN] = acc[r];
+    return;
+  }
   const int co = tile_n * BN + wn * 32 + l31;
   if (co >= d.Cd) return;
-  const float bv = ((d.flags & FO_BIAS) && slice == 0) ? a.bias[co] : 0.f;
+  const float bv = (d.flags & FO_BIAS) ? a.bias[co] : 0.f;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
     const long long pix = rowdst[row];
     if (pix < 0) continue;
     float v = acc[r] + bv;
-    if (a.ksplit > 1) { atomicAdd(a.dst + pix * d.ldD + co, v); continue; }   // dst was zeroed by the caller
     if (d.flags & FO_OUT_LRELU) v = v > 0.f ? v : v * d.slope;
     if (d.flags & FO_MASK_LRELU) v = a.mask[pix * d.ldMask + co] > 0.f ? v : v * d.slope;
     float* o = a.dst + pix * d.ldD + co;
     if (d.flags & FO_ADD) v += *o;
     *o = v;
+  }
+}
+
+// K-sliced launches: dst = epilogue(sum over the slices of a tile, in slice order).  One thread per (tile row, 4 columns).
+__global__ void conv_gen_reduce_kernel(const GenArgs a, long long ntiles) {
+  const fo_convnd_desc& d = a.d;
+  const long long total = ntiles * (BM * BN / 4);
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(e % (BN / 4)), r = (int)((e / (BN / 4)) % BM);
+    const long long tile = e / (BM * BN / 4);
+    const int tile_n = (int)(tile % a.tilesN), tile_m = (int)(tile / a.tilesN);
+    const int phase = tile_m / a.tilesPerPhase, mt = tile_m - phase * a.tilesPerPhase;
+    int m = mt * BM + r;
+    if (m >= a.rowsPerPhase) continue;
+    const int qw = m % a.Wq; m /= a.Wq;
+    const int qh = m % a.Hq; m /= a.Hq;
+    const int qd = m % a.Dq; const int n = m / a.Dq;
+    int dd = qd, dh = qh, dw = qw;
+    if (a.transposed) { dw = qw * d.sW + phase % d.sW; dh = qh * d.sH + (phase / d.sW) % d.sH; dd = qd * d.sD + phase / (d.sW * d.sH); }
+    if (dd >= d.Dd || dh >= d.Hd || dw >= d.Wd) continue;
+    const long long pix = (((long long)n * d.Dd + dd) * d.Hd + dh) * d.Wd + dw;
+    const float* p = a.ws + (size_t)tile * (BM * BN) + r * BN + c4 * 4;
+    f32x4 sum = *reinterpret_cast<const f32x4*>(p);
+    for (int sl = 1; sl < a.ksplit; ++sl) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(p + (size_t)sl * ntiles * (BM * BN));
+      sum[0] += t[0]; sum[1] += t[1]; sum[2] += t[2]; sum[3] += t[3];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int co = tile_n * BN + c4 * 4 + k;
+      if (co >= d.Cd) continue;
+      float v = sum[k] + ((d.flags & FO_BIAS) ? a.bias[co] : 0.f);
+      if (d.flags & FO_OUT_LRELU) v = v > 0.f ? v : v * d.slope;
+      if (d.flags & FO_MASK_LRELU) v = a.mask[pix * d.ldMask + co] > 0.f ? v : v * d.slope;
+      float* o = a.dst + pix * d.ldD + co;
+      if (d.flags & FO_ADD) v += *o;
+      *o = v;
+    }
   }
 }
 
@@ -401,17 +446,8 @@ int fo_pack_convnd(const float* w, float* wp, int O, int I, int taps, int transp
   return FO_OK;
 }
 
-// forward (transposed = 0): src = input, dst = output.  transposed = 1: src = output gradient (on the conv's OUTPUT grid,
-// Cs = the conv's Cout), dst = input gradient (on the conv's INPUT grid, Cd = the conv's Cin); K*, s*, p* are the CONV's.
-int fo_convnd(const fo_convnd_desc* d, int transposed, const float* src, const float* wp, const float* bias, const float* mask,
-              float* dst, void* stream) {
-  if (int rc = check_desc(d)) return rc;
-  FO_REQUIRE(src && wp && dst && fo_aligned16(src) && fo_aligned16(wp), FO_E_ALIGN, "convnd: pointers");
-  FO_REQUIRE(!(d->flags & FO_BIAS) || bias, FO_E_SHAPE, "convnd: FO_BIAS without bias");
-  FO_REQUIRE(!(d->flags & FO_MASK_LRELU) || (mask && d->ldMask >= d->Cd), FO_E_SHAPE, "convnd: FO_MASK_LRELU without mask");
-  FO_REQUIRE(!(d->flags & ~(FO_BIAS | FO_OUT_LRELU | FO_MASK_LRELU | FO_ADD | FO_KSPLIT)), FO_E_SHAPE, "convnd: unsupported flag");
-  GenArgs a;
-  a.d = *d; a.src = src; a.wp = wp; a.bias = bias; a.mask = mask; a.dst = dst; a.transposed = transposed;
+// tiles and K-slices of a launch: fills the grid members of `a`, returns the number of 64 x 64 tiles
+static long long plan_convnd(const fo_convnd_desc* d, int transposed, GenArgs& a) {
   a.taps = d->KD * d->KH * d->KW;
   int phases = 1;
   if (transposed) {
@@ -419,10 +455,46 @@ int fo_convnd(const fo_convnd_desc* d, int transposed, const float* src, const f
     phases = d->sD * d->sH * d->sW;
   } else { a.Dq = d->Dd; a.Hq = d->Hd; a.Wq = d->Wd; }
   const long long rows = (long long)d->N * a.Dq * a.Hq * a.Wq;
-  FO_REQUIRE(rows < (1ll << 30), FO_E_SHAPE, "convnd: too many rows");
+  if (rows >= (1ll << 30)) return -1;
   a.rowsPerPhase = (int)rows;
   a.tilesPerPhase = (a.rowsPerPhase + BM - 1) / BM;
   a.tilesN = (d->Cd + BN - 1) / BN;
+  const long long tiles = (long long)phases * a.tilesPerPhase * a.tilesN;
+  // few tiles but a long contraction (the 256 -> 512 layer: 292 tiles x 512 K-steps): slice K over workgroups
+  a.ksplit = 1;
+  const int steps = a.taps * (d->Cs / 32) / phases;
+  if ((d->flags & FO_KSPLIT) && tiles < 2048 && steps >= 32) {
+    long long k = (2048 + tiles - 1) / tiles;
+    if (k > steps / 16) k = steps / 16;
+    if (k > 1) a.ksplit = (int)k;
+  }
+  return tiles;
+}
+
+// bytes of workspace a launch with FO_KSPLIT in d->flags needs (0: it will not slice)
+int64_t fo_convnd_ws_bytes(const fo_convnd_desc* d, int transposed) {
+  if (check_desc(d)) return -1;
+  GenArgs a;
+  const long long tiles = plan_convnd(d, transposed, a);
+  return (tiles < 0 || a.ksplit == 1) ? 0 : (int64_t)a.ksplit * tiles * BM * BN * 4;
+}
+
+// forward (transposed = 0): src = input, dst = output.  transposed = 1: src = output gradient (on the conv's OUTPUT grid,
+// Cs = the conv's Cout), dst = input gradient (on the conv's INPUT grid, Cd = the conv's Cin); K*, s*, p* are the CONV's.
+int fo_convnd(const fo_convnd_desc* d, int transposed, const float* src, const float* wp, const float* bias, const float* mask,
+              float* dst, float* ws, int64_t ws_bytes, void* stream) {
+  if (int rc = check_desc(d)) return rc;
+  FO_REQUIRE(src && wp && dst && fo_aligned16(src) && fo_aligned16(wp), FO_E_ALIGN, "convnd: pointers");
+  FO_REQUIRE(!(d->flags & FO_BIAS) || bias, FO_E_SHAPE, "convnd: FO_BIAS without bias");
+  FO_REQUIRE(!(d->flags & FO_MASK_LRELU) || (mask && d->ldMask >= d->Cd), FO_E_SHAPE, "convnd: FO_MASK_LRELU without mask");
+  FO_REQUIRE(!(d->flags & ~(FO_BIAS | FO_OUT_LRELU | FO_MASK_LRELU | FO_ADD | FO_KSPLIT)), FO_E_SHAPE, "convnd: unsupported flag");
+  GenArgs a;
+  a.d = *d; a.src = src; a.wp = wp; a.bias = bias; a.mask = mask; a.dst = dst; a.transposed = transposed;
+  const long long tiles = plan_convnd(d, transposed, a);
+  FO_REQUIRE(tiles >= 0, FO_E_SHAPE, "convnd: too many rows");
+  a.ws = ws;
+  FO_REQUIRE(a.ksplit == 1 || (ws && fo_aligned16(ws) && ws_bytes >= (int64_t)a.ksplit * tiles * BM * BN * 4), FO_E_SHAPE,
+             "convnd: FO_KSPLIT needs a workspace of fo_convnd_ws_bytes");
   const unsigned long long srcBytes = (((unsigned long long)d->N * d->Ds * d->Hs * d->Ws - 1) * d->ldS + d->Cs) * 4ull;
   const unsigned long long wpBytes = (unsigned long long)a.tilesN * BN * a.taps * d->Cs * 4ull;
   // the descriptor starts `margin` bytes below src so that (base coordinate < 0) row offsets stay non-negative
@@ -430,22 +502,15 @@ int fo_convnd(const fo_convnd_desc* d, int transposed, const float* src, const f
                                       : ((((long long)d->pD * d->Hs + d->pH) * d->Ws + d->pW) * d->ldS) * 4ll;
   FO_REQUIRE(srcBytes + (unsigned long long)margin < (1ull << 31) && wpBytes < (1ull << 31), FO_E_SHAPE, "convnd: tensor exceeds the 2 GiB window");
   a.srcBytes = (unsigned)srcBytes; a.wpBytes = (unsigned)wpBytes; a.margin = (int)margin;
-  // few tiles but a long contraction (the 1-channel patch head: 192 tiles x 1024 K-steps): slice K over workgroups
-  a.ksplit = 1;
-  {
-    const long long tiles = (long long)phases * a.tilesPerPhase * a.tilesN;
-    const int steps = a.taps * (d->Cs / 32) / phases;
-    if ((d->flags & FO_KSPLIT) && tiles < 2048 && steps >= 32) {
-      long long k = (2048 + tiles - 1) / tiles;
-      if (k > steps / 16) k = steps / 16;
-      if (k > 1) a.ksplit = (int)k;
-    }
-    FO_REQUIRE(a.ksplit == 1 || !(d->flags & (FO_OUT_LRELU | FO_MASK_LRELU | FO_ADD)), FO_E_SHAPE, "convnd: FO_KSPLIT with a non-linear epilogue");
-  }
-  const long long grid = (long long)phases * a.tilesPerPhase * a.tilesN * a.ksplit;
+  const long long grid = tiles * a.ksplit;
   FO_REQUIRE(grid < (1ll << 31), FO_E_SHAPE, "convnd: grid");
   hipLaunchKernelGGL(conv_gen_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
   FO_CHECK_LAUNCH();
+  if (a.ksplit > 1) {
+    hipLaunchKernelGGL(conv_gen_reduce_kernel, dim3((unsigned)std::min<long long>((tiles * (BM * BN / 4) + 255) / 256, 8192)), dim3(256), 0,
+                       (hipStream_t)stream, a, tiles);
+    FO_CHECK_LAUNCH();
+  }
   return FO_OK;
 }
 

@@ -109,34 +109,73 @@ __global__ __launch_bounds__(512, 1) void vq_assign_kernel(const float* __restri
 }
 
 // EMA statistics (:60-61): counts[c] = #vectors assigned to c, esum[c][:] = sum of those vectors.
-// The reference builds a [Nvec,512] one-hot and runs a second sgemm; here each workgroup keeps a
-// private [512][64] table in LDS (ds_add_f32: a wave adds one vector's 64 dims to 64 consecutive
-// banks, so hot codes cost nothing extra), writes it as a slab, and a second kernel sums the slabs
-// in a fixed order.  No global atomics: a degenerate codebook (all vectors on one code) is as fast
-// as a uniform one.
+// The reference builds a [Nvec,512] one-hot and runs a second sgemm; here each workgroup keeps a private [512][64] table in LDS,
+// writes it as a slab, and a second kernel sums the slabs in a fixed order.  No atomics anywhere and a summation order that depends
+// on the data only -- the codebook update is bit-reproducible run to run:
+//   * the 16 waves stage 64 vectors at a time in LDS (wave w loads rows 4w .. 4w+3; the next two blocks' rows are in flight meanwhile);
+//   * wave w owns the codes c with c % 16 == w: one ballot over the block's 64 indices finds its vectors, a second one per distinct
+//     code gathers that code's vectors, which are summed in vector order in registers (64 dims on the 64 lanes) and added to the
+//     table row once.  A degenerate codebook (every vector on one code) costs 64 LDS reads per block on one wave, not 64 serialised
+//     read-modify-writes.
 __global__ __launch_bounds__(1024, 1) void vq_stats_kernel(const float* __restrict__ x, int ldx, long long nvec,
                                                            const long long* __restrict__ ind, float* __restrict__ ws) {
   __shared__ float tab[VQ_K * VQ_D + VQ_K];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ float stage[64 * VQ_D];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   for (int i = tid; i < VQ_K * VQ_D + VQ_K; i += 1024) tab[i] = 0.f;
-  __syncthreads();
   const long long per = (nvec + gridDim.x - 1) / gridDim.x;
   const long long v0 = blockIdx.x * per, v1 = min(nvec, v0 + per);
-  for (long long v = v0 + wave * 4; v < v1; v += 16 * 4) {
-    float xv[4];
-    int id[4];
+  // rows of the next TWO blocks wait in registers (ra: next block, rb: the one after) while the staged block is consumed
+  float ra[4], rb[4];
+  auto load_rows = [&](long long base, float* r) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const long long vv = min(v + u, v1 - 1);
-      xv[u] = x[(size_t)vv * ldx + lane];
-      id[u] = (int)ind[vv];
+      const long long vv = base + wave * 4 + u;
+      r[u] = vv < v1 ? x[(size_t)vv * ldx + lane] : 0.f;
     }
+  };
+  auto block = [&](long long base, float* r, int id) {     // r: this block's rows; refilled with the rows of block base + 128
+    __syncthreads();                 // the previous block has been consumed (first pass: the table is zero)
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
-      if (v + u < v1) {
-        atomicAdd(&tab[id[u] * VQ_D + lane], xv[u]);
-        if (lane == 0) atomicAdd(&tab[VQ_K * VQ_D + id[u]], 1.f);
+    for (int u = 0; u < 4; ++u) stage[(wave * 4 + u) * VQ_D + lane] = r[u];
+    __syncthreads();
+    if (base + 128 < v1) load_rows(base + 128, r);
+    unsigned long long m = __ballot(id >= 0 && (id & 15) == wave);
+    while (m) {
+      const int c = __builtin_amdgcn_readlane(id, (int)__ffsll((long long)m) - 1);
+      unsigned long long mc = __ballot(id == c);
+      m &= ~mc;
+      const float cnt = (float)__popcll(mc);
+      float acc = 0.f;
+      while (mc) {
+        int b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          b[u] = mc ? (int)__ffsll((long long)mc) - 1 : -1;
+          if (mc) mc &= mc - 1;
+        }
+        float t[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) t[u] = b[u] >= 0 ? stage[b[u] * VQ_D + lane] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (b[u] >= 0) acc += t[u];
       }
+      tab[c * VQ_D + lane] += acc;
+      if (lane == 0) tab[VQ_K * VQ_D + c] += cnt;
+    }
+  };
+  auto index_of = [&](long long base) { return (base + lane < v1) ? (int)ind[base + lane] : -1; };
+  if (v0 < v1) load_rows(v0, ra);
+  if (v0 + 64 < v1) load_rows(v0 + 64, rb);
+  int ida = index_of(v0), idb = index_of(v0 + 64);
+  for (long long base = v0; base < v1; base += 128) {
+    const int id0 = ida, id1 = idb;
+    ida = index_of(base + 128);
+    idb = index_of(base + 192);
+    block(base, ra, id0);
+    if (base + 64 < v1) block(base + 64, rb, id1);
   }
   __syncthreads();
   float* slab = ws + (size_t)blockIdx.x * (VQ_K * VQ_D + VQ_K);

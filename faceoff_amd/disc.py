@@ -206,8 +206,7 @@ class DiscEngine:
                 xs = self._s2d(x)
                 y = torch.empty((N,) + dd + (co,), device=self.device)
                 d = self._desc0(N, self._dims_of(xs), xs.shape[-1], xs.shape[-1], dd, co, co, FO_BIAS | FO_OUT_LRELU)
-                _lib.call("fo_convnd", C.byref(d), 0, ops._ptr(xs), ops._ptr(self._wp[key + ".0.weight"]), ops._ptr(self.params[key + ".0.bias"]),
-                          None, ops._ptr(y), ops._stream())
+                self._convnd(d, 0, xs, self._wp[key + ".0.weight"], self.params[key + ".0.bias"], None, y)
                 feat.append(y)
                 inp += [xs, y]
                 h, cin = y, co
@@ -215,19 +214,18 @@ class DiscEngine:
             ld_out = max(32, co)
             # the 1-channel head is written into a zeroed 32-float pixel
             # few output tiles behind a long contraction -- the 1-channel head (192 tiles x 1024 K-steps) and the 256 -> 512 layer (292 tiles
-            # of a 16 384-deep contraction on 512 workgroup slots: one round, 57 % full) --: the launch may slice K (y is zeroed for it)
+            # of a 16 384-deep contraction on 512 workgroup slots: one round, 57 % full) --: the launch may slice K (through a workspace)
             # (and every other layer whose output is fewer than 1024 tiles: the epilogue is bias only, InstanceNorm is its own launch)
             few_tiles = (N * dd[0] * dd[1] * dd[2] + 63) // 64 * ((co + 63) // 64) < 1024
             ksplit = (co < 32 or j >= 3 or few_tiles) and not _os.environ.get("FACEOFF_NO_DISC_KSPLIT")
-            y = (torch.zeros if ksplit else torch.empty)((N,) + dd + (ld_out,), device=self.device)
+            y = (torch.zeros if co < 32 else torch.empty)((N,) + dd + (ld_out,), device=self.device)
             flags = FO_BIAS | (FO_OUT_LRELU if j == 0 else 0) | (FO_KSPLIT if ksplit else 0)
             d = self._desc(N, sd, cin, h.shape[-1], dd, co, ld_out, s, flags)
             if self._head_ok(co, s, cin):       # the 1-channel head: dot products, not a 64-column tile (csrc/disc_head.hip)
                 _lib.call("fo_disc_head_fwd", C.byref(d), ops._ptr(h), ops._ptr(self._wp[key + ".0.weight"]), ops._ptr(self.params[key + ".0.bias"]),
                           ops._ptr(y), ops._stream())
             else:
-                _lib.call("fo_convnd", C.byref(d), 0, ops._ptr(h), ops._ptr(self._wp[key + ".0.weight"]), ops._ptr(self.params[key + ".0.bias"]),
-                          None, ops._ptr(y), ops._stream())
+                self._convnd(d, 0, h, self._wp[key + ".0.weight"], self.params[key + ".0.bias"], None, y)
             if 1 <= j <= 3:
                 rows = dd[0] * dd[1] * dd[2]
                 st = torch.empty((N, 2 * co), device=self.device)
@@ -264,6 +262,14 @@ class DiscEngine:
     @staticmethod
     def _head_ok(co, stride, cin):
         return co == 1 and stride == 1 and cin in (256, 512) and not _os.environ.get("FACEOFF_NO_DISC_HEAD")
+
+    @staticmethod
+    def _convnd(d, transposed, src, wp, bias, mask, dst):
+        """fo_convnd with the workspace its K-slices need (FO_KSPLIT in d.flags and a shape the C side decides to slice)"""
+        nbytes = _lib.load().fo_convnd_ws_bytes(C.byref(d), transposed) if d.flags & FO_KSPLIT else 0
+        ws = ops._workspace(nbytes, src.device) if nbytes else None
+        _lib.call("fo_convnd", C.byref(d), transposed, ops._ptr(src), ops._ptr(wp), ops._ptr(bias), ops._ptr(mask), ops._ptr(dst),
+                  ops._ptr(ws), C.c_int64(ws.numel() * 4 if ws is not None else 0), ops._stream())
 
     @staticmethod
     def _wgradnd(d, g, src, dw, cs_real):
@@ -314,7 +320,7 @@ class DiscEngine:
                     return None
                 gxs = torch.empty_like(x_in)
                 d = self._desc0(N, dd, co, g.shape[-1], sd, ph * self.nc, cin_pad)
-                _lib.call("fo_convnd", C.byref(d), 1, ops._ptr(g), ops._ptr(self._wpt[key + ".0.weight"]), None, None, ops._ptr(gxs), ops._stream())
+                self._convnd(d, 1, g, self._wpt[key + ".0.weight"], None, None, gxs)
                 gx = torch.zeros(sc["x_shape"], device=self.device)
                 return self._s2d(gxs, inverse_into=gx)
             if param_grads:
@@ -323,15 +329,14 @@ class DiscEngine:
             # data gradient: source = g on the conv's output grid (channels padded to 32), destination = the conv's input
             cs = max(32, co)
             ksplit = j >= 3 and not _os.environ.get("FACEOFF_NO_DISC_KSPLIT")     # (as the forward: few tiles, long contraction, linear epilogue)
-            gin = torch.empty_like(x_in) if (j > 0 and not ksplit) else torch.zeros_like(x_in)
+            gin = torch.empty_like(x_in) if j > 0 else torch.zeros_like(x_in)
             flags = (FO_MASK_LRELU if j == 1 else 0) | (FO_KSPLIT if ksplit else 0)          # layer 0's LeakyReLU (no norm in between): mask = its output
             if self._head_ok(co, s, cin_pad) and cin_real == cin_pad:
                 dfw = self._desc(N, sd, cin_pad, cin_pad, dd, co, g.shape[-1], s)       # the forward convolution's description
                 _lib.call("fo_disc_head_dgrad", C.byref(dfw), ops._ptr(g), ops._ptr(self._wp[key + ".0.weight"]), ops._ptr(gin), ops._stream())
             else:
                 d = self._desc(N, dd, cs, g.shape[-1], sd, cin_real, cin_pad, s, flags, ld_mask=cin_pad if j == 1 else 0)
-                _lib.call("fo_convnd", C.byref(d), 1, ops._ptr(g), ops._ptr(self._wpt[key + ".0.weight"]), None,
-                          ops._ptr(x_in) if j == 1 else None, ops._ptr(gin), ops._stream())
+                self._convnd(d, 1, g, self._wpt[key + ".0.weight"], None, x_in if j == 1 else None, gin)
             g = gin
         return g
 

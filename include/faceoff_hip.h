@@ -177,8 +177,8 @@ int fo_vq_prepare(const float* embed, float* embedT, float* enorm, void* stream)
 int fo_vq_assign(const float* x, int ldx, int64_t nvec, const float* embedT, const float* enorm, int64_t* ind,
                  float* q_ste, int ldq, float* sq_sum, void* stream);
 /* EMA statistics of the assignment (:60-61, replaces F.one_hot + the second sgemm): counts[512] and
- * esum[512][64] (code-major) are OVERWRITTEN.  ws: fo_vq_stats_ws_bytes(nvec).  No global atomics;
- * within-workgroup LDS float adds make the last bits run-dependent. */
+ * esum[512][64] (code-major) are OVERWRITTEN.  ws: fo_vq_stats_ws_bytes(nvec).  No atomics: a wave owns the codes
+ * c % 16 == wave and adds their vectors in vector order, workgroup slabs are summed in a fixed order -- bit-reproducible. */
 int64_t fo_vq_stats_ws_bytes(int64_t nvec);
 int fo_vq_stats(const float* x, int ldx, int64_t nvec, const int64_t* ind, float* counts, float* esum, float* ws,
                 void* stream);
@@ -316,8 +316,8 @@ int fo_denorm_u8(const float* src, int ld, int C, int c0, uint8_t* out, int N, i
  * (a 2-D tensor has D = 1). */
 #define FO_OUT_LRELU 64   /* fo_convnd: LeakyReLU(slope) on the result */
 #define FO_MASK_LRELU 128 /* fo_convnd: result *= (mask[pixel][c] > 0 ? 1 : slope)  (LeakyReLU backward fused into a data gradient) */
-#define FO_KSPLIT 256     /* fo_convnd: the launch MAY cut the contraction into slices combined with float atomics (few tiles, long K:
-                             the 1-channel patch head); dst must be ZERO on entry; only with FO_BIAS */
+#define FO_KSPLIT 256     /* fo_convnd: the launch MAY cut the contraction into slices (few tiles behind a long K: the 256 -> 512 layers),
+                             added in slice order by a second launch through the workspace of fo_convnd_ws_bytes */
 typedef struct fo_convnd_desc {
   int32_t N;
   int32_t Ds, Hs, Ws, Cs, ldS; /* SOURCE tensor of the launch (forward: the conv's input; transposed: the output gradient) */
@@ -333,8 +333,12 @@ int fo_pack_convnd(const float* w, float* wp, int O, int I, int taps, int transp
 /* transposed = 0: dst = conv(src) (+ bias, LeakyReLU).  transposed = 1: dst = data gradient of that conv for the output
  * gradient src (Cs = the conv's Cout padded to 32 with zero channels, Cd = the conv's Cin), as a gather (no atomics).
  * Source channels must be a multiple of 32. */
+/* With FO_KSPLIT in d->flags a launch of few tiles behind a long contraction slices K over workgroups: the slices leave
+ * partial tiles in ws (>= fo_convnd_ws_bytes(d, transposed); 0 = this shape is not sliced) and a second launch adds them in slice
+ * order and applies the epilogue -- no atomics, bit-reproducible.  Taps that only padding can reach from a tile are skipped. */
+int64_t fo_convnd_ws_bytes(const fo_convnd_desc* d, int transposed);
 int fo_convnd(const fo_convnd_desc* d, int transposed, const float* src, const float* wp, const float* bias, const float* mask,
-              float* dst, void* stream);
+              float* dst, float* ws, int64_t ws_bytes, void* stream);
 /* dw[Cd][CsReal][taps] = sum over output positions of g (x) src for the FORWARD conv d (g on the destination grid).
  * Rows (and, for a depth tap, only the frames whose input is not padding) are the contraction index; when the layer needs
  * fo_wgradnd_splits(d) > 1 row slices to fill the chip, the slices leave partial sums in ws (>= fo_wgradnd_ws_bytes(d), 0

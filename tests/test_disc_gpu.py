@@ -129,9 +129,27 @@ def test_convnd_forward_transposed_and_wgrad_vs_torch(dims, N, Cin, Cout, size, 
     wp = torch.empty(((Cout + 63) // 64 * 64) * taps * Cin, device="cuda")
     _lib.call("fo_pack_convnd", ops._ptr(wc), ops._ptr(wp), Cout, Cin, taps, 0, ops._stream())
     out = torch.zeros((N, Do, Ho, Wo, ldo), device="cuda")
-    _lib.call("fo_convnd", C.byref(d), 0, ops._ptr(xc), ops._ptr(wp), ops._ptr(b.cuda()), None, ops._ptr(out), ops._stream())
+    _lib.call("fo_convnd", C.byref(d), 0, ops._ptr(xc), ops._ptr(wp), ops._ptr(b.cuda()), None, ops._ptr(out), None, C.c_int64(0), ops._stream())
     got = out[..., :Cout].permute(0, 4, 1, 2, 3).cpu()
     assert (got - y.detach()).abs().max().item() <= 2e-5 * y.detach().abs().max().item()
+    # the same launch with its contraction sliced over workgroups (FO_KSPLIT; through a workspace, epilogue in the reduce launch):
+    # equal up to summation order, and bit-reproducible
+    from faceoff_amd._lib import FO_KSPLIT, FO_OUT_LRELU
+    d.flags = FO_BIAS | FO_OUT_LRELU | FO_KSPLIT
+    nb = _lib.load().fo_convnd_ws_bytes(C.byref(d), 0)
+    assert nb >= 0
+    if nb:
+        ws = torch.empty(nb // 4, device="cuda")
+        outs = []
+        for _ in range(2):
+            o = torch.full((N, Do, Ho, Wo, ldo), 3.0, device="cuda")
+            _lib.call("fo_convnd", C.byref(d), 0, ops._ptr(xc), ops._ptr(wp), ops._ptr(b.cuda()), None, ops._ptr(o), ops._ptr(ws), C.c_int64(nb), ops._stream())
+            outs.append(o)
+        assert torch.equal(outs[0], outs[1])
+        want = torch.nn.functional.leaky_relu(y.detach(), 0.2)
+        assert (outs[0][..., :Cout].permute(0, 4, 1, 2, 3).cpu() - want).abs().max().item() <= 2e-5 * want.abs().max().item()
+        with pytest.raises(_lib.FaceoffHipError):          # sliced launch without its workspace
+            _lib.call("fo_convnd", C.byref(d), 0, ops._ptr(xc), ops._ptr(wp), ops._ptr(b.cuda()), None, ops._ptr(o), None, C.c_int64(0), ops._stream())
     # transposed: source = gy padded to a multiple of 32 channels
     cs = (Cout + 31) // 32 * 32
     gc = torch.zeros((N, Do, Ho, Wo, cs), device="cuda")
@@ -141,7 +159,7 @@ def test_convnd_forward_transposed_and_wgrad_vs_torch(dims, N, Cin, Cout, size, 
     dt = ConvNdDesc(N=N, Ds=Do, Hs=Ho, Ws=Wo, Cs=cs, ldS=cs, Dd=D, Hd=H, Wd=W, Cd=Cin, ldD=Cin, KD=kshape[0], KH=4, KW=4,
                     sD=st[0], sH=st[1], sW=st[2], pD=pad[0], pH=2, pW=2, ldMask=0, flags=0, slope=0.2)
     gin = torch.full((N, D, H, W, Cin), 9.0, device="cuda")
-    _lib.call("fo_convnd", C.byref(dt), 1, ops._ptr(gc), ops._ptr(wpt), None, None, ops._ptr(gin), ops._stream())
+    _lib.call("fo_convnd", C.byref(dt), 1, ops._ptr(gc), ops._ptr(wpt), None, None, ops._ptr(gin), None, C.c_int64(0), ops._stream())
     got = gin.permute(0, 4, 1, 2, 3).cpu()
     assert (got - xr.grad).abs().max().item() <= 2e-5 * xr.grad.abs().max().item()
     # filter gradient

@@ -23,8 +23,8 @@ def test_host_fed_steps_equal_resident_steps_bitwise(pinned):
     from faceoff_amd.engine import VQVAEEngine
     from faceoff_amd.trainer import FaceOffTrainer
     T, H, W, steps = 3, 32, 64, 4
-    # (bitwise through the FIRST update; from the second step on the EMA codebook statistics enter, whose LDS float atomics make them
-    # reproducible to rounding only -- the same between two resident runs)
+    # (bitwise through EVERY update: gradients, parameters and the EMA codebook buffers -- the statistics kernel adds in an order that
+    # depends on the data only; only the loss scalars meet in float atomics)
     data = _batches(steps, T, H, W, pinned)
     runs = []
     for fed in (False, True):
@@ -50,13 +50,9 @@ def test_host_fed_steps_equal_resident_steps_bitwise(pinned):
         torch.testing.assert_close(r0, r1, rtol=1e-6, atol=0)      # (loss sums use float atomics: their order varies run to run)
         torch.testing.assert_close(d0, d1, rtol=1e-6, atol=0)
     assert torch.equal(f0[0], f1[0]) and torch.equal(f0[1], f1[1])          # first step: gradients and updated parameters, bit for bit
-    # later steps: two RESIDENT runs differ from each other in the same way (EMA statistics by float atomics -> parameters that differ in the last
-    # bits -> here and there a ReLU or a code index on the other side of a near-tie), so the bound is on the whole gradient, not per element
-    assert ((g0 - g1).norm() / g0.norm()).item() < 2e-3
-    assert ((g0 - g1).abs() > 1e-5 * g0.abs().max()).float().mean().item() < 0.02
-    torch.testing.assert_close(p0, p1, rtol=0, atol=4 * 2.1 * 3e-4)          # (Adam's first steps move a parameter by ~lr * sign(g))
+    assert torch.equal(g0, g1) and torch.equal(p0, p1)                      # ... and after four steps
     for k in b0:
-        torch.testing.assert_close(b0[k], b1[k], rtol=1e-4, atol=1e-6 * b0[k].abs().max().item())
+        assert torch.equal(b0[k], b1[k]), k
 
 
 def test_host_fed_iterator_hands_out_every_batch_once_and_in_order():

@@ -118,3 +118,31 @@ def test_random_choices_follow_the_reference_call_order():
     want["flip_real"] = ref.randint(0, 1) == 0
     want["frame_id"] = ref.randint(1, 15)
     assert d == want
+
+
+def test_gan_iterations_are_bit_reproducible():
+    """Two trainers from the same state, two iterations each (generator, then discriminator), at a size where the discriminators'
+    convolutions and filter gradients run sliced (K-slices / row slices through workspaces, added in slice order): every parameter
+    of the generator and of both discriminators, and the running statistics, equal bit for bit."""
+    from faceoff_amd.disc import DiscEngine
+    from faceoff_amd.engine import VQVAEEngine
+    from faceoff_amd.gan_trainer import GANTrainer
+    n, h, w, win = 10, 128, 128, 10
+    img, gt = make_batch(5, 1, n, h, w)
+    x = torch.from_numpy(img).reshape(n, 6, h, w).cuda()
+    y = torch.from_numpy(gt).reshape(n, 3, h, w).cuda()
+    states = []
+    for _ in range(2):
+        eng = VQVAEEngine(make_state_dict(2, codebook_scale=0.3, gain=2.0), "cuda:0")
+        d3 = DiscEngine(make_disc_state(8, 3), "cuda:0", dims=3, n_frames=win - 1)
+        d2 = DiscEngine(make_disc_state(9, 2), "cuda:0", dims=2)
+        tr = GANTrainer(eng, d3, d2, lr=3e-4, d_lr=1e-4, window=win, rng=random.Random(4))
+        for _ in range(2):
+            tr.step(x, y)
+        torch.cuda.synchronize()
+        st = {"g." + k: v.clone() for k, v in eng.state_dict().items()}
+        st.update({"d3." + k: v.clone() for k, v in d3.state_dict().items()})
+        st.update({"d2." + k: v.clone() for k, v in d2.state_dict().items()})
+        states.append(st)
+    diff = [k for k in states[0] if not torch.equal(states[0][k], states[1][k])]
+    assert not diff, diff[:8]

@@ -39,8 +39,8 @@ for scale, (D, H, W) in enumerate([(15, 256, 256), (15, 128, 128)]):
         dt = ConvNdDesc(N=N, Ds=Do, Hs=Ho, Ws=Wo, Cs=ldo, ldS=ldo, Dd=D, Hd=H, Wd=W, Cd=cin_real, ldD=cs, KD=4, KH=4, KW=4, sD=s, sH=s, sW=s, pD=2, pH=2,
                         pW=2, ldMask=0, flags=0, slope=0.2)
         flop = 2.0 * N * Do * Ho * Wo * co * cin_real * 64
-        t_f = timeit(lambda: _lib.call("fo_convnd", C.byref(d), 0, ops._ptr(x), ops._ptr(wp), None, None, ops._ptr(y), ops._stream()))
-        t_d = timeit(lambda: _lib.call("fo_convnd", C.byref(dt), 1, ops._ptr(g), ops._ptr(wpt), None, None, ops._ptr(gin), ops._stream()))
+        t_f = timeit(lambda: _lib.call("fo_convnd", C.byref(d), 0, ops._ptr(x), ops._ptr(wp), None, None, ops._ptr(y), None, C.c_int64(0), ops._stream()))
+        t_d = timeit(lambda: _lib.call("fo_convnd", C.byref(dt), 1, ops._ptr(g), ops._ptr(wpt), None, None, ops._ptr(gin), None, C.c_int64(0), ops._stream()))
         ws = ops._workspace(_lib.load().fo_wgradnd_ws_bytes(C.byref(d)), dw.device)
         t_w = timeit(lambda: _lib.call("fo_wgradnd", C.byref(d), ops._ptr(g), ops._ptr(x), ops._ptr(dw), cin_real, ops._ptr(ws), C.c_int64(ws.numel() * 4),
                                        ops._stream()))
