@@ -22,6 +22,9 @@
 #include <stdio.h>
 #include "common.h"
 
+#ifndef FO_RB_ST   // cache policy of the output / hidden stores.  -DFO_RB_ST=2 (nt): the outputs stop evicting the input frame from the XCD's L2 --
+#define FO_RB_ST 0  // HBM reads 499 -> 349 MB per 64^2 launch (1.49 -> 1.04 x the input) -- but the launch is 9 % SLOWER (0.549 -> 0.600 ms): not used
+#endif
 #ifndef FO_ABLATE_RB   // diagnostic builds: bit 0 no patch DMA, 1 no 3x3 MFMAs, 2 no epilogue residual loads / stores
 #define FO_ABLATE_RB 0
 #endif
@@ -235,8 +238,8 @@ __global__ __launch_bounds__(256, 2) void resblock_halo_fwd_kernel(const RBArgs 
       s1.x = fmaxf(s1.x, 0.f); s1.y = fmaxf(s1.y, 0.f); s1.z = fmaxf(s1.z, 0.f); s1.w = fmaxf(s1.w, 0.f);
       *reinterpret_cast<f32x4*>(Hs + hp * HLD + hc) = s0;
       *reinterpret_cast<f32x4*>(Hs + hp * HLD + hc + 4) = s1;
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, s0), rh, hlane, pix0 * a.ldH * 4, 0);
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, s1), rh, hlane + 16, pix0 * a.ldH * 4, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, s0), rh, hlane, pix0 * a.ldH * 4, FO_RB_ST);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, s1), rh, hlane + 16, pix0 * a.ldH * 4, FO_RB_ST);
     }
     STAMP(4);
     __syncthreads();                                       // the partials are consumed: the slices are free
@@ -267,7 +270,7 @@ __global__ __launch_bounds__(256, 2) void resblock_halo_fwd_kernel(const RBArgs 
         f32x4 v = {acc2[mb][4 * j], acc2[mb][4 * j + 1], acc2[mb][4 * j + 2], acc2[mb][4 * j + 3]};
         if (a.relu2) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         if (!(FO_ABLATE_RB & 4) || v.x == 12345.f)
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, olane + 32 * j, (pix0 + mb * a.W) * a.ldO * 4, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, olane + 32 * j, (pix0 + mb * a.W) * a.ldO * 4, FO_RB_ST);
       }
     STAMP(8);
     // (no barrier here: the next tile's first shared write is its partial sums -- over a wave's own slice -- and the hidden tile is only
