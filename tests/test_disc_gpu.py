@@ -102,17 +102,24 @@ def test_discriminator_engine_vs_reference_golden(golden_dir, tag, dims):
                                                          (3, 1, 64, 1, (3, 6, 6), 1), (2, 1, 32, 200, (1, 17, 9), 1),
                                                          # enough rows for the filter gradient to run as row slices + the reduce launch
                                                          (2, 2, 32, 64, (1, 40, 44), 1), (3, 1, 32, 64, (3, 20, 20), 1), (3, 2, 32, 64, (8, 21, 23), 2)])
-def test_convnd_forward_transposed_and_wgrad_vs_torch(dims, N, Cin, Cout, size, stride):
-    """fo_convnd forward / transposed (gather data gradient, phase-major rows) / fo_wgradnd against torch-CPU conv k4 p2."""
+@pytest.mark.parametrize("ksize,padding", [(4, 2), (3, 1), (5, 2), (2, 0), (3, 3)])
+def test_convnd_forward_transposed_and_wgrad_vs_torch(dims, N, Cin, Cout, size, stride, ksize, padding):
+    """fo_convnd forward / transposed (gather data gradient, phase-major rows) / fo_wgradnd against torch-CPU convolutions: the discriminators' k4 p2
+    (mocoganhd_video_disc.py:133-158) and other kernel sizes / paddings (the walks leave out the taps and frames that only see padding: generic code)."""
+    if (ksize, padding) != (4, 2) and (Cout in (1, 200) or size[1] >= 40):
+        pytest.skip("the other kernel sizes run on three of the shapes")
     from faceoff_amd import _lib, ops
     from faceoff_amd._lib import ConvNdDesc, FO_BIAS
     g = torch.Generator().manual_seed(dims * 100 + Cin + Cout)
     D, H, W = size
     x = torch.randn((N, Cin, D, H, W), generator=g)
-    kshape = (4, 4, 4) if dims == 3 else (1, 4, 4)
+    K, P = ksize, padding
+    kshape = (K, K, K) if dims == 3 else (1, K, K)
     w = torch.randn((Cout, Cin) + kshape, generator=g) * 0.05
     b = torch.randn(Cout, generator=g)
-    pad = (2, 2, 2) if dims == 3 else (0, 2, 2)
+    pad = (P, P, P) if dims == 3 else (0, P, P)
+    if any((n + 2 * p - k) < 0 for n, p, k in zip(size, pad, kshape)):
+        pytest.skip("kernel larger than the padded input")
     st = (stride,) * 3 if dims == 3 else (1, stride, stride)
     xr = x.clone().requires_grad_(True)
     wr = w.clone().requires_grad_(True)
@@ -121,10 +128,10 @@ def test_convnd_forward_transposed_and_wgrad_vs_torch(dims, N, Cin, Cout, size, 
     y.backward(gy)
     Do, Ho, Wo = y.shape[2:]
     ldo = max(32, (Cout + 31) // 32 * 32)
-    d = ConvNdDesc(N=N, Ds=D, Hs=H, Ws=W, Cs=Cin, ldS=Cin, Dd=Do, Hd=Ho, Wd=Wo, Cd=Cout, ldD=ldo, KD=kshape[0], KH=4, KW=4,
-                   sD=st[0], sH=st[1], sW=st[2], pD=pad[0], pH=2, pW=2, ldMask=0, flags=FO_BIAS, slope=0.2)
+    d = ConvNdDesc(N=N, Ds=D, Hs=H, Ws=W, Cs=Cin, ldS=Cin, Dd=Do, Hd=Ho, Wd=Wo, Cd=Cout, ldD=ldo, KD=kshape[0], KH=K, KW=K,
+                   sD=st[0], sH=st[1], sW=st[2], pD=pad[0], pH=P, pW=P, ldMask=0, flags=FO_BIAS, slope=0.2)
     xc = x.permute(0, 2, 3, 4, 1).contiguous().cuda()
-    taps = kshape[0] * 16
+    taps = kshape[0] * K * K
     wc = w.reshape(Cout, Cin, taps).contiguous().cuda()
     wp = torch.empty(((Cout + 63) // 64 * 64) * taps * Cin, device="cuda")
     _lib.call("fo_pack_convnd", ops._ptr(wc), ops._ptr(wp), Cout, Cin, taps, 0, ops._stream())
@@ -156,8 +163,8 @@ def test_convnd_forward_transposed_and_wgrad_vs_torch(dims, N, Cin, Cout, size, 
     gc[..., :Cout] = gy.permute(0, 2, 3, 4, 1).cuda()
     wpt = torch.empty(((Cin + 63) // 64 * 64) * taps * cs, device="cuda")
     _lib.call("fo_pack_convnd", ops._ptr(wc), ops._ptr(wpt), Cout, Cin, taps, 1, ops._stream())
-    dt = ConvNdDesc(N=N, Ds=Do, Hs=Ho, Ws=Wo, Cs=cs, ldS=cs, Dd=D, Hd=H, Wd=W, Cd=Cin, ldD=Cin, KD=kshape[0], KH=4, KW=4,
-                    sD=st[0], sH=st[1], sW=st[2], pD=pad[0], pH=2, pW=2, ldMask=0, flags=0, slope=0.2)
+    dt = ConvNdDesc(N=N, Ds=Do, Hs=Ho, Ws=Wo, Cs=cs, ldS=cs, Dd=D, Hd=H, Wd=W, Cd=Cin, ldD=Cin, KD=kshape[0], KH=K, KW=K,
+                    sD=st[0], sH=st[1], sW=st[2], pD=pad[0], pH=P, pW=P, ldMask=0, flags=0, slope=0.2)
     gin = torch.full((N, D, H, W, Cin), 9.0, device="cuda")
     _lib.call("fo_convnd", C.byref(dt), 1, ops._ptr(gc), ops._ptr(wpt), None, None, ops._ptr(gin), None, C.c_int64(0), ops._stream())
     got = gin.permute(0, 4, 1, 2, 3).cpu()
