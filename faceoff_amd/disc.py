@@ -241,13 +241,17 @@ class DiscEngine:
         return {"feat": feat, "stats": stats, "inp": inp[:5], "prefix": prefix, "x_shape": tuple(x.shape)}
 
     # ------------------------------------------------------------------ backward
-    def backward(self, S, g_logits, param_grads=True, input_grad=False):
+    def backward(self, S, g_logits, param_grads=True, input_grad=False, samples=None):
         """g_logits[i]: gradient of the loss with respect to S['logits'][i] (same shape; only channel 0 is read).
-        Fills self.grads (param_grads) and / or returns the gradient with respect to the input x [N][D][H][W][32]."""
-        N = S["N"]
+        Fills self.grads (param_grads) and / or returns the gradient with respect to the input x [N][D][H][W][32].
+        samples = (n0, n1): only samples n0 .. n1-1 carry gradient (the generator iteration: the real sample's logits get none, :359-360) --
+        the backward runs on those samples alone and returns their input gradient [n1-n0][D][H][W][32]; not with param_grads."""
+        n0, n1 = samples if samples is not None else (0, S["N"])
+        assert 0 <= n0 < n1 <= S["N"] and (samples is None or not param_grads)
+        N = n1 - n0
         gx_scale = [None] * self.num_D
         for i in range(self.num_D):
-            gx_scale[i] = self._scale_bwd(S["scales"][i], g_logits[i], param_grads, input_grad)
+            gx_scale[i] = self._scale_bwd(S["scales"][i], g_logits[i], param_grads, input_grad, n0, n1)
         if not input_grad:
             return None
         # chain the scales: the input of scale i+1 is the average pool of the input of scale i
@@ -288,10 +292,12 @@ class DiscEngine:
         rows = g.numel() // g.shape[-1]
         ops.bias_grad(g.view(rows, 1, 1, g.shape[-1]), self.grads[key + ".0.bias"], d.Cd)
 
-    def _scale_bwd(self, sc, g_logit, param_grads, input_grad):
-        prefix, feat, stats, inp = sc["prefix"], sc["feat"], sc["stats"], sc["inp"]
-        N = inp[0].shape[0]
-        g = g_logit                      # gradient wrt the conv output of layer j (pre-norm), channels-last, ld = max(32, co)
+    def _scale_bwd(self, sc, g_logit, param_grads, input_grad, n0, n1):
+        prefix = sc["prefix"]
+        cut = lambda ts: [None if t is None else t[n0:n1] for t in ts]       # (sample slices of channels-last tensors are contiguous)
+        feat, stats, inp = cut(sc["feat"]), cut(sc["stats"]), cut(sc["inp"])
+        N = n1 - n0
+        g = g_logit[n0:n1]               # gradient wrt the conv output of layer j (pre-norm), channels-last, ld = max(32, co)
         for j in range(4, -1, -1):
             key = f"{prefix}_layer{j}"
             co, s = DISC_CHANNELS[j], STRIDES[j]
@@ -321,7 +327,7 @@ class DiscEngine:
                 gxs = torch.empty_like(x_in)
                 d = self._desc0(N, dd, co, g.shape[-1], sd, ph * self.nc, cin_pad)
                 self._convnd(d, 1, g, self._wpt[key + ".0.weight"], None, None, gxs)
-                gx = torch.zeros(sc["x_shape"], device=self.device)
+                gx = torch.zeros((N,) + tuple(sc["x_shape"][1:]), device=self.device)
                 return self._s2d(gxs, inverse_into=gx)
             if param_grads:
                 d = self._desc(N, sd, cin_pad, cin_pad, dd, co, g.shape[-1], s)

@@ -113,14 +113,14 @@ class GANTrainer:
             S2 = self.d2.forward(x2, training=True, sample_order=[0, 1])
             l2 = torch.zeros(1, device=eng.device)
             g2 = ralsgan_pair(S2["logits"], 0, 1, 1.0, 0.0, 0.5, l2, want_gb=False)
-            gx2 = self.d2.backward(S2, g2, param_grads=False, input_grad=True)
+            gx2 = self.d2.backward(S2, g2, param_grads=False, input_grad=True, samples=(0, 1))    # (the real sample's logits carry no gradient)
             pairs_backward(gx2[0], 0, c["frame_id"], 1, 1, g_win)
             # video discriminator: module calls real, then fake (:368-369)
             x3 = self._video_pairs(dec_win, gt_win, c)
             S3 = self.d3.forward(x3, training=True, sample_order=[1, 0])
             l3 = torch.zeros(1, device=eng.device)
             g3 = ralsgan_pair(S3["logits"], 0, 1, 1.0, 0.0, 0.5, l3, want_gb=False)
-            gx3 = self.d3.backward(S3, g3, param_grads=False, input_grad=True)
+            gx3 = self.d3.backward(S3, g3, param_grads=False, input_grad=True, samples=(0, 1))
             first, step = (w - 1, -1) if c["flip_fake"] else (1, 1)
             pairs_backward(gx3[0], 0, first, step, w - 1, g_win)
             eng.backward(S, g_dec, one * LATENT_LOSS_WEIGHT)                  # G_loss = recon + latent + G_2d + G_3d (:375)
