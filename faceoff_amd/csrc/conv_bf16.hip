@@ -1278,7 +1278,7 @@ static int conv_bf16_impl(const fo_conv_desc* d, const void* in, const void* wp,
   // big tiles (one workgroup per CU) where the launch still fills the chip for a few rounds: stride-1 same-size convs.
   // Measured at the C3 shapes and at a fifth of them (tools/ab_bf16.py): 256-column tiles +22...30 % over conv_bf16_kernel
   // on conv3_x / conv4_x, 128-column tiles +5...10 % on conv2_x and +12...15 % on 2-round launches, the 512 x 128 tile (32 MFMAs per
-  // phase and wave instead of 16: half the barriers per FLOP) another +14...17 % where there are >= 8 rounds of them (a 512 x 64 tile for the 64-column layers measured -8 %); 64-column layers
+  // phase and wave instead of 16: half the barriers per FLOP) another +14...17 % where there are >= 5 whole rounds of them (round 3: the VQ-VAE's 64^2 latents are exactly 5 rounds, config 3 -0.6...-1.6 ms; the first threshold, 8, was only ever measured on the VGG shapes) (a 512 x 64 tile for the 64-column layers measured -8 %); 64-column layers
   // (K = 576: 18 phases) stay on conv_bf16_kernel, whose second workgroup hides the prologue and epilogue
   const bool same = d->stride == 1 && d->ostride == 1 && d->Hm == d->Hout && d->Wm == d->Wout && d->Hin == d->Hm && d->Win == d->Wm && !d2s;
   const char* nobig = getenv("FACEOFF_BF16_SMALL_TILES");            // diagnostics / tests: never
@@ -1296,7 +1296,7 @@ static int conv_bf16_impl(const fo_conv_desc* d, const void* in, const void* wp,
     }
     const char* t512 = getenv("FACEOFF_BF16_TILE512");               // 0: never the 512-row tile (diagnostics)
     const long long tilesM512 = (a.M + 511) / 512;
-    if (!(t512 && !atoi(t512)) && tilesM512 * (d->Cout / 128) >= 8 * cus && (cus > 0 || (t512 && atoi(t512)))) {
+    if (!(t512 && !atoi(t512)) && tilesM512 * (d->Cout / 128) >= 5 * cus && (cus > 0 || (t512 && atoi(t512)))) {
       a.tilesM = (int)tilesM512; a.tilesN = d->Cout / 128;
       a.frameTiles = a.HWm % 512 == 0;
       return launch_pp16<512, 128, 8, 1>(a, s);
