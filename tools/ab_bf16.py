@@ -27,7 +27,8 @@ def main():
         name, _, envs = v.partition(":")
         variants.append((name, dict(e.split("=") for e in envs.split(",") if e)))
     shapes = [("conv1_2", 256, 64, 64), ("conv2_1", 128, 64, 128), ("conv2_2", 128, 128, 128), ("conv3_1", 64, 128, 256),
-              ("conv3_2", 64, 256, 256), ("conv4_1", 32, 256, 512), ("conv4_2", 32, 512, 512), ("conv5_x", 16, 512, 512)]
+              ("conv3_2", 64, 256, 256), ("conv4_1", 32, 256, 512), ("conv4_2", 32, 512, 512), ("conv5_x", 16, 512, 512),
+              ("vq128_64", 64, 128, 128), ("vq128_32", 32, 128, 128)]          # the bf16 VQ-VAE's 128-channel 3x3 layers at the two latent sizes
     for name, H, ci, co in shapes:
         for kind in ("fwd", "dgrad"):
             if flt not in f"{name} {kind}":
