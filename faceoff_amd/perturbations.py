@@ -63,8 +63,8 @@ def _u8_frames(image):
 
 def _per_frame(value, N):
     """one parameter for all N frames, or a sequence of N -> list of N"""
-    if isinstance(value, (int, float)):
-        return [value], 0
+    if not hasattr(value, "__len__"):        # a number (Python or numpy scalar)
+        return [float(value)], 0
     value = list(value)
     if len(value) != N:
         raise ValueError(f"faceoff_amd: {len(value)} per-frame parameters for {N} frames")
@@ -114,7 +114,8 @@ def rotate_image(rotation, image, center=None):
     if _is_u8(image):
         N = _u8_frames(image).shape[0]
         rs, pf = _per_frame(rotation, N)
-        cs = [(w // 2, h // 2)] if center is None else ([tuple(center)] if isinstance(center[0], (int, float)) else [tuple(c) for c in center])
+        one = center is not None and not hasattr(center[0], "__len__")       # (x, y) -- ints, floats or numpy scalars, as find_eye_center returns them
+        cs = [(w // 2, h // 2)] if center is None else ([tuple(center)] if one else [tuple(c) for c in center])
         if len(cs) > 1 or pf:
             if len(cs) not in (1, N):
                 raise ValueError(f"faceoff_amd: {len(cs)} rotation centres for {N} frames")

@@ -127,9 +127,13 @@ def test_u8_perturbations_equal_the_opencv_restatement_bit_for_bit():
             same(P.resize_image(k / 100, xg), lambda im: O.resize_image(k / 100, im))
         for code in (0, 1, -1):
             same(P.image_flip(code, xg), lambda im: O.image_flip(code, im))
-    # a single [H,W,C] image
+    # a single [H,W,C] image; numpy scalars as parameters and centre (find_eye_center returns numpy ints, perturbations.py:183-196)
     x = _u8((40, 56, 3), 9)
     assert np.array_equal(P.rotate_image(5, torch.from_numpy(x).cuda()).cpu().numpy(), O.rotate_image(5, x))
+    c = np.array([21.6, 17.2]).astype("int")
+    got = P.rotate_image(np.float64(-3.0), torch.from_numpy(x).cuda(), center=c).cpu().numpy()
+    assert np.array_equal(got, O.rotate_image(-3.0, x, center=(21, 17)))
+    assert np.array_equal(P.translate_horizontal(np.int64(2), torch.from_numpy(x).cuda()).cpu().numpy(), O.translate_horizontal(2, x))
 
 
 def test_u8_perturbations_per_frame_parameters_at_full_size():
