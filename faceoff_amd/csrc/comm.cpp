@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <mutex>
+#include <string>
 #include <rccl/rccl.h>
 #include "common.h"
 
@@ -24,14 +25,26 @@ struct Rccl {
 Rccl g_rccl;
 std::once_flag g_once;
 bool g_ok = false;
+std::string g_why;          // why librccl could not be used: dlerror() captured right where dlopen / dlsym failed (it is cleared by being read)
 
 bool load_rccl() {
   std::call_once(g_once, [] {
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char* n : names)
+    for (const char* n : names) {
       if ((g_rccl.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL)) != nullptr) break;
+      const char* e = dlerror();
+      g_why += std::string(g_why.empty() ? "" : "; ") + (e ? e : n);
+    }
     if (!g_rccl.lib) return;
-#define FO_SYM(field, name) g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(g_rccl.lib, name))
+    g_why.clear();
+#define FO_SYM(field, name)                                                                    \
+  do {                                                                                         \
+    g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(g_rccl.lib, name));          \
+    if (!g_rccl.field) {                                                                       \
+      const char* e = dlerror();                                                               \
+      g_why += std::string(g_why.empty() ? "" : "; ") + (e ? e : "missing symbol " name);      \
+    }                                                                                          \
+  } while (0)
     FO_SYM(GetUniqueId, "ncclGetUniqueId");
     FO_SYM(CommInitRank, "ncclCommInitRank");
     FO_SYM(AllReduce, "ncclAllReduce");
@@ -74,7 +87,7 @@ extern "C" {
 
 int fo_comm_unique_id(void* id128) {
   FO_REQUIRE(id128, FO_E_SHAPE, "comm_unique_id: null buffer");
-  FO_REQUIRE(load_rccl(), FO_E_HIP, "comm: librccl.so could not be opened (%s)", dlerror() ? dlerror() : "symbols missing");
+  FO_REQUIRE(load_rccl(), FO_E_HIP, "comm: librccl.so cannot be used: %s", g_why.c_str());
   static_assert(sizeof(ncclUniqueId) == 128, "the C-ABI hands the RCCL id around as 128 opaque bytes");
   ncclUniqueId id;
   FO_NCCL(g_rccl.GetUniqueId(&id));
@@ -84,7 +97,7 @@ int fo_comm_unique_id(void* id128) {
 
 int fo_comm_init(fo_comm** out, int rank, int world, const void* id128, int device) {
   FO_REQUIRE(out && id128 && world >= 1 && rank >= 0 && rank < world, FO_E_SHAPE, "comm_init: bad rank / world / id");
-  FO_REQUIRE(load_rccl(), FO_E_HIP, "comm: librccl.so could not be opened");
+  FO_REQUIRE(load_rccl(), FO_E_HIP, "comm: librccl.so cannot be used: %s", g_why.c_str());
   FO_HIP(hipSetDevice(device));
   fo_comm* c = new fo_comm();
   c->rank = rank; c->world = world; c->device = device; c->issued = 0;

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <atomic>
 #include "faceoff_hip.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -37,8 +38,9 @@ int fo_conv3x3_c128to32_halo_bf16_try(const fo_conv_desc* d, const void* in, con
 int fo_conv3x3_c32to128_halo_bf16_try(const fo_conv_desc* d, const void* in, const void* wp, const void* mask, const void* add, void* out,
                                       hipStream_t stream);
 
-// elementwise.hip: out[c] = sum of the nblk partial rows ws[b][C], c < Creal (the second stage of every column sum)
-extern "C" int fo_colsum_finish(const float* ws, float* out, int nblk, int C, int Creal, void* stream);
+// elementwise.hip: out[c] = sum of the nblk partial rows ws[b][C], c < Creal (the second stage of every column sum).
+// Internal (C++ linkage): exports.map keeps everything but the C names of include/faceoff_hip.h out of the dynamic symbol table.
+int fo_colsum_finish(const float* ws, float* out, int nblk, int C, int Creal, void* stream);
 
 #define FO_CHECK_LAUNCH()                                                     \
   do {                                                                        \
@@ -56,6 +58,24 @@ extern "C" int fo_colsum_finish(const float* ws, float* out, int nblk, int C, in
       return (code);                \
     }                               \
   } while (0)
+
+// Opt a kernel in to more than the default 64 KB of dynamic LDS.  hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute
+// (fo_comm_init / hipSetDevice allow several devices in one process), so the "already done" state is a bit per device, and atomic because
+// two host threads may launch on distinct streams.  Returns false (with fo_last_error set) if the runtime refuses.
+struct fo_lds_once { std::atomic<unsigned long long> devs{0}; };
+static inline bool fo_lds_optin(fo_lds_once& once, const void* kern, int bytes, const char* who) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (dev < 64 && (once.devs.load(std::memory_order_acquire) & bit)) return true;
+  const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) {
+    fo_set_error("%s: cannot reserve %d bytes of LDS on device %d: %s", who, bytes, dev, hipGetErrorString(e));
+    return false;
+  }
+  if (dev < 64) once.devs.fetch_or(bit, std::memory_order_release);
+  return true;
+}
 
 static inline bool fo_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 

@@ -1079,14 +1079,8 @@ static int launch_halo64(const ConvArgsH& c, hipStream_t s, void* pooled = nullp
   a.tilesX = d.Win / 32; a.tilesY = d.Hin / 4; a.ntiles = d.N * a.tilesX * a.tilesY;
   a.ldIn = d.ldIn; a.ldOut = d.ldOut; a.ldMask = d.ldMask; a.flags = d.flags; a.inBytes = c.inBytes;
   constexpr int ldsBytes = 2 * 2 * 6 * 48 * 64;            // two stages of two planes
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo64_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, ldsBytes) != hipSuccess) {
-      fo_set_error("conv_bf16: cannot reserve %d bytes of LDS", ldsBytes);
-      return FO_E_HIP;
-    }
-    attr_set = true;
-  }
+  static fo_lds_once once;
+  if (!fo_lds_optin(once, reinterpret_cast<const void*>(conv_halo64_bf16_kernel), ldsBytes, "conv_bf16 (halo64)")) return FO_E_HIP;
   const int cus = fo_cu_count();
   int grid = std::min(2 * cus / a.halves * a.halves, a.ntiles * a.halves);          // two workgroups per CU
   grid = std::max(a.halves, grid / a.halves * a.halves);
@@ -1098,15 +1092,9 @@ static int launch_halo64(const ConvArgsH& c, hipStream_t s, void* pooled = nullp
 template <int BMB, int BN, int WAVES_M, int WAVES_N>
 int launch_pp16(const ConvArgsH& a, hipStream_t s) {
   constexpr int ldsBytes = 4 * (BMB + BN) * 64;
-  static bool attr_set = false;
+  static fo_lds_once once;
   void (*kern)(const ConvArgsH) = conv_bf16_pp16_kernel<BMB, BN, WAVES_M, WAVES_N>;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, ldsBytes) != hipSuccess) {
-      fo_set_error("conv_bf16: cannot reserve %d bytes of LDS", ldsBytes);
-      return FO_E_HIP;
-    }
-    attr_set = true;
-  }
+  if (!fo_lds_optin(once, reinterpret_cast<const void*>(kern), ldsBytes, "conv_bf16 (pp16)")) return FO_E_HIP;
   hipLaunchKernelGGL(kern, dim3(a.tilesM * a.tilesN), dim3(512), ldsBytes, s, a);
   FO_CHECK_LAUNCH();
   return FO_OK;
@@ -1240,15 +1228,8 @@ static int conv_bf16_impl(const fo_conv_desc* d, const void* in, const void* wp,
       d->padH == 1 && d->padW == 1 && d->Hin == d->Hm && d->Win == d->Wm && d->Hm == d->Hout && d->Wm == d->Wout && flags == 0 &&
       d->Win % 64 == 0 && a.M >= 64 * 1024 && !(norgb && atoi(norgb))) {
     constexpr int ldsBytes = 2 * 28 * 1024;
-    static bool attr_set = false;
-    if (!attr_set) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_rgb_dgrad_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, ldsBytes) !=
-          hipSuccess) {
-        fo_set_error("conv_bf16: cannot reserve %d bytes of LDS", ldsBytes);
-        return FO_E_HIP;
-      }
-      attr_set = true;
-    }
+    static fo_lds_once once;
+    if (!fo_lds_optin(once, reinterpret_cast<const void*>(conv_rgb_dgrad_bf16_kernel), ldsBytes, "conv_bf16 (rgb dgrad)")) return FO_E_HIP;
     const int segsPerRow = d->Win / 64, nseg = d->N * d->Hin * segsPerRow;
     hipLaunchKernelGGL(conv_rgb_dgrad_bf16_kernel, dim3(std::min(nseg, 2 * fo_cu_count())), dim3(256), ldsBytes, s, a, nseg, segsPerRow);
     FO_CHECK_LAUNCH();

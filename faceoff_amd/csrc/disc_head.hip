@@ -185,7 +185,7 @@ int fill(const fo_convnd_desc* d, HeadArgs& a, const char* what) {
 }
 
 template <typename K>
-int set_lds(K kern, int bytes) {
+int set_lds(K kern, int bytes) {          // set at every launch (a dozen launches per iteration): correct on any device of the process
   if (bytes > 64 * 1024)
     FO_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess, FO_E_HIP,
                "disc_head: cannot reserve %d bytes of LDS", bytes);

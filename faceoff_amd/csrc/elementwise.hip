@@ -201,13 +201,16 @@ int fo_bias_grad(const float* g, float* dbias, int64_t M, int C, int Creal, int 
   return FO_OK;
 }
 
-// out[c] = sum over the nblk partial rows ws[b][C] (c < Creal): the second stage of every column-sum in this library
+}  // extern "C"
+
+// out[c] = sum over the nblk partial rows ws[b][C] (c < Creal): the second stage of every column-sum in this library (internal)
 int fo_colsum_finish(const float* ws, float* out, int nblk, int C, int Creal, void* stream) {
   hipLaunchKernelGGL(colsum_stage2, dim3((Creal + 63) / 64), dim3(1024), 0, (hipStream_t)stream, ws, out, nblk, C, Creal);
   FO_CHECK_LAUNCH();
   return FO_OK;
 }
 
+extern "C" {
 int fo_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                  float bias_corr1, float bias_corr2, float grad_scale, void* stream) {
   FO_REQUIRE(n % 4 == 0, FO_E_ALIGN, "adam: arena length must be a multiple of 4");

@@ -302,11 +302,8 @@ int fo_conv3x3_c128to32_halo_bf16_try(const fo_conv_desc* d, const void* in, con
   const size_t xB = (npix - 1) * d->ldIn * 2 + 256, hB = (npix - 1) * d->ldOut * 2 + 64;
   if (xB >= 0x7fffffffull || hB >= 0x7fffffffull) return 0;
   a.xBytes = (unsigned)xB; a.hBytes = (unsigned)hB;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c128to32_halo_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, C1_LDS) != hipSuccess) return 0;
-    attr_set = true;
-  }
+  static fo_lds_once once;
+  if (!fo_lds_optin(once, reinterpret_cast<const void*>(conv3x3_c128to32_halo_bf16_kernel), C1_LDS, "resblock_bf16")) return 0;   // -> the tiled kernel
   hipLaunchKernelGGL(conv3x3_c128to32_halo_bf16_kernel, dim3(std::max(8, std::min((a.ntiles + 7) / 8 * 8, 2 * cus) / 8 * 8)), dim3(256), C1_LDS, stream, a);
   return 1;
 }

@@ -519,11 +519,8 @@ int fo_resblock_wgrad1_halo_try(const fo_conv_desc* d, const float* P, const flo
   a.xBytes = (unsigned)xB; a.ghBytes = (unsigned)gB;
   const int grid = std::max(8, std::min((a.ntiles + 7) / 8 * 8, 2 * cus) / 8 * 8);
   if (ws_bytes < (int64_t)grid * W1_SLAB * 4) return 0;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(resblock_wgrad1_halo_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, W1_LDS) != hipSuccess) return 0;
-    attr_set = true;
-  }
+  static fo_lds_once once;
+  if (!fo_lds_optin(once, reinterpret_cast<const void*>(resblock_wgrad1_halo_kernel), W1_LDS, "resblock_wgrad1")) return 0;        // -> the tiled kernel
   hipLaunchKernelGGL(resblock_wgrad1_halo_kernel, dim3(grid), dim3(256), W1_LDS, stream, a);
   hipLaunchKernelGGL(resblock_wgrad1_reduce_kernel, dim3((W1_SLAB + 63) / 64), dim3(512), 0, stream, ws, grid, dw, dbias);
   return 1;
@@ -548,12 +545,8 @@ extern "C" int fo_resblock_bwd_conv3(int64_t M, const float* g, int ldG, const f
   a.gBytes = (unsigned)gB; a.hBytes = (unsigned)hB; a.ghBytes = (unsigned)ghB;
   const int grid = grid_for(a.ntiles);
   hipStream_t s = (hipStream_t)stream;
-  static bool attr_set = false;
-  if (!attr_set) {
-    FO_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(resblock_bwd_conv3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess,
-               FO_E_HIP, "resblock_bwd_conv3: cannot reserve %d bytes of LDS", LDS_BYTES);
-    attr_set = true;
-  }
+  static fo_lds_once once;
+  if (!fo_lds_optin(once, reinterpret_cast<const void*>(resblock_bwd_conv3_kernel), LDS_BYTES, "resblock_bwd_conv3")) return FO_E_HIP;
   hipLaunchKernelGGL(resblock_bwd_conv3_kernel, dim3(grid), dim3(256), LDS_BYTES, s, a);
   FO_CHECK_LAUNCH();
   hipLaunchKernelGGL(resblock_bwd_conv3_reduce_kernel, dim3((128 * 32 + 128 + 63) / 64), dim3(512), 0, s, ws, grid, dw3, db3);

@@ -309,11 +309,8 @@ int fo_resblock_halo_try(const fo_conv_desc* d, const float* x, const float* wp1
   const int cus = fo_cu_count();
   if (a.ntiles < 4 * cus && !force) return 0;              // small launches: the tiled kernel's many small workgroups fill the chip better
   constexpr int ldsBytes = LDS_BYTES;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(resblock_halo_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, ldsBytes) != hipSuccess) return 0;
-    attr_set = true;
-  }
+  static fo_lds_once once;
+  if (!fo_lds_optin(once, reinterpret_cast<const void*>(resblock_halo_fwd_kernel), ldsBytes, "resblock_halo")) return 0;           // -> the tiled kernel
   a.stamps = nullptr;
 #if FO_RB_STAMP
   const int grid_ = std::max(8, std::min((a.ntiles + 7) / 8 * 8, 2 * cus) / 8 * 8);

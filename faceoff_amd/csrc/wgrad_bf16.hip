@@ -508,32 +508,29 @@ constexpr int wgrad_lds_bytes() {
 }
 
 template <int TA, int TB, int WA, int NKW, int KR, bool FAST, bool SMALLC>
-void launch_w(const WArgs& a, int grid, hipStream_t s) {
+int launch_w(const WArgs& a, int grid, hipStream_t s) {       // 1 = launched, -1 = the LDS opt-in failed (fo_last_error says why)
   constexpr int ldsBytes = wgrad_lds_bytes<TA, TB, NKW, KR, FAST, SMALLC>();
   void (*kern)(const WArgs) = wgrad_bf16_kernel<TA, TB, WA, NKW, KR, FAST, SMALLC>;
-  static bool attr_set = false;
-  if (!attr_set && ldsBytes > 48 * 1024) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, ldsBytes);
-    attr_set = true;
-  }
+  static fo_lds_once once;
+  if (ldsBytes > 48 * 1024 && !fo_lds_optin(once, reinterpret_cast<const void*>(kern), ldsBytes, "wgrad_bf16")) return -1;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), ldsBytes, s, a);
+  return 1;
 }
 
 // (block shape, taps per workgroup) -> instantiation; KR and WA follow from them (make_plan)
 template <int NKW, bool FAST>
-bool dispatch(const WPlan& p, const WArgs& a, int grid, hipStream_t s) {
+int dispatch(const WPlan& p, const WArgs& a, int grid, hipStream_t s) {       // as launch_w; 0 = no instantiation for this block shape
   const int key = p.TA * 1000 + p.TB;
   constexpr int K2 = 2;
-  if (key == 128128) launch_w<128, 128, 2, NKW, (NKW * 4 * 2 <= 8 ? K2 : 1), FAST, false>(a, grid, s);
-  else if (key == 128064) launch_w<128, 64, 4, NKW, (NKW * 2 * 2 <= 8 ? K2 : 1), FAST, false>(a, grid, s);
-  else if (key == 128032) launch_w<128, 32, 4, NKW, (NKW * 2 * 1 <= 8 ? K2 : 1), FAST, false>(a, grid, s);
-  else if (key == 64128) launch_w<64, 128, 2, NKW, (NKW * 2 * 2 <= 8 ? K2 : 1), FAST, false>(a, grid, s);
-  else if (key == 64064) launch_w<64, 64, 2, NKW, (NKW * 2 * 1 <= 8 ? K2 : 1), FAST, false>(a, grid, s);
-  else if (key == 64032) launch_w<64, 32, 4, NKW, (NKW * 1 * 1 <= 8 ? K2 : 1), FAST, false>(a, grid, s);
-  else if (key == 32128) launch_w<32, 128, 1, NKW, (NKW * 2 * 1 <= 8 ? K2 : 1), FAST, false>(a, grid, s);
-  else if (key == 32064) launch_w<32, 64, 2, NKW, (NKW * 1 * 1 <= 8 ? K2 : 1), FAST, false>(a, grid, s);
-  else return false;
-  return true;
+  if (key == 128128) return launch_w<128, 128, 2, NKW, (NKW * 4 * 2 <= 8 ? K2 : 1), FAST, false>(a, grid, s);
+  else if (key == 128064) return launch_w<128, 64, 4, NKW, (NKW * 2 * 2 <= 8 ? K2 : 1), FAST, false>(a, grid, s);
+  else if (key == 128032) return launch_w<128, 32, 4, NKW, (NKW * 2 * 1 <= 8 ? K2 : 1), FAST, false>(a, grid, s);
+  else if (key == 64128) return launch_w<64, 128, 2, NKW, (NKW * 2 * 2 <= 8 ? K2 : 1), FAST, false>(a, grid, s);
+  else if (key == 64064) return launch_w<64, 64, 2, NKW, (NKW * 2 * 1 <= 8 ? K2 : 1), FAST, false>(a, grid, s);
+  else if (key == 64032) return launch_w<64, 32, 4, NKW, (NKW * 1 * 1 <= 8 ? K2 : 1), FAST, false>(a, grid, s);
+  else if (key == 32128) return launch_w<32, 128, 1, NKW, (NKW * 2 * 1 <= 8 ? K2 : 1), FAST, false>(a, grid, s);
+  else if (key == 32064) return launch_w<32, 64, 2, NKW, (NKW * 1 * 1 <= 8 ? K2 : 1), FAST, false>(a, grid, s);
+  return 0;
 }
 
 }  // namespace
@@ -568,12 +565,13 @@ extern "C" int fo_conv_wgrad_bf16(const fo_conv_desc* d, const void* P, const vo
   a.wsBias = ws + ws_floats_main(p);
   const int grid = p.tilesA * p.tilesB * p.X * p.wgPerX;
   hipStream_t s = (hipStream_t)stream;
-  bool ok;
-  if (p.smallc) { launch_w<64, 32, 4, 4, 2, true, true>(a, grid, s); ok = true; }
+  int ok;
+  if (p.smallc) ok = launch_w<64, 32, 4, 4, 2, true, true>(a, grid, s);
   else if (p.fast && p.NKW == 3) ok = dispatch<3, true>(p, a, grid, s);
   else if (p.fast && p.NKW == 4) ok = dispatch<4, true>(p, a, grid, s);
   else if (p.fast) ok = dispatch<1, true>(p, a, grid, s);
   else ok = dispatch<1, false>(p, a, grid, s);
+  if (ok < 0) return FO_E_HIP;
   FO_REQUIRE(ok, FO_E_SHAPE, "wgrad_bf16: no kernel for a %d x %d block with %d taps per workgroup", p.TA, p.TB, p.NKW);
   FO_CHECK_LAUNCH();
   const long long total = (long long)Areal * Breal * p.taps + (dbias ? Areal : 0);

@@ -596,15 +596,8 @@ extern "C" int fo_wino_gemm_split(const float* V, const float* U, void* U3, floa
     const int maxUseful = ((a.tiles + 7) / 8) * 8;
     if (grid > maxUseful) grid = maxUseful;
     constexpr int ldsBytes = 18 * PIECE;
-    static bool attr256 = false;
-    if (!attr256) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(wino_gemm_split256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, ldsBytes) !=
-          hipSuccess) {
-        fo_set_error("wino_gemm_split: cannot reserve %d bytes of LDS", ldsBytes);
-        return FO_E_HIP;
-      }
-      attr256 = true;
-    }
+    static fo_lds_once once256;
+    if (!fo_lds_optin(once256, reinterpret_cast<const void*>(wino_gemm_split256_kernel), ldsBytes, "wino_gemm_split256")) return FO_E_HIP;
     hipLaunchKernelGGL(wino_gemm_split256_kernel, dim3(grid), dim3(512), ldsBytes, (hipStream_t)stream, a);
     FO_CHECK_LAUNCH();
     return FO_OK;
@@ -614,15 +607,8 @@ extern "C" int fo_wino_gemm_split(const float* V, const float* U, void* U3, floa
   const int maxUseful = ((a.tiles + 7) / 8) * 8;
   if (grid > maxUseful) grid = maxUseful;
   constexpr int ldsBytes = 9 * PIECE;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(wino_gemm_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, ldsBytes) !=
-        hipSuccess) {
-      fo_set_error("wino_gemm_split: cannot reserve %d bytes of LDS", ldsBytes);
-      return FO_E_HIP;
-    }
-    attr_set = true;
-  }
+  static fo_lds_once once;
+  if (!fo_lds_optin(once, reinterpret_cast<const void*>(wino_gemm_split_kernel), ldsBytes, "wino_gemm_split")) return FO_E_HIP;
   hipLaunchKernelGGL(wino_gemm_split_kernel, dim3(grid), dim3(256), ldsBytes, (hipStream_t)stream, a);
   FO_CHECK_LAUNCH();
   return FO_OK;

@@ -441,7 +441,13 @@ class VQVAEEngine:
         L = self.layers
         c3, c1 = L[prefix + ".conv.3"], L[prefix + ".conv.1"]
         g_h = torch.empty_like(hbuf)
-        if self.fused_resblock_bwd and not self.bf16 and g_out.shape[-1] == 128:
+        fused = self.fused_resblock_bwd and not self.bf16 and g_out.shape[-1] == 128
+        if fused and max(g_out.numel(), 4 * hbuf.numel()) * 4 + 512 >= 2 ** 31:
+            # fo_resblock_bwd_conv3 addresses g_out / h / g_h with 32-bit buffer offsets (FO_E_SHAPE from 2 GiB up): three launches instead
+            ops._log_once(("resblock_bwd_conv3", tuple(g_out.shape)), f"faceoff_amd: resblock backward on {tuple(g_out.shape)}: tensors of 2 GiB "
+                          "and more take the three-launch path (1x1 filter gradient, data gradient) instead of fo_resblock_bwd_conv3")
+            fused = False
+        if fused:
             # the 1x1's data, filter and bias gradients in one pass over g_out (three launches streamed it three times, each at the HBM roof)
             ops.resblock_bwd_conv3(g_out, hbuf, c3.wp, g_h, c3.gw, c3.gb)
             self._ready(c3.name)

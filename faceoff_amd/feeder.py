@@ -25,9 +25,11 @@ class HostFedBatches:
     being copied on a side stream.  Pinned staging buffers are allocated once (a loader built with pin_memory=True skips the staging copy)."""
 
     def __init__(self, loader, device, depth=2):
+        if int(depth) < 2:
+            raise ValueError(f"faceoff_amd: HostFedBatches needs depth >= 2 (one slot being read by the step, one being filled), got {depth}")
         self.loader = loader
         self.device = torch.device(device)
-        self.depth = depth
+        self.depth = int(depth)
         self.copy_stream = torch.cuda.Stream(device=self.device)
         self._dev = [None] * depth         # per slot: (source, background, ground_truth) device tensors
         self._pin = [None] * depth         # per slot: pinned host staging tensors
@@ -38,6 +40,9 @@ class HostFedBatches:
         source, target, background, source_images, _ = data                # (source_images_original stays on the host: SURVEY a0)
         T = source.shape[-4]
         host = [_frames(t) for t in (source, background, source_images)]
+        for h in host:
+            if h.dtype != torch.float32 or h.is_cuda:
+                raise TypeError(f"faceoff_amd: HostFedBatches takes the loader's float32 CPU tensors (ToTensor + Normalize output), got {h.dtype} on {h.device}")
         if self._dev[slot] is None or any(d.shape != h.shape for d, h in zip(self._dev[slot], host)):
             self._dev[slot] = [torch.empty(h.shape, dtype=torch.float32, device=self.device) for h in host]
             self._pin[slot] = [None if h.is_pinned() else torch.empty(h.shape, dtype=torch.float32).pin_memory() for h in host]

@@ -3,7 +3,7 @@ transformations of TemporalAlignment/perturbations.py (:45-105 translate_horizon
 resize_image; composition :208-264 perturb_image_composite, :271-295 perturb_image; ranges TemporalAlignment/ranges.py), applied
 to whole clips [T,C,H,W] of float frames resident in HBM by one warp kernel (fo_affine_warp) instead of per frame with cv2 on
 two CPU loader workers (utils.py:73).  Same function names, argument order and parameter draws (`random.randint` in the
-reference's order, from a `random.Random`).
+reference's order, from a `random.Random`; `draw_composite` is checked live against the reference's own function).
 
 Two frame formats, chosen by dtype:
   * uint8 [N,H,W,C] (or [H,W,C]) -- what cv2 hands the reference.  These go through the kernels of csrc/warp_u8.hip, which follow
@@ -190,25 +190,52 @@ def perturb_image(face_image, rng=None):
     return fn(rng.randint(lo, hi) / div, face_image)
 
 
-def perturb_image_composite(face_image, eyes_center, rng=None):
-    """:208-264 without `distort_image` (Wand): every perturbation is included with probability 1/2 (at least one), values drawn
-    from TemporalAlignment/ranges.py; rotation is about the eye centre.  Returns (frames, gt_transformations)."""
+N_DISTORTIONS = 3               # len(Distortion), TemporalAlignment/perturbations.py:36-39
+
+
+def draw_composite(rng=None):
+    """The random draws of `perturb_image_composite` (:236-262) in the reference's order, on the host: per pass FIVE coins
+    (translate_horizontal, translate_vertical, rotate_image, resize_image, distort_image), repeated until one comes up; then per
+    chosen perturbation its value.  A chosen `distort_image` draws its type from randint(0, len(Distortion)) and, inside the
+    function, the three barrel_inverse parameters (:156-158: `Distortion.X.value` are 1-tuples -- `ARC = 1,` -- so the comparisons
+    at :137,144 are never true and every type takes the last branch); those draws are burned here so that the stream stays the
+    reference's.  Returns [(name, value), ...]; the distortion entry carries (type, (b, c, d))."""
     rng = rng or _random
-    fns = [translate_horizontal, translate_vertical, rotate_image, resize_image]
-    ranges = {translate_horizontal: (-translation_range, translation_range, 1), translate_vertical: (-translation_range, translation_range, 1),
-              rotate_image: (-rotation_range, rotation_range, 1), resize_image: (scale_ranges[0], scale_ranges[1], 100)}
-    gt = {"translate_horizontal": 0, "translate_vertical": 0, "rotate_image": 0}
+    names = ("translate_horizontal", "translate_vertical", "rotate_image", "resize_image", "distort_image")
+    ranges = {"translate_horizontal": (-translation_range, translation_range, 1), "translate_vertical": (-translation_range, translation_range, 1),
+              "rotate_image": (-rotation_range, rotation_range, 1), "resize_image": (scale_ranges[0], scale_ranges[1], 100),
+              "distort_image": (0, N_DISTORTIONS, 1)}
     chosen = []
     while not chosen:
-        chosen = [f for f in fns if rng.randint(0, 1)]
-    for fn in chosen:
-        lo, hi, div = ranges[fn]
+        chosen = [n for n in names if rng.randint(0, 1)]
+    plan = []
+    for n in chosen:
+        lo, hi, div = ranges[n]
         value = rng.randint(lo, hi) / div
-        if fn is translate_horizontal:
-            gt["translate_horizontal"] = value
-        elif fn is translate_vertical:
-            gt["translate_vertical"] = value
+        if n == "distort_image":
+            value = (value, (rng.randint(0, 2) / 10, rng.randint(-5, 0) / 10, rng.randint(10, 10) / 10))
+        plan.append((n, value))
+    return plan
+
+
+def perturb_image_composite(face_image, eyes_center, rng=None, distort_fn=None):
+    """:208-264: every perturbation is included with probability 1/2 (at least one), values drawn from
+    TemporalAlignment/ranges.py in the reference's order (`draw_composite`); rotation is about the eye centre.  `distort_image`
+    (Wand / ImageMagick) is not built: its draws are consumed, and the frames pass through it unchanged unless the caller hands
+    a `distort_fn(type, (b, c, d), frames)`.  Returns (frames, gt_transformations)."""
+    fns = {"translate_horizontal": translate_horizontal, "translate_vertical": translate_vertical, "rotate_image": rotate_image,
+           "resize_image": resize_image}
+    gt = {"translate_horizontal": 0, "translate_vertical": 0, "rotate_image": 0}
+    for name, value in draw_composite(rng):
+        if name == "distort_image":
+            gt["rotate_image"] = value[0]            # (the reference records resize and distortion values under this key too, :253-254)
+            if distort_fn is not None:
+                face_image = distort_fn(value[0], value[1], face_image)
+            continue
+        if name in ("translate_horizontal", "translate_vertical"):
+            gt[name] = value
         else:
-            gt["rotate_image"] = value               # (the reference records resize values under this key too, :253-254)
-        face_image = fn(value, face_image, center=eyes_center) if fn is rotate_image else fn(value, face_image)
+            gt["rotate_image"] = value
+        fn = fns[name]
+        face_image = fn(value, face_image, center=eyes_center) if name == "rotate_image" else fn(value, face_image)
     return face_image, gt

@@ -22,6 +22,11 @@ def test_library_exports_every_declared_symbol():
     missing = [s for s in declared if not hasattr(lib, s)]
     assert not missing, missing
     assert sorted(_lib.SIGNATURES) == declared, set(declared) ^ set(_lib.SIGNATURES)
+    # ... and nothing else: the dynamic symbol table IS the header (csrc/exports.map keeps cross-file helpers local)
+    import subprocess
+    nm = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted(ln.split()[-1] for ln in nm.splitlines() if ln.strip())
+    assert exported == declared, set(exported) ^ set(declared)
     assert _lib.load().fo_version() >= 100            # no compute calls without a GPU
 
 
