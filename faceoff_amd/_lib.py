@@ -101,20 +101,22 @@ SIGNATURES = {
     "fo_conv_wgrad": (_I, [_D, _P, _P, _P, _I, _I, _P, _P, _L, _P]),
     "fo_bias_grad": (_I, [_P, _P, _L, _I, _I, _I, _P, _P]),
     "fo_vq_prepare": (_I, [_P, _P, _P, _P]),
-    "fo_vq_assign": (_I, [_P, _I, _L, _P, _P, _P, _P, _I, _P, _P]),
+    "fo_vq_assign_ws_bytes": (_L, []),
+    "fo_vq_assign": (_I, [_P, _I, _L, _P, _P, _P, _P, _I, _P, _P, _P]),
     "fo_vq_stats_ws_bytes": (_L, [_L]),
     "fo_vq_stats": (_I, [_P, _I, _L, _P, _P, _P, _P, _P]),
     "fo_vq_ema": (_I, [_P, _P, _P, _P, _P, _F, _F, _F, _P]),
     "fo_vq_bwd": (_I, [_P, _I, _P, _I, _P, _I, _P, _F, _P, _I, _L, _P]),
     "fo_vq_gather": (_I, [_P, _P, _P, _I, _L, _P]),
-    "fo_mse_slice_fwd": (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _P]),
+    "fo_mse_slice_fwd": (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _P, _P]),
     "fo_mse_slice_bwd": (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _F, _P, _I, _P]),
-    "fo_mse_slice_fwd_bwd": (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _F, _P, _I, _P, _P]),
+    "fo_mse_slice_fwd_bwd": (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _F, _P, _I, _P, _P, _P]),
     "fo_lpips_prep": (_I, [_P, _I, _I, _P, _I, _I, _I, _P, _P, _P]),
     "fo_lpips_prep_bwd": (_I, [_P, _I, _P, _I, _L, _P, _P, _F, _P]),
     "fo_maxpool2_fwd": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "fo_maxpool2_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
-    "fo_lpips_tap_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "fo_lpips_tap_ws_bytes": (_L, [_I, _I, _I]),
+    "fo_lpips_tap_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "fo_lpips_tap_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "fo_pack_conv_bf16": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "fo_pack_conv_dgrad_bf16": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
@@ -128,15 +130,16 @@ SIGNATURES = {
     "fo_f32_to_bf16": (_I, [_P, _L, _P, _L, _L, _I, _P]),
     "fo_bf16_to_f32": (_I, [_P, _L, _P, _L, _L, _I, _P]),
     "fo_nchw2_to_nhwc8_bf16": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _P]),
-    "fo_vq_assign2": (_I, [_P, _I, _L, _P, _P, _P, _P, _I, _P, _P, _I, _P]),
+    "fo_vq_assign2": (_I, [_P, _I, _L, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P]),
     "fo_vq_bwd_bf16": (_I, [_P, _I, _P, _I, _P, _I, _P, _F, _P, _I, _L, _P]),
     "fo_lpips_prep_bf16": (_I, [_P, _I, _I, _P, _I, _I, _I, _P, _P, _P]),
     "fo_lpips_prep_bwd_bf16": (_I, [_P, _P, _I, _L, _P, _P, _F, _P]),
     "fo_maxpool2_fwd_bf16": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "fo_maxpool2_bwd_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
-    "fo_lpips_tap_fwd_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "fo_lpips_tap_ws_bytes_bf16": (_L, [_I, _I, _I, _I]),
+    "fo_lpips_tap_fwd_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "fo_lpips_tap_bwd_bf16": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
-    "fo_lpips_tap_fwd_bwd_bf16": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "fo_lpips_tap_fwd_bwd_bf16": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "fo_adam_flat": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _F, _P]),
     "fo_zero": (_I, [_P, _L, _P]),
     "fo_relu": (_I, [_P, _I, _P, _I, _L, _I, _P]),

@@ -41,6 +41,8 @@ int fo_conv3x3_c32to128_halo_bf16_try(const fo_conv_desc* d, const void* in, con
 // elementwise.hip: out[c] = sum of the nblk partial rows ws[b][C], c < Creal (the second stage of every column sum).
 // Internal (C++ linkage): exports.map keeps everything but the C names of include/faceoff_hip.h out of the dynamic symbol table.
 int fo_colsum_finish(const float* ws, float* out, int nblk, int C, int Creal, void* stream);
+// elementwise.hip: out[0] = part[0] + ... + part[n-1] in a fixed order (one wave): how every loss scalar leaves its kernel's per-workgroup partials
+int fo_ordered_sum(const float* part, int n, float* out, void* stream);
 
 #define FO_CHECK_LAUNCH()                                                     \
   do {                                                                        \

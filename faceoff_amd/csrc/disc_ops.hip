@@ -290,7 +290,7 @@ __global__ __launch_bounds__(1024) void ralsgan_kernel(const float* __restrict__
   for (int i = tid; i < nb; i += 1024) { const float e = b[(long long)i * ld] - ma - tb; l2 += e * e; }
   l1 = block_sum(l1, sh) / (float)na;
   l2 = block_sum(l2, sh) / (float)nb;
-  if (tid == 0) atomicAdd(loss_acc, w * (l1 + l2));
+  if (tid == 0) loss_acc[0] += w * (l1 + l2);      // one thread of the launch's only workgroup; launches are ordered on their stream: no atomic needed
   const float gs = w * (gscale ? gscale[0] : 1.f);
   // d/da_i = 2 (a_i - mb - ta) / na  (own term)  -  2 (mb - ma - tb) / na  (through mean(a) in the other term); b likewise
   if (ga)

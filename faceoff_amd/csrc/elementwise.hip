@@ -11,10 +11,32 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// A workgroup's share of a loss sum without float atomics: wave sums (shuffle tree), added in wave order by thread 0, written to part[blockIdx.x];
+// ordered_sum_kernel then adds the partials in a fixed order.  The printed loss is the same bits run after run.
+__device__ __forceinline__ void block_partial(float s, float* __restrict__ part) {
+  __shared__ float wsum[16];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += wsum[w];
+    part[blockIdx.x] = t;
+  }
+}
+
+// out[0] = part[0] + ... + part[n-1]: lane i adds part[i], part[i + 64], ... in order, then a shuffle tree.  One wave.
+__global__ __launch_bounds__(64) void ordered_sum_kernel(const float* __restrict__ part, int n, float* __restrict__ out) {
+  float t = 0.f;
+  for (int i = threadIdx.x; i < n; i += 64) t += part[i];
+  t = wave_sum(t);
+  if (threadIdx.x == 0) out[0] = t;
+}
+
 // criterion = nn.MSELoss() on out[:, :3] (train_faceoff_perceptual.py:21,37-39): dec is NHWC (ld floats
-// per pixel), gt is the loader's NCHW tensor.  Accumulates sum of squares into *sum.
+// per pixel), gt is the loader's NCHW tensor.  One partial sum of squares per workgroup (block_partial).
 __global__ void mse_slice_fwd_kernel(const float* __restrict__ dec, int ldd, const float* __restrict__ gt, int HW,
-                                     long long npix, int C3, float* sum) {
+                                     long long npix, int C3, float* __restrict__ part) {
   float s = 0.f;
   for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < npix; p += (long long)gridDim.x * blockDim.x) {
     const long long n = p / HW;
@@ -25,8 +47,7 @@ __global__ void mse_slice_fwd_kernel(const float* __restrict__ dec, int ldd, con
     for (int c = 0; c < 3; ++c)
       if (c < C3) { const float e = d[c] - g[(long long)c * HW]; s = fmaf(e, e, s); }
   }
-  s = wave_sum(s);
-  if ((threadIdx.x & 63) == 0) atomicAdd(sum, s);
+  block_partial(s, part);
 }
 
 __global__ void mse_slice_bwd_kernel(const float* __restrict__ dec, int ldd, const float* __restrict__ gt, int HW,
@@ -49,7 +70,7 @@ __global__ void mse_slice_bwd_kernel(const float* __restrict__ dec, int ldd, con
 
 // Both at once (the training step needs the loss value AND its gradient; neither depends on the other): one pass over dec and gt.
 __global__ void mse_slice_fwd_bwd_kernel(const float* __restrict__ dec, int ldd, const float* __restrict__ gt, int HW, long long npix, int C3,
-                                         const float* __restrict__ gscale, float inv_numel, float* __restrict__ gdec, int ldg, float* sum) {
+                                         const float* __restrict__ gscale, float inv_numel, float* __restrict__ gdec, int ldg, float* __restrict__ part) {
   const float k = 2.f * inv_numel * gscale[0];
   float s = 0.f;
   for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < npix; p += (long long)gridDim.x * blockDim.x) {
@@ -64,8 +85,7 @@ __global__ void mse_slice_fwd_bwd_kernel(const float* __restrict__ dec, int ldd,
     *reinterpret_cast<f32x4*>(gdec + p * ldg) = o;
     for (int c = 4; c < ldg; c += 4) *reinterpret_cast<f32x4*>(gdec + p * ldg + c) = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  s = wave_sum(s);
-  if ((threadIdx.x & 63) == 0) atomicAdd(sum, s);
+  block_partial(s, part);
 }
 
 // column sums of g[M][ld] (first C channels): stage 1 -> ws[block][C], stage 2 sums blocks in order
@@ -159,15 +179,22 @@ inline int grid_for(long long total, int cap = 4096) {
 
 }  // namespace
 
-extern "C" {
-
-int fo_mse_slice_fwd(const float* dec, int ldd, const float* gt_nchw, int N, int H, int W, int C3, float* sum, void* stream) {
-  FO_REQUIRE(C3 <= 3 && ldd % 4 == 0, FO_E_SHAPE, "mse: at most 3 channels, ld %% 4 == 0");
-  const long long npix = (long long)N * H * W;
-  hipLaunchKernelGGL(mse_slice_fwd_kernel, dim3(grid_for(npix, 2048)), dim3(256), 0, (hipStream_t)stream, dec, ldd, gt_nchw,
-                     H * W, npix, C3, sum);
+// out[0] = the sum of n partials in a fixed order (internal: the finish launch of every loss sum in this library)
+int fo_ordered_sum(const float* part, int n, float* out, void* stream) {
+  hipLaunchKernelGGL(ordered_sum_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, part, n, out);
   FO_CHECK_LAUNCH();
   return FO_OK;
+}
+
+extern "C" {
+
+int fo_mse_slice_fwd(const float* dec, int ldd, const float* gt_nchw, int N, int H, int W, int C3, float* sum, float* ws, void* stream) {
+  FO_REQUIRE(C3 <= 3 && ldd % 4 == 0 && ws && sum, FO_E_SHAPE, "mse: at most 3 channels, ld %% 4 == 0, a workspace of FO_LOSS_WS_BYTES");
+  const long long npix = (long long)N * H * W;
+  const int grid = grid_for(npix, 2048);
+  hipLaunchKernelGGL(mse_slice_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dec, ldd, gt_nchw, H * W, npix, C3, ws);
+  FO_CHECK_LAUNCH();
+  return fo_ordered_sum(ws, grid, sum, stream);
 }
 
 int fo_mse_slice_bwd(const float* dec, int ldd, const float* gt_nchw, int N, int H, int W, int C3, const float* gscale,
@@ -181,13 +208,14 @@ int fo_mse_slice_bwd(const float* dec, int ldd, const float* gt_nchw, int N, int
 }
 
 int fo_mse_slice_fwd_bwd(const float* dec, int ldd, const float* gt_nchw, int N, int H, int W, int C3, const float* gscale,
-                         float inv_numel, float* gdec, int ldg, float* sum, void* stream) {
-  FO_REQUIRE(C3 <= 3 && ldd % 4 == 0 && ldg % 4 == 0, FO_E_SHAPE, "mse: at most 3 channels, ld %% 4 == 0");
+                         float inv_numel, float* gdec, int ldg, float* sum, float* ws, void* stream) {
+  FO_REQUIRE(C3 <= 3 && ldd % 4 == 0 && ldg % 4 == 0 && ws && sum, FO_E_SHAPE, "mse: at most 3 channels, ld %% 4 == 0, a workspace of FO_LOSS_WS_BYTES");
   const long long npix = (long long)N * H * W;
-  hipLaunchKernelGGL(mse_slice_fwd_bwd_kernel, dim3(grid_for(npix, 4096)), dim3(256), 0, (hipStream_t)stream, dec, ldd, gt_nchw, H * W, npix,
-                     C3, gscale, inv_numel, gdec, ldg, sum);
+  const int grid = grid_for(npix, 4096);
+  hipLaunchKernelGGL(mse_slice_fwd_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dec, ldd, gt_nchw, H * W, npix,
+                     C3, gscale, inv_numel, gdec, ldg, ws);
   FO_CHECK_LAUNCH();
-  return FO_OK;
+  return fo_ordered_sum(ws, grid, sum, stream);
 }
 
 int fo_bias_grad(const float* g, float* dbias, int64_t M, int C, int Creal, int ld, float* ws, void* stream) {

@@ -107,10 +107,11 @@ __global__ void maxpool2_bwd_kernel(const float* __restrict__ x, const float* __
 }
 
 // LPIPS head for one tap (lpips.py:85-89,155-161): one wave per pixel, lane holds CPL = C/64 channels.
-//   n0 = f0 / (||f0|| + eps), n1 = f1 / (||f1|| + eps);  val[n] += sum_c lin_c (n0_c - n1_c)^2 / (H*W)
+//   n0 = f0 / (||f0|| + eps), n1 = f1 / (||f1|| + eps);  pix[p] = sum_c lin_c (n0_c - n1_c)^2; lpips_pix_finish_kernel: val[n] += mean over the
+//   frame's pixels, added in pixel order (no float atomics: the printed loss is reproducible bit for bit)
 template <int CPL>
 __global__ void lpips_head_fwd_kernel(const float* __restrict__ f0, const float* __restrict__ f1, const float* __restrict__ lin,
-                                      float* __restrict__ val, int HW, long long npix, float inv_hw) {
+                                      float* __restrict__ pix, long long npix) {
   constexpr int C = CPL * 64;
   const int lane = threadIdx.x & 63;
   const long long wave = (blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 6;
@@ -133,8 +134,16 @@ __global__ void lpips_head_fwd_kernel(const float* __restrict__ f0, const float*
 #pragma unroll
     for (int k = 0; k < CPL; ++k) { const float r = a[k] * ia - b[k] * ib; acc = fmaf(w[k] * r, r, acc); }
     acc = wave_sum(acc);
-    if (lane == 0) atomicAdd(&val[p / HW], acc * inv_hw);
+    if (lane == 0) pix[p] = acc;
   }
+}
+
+__global__ __launch_bounds__(64) void lpips_pix_finish_kernel(const float* __restrict__ pix, float* __restrict__ val, int HW, float inv_hw) {
+  const long long n = blockIdx.x;
+  float t = 0.f;
+  for (int i = threadIdx.x; i < HW; i += 64) t += pix[n * HW + i];
+  t = wave_sum(t);
+  if (threadIdx.x == 0) val[n] += t * inv_hw;
 }
 
 // Gradient wrt f1 (the reconstruction branch), through the normalisation and through f1's own ReLU:
@@ -225,18 +234,20 @@ int fo_maxpool2_bwd(const float* x, const float* gy, const float* add, float* gx
   return FO_OK;
 }
 
-int fo_lpips_tap_fwd(const float* f0, const float* f1, const float* lin, float* val, int N, int H, int W, int C, void* stream) {
+int64_t fo_lpips_tap_ws_bytes(int N, int H, int W) { return (int64_t)N * H * W * 4 + 1024; }      // one float per pixel
+
+int fo_lpips_tap_fwd(const float* f0, const float* f1, const float* lin, float* val, int N, int H, int W, int C, float* ws, void* stream) {
+  FO_REQUIRE(ws && (C == 64 || C == 128 || C == 256 || C == 512), FO_E_SHAPE, "lpips_tap: C must be 64/128/256/512 (got %d), and a workspace", C);
   const long long npix = (long long)N * H * W;
   const int grid = grid_for(npix * 64, 4096);
-  const float inv = 1.f / (float)(H * W);
-#define FO_HEAD_FWD(CPL_) \
-  hipLaunchKernelGGL(lpips_head_fwd_kernel<CPL_>, dim3(grid), dim3(256), 0, (hipStream_t)stream, f0, f1, lin, val, H * W, npix, inv)
+#define FO_HEAD_FWD(CPL_) hipLaunchKernelGGL(lpips_head_fwd_kernel<CPL_>, dim3(grid), dim3(256), 0, (hipStream_t)stream, f0, f1, lin, ws, npix)
   if (C == 64) FO_HEAD_FWD(1);
   else if (C == 128) FO_HEAD_FWD(2);
   else if (C == 256) FO_HEAD_FWD(4);
-  else if (C == 512) FO_HEAD_FWD(8);
-  else FO_REQUIRE(false, FO_E_SHAPE, "lpips_tap: C must be 64/128/256/512 (got %d)", C);
+  else FO_HEAD_FWD(8);
 #undef FO_HEAD_FWD
+  FO_CHECK_LAUNCH();
+  hipLaunchKernelGGL(lpips_pix_finish_kernel, dim3(N), dim3(64), 0, (hipStream_t)stream, ws, val, H * W, 1.f / (float)(H * W));
   FO_CHECK_LAUNCH();
   return FO_OK;
 }

@@ -112,10 +112,12 @@ __global__ void maxpool2_bwd_bf16_kernel(const bf16x8* __restrict__ x, const bf1
 }
 
 // LPIPS head for one tap: LPP = C/8 lanes per pixel (a lane holds 8 channels = 16 B), 64/LPP pixels per wave pass.
-// Every wave walks a contiguous range of pixels and keeps a running sum per frame: one atomic per wave and frame.
+// Every wave walks a contiguous range of pixels and keeps a running sum per frame.  No float atomics: wave w writes the sum it holds for frame n
+// to slot[w * S + (n - first frame of w)] (S = the most frames a range can touch); lpips_val_finish_kernel adds a frame's slots in wave order.
+// Tiny maps (H W < 64, where a pass may span frames) write one value per PIXEL instead, summed per frame in pixel order.
 template <int LPP>
 __global__ void lpips_head_fwd_bf16_kernel(const bf16x8* __restrict__ f0, const bf16x8* __restrict__ f1, const float* __restrict__ lin,
-                                           float* __restrict__ val, int HW, long long npix, float inv_hw) {
+                                           float* __restrict__ slot, int HW, long long npix, int S) {
   constexpr int PPW = 64 / LPP;
   const int lane = threadIdx.x & 63;
   const int sub = lane % LPP, pl = lane / LPP;
@@ -123,6 +125,7 @@ __global__ void lpips_head_fwd_bf16_kernel(const bf16x8* __restrict__ f0, const 
   const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
   const long long per = ((npix + nwaves - 1) / nwaves + PPW - 1) / PPW * PPW;
   const long long p_begin = wave * per, p_end = min(npix, p_begin + per);
+  float* const myslot = slot + wave * S - p_begin / HW;       // myslot[n]: this wave's sum for frame n
   float w[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) w[k] = lin[sub * 8 + k];
@@ -142,9 +145,9 @@ __global__ void lpips_head_fwd_bf16_kernel(const bf16x8* __restrict__ f0, const 
 #pragma unroll
     for (int k = 0; k < 8; ++k) { const float r = (float)a[k] * ia - (float)b[k] * ib; acc = fmaf(w[k] * r, r, acc); }
     acc = ok ? acc : 0.f;
-    if (HW < 64) {   // tiny maps: a pass may span several frames -- one atomic per pixel (there are few)
+    if (HW < 64) {   // tiny maps: a pass may span several frames -- one value per pixel (there are few)
       acc = group_sum<LPP>(acc);
-      if (ok && sub == 0) atomicAdd(&val[p / HW], acc * inv_hw);
+      if (ok && sub == 0) slot[p] = acc;
       continue;
     }
     // frames of the first and last pixel of this pass (wave-uniform); a pass straddles at most two frames when PPW <= HW
@@ -152,7 +155,7 @@ __global__ void lpips_head_fwd_bf16_kernel(const bf16x8* __restrict__ f0, const 
     const long long last = min(p0 + PPW, p_end) - 1;
     const long long n_last = last / HW;
     if (n_first != run_n) {
-      if (run_n >= 0) { const float t = group_sum<64>(run); if (lane == 0) atomicAdd(&val[run_n], t * inv_hw); }
+      if (run_n >= 0) { const float t = group_sum<64>(run); if (lane == 0) myslot[run_n] = t; }
       run = 0.f; run_n = n_first;
     }
     if (n_last == n_first) {
@@ -161,12 +164,12 @@ __global__ void lpips_head_fwd_bf16_kernel(const bf16x8* __restrict__ f0, const 
       const bool mine = (pp / HW) == n_first;
       run += mine ? acc : 0.f;
       const float t = group_sum<64>(run);
-      if (lane == 0) atomicAdd(&val[run_n], t * inv_hw);
+      if (lane == 0) myslot[run_n] = t;
       run = mine ? 0.f : acc;
       run_n = n_last;
     }
   }
-  if (run_n >= 0) { const float t = group_sum<64>(run); if (lane == 0) atomicAdd(&val[run_n], t * inv_hw); }
+  if (run_n >= 0) { const float t = group_sum<64>(run); if (lane == 0) myslot[run_n] = t; }
 }
 
 // gradient wrt f1 through the normalisation and f1's own ReLU (see lpips.hip), rounded to bf16 once
@@ -213,8 +216,8 @@ __global__ void lpips_head_bwd_bf16_kernel(const bf16x8* __restrict__ f0, const 
 // lpips_head_bwd_bf16_kernel from the same loads.  Saves one read of both maps per tap (2.7 GB at relu1_2).
 template <int LPP>
 __global__ void lpips_head_fwd_bwd_bf16_kernel(const bf16x8* __restrict__ f0, const bf16x8* __restrict__ f1, const float* __restrict__ lin,
-                                               float* __restrict__ val, const float* __restrict__ gscale, bf16x8* __restrict__ gf1, int HW,
-                                               long long npix, float inv_hw, float k_scale) {
+                                               float* __restrict__ slot, const float* __restrict__ gscale, bf16x8* __restrict__ gf1, int HW,
+                                               long long npix, int S, float k_scale) {
   constexpr int PPW = 64 / LPP;
   const int lane = threadIdx.x & 63;
   const int sub = lane % LPP, pl = lane / LPP;
@@ -222,6 +225,7 @@ __global__ void lpips_head_fwd_bwd_bf16_kernel(const bf16x8* __restrict__ f0, co
   const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
   const long long per = ((npix + nwaves - 1) / nwaves + PPW - 1) / PPW * PPW;
   const long long p_begin = wave * per, p_end = min(npix, p_begin + per);
+  float* const myslot = slot + wave * S - p_begin / HW;       // myslot[n]: this wave's sum for frame n
   const float gk = gscale[0] * k_scale;
   float w[8];
 #pragma unroll
@@ -254,16 +258,16 @@ __global__ void lpips_head_fwd_bwd_bf16_kernel(const bf16x8* __restrict__ f0, co
     for (int k = 0; k < 8; ++k) rr[k] = (__bf16)((float)b[k] > 0.f ? gn[k] * ib - (float)b[k] * c2 : 0.f);
     if (ok) gf1[p * LPP + sub] = rr;
     acc = ok ? acc : 0.f;
-    if (HW < 64) {   // tiny maps: a pass may span several frames -- one atomic per pixel (there are few)
+    if (HW < 64) {   // tiny maps: a pass may span several frames -- one value per pixel (there are few)
       acc = group_sum<LPP>(acc);
-      if (ok && sub == 0) atomicAdd(&val[p / HW], acc * inv_hw);
+      if (ok && sub == 0) slot[p] = acc;
       continue;
     }
     const long long n_first = p0 / HW;
     const long long last = min(p0 + PPW, p_end) - 1;
     const long long n_last = last / HW;
     if (n_first != run_n) {
-      if (run_n >= 0) { const float t = group_sum<64>(run); if (lane == 0) atomicAdd(&val[run_n], t * inv_hw); }
+      if (run_n >= 0) { const float t = group_sum<64>(run); if (lane == 0) myslot[run_n] = t; }
       run = 0.f; run_n = n_first;
     }
     if (n_last == n_first) {
@@ -272,16 +276,44 @@ __global__ void lpips_head_fwd_bwd_bf16_kernel(const bf16x8* __restrict__ f0, co
       const bool mine = (pp / HW) == n_first;
       run += mine ? acc : 0.f;
       const float t = group_sum<64>(run);
-      if (lane == 0) atomicAdd(&val[run_n], t * inv_hw);
+      if (lane == 0) myslot[run_n] = t;
       run = mine ? 0.f : acc;
       run_n = n_last;
     }
   }
-  if (run_n >= 0) { const float t = group_sum<64>(run); if (lane == 0) atomicAdd(&val[run_n], t * inv_hw); }
+  if (run_n >= 0) { const float t = group_sum<64>(run); if (lane == 0) myslot[run_n] = t; }
 }
 
 inline int grid_for(long long total, int cap = 4096) {
   return (int)std::max<long long>(1, std::min<long long>((total + 255) / 256, cap));
+}
+
+// val[n] += inv_hw * (the head kernels' sums for frame n, in a fixed order): one wave per frame; lane i adds every 64th slot (pixel) in order,
+// then a shuffle tree.  `per` / S as the head kernel computed them (head_plan).
+__global__ __launch_bounds__(64) void lpips_val_finish_kernel(const float* __restrict__ slot, float* __restrict__ val, int HW, long long npix,
+                                                              long long per, int S, float inv_hw) {
+  const long long n = blockIdx.x;
+  const int lane = threadIdx.x;
+  float t = 0.f;
+  if (HW < 64) {
+    for (int i = lane; i < HW; i += 64) t += slot[n * HW + i];
+  } else {
+    const long long w0 = (n * HW) / per, w1 = (min((n + 1) * HW, npix) - 1) / per;
+    for (long long w = w0 + lane; w <= w1; w += 64) t += slot[w * S + (n - (w * per) / HW)];
+  }
+  t = group_sum<64>(t);
+  if (lane == 0) val[n] += t * inv_hw;
+}
+
+struct HeadPlan { long long per; int S; long long floats; };
+// the pixel range per wave and the slot count of a head launch of `grid` workgroups of 4 waves, PPW pixels per pass
+inline HeadPlan head_plan(long long npix, int HW, int grid, int PPW) {
+  const long long nwaves = (long long)grid * 4;
+  HeadPlan h;
+  h.per = ((npix + nwaves - 1) / nwaves + PPW - 1) / PPW * PPW;
+  h.S = (int)((h.per + HW - 1) / HW) + 1;
+  h.floats = HW < 64 ? npix : nwaves * h.S;
+  return h;
 }
 
 }  // namespace
@@ -328,39 +360,51 @@ int fo_maxpool2_bwd_bf16(const void* x, const void* gy, const void* add, void* g
   return FO_OK;
 }
 
-int fo_lpips_tap_fwd_bf16(const void* f0, const void* f1, const float* lin, float* val, int N, int H, int W, int C, void* stream) {
+int64_t fo_lpips_tap_ws_bytes_bf16(int N, int H, int W, int C) {
+  if (C != 64 && C != 128 && C != 256 && C != 512) return -1;
+  const long long npix = (long long)N * H * W;
+  const long long a = head_plan(npix, H * W, grid_for(npix * (C / 8), 4096), 64 / (C / 8)).floats;      // fwd_bwd's grid
+  const long long b = head_plan(npix, H * W, grid_for(npix * (C / 8), 2048), 64 / (C / 8)).floats;      // fwd's grid
+  return std::max(a, b) * 4 + 1024;
+}
+
+int fo_lpips_tap_fwd_bf16(const void* f0, const void* f1, const float* lin, float* val, int N, int H, int W, int C, float* ws, void* stream) {
+  FO_REQUIRE(ws && (C == 64 || C == 128 || C == 256 || C == 512), FO_E_SHAPE, "lpips_tap_bf16: C must be 64/128/256/512 (got %d), and a workspace", C);
   const long long npix = (long long)N * H * W;
   const int grid = grid_for(npix * (C / 8), 2048);
-  const float inv = 1.f / (float)(H * W);
+  const HeadPlan h = head_plan(npix, H * W, grid, 64 / (C / 8));
 #define FO_HEAD_FWD(LPP_)                                                                                                \
   hipLaunchKernelGGL(lpips_head_fwd_bf16_kernel<LPP_>, dim3(grid), dim3(256), 0, (hipStream_t)stream,                    \
-                     reinterpret_cast<const bf16x8*>(f0), reinterpret_cast<const bf16x8*>(f1), lin, val, H * W, npix, inv)
+                     reinterpret_cast<const bf16x8*>(f0), reinterpret_cast<const bf16x8*>(f1), lin, ws, H * W, npix, h.S)
   if (C == 64) FO_HEAD_FWD(8);
   else if (C == 128) FO_HEAD_FWD(16);
   else if (C == 256) FO_HEAD_FWD(32);
-  else if (C == 512) FO_HEAD_FWD(64);
-  else FO_REQUIRE(false, FO_E_SHAPE, "lpips_tap_bf16: C must be 64/128/256/512 (got %d)", C);
+  else FO_HEAD_FWD(64);
 #undef FO_HEAD_FWD
+  FO_CHECK_LAUNCH();
+  hipLaunchKernelGGL(lpips_val_finish_kernel, dim3(N), dim3(64), 0, (hipStream_t)stream, ws, val, H * W, npix, h.per, h.S, 1.f / (float)(H * W));
   FO_CHECK_LAUNCH();
   return FO_OK;
 }
 
 int fo_lpips_tap_fwd_bwd_bf16(const void* f0, const void* f1, const float* lin, float* val, const float* gscale, void* gf1, int N, int H, int W,
-                              int C, void* stream) {
+                              int C, float* ws, void* stream) {
+  FO_REQUIRE(ws && (C == 64 || C == 128 || C == 256 || C == 512), FO_E_SHAPE, "lpips_tap_bf16: C must be 64/128/256/512 (got %d), and a workspace", C);
   const long long npix = (long long)N * H * W;
   const int grid = grid_for(npix * (C / 8), 4096);
-  const float inv = 1.f / (float)(H * W);
+  const HeadPlan h = head_plan(npix, H * W, grid, 64 / (C / 8));
   const float ks = 1.f / ((float)(H * W) * (float)N);
 #define FO_HEAD_FB(LPP_)                                                                                                 \
   hipLaunchKernelGGL(lpips_head_fwd_bwd_bf16_kernel<LPP_>, dim3(grid), dim3(256), 0, (hipStream_t)stream,                \
-                     reinterpret_cast<const bf16x8*>(f0), reinterpret_cast<const bf16x8*>(f1), lin, val, gscale,          \
-                     reinterpret_cast<bf16x8*>(gf1), H * W, npix, inv, ks)
+                     reinterpret_cast<const bf16x8*>(f0), reinterpret_cast<const bf16x8*>(f1), lin, ws, gscale,           \
+                     reinterpret_cast<bf16x8*>(gf1), H * W, npix, h.S, ks)
   if (C == 64) FO_HEAD_FB(8);
   else if (C == 128) FO_HEAD_FB(16);
   else if (C == 256) FO_HEAD_FB(32);
-  else if (C == 512) FO_HEAD_FB(64);
-  else FO_REQUIRE(false, FO_E_SHAPE, "lpips_tap_bf16: C must be 64/128/256/512 (got %d)", C);
+  else FO_HEAD_FB(64);
 #undef FO_HEAD_FB
+  FO_CHECK_LAUNCH();
+  hipLaunchKernelGGL(lpips_val_finish_kernel, dim3(N), dim3(64), 0, (hipStream_t)stream, ws, val, H * W, npix, h.per, h.S, 1.f / (float)(H * W));
   FO_CHECK_LAUNCH();
   return FO_OK;
 }

@@ -39,9 +39,10 @@ __global__ void vq_prepare_kernel(const float* __restrict__ embed, float* __rest
 __global__ __launch_bounds__(512, 1) void vq_assign_kernel(const float* __restrict__ x, int ldx, long long nvec,
                                                            const float* __restrict__ embedT,
                                                            const float* __restrict__ enorm, long long* __restrict__ ind,
-                                                           float* __restrict__ qout, int ldq, float* sq_sum,
-                                                           __bf16* __restrict__ qb16, int ldqb) {
+                                                           float* __restrict__ qout, int ldq, float* __restrict__ sq_part,
+                                                           __bf16* __restrict__ qb16, int ldqb, const long long* __restrict__ forced) {
   __shared__ float E[VQ_K * VQ_LD + VQ_K];
+  __shared__ float wave_sq[8];
   float* En = E + VQ_K * VQ_LD;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
   for (int idx = tid; idx < VQ_K * VQ_D; idx += 512) E[(idx >> 6) * VQ_LD + (idx & 63)] = embedT[idx];
@@ -67,6 +68,9 @@ __global__ __launch_bounds__(512, 1) void vq_assign_kernel(const float* __restri
 
     float best_d = INFINITY;
     int best_i = 0;
+    if (forced) {       // teacher-forced codes (wave-uniform branch): gather, straight-through and commitment sum on the GIVEN indices
+      best_i = valid ? (int)forced[v] : 0;
+    } else
     for (int ct = 0; ct < VQ_K / 32; ++ct) {
       f32x16 acc;
 #pragma unroll
@@ -81,9 +85,11 @@ __global__ __launch_bounds__(512, 1) void vq_assign_kernel(const float* __restri
         if (d < best_d) { best_d = d; best_i = code; }
       }
     }
-    const float od = __shfl_xor(best_d, 32);
-    const int oi = __shfl_xor(best_i, 32);
-    if (od < best_d || (od == best_d && oi < best_i)) { best_d = od; best_i = oi; }
+    if (!forced) {
+      const float od = __shfl_xor(best_d, 32);
+      const int oi = __shfl_xor(best_i, 32);
+      if (od < best_d || (od == best_d && oi < best_i)) { best_d = od; best_i = oi; }
+    }
     if (half == 0 && valid) ind[v] = best_i;
 
     // gather + straight-through: the wave walks its 32 vectors, 64 lanes = 64 dims.  The x rows (this layout: lane = dimension)
@@ -102,11 +108,20 @@ __global__ __launch_bounds__(512, 1) void vq_assign_kernel(const float* __restri
       }
     }
   }
-  // commitment sum: wave reduce, then one atomic per wave
+  // commitment sum without atomics: wave reduce, the eight waves' sums added in wave order, one partial per workgroup; fo_ordered_sum
+  // adds the partials in workgroup order -- the printed latent loss is the same bits run after run
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
-  if (lane == 0) atomicAdd(sq_sum, sq);
+  if (lane == 0) wave_sq[wave] = sq;
+  __syncthreads();
+  if (tid == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) t += wave_sq[w];
+    sq_part[blockIdx.x] = t;
+  }
 }
+
 
 // EMA statistics (:60-61): counts[c] = #vectors assigned to c, esum[c][:] = sum of those vectors.
 // The reference builds a [Nvec,512] one-hot and runs a second sgemm; here each workgroup keeps a private [512][64] table in LDS,
@@ -272,21 +287,23 @@ int fo_vq_prepare(const float* embed, float* embedT, float* enorm, void* stream)
   return FO_OK;
 }
 
+int64_t fo_vq_assign_ws_bytes() { return 4096; }      // one float per workgroup (one workgroup per CU)
+
 int fo_vq_assign2(const float* x, int ldx, int64_t nvec, const float* embedT, const float* enorm, int64_t* ind,
-                  float* q_ste, int ldq, float* sq_sum, void* q_bf16, int ldqb, void* stream) {
-  FO_REQUIRE(nvec > 0 && ldx >= VQ_D && ldq >= VQ_D && (!q_bf16 || ldqb >= VQ_D), FO_E_SHAPE, "vq_assign: bad shape");
+                  float* q_ste, int ldq, float* sq_sum, void* q_bf16, int ldqb, const int64_t* forced_ind, float* ws, void* stream) {
+  FO_REQUIRE(nvec > 0 && ldx >= VQ_D && ldq >= VQ_D && (!q_bf16 || ldqb >= VQ_D) && ws && sq_sum, FO_E_SHAPE, "vq_assign: bad shape / null workspace");
   const int cus = fo_cu_count();
   const int64_t ntiles = (nvec + 31) / 32;
-  const int grid = (int)std::min<int64_t>(cus, (ntiles + 7) / 8);
+  const int grid = (int)std::min<int64_t>(std::min(cus, 1024), (ntiles + 7) / 8);
   hipLaunchKernelGGL(vq_assign_kernel, dim3(grid), dim3(512), 0, (hipStream_t)stream, x, ldx, (long long)nvec, embedT, enorm,
-                     (long long*)ind, q_ste, ldq, sq_sum, reinterpret_cast<__bf16*>(q_bf16), ldqb);
+                     (long long*)ind, q_ste, ldq, ws, reinterpret_cast<__bf16*>(q_bf16), ldqb, (const long long*)forced_ind);
   FO_CHECK_LAUNCH();
-  return FO_OK;
+  return fo_ordered_sum(ws, grid, sq_sum, stream);
 }
 
 int fo_vq_assign(const float* x, int ldx, int64_t nvec, const float* embedT, const float* enorm, int64_t* ind,
-                 float* q_ste, int ldq, float* sq_sum, void* stream) {
-  return fo_vq_assign2(x, ldx, nvec, embedT, enorm, ind, q_ste, ldq, sq_sum, nullptr, 0, stream);
+                 float* q_ste, int ldq, float* sq_sum, float* ws, void* stream) {
+  return fo_vq_assign2(x, ldx, nvec, embedT, enorm, ind, q_ste, ldq, sq_sum, nullptr, 0, nullptr, ws, stream);
 }
 
 int64_t fo_vq_stats_ws_bytes(int64_t nvec) { return (int64_t)stats_blocks(nvec) * (VQ_K * VQ_D + VQ_K) * 4; }

@@ -571,7 +571,8 @@ class VQVAEEngine:
         f32 = torch.float32        # the quantisers' inputs stay fp32 in either engine (VQ distances, arg-min and commitment loss are fp32)
         qt_in = self._new(N, h8, w8, 64, f32); L["quantize_conv_t"].fwd(d3, qt_in)
         quant_t = self._new(N, h8, w8, 64)
-        id_t, stats_t, S["quant_t_f32"] = self._quantize("quantize_t", qt_in, quant_t, training)
+        force = S.get("_force_ids") or (None, None)          # teacher-forced codes (parity tests: forward(force_ids=...))
+        id_t, stats_t, S["quant_t_f32"] = self._quantize("quantize_t", qt_in, quant_t, training, force[0])
         u0 = self._new(N, h8, w8, 128); L["dec_t.blocks.0"].fwd(quant_t, u0)
         u1 = self._new(N, h8, w8, 128); S["h_dt1"] = self._resblock_fwd("dec_t.blocks.1", u0, u1, False)
         u2 = self._new(N, h8, w8, 128); S["h_dt2"] = self._resblock_fwd("dec_t.blocks.2", u1, u2, True)
@@ -580,7 +581,7 @@ class VQVAEEngine:
             torch.cuda.current_stream().wait_event(S.pop("_join_conv3d_b"))
         qb_in = self._new(N, h4, w4, 64, f32); L["quantize_conv_b"].fwd(cat_b, qb_in)
         cat_d = self._new(N, h4, w4, 128)
-        id_b, stats_b, S["quant_b_f32"] = self._quantize("quantize_b", qb_in, cat_d[..., 64:128], training)
+        id_b, stats_b, S["quant_b_f32"] = self._quantize("quantize_b", qb_in, cat_d[..., 64:128], training, force[1])
         S.update(qt_in=qt_in, quant_t=quant_t, u0=u0, u1=u1, u2=u2, qb_in=qb_in, cat_d=cat_d, id_t=id_t, id_b=id_b)
         S["_vq_stats"] = (stats_t, stats_b)      # read by the codebook update on its side stream: alive until S goes (after the join)
         # diff = diff_t + diff_b, each mean((q - x)^2) (:77,268,276,278)
@@ -610,10 +611,12 @@ class VQVAEEngine:
         dec = torch.empty((N, 4 * h4, 4 * w4, 8), device=self.device); L["dec.blocks.6"].fwd(w1, dec)   # (fp32 in either engine; every pixel, all 8 floats, is written)
         S.update(v0=v0, v1=v1, v2=v2, w1=w1, dec=dec)
 
-    def forward(self, img_nchw, training=True, T=None):
+    def forward(self, img_nchw, training=True, T=None, force_ids=None):
         """VQVAE.forward (:243-259).  img_nchw [N,6,H,W] (N = B*T frames), or the pair (source, background) of
         [N,3,H,W] tensors process_data would concatenate (utils.py:32) -- the cat then happens inside the layout kernel.
-        Returns S: dict of saved activations incl. S[dec] NHWC [N,H,W,8], S[diff] [1], S[id_t], S[id_b]."""
+        Returns S: dict of saved activations incl. S[dec] NHWC [N,H,W,8], S[diff] [1], S[id_t], S[id_b].
+        force_ids = (id_t [N,H/8,W/8], id_b [N,H/4,W/4]): teacher-forced codes -- both quantisers skip the search and use these
+        (gather, straight-through value, commitment loss and EMA statistics all on the given codes); everything else is the step."""
         parts = None
         if isinstance(img_nchw, (tuple, list)):
             parts = img_nchw
@@ -632,6 +635,8 @@ class VQVAEEngine:
         else:
             x8 = ops.cat_nchw_to_nhwc8(*parts) if parts is not None else ops.nchw_to_nhwc(img_nchw, cpad=ops.pad_in(Cin))
         S = {"T": T, "x8": x8}
+        if force_ids is not None:
+            S["_force_ids"] = tuple(force_ids)
         self.stage_encode(S)
         self.stage_conv3d(S)
         self.stage_quantize(S, training, join=False)
@@ -640,16 +645,16 @@ class VQVAEEngine:
             torch.cuda.current_stream().wait_stream(self.vq_stream)
         return S
 
-    def _quantize(self, name, x, q_out, training):
+    def _quantize(self, name, x, q_out, training, force_ind=None):
         if self.vq_stream is not None:       # the previous step's codebook update (long finished; the join is what orders it)
             torch.cuda.current_stream().wait_stream(self.vq_stream)
         embedT, enorm = ops.vq_prepare(self.buffers[name + ".embed"])
         stats = torch.zeros(1 + 512 + 512 * 64, device=self.device)
         if self.bf16:        # the straight-through output twice: fp32 (kept for the backward's 2 (x - q) / numel term), bf16 for the next conv
             q32 = torch.empty(x.shape, device=self.device, dtype=torch.float32)
-            ind = ops.vq_assign_bf16out(x, embedT, enorm, q32, q_out, stats, training, stats_stream=self.vq_stream)
+            ind = ops.vq_assign_bf16out(x, embedT, enorm, q32, q_out, stats, training, stats_stream=self.vq_stream, force_ind=force_ind)
             return ind, stats, q32
-        ind = ops.vq_assign(x, embedT, enorm, q_out, stats, training, stats_stream=self.vq_stream)
+        ind = ops.vq_assign(x, embedT, enorm, q_out, stats, training, stats_stream=self.vq_stream, force_ind=force_ind)
         return ind, stats, None
 
     def _vq_bwd(self, gq, x, q, q32, g_diff):
@@ -777,10 +782,10 @@ class VQVAEEngine:
             torch.cuda.current_stream().wait_stream(self.wgrad_stream)
 
     # ------------------------------------------------------------------ fused train step (bench / trainer fast path)
-    def loss_and_backward(self, img_nchw, gt_nchw, T=None, latent_weight=1.0):
+    def loss_and_backward(self, img_nchw, gt_nchw, T=None, latent_weight=1.0, force_ids=None):
         """run_step + backward (train_faceoff_perceptual.py:32-47,98-100) for recon + latent loss.
-        Returns device scalars (recon, latent).  Gradients land in self.flat_grads."""
-        S = self.forward(img_nchw, training=True, T=T)
+        Returns device scalars (recon, latent).  Gradients land in self.flat_grads.  force_ids: see forward()."""
+        S = self.forward(img_nchw, training=True, T=T, force_ids=force_ids)
         dec = S["dec"]
         acc = torch.zeros(1, device=self.device)
         one = torch.ones(1, device=self.device)

@@ -202,8 +202,9 @@ class LPIPSEngine:
 
             def run_head(k):
                 n, h, w, c = taps1[k].shape
+                ws = ops._workspace(_lib.load().fo_lpips_tap_ws_bytes_bf16(n, h, w, c), self.device)      # (per stream: the heads run on two)
                 _lib.call("fo_lpips_tap_fwd_bwd_bf16", ops._ptr(taps0[k]), ops._ptr(taps1[k]), ops._ptr(self.lin[k]), ops._ptr(vals[k]), ops._ptr(gscale),
-                          ops._ptr(head[k]), n, h, w, c, ops._stream())
+                          ops._ptr(head[k]), n, h, w, c, ops._ptr(ws), ops._stream())
             run_head(4)
             if overlap:
                 side = self._head_stream
@@ -225,8 +226,9 @@ class LPIPSEngine:
             val = torch.zeros(N, device=self.device)
             for k in range(5):
                 n, h, w, c = taps1[k].shape
+                nb = _lib.load().fo_lpips_tap_ws_bytes_bf16(n, h, w, c) if self.bf16 else _lib.load().fo_lpips_tap_ws_bytes(n, h, w)
                 _lib.call("fo_lpips_tap_fwd_bf16" if self.bf16 else "fo_lpips_tap_fwd", ops._ptr(taps0[k]), ops._ptr(taps1[k]), ops._ptr(self.lin[k]),
-                          ops._ptr(val), n, h, w, c, ops._stream())
+                          ops._ptr(val), n, h, w, c, ops._ptr(ops._workspace(nb, self.device)), ops._stream())
             loss = val.mean().reshape(1)
             self.last_per_image = val
         if g_dec is None:

@@ -760,13 +760,23 @@ def _vq_stats(x, nvec, ind, stats, side):
     # (no record_stream: the caller keeps x, ind and stats alive until the stream that made them has joined `side` -- VQVAEEngine does, in S)
 
 
-def vq_assign_bf16out(x, embedT, enorm, q_f32, q_bf16, stats, train, stats_stream=None):
+def _forced(force_ind, shape, device):
+    if force_ind is None:
+        return None
+    f = force_ind.to(device=device, dtype=torch.int64).contiguous()
+    if tuple(f.shape) != tuple(shape) or int(f.min()) < 0 or int(f.max()) >= 512:
+        raise ValueError(f"faceoff_amd: forced code indices must be {tuple(shape)} in [0, 512), got {tuple(f.shape)}")
+    return f
+
+
+def vq_assign_bf16out(x, embedT, enorm, q_f32, q_bf16, stats, train, stats_stream=None, force_ind=None):
     """vq_assign on the fp32 input x, writing the straight-through output both as fp32 (q_f32, kept for the backward) and as bf16
     (q_bf16: the operand of the next convolution; may be a channel slice)."""
     nvec = x.shape[0] * x.shape[1] * x.shape[2]
     ind = torch.empty(x.shape[:-1], device=x.device, dtype=torch.int64)
+    f = _forced(force_ind, ind.shape, x.device)
     _lib.call("fo_vq_assign2", _ptr(x), ld_of(x), C.c_int64(nvec), _ptr(embedT), _ptr(enorm), _ptr(ind), _ptr(q_f32), ld_of(q_f32), _ptr(stats[0:1]),
-              _ptr(q_bf16), ld_of(q_bf16, BF), _stream())
+              _ptr(q_bf16), ld_of(q_bf16, BF), _ptr(f) if f is not None else None, _ptr(_workspace(4096, x.device)), _stream())
     if train:
         _vq_stats(x, nvec, ind, stats, stats_stream)
     return ind
@@ -887,13 +897,20 @@ def vq_prepare(embed):
     return embedT, enorm
 
 
-def vq_assign(x, embedT, enorm, q_out, stats, train, stats_stream=None):
-    """x, q_out: [..., 64] views; stats: float32[1 + 512 + 512*64] = (sq_sum, counts, esum[512][64]); stats[0]
-    must be zero on entry.  With train=True the EMA statistics (counts, esum) are written as well."""
+def vq_assign(x, embedT, enorm, q_out, stats, train, stats_stream=None, force_ind=None):
+    """x, q_out: [..., 64] views; stats: float32[1 + 512 + 512*64] = (sq_sum, counts, esum[512][64]); stats[0] is
+    overwritten (an ordered sum of per-workgroup partials: bit-reproducible).  With train=True the EMA statistics (counts, esum)
+    are written as well.  force_ind: teacher-forced codes (the search is skipped; see fo_vq_assign2)."""
     nvec = x.numel() // 64 if x.is_contiguous() else x.shape[0] * x.shape[1] * x.shape[2]
     ind = torch.empty(x.shape[:-1], device=x.device, dtype=torch.int64)
-    _lib.call("fo_vq_assign", _ptr(x), ld_of(x), C.c_int64(nvec), _ptr(embedT), _ptr(enorm), _ptr(ind), _ptr(q_out),
-              ld_of(q_out), _ptr(stats[0:1]), _stream())
+    f = _forced(force_ind, ind.shape, x.device)
+    ws = _workspace(4096, x.device)
+    if f is None:
+        _lib.call("fo_vq_assign", _ptr(x), ld_of(x), C.c_int64(nvec), _ptr(embedT), _ptr(enorm), _ptr(ind), _ptr(q_out),
+                  ld_of(q_out), _ptr(stats[0:1]), _ptr(ws), _stream())
+    else:
+        _lib.call("fo_vq_assign2", _ptr(x), ld_of(x), C.c_int64(nvec), _ptr(embedT), _ptr(enorm), _ptr(ind), _ptr(q_out), ld_of(q_out),
+                  _ptr(stats[0:1]), None, 0, _ptr(f), _ptr(ws), _stream())
     if train:
         _vq_stats(x, nvec, ind, stats, stats_stream)
     return ind
@@ -916,11 +933,16 @@ def vq_gather(ind, embedT, q_out):
 
 
 # ------------------------------------------------------------------ losses / optimiser
+LOSS_WS_BYTES = 16384          # FO_LOSS_WS_BYTES (include/faceoff_hip.h): one partial per workgroup, added in order by a finish launch
+
+
 def mse_slice_fwd(dec, gt_nchw, acc):
+    """acc[0] = the sum of squares (overwritten; an ordered sum of per-workgroup partials: bit-reproducible)"""
     N, H, W, _ = dec.shape
     gt_nchw = dense_f32(gt_nchw, "ground truth")
     assert gt_nchw.shape[0] == N and gt_nchw.shape[2:] == (H, W), "ground truth must be [N,C,H,W] like the decoder output"
-    _lib.call("fo_mse_slice_fwd", _ptr(dec), ld_of(dec), _ptr(gt_nchw), N, H, W, gt_nchw.shape[1], _ptr(acc), _stream())
+    _lib.call("fo_mse_slice_fwd", _ptr(dec), ld_of(dec), _ptr(gt_nchw), N, H, W, gt_nchw.shape[1], _ptr(acc), _ptr(_workspace(LOSS_WS_BYTES, dec.device)),
+              _stream())
 
 
 def mse_slice_bwd(dec, gt_nchw, gscale, gdec):
@@ -932,13 +954,13 @@ def mse_slice_bwd(dec, gt_nchw, gscale, gdec):
 
 
 def mse_slice_fwd_bwd(dec, gt_nchw, acc, gscale, gdec):
-    """sum of squares into acc AND the gradient into gdec, one pass (training step)"""
+    """sum of squares into acc (overwritten) AND the gradient into gdec, one pass (training step)"""
     N, H, W, _ = dec.shape
     gt_nchw = dense_f32(gt_nchw, "ground truth")
     assert gt_nchw.shape[0] == N and gt_nchw.shape[2:] == (H, W), "ground truth must be [N,C,H,W] like the decoder output"
     c3 = gt_nchw.shape[1]
     _lib.call("fo_mse_slice_fwd_bwd", _ptr(dec), ld_of(dec), _ptr(gt_nchw), N, H, W, c3, _ptr(gscale), C.c_float(1.0 / (N * c3 * H * W)),
-              _ptr(gdec), ld_of(gdec), _ptr(acc), _stream())
+              _ptr(gdec), ld_of(gdec), _ptr(acc), _ptr(_workspace(LOSS_WS_BYTES, dec.device)), _stream())
 
 
 def adam_flat(p, g, m, v, lr, step, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0):

@@ -81,9 +81,9 @@ class FaceOffTrainer:
                 vq_ar = fused_vq_allreduce(group)
                 engine.vq_allreduce = (lambda st: vq_ar(st, always=True)) if force_collectives else vq_ar
 
-    def step(self, img, ground_truth, T=None):
+    def step(self, img, ground_truth, T=None, force_ids=None):
         """img [B,T,6,H,W] or [N,6,H,W]; ground_truth likewise with 3 channels (utils.py:29-38).
-        Returns device scalars (recon_loss, latent_loss, perceptual_loss)."""
+        Returns device scalars (recon_loss, latent_loss, perceptual_loss).  force_ids: teacher-forced codes (VQVAEEngine.forward)."""
         if isinstance(img, (tuple, list)):       # (source, background): concatenated inside the input-layout kernel
             if img[0].dim() == 5:
                 T = T or img[0].shape[1]
@@ -107,7 +107,8 @@ class FaceOffTrainer:
             if taps0 is not None:
                 for t in taps0:
                     t.record_stream(main)        # allocated on the side stream, read (and freed) on the main one
-        S = eng.forward(img, training=True, T=T)
+        S = eng.forward(img, training=True, T=T, force_ids=force_ids)
+        self.last_ids = (S["id_t"], S["id_b"])           # the codes of the step just enqueued (two small int64 tensors)
         dec = S["dec"]
         acc = torch.zeros(1, device=eng.device)
         one = torch.ones(1, device=eng.device)

@@ -170,12 +170,15 @@ int fo_bias_grad(const float* g, float* dbias, int64_t M, int C, int Creal, int 
 
 /* ---------------------------------------------------------------- vector quantiser (Quantize.forward :47-80) */
 /* x[Nvec][ldx] (dim 64) vs embed[64][512].  Writes ind (int64, :54) and q_ste = x + (embed[:,ind] - x)
- * (:57,78); accumulates sum((q-x)^2) into *sq_sum (:77; zero it first).  Distances use the reference's
+ * (:57,78); *sq_sum = sum((q-x)^2) (:77; OVERWRITTEN).  Distances use the reference's
  * expanded form ||x||^2 - 2 x.e + ||e||^2 in fp32 with k-ordered fma chains and first-index arg-min
- * (torch.max tie-break): restated bit-for-bit by oracle/vq_oracle.c.  `enorm`[512] from fo_vq_prepare. */
+ * (torch.max tie-break): restated bit-for-bit by oracle/vq_oracle.c.  `enorm`[512] from fo_vq_prepare.
+ * ws: fo_vq_assign_ws_bytes() of scratch -- the commitment sum meets there as one partial per workgroup, added in workgroup
+ * order by a one-wave finish launch (no float atomics: the latent loss is the same bits run after run). */
 int fo_vq_prepare(const float* embed, float* embedT, float* enorm, void* stream); /* [64][512] -> [512][64], ||e||^2 */
+int64_t fo_vq_assign_ws_bytes(void);
 int fo_vq_assign(const float* x, int ldx, int64_t nvec, const float* embedT, const float* enorm, int64_t* ind,
-                 float* q_ste, int ldq, float* sq_sum, void* stream);
+                 float* q_ste, int ldq, float* sq_sum, float* ws, void* stream);
 /* EMA statistics of the assignment (:60-61, replaces F.one_hot + the second sgemm): counts[512] and
  * esum[512][64] (code-major) are OVERWRITTEN.  ws: fo_vq_stats_ws_bytes(nvec).  No atomics: a wave owns the codes
  * c % 16 == wave and adds their vectors in vector order, workgroup slabs are summed in a fixed order -- bit-reproducible. */
@@ -192,15 +195,18 @@ int fo_vq_bwd(const float* gq, int ldg, const float* x, int ldx, const float* q,
 int fo_vq_gather(const int64_t* ind, const float* embedT, float* q, int ldq, int64_t nvec, void* stream);
 
 /* ---------------------------------------------------------------- losses */
-/* sum over n,c<3,h,w of (dec[n][h][w][c] - gt[n][c][h][w])^2 accumulated into *sum
- * (criterion = nn.MSELoss() on out[:, :3], train_faceoff_perceptual.py:21,37-39). */
-int fo_mse_slice_fwd(const float* dec, int ldd, const float* gt_nchw, int N, int H, int W, int C3, float* sum, void* stream);
+/* *sum = sum over n,c<3,h,w of (dec[n][h][w][c] - gt[n][c][h][w])^2 (OVERWRITTEN)
+ * (criterion = nn.MSELoss() on out[:, :3], train_faceoff_perceptual.py:21,37-39).
+ * Loss scalars never meet in float atomics: a kernel leaves one partial per workgroup in `ws` (FO_LOSS_WS_BYTES of scratch) and a one-wave
+ * finish launch adds them in a fixed order -- recon / latent / perceptual / GAN losses are the same bits run after run. */
+#define FO_LOSS_WS_BYTES 16384
+int fo_mse_slice_fwd(const float* dec, int ldd, const float* gt_nchw, int N, int H, int W, int C3, float* sum, float* ws, void* stream);
 /* gdec[n][h][w][c] = c<3 ? gscale * 2 (dec-gt)/numel : 0, for c < ldg  (gscale read from device) */
 int fo_mse_slice_bwd(const float* dec, int ldd, const float* gt_nchw, int N, int H, int W, int C3,
                      const float* gscale, float inv_numel, float* gdec, int ldg, void* stream);
 /* both in one pass over dec and gt (the training step, :37-39 then :100) */
 int fo_mse_slice_fwd_bwd(const float* dec, int ldd, const float* gt_nchw, int N, int H, int W, int C3, const float* gscale,
-                         float inv_numel, float* gdec, int ldg, float* sum, void* stream);
+                         float inv_numel, float* gdec, int ldg, float* sum, float* ws, void* stream);
 
 /* ---------------------------------------------------------------- LPIPS / VGG-16 (models/lpips.py:80-161, loss.py:27-33)
  * The 13 VGG convolutions (+ReLU) are fo_conv_igemm launches (first layer: Cin 3 padded to 8, KW padded
@@ -218,7 +224,8 @@ int fo_maxpool2_fwd(const float* x, float* y, int N, int H, int W, int C, void* 
 /* gx = relu'(x) * ([x is the first maximum of its 2x2 window] * gy + add); add may be NULL (a LPIPS tap gradient). */
 int fo_maxpool2_bwd(const float* x, const float* gy, const float* add, float* gx, int N, int H, int W, int C, void* stream);
 /* One LPIPS tap (:85-89,155-161): val[n] += mean_hw sum_c lin_c (f0/(|f0|+eps) - f1/(|f1|+eps))^2, C in {64,128,256,512}. */
-int fo_lpips_tap_fwd(const float* f0, const float* f1, const float* lin, float* val, int N, int H, int W, int C, void* stream);
+int64_t fo_lpips_tap_ws_bytes(int N, int H, int W);   /* scratch of fo_lpips_tap_fwd: per-pixel values, summed per frame in pixel order (no atomics) */
+int fo_lpips_tap_fwd(const float* f0, const float* f1, const float* lin, float* val, int N, int H, int W, int C, float* ws, void* stream);
 /* Gradient of mean_n(sum of taps) wrt f1 (the reconstruction branch), times gscale[0], through f1's own ReLU. */
 int fo_lpips_tap_bwd(const float* f0, const float* f1, const float* lin, const float* gscale, float* gf1, int N, int H, int W,
                      int C, void* stream);
@@ -383,7 +390,8 @@ int fo_disc_pairs_bwd(const float* gout, int ldOut, int H, int W, int f0, int fi
 int fo_space_to_depth2(float* x, int ldx, float* xs, int ldxs, int N, int D, int H, int W, int C, int depth_too, int inverse, void* stream);
 int fo_s2d_filter(float* w, float* w2, int O, int C, int KD, int inverse, void* stream);
 /* Relativistic average LSGAN (mocoganhd_losses.py:108-126) on one scale's patch logits a[na], b[nb] (pixel stride ld):
- *   loss = w * ( mean((a - mean(b) - ta)^2) + mean((b - mean(a) - tb)^2) )       accumulated into *loss_acc;
+ *   loss = w * ( mean((a - mean(b) - ta)^2) + mean((b - mean(a) - tb)^2) )       added to *loss_acc (a plain read-modify-write by one
+ *   thread: calls that share a loss_acc must be ordered on one stream);
  * ga / gb (either may be NULL) receive d loss / d a, d loss / d b times gscale[0] (stride ld, written not added). */
 int fo_ralsgan(const float* a, int na, const float* b, int nb, int ld, float ta, float tb, float w, float* loss_acc,
                const float* gscale, float* ga, float* gb, void* stream);
@@ -439,9 +447,13 @@ int fo_bf16_to_f32(const void* x, int64_t ldx, float* y, int64_t ldy, int64_t ro
 /* fo_nchw2_to_nhwc8 with the result rounded to bf16 (the network input of the bf16-operand engine; utils.py:32). */
 int fo_nchw2_to_nhwc8_bf16(const float* a, int Ca, const float* b, int Cb, void* y, int N, int H, int W, void* stream);
 /* fo_vq_assign that also writes a bf16 copy of the straight-through output (q_bf16 [nvec][ldqb], may be NULL): the quantiser itself
- * -- distances, arg-min, gather, commitment sum -- runs in fp32 on the fp32 input exactly as fo_vq_assign. */
+ * -- distances, arg-min, gather, commitment sum -- runs in fp32 on the fp32 input exactly as fo_vq_assign.
+ * forced_ind (may be NULL): teacher-forced codes -- the search is skipped, `ind` receives forced_ind, and the gather, straight-through
+ * value and commitment sum use it (what Quantize.forward :57,77-78 would compute had :54 returned these indices; decode_code's
+ * direction, :287-295, with the commitment term).  Used by the parity tests to compare a bf16-operand step with the oracle on the
+ * oracle's own codes, where a near-tie cannot open an O(1) gap. */
 int fo_vq_assign2(const float* x, int ldx, int64_t nvec, const float* embedT, const float* enorm, int64_t* ind, float* q_ste, int ldq,
-                  float* sq_sum, void* q_bf16, int ldqb, void* stream);
+                  float* sq_sum, void* q_bf16, int ldqb, const int64_t* forced_ind, float* ws, void* stream);
 /* fo_vq_bwd with bf16 gradients: gx = bf16(gq + gdiff[0] * scale * (x - q)); gq, gx bf16, x and q fp32. */
 int fo_vq_bwd_bf16(const void* gq, int ldg, const float* x, int ldx, const float* q, int ldq, const float* gdiff, float scale, void* gx,
                    int ldgx, int64_t nvec, void* stream);
@@ -451,13 +463,16 @@ int fo_lpips_prep_bwd_bf16(const void* g /* [npix][8] */, float* gdec, int ldd, 
                            const float* gscale, float weight, void* stream);
 int fo_maxpool2_fwd_bf16(const void* x, void* y, int N, int H, int W, int C, void* stream);
 int fo_maxpool2_bwd_bf16(const void* x, const void* gy, const void* add, void* gx, int N, int H, int W, int C, void* stream);
-int fo_lpips_tap_fwd_bf16(const void* f0, const void* f1, const float* lin, float* val, int N, int H, int W, int C, void* stream);
+/* ws: fo_lpips_tap_ws_bytes_bf16(N, H, W, C) of scratch (both head entry points): every wave leaves its per-frame sums in its own slots and a
+ * finish launch adds a frame's slots in wave order -- val[] is reproducible bit for bit (it met in float atomics before round 4). */
+int64_t fo_lpips_tap_ws_bytes_bf16(int N, int H, int W, int C);
+int fo_lpips_tap_fwd_bf16(const void* f0, const void* f1, const float* lin, float* val, int N, int H, int W, int C, float* ws, void* stream);
 int fo_lpips_tap_bwd_bf16(const void* f0, const void* f1, const float* lin, const float* gscale, void* gf1, int N, int H, int W,
                           int C, void* stream);
 /* fo_lpips_tap_fwd_bf16 and fo_lpips_tap_bwd_bf16 in ONE pass over the two feature maps (training: the tap's upstream gradient
  * gscale[0] / (N H W) is known before its value is): val[n] += the tap's value per frame, gf1 = its gradient wrt f1. */
 int fo_lpips_tap_fwd_bwd_bf16(const void* f0, const void* f1, const float* lin, float* val, const float* gscale, void* gf1, int N, int H,
-                              int W, int C, void* stream);
+                              int W, int C, float* ws, void* stream);
 
 /* ---------------------------------------------------------------- optimiser + utilities */
 /* torch.optim.Adam defaults (train_faceoff_perceptual.py:190) over one flat parameter arena. */

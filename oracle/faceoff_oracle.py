@@ -49,7 +49,7 @@ def to_torch_state(sd, requires_grad=True):
 
 # --------------------------------------------------------------------------- Quantize
 def quantize_forward(x, embed, cluster_size, embed_avg, training, all_reduce=None,
-                     decay=EMA_DECAY, eps=EMA_EPS):
+                     decay=EMA_DECAY, eps=EMA_EPS, force_ind=None):
     """Quantize.forward (vqvae_conv3d_latent.py:47-80).  x[..., dim] channels-last.
 
     Returns (quantize_ste, diff, embed_ind, new_buffers or None).  Buffers are NOT mutated;
@@ -61,6 +61,8 @@ def quantize_forward(x, embed, cluster_size, embed_avg, training, all_reduce=Non
     dist = (flatten.pow(2).sum(1, keepdim=True) - 2 * flatten @ embed
             + embed.pow(2).sum(0, keepdim=True))                     # :49-53
     _, embed_ind = (-dist).max(1)                                    # :54
+    if force_ind is not None:        # teacher-forced codes (parity tests of the bf16-operand engine: both sides use the SAME codes,
+        embed_ind = force_ind.reshape(-1).to(torch.int64)   # so a near-tie cannot open an O(1) gap; everything below is :55-78 unchanged)
     embed_onehot = F.one_hot(embed_ind, n_embed).type(flatten.dtype)  # :55
     embed_ind = embed_ind.view(*x.shape[:-1])
     quantize = F.embedding(embed_ind, embed.transpose(0, 1))         # :57,82-83
@@ -200,7 +202,7 @@ def conv3d_postnet(x5, p, prefix, r=_NoSim):
     return x5
 
 
-def vqvae_forward(x, p, training=True, all_reduce=None, T=None, bf16sim=False):
+def vqvae_forward(x, p, training=True, all_reduce=None, T=None, bf16sim=False, force_ids=None):
     """VQVAE.forward (:243-259) generalised to clips.
 
     x: [B,T,6,H,W] (or [N,6,H,W] with T=None => one clip of N frames, the literal reference).
@@ -232,14 +234,14 @@ def vqvae_forward(x, p, training=True, all_reduce=None, T=None, bf16sim=False):
     qt_in = r.grad(F.conv2d(enc_t_conv, r.w(p["quantize_conv_t.weight"]), p["quantize_conv_t.bias"]).permute(0, 2, 3, 1))
     quant_t, diff_t, id_t, new_t = quantize_forward(
         qt_in, p["quantize_t.embed"], p["quantize_t.cluster_size"], p["quantize_t.embed_avg"],
-        training, all_reduce)
+        training, all_reduce, force_ind=None if force_ids is None else force_ids[0])
     quant_t = r.act(quant_t.permute(0, 3, 1, 2))
     dec_t = r.act(decoder(quant_t, p, "dec_t", 2, r=r))
     cat_b = torch.cat([dec_t, enc_b_conv], 1)
     qb_in = r.grad(F.conv2d(cat_b, r.w(p["quantize_conv_b.weight"]), p["quantize_conv_b.bias"]).permute(0, 2, 3, 1))
     quant_b, diff_b, id_b, new_b = quantize_forward(
         qb_in, p["quantize_b.embed"], p["quantize_b.cluster_size"], p["quantize_b.embed_avg"],
-        training, all_reduce)
+        training, all_reduce, force_ind=None if force_ids is None else force_ids[1])
     quant_b = r.act(quant_b.permute(0, 3, 1, 2))
     diff = diff_t.unsqueeze(0) + diff_b.unsqueeze(0)
 
@@ -307,13 +309,14 @@ def lpips_forward(inp, target, lp, per_tap=False, bf16sim=False):
 
 
 # --------------------------------------------------------------------------- the step
-def run_step(x, ground_truth, p, lpips_state=None, training=True, all_reduce=None, lpips_bf16sim=False, bf16sim=False):
+def run_step(x, ground_truth, p, lpips_state=None, training=True, all_reduce=None, lpips_bf16sim=False, bf16sim=False, force_ids=None,
+             weights=(1.0, LATENT_LOSS_WEIGHT, PERCEPTUAL_LOSS_WEIGHT)):
     """run_step + loss composition (train_faceoff_perceptual.py:32-47,97-98).
 
     x[B,T,6,H,W], ground_truth[B,T,3,H,W].  Returns dict with recon/latent/perceptual/loss
     and the forward dict.  perceptual is 0 when lpips_state is None (BASELINE config 2).
     """
-    fw = vqvae_forward(x, p, training=training, all_reduce=all_reduce, bf16sim=bf16sim)
+    fw = vqvae_forward(x, p, training=training, all_reduce=all_reduce, bf16sim=bf16sim, force_ids=force_ids)
     gt = ground_truth.reshape(-1, *ground_truth.shape[-3:])
     out = fw["dec"][:, :3]                                   # :37
     recon = F.mse_loss(out, gt)                              # :21,39
@@ -322,7 +325,7 @@ def run_step(x, ground_truth, p, lpips_state=None, training=True, all_reduce=Non
         perceptual = lpips_forward(gt.contiguous(), out.contiguous(), lpips_state, bf16sim=lpips_bf16sim).mean()   # loss.py:33
     else:
         perceptual = torch.zeros(())
-    loss = recon + LATENT_LOSS_WEIGHT * latent + PERCEPTUAL_LOSS_WEIGHT * perceptual   # :98
+    loss = weights[0] * recon + weights[1] * latent + weights[2] * perceptual   # :98 (weights: (1, 1, 1) in the reference; tests isolate a term)
     return dict(recon=recon, latent=latent, perceptual=perceptual, loss=loss, fw=fw)
 
 
@@ -341,12 +344,13 @@ def adam_step(p, grads, state, lr=3e-4, betas=(0.9, 0.999), eps=1e-8):
             p[k].addcdiv_(m, denom, value=-lr / (1 - b1 ** t))
 
 
-def train_step(x, ground_truth, p, lpips_state=None, adam_state=None, lr=3e-4, lpips_bf16sim=False, bf16sim=False):
+def train_step(x, ground_truth, p, lpips_state=None, adam_state=None, lr=3e-4, lpips_bf16sim=False, bf16sim=False, force_ids=None,
+               weights=(1.0, LATENT_LOSS_WEIGHT, PERCEPTUAL_LOSS_WEIGHT)):
     """One iteration of train() (:93-107): zero_grad, run_step, backward, (Adam), EMA buffers."""
     params = {k: v for k, v in p.items() if v.requires_grad}
     for v in params.values():
         v.grad = None
-    r = run_step(x, ground_truth, p, lpips_state, training=True, lpips_bf16sim=lpips_bf16sim, bf16sim=bf16sim)
+    r = run_step(x, ground_truth, p, lpips_state, training=True, lpips_bf16sim=lpips_bf16sim, bf16sim=bf16sim, force_ids=force_ids, weights=weights)
     r["loss"].backward()
     grads = {k: v.grad.detach().clone() for k, v in params.items()}
     with torch.no_grad():

@@ -8,6 +8,10 @@ on a real MI355X: the engine with dtype="bf16" against
   (2) the pure-fp32 oracle (the reference's arithmetic): reported, and bounded by what the bf16-simulated oracle itself deviates from it
       ("1e-3 vs an fp32 oracle is not attainable with bf16 operands ... state both").
 
+Flip-free evidence: the TEACHER-FORCED step -- engine and oracle both use the oracle's code indices, so no VQ near-tie can open
+an O(1) gap -- holds the decoder output to 1e-2 and every one of the 70 gradient tensors to twice its recorded error (tests/_observed.py); the
+free-running step compares the decoder output OUTSIDE the receptive fields of its (margin-gated) flipped codes at the same 1e-2.
+
 Sizes: 2 clips x 2 frames of 64x64 (BASELINE config 1's shape) and a ragged 3 x 3 x 40x24 (gather-form filter gradients, tile tails);
 at the timed size (160 frames of 256x256) size-independent properties: finite, bit-reproducible, every code a true nearest code of its fp32
 input, and agreement with the fp32 engine at bf16 level."""
@@ -16,25 +20,74 @@ import pytest
 import torch
 
 from faceoff_amd.synth import make_state_dict, make_batch
+from _observed import Observed
 
 pytestmark = pytest.mark.gpu
+FIXTURES = [(2, 2, 64, 64, 0), (3, 3, 40, 24, 11)]
 
 
 def _rel_l2(a, b):
     return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
 
 
-def _step(sd, img, gt, B, T, H, W, dtype="bf16"):
+def _step(sd, img, gt, B, T, H, W, dtype="bf16", force_ids=None):
     from faceoff_amd.engine import VQVAEEngine
     eng = VQVAEEngine(sd, "cuda:0", dtype=dtype)
     x = torch.from_numpy(img).reshape(B * T, 6, H, W).cuda()
     y = torch.from_numpy(gt).reshape(B * T, 3, H, W).cuda()
-    recon, diff, S = eng.loss_and_backward(x, y, T=T)
+    recon, diff, S = eng.loss_and_backward(x, y, T=T, force_ids=force_ids)
     torch.cuda.synchronize()
     return eng, recon, diff, S
 
 
-@pytest.mark.parametrize("B,T,H,W,seed", [(2, 2, 64, 64, 0), (3, 3, 40, 24, 11)])
+def _dilate(m, r):
+    """m: bool [N,h,w]; a (2r+1)^2 box dilation"""
+    return torch.nn.functional.max_pool2d(m.float().unsqueeze(1), 2 * r + 1, 1, r).squeeze(1) > 0
+
+
+def _outside_flipped_receptive_fields(bad_t, bad_b):
+    """bool [N,H,W] at image resolution: the pixels of `dec` that no flipped code can reach.  A top code (1/8 resolution) enters the decoder
+    through upsample_t (k4 s2 p1: latent rows 2y-1 .. 2y+2); a bottom code (1/4 resolution) directly.  From there `dec` (:218-225) is a 3x3
+    conv, two ResBlocks (3x3 each) and two k4 s2 p1 transposed convs: 3 latent pixels + 1 per transposed stage -- 5 latent pixels on each
+    side are excluded (one to spare)."""
+    up = _dilate(bad_t, 1).repeat_interleave(2, 1).repeat_interleave(2, 2)
+    reach = _dilate(bad_b | up, 5)
+    return ~reach.repeat_interleave(4, 1).repeat_interleave(4, 2)
+
+
+@pytest.mark.parametrize("B,T,H,W,seed", FIXTURES)
+def test_bf16_engine_teacher_forced_step_vs_bf16_simulated_oracle(B, T, H, W, seed):
+    """The flip-free comparison: the engine runs the step on the bf16-simulated oracle's own code indices (forward(force_ids=...): the search
+    is skipped, gather / straight-through / commitment loss / EMA statistics use the given codes).  What separates the two sides is then only
+    fp32 summation order and the isolated bf16 roundings / ReLU masks it flips -- no code can differ, so nothing opens an O(1) gap:
+    decoder output <= 1e-2, losses 2e-3, EMA buffers 5e-3, and EVERY gradient tensor within twice its recorded error."""
+    from faceoff_amd import ops
+    from oracle import faceoff_oracle as O
+    sd = make_state_dict(seed, codebook_scale=0.3, gain=2.0)
+    img, gt = make_batch(1234 + seed, B, T, H, W)
+    r = O.train_step(torch.from_numpy(img), torch.from_numpy(gt), O.to_torch_state(sd), bf16sim=True)
+    ids = (r["fw"]["id_t"], r["fw"]["id_b"])
+    # (the oracle forced onto its own codes is the oracle: checked once here, so that `r` IS the teacher-forced reference)
+    r2 = O.train_step(torch.from_numpy(img), torch.from_numpy(gt), O.to_torch_state(sd), bf16sim=True, force_ids=ids)
+    assert torch.equal(r2["fw"]["dec"], r["fw"]["dec"]) and all(torch.equal(r2["grads"][k], g) for k, g in r["grads"].items())
+    eng, recon, diff, S = _step(sd, img, gt, B, T, H, W, force_ids=ids)
+    assert torch.equal(S["id_t"].cpu(), ids[0]) and torch.equal(S["id_b"].cpu(), ids[1])
+    obs = Observed(f"forced_{B}x{T}x{H}x{W}")
+    np.testing.assert_allclose(recon.item(), r["recon"].item(), rtol=2e-3)
+    np.testing.assert_allclose(diff.item(), r["latent"].item(), rtol=2e-3)
+    dec_err = _rel_l2(ops.nhwc_to_nchw(S["dec"], 6).cpu(), r["fw"]["dec"].detach())
+    obs.check("dec", dec_err, cap=1e-2)
+    errs = sorted(((_rel_l2(eng.grads[k].cpu(), g), k) for k, g in r["grads"].items()), reverse=True)
+    print(f"[bf16 engine, teacher-forced {B}x{T}x{H}x{W}] dec rel L2 {dec_err:.2e}; gradients vs bf16-simulated oracle: worst {errs[0][0]:.2e} ({errs[0][1]}), "
+          f"median {errs[len(errs) // 2][0]:.2e}, best {errs[-1][0]:.2e} ({errs[-1][1]})")
+    for e, k in errs:
+        obs.check("grad:" + k, e, cap=6e-2)
+    for k in eng.buffers:
+        np.testing.assert_allclose(eng.buffers[k].cpu().numpy(), r["fw"]["new_buffers"][k].numpy(), rtol=5e-3, atol=5e-3 * float(r["fw"]["new_buffers"][k].abs().max()))
+    obs.flush()
+
+
+@pytest.mark.parametrize("B,T,H,W,seed", FIXTURES)
 def test_bf16_engine_step_vs_bf16_simulated_oracle_and_vs_fp32_oracle(B, T, H, W, seed):
     from faceoff_amd import ops
     from oracle import faceoff_oracle as O
@@ -52,9 +105,10 @@ def test_bf16_engine_step_vs_bf16_simulated_oracle_and_vs_fp32_oracle(B, T, H, W
     np.testing.assert_allclose(diff.item(), r["latent"].item(), rtol=2e-3)
     # code indices: equal, or a near-tie of the bf16-simulated oracle's own distances (its top-2 margin below 1e-2: the quantiser's input
     # carries ~1e-3 of summation-order noise per element after a dozen bf16-rounded layers; typical margins are ~0.2)
-    flips = 0
+    flips, badmap = 0, {}
     for lvl in "tb":
         bad = (S["id_" + lvl].cpu() != r["fw"]["id_" + lvl]).reshape(-1)
+        badmap[lvl] = bad.reshape(r["fw"]["id_" + lvl].shape).clone()
         if lvl == "b" and flips:
             # a flipped TOP code (a near-tie, gated in the previous round of this loop) is decoded into the bottom quantiser's input: around
             # it that input differs by O(1) and the bottom codes with it.  Those positions (at most a 24 x 24 neighbourhood per flipped
@@ -66,18 +120,27 @@ def test_bf16_engine_step_vs_bf16_simulated_oracle_and_vs_fp32_oracle(B, T, H, W
         margin = O.vq_margin(r["fw"][f"q{lvl}_in"].detach(), torch.from_numpy(sd[f"quantize_{lvl}.embed"]))
         assert bool((margin[bad] < 1e-2).all()) and bad.float().mean().item() < 1e-2, (lvl, int(bad.sum()), margin[bad].max().item() if bad.any() else 0)
         flips += int(bad.sum())
-    # decoder output: a flipped code changes a 4x4 (bottom) or 40x40 (top) patch by O(1)
-    dec_err = _rel_l2(dec, r["fw"]["dec"].detach())
-    assert dec_err < (1e-2 if flips == 0 else 0.25), dec_err
-    # all 70 gradients, relative L2 per tensor
+    obs = Observed(f"free_{B}x{T}x{H}x{W}")
+    # decoder output: a flipped code changes a patch by O(1) -- compared OUTSIDE the flipped codes' receptive fields, at the flip-free bound
+    keep = _outside_flipped_receptive_fields(badmap["t"], badmap["b"]).unsqueeze(1).expand(-1, 3, -1, -1)
+    assert keep.float().mean().item() > 0.3, "the flipped codes' receptive fields cover most of the fixture: nothing left to compare"
+    ref_dec = r["fw"]["dec"].detach()[:, :3]
+    dec_err = _rel_l2(dec[:, :3][keep], ref_dec[keep])
+    dec_all = _rel_l2(dec, r["fw"]["dec"].detach())
+    obs.check("dec_outside_flips", dec_err, cap=1e-2)
+    # all 70 gradients, relative L2 per tensor: filter gradients are sums over every position, the flipped codes' patches included, so the
+    # per-tensor statement lives in the teacher-forced test above; here the aggregate is held to twice what this fixture was recorded at
     errs = sorted(((_rel_l2(eng.grads[k].cpu(), g), k) for k, g in r["grads"].items()), reverse=True)
     med = errs[len(errs) // 2][0]
     errs32 = sorted(((_rel_l2(eng.grads[k].cpu(), g), k) for k, g in ref["fp32"]["grads"].items()), reverse=True)
     sim32 = sorted(((_rel_l2(r["grads"][k], g), k) for k, g in ref["fp32"]["grads"].items()), reverse=True)
-    print(f"[bf16 engine {B}x{T}x{H}x{W}] index flips {flips}; dec rel L2 {dec_err:.2e}; gradients vs bf16-simulated oracle: worst {errs[0][0]:.2e} ({errs[0][1]}), "
+    print(f"[bf16 engine {B}x{T}x{H}x{W}] index flips {flips}; dec rel L2 {dec_all:.2e} ({dec_err:.2e} outside the flipped codes' receptive fields, "
+          f"{keep.float().mean().item():.2f} of the pixels); gradients vs bf16-simulated oracle: worst {errs[0][0]:.2e} ({errs[0][1]}), "
           f"median {med:.2e}; vs fp32 oracle: worst {errs32[0][0]:.2e}, median {errs32[len(errs32) // 2][0]:.2e}; "
           f"bf16-simulated oracle vs fp32 oracle: worst {sim32[0][0]:.2e}, median {sim32[len(sim32) // 2][0]:.2e}")
-    assert med < (3e-2 if flips == 0 else 6e-2) and errs[0][0] < (6e-2 if flips == 0 else 0.3), (errs[:3], med)
+    obs.check("grad_median", med)
+    obs.check("grad_worst", errs[0][0])
+    obs.flush()
     # the rounding points are the oracle's: the engine is no further from the fp32 arithmetic than the bf16-simulated oracle is (within 25 %)
     assert errs32[len(errs32) // 2][0] <= (1.25 if flips == 0 else 2.0) * sim32[len(sim32) // 2][0] + 1e-3
     # EMA codebook buffers (fp32 statistics of fp32 inputs; a flipped code moves two rows)

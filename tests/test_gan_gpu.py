@@ -123,7 +123,7 @@ def test_random_choices_follow_the_reference_call_order():
 def test_gan_iterations_are_bit_reproducible():
     """Two trainers from the same state, two iterations each (generator, then discriminator), at a size where the discriminators'
     convolutions and filter gradients run sliced (K-slices / row slices through workspaces, added in slice order): every parameter
-    of the generator and of both discriminators, and the running statistics, equal bit for bit."""
+    of the generator and of both discriminators, the running statistics and the LOSS SCALARS of both iterations equal bit for bit."""
     from faceoff_amd.disc import DiscEngine
     from faceoff_amd.engine import VQVAEEngine
     from faceoff_amd.gan_trainer import GANTrainer
@@ -137,10 +137,12 @@ def test_gan_iterations_are_bit_reproducible():
         d3 = DiscEngine(make_disc_state(8, 3), "cuda:0", dims=3, n_frames=win - 1)
         d2 = DiscEngine(make_disc_state(9, 2), "cuda:0", dims=2)
         tr = GANTrainer(eng, d3, d2, lr=3e-4, d_lr=1e-4, window=win, rng=random.Random(4))
-        for _ in range(2):
-            tr.step(x, y)
+        losses = {}
+        for it in range(2):
+            losses.update({f"loss{it}." + k: v.clone() for k, v in tr.step(x, y).items()})
         torch.cuda.synchronize()
         st = {"g." + k: v.clone() for k, v in eng.state_dict().items()}
+        st.update(losses)              # the printed losses too: MSE / commitment sums as ordered partials, RaLSGAN as ordered launches
         st.update({"d3." + k: v.clone() for k, v in d3.state_dict().items()})
         st.update({"d2." + k: v.clone() for k, v in d2.state_dict().items()})
         states.append(st)
