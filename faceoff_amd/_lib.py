@@ -59,6 +59,8 @@ SIGNATURES = {
     "fo_comm_wait": (_I, [_P, _P]),
     "fo_comm_destroy": (_I, [_P]),
     "fo_last_error": (C.c_char_p, []),
+    "fo_kernel_notes": (_I, [_I]),
+    "fo_last_kernel": (C.c_char_p, []),
     "fo_device_info": (_I, [C.POINTER(C.c_int32)]),
     "fo_nchw_to_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "fo_nchw2_to_nhwc8": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _P]),

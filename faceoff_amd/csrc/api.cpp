@@ -12,6 +12,24 @@ void fo_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+std::atomic<int> fo_notes_on{0};
+static thread_local char g_kernel[160] = "";
+
+void fo_note_kernel(const char* base, const char* pretty) {
+  if (!pretty) {
+    snprintf(g_kernel, sizeof g_kernel, "%s", base);
+    return;
+  }
+  // pretty = "const char *fo_tname() [T = fo_vals<256, 256, 2, 4>]": keep what stands between "fo_vals" and the closing bracket
+  const char* a = strstr(pretty, "fo_vals<");
+  const char* z = a ? strrchr(a, ']') : nullptr;
+  if (!a || !z) {
+    snprintf(g_kernel, sizeof g_kernel, "%s<?>", base);
+    return;
+  }
+  snprintf(g_kernel, sizeof g_kernel, "%s%.*s", base, (int)(z - (a + 7)), a + 7);
+}
+
 int fo_cu_count() {
   static int cus = 0;
   if (cus == 0) {
@@ -28,6 +46,13 @@ int fo_cu_count() {
 extern "C" {
 int fo_version(void) { return 100; }
 const char* fo_last_error(void) { return g_err; }
+int fo_kernel_notes(int enable) { return fo_notes_on.exchange(enable ? 1 : 0); }
+const char* fo_last_kernel(void) {
+  static thread_local char out[160];
+  memcpy(out, g_kernel, sizeof out);
+  g_kernel[0] = 0;
+  return out;
+}
 int fo_device_info(int32_t* out3) {
   int dev = 0;
   hipDeviceProp_t p;

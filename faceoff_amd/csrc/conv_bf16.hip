@@ -1084,6 +1084,7 @@ static int launch_halo64(const ConvArgsH& c, hipStream_t s, void* pooled = nullp
   const int cus = fo_cu_count();
   int grid = std::min(2 * cus / a.halves * a.halves, a.ntiles * a.halves);          // two workgroups per CU
   grid = std::max(a.halves, grid / a.halves * a.halves);
+  FO_NOTE("conv_halo64_bf16_kernel");
   hipLaunchKernelGGL(conv_halo64_bf16_kernel, dim3(grid), dim3(256), ldsBytes, s, a);
   FO_CHECK_LAUNCH();
   return FO_OK;
@@ -1095,6 +1096,7 @@ int launch_pp16(const ConvArgsH& a, hipStream_t s) {
   static fo_lds_once once;
   void (*kern)(const ConvArgsH) = conv_bf16_pp16_kernel<BMB, BN, WAVES_M, WAVES_N>;
   if (!fo_lds_optin(once, reinterpret_cast<const void*>(kern), ldsBytes, "conv_bf16 (pp16)")) return FO_E_HIP;
+  FO_NOTE_T("conv_bf16_pp16_kernel", BMB, BN, WAVES_M, WAVES_N);
   hipLaunchKernelGGL(kern, dim3(a.tilesM * a.tilesN), dim3(512), ldsBytes, s, a);
   FO_CHECK_LAUNCH();
   return FO_OK;
@@ -1102,6 +1104,7 @@ int launch_pp16(const ConvArgsH& a, hipStream_t s) {
 
 template <int BN, int WAVES_M, int WAVES_N, int TM, int TN>
 int launch_dma(const ConvArgsH& a, hipStream_t s) {
+  FO_NOTE_T("conv_bf16_dma_kernel", BN, WAVES_M, WAVES_N, TM, TN);
   hipLaunchKernelGGL((conv_bf16_dma_kernel<BN, WAVES_M, WAVES_N, TM, TN>), dim3(a.tilesM * a.tilesN), dim3(256), 0, s, a);
   FO_CHECK_LAUNCH();
   return FO_OK;
@@ -1110,12 +1113,16 @@ int launch_dma(const ConvArgsH& a, hipStream_t s) {
 template <int BN, int WAVES_M, int WAVES_N, int TM, int TN>
 int launch(const ConvArgsH& a, bool smallc, hipStream_t s) {
   const int grid = a.tilesM * a.tilesN;
-  if (smallc)
+  if (smallc) {
+    FO_NOTE_T("conv_bf16_kernel", BN, WAVES_M, WAVES_N, TM, TN, true, false);
     hipLaunchKernelGGL((conv_bf16_kernel<BN, WAVES_M, WAVES_N, TM, TN, true, false>), dim3(grid), dim3(256), 0, s, a);
-  else if (a.d.flags & FO_IN_RELU)
+  } else if (a.d.flags & FO_IN_RELU) {
+    FO_NOTE_T("conv_bf16_kernel", BN, WAVES_M, WAVES_N, TM, TN, false, true);
     hipLaunchKernelGGL((conv_bf16_kernel<BN, WAVES_M, WAVES_N, TM, TN, false, true>), dim3(grid), dim3(256), 0, s, a);
-  else
+  } else {
+    FO_NOTE_T("conv_bf16_kernel", BN, WAVES_M, WAVES_N, TM, TN, false, false);
     hipLaunchKernelGGL((conv_bf16_kernel<BN, WAVES_M, WAVES_N, TM, TN, false, false>), dim3(grid), dim3(256), 0, s, a);
+  }
   FO_CHECK_LAUNCH();
   return FO_OK;
 }
@@ -1220,6 +1227,7 @@ static int conv_bf16_impl(const fo_conv_desc* d, const void* in, const void* wp,
       a.Ktot == 128 && inBytes < (1ull << 31) && !(norgb && atoi(norgb))) {
     const int nblocks = (a.M + 31) / 32;
     const int grid = std::min((nblocks + 3) / 4, fo_cu_count() * 3);
+    FO_NOTE("conv_rgb_bf16_kernel");
     hipLaunchKernelGGL(conv_rgb_bf16_kernel, dim3(grid), dim3(256), 0, s, a, nblocks);
     FO_CHECK_LAUNCH();
     return FO_OK;
@@ -1231,6 +1239,7 @@ static int conv_bf16_impl(const fo_conv_desc* d, const void* in, const void* wp,
     static fo_lds_once once;
     if (!fo_lds_optin(once, reinterpret_cast<const void*>(conv_rgb_dgrad_bf16_kernel), ldsBytes, "conv_bf16 (rgb dgrad)")) return FO_E_HIP;
     const int segsPerRow = d->Win / 64, nseg = d->N * d->Hin * segsPerRow;
+    FO_NOTE("conv_rgb_dgrad_bf16_kernel");
     hipLaunchKernelGGL(conv_rgb_dgrad_bf16_kernel, dim3(std::min(nseg, 2 * fo_cu_count())), dim3(256), ldsBytes, s, a, nseg, segsPerRow);
     FO_CHECK_LAUNCH();
     return FO_OK;

@@ -504,6 +504,7 @@ int fo_convnd(const fo_convnd_desc* d, int transposed, const float* src, const f
   a.srcBytes = (unsigned)srcBytes; a.wpBytes = (unsigned)wpBytes; a.margin = (int)margin;
   const long long grid = tiles * a.ksplit;
   FO_REQUIRE(grid < (1ll << 31), FO_E_SHAPE, "convnd: grid");
+  FO_NOTE("conv_gen_kernel");
   hipLaunchKernelGGL(conv_gen_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
   FO_CHECK_LAUNCH();
   if (a.ksplit > 1) {
@@ -552,6 +553,7 @@ int fo_wgradnd(const fo_convnd_desc* d, const float* g, const float* src, float*
   FO_REQUIRE(srcBytes < (1ull << 31) && gBytes < (1ull << 31), FO_E_SHAPE, "wgradnd: tensor exceeds the 2 GiB window");
   a.srcBytes = (unsigned)srcBytes; a.gBytes = (unsigned)gBytes; a.margin = 0;
   const long long grid = (long long)a.taps * a.tilesCo * a.tilesCi * a.splits;
+  FO_NOTE("wgrad_gen_kernel");
   hipLaunchKernelGGL(wgrad_gen_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
   FO_CHECK_LAUNCH();
   if (a.splits > 1) {

@@ -504,6 +504,8 @@ template <int BN, int WAVES_M, int WAVES_N, int TM, int TN>
 int launch(const ConvArgs& a, bool smallc, hipStream_t s) {
   const int grid = a.tilesM * a.tilesN;
   const bool inrelu = (a.d.flags & FO_IN_RELU) != 0;
+  if (smallc) { if (inrelu) FO_NOTE_T("conv_igemm_kernel", BN, WAVES_M, WAVES_N, TM, TN, true, true, false); else FO_NOTE_T("conv_igemm_kernel", BN, WAVES_M, WAVES_N, TM, TN, true, false, false); }
+  else { if (inrelu) FO_NOTE_T("conv_igemm_kernel", BN, WAVES_M, WAVES_N, TM, TN, false, true, false); else FO_NOTE_T("conv_igemm_kernel", BN, WAVES_M, WAVES_N, TM, TN, false, false, false); }
   if (smallc && inrelu)
     hipLaunchKernelGGL((conv_igemm_kernel<BN, WAVES_M, WAVES_N, TM, TN, true, true>), dim3(grid), dim3(256), 0, s, a);
   else if (smallc)
@@ -623,6 +625,7 @@ static int conv_igemm_impl(const fo_conv_desc* d, const float* in, const float* 
   if (d->Cout > 64) {
     a.tilesN = (d->Cout + 127) / 128;
     if (pick_variant(d) == 3 && bank_frames == 0) {
+      if (d->flags & FO_IN_RELU) FO_NOTE_T("conv_igemm3_kernel", 2, 2, true); else FO_NOTE_T("conv_igemm3_kernel", 2, 2, false);
       if (d->flags & FO_IN_RELU) hipLaunchKernelGGL((conv_igemm3_kernel<2, 2, true>), dim3(a.tilesM * a.tilesN), dim3(256), 0, s, a);
       else hipLaunchKernelGGL((conv_igemm3_kernel<2, 2, false>), dim3(a.tilesM * a.tilesN), dim3(256), 0, s, a);
       FO_CHECK_LAUNCH();
@@ -665,6 +668,7 @@ extern "C" int fo_resblock_fwd(const fo_conv_desc* d, const float* x, const floa
   if (int rc = fill_args(&dd, x, wp1, b1, nullptr, x, hbuf, 0, a)) return rc;
   a.wp2 = wp3; a.bias2 = b3; a.out2 = out; a.ldOut2 = ldOut2; a.relu2 = out_relu;
   a.tilesN = 1;
+  FO_NOTE_T("conv_igemm_kernel", 32, 4, 1, 1, 1, false, true, true);
   hipLaunchKernelGGL((conv_igemm_kernel<32, 4, 1, 1, 1, false, true, true>), dim3(a.tilesM * a.tilesN), dim3(256), 0, (hipStream_t)stream, a);
   FO_CHECK_LAUNCH();
   return FO_OK;

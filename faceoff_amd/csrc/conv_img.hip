@@ -175,6 +175,8 @@ int fo_conv_img_try(const fo_conv_desc* d, const float* in, const float* wp, con
     if (((long long)g * 128) % HWo == 0) { grid = g; break; }
   if (!grid || (long long)grid * 128 > M) return 1;
   const bool hm = d->flags & FO_MASK, ha = d->flags & FO_ADD;
+  if (hm) { if (ha) FO_NOTE_T("conv_img_kernel", true, true); else FO_NOTE_T("conv_img_kernel", true, false); }
+  else { if (ha) FO_NOTE_T("conv_img_kernel", false, true); else FO_NOTE_T("conv_img_kernel", false, false); }
   if (hm && ha) hipLaunchKernelGGL((conv_img_kernel<true, true>), dim3(grid), dim3(256), 0, stream, a);
   else if (hm) hipLaunchKernelGGL((conv_img_kernel<true, false>), dim3(grid), dim3(256), 0, stream, a);
   else if (ha) hipLaunchKernelGGL((conv_img_kernel<false, true>), dim3(grid), dim3(256), 0, stream, a);

@@ -561,8 +561,11 @@ extern "C" int64_t fo_wgrad_ws_bytes(const fo_conv_desc* d) { return wgrad_ws_by
 extern "C" int64_t fo_wgrad_banked_ws_bytes(const fo_conv_desc* d, int banks) { return wgrad_ws_bytes(d, banks); }
 
 #define WG_LAUNCH1(TA_, TB_, WA_, WB_, TM_, TN_, SC_, FR_, IR_)                                                       \
-  hipLaunchKernelGGL((conv_wgrad_kernel<TA_, TB_, WA_, WB_, TM_, TN_, SC_, FR_, IR_>), dim3(grid), dim3(64 * WA_ * WB_), \
-                     0, s, a)
+  do {                                                                                                                \
+    FO_NOTE_T("conv_wgrad_kernel", TA_, TB_, WA_, WB_, TM_, TN_, SC_, FR_, IR_);                                       \
+    hipLaunchKernelGGL((conv_wgrad_kernel<TA_, TB_, WA_, WB_, TM_, TN_, SC_, FR_, IR_>), dim3(grid), dim3(64 * WA_ * WB_), \
+                       0, s, a);                                                                                      \
+  } while (0)
 #define WG_LAUNCH(TA_, TB_, WA_, WB_, TM_, TN_)                     \
   do {                                                               \
     if (fastrow && inrelu) WG_LAUNCH1(TA_, TB_, WA_, WB_, TM_, TN_, false, true, true); \

@@ -204,8 +204,8 @@ int fo_disc_head_fwd(const fo_convnd_desc* d, const float* x, const float* wp, c
   const int lds = a.KD * a.KH * a.KW * a.C * 4;
   const long long M = (long long)a.N * a.Dd * a.Hd * a.Wd;
   const int grid = (int)std::min<long long>((M + 3) / 4, fo_cu_count());
-  if (a.C == 512) { if (int rc = set_lds(disc_head_fwd_kernel<8>, lds)) return rc; hipLaunchKernelGGL(disc_head_fwd_kernel<8>, dim3(grid), dim3(256), lds, (hipStream_t)stream, a); }
-  else { if (int rc = set_lds(disc_head_fwd_kernel<4>, lds)) return rc; hipLaunchKernelGGL(disc_head_fwd_kernel<4>, dim3(grid), dim3(256), lds, (hipStream_t)stream, a); }
+  if (a.C == 512) { if (int rc = set_lds(disc_head_fwd_kernel<8>, lds)) return rc; FO_NOTE_T("disc_head_fwd_kernel", 8); hipLaunchKernelGGL(disc_head_fwd_kernel<8>, dim3(grid), dim3(256), lds, (hipStream_t)stream, a); }
+  else { if (int rc = set_lds(disc_head_fwd_kernel<4>, lds)) return rc; FO_NOTE_T("disc_head_fwd_kernel", 4); hipLaunchKernelGGL(disc_head_fwd_kernel<4>, dim3(grid), dim3(256), lds, (hipStream_t)stream, a); }
   FO_CHECK_LAUNCH();
   return FO_OK;
 }
@@ -218,8 +218,8 @@ int fo_disc_head_dgrad(const fo_convnd_desc* d, const float* g, const float* wp,
   const int lds = a.KD * a.KH * a.KW * a.C * 4;
   const long long M = (long long)a.N * a.Ds * a.Hs * a.Ws;
   const int grid = (int)std::min<long long>((M + 3) / 4, fo_cu_count());
-  if (a.C == 512) { if (int rc = set_lds(disc_head_dgrad_kernel<8>, lds)) return rc; hipLaunchKernelGGL(disc_head_dgrad_kernel<8>, dim3(grid), dim3(256), lds, (hipStream_t)stream, a); }
-  else { if (int rc = set_lds(disc_head_dgrad_kernel<4>, lds)) return rc; hipLaunchKernelGGL(disc_head_dgrad_kernel<4>, dim3(grid), dim3(256), lds, (hipStream_t)stream, a); }
+  if (a.C == 512) { if (int rc = set_lds(disc_head_dgrad_kernel<8>, lds)) return rc; FO_NOTE_T("disc_head_dgrad_kernel", 8); hipLaunchKernelGGL(disc_head_dgrad_kernel<8>, dim3(grid), dim3(256), lds, (hipStream_t)stream, a); }
+  else { if (int rc = set_lds(disc_head_dgrad_kernel<4>, lds)) return rc; FO_NOTE_T("disc_head_dgrad_kernel", 4); hipLaunchKernelGGL(disc_head_dgrad_kernel<4>, dim3(grid), dim3(256), lds, (hipStream_t)stream, a); }
   FO_CHECK_LAUNCH();
   return FO_OK;
 }
@@ -238,11 +238,11 @@ int fo_disc_head_wgrad(const fo_convnd_desc* d, const float* g, const float* x, 
   const long long M = (long long)a.N * a.Ds * a.Hs * a.Ws;
   const int grid = (int)std::min<long long>(M, fo_cu_count());
   if (a.C == 512) {
-    if (taps > 16) hipLaunchKernelGGL((disc_head_wgrad_kernel<64, 2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((disc_head_wgrad_kernel<16, 2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    if (taps > 16) { FO_NOTE_T("disc_head_wgrad_kernel", 64, 2); hipLaunchKernelGGL((disc_head_wgrad_kernel<64, 2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a); }
+    else { FO_NOTE_T("disc_head_wgrad_kernel", 16, 2); hipLaunchKernelGGL((disc_head_wgrad_kernel<16, 2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a); }
   } else {
-    if (taps > 16) hipLaunchKernelGGL((disc_head_wgrad_kernel<64, 1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((disc_head_wgrad_kernel<16, 1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    if (taps > 16) { FO_NOTE_T("disc_head_wgrad_kernel", 64, 1); hipLaunchKernelGGL((disc_head_wgrad_kernel<64, 1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a); }
+    else { FO_NOTE_T("disc_head_wgrad_kernel", 16, 1); hipLaunchKernelGGL((disc_head_wgrad_kernel<16, 1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a); }
   }
   FO_CHECK_LAUNCH();
   hipLaunchKernelGGL(disc_head_wgrad_reduce_kernel, dim3((taps * a.C + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws, grid, taps, a.C, CsReal, dw);

@@ -304,6 +304,7 @@ int fo_conv3x3_c128to32_halo_bf16_try(const fo_conv_desc* d, const void* in, con
   a.xBytes = (unsigned)xB; a.hBytes = (unsigned)hB;
   static fo_lds_once once;
   if (!fo_lds_optin(once, reinterpret_cast<const void*>(conv3x3_c128to32_halo_bf16_kernel), C1_LDS, "resblock_bf16")) return 0;   // -> the tiled kernel
+  FO_NOTE("conv3x3_c128to32_halo_bf16_kernel");
   hipLaunchKernelGGL(conv3x3_c128to32_halo_bf16_kernel, dim3(std::max(8, std::min((a.ntiles + 7) / 8 * 8, 2 * cus) / 8 * 8)), dim3(256), C1_LDS, stream, a);
   return 1;
 }
@@ -328,6 +329,7 @@ int fo_conv3x3_c32to128_halo_bf16_try(const fo_conv_desc* d, const void* in, con
   const size_t gB = (npix - 1) * d->ldIn * 2 + 64, mB = (npix - 1) * d->ldMask * 2 + 256, aB = (npix - 1) * d->ldAdd * 2 + 256, oB = (npix - 1) * d->ldOut * 2 + 256;
   if (gB >= 0x7fffffffull || mB >= 0x7fffffffull || aB >= 0x7fffffffull || oB >= 0x7fffffffull) return 0;
   a.ghBytes = (unsigned)gB; a.mBytes = (unsigned)mB; a.aBytes = (unsigned)aB; a.oBytes = (unsigned)oB;
+  FO_NOTE("conv3x3_c32to128_halo_bf16_kernel");
   hipLaunchKernelGGL(conv3x3_c32to128_halo_bf16_kernel, dim3(std::max(8, std::min((a.ntiles + 7) / 8 * 8, 2 * cus) / 8 * 8)), dim3(256), 2 * SLB, stream, a);
   return 1;
 }

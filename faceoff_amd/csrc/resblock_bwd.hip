@@ -341,6 +341,8 @@ int fo_conv3x3_c32_halo_try(const fo_conv_desc* d, const float* in, const float*
   if (ghB >= 0x7fffffffull || mB >= 0x7fffffffull || aB >= 0x7fffffffull || oB >= 0x7fffffffull) return 0;
   a.ghBytes = (unsigned)ghB; a.mBytes = (unsigned)mB; a.aBytes = (unsigned)aB; a.oBytes = (unsigned)oB;
   const dim3 grid(std::max(8, std::min((a.ntiles + 7) / 8 * 8, 2 * cus) / 8 * 8));
+  if (mask) { if (add) FO_NOTE_T("conv3x3_c32_halo_kernel", true, true); else FO_NOTE_T("conv3x3_c32_halo_kernel", true, false); }
+  else { if (add) FO_NOTE_T("conv3x3_c32_halo_kernel", false, true); else FO_NOTE_T("conv3x3_c32_halo_kernel", false, false); }
   if (mask && add) hipLaunchKernelGGL((conv3x3_c32_halo_kernel<true, true>), grid, dim3(256), 2 * PATCHB, stream, a);
   else if (mask) hipLaunchKernelGGL((conv3x3_c32_halo_kernel<true, false>), grid, dim3(256), 2 * PATCHB, stream, a);
   else if (add) hipLaunchKernelGGL((conv3x3_c32_halo_kernel<false, true>), grid, dim3(256), 2 * PATCHB, stream, a);
@@ -521,6 +523,7 @@ int fo_resblock_wgrad1_halo_try(const fo_conv_desc* d, const float* P, const flo
   if (ws_bytes < (int64_t)grid * W1_SLAB * 4) return 0;
   static fo_lds_once once;
   if (!fo_lds_optin(once, reinterpret_cast<const void*>(resblock_wgrad1_halo_kernel), W1_LDS, "resblock_wgrad1")) return 0;        // -> the tiled kernel
+  FO_NOTE("resblock_wgrad1_halo_kernel");
   hipLaunchKernelGGL(resblock_wgrad1_halo_kernel, dim3(grid), dim3(256), W1_LDS, stream, a);
   hipLaunchKernelGGL(resblock_wgrad1_reduce_kernel, dim3((W1_SLAB + 63) / 64), dim3(512), 0, stream, ws, grid, dw, dbias);
   return 1;
@@ -547,6 +550,7 @@ extern "C" int fo_resblock_bwd_conv3(int64_t M, const float* g, int ldG, const f
   hipStream_t s = (hipStream_t)stream;
   static fo_lds_once once;
   if (!fo_lds_optin(once, reinterpret_cast<const void*>(resblock_bwd_conv3_kernel), LDS_BYTES, "resblock_bwd_conv3")) return FO_E_HIP;
+  FO_NOTE("resblock_bwd_conv3_kernel");
   hipLaunchKernelGGL(resblock_bwd_conv3_kernel, dim3(grid), dim3(256), LDS_BYTES, s, a);
   FO_CHECK_LAUNCH();
   hipLaunchKernelGGL(resblock_bwd_conv3_reduce_kernel, dim3((128 * 32 + 128 + 63) / 64), dim3(512), 0, s, ws, grid, dw3, db3);

@@ -318,6 +318,7 @@ int fo_resblock_halo_try(const fo_conv_desc* d, const float* x, const float* wp1
   if (!dstamps) (void)hipMalloc(&dstamps, (size_t)grid_ * 4 * 9 * 8 + 16);
   a.stamps = dstamps;
 #endif
+  FO_NOTE("resblock_halo_fwd_kernel");
   hipLaunchKernelGGL(resblock_halo_fwd_kernel, dim3(std::max(8, std::min((a.ntiles + 7) / 8 * 8, 2 * cus) / 8 * 8)), dim3(256), ldsBytes, stream, a);
 #if FO_RB_STAMP
   {

@@ -513,6 +513,7 @@ int launch_w(const WArgs& a, int grid, hipStream_t s) {       // 1 = launched, -
   void (*kern)(const WArgs) = wgrad_bf16_kernel<TA, TB, WA, NKW, KR, FAST, SMALLC>;
   static fo_lds_once once;
   if (ldsBytes > 48 * 1024 && !fo_lds_optin(once, reinterpret_cast<const void*>(kern), ldsBytes, "wgrad_bf16")) return -1;
+  FO_NOTE_T("wgrad_bf16_kernel", TA, TB, WA, NKW, KR, FAST, SMALLC);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), ldsBytes, s, a);
   return 1;
 }

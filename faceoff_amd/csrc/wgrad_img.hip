@@ -207,6 +207,7 @@ int fo_wgrad_img_try(const fo_conv_desc* d, const float* P, const float* Q, floa
   a.perWave = (int)(((M + waves - 1) / waves + 1) / 2 * 2);
   a.pBytes = (unsigned)(((unsigned long long)(M - 1) * d->ldOut + 64) * 4ull);
   a.qBytes = (unsigned)((unsigned long long)M * 4 * 32ull);
+  FO_NOTE("wgrad_img_kernel");
   hipLaunchKernelGGL(wgrad_img_kernel, dim3(nslabs()), dim3(256), 0, stream, a);
   hipLaunchKernelGGL(wgrad_img_reduce_kernel, dim3((SLAB + 63) / 64), dim3(256), 0, stream, ws, nslabs(), dw, Areal, Breal, dbias);
   return hipGetLastError() == hipSuccess ? 0 : 1;

@@ -271,6 +271,7 @@ extern "C" int fo_wino_gemm(const float* V, const float* U, float* M, int planes
   grid = (grid + 7) / 8 * 8;
   const int maxUseful = ((a.tiles + 7) / 8) * 8;
   if (grid > maxUseful) grid = maxUseful;
+  FO_NOTE("wino_gemm_kernel");
   hipLaunchKernelGGL(wino_gemm_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
   FO_CHECK_LAUNCH();
   return FO_OK;

@@ -598,6 +598,7 @@ extern "C" int fo_wino_gemm_split(const float* V, const float* U, void* U3, floa
     constexpr int ldsBytes = 18 * PIECE;
     static fo_lds_once once256;
     if (!fo_lds_optin(once256, reinterpret_cast<const void*>(wino_gemm_split256_kernel), ldsBytes, "wino_gemm_split256")) return FO_E_HIP;
+    FO_NOTE("wino_gemm_split256_kernel");
     hipLaunchKernelGGL(wino_gemm_split256_kernel, dim3(grid), dim3(512), ldsBytes, (hipStream_t)stream, a);
     FO_CHECK_LAUNCH();
     return FO_OK;
@@ -609,6 +610,7 @@ extern "C" int fo_wino_gemm_split(const float* V, const float* U, void* U3, floa
   constexpr int ldsBytes = 9 * PIECE;
   static fo_lds_once once;
   if (!fo_lds_optin(once, reinterpret_cast<const void*>(wino_gemm_split_kernel), ldsBytes, "wino_gemm_split")) return FO_E_HIP;
+  FO_NOTE("wino_gemm_split_kernel");
   hipLaunchKernelGGL(wino_gemm_split_kernel, dim3(grid), dim3(256), ldsBytes, (hipStream_t)stream, a);
   FO_CHECK_LAUNCH();
   return FO_OK;

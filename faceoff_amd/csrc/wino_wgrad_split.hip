@@ -397,6 +397,7 @@ extern "C" int fo_wino_wgrad_split(const float* dM, const float* V, float* dU, f
     b.Cin = Cin; b.Cout = Cout; b.planeRows = (long long)N * P;
     const int blocks3 = planes * b.tilesA * b.tilesB;
     b.slabs = pick_slabs3(blocks3, b.units);
+    FO_NOTE("wino_wgrad_split3_kernel");
     hipLaunchKernelGGL(wino_wgrad_split3_kernel, dim3(blocks3 * b.slabs), dim3(512), 0, (hipStream_t)stream, b);
     FO_CHECK_LAUNCH();
     const long long total3 = (long long)planes * KD * Cout * Cin;
@@ -416,6 +417,7 @@ extern "C" int fo_wino_wgrad_split(const float* dM, const float* V, float* dU, f
   a.Cin = Cin; a.Cout = Cout;
   const int blocks = planes * KD * a.tilesA * a.tilesB;
   a.slabs = pick_slabs(blocks, a.planeRows / 32);
+  FO_NOTE("wino_wgrad_split_kernel");
   hipLaunchKernelGGL(wino_wgrad_split_kernel, dim3(blocks * a.slabs), dim3(256), 0, (hipStream_t)stream, a);
   FO_CHECK_LAUNCH();
   const long long total = (long long)planes * KD * Cout * Cin;

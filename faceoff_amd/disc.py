@@ -222,8 +222,9 @@ class DiscEngine:
             flags = FO_BIAS | (FO_OUT_LRELU if j == 0 else 0) | (FO_KSPLIT if ksplit else 0)
             d = self._desc(N, sd, cin, h.shape[-1], dd, co, ld_out, s, flags)
             if self._head_ok(co, s, cin):       # the 1-channel head: dot products, not a 64-column tile (csrc/disc_head.hip)
-                _lib.call("fo_disc_head_fwd", C.byref(d), ops._ptr(h), ops._ptr(self._wp[key + ".0.weight"]), ops._ptr(self.params[key + ".0.bias"]),
-                          ops._ptr(y), ops._stream())
+                self._profiled("fo_disc_head_fwd", self._conv_flops(d) if ops.PROFILER is not None else None, lambda: _lib.call(
+                    "fo_disc_head_fwd", C.byref(d), ops._ptr(h), ops._ptr(self._wp[key + ".0.weight"]), ops._ptr(self.params[key + ".0.bias"]),
+                    ops._ptr(y), ops._stream()))
             else:
                 self._convnd(d, 0, h, self._wp[key + ".0.weight"], self.params[key + ".0.bias"], None, y)
             if 1 <= j <= 3:
@@ -268,23 +269,50 @@ class DiscEngine:
         return co == 1 and stride == 1 and cin in (256, 512) and not _os.environ.get("FACEOFF_NO_DISC_HEAD")
 
     @staticmethod
-    def _convnd(d, transposed, src, wp, bias, mask, dst):
+    def _conv_flops(d, transposed=0, cs_real=None):
+        """(algorithmic, nominal) FLOP of the convolution d describes, in either direction: 2 x output positions x Cout x taps x Cin, where
+        `algorithmic` counts only the taps whose input exists (per axis, the (position, tap) pairs inside the input: padded taps are
+        structural zeros the kernels skip) and `nominal` counts every tap.  Channels as the launch sees them (the source padded to 32)."""
+        # the conv's input grid / output grid: forward = (source, destination), transposed = (destination, source)
+        gin = (d.Dd, d.Hd, d.Wd) if transposed else (d.Ds, d.Hs, d.Ws)
+        gout = (d.Ds, d.Hs, d.Ws) if transposed else (d.Dd, d.Hd, d.Wd)
+        valid, nominal = 1.0, 1.0
+        for nin, nout, k, st, pd in zip(gin, gout, (d.KD, d.KH, d.KW), (d.sD, d.sH, d.sW), (d.pD, d.pH, d.pW)):
+            valid *= sum(1 for o in range(nout) for t in range(k) if 0 <= o * st + t - pd < nin)
+            nominal *= nout * k
+        ch = 2.0 * d.N * d.Cd * (cs_real if cs_real is not None else d.Cs)
+        return ch * valid, ch * nominal
+
+    @staticmethod
+    def _profiled(label, flops, fn):
+        prof = ops.PROFILER
+        if prof is not None:
+            prof.begin(label, *flops)
+        fn()
+        if prof is not None:
+            prof.end()
+
+    @classmethod
+    def _convnd(cls, d, transposed, src, wp, bias, mask, dst):
         """fo_convnd with the workspace its K-slices need (FO_KSPLIT in d.flags and a shape the C side decides to slice)"""
         nbytes = _lib.load().fo_convnd_ws_bytes(C.byref(d), transposed) if d.flags & FO_KSPLIT else 0
         ws = ops._workspace(nbytes, src.device) if nbytes else None
-        _lib.call("fo_convnd", C.byref(d), transposed, ops._ptr(src), ops._ptr(wp), ops._ptr(bias), ops._ptr(mask), ops._ptr(dst),
-                  ops._ptr(ws), C.c_int64(ws.numel() * 4 if ws is not None else 0), ops._stream())
+        cls._profiled("fo_convnd" + ("_t" if transposed else ""), cls._conv_flops(d, transposed) if ops.PROFILER is not None else None, lambda: _lib.call(
+            "fo_convnd", C.byref(d), transposed, ops._ptr(src), ops._ptr(wp), ops._ptr(bias), ops._ptr(mask), ops._ptr(dst),
+            ops._ptr(ws), C.c_int64(ws.numel() * 4 if ws is not None else 0), ops._stream()))
 
-    @staticmethod
-    def _wgradnd(d, g, src, dw, cs_real):
+    @classmethod
+    def _wgradnd(cls, d, g, src, dw, cs_real):
         ws = ops._workspace(_lib.load().fo_wgradnd_ws_bytes(C.byref(d)), g.device)
-        _lib.call("fo_wgradnd", C.byref(d), ops._ptr(g), ops._ptr(src), ops._ptr(dw), cs_real, ops._ptr(ws), C.c_int64(ws.numel() * 4), ops._stream())
+        cls._profiled("fo_wgradnd", cls._conv_flops(d, 0, cs_real) if ops.PROFILER is not None else None, lambda: _lib.call(
+            "fo_wgradnd", C.byref(d), ops._ptr(g), ops._ptr(src), ops._ptr(dw), cs_real, ops._ptr(ws), C.c_int64(ws.numel() * 4), ops._stream()))
 
     def _wgrad(self, d, g, src, key, cs_real):
         dw = self.grads[key + ".0.weight"]
         if self._head_ok(d.Cd, d.sH, d.Cs):
             ws = ops._workspace(_lib.load().fo_disc_head_wgrad_ws_bytes(C.byref(d)), g.device)
-            _lib.call("fo_disc_head_wgrad", C.byref(d), ops._ptr(g), ops._ptr(src), ops._ptr(dw), cs_real, ops._ptr(ws), C.c_int64(ws.numel() * 4), ops._stream())
+            self._profiled("fo_disc_head_wgrad", self._conv_flops(d, 0, cs_real) if ops.PROFILER is not None else None, lambda: _lib.call(
+                "fo_disc_head_wgrad", C.byref(d), ops._ptr(g), ops._ptr(src), ops._ptr(dw), cs_real, ops._ptr(ws), C.c_int64(ws.numel() * 4), ops._stream()))
             rows = g.numel() // g.shape[-1]
             ops.bias_grad(g.view(rows, 1, 1, g.shape[-1]), self.grads[key + ".0.bias"], d.Cd)
             return
@@ -339,7 +367,8 @@ class DiscEngine:
             flags = (FO_MASK_LRELU if j == 1 else 0) | (FO_KSPLIT if ksplit else 0)          # layer 0's LeakyReLU (no norm in between): mask = its output
             if self._head_ok(co, s, cin_pad) and cin_real == cin_pad:
                 dfw = self._desc(N, sd, cin_pad, cin_pad, dd, co, g.shape[-1], s)       # the forward convolution's description
-                _lib.call("fo_disc_head_dgrad", C.byref(dfw), ops._ptr(g), ops._ptr(self._wp[key + ".0.weight"]), ops._ptr(gin), ops._stream())
+                self._profiled("fo_disc_head_dgrad", self._conv_flops(dfw) if ops.PROFILER is not None else None, lambda: _lib.call(
+                    "fo_disc_head_dgrad", C.byref(dfw), ops._ptr(g), ops._ptr(self._wp[key + ".0.weight"]), ops._ptr(gin), ops._stream()))
             else:
                 d = self._desc(N, dd, cs, g.shape[-1], sd, cin_real, cin_pad, s, flags, ld_mask=cin_pad if j == 1 else 0)
                 self._convnd(d, 1, g, self._wpt[key + ".0.weight"], None, x_in if j == 1 else None, gin)

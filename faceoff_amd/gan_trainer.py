@@ -28,8 +28,11 @@ from .trainer import FlatAdam, LATENT_LOSS_WEIGHT
 
 class GANTrainer:
     def __init__(self, engine: VQVAEEngine, disc3d: DiscEngine, disc2d: DiscEngine, lr=3e-4, d_lr=1e-4, scheduler=None, window=16,
-                 rng=None):
+                 rng=None, comm=None):
+        """comm: a distributed.comm.AbiComm -- the three gradient arenas and the VQ statistics then travel through the C-ABI communicator
+        (fo_comm_*) instead of torch.distributed."""
         self.engine, self.d3, self.d2 = engine, disc3d, disc2d
+        self.comm = comm
         self.optimizer = FlatAdam(engine, lr=lr)
         self.scheduler = scheduler
         self.d_lr = d_lr
@@ -39,13 +42,23 @@ class GANTrainer:
         # data parallel (the reference wraps generator and both discriminators in DDP): every rank runs its own clip, the
         # flat gradient arenas are summed over ranks in one all-reduce each and averaged inside the Adam launch; the VQ
         # statistics are summed in the forward (vqvae_conv3d_latent.py:63-64)
-        self.world = get_world_size()
-        if self.world > 1:
+        self.world = comm.world if comm is not None else get_world_size()
+        if comm is not None and self.world > 1:
+            def vq_ar_abi(st):
+                comm.allreduce_async(st)
+                comm.wait()
+                return st
+            engine.vq_allreduce = vq_ar_abi
+        elif self.world > 1:
             engine.vq_allreduce = fused_vq_allreduce()
 
     def _sum_over_ranks(self, flat):
         if self.world > 1:
-            torch.distributed.all_reduce(flat)
+            if self.comm is not None:
+                self.comm.allreduce_async(flat)
+                self.comm.wait()
+            else:
+                torch.distributed.all_reduce(flat)
         return 1.0 / self.world
 
     # ------------------------------------------------------------------ the random choices, in the reference's call order

@@ -17,28 +17,43 @@ from ._lib import ConvDesc, FO_IN_RELU, FO_BIAS, FO_MASK, FO_ADD, FO_OUT_RELU, F
 
 class KernelProfiler:
     """Live per-launch timing with HIP events on the launch stream (bench.py's roofline leg).
-    Groups launches by kernel instance name; `flops` is the ALGORITHMIC work of the launch: multiply-adds whose
-    operands exist.  For a Conv3d that excludes the temporal taps that fall into clip padding (structural zeros the
-    kernels skip: 2 of 15 at T=5, `temporal_share`); `nominal` is the padded-tap count SURVEY.md section 8(d) quotes."""
+    Launches are grouped by the SYMBOL of the kernel the library launched -- name and template arguments as rocprofv3 prints them, reported
+    by the library itself (fo_kernel_notes / fo_last_kernel) -- so that an entry of bench.py's JSON line can be looked up in
+    profiles/*_kernel_stats.md.  `flops` is the ALGORITHMIC work of the launch: multiply-adds whose operands exist.  For a Conv3d that
+    excludes the temporal taps that fall into clip padding (structural zeros the kernels skip: 2 of 15 at T=5, `temporal_share`);
+    `nominal` is the padded-tap count SURVEY.md section 8(d) quotes.  An entry point that launches a main kernel plus a small reduce
+    (filter gradients) is timed as a whole under the main kernel's symbol."""
 
     def __init__(self, detail=False):
-        self.records = {}     # name -> list of (start_event, end_event, flops)
+        self.records = {}     # symbol -> list of (start_event, end_event, flops)
         self._cur = None
         self.detail = detail  # key launches by geometry as well (tools/, not bench.py's JSON line)
+        self._lib = _lib.load()
+        self._lib.fo_kernel_notes(1)
 
-    def begin(self, name, flops, nominal=None):
+    def close(self):
+        self._lib.fo_kernel_notes(0)
+
+    def begin(self, label, flops, nominal=None):
+        """label: the call's own description; used as the key only if the library noted no kernel.  In detail mode a trailing
+        " [geometry]" of the label is appended to the symbol."""
+        self._lib.fo_last_kernel()           # (reading clears: a stale note of an un-profiled call must not name this one)
         s = torch.cuda.Event(enable_timing=True)
         s.record(torch.cuda.current_stream())
-        self._cur = (name, s, (flops, flops if nominal is None else nominal))
+        self._cur = (label, s, (flops, flops if nominal is None else nominal))
 
     def end(self):
-        name, s, flops = self._cur
+        label, s, flops = self._cur
         e = torch.cuda.Event(enable_timing=True)
         e.record(torch.cuda.current_stream())
+        sym = self._lib.fo_last_kernel().decode()
+        name = sym or label
+        if sym and self.detail and " [" in label:
+            name = sym + label[label.index(" ["):]
         self.records.setdefault(name, []).append((s, e, flops))
 
     def summary(self):
-        """name -> dict(launches, total_ms, avg_ms, flops_per_launch, tflops) (synchronises)."""
+        """symbol -> dict(launches, total_ms, avg_ms, flops_per_launch, tflops) (synchronises)."""
         torch.cuda.synchronize()
         out = {}
         for name, recs in self.records.items():

@@ -54,6 +54,12 @@ extern "C" {
 
 int fo_version(void);
 const char* fo_last_error(void);
+/* Kernel notes (measurement plumbing, off by default).  fo_kernel_notes(1): from now on every entry point records the symbol of the MAIN kernel
+ * it launches -- name and template arguments as rocprofv3 --kernel-trace prints them, e.g. "conv_bf16_pp16_kernel<256, 256, 2, 4>" -- in a
+ * thread-local; returns the previous setting.  fo_last_kernel(): the symbol recorded by the calling thread's last entry point ("" if none),
+ * cleared by the read.  bench.py keys its per-kernel timings by these names, so `roofline.kernel` can be looked up in profiles/. */
+int fo_kernel_notes(int enable);
+const char* fo_last_kernel(void);
 /* device properties the host needs for the roofline report: [0]=CU count, [1]=clock kHz, [2]=is gfx950 */
 int fo_device_info(int32_t* out3);
 

@@ -27,18 +27,11 @@ def short(name):
 
 
 def label(name):
-    """bench.py's kernel label for a rocprof kernel name (None if not one of the conv kernels)."""
-    m = re.search(r"conv_igemm_kernel<(\d+), *\d+, *\d+, *\d+, *\d+, *(true|false|\(bool\)[01]|[01])", name)
-    if m:
-        small = m.group(2) in ("true", "(bool)1", "1")
-        return f"conv_igemm_bn{m.group(1)}" + ("_smallc" if small else "")
-    if "conv_igemm3_kernel" in name:
-        return "conv_igemm3"
-    if "wino_gemm_kernel" in name:
-        return "wino_gemm"
-    m = re.search(r"conv_wgrad_kernel<(\d+), *(\d+)", name)
-    if m:
-        return f"conv_wgrad_tile{m.group(1)}x{m.group(2)}"
+    """bench.py's per-kernel key for a rocprof kernel name: since round 4 that IS the short symbol (ops.KernelProfiler keys launches by what
+    the library reports through fo_last_kernel, which is what rocprofv3 prints).  Small reduce / layout kernels are left out of the table."""
+    n = short(name)
+    if re.search(r"(conv_|wgrad_|wino_gemm|wino_wgrad|resblock_|vq_assign|disc_head)", n) and "reduce" not in n and "pack" not in n:
+        return n
     return None
 
 

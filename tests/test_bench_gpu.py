@@ -30,6 +30,12 @@ def test_bench_emits_one_valid_json_line():
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     # achieved = algorithmic FLOP per launch / average launch duration
     assert abs(r["achieved"] - r["algorithmic_gflop_per_launch"] / r["avg_launch_ms"]) < 0.02 * r["achieved"]
+    # per-kernel entries are keyed by the kernel SYMBOL the library reports (what rocprofv3 prints: profiles/*_kernel_stats.md), not by a label
+    assert r["kernel"] == "wino_gemm_kernel", r["kernel"]
+    assert "resblock_halo_fwd_kernel" in d["kernels"] and any(k.startswith("conv_wgrad_kernel<") for k in d["kernels"]), list(d["kernels"])
+    assert not any(k.startswith(("conv_igemm_bn", "fo_")) for k in d["kernels"]), list(d["kernels"])       # no made-up bucket names left
+    dc = r["direct_conv"]
+    assert dc["kernel"].startswith("conv_igemm3_kernel<") and 0 < dc["step_frac_executed_flop"] < dc["step_frac_nominal_direct_conv_flop"] <= 1.0
     # the opt-in leg with fp32 products on the bf16 matrix pipe: its own step time (its losses are those of its own, fresh
     # trainer after its own number of steps; tests/test_split_gpu.py compares the two paths on equal inputs)
     # config 3 (bf16 MFMA operands for the VQ-VAE and the LPIPS branch): its own value, roofline block against the bf16 peak, and the two
@@ -40,7 +46,14 @@ def test_bench_emits_one_valid_json_line():
     assert r3["peak"] == 2500.0 and r3["bound"] == "mfma" and 0 < r3["frac"] <= 1.0 and abs(r3["frac"] - r3["achieved"] / r3["peak"]) < 1e-3
     assert c3["vqvae_only_bf16"]["value"] > c3["value"] and c3["fp32_vqvae"]["value"] > 0
     assert 0 < c3["loss"]["perceptual"] and 0 < c3["loss"]["recon"] < 1
+    assert r3["kernel"].startswith(("conv_bf16_", "wgrad_bf16_kernel<", "conv_halo64_bf16")) and not any(k.startswith(("conv_bf16_bn", "conv_bf16_big")) for k in c3["kernels"])
+    # config 5: its own roofline / kernels block
+    c5 = d["c5"]
+    r5 = c5["roofline"]
+    assert r5["peak"] == 157.3 and 0 < r5["frac"] <= 1.0 and abs(r5["frac"] - r5["achieved"] / r5["peak"]) < 1e-3 and r5["kernel"] in c5["kernels"]
+    assert "conv_gen_kernel" in c5["kernels"] and "wgrad_gen_kernel" in c5["kernels"] and 0 < c5["iteration_frac_executed_flop"] < 1
     x = d["bf16x6"]
+    assert any(k.startswith("wino_gemm_split") for k in x["kernels"]), list(x["kernels"])
     assert x["value"] > 0 and abs(x["value"] - 160 / (x["ms_per_step"] * 1e-3)) < 1e-2 * x["value"]
     assert 0 < x["loss"]["recon"] < 1 and 0 < x["loss"]["latent"] < 1
 
@@ -59,11 +72,23 @@ def test_bench_multi_gpu_code_path_with_one_rank():
     # the self-proving `comm` block: ranks the group really had, bytes moved, buckets, exposed all-reduce time, per-rank spread
     c = d["comm"]
     assert c["ranks_in_group"] == 1 and c["backend"] == "nccl" and c["rccl_version"] and c["collectives_forced_in_one_rank_group"] is True
+    # default exchange for an RCCL group: the C-ABI communicator -- every bucket + the two quantisers' statistics per step went through fo_comm_*
+    assert c["path"] == "fo_comm" and c["fo_comm_issued_per_step"] == c["buckets"] + 2, (c["path"], c["fo_comm_issued_per_step"], c["buckets"])
     assert c["grad_allreduce_bytes_per_step"] >= 4 * 4049990 and c["grad_allreduce_bytes_per_step"] % 16 == 0 and c["vq_stats_allreduce_bytes_per_step"] == 2 * (512 + 512 * 64) * 4
     assert c["allreduce_bytes_per_step"] == c["grad_allreduce_bytes_per_step"] + c["vq_stats_allreduce_bytes_per_step"]
     assert c["buckets"] == len(c["bucket_bytes"]) >= 3 and sum(c["bucket_bytes"]) == c["grad_allreduce_bytes_per_step"]
     assert c["exposed_ms"] is not None and 0 <= c["exposed_ms"] < d["ms_per_step"]
     assert c["ms_per_step_min_rank"] <= c["ms_per_step_max_rank"] and abs(c["ms_per_step_max_rank"] - d["ms_per_step"]) < 1e-2 * d["ms_per_step"]
+
+
+def test_bench_multi_gpu_code_path_over_torch_distributed():
+    """--comm torch: the same forced one-rank run with the all-reduces issued through torch.distributed (round 3's path)."""
+    env = dict(os.environ, FACEOFF_BENCH_FORCE_DDP="1", MASTER_PORT="29578")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-kernel-events",
+                          "--no-c3", "--no-c5", "--no-x6-leg", "--no-h2d-leg", "--comm", "torch"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    c = json.loads([l for l in out.stdout.splitlines() if l.strip()][0])["comm"]
+    assert c["path"] == "torch.distributed" and c["fo_comm_issued_per_step"] is None and c["buckets"] >= 3
 
 
 def test_bench_two_rank_control_flow_on_one_gpu():
