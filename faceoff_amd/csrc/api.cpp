@@ -12,7 +12,7 @@ void fo_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-std::atomic<int> fo_notes_on{0};
+std::atomic<int> faceoff_notes_on{0};
 static thread_local char g_kernel[160] = "";
 
 void fo_note_kernel(const char* base, const char* pretty) {
@@ -46,7 +46,7 @@ int fo_cu_count() {
 extern "C" {
 int fo_version(void) { return 100; }
 const char* fo_last_error(void) { return g_err; }
-int fo_kernel_notes(int enable) { return fo_notes_on.exchange(enable ? 1 : 0); }
+int fo_kernel_notes(int enable) { return faceoff_notes_on.exchange(enable ? 1 : 0); }
 const char* fo_last_kernel(void) {
   static thread_local char out[160];
   memcpy(out, g_kernel, sizeof out);

@@ -14,12 +14,12 @@ void fo_set_error(const char* fmt, ...);
 // Kernel notes (fo_kernel_notes / fo_last_kernel, include/faceoff_hip.h): while enabled, every launcher records the symbol of the MAIN kernel it
 // launches -- name and template arguments exactly as rocprofv3 prints them -- so that bench.py's per-kernel entries carry the names found in
 // profiles/*_kernel_stats.md.  FO_NOTE("wino_gemm_kernel"); FO_NOTE_T("conv_bf16_pp16_kernel", BMB, BN, WAVES_M, WAVES_N) -> "...<256, 256, 2, 4>".
-extern std::atomic<int> fo_notes_on;
+extern std::atomic<int> faceoff_notes_on;
 void fo_note_kernel(const char* base, const char* pretty_targs);
 template <auto... V> struct fo_vals {};
 template <class T> const char* fo_tname() { return __PRETTY_FUNCTION__; }      // "... [T = fo_vals<256, 256, 2, 4>]": clang prints what the demangler prints
-#define FO_NOTE(base) do { if (fo_notes_on.load(std::memory_order_relaxed)) fo_note_kernel(base, nullptr); } while (0)
-#define FO_NOTE_T(base, ...) do { if (fo_notes_on.load(std::memory_order_relaxed)) fo_note_kernel(base, fo_tname<fo_vals<__VA_ARGS__>>()); } while (0)
+#define FO_NOTE(base) do { if (faceoff_notes_on.load(std::memory_order_relaxed)) fo_note_kernel(base, nullptr); } while (0)
+#define FO_NOTE_T(base, ...) do { if (faceoff_notes_on.load(std::memory_order_relaxed)) fo_note_kernel(base, fo_tname<fo_vals<__VA_ARGS__>>()); } while (0)
 int fo_cu_count();  // compute units of the current device (cached; 256 on MI355X)
 // wgrad_img.hip: the filter gradient of the same layers (pixels as the contraction index, operands straight from global memory)
 int64_t fo_wgrad_img_ws_bytes(const fo_conv_desc* d);
