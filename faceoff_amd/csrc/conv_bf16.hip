@@ -89,6 +89,12 @@ __device__ __forceinline__ unsigned tap_mask(const fo_conv_desc& d, bool pv, int
 // relu() of two packed bf16
 __device__ __forceinline__ unsigned relu_pk(unsigned w) { return w & ~(((w & 0x80008000u) >> 15) * 0xffffu); }
 
+#ifndef FO_ABLATE_PP      // diagnostic builds of conv_bf16_pp16_kernel (tools/ablate_pp16.sh; results are wrong, only the timing is of interest):
+#define FO_ABLATE_PP 0    // bit 0 drop the loop's LDS-DMAs, bit 1 drop its MFMAs (one per phase stays), bit 2 one fragment read per operand
+#endif
+#ifndef FO_ABLATE_PP_LINES
+#define FO_ABLATE_PP_LINES 0
+#endif
 #ifndef FO_ABLATE_H   // diagnostic builds (tools/ablate_bf16.sh): bit 0 drop the loop's global loads, 1 its LDS stores,
 #define FO_ABLATE_H 0 // 2 its fragment reads (results are wrong, only the timing is of interest)
 #endif
@@ -760,8 +766,13 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_pp16_kernel(const ConvArgsH 
   unsigned tapmaskA[NPA], woffB[NPB];
 #pragma unroll
   for (int i = 0; i < NPA; ++i) {
+#if FO_ABLATE_PP_LINES      // diagnostic: a piece fetches 8 rows x 128 B (whole cache lines) instead of 16 rows x 64 B -- same bytes, half the lines; wrong results
+    const int row = (i * 8 + wave) * 16 + (lane >> 3) * 2;
+    const int chunk = lane & 7;
+#else
     const int row = (i * 8 + wave) * 16 + drow;
     const int chunk = dpos ^ swz(row);
+#endif
     const int m = tile_m * BMB + row;
     const bool pv = m < a.M;
     const int mm = pv ? m : 0;
@@ -791,7 +802,8 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_pp16_kernel(const ConvArgsH 
 #pragma unroll
     for (int i = 0; i < NPA; ++i) {
       // padding tap / row past M -> zeros; K tiles past the end: whatever the walk points at (never multiplied in: the loop ends first)
-      const unsigned pad = (((tapmaskA[i] >> kw_.tap) & 1u) - 1u) & OOB;
+      unsigned pad = (((tapmaskA[i] >> kw_.tap) & 1u) - 1u) & OOB;
+      if ((FO_ABLATE_PP & 8) && kw_.kw != 1) pad = OOB;         // diagnostic: the A operand fetched for the centre column tap only (zero-fill DMAs otherwise)
       dma16(rin, sa + (i * 8 + wave) * 1024, (unsigned)(rowoffA[i] + stepoff) | pad);
     }
 #pragma unroll
@@ -826,10 +838,10 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_pp16_kernel(const ConvArgsH 
     const unsigned char* Bs = lds + (p & 3) * SLOT + boff;
     bf16x8 fa[TM], fb[TN];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(Bs + j * 16 * 64);
+    for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(Bs + ((FO_ABLATE_PP & 4) ? 0 : j) * 16 * 64);
 #pragma unroll
-    for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(As + i * 16 * 64);
-    dma_tile();                                           // G0: tile p+2, G1: tile p+3
+    for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(As + ((FO_ABLATE_PP & 4) ? 0 : i) * 16 * 64);
+    if (!(FO_ABLATE_PP & 1)) dma_tile();                  // G0: tile p+2, G1: tile p+3
     if (g1) wait_vmcnt<2 * NP>();
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
@@ -838,7 +850,8 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_pp16_kernel(const ConvArgsH 
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < TN; ++j)
+        if (!(FO_ABLATE_PP & 2) || (i == 0 && j == 0)) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
     if (!g1) wait_vmcnt<NP>();
     __builtin_amdgcn_sched_barrier(0);
@@ -873,6 +886,249 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_pp16_kernel(const ConvArgsH 
     __builtin_amdgcn_wave_barrier();
     const int mbase = tile_m * BMB + wm * TM * 16 + i2 * 32;
     bf16x8 mk[32 / RPP], ad[32 / RPP];                    // all mask / add loads of the round in flight before the first use
+    if (flags & FO_MASK) {
+#pragma unroll
+      for (int pp = 0; pp < 32 / RPP; ++pp) {
+        const int m = mbase + pp * RPP + r0;
+        mk[pp] = *reinterpret_cast<const bf16x8*>(mask + (size_t)(m < a.M ? m : 0) * d.ldMask + co);
+      }
+    }
+    if (flags & FO_ADD) {
+#pragma unroll
+      for (int pp = 0; pp < 32 / RPP; ++pp) {
+        const int m = mbase + pp * RPP + r0;
+        ad[pp] = *reinterpret_cast<const bf16x8*>(addp + (size_t)(m < a.M ? m : 0) * d.ldAdd + co);
+      }
+    }
+#pragma unroll
+    for (int pp = 0; pp < 32 / RPP; ++pp) {
+      const int row = pp * RPP + r0;
+      const int m = mbase + row;
+      const float* crow = Cs + row * C_LD + c8 * 8;
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(crow);
+      const f32x4 v1 = *reinterpret_cast<const f32x4*>(crow + 4);
+      float v[8] = {v0.x + bv[0], v0.y + bv[1], v0.z + bv[2], v0.w + bv[3], v1.x + bv[4], v1.y + bv[5], v1.z + bv[6], v1.w + bv[7]};
+      emit8(a, flags, v, mk[pp], ad[pp], (size_t)(m < a.M ? m : 0), co, m < a.M);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ big tiles, 3x3: the A operand staged ONCE for the nine taps
+// conv_bf16_pp16_kernel DMAs a tile's A rows again for every tap: nine 64-byte fetches of the same pixel per 32 input channels, and what
+// bounds that kernel is the LDS-DMA stream, not the matrix pipe (tools/ablate_pp16.sh, 512 x 128 tile on the 64^2 latents: MFMAs alone
+// 0.184 ms, DMAs alone 0.196 ms, both 0.252 ms; with the A fetches of the six off-centre taps turned into zero fills, still issued, 0.220).
+// Here, for 3x3 (x3) pad-1 stride-1 layers whose tiles are whole image rows (W | BMB, BMB | H W), a 32-channel chunk of the tile's pixels PLUS
+// one image row above and below -- BMB + 2 W rows of 64 B, the "extended tile" -- is DMA'd once per (depth tap, chunk) and serves nine phases:
+// tap (kh, kw) reads its fragments at row offset (kh - 1) W + (kw - 1).  kh shifts are multiples of 16 rows (block-uniform, the swizzle does
+// not see them); kw shifts move a lane's row by +-1, so the swizzle is 2 ((row >> 2) & 1), conflict-free for ds_read_b128 at shifts -1, 0, +1
+// (exhaustive search over the instruction's lane groups); a lane whose shifted pixel would wrap into the neighbouring image row -- lane 0 of
+// a block that starts an image row (kw = 0), lane 15 of one that ends it (kw = 2) -- reads a row of zeros instead.  Rows above / below the
+// frame are zero-filled by the DMA (out-of-range offsets), as are depth taps outside the clip (kwalk_range skips those whole).
+// LDS-DMA instructions per wave and nine phases: NPE + 9 NPB instead of 9 (NPA + NPB) -- 512 x 128: 15 instead of 45.
+//
+// Protocol: the B (filter) ring and the two wave groups one barrier apart are conv_bf16_pp16_kernel's.  The extended tiles alternate between
+// two slots; group g + 1's pieces are issued one per wave and phase in phases 1 .. NPE of group g (its slot was last read in the last phase
+// of group g - 1: retired two segments before the first issue), each behind that phase's B pieces.  vmcnt is in order, so the counted waits
+// grow by the A pieces of the phases they let fly: G0 (end of phase j) vmcnt(NPB + a(j)), G1 (after its issue in phase j)
+// vmcnt(2 NPB + a(j) + a(j - 1)), a(j) = 1 for 1 <= j <= NPE; the last piece (phase NPE <= 6) has landed by the waits of phase NPE + 2 <= 8.
+__device__ __forceinline__ int swz2(int row) { return ((row >> 2) & 1) * 2; }
+template <int N> __device__ __forceinline__ void wait_vmcnt_n() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int BMB, int BN, int WAVES_M, int WAVES_N, int NPE>
+__global__ __launch_bounds__(512, 1) void conv_bf16_pph_kernel(const ConvArgsH a) {
+  static_assert(WAVES_M * WAVES_N == 8 && (BMB == 256 || BMB == 512) && (BN == 256 || BN == 128) && NPE >= 1 && NPE <= 6, "8 waves");
+  constexpr int TM = BMB / WAVES_M / 16, TN = BN / WAVES_N / 16;
+  constexpr int WCOLS = TN * 16;
+  static_assert(WCOLS == 64 || WCOLS == 128, "the epilogue stores 64- or 128-column wave tiles");
+  static_assert(TM % 2 == 0, "the epilogue walks pairs of 16-row blocks");
+  constexpr int ASLOT = NPE * 128 * 64;                   // an extended tile: NPE pieces of 16 rows per wave
+  constexpr int BSLOT = BN * 64;
+  constexpr int NPB = BN / 128;
+  constexpr int OFF_B = 2 * ASLOT, OFF_Z = OFF_B + 4 * BSLOT;
+  constexpr int C_LD = WCOLS + 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const fo_conv_desc& d = a.d;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, quad = lane >> 4;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const bool g1 = __builtin_amdgcn_readfirstlane(wave >> 2) != 0;
+  const int logical = fo_xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_n = logical % a.tilesN;
+  const int tile_m = logical / a.tilesN;
+  const int chunks32 = a.cinChunks;
+  const int W = d.Wm;
+  int kd0, kd1;
+  kwalk_range(a, tile_m * BMB, kd0, kd1);
+  const int ng = (kd1 - kd0) * chunks32;                  // extended tiles (groups of nine phases) of this row tile
+  const int nt = ng * 9;
+  // the tile: BMB consecutive pixels of ONE frame starting at an image-row boundary (host: W | BMB, BMB | H W)
+  const int m0 = tile_m * BMB;
+  const int fn = m0 / a.HWm;
+  const int y0 = (m0 - fn * a.HWm) / W;
+  const int drow = lane >> 2, dpos = lane & 3;
+  int rowoffE[NPE];                                       // byte offset of this lane's row of piece k at depth tap 0, chunk 0 (negative for frame 0 when padD = 1)
+  unsigned validE = 0;                                    // bit k: that row is a pixel of the frame (else: zero fill)
+#pragma unroll
+  for (int k = 0; k < NPE; ++k) {
+    const int e = (k * 8 + wave) * 16 + drow;             // extended row: pixel m0 - W + e
+    const int yy = y0 - 1 + e / W, xx = e % W;
+    const bool ok = e < BMB + 2 * W && (unsigned)yy < (unsigned)d.Hin;
+    rowoffE[k] = ((((fn - d.padD) * d.Hin + yy) * d.Win + xx) * d.ldIn) * 2 + (dpos ^ swz2(e)) * 16;
+    validE |= (ok ? 1u : 0u) << k;
+  }
+  unsigned woffB[NPB];
+#pragma unroll
+  for (int i = 0; i < NPB; ++i) {
+    const int row = (i * 8 + wave) * 16 + drow;
+    woffB[i] = (unsigned)(((size_t)(tile_n * BN + row) * a.Ktot) * 2 + (dpos ^ swz2(row)) * 16);
+  }
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in), 0, a.inBytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rwp = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wp), 0, a.wpBytes, 0x00020000);
+  lds_byte* const lds3 = (lds_byte*)lds;
+  if (tid < 16) reinterpret_cast<unsigned*>(lds + OFF_Z)[tid] = 0u;       // the row of zeros (made visible by the barriers below)
+
+  // ---- the two DMA streams, each with its own running position
+  int bq = 0, bj = 0, bchunk = 0, bkd = kd0;              // next B tile: phase bq = 9 * group + bj, group = (bkd, bchunk)
+  auto dma_b = [&]() {
+    const int kpos = (bkd * 9 + bj) * chunks32 + bchunk;  // 32-element position inside a filter row: tap * chunks + chunk
+    lds_byte* const sb = lds3 + OFF_B + (bq & 3) * BSLOT;
+#pragma unroll
+    for (int i = 0; i < NPB; ++i) dma16(rwp, sb + (i * 8 + wave) * 1024, bq < nt ? woffB[i] + kpos * 64 : OOB);
+    ++bq;
+    if (++bj == 9) { bj = 0; if (++bchunk == chunks32) { bchunk = 0; ++bkd; } }
+  };
+  int ag = 0, achunk = 0, akd = kd0;                      // next extended tile: group ag = (akd, achunk)
+  auto dma_a_piece = [&](int k) {
+    const int goff = ((akd * d.Hin * d.Win) * d.ldIn + achunk * 32) * 2;
+    const unsigned pad = (((validE >> k) & 1u) - 1u) & OOB;
+    const unsigned off = ag < ng ? (unsigned)(rowoffE[k] + goff) | pad : OOB;
+    dma16(rin, lds3 + (ag & 1) * ASLOT + (k * 8 + wave) * 1024, off);
+  };
+  auto a_next = [&]() { ++ag; if (++achunk == chunks32) { achunk = 0; ++akd; } };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment addressing.  B: row (lane & 15) of a 16-row block, chunk quad.  A: extended row W + (wave block) + i * 16 + l15 + (kh - 1) W + (kw - 1)
+  const int boff = OFF_B + (wn * TN * 16 + l15) * 64 + (quad ^ swz2(l15)) * 16;
+  int aoff[3];                                            // per kw: byte offset of this lane's row in block 0 of the wave at kh = 0
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw) {
+    const int r = l15 + kw - 1;                           // -1 .. 16 (block bases and kh shifts are multiples of 16: the swizzle sees r only)
+    aoff[kw] = (wm * TM * 16 + r) * 64 + (quad ^ swz2(r + 16)) * 16;
+  }
+  const int zoff = OFF_Z + quad * 16;
+  // blocks whose first pixel starts an image row (lane 0 wraps at kw = 0) / whose last pixel ends one (lane 15 wraps at kw = 2)
+  unsigned wrapL = 0, wrapR = 0;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int x0 = (wm * TM * 16 + i * 16) % W;
+    wrapL |= (x0 == 0 ? 1u : 0u) << i;
+    wrapR |= (x0 + 16 == W ? 1u : 0u) << i;
+  }
+  const bool edgeL = l15 == 0, edgeR = l15 == 15;
+  const int W64 = W * 64;
+
+#pragma unroll
+  for (int k = 0; k < NPE; ++k) dma_a_piece(k);           // extended tile 0, whole
+  a_next();
+  dma_b();
+  dma_b();
+  if (g1) {
+    dma_b();
+    wait_vmcnt_n<2 * NPB>();                              // A(0) and B(0) of this wave have landed
+  } else {
+    wait_vmcnt_n<NPB>();
+  }
+  __builtin_amdgcn_s_barrier();
+  if (g1) __builtin_amdgcn_s_barrier();                   // G1 runs one segment behind G0 from here on
+  __builtin_amdgcn_sched_barrier(0);
+
+  for (int g = 0; g < ng; ++g) {
+    const unsigned char* Ag = lds + (g & 1) * ASLOT;
+    // (opaque per iteration: otherwise the nine phases' per-lane addresses -- 9 bases, 2 TM wrap selects -- are hoisted out of the g loop
+    // and the kernel spills)
+    int ao0 = aoff[0], ao1 = aoff[1], ao2 = aoff[2];
+    asm volatile("" : "+v"(ao0), "+v"(ao1), "+v"(ao2));
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+      const int kh = j / 3, kw = j % 3;
+      const int p = g * 9 + j;
+      const unsigned char* Bs = lds + (p & 3) * BSLOT + boff;
+      bf16x8 fa[TM], fb[TN];
+#pragma unroll
+      for (int jn = 0; jn < TN; ++jn) fb[jn] = *reinterpret_cast<const bf16x8*>(Bs + jn * 16 * 64);
+      const int abase = (kw == 0 ? ao0 : kw == 1 ? ao1 : ao2) + kh * W64;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        int ad_ = abase + i * 16 * 64;
+        if (kw == 0) ad_ = (edgeL && ((wrapL >> i) & 1)) ? zoff - (int)((g & 1) * ASLOT) : ad_;
+        if (kw == 2) ad_ = (edgeR && ((wrapR >> i) & 1)) ? zoff - (int)((g & 1) * ASLOT) : ad_;
+        fa[i] = *reinterpret_cast<const bf16x8*>(Ag + ad_);
+      }
+      dma_b();                                            // G0: B tile p + 2, G1: p + 3
+      if (j >= 1 && j <= NPE) {
+        dma_a_piece(j - 1);                               // extended tile g + 1, one piece per phase
+        if (j == NPE) a_next();
+      }
+      if (g1) {
+        // in flight at most: this phase's and the previous phase's pieces
+        if (j == 0) wait_vmcnt_n<2 * NPB>();
+        else if (j == 1) wait_vmcnt_n<2 * NPB + 1>();
+        else if (j <= NPE) wait_vmcnt_n<2 * NPB + 2>();
+        else if (j == NPE + 1) wait_vmcnt_n<2 * NPB + 1>();
+        else wait_vmcnt_n<2 * NPB>();
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[jn], acc[i][jn], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      if (!g1) {
+        if (j >= 1 && j <= NPE) wait_vmcnt_n<NPB + 1>();
+        else wait_vmcnt_n<NPB>();
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if (!g1) __builtin_amdgcn_s_barrier();                  // G0 waits out G1's last segment
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the zero-fill DMAs of tiles past the end
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+
+  // ---- epilogue: as conv_bf16_pp16_kernel
+  float* Cs = reinterpret_cast<float*>(lds) + wave * 32 * C_LD;
+  const int flags = d.flags;
+  constexpr int C8 = WCOLS / 8, RPP = 64 / C8;
+  const int c8 = lane % C8, r0 = lane / C8;
+  const int co = tile_n * BN + wn * WCOLS + c8 * 8;
+  float bv[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bv[e] = ((flags & FO_BIAS) && co + e < d.Cout) ? a.bias[co + e] : 0.f;
+  const __bf16* mask = reinterpret_cast<const __bf16*>(a.mask);
+  const __bf16* addp = reinterpret_cast<const __bf16*>(a.add);
+#pragma unroll
+  for (int i2 = 0; i2 < TM / 2; ++i2) {
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Cs[(ii * 16 + quad * 4 + r) * C_LD + j * 16 + l15] = acc[i2 * 2 + ii][j][r];
+    __builtin_amdgcn_wave_barrier();
+    const int mbase = tile_m * BMB + wm * TM * 16 + i2 * 32;
+    bf16x8 mk[32 / RPP], ad[32 / RPP];
     if (flags & FO_MASK) {
 #pragma unroll
       for (int pp = 0; pp < 32 / RPP; ++pp) {
@@ -1102,6 +1358,32 @@ int launch_pp16(const ConvArgsH& a, hipStream_t s) {
   return FO_OK;
 }
 
+template <int BMB, int BN, int WAVES_M, int WAVES_N, int NPE>
+int launch_pph(const ConvArgsH& a, hipStream_t s) {
+  constexpr int ring = 2 * NPE * 128 * 64 + 4 * BN * 64 + 64;
+  constexpr int epi = 8 * 32 * (BN / WAVES_N + 4) * 4;
+  constexpr int ldsBytes = (ring > epi ? ring : epi) + 64;
+  static_assert(ldsBytes <= 160 * 1024, "LDS");
+  static fo_lds_once once;
+  void (*kern)(const ConvArgsH) = conv_bf16_pph_kernel<BMB, BN, WAVES_M, WAVES_N, NPE>;
+  if (!fo_lds_optin(once, reinterpret_cast<const void*>(kern), ldsBytes, "conv_bf16 (pph)")) return FO_E_HIP;
+  FO_NOTE_T("conv_bf16_pph_kernel", BMB, BN, WAVES_M, WAVES_N, NPE);
+  hipLaunchKernelGGL(kern, dim3(a.tilesM * a.tilesN), dim3(512), ldsBytes, s, a);
+  FO_CHECK_LAUNCH();
+  return FO_OK;
+}
+
+// the extended-tile kernel takes 3x3 (x3) pad-1 layers whose BMB-row tiles are whole image rows of one frame; NPE = 16-row pieces per wave
+template <int BMB>
+static int pph_pieces(const fo_conv_desc* d, const ConvArgsH& a) {
+  const char* off = getenv("FACEOFF_BF16_NO_PPH");                   // diagnostics / A-B: conv_bf16_pp16_kernel everywhere
+  if (off && atoi(off)) return 0;
+  if (d->KH != 3 || d->KW != 3 || d->padH != 1 || d->padW != 1 || (d->KD != 1 && (d->KD != 3 || d->padD != 1)) || (d->KD == 1 && d->padD != 0)) return 0;
+  const int W = d->Wm;
+  if (W % 16 != 0 || BMB % W != 0 || a.HWm % BMB != 0 || a.M % BMB != 0) return 0;
+  return (BMB + 2 * W + 127) / 128;
+}
+
 template <int BN, int WAVES_M, int WAVES_N, int TM, int TN>
 int launch_dma(const ConvArgsH& a, hipStream_t s) {
   FO_NOTE_T("conv_bf16_dma_kernel", BN, WAVES_M, WAVES_N, TM, TN);
@@ -1282,6 +1564,9 @@ static int conv_bf16_impl(const fo_conv_desc* d, const void* in, const void* wp,
     if (d->Cout % 256 == 0 && tilesM256 * (d->Cout / 256) >= 3 * cus) {
       a.tilesM = (int)tilesM256; a.tilesN = d->Cout / 256;
       a.frameTiles = a.HWm % 256 == 0;
+      const int npe = pph_pieces<256>(d, a);
+      if (npe == 3) return launch_pph<256, 256, 2, 4, 3>(a, s);
+      if (npe == 4) return launch_pph<256, 256, 2, 4, 4>(a, s);
       return launch_pp16<256, 256, 2, 4>(a, s);
     }
     const char* t512 = getenv("FACEOFF_BF16_TILE512");               // 0: never the 512-row tile (diagnostics)
@@ -1289,11 +1574,17 @@ static int conv_bf16_impl(const fo_conv_desc* d, const void* in, const void* wp,
     if (!(t512 && !atoi(t512)) && tilesM512 * (d->Cout / 128) >= 5 * cus && (cus > 0 || (t512 && atoi(t512)))) {
       a.tilesM = (int)tilesM512; a.tilesN = d->Cout / 128;
       a.frameTiles = a.HWm % 512 == 0;
+      const int npe = pph_pieces<512>(d, a);
+      if (npe == 5) return launch_pph<512, 128, 4, 2, 5>(a, s);     // (4 x 2 waves: 8 x 4 blocks per wave as the 256 x 256 tile; 8 x 1 spills with nine phases unrolled)
+      if (npe == 6) return launch_pph<512, 128, 4, 2, 6>(a, s);
       return launch_pp16<512, 128, 8, 1>(a, s);
     }
     if (tilesM256 * (d->Cout / 128) >= 2 * cus) {
       a.tilesM = (int)tilesM256; a.tilesN = d->Cout / 128;
       a.frameTiles = a.HWm % 256 == 0;
+      const int npe = pph_pieces<256>(d, a);
+      if (npe == 3) return launch_pph<256, 128, 4, 2, 3>(a, s);
+      if (npe == 4) return launch_pph<256, 128, 4, 2, 4>(a, s);
       return launch_pp16<256, 128, 4, 2>(a, s);
     }
   }

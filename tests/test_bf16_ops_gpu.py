@@ -337,3 +337,64 @@ print(json.dumps(res))
         a, b = np.array(outs["halo"][key]["y"]), np.array(outs["tiled"][key]["y"])
         assert np.array_equal(np.array(outs["halo"][key.replace("dense", "slice")]["y"]), a)         # the pixel stride does not enter the arithmetic
         assert (a != b).mean() < 0.02 and np.abs(a - b).max() <= 2.0 ** -7 * (np.abs(b).max() + 1.0), key
+
+
+# ------------------------------------------------------------------------------------------------ the extended-tile (halo) ping-pong kernel
+@pytest.mark.parametrize("N,H,W,cin,cout,T,tile512", [
+    (4, 16, 16, 256, 256, 1, False),      # 256 x 256 tile, one frame per tile, 3 pieces per wave
+    (2, 32, 32, 128, 256, 1, False),      # 256 x 256, 8 image rows per tile
+    (1, 64, 64, 64, 256, 1, False),       # 256 x 256, W = 64 (4 image rows per tile); 64 input channels = 2 chunks
+    (1, 128, 128, 128, 128, 1, True),     # 512 x 128 tile, W = 128: 6 pieces per wave (VGG conv2_2's shape)
+    (2, 64, 64, 128, 128, 1, True),       # 512 x 128, W = 64: 5 pieces per wave
+    (6, 32, 32, 128, 128, 3, True),       # 512 x 128 with depth taps, clips of 3 frames (the VQ-VAE's Conv3d at the top latent size)
+    (5, 32, 32, 128, 128, 5, False),      # 256 x 128 with depth taps, one clip of 5
+    (2, 32, 64, 96, 128, 1, False),       # 256 x 128, a non-square frame, 96 input channels (3 chunks)
+])
+def test_extended_tile_kernel_vs_torch_and_vs_the_per_tap_kernel(N, H, W, cin, cout, T, tile512, monkeypatch):
+    """conv_bf16_pph_kernel (the A operand staged once per (depth tap, 32-channel chunk) for the nine 3x3 taps: kw shifts read the staged
+    rows at +-1 with a zero row for lanes that would wrap into the neighbouring image row, kh shifts at +-W) at every tile shape and piece
+    count it is built for: forward (bias, ReLU) and masked data gradient with fan-in add against torch-CPU on the same bf16 operands, and
+    against conv_bf16_pp16_kernel (FACEOFF_BF16_NO_PPH=1) -- same products, another summation order: equal up to isolated 1-ulp roundings.
+    The library reports which kernel ran (fo_last_kernel)."""
+    from faceoff_amd import ops, _lib
+    monkeypatch.setenv("FACEOFF_BF16_BIG_TILES", "1")
+    if tile512:
+        monkeypatch.setenv("FACEOFF_BF16_TILE512", "1")
+    g = gen(N * 1000 + W + cin)
+    kd = 3 if T > 1 else 1
+    x = rb(torch.randn((N, cin, H, W), generator=g))
+    w = rb(torch.randn((cout, cin, kd, 3, 3), generator=g) / np.sqrt(9 * kd * cin))
+    b = torch.randn(cout, generator=g)
+    mask = rb(torch.randn((N, cout, H, W), generator=g))
+    add = rb(torch.randn((N, cout, H, W), generator=g))
+    B = N // T
+    if kd == 3:
+        x5 = x.reshape(B, T, cin, H, W).permute(0, 2, 1, 3, 4)
+        ref = F.conv3d(x5, w, b, padding=1).permute(0, 2, 1, 3, 4).reshape(N, cout, H, W)
+    else:
+        ref = F.conv2d(x, w[:, :, 0], b, padding=1)
+    ref_fwd = F.relu(ref)
+    ref_msk = (ref - b.view(1, -1, 1, 1)) * (mask > 0) + add
+    wp = packed_bf16(ops.pack_conv(w.reshape(cout, cin, kd * 9).cuda()))
+    xin = torch.zeros((N, H, W, cin + 32), device="cuda", dtype=BF)          # a channel slice of a wider buffer (ldIn > Cin)
+    xin[..., :cin] = nhwc(x)
+    lib = _lib.load()
+    outs = {}
+    for name, env in (("pph", "0"), ("pp16", "1")):
+        monkeypatch.setenv("FACEOFF_BF16_NO_PPH", env)
+        o1 = torch.empty((N, H, W, cout), device="cuda", dtype=BF)
+        lib.fo_kernel_notes(1); lib.fo_last_kernel()
+        ops.conv_bf16g(xin[..., :cin], wp, b.cuda(), o1, T=T, k=(kd, 3, 3), pad=(kd // 2, 1, 1), cin=cin, cout=cout, flags=ops.FO_OUT_RELU)
+        kern = lib.fo_last_kernel().decode(); lib.fo_kernel_notes(0)
+        assert kern.startswith("conv_bf16_pph_kernel<" if name == "pph" else "conv_bf16_pp16_kernel<"), kern
+        want_tile = "512, 128" if tile512 else ("256, 256" if cout % 256 == 0 else "256, 128")
+        assert want_tile in kern, kern
+        o2 = torch.empty((N, H, W, cout), device="cuda", dtype=BF)
+        ops.conv_bf16g(xin[..., :cin], wp, None, o2, T=T, k=(kd, 3, 3), pad=(kd // 2, 1, 1), cin=cin, cout=cout, mask=nhwc(mask), add=nhwc(add))
+        torch.cuda.synchronize()
+        close_bf16(back(o1), ref_fwd, f"{name} forward {kern}")
+        close_bf16(back(o2), ref_msk, f"{name} masked + add {kern}")
+        outs[name] = (o1.float(), o2.float())
+    for a_, b_ in zip(outs["pph"], outs["pp16"]):
+        diff = (a_ - b_).abs()
+        assert (diff > 0).float().mean().item() < 2e-2 and bool((diff <= b_.abs() * 2.0 ** -7 + 1e-3 * b_.abs().max()).all())
