@@ -1070,9 +1070,9 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_pph_kernel(const ConvArgsH a
         if (kw == 2) ad_ = (edgeR && ((wrapR >> i) & 1)) ? zoff - (int)((g & 1) * ASLOT) : ad_;
         fa[i] = *reinterpret_cast<const bf16x8*>(Ag + ad_);
       }
-      dma_b();                                            // G0: B tile p + 2, G1: p + 3
+      if (!(FO_ABLATE_PP & 1)) dma_b();                   // G0: B tile p + 2, G1: p + 3
       if (j >= 1 && j <= NPE) {
-        dma_a_piece(j - 1);                               // extended tile g + 1, one piece per phase
+        if (!(FO_ABLATE_PP & 1)) dma_a_piece(j - 1);      // extended tile g + 1, one piece per phase
         if (j == NPE) a_next();
       }
       if (g1) {
@@ -1090,7 +1090,8 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_pph_kernel(const ConvArgsH a
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int jn = 0; jn < TN; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[jn], acc[i][jn], 0, 0, 0);
+        for (int jn = 0; jn < TN; ++jn)
+          if (!(FO_ABLATE_PP & 2) || (i == 0 && jn == 0)) acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[jn], acc[i][jn], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
       if (!g1) {
         if (j >= 1 && j <= NPE) wait_vmcnt_n<NPB + 1>();
@@ -1107,6 +1108,15 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_pph_kernel(const ConvArgsH a
   __builtin_amdgcn_sched_barrier(0);
 
   // ---- epilogue: as conv_bf16_pp16_kernel
+  if (FO_ABLATE_PP & 16) {                                // diagnostic: no epilogue (one store per lane keeps the accumulators alive)
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (t == 12345.678f) reinterpret_cast<float*>(a.out)[tid] = t;
+    return;
+  }
   float* Cs = reinterpret_cast<float*>(lds) + wave * 32 * C_LD;
   const int flags = d.flags;
   constexpr int C8 = WCOLS / 8, RPP = 64 / C8;
@@ -1151,7 +1161,7 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_pph_kernel(const ConvArgsH a
       const f32x4 v0 = *reinterpret_cast<const f32x4*>(crow);
       const f32x4 v1 = *reinterpret_cast<const f32x4*>(crow + 4);
       float v[8] = {v0.x + bv[0], v0.y + bv[1], v0.z + bv[2], v0.w + bv[3], v1.x + bv[4], v1.y + bv[5], v1.z + bv[6], v1.w + bv[7]};
-      emit8(a, flags, v, mk[pp], ad[pp], (size_t)(m < a.M ? m : 0), co, m < a.M);
+      emit8(a, flags, v, mk[pp], ad[pp], (size_t)(m < a.M ? m : 0), co, (FO_ABLATE_PP & 32) ? (m < a.M && (flags & 0x4000)) : m < a.M);
     }
   }
 }

@@ -162,7 +162,9 @@ def test_bf16_engine_kernel_paths_agree(monkeypatch):
     np.testing.assert_allclose([r0.item(), d0.item()], [r1.item(), d1.item()], rtol=2e-3)
     same = [(S0["id_" + l] == S1["id_" + l]).float().mean().item() for l in "tb"]
     assert min(same) > 0.99, same
-    for k in ("a1", "eb", "c1", "d3", "u2", "v2"):
+    # activations: in front of the quantisers always; behind them only where every code agrees (the two kernel families walk K in different
+    # orders -- (tap, chunk) against (chunk, taps) -- so a near-tie of the quantiser's input may resolve the other way: `same` bounds how often)
+    for k in ("a1", "eb", "c1", "d3") + (("u2", "v2") if min(same) == 1.0 else ()):
         a, b = S0[k].float(), S1[k].float()
         assert _rel_l2(a, b) < 1e-2, k
     worst = max((_rel_l2(e0.grads[k], e1.grads[k]), k) for k in e0.grads)

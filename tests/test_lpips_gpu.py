@@ -266,7 +266,8 @@ def test_conv_bf16_dma_kernels_are_deterministic(cin, cout, monkeypatch):
     monkeypatch.delenv("FACEOFF_BF16_NO_DMA")
     monkeypatch.setenv("FACEOFF_BF16_BIG_TILES", "1")
     first = run()
-    assert ((first.float() - ref.float()).abs() <= 2.0 ** -7 * ref.float().abs() + 1e-6).all()
+    # (one bf16 rounding, + fp32 summation-order noise where a sum cancels: the extended-tile kernel walks K as (chunk, taps), the others as (tap, chunks))
+    assert ((first.float() - ref.float()).abs() <= 2.0 ** -7 * ref.float().abs() + 2e-5 * ref.float().abs().max()).all()
     side, noise = torch.cuda.Stream(), torch.empty(64 << 20, device="cuda")
     for r in range(30):
         if r & 1:
