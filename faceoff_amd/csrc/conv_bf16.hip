@@ -1161,7 +1161,8 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_pph_kernel(const ConvArgsH a
       const f32x4 v0 = *reinterpret_cast<const f32x4*>(crow);
       const f32x4 v1 = *reinterpret_cast<const f32x4*>(crow + 4);
       float v[8] = {v0.x + bv[0], v0.y + bv[1], v0.z + bv[2], v0.w + bv[3], v1.x + bv[4], v1.y + bv[5], v1.z + bv[6], v1.w + bv[7]};
-      emit8(a, flags, v, mk[pp], ad[pp], (size_t)(m < a.M ? m : 0), co, (FO_ABLATE_PP & 32) ? (m < a.M && (flags & 0x4000)) : m < a.M);
+      emit8(a, flags, v, mk[pp], ad[pp], (FO_ABLATE_PP & 64) ? (size_t)(m & 511) : (size_t)(m < a.M ? m : 0), co,
+            (FO_ABLATE_PP & 32) ? (m < a.M && (flags & 0x4000)) : m < a.M);          // (diagnostics: bit 5 no stores, bit 6 every tile stores to the same 512 rows)
     }
   }
 }

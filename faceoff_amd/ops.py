@@ -383,12 +383,15 @@ def conv3d_winograd(x, U, bias, out, *, T, cin, cout, flags=0, mask=None, add=No
             _lib.call("fo_conv_igemm", C.byref(d), _ptr(vin), _ptr(wp), None, None, None, _ptr(mout), _stream())
         if prof is not None:
             prof.end()
+    if mask is not None and _DIAG_WINO_NO_MASK:       # DIAGNOSTIC (wrong gradients, timing only): the data gradient's output transform without its
+        mask, flags = None, flags & ~FO_MASK            # ReLU-mask read -- the upper bound of what a bit-plane mask could save
     _lib.call("fo_wino_output", _ptr(M), _ptr(bias), _ptr(mask), ld_of(mask) if mask is not None else 0, _ptr(add),
               ld_of(add) if add is not None else 0, _ptr(out), ld_of(out), N, H, W, cout, flags, m, _stream())
     return V if keep_v else None
 
 
 # ---------------------------------------------------------------- Winograd F(4x4, 2x2) for the k4 s2 p1 stems (csrc/wino42.hip)
+_DIAG_WINO_NO_MASK = bool(_os.environ.get("FACEOFF_DIAG_WINO_NO_MASK"))
 W42 = not _os.environ.get("FACEOFF_NO_W42")
 W42_MIN_ROWS = 1024          # tiles per plane below which the direct kernels are used (tests lower it to reach this path at small sizes)
 

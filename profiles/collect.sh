@@ -14,6 +14,10 @@ mkdir -p "$OUT" "$SUM"
 export TMPDIR=/tmp
 # --serial-streams: per-kernel durations need each kernel alone on the GPU (bench.py times its kernel events the same way)
 BENCH="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events --no-c3 --no-c5 --no-direct-leg --no-x6-leg --no-h2d-leg --serial-streams"
+# config 3 as timed (bf16 MFMA operands throughout) instead of the headline workload:  CONFIG=c3 bash profiles/collect.sh r04_c3 pmc
+if [ "${CONFIG:-c2}" = "c3" ]; then
+  BENCH="python3 bench.py --steps 2 --warmup 1 --perceptual --vqvae-dtype bf16 --no-cpu-baseline --no-kernel-events --no-c5 --no-h2d-leg --serial-streams"
+fi
 
 if [ "$WHAT" = "trace" ] || [ "$WHAT" = "all" ]; then
   rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace -- $BENCH > "$OUT/trace.log" 2>&1
@@ -26,5 +30,5 @@ if [ "$WHAT" = "pmc" ] || [ "$WHAT" = "all" ]; then
   rocprofv3 --kernel-trace --output-format csv -d "$OUT/pmc_write" -o pmc --pmc WRITE_SIZE -- $BENCH > "$OUT/pmc_write.log" 2>&1
   rocprofv3 --kernel-trace --output-format csv -d "$OUT/pmc_l2" -o pmc --pmc TCC_HIT_sum TCC_MISS_sum -- $BENCH > "$OUT/pmc_l2.log" 2>&1
 fi
-python3 profiles/summarize.py "$OUT" "$SUM" "$TAG"
+python3 profiles/summarize.py "$OUT" "$SUM" "$TAG" "${CONFIG:-c2}"
 ls -la "$SUM"

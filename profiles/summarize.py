@@ -57,6 +57,9 @@ def read_counters(raw, sub):
 
 def main():
     raw, out, tag = sys.argv[1], sys.argv[2], sys.argv[3]
+    config = sys.argv[4] if len(sys.argv) > 4 else "c2"       # c3: the traced command is bench.py --perceptual --vqvae-dtype bf16 (profiles/collect.sh)
+    what = ("bench.py --steps 2 --warmup 1 --serial-streams" if config == "c2" else
+            "bench.py --perceptual --vqvae-dtype bf16 --serial-streams --steps 2 --warmup 1 (config 3 as timed: bf16 MFMA operands for the VQ-VAE and LPIPS)")
     os.makedirs(out, exist_ok=True)
     # ---- kernel stats
     stats = []
@@ -69,7 +72,7 @@ def main():
         tot = sum(float(r["TotalDurationNs"]) for r in stats) or 1.0
         stats.sort(key=lambda r: -float(r["TotalDurationNs"]))
         with open(os.path.join(out, f"{tag}_kernel_stats.md"), "w") as fh:
-            fh.write(f"# rocprofv3 --kernel-trace --stats: bench.py --steps 2 --warmup 1 (3 steps traced), tag {tag}\n\n")
+            fh.write(f"# rocprofv3 --kernel-trace --stats: {what} (3 steps traced), tag {tag}\n\n")
             fh.write("| kernel | calls | total ms | avg us | min us | max us | % of GPU time |\n|---|---|---|---|---|---|---|\n")
             for r in stats[:40]:
                 n = short(r["Name"])
@@ -86,7 +89,7 @@ def main():
     traffic = {}
     if kernels:
         with open(os.path.join(out, f"{tag}_pmc.md"), "w") as fh:
-            fh.write(f"# rocprofv3 --pmc passes (separate runs), per-dispatch averages, tag {tag}\n\n")
+            fh.write(f"# rocprofv3 --pmc passes (separate runs) of {what}, per-dispatch averages, tag {tag}\n\n")
             fh.write("MFMA busy share = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 4 SIMD * 256 CU); effective clock = "
                      "GRBM_GUI_ACTIVE / 8 / duration.  HBM read = 2 x FETCH_SIZE KB (gfx950 counts 128-B requests of wide "
                      "streams as 64 B; MI355X_MICROARCH.md, HBM), HBM write = WRITE_SIZE KB.\n\n")
@@ -119,7 +122,7 @@ def main():
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         from faceoff_amd._lib import kernel_source_sha16
         traffic["_kernel_source_sha16"] = kernel_source_sha16()
-        with open(os.path.join(out, "pmc_traffic.json"), "w") as fh:
+        with open(os.path.join(out, "pmc_traffic.json" if config == "c2" else f"pmc_traffic_{config}.json"), "w") as fh:
             json.dump(traffic, fh, indent=1)
     print("summaries written to", out)
 
