@@ -65,11 +65,13 @@ class DiscEngine:
         self.v = torch.zeros_like(self.flat_params)
         self.t = 0
         self._wp, self._wpt, self._w2 = {}, {}, {}
+        self._packs_stale, self._packed_version = True, -1
         if state_dict is not None:
             self.load_state_dict(state_dict)
 
     # ------------------------------------------------------------------ state
     def load_state_dict(self, sd):
+        self._packs_stale = True
         for k, v in sd.items():
             k = k[len("module."):] if k.startswith("module.") else k
             t = torch.as_tensor(v).to(self.device)
@@ -90,6 +92,7 @@ class DiscEngine:
         """torch.optim.Adam(netD.parameters(), lr, betas=(0.5, 0.999)) (mocoganhd_video_disc.py:24-26) as one launch."""
         self.t += 1
         ops.adam_flat(self.flat_params, self.flat_grads, self.m, self.v, lr, self.t, betas, eps, grad_scale)
+        self._packs_stale = True              # (the launch writes the arena through a raw pointer: torch's version counter does not see it)
 
     # ------------------------------------------------------------------ helpers
     def _desc(self, N, src_dims, cs, ld_s, dst_dims, cd, ld_d, stride, flags=0, ld_mask=0):
@@ -127,7 +130,15 @@ class DiscEngine:
         return inverse_into
 
     def pack_filters(self):
-        """Checkpoint-layout filters -> forward and data-gradient packs (every step: the optimiser rewrites the weights)."""
+        """Checkpoint-layout filters -> forward and data-gradient packs.  Re-packed only when the weights have changed since the last pack:
+        the generator iteration (:338-341 alternates G / D by step parity) runs both discriminators on weights the previous iteration
+        already packed -- 40 small launches, 0.4 ms, in front of the first discriminator convolution.  "Changed" = this engine's own Adam
+        launch or load_state_dict (explicit flag), or any in-place torch op on the parameter arena or a view of it, e.g. the module
+        mirror's torch.optim step (the arena's autograd version counter)."""
+        ver = self.flat_params._version
+        if not self._packs_stale and self._packed_version == ver and self._wp:
+            return
+        self._packs_stale, self._packed_version = False, ver
         taps = K ** self.dims
         for k, w in self.params.items():
             if not k.endswith(".weight"):
