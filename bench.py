@@ -73,32 +73,37 @@ def _cgroup_cpus():
 
 def cpu_baseline(T, H, W, steps=20, all_cores_budget_s=40):
     """The CPU oracle (torch-CPU restatement of the reference step, kind "port") timed on this box's host cores on a bounded sample: one
-    clip of T frames at HxW, forward + backward + Adam.  Timed at TWO thread counts: 32 threads (what torch-CPU / oneDNN scales to on
-    these layer sizes; `value`) and os.cpu_count() threads ("k = all host cores of the box").  The second runs in a
-    child process under a wall-clock budget: on this pool the 256-thread step is ~200x SLOWER than the 32-thread one (0.043 frames/s
-    measured, 116 s per step), and the default bench run must stay within minutes -- if it does not finish, the line says so."""
+    clip of T frames at HxW, forward + backward + Adam.  BASELINE.md section 3 says "k = all host cores of the box": what the box GIVES
+    this process is its cgroup CPU quota (16 CPUs on the pool's boxes, whatever os.cpu_count() says -- 256), so the step is timed at
+    the quota's thread count and at 32 threads (rounds 1-3), `value` = the faster.  os.cpu_count() threads are only tried -- in a child
+    process, under a wall-clock budget -- where no quota restricts the process: under a 16-CPU quota 256 threads measured 0.043 frames/s
+    (116 s per step, gpurun_out/r04d/bench.json), 200x slower than 32."""
     host = os.cpu_count() or 1
-    runs = {}
-    c32 = min(host, 32)
-    runs[c32] = _cpu_oracle_rate(T, H, W, c32, steps)
-    if host != c32:
-        code = (f"import sys, json; sys.path.insert(0, {ROOT!r}); import bench; "
-                f"print('CPU_RATE ' + json.dumps(bench._cpu_oracle_rate({T}, {H}, {W}, {host}, 3, warm=1)))")
-        try:
-            env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")          # a CPU-only child
-            res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=all_cores_budget_s, env=env)
-            line = [l for l in res.stdout.splitlines() if l.startswith("CPU_RATE ")]
-            runs[host] = json.loads(line[0][9:]) if line else {"frames_per_s": None, "note": "child failed: " + res.stderr[-200:]}
-        except subprocess.TimeoutExpired:
-            runs[host] = {"frames_per_s": None, "note": f"1 warm-up + 3 steps did not finish within {all_cores_budget_s} s "
-                                                        f"(< {round(4 * T / all_cores_budget_s, 2)} frames/s); measured once in round 4: 0.043 frames/s "
-                                                        "(gpurun_out/r04d/bench.json)"}
+    quota = _cgroup_cpus()
+    counts = {min(host, 32)}
+    if quota is not None and quota >= 1:
+        counts.add(max(1, min(host, int(round(quota)))))
+    runs = {c: _cpu_oracle_rate(T, H, W, c, steps) for c in sorted(counts)}
+    if host not in runs:
+        if quota is not None and quota < host:
+            runs[host] = {"frames_per_s": None, "note": f"not run: the cgroup quota gives this process {quota:g} CPUs; {host} threads on them measured 0.043 frames/s "
+                                                        "in round 4 (gpurun_out/r04d/bench.json: 116 s per step)"}
+        else:
+            code = (f"import sys, json; sys.path.insert(0, {ROOT!r}); import bench; "
+                    f"print('CPU_RATE ' + json.dumps(bench._cpu_oracle_rate({T}, {H}, {W}, {host}, 3, warm=1)))")
+            try:
+                env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")          # a CPU-only child
+                res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=all_cores_budget_s, env=env)
+                line = [l for l in res.stdout.splitlines() if l.startswith("CPU_RATE ")]
+                runs[host] = json.loads(line[0][9:]) if line else {"frames_per_s": None, "note": "child failed: " + res.stderr[-200:]}
+            except subprocess.TimeoutExpired:
+                runs[host] = {"frames_per_s": None, "note": f"1 warm-up + 3 steps did not finish within {all_cores_budget_s} s"}
     done = {c: v for c, v in runs.items() if v.get("frames_per_s")}
     best = max(done, key=lambda c: done[c]["frames_per_s"])
-    return {"value": runs[best]["frames_per_s"], "unit": "frames/s", "cores": best, "host_cores": host, "cgroup_cpu_quota": _cgroup_cpus(), "kind": "port",
-            "by_threads": {str(c): v for c, v in runs.items()},
-            "sample": f"1 clip x {T} frames {H}x{W}, fwd+bwd+Adam, torch-CPU oracle; {c32} threads: {steps} timed steps (~{runs[c32]['seconds']:.0f} s) after 2 "
-                      f"warm-ups; {host} threads (every host core): 3 steps after 1 warm-up in a child process under a {all_cores_budget_s} s budget; value = the faster"}
+    return {"value": runs[best]["frames_per_s"], "unit": "frames/s", "cores": best, "host_cores": host, "cgroup_cpu_quota": quota, "kind": "port",
+            "by_threads": {str(c): v for c, v in sorted(runs.items())},
+            "sample": f"1 clip x {T} frames {H}x{W}, fwd+bwd+Adam, torch-CPU oracle, {steps} timed steps after 2 warm-ups at each of " +
+                      ", ".join(f"{c} threads (~{v['seconds']:.0f} s)" for c, v in sorted(done.items())) + "; value = the faster"}
 
 
 def parse_args(argv=None):
@@ -501,6 +506,17 @@ def main():
             rc = dominant(summ_c, k_c, ms_serial_c)
             rc["measured"] = "HIP events per launch, side streams joined (as `roofline`); algorithmic FLOP of the launches (clip-padding taps excluded) against the dense bf16 MFMA peak"
             rc["ms_per_step_serial"] = round(ms_serial_c, 3)
+            pmc_c = os.path.join(ROOT, "profiles", "pmc_traffic_c3.json")        # CONFIG=c3 bash profiles/collect.sh <tag>: the same counters on this leg's command
+            if os.path.exists(pmc_c):
+                try:
+                    tj = json.load(open(pmc_c))
+                    from faceoff_amd._lib import kernel_source_sha16
+                    rc["traffic"] = tj.get(rc["kernel"])
+                    rc["traffic_source"] = (f"HBM bytes per launch from the committed rocprofv3 --pmc passes ({tj.get('_source')}), measured on kernel sources "
+                                            f"{tj.get('_kernel_source_sha16')}" + (" = this run's sources" if tj.get("_kernel_source_sha16") == kernel_source_sha16()
+                                                                                    else f", this run's sources {kernel_source_sha16()}"))
+                except Exception:
+                    pass
             out["c3"]["roofline"] = rc
             out["c3"]["kernels"] = {k: {"launches_per_step": v["launches"] / k_c, "avg_ms": round(v["avg_ms"], 4), "tflops": round(v["tflops"], 1),
                                         "frac_of_bf16_peak": round(v["tflops"] / BF16_MFMA_PEAK_TFLOPS, 4), "ms_per_step": round(v["total_ms"] / k_c, 3)}

@@ -63,7 +63,7 @@ class FaceOffTrainer:
         # Flow control: the host may enqueue at most this many steps ahead of the GPU.  A training loop that never reads a loss lets the host
         # run arbitrarily far ahead, and with several streams per step the caching allocator then cannot hand a step's blocks to the next
         # one (their uses are still pending): the pool grew by 20-60 GB a few steps into a run -- device mallocs of gigabytes in the middle
-        # of training (tools/scratch/c3_steps_probe.py).  Two steps in flight keep the GPU fed; the wait costs nothing when it is the bottleneck.
+        # of training (tools/probes/c3_steps_probe.py).  Two steps in flight keep the GPU fed; the wait costs nothing when it is the bottleneck.
         self.max_inflight_steps = int(_os.environ.get("FACEOFF_MAX_INFLIGHT_STEPS", "2"))
         self._inflight = []
         self.reducer = None

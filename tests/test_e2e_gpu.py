@@ -135,7 +135,7 @@ def test_c2_oneclip_vs_reference_golden(golden_dir):
 
 
 def test_c2_oneclip_direct_engine_is_tight_and_the_default_engine_differs_by_relu_near_ties_only(golden_dir, monkeypatch):
-    """Where the 256x256 clip's first-layer filter gradient gets its 0.9e-3 (bound 1e-3) from -- measured (tools/scratch/
+    """Where the 256x256 clip's first-layer filter gradient gets its 0.9e-3 (bound 1e-3) from -- measured (tools/probes/
     c2clip_probe.py): NOT from the arithmetic of any backward kernel (switching single data- / filter-gradient passes between
     their Winograd and direct forms moves it in the 4th digit) but from ~25 ReLU masks that the Winograd FORWARD passes'
     2e-5 of rounding flip on pre-activations within rounding of zero (enc_b.blocks.2 on F(4x4,2x2) alone accounts for half).  The inputs

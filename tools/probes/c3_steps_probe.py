@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-step wall time and allocator state of the C3 trainer over many steps: python tools/scratch/c3_steps_probe.py [steps]"""
+"""Per-step wall time and allocator state of the C3 trainer over many steps: python tools/probes/c3_steps_probe.py [steps]"""
 import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))

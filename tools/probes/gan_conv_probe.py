@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-launch time and rate of the discriminators' generic convolutions (fo_convnd) inside a GAN iteration: python tools/scratch/gan_conv_probe.py"""
+"""Per-launch time and rate of the discriminators' generic convolutions (fo_convnd) inside a GAN iteration: python tools/probes/gan_conv_probe.py"""
 import os, sys, random, collections
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))

@@ -1,4 +1,4 @@
-"""Launch times of the uint8 perturbation kernels on a loader batch (160 frames 256x256x3).  python tools/scratch/u8_perturb_bench.py"""
+"""Launch times of the uint8 perturbation kernels on a loader batch (160 frames 256x256x3).  python tools/probes/u8_perturb_bench.py"""
 import random
 import torch
 from faceoff_amd import perturbations as P

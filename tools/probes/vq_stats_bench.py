@@ -1,4 +1,4 @@
-"""vq_stats launch time at the C2 sizes, uniform and skewed assignments.  PYTHONPATH=. python tools/scratch/vq_stats_bench.py"""
+"""vq_stats launch time at the C2 sizes, uniform and skewed assignments.  PYTHONPATH=. python tools/probes/vq_stats_bench.py"""
 import torch
 from faceoff_amd import ops, _lib
 import ctypes as C
