@@ -15,6 +15,7 @@
 // The transposed form orders its GEMM rows PHASE-MAJOR (destination coordinate = stride * q + phase): all rows of a tile
 // share the phase, so only the taps whose parity matches it are visited (1/8 of a k4 s2 Conv3d's taps) -- the sub-pixel
 // decomposition expressed as an index map instead of 8 launches.
+#include <stdlib.h>
 #include <algorithm>
 #include "common.h"
 
@@ -309,11 +310,16 @@ struct WgArgs {
   int margin;
 };
 
+// TM x TN 32 x 32 accumulators per wave (2 x 2 waves): a (64 TM) x (64 TN) block of dw[.][.][tap].  Round 4: 2 x 2 for the layers with >= 128
+// channels on both sides -- a quarter of the G / X bytes staged per FLOP and of the per-row address decodes (the 64 x 64 block ran at 60 TFLOP/s).
+template <int TM, int TN>
 __global__ __launch_bounds__(256, 2) void wgrad_gen_kernel(const WgArgs a) {
   constexpr int RK = 32;                   // rows (GEMM K) per step
-  constexpr int PITCH = 64 + 4;            // floats per staged row: [row][64 channels]
-  __shared__ __attribute__((aligned(16))) float Gs[2][RK * PITCH];
-  __shared__ __attribute__((aligned(16))) float Xs[2][RK * PITCH];
+  constexpr int BA = 64 * TM, BB = 64 * TN;
+  constexpr int PA = BA + 4, PB = BB + 4;  // floats per staged row: [row][channels]
+  extern __shared__ __attribute__((aligned(16))) float wg_lds[];       // 2 x RK x (PA + PB) floats (67.6 KB for the 128 x 128 block: dynamic, opted in)
+  float (*Gs)[RK * PA] = reinterpret_cast<float (*)[RK * PA]>(wg_lds);
+  float (*Xs)[RK * PB] = reinterpret_cast<float (*)[RK * PB]>(wg_lds + 2 * RK * PA);
   const fo_convnd_desc& d = a.d;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, half = lane >> 5;
@@ -328,8 +334,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_gen_kernel(const WgArgs a) {
   const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.g), 0, a.gBytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<char*>(reinterpret_cast<const char*>(a.src) - a.margin), 0, a.srcBytes + a.margin, 0x00020000);
-  // loader: thread -> (row r = tid / 16 (+16), 16 B at channel (tid % 16) * 4) of the 32 x 64 staged blocks
-  const int lr = tid >> 4, lc = (tid & 15) * 4;
+  // loaders: 16-byte chunk id = tid + 256 i -> (row id / (16 T), channel (id % (16 T)) * 4) of the 32 x (64 T) staged block
+  constexpr int CGA = 16 * TM, CGB = 16 * TN, NLA = 2 * TM, NLB = 2 * TN;
   // rows whose input frame lies in the depth padding for this tap contribute zeros and are left out: the contraction runs over
   // the VALID rows v = (n, od in [odlo, odhi], oh, ow) only, cut into `splits` equal slices
   const int HWd = d.Hd * d.Wd;
@@ -340,57 +346,92 @@ __global__ __launch_bounds__(256, 2) void wgrad_gen_kernel(const WgArgs a) {
   const int V = d.N * seg;
   const int perSplit = ((V + a.splits - 1) / a.splits + 31) / 32 * 32;
   const int m_begin = min(V, split * perSplit), m_end = min(V, m_begin + perSplit);
-  f32x4 rgv[2], rxv[2];
+  f32x4 rgv[NLA], rxv[NLB];
+  // valid row v -> output position m (and whether v is inside this slice)
+  auto row_m = [&](int v, bool& ok) {
+    ok = v < m_end;
+    const int vn = ok ? v / seg : 0;
+    return ok ? (vn * d.Dd + odlo) * HWd + (v - vn * seg) : 0;
+  };
   auto load = [&](int m0) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int v = m0 + lr + 16 * i;
-      const bool ok = v < m_end;
-      const int vn = ok ? v / seg : 0;
-      const int m = ok ? (vn * d.Dd + odlo) * HWd + (v - vn * seg) : 0;
-      int t = m;
+    for (int i = 0; i < NLA; ++i) {
+      const int id = tid + 256 * i;
+      bool ok;
+      const int m = row_m(m0 + id / CGA, ok);
+      const int c = tco * BA + (id % CGA) * 4;
+      rgv[i] = bufload(rg, (ok && c < d.Cd) ? (unsigned)(((long long)m * d.ldD + c) * 4) : OOB, 0);     // (Cd may be < 64: the 1-channel head)
+    }
+#pragma unroll
+    for (int i = 0; i < NLB; ++i) {
+      const int id = tid + 256 * i;
+      bool ok;
+      int t = row_m(m0 + id / CGB, ok);
       const int ow = t % d.Wd; t /= d.Wd;
       const int oh = t % d.Hd; t /= d.Hd;
       const int od = t % d.Dd; const int n = t / d.Dd;
-      const int id = od * d.sD - d.pD + kd, ih = oh * d.sH - d.pH + kh, iw = ow * d.sW - d.pW + kw;
-      const bool in_ok = ok & ((unsigned)id < (unsigned)d.Ds) & ((unsigned)ih < (unsigned)d.Hs) & ((unsigned)iw < (unsigned)d.Ws);
-      const long long p = (((long long)n * d.Ds + id) * d.Hs + ih) * d.Ws + iw;
-      const bool gch = tco * 64 + lc < d.Cd;      // channel group inside the tensor (Cd may be < 64: the 1-channel head)
-      rgv[i] = bufload(rg, (ok && gch) ? (unsigned)(((long long)m * d.ldD + tco * 64 + lc) * 4) : OOB, 0);
-      rxv[i] = bufload(rx, in_ok ? (unsigned)((p * d.ldS + tci * 64 + lc) * 4 + a.margin) : OOB, 0);
+      const int idp = od * d.sD - d.pD + kd, ih = oh * d.sH - d.pH + kh, iw = ow * d.sW - d.pW + kw;
+      const bool in_ok = ok & ((unsigned)idp < (unsigned)d.Ds) & ((unsigned)ih < (unsigned)d.Hs) & ((unsigned)iw < (unsigned)d.Ws);
+      const long long p = (((long long)n * d.Ds + idp) * d.Hs + ih) * d.Ws + iw;
+      const int c = tci * BB + (id % CGB) * 4;
+      rxv[i] = bufload(rx, (in_ok && c < d.Cs) ? (unsigned)((p * d.ldS + c) * 4 + a.margin) : OOB, 0);
     }
   };
   auto store = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      *reinterpret_cast<f32x4*>(&Gs[buf][(lr + 16 * i) * PITCH + lc]) = rgv[i];
-      *reinterpret_cast<f32x4*>(&Xs[buf][(lr + 16 * i) * PITCH + lc]) = rxv[i];
+    for (int i = 0; i < NLA; ++i) {
+      const int id = tid + 256 * i;
+      *reinterpret_cast<f32x4*>(&Gs[buf][(id / CGA) * PA + (id % CGA) * 4]) = rgv[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NLB; ++i) {
+      const int id = tid + 256 * i;
+      *reinterpret_cast<f32x4*>(&Xs[buf][(id / CGB) * PB + (id % CGB) * 4]) = rxv[i];
     }
   };
-  f32x16 acc;
+  f32x16 acc[TM][TN];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.f;
   if (m_begin < m_end) { load(m_begin); store(0); }
   __syncthreads();
   int cur = 0;
   for (int m0 = m_begin; m0 < m_end; m0 += RK) {
     if (m0 + RK < m_end) load(m0 + RK);
-    const float* gs = &Gs[cur][half * PITCH + wm * 32 + l31];
-    const float* xs = &Xs[cur][half * PITCH + wn * 32 + l31];
+    const float* gs = &Gs[cur][half * PA + wm * 32 * TM + l31];
+    const float* xs = &Xs[cur][half * PB + wn * 32 * TN + l31];
 #pragma unroll
-    for (int k = 0; k < RK / 2; ++k)       // MFMA k-slot = lane half = staged row 2k + half
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(gs[2 * k * PITCH], xs[2 * k * PITCH], acc, 0, 0, 0);
+    for (int k = 0; k < RK / 2; ++k) {     // MFMA k-slot = lane half = staged row 2k + half
+      float gv[TM], xv[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) gv[i] = gs[2 * k * PA + 32 * i];
+#pragma unroll
+      for (int jn = 0; jn < TN; ++jn) xv[jn] = xs[2 * k * PB + 32 * jn];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(gv[i], xv[jn], acc[i][jn], 0, 0, 0);
+    }
     if (m0 + RK < m_end) store(cur ^ 1);
     __syncthreads();
     cur ^= 1;
   }
-  const int ci = tci * 64 + wn * 32 + l31;
+  const int CoP = a.tilesCo * BA, CiP = a.tilesCi * BB;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int co = tco * 64 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-    if (a.splits > 1) a.ws[(((size_t)split * a.taps + tap) * (a.tilesCo * 64) + co) * (a.tilesCi * 64) + ci] = acc[r];
-    else if (co < d.Cd && ci < a.CsReal) a.dw[((size_t)co * a.CsReal + ci) * a.taps + tap] = acc[r];
-  }
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int jn = 0; jn < TN; ++jn) {
+      const int ci = tci * BB + wn * 32 * TN + jn * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = tco * BA + wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (a.splits > 1) a.ws[(((size_t)split * a.taps + tap) * CoP + co) * CiP + ci] = acc[i][jn][r];
+        else if (co < d.Cd && ci < a.CsReal) a.dw[((size_t)co * a.CsReal + ci) * a.taps + tap] = acc[i][jn][r];
+      }
+    }
 }
 
 // dw[co][ci][tap] = sum over the row slices, in slice order (bit-reproducible); one thread per (tap, co, ci), ci fastest
@@ -518,10 +559,20 @@ int fo_convnd(const fo_convnd_desc* d, int transposed, const float* src, const f
 // dw [Cd][CsReal][taps] = filter gradient of the forward conv described by d (src = the conv's input with Cs >= CsReal
 // padded channels, g = output gradient [N*Dd*Hd*Wd][ldD]).  With fo_wgradnd_splits(d) > 1 the row slices leave their partial
 // sums in ws (fo_wgradnd_ws_bytes) and a second launch adds them in slice order.
+// block shape: 128 channels of a side per workgroup where that side has >= 128 (FACEOFF_WGRADND_TILE64=1: the 64 x 64 block everywhere)
+static void wgradnd_tile(const fo_convnd_desc* d, int& ta, int& tb) {
+  const char* e = getenv("FACEOFF_WGRADND_TILE64");
+  const bool small = e && atoi(e);
+  ta = (!small && d->Cd >= 128) ? 128 : 64;
+  tb = (!small && d->Cs >= 128) ? 128 : 64;
+}
+
 int fo_wgradnd_splits(const fo_convnd_desc* d) {
   if (check_desc(d)) return -1;
+  int ta, tb;
+  wgradnd_tile(d, ta, tb);
   const long long M = (long long)d->N * d->Dd * d->Hd * d->Wd;
-  const long long wgs = (long long)d->KD * d->KH * d->KW * ((d->Cd + 63) / 64) * (d->Cs / 64 > 0 ? (d->Cs + 63) / 64 : 1);
+  const long long wgs = (long long)d->KD * d->KH * d->KW * ((d->Cd + ta - 1) / ta) * ((d->Cs + tb - 1) / tb);
   long long s = 1;
   while (wgs * s < 1024 && M / (s * 2) >= 256) s *= 2;
   return (int)s;
@@ -530,7 +581,9 @@ int fo_wgradnd_splits(const fo_convnd_desc* d) {
 int64_t fo_wgradnd_ws_bytes(const fo_convnd_desc* d) {
   const int s = fo_wgradnd_splits(d);
   if (s <= 1) return 0;
-  return (int64_t)s * d->KD * d->KH * d->KW * ((d->Cd + 63) / 64 * 64) * ((d->Cs + 63) / 64 * 64) * 4;
+  int ta, tb;
+  wgradnd_tile(d, ta, tb);
+  return (int64_t)s * d->KD * d->KH * d->KW * ((d->Cd + ta - 1) / ta * ta) * ((d->Cs + tb - 1) / tb * tb) * 4;
 }
 
 int fo_wgradnd(const fo_convnd_desc* d, const float* g, const float* src, float* dw, int CsReal, float* ws, int64_t ws_bytes, void* stream) {
@@ -543,8 +596,10 @@ int fo_wgradnd(const fo_convnd_desc* d, const float* g, const float* src, float*
   FO_REQUIRE(M < (1ll << 30), FO_E_SHAPE, "wgradnd: too many rows");
   a.M = (int)M;
   a.taps = d->KD * d->KH * d->KW;
-  a.tilesCo = (d->Cd + 63) / 64;
-  a.tilesCi = (d->Cs + 63) / 64;
+  int ta, tb;
+  wgradnd_tile(d, ta, tb);
+  a.tilesCo = (d->Cd + ta - 1) / ta;
+  a.tilesCi = (d->Cs + tb - 1) / tb;
   a.splits = fo_wgradnd_splits(d);
   a.ws = ws;
   FO_REQUIRE(a.splits == 1 || (ws && ws_bytes >= fo_wgradnd_ws_bytes(d)), FO_E_SHAPE, "wgradnd: workspace too small (fo_wgradnd_ws_bytes)");
@@ -553,13 +608,24 @@ int fo_wgradnd(const fo_convnd_desc* d, const float* g, const float* src, float*
   FO_REQUIRE(srcBytes < (1ull << 31) && gBytes < (1ull << 31), FO_E_SHAPE, "wgradnd: tensor exceeds the 2 GiB window");
   a.srcBytes = (unsigned)srcBytes; a.gBytes = (unsigned)gBytes; a.margin = 0;
   const long long grid = (long long)a.taps * a.tilesCo * a.tilesCi * a.splits;
-  FO_NOTE("wgrad_gen_kernel");
-  hipLaunchKernelGGL(wgrad_gen_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
+#define FO_WG_LAUNCH(TM_, TN_)                                                                                                   \
+  do {                                                                                                                           \
+    constexpr int ldsB = 2 * 32 * (64 * TM_ + 4 + 64 * TN_ + 4) * 4;                                                             \
+    static fo_lds_once once;                                                                                                     \
+    if (ldsB > 64 * 1024 && !fo_lds_optin(once, reinterpret_cast<const void*>(wgrad_gen_kernel<TM_, TN_>), ldsB, "wgradnd")) return FO_E_HIP; \
+    FO_NOTE_T("wgrad_gen_kernel", TM_, TN_);                                                                                     \
+    hipLaunchKernelGGL((wgrad_gen_kernel<TM_, TN_>), dim3((unsigned)grid), dim3(256), ldsB, (hipStream_t)stream, a);             \
+  } while (0)
+  if (ta == 128 && tb == 128) FO_WG_LAUNCH(2, 2);
+  else if (ta == 128) FO_WG_LAUNCH(2, 1);
+  else if (tb == 128) FO_WG_LAUNCH(1, 2);
+  else FO_WG_LAUNCH(1, 1);
+#undef FO_WG_LAUNCH
   FO_CHECK_LAUNCH();
   if (a.splits > 1) {
     const size_t total = (size_t)a.taps * d->Cd * CsReal;
     hipLaunchKernelGGL(wgrad_gen_reduce_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream, ws, dw,
-                       a.splits, a.taps, a.tilesCo * 64, a.tilesCi * 64, d->Cd, CsReal);
+                       a.splits, a.taps, a.tilesCo * ta, a.tilesCi * tb, d->Cd, CsReal);
     FO_CHECK_LAUNCH();
   }
   return FO_OK;
