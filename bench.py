@@ -600,6 +600,7 @@ def main():
         if not args.no_kernel_events:
             # per-kernel timing as for `roofline`: side streams folded, HIP events per launch, two generator + two discriminator iterations
             eng_g.set_stream_overlap(False)
+            gan.overlap_d2 = False
             gan.step(cimg, cgt); gan.step(cimg, cgt)
             prof5 = ops.KernelProfiler()
             ops.PROFILER = prof5

@@ -39,6 +39,13 @@ class GANTrainer:
         self.window = window
         self.rng = rng if rng is not None else _random.Random()
         self.iteration = 0
+        # the image discriminator (two samples of ONE frame pair: launches of a few hundred workgroups) runs on its own stream beside the video
+        # discriminator -- the two are independent until their input gradients meet in the decoder-output gradient (FACEOFF_NO_D2_OVERLAP=1: serial)
+        import os as _os
+        self.d2_stream = None
+        if engine.device.type == "cuda" and not _os.environ.get("FACEOFF_NO_D2_OVERLAP"):
+            self.d2_stream = torch.cuda.Stream(device=engine.device)
+        self.overlap_d2 = True                     # (bench.py's per-kernel region folds it, like the engine's side streams)
         # data parallel (the reference wraps generator and both discriminators in DDP): every rank runs its own clip, the
         # flat gradient arenas are summed over ranks in one all-reduce each and averaged inside the Adam launch; the VQ
         # statistics are summed in the forward (vqvae_conv3d_latent.py:63-64)
@@ -51,6 +58,23 @@ class GANTrainer:
             engine.vq_allreduce = vq_ar_abi
         elif self.world > 1:
             engine.vq_allreduce = fused_vq_allreduce()
+
+    def _beside(self):
+        """Context manager: the body runs on the image discriminator's side stream behind everything enqueued so far on the current stream
+        (or inline when there is no side stream / overlap is off); the value it yields, called later on the main stream, joins the side stream."""
+        import contextlib
+        side = self.d2_stream if self.overlap_d2 else None
+
+        @contextlib.contextmanager
+        def cm():
+            if side is None:
+                yield (lambda: None)
+                return
+            main = torch.cuda.current_stream(self.engine.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                yield (lambda: main.wait_stream(side))
+        return cm()
 
     def _sum_over_ranks(self, flat):
         if self.world > 1:
@@ -122,18 +146,20 @@ class GANTrainer:
             ops.mse_slice_bwd(dec, ground_truth, one, g_dec)
             g_win = g_dec[r:r + w]
             # image discriminator: module calls fake, then real (:354,357); only the fake logits reach the generator
-            x2 = self._image_pairs(dec_win, gt_win, c)
-            S2 = self.d2.forward(x2, training=True, sample_order=[0, 1])
-            l2 = torch.zeros(1, device=eng.device)
-            g2 = ralsgan_pair(S2["logits"], 0, 1, 1.0, 0.0, 0.5, l2, want_gb=False)
-            gx2 = self.d2.backward(S2, g2, param_grads=False, input_grad=True, samples=(0, 1))    # (the real sample's logits carry no gradient)
-            pairs_backward(gx2[0], 0, c["frame_id"], 1, 1, g_win)
+            with self._beside() as joined:
+                x2 = self._image_pairs(dec_win, gt_win, c)
+                S2 = self.d2.forward(x2, training=True, sample_order=[0, 1])
+                l2 = torch.zeros(1, device=eng.device)
+                g2 = ralsgan_pair(S2["logits"], 0, 1, 1.0, 0.0, 0.5, l2, want_gb=False)
+                gx2 = self.d2.backward(S2, g2, param_grads=False, input_grad=True, samples=(0, 1))    # (the real sample's logits carry no gradient)
             # video discriminator: module calls real, then fake (:368-369)
             x3 = self._video_pairs(dec_win, gt_win, c)
             S3 = self.d3.forward(x3, training=True, sample_order=[1, 0])
             l3 = torch.zeros(1, device=eng.device)
             g3 = ralsgan_pair(S3["logits"], 0, 1, 1.0, 0.0, 0.5, l3, want_gb=False)
             gx3 = self.d3.backward(S3, g3, param_grads=False, input_grad=True, samples=(0, 1))
+            joined()                                                          # both input gradients add into g_win: on this stream, image then video
+            pairs_backward(gx2[0], 0, c["frame_id"], 1, 1, g_win)
             first, step = (w - 1, -1) if c["flip_fake"] else (1, 1)
             pairs_backward(gx3[0], 0, first, step, w - 1, g_win)
             eng.backward(S, g_dec, one * LATENT_LOSS_WEIGHT)                  # G_loss = recon + latent + G_2d + G_3d (:375)
@@ -142,6 +168,15 @@ class GANTrainer:
             self.optimizer.step(grad_scale=self._sum_over_ranks(eng.flat_grads))
             out.update(g_loss_2d=l2, g_loss_3d=l3)
         else:
+            # image discriminator: module calls real, then fake (:412-413) -- its whole update beside the video discriminator's (the reference runs
+            # the video discriminator first, :392-409; the two updates touch disjoint parameters and random draws were made above, in its order)
+            with self._beside() as joined:
+                x2 = self._image_pairs(dec_win, gt_win, c)
+                S2 = self.d2.forward(x2, training=True, sample_order=[1, 0])
+                l2 = torch.zeros(1, device=eng.device)
+                g2 = ralsgan_pair(S2["logits"], 1, 0, 1.0, 0.0, 0.5, l2)
+                self.d2.backward(S2, g2, param_grads=True, input_grad=False)
+                self.d2.adam_step(self.d_lr, grad_scale=self._sum_over_ranks(self.d2.flat_grads))
             # video discriminator: module calls fake, then real (:392-393); both logits carry gradient to its parameters
             x3 = self._video_pairs(dec_win, gt_win, c)
             S3 = self.d3.forward(x3, training=True, sample_order=[0, 1])
@@ -149,12 +184,6 @@ class GANTrainer:
             g3 = ralsgan_pair(S3["logits"], 1, 0, 1.0, 0.0, 0.5, l3)
             self.d3.backward(S3, g3, param_grads=True, input_grad=False)
             self.d3.adam_step(self.d_lr, grad_scale=self._sum_over_ranks(self.d3.flat_grads))
-            # image discriminator: module calls real, then fake (:412-413)
-            x2 = self._image_pairs(dec_win, gt_win, c)
-            S2 = self.d2.forward(x2, training=True, sample_order=[1, 0])
-            l2 = torch.zeros(1, device=eng.device)
-            g2 = ralsgan_pair(S2["logits"], 1, 0, 1.0, 0.0, 0.5, l2)
-            self.d2.backward(S2, g2, param_grads=True, input_grad=False)
-            self.d2.adam_step(self.d_lr, grad_scale=self._sum_over_ranks(self.d2.flat_grads))
+            joined()
             out.update(d_loss_3d=l3, d_loss_2d=l2)
         return out

@@ -17,6 +17,7 @@ eng = VQVAEEngine(make_state_dict(0, codebook_scale=0.3, gain=2.0), dev)
 tr = GANTrainer(eng, DiscEngine(make_disc_state(1, 3), dev, dims=3, n_frames=15), DiscEngine(make_disc_state(2, 2), dev, dims=2), rng=random.Random(3))
 if "--overlap" not in sys.argv:
     eng.set_stream_overlap(False)
+    tr.overlap_d2 = False
 for _ in range(4):
     tr.step(img, gt)
 torch.cuda.synchronize()
