@@ -601,6 +601,7 @@ def main():
             # per-kernel timing as for `roofline`: side streams folded, HIP events per launch, two generator + two discriminator iterations
             eng_g.set_stream_overlap(False)
             gan.overlap_d2 = False
+            gan.d3.overlap_scales = gan.d2.overlap_scales = False
             gan.step(cimg, cgt); gan.step(cimg, cgt)
             prof5 = ops.KernelProfiler()
             ops.PROFILER = prof5

@@ -15,6 +15,7 @@ chunks); the 1-channel patch logits live in a 32-float pixel (channel 0), which 
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 from collections import OrderedDict
 
@@ -66,6 +67,8 @@ class DiscEngine:
         self.t = 0
         self._wp, self._wpt, self._w2 = {}, {}, {}
         self._packs_stale, self._packed_version = True, -1
+        self.overlap_scales = not _os.environ.get("FACEOFF_NO_DISC_SCALE_OVERLAP")
+        self._scale_stream = None
         if state_dict is not None:
             self.load_state_dict(state_dict)
 
@@ -178,13 +181,35 @@ class DiscEngine:
         N = x.shape[0]
         order = list(sample_order) if sample_order is not None else list(range(N))
         S = {"scales": [], "logits": [], "N": N, "training": training}
-        h = x
-        for i in range(self.num_D):
-            S["scales"].append(self._scale_fwd(h, f"netD.scale{self.num_D - 1 - i}", training, order))
-            S["logits"].append(S["scales"][-1]["feat"][4])
-            if i != self.num_D - 1:
-                h = self._downsample(h)
+        # the scales are independent once their inputs exist (scale i+1 sees the average pool of scale i's input; separate filters, separate
+        # running statistics): the pooled inputs first, then the coarser scales -- launches of a few dozen tiles -- on a side stream beside the
+        # full-resolution one
+        hs = [x]
+        for i in range(1, self.num_D):
+            hs.append(self._downsample(hs[-1]))
+        side, main = self._side(), None
+        if side is not None and self.num_D > 1:
+            main = torch.cuda.current_stream(self.device)
+            side.wait_stream(main)
+        scales = [None] * self.num_D
+        for i in list(range(1, self.num_D)) + [0]:
+            ctx = torch.cuda.stream(side) if (main is not None and i > 0) else contextlib.nullcontext()
+            with ctx:
+                scales[i] = self._scale_fwd(hs[i], f"netD.scale{self.num_D - 1 - i}", training, order)
+        if main is not None:
+            main.wait_stream(side)
+        S["scales"] = scales
+        S["logits"] = [sc["feat"][4] for sc in scales]
         return S
+
+    def _side(self):
+        """The stream the coarser scales run on (None: no overlap -- CPU-less builds never get here; FACEOFF_NO_DISC_SCALE_OVERLAP=1; bench.py's
+        per-kernel region, which wants every launch alone on the GPU)."""
+        if not self.overlap_scales or self.device.type != "cuda":
+            return None
+        if self._scale_stream is None:
+            self._scale_stream = torch.cuda.Stream(device=self.device)
+        return self._scale_stream
 
     def _pool_args(self):
         if self.dims == 3:
@@ -262,8 +287,16 @@ class DiscEngine:
         assert 0 <= n0 < n1 <= S["N"] and (samples is None or not param_grads)
         N = n1 - n0
         gx_scale = [None] * self.num_D
-        for i in range(self.num_D):
-            gx_scale[i] = self._scale_bwd(S["scales"][i], g_logits[i], param_grads, input_grad, n0, n1)
+        side, main = self._side(), None
+        if side is not None and self.num_D > 1:
+            main = torch.cuda.current_stream(self.device)
+            side.wait_stream(main)
+        for i in list(range(1, self.num_D)) + [0]:               # (as the forward: the coarser scales beside the full-resolution one)
+            ctx = torch.cuda.stream(side) if (main is not None and i > 0) else contextlib.nullcontext()
+            with ctx:
+                gx_scale[i] = self._scale_bwd(S["scales"][i], g_logits[i], param_grads, input_grad, n0, n1)
+        if main is not None:
+            main.wait_stream(side)
         if not input_grad:
             return None
         # chain the scales: the input of scale i+1 is the average pool of the input of scale i

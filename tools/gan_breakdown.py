@@ -18,6 +18,7 @@ tr = GANTrainer(eng, DiscEngine(make_disc_state(1, 3), dev, dims=3, n_frames=15)
 if "--overlap" not in sys.argv:
     eng.set_stream_overlap(False)
     tr.overlap_d2 = False
+    tr.d3.overlap_scales = tr.d2.overlap_scales = False
 for _ in range(4):
     tr.step(img, gt)
 torch.cuda.synchronize()
