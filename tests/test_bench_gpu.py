@@ -51,7 +51,7 @@ def test_bench_emits_one_valid_json_line():
     c5 = d["c5"]
     r5 = c5["roofline"]
     assert r5["peak"] == 157.3 and 0 < r5["frac"] <= 1.0 and abs(r5["frac"] - r5["achieved"] / r5["peak"]) < 1e-3 and r5["kernel"] in c5["kernels"]
-    assert "conv_gen_kernel" in c5["kernels"] and "wgrad_gen_kernel" in c5["kernels"] and 0 < c5["iteration_frac_executed_flop"] < 1
+    assert "conv_gen_kernel" in c5["kernels"] and any(k.startswith("wgrad_gen_kernel<") for k in c5["kernels"]) and 0 < c5["iteration_frac_executed_flop"] < 1
     x = d["bf16x6"]
     assert any(k.startswith("wino_gemm_split") for k in x["kernels"]), list(x["kernels"])
     assert x["value"] > 0 and abs(x["value"] - 160 / (x["ms_per_step"] * 1e-3)) < 1e-2 * x["value"]
