@@ -280,6 +280,44 @@ def test_conv2d_winograd_fwd_dgrad_wgrad(N, H, W, m):
         _close(db, b.grad, rtol=2e-5, what="winograd conv2d bias grad")
 
 
+def test_vq_assign_teacher_forced_indices_and_reproducible_commitment_sum():
+    """fo_vq_assign2(..., forced_ind, ...): the search is skipped and the GIVEN codes are used -- index output = the forced codes, straight-through
+    value x + (embed[:, ind] - x), commitment sum and EMA statistics of THAT assignment (Quantize.forward :55-78 with :54 replaced), in the fp32
+    and the fp32 + bf16-copy forms; a code that is not the nearest one is taken as given.  The commitment sum is an ordered sum of
+    per-workgroup partials: the same bits on every launch, and overwritten (a stale value in stats[0] does not leak in)."""
+    from faceoff_amd import ops
+    dev = _dev()
+    rng = np.random.default_rng(21)
+    x_np = rng.standard_normal((5, 9, 7, 64)).astype(np.float32) * 0.8
+    e_np = rng.standard_normal((64, 512)).astype(np.float32)
+    forced_np = rng.integers(0, 512, size=(5, 9, 7)).astype(np.int64)
+    x, embed, forced = torch.from_numpy(x_np).to(dev), torch.from_numpy(e_np).to(dev), torch.from_numpy(forced_np).to(dev)
+    embedT, enorm = ops.vq_prepare(embed)
+    qe = torch.from_numpy(e_np.T[forced_np])                                   # [.., 64] = embed[:, ind]
+    want_q = (x_np + (qe.numpy() - x_np)).astype(np.float32)
+    want_sq = float(((qe.numpy().astype(np.float64) - x_np) ** 2).sum())
+    runs = []
+    for rep in range(3):
+        q = torch.empty_like(x)
+        stats = torch.full((1 + 512 + 512 * 64,), 123.0, device=dev)           # stale values everywhere
+        ind = ops.vq_assign(x, embedT, enorm, q, stats, True, force_ind=forced)
+        assert torch.equal(ind, forced)
+        assert np.array_equal(q.cpu().numpy(), want_q)
+        np.testing.assert_allclose(stats[0].item(), want_sq, rtol=1e-5)
+        counts = np.bincount(forced_np.ravel(), minlength=512).astype(np.float32)
+        assert np.array_equal(stats[1:513].cpu().numpy(), counts)
+        runs.append(stats[0].item())
+    assert runs[0] == runs[1] == runs[2]
+    q32, q16 = torch.empty_like(x), torch.empty(x.shape, device=dev, dtype=torch.bfloat16)
+    stats = torch.zeros(1 + 512 + 512 * 64, device=dev)
+    ind = ops.vq_assign_bf16out(x, embedT, enorm, q32, q16, stats, False, force_ind=forced)
+    assert torch.equal(ind, forced) and np.array_equal(q32.cpu().numpy(), want_q) and torch.equal(q16, q32.bfloat16()) and stats[0].item() == runs[0]
+    free = ops.vq_assign(x, embedT, enorm, torch.empty_like(x), torch.zeros_like(stats), False)
+    assert (free != forced).float().mean().item() > 0.9                        # (the forced codes really were not the nearest ones)
+    with pytest.raises(ValueError):
+        ops.vq_assign(x, embedT, enorm, torch.empty_like(x), stats, False, force_ind=forced + 512)
+
+
 def test_vq_assign_bit_exact_and_golden(golden_dir):
     """Indices bit-exact vs oracle/vq_oracle.c and vs the reference's own (golden) indices."""
     from faceoff_amd import ops
