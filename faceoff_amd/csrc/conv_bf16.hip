@@ -1336,6 +1336,211 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16_kernel(const HaloArgs
   }
 }
 
+// ------------------------------------------------------------------------------------------------ VGG conv1_1 + conv1_2 in one launch
+// relu1_1 (64 channels at full resolution: 1.34 GB in bf16 at 160 x 256^2) is written by conv1_1 only to be read back -- 1.6 x, through the halo
+// overlap -- by conv1_2; the ground-truth branch of LPIPS (lpips.py:80-93) never needs it again, the reconstruction branch only as the ReLU
+// mask of its backward.  Here the halo-tile kernel above MAKES its input patch instead of fetching it: per tile the 8 x 36-pixel patch of the
+// scaled image (16 bytes per pixel: 4.6 KB) is DMA'd, conv1_1 (K = 9 taps x 8 channels = 72, padded to 96) runs on it for the 6 x 34 pixels of
+// the relu1_1 patch -- v_mfma_f32_16x16x32_bf16 with the filter (13 KB, in LDS) as the row operand, a pixel's tap as one 16-byte fragment read --
+// and bias + ReLU + zero halo + bf16 rounding go straight into the LDS image the nine taps of conv1_2 read (same layout and swizzle).  +37 %
+// MFMA work in a launch that was bound by its 2.1 GB of patch reads; conv1_1's own launch (0.40 ms) disappears.  out1 (relu1_1) is optional.
+struct Vgg1Args {
+  const __bf16* x8;          // [N][H][W][8]
+  const __bf16* wp1;         // [64][128], k = tap * 8 + channel (zero from k = 72 up)
+  const float* b1;
+  const __bf16* wp2;         // [64][9][64]
+  const float* b2;
+  __bf16* out1;              // relu1_1 [N][H][W][64] (OUT1) or unused
+  __bf16* out2;              // relu1_2 [N][H][W][64]
+  __bf16* pooled;            // max-pool 2x2 of relu1_2 [N][H/2][W/2][64] (POOL) or unused
+  int N, H, W, tilesX, tilesY, ntiles;
+  unsigned x8Bytes, out1Bytes;
+};
+
+template <bool OUT1, bool POOL>
+__global__ __launch_bounds__(256, 2) void vgg_conv1_fused_bf16_kernel(const Vgg1Args a) {
+  constexpr int PITCH = 48, ROWS = 6, PLANE = ROWS * PITCH * 64;       // the relu1_1 patch: two 32-channel planes of 64-byte pixels
+  constexpr int OFF_RGB = 2 * PLANE, RGBB = 8 * 1024;                  // two image-patch buffers of 512 pixels x 16 B (288 used)
+  constexpr int OFF_W1 = OFF_RGB + 2 * RGBB, W1P = 208;                // conv1_1 filter: 64 rows of 96 k, row pitch 208 B (conflict-free 16-B reads)
+  constexpr int OFF_B1 = OFF_W1 + 64 * W1P;                            // conv1_1 bias, 64 floats
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, quad = lane >> 4;
+  const int wm = wave >> 1, wn = wave & 1;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.x8), 0, a.x8Bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ro1 = __builtin_amdgcn_make_buffer_rsrc(a.out1, 0, OUT1 ? a.out1Bytes : 0u, 0x00020000);
+  lds_byte* const lds3 = (lds_byte*)lds;
+
+  // conv1_2's filter fragments, resident (as conv_halo64_bf16_kernel)
+  bf16x8 wf[9][2][2];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        wf[t][sl][j] = *reinterpret_cast<const bf16x8*>(a.wp2 + (size_t)(wn * 32 + j * 16 + l15) * 576 + t * 64 + sl * 32 + quad * 8);
+  // conv1_1's filter and bias -> LDS
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int id = tid + 256 * i, row = id / 12, c16 = id - row * 12;
+    *reinterpret_cast<u32x4*>(lds + OFF_W1 + row * W1P + c16 * 16) = *reinterpret_cast<const u32x4*>(a.wp1 + (size_t)row * 128 + c16 * 8);
+  }
+  if (tid < 64) reinterpret_cast<float*>(lds + OFF_B1)[tid] = a.b1[tid];
+
+  auto dma_rgb = [&](int tile, int buf) {
+    const bool live = tile < a.ntiles;
+    const int tx = tile % a.tilesX, r1 = tile / a.tilesX;
+    const int ty = r1 % a.tilesY, n = r1 / a.tilesY;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int pc = wave + 4 * k;                         // piece of 64 pixels; patch pixel q = row * 36 + column, rows y0 - 2 .., columns x0 - 2 ..
+      const int q = pc * 64 + lane, r = q / 36, c = q - r * 36;
+      const int iy = ty * 4 - 2 + r, ix = tx * 32 - 2 + c;
+      const bool ok = live & (q < 288) & ((unsigned)iy < (unsigned)a.H) & ((unsigned)ix < (unsigned)a.W);
+      dma16(rx, lds3 + OFF_RGB + buf * RGBB + pc * 1024, ok ? (unsigned)((((size_t)n * a.H + iy) * a.W + ix) * 16) : OOB);
+    }
+  };
+
+  // per-lane constants of the producer: the tap this lane's k-chunk belongs to in each of the three 32-deep steps (taps >= 9: the filter is zero there)
+  int xoff[3];
+#pragma unroll
+  for (int s2 = 0; s2 < 3; ++s2) {
+    const int t = min(4 * s2 + quad, 8);
+    xoff[s2] = ((t / 3) * 36 + (t % 3)) * 16;
+  }
+  int cq[3];
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw) cq[kw] = (l15 + kw) * 64 + ((quad ^ swz(l15 + kw)) * 16);
+  float bv[2][4];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bv[j][r] = a.b2[wn * 32 + j * 16 + quad * 4 + r];
+
+  int tile = blockIdx.x;
+  dma_rgb(tile, 0);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  for (int it = 0; tile < a.ntiles; tile += gridDim.x, ++it) {
+    const int buf = it & 1;
+    const int tx = tile % a.tilesX, r1 = tile / a.tilesX;
+    const int ty = r1 % a.tilesY, n = r1 / a.tilesY;
+    dma_rgb(tile + gridDim.x, buf ^ 1);                    // the next tile's image patch flies during this tile's work
+    // ---- producer: relu1_1 on the 6 x 34 patch (18 blocks of 16 pixels: patch row blk / 3, columns 16 (blk % 3) ..; dealt over the 4 waves)
+    const unsigned char* const rgb = lds + OFF_RGB + buf * RGBB;
+    // conv1_1's filter fragments live in registers for the length of this phase only (conv1_2's accumulators and fragments are dead here), one
+    // 32-channel half of the output at a time: read per block they made the phase a chain of dependent LDS reads -- 15 per 12 MFMAs -- and the
+    // launch no faster than the two it replaces; all twelve at once spilled
+#pragma unroll
+    for (int hc = 0; hc < 2; ++hc) {                       // output channels 32 hc .. + 31 = plane hc of the patch
+      bf16x8 w1r[2][3];
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int s2 = 0; s2 < 3; ++s2)
+          w1r[j][s2] = *reinterpret_cast<const bf16x8*>(lds + OFF_W1 + ((hc * 2 + j) * 16 + l15) * W1P + s2 * 64 + quad * 16);
+#pragma unroll
+      for (int k = 0; k < 5; ++k) {
+        const int blk = wave + 4 * k;
+        const int r = blk / 3, c = (blk - r * 3) * 16 + l15;
+        const bool live = blk < 18;                        // (wave-uniform)
+        f32x4 p1[2];
+        if (live) {
+          p1[0] = p1[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+          const unsigned char* const xb = rgb + (r * 36 + c) * 16;
+          bf16x8 xf1[3];
+#pragma unroll
+          for (int s2 = 0; s2 < 3; ++s2) xf1[s2] = *reinterpret_cast<const bf16x8*>(xb + xoff[s2]);
+#pragma unroll
+          for (int s2 = 0; s2 < 3; ++s2)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) p1[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1r[j][s2], xf1[s2], p1[j], 0, 0, 0);
+        }
+        const int iy = ty * 4 - 1 + r, ix = tx * 32 - 1 + c;
+        const bool inimg = ((unsigned)iy < (unsigned)a.H) & ((unsigned)ix < (unsigned)a.W) & (c < 34);
+        const bool interior = live & (r >= 1) & (r <= 4) & (c >= 1) & (c <= 32);
+        const unsigned o1 = interior ? (unsigned)((((size_t)n * a.H + iy) * a.W + ix) * 128 + hc * 64 + quad * 8) : OOB;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          bf16x4 o = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+          if (live) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(lds + OFF_B1 + (hc * 32 + j * 16 + quad * 4) * 4);
+            const float v0 = inimg ? fmaxf(p1[j][0] + b4.x, 0.f) : 0.f, v1 = inimg ? fmaxf(p1[j][1] + b4.y, 0.f) : 0.f;
+            const float v2 = inimg ? fmaxf(p1[j][2] + b4.z, 0.f) : 0.f, v3 = inimg ? fmaxf(p1[j][3] + b4.w, 0.f) : 0.f;
+            o = bf16x4{(__bf16)v0, (__bf16)v1, (__bf16)v2, (__bf16)v3};
+            // channel 32 hc + 16 j + 4 quad .. + 3 of patch pixel (r, c): plane hc, logical 16-byte chunk 2 j + (quad >> 1), half quad & 1
+            *reinterpret_cast<bf16x4*>(lds + hc * PLANE + (r * PITCH + c) * 64 + (((2 * j + (quad >> 1)) ^ swz(c & 15)) * 16) + (quad & 1) * 8) = o;
+          }
+          if (OUT1) {
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), ro1, o1 == OOB ? OOB : o1 + j * 32, 0, 0);
+          }
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                          // the patch is complete
+    // ---- conv1_2 on the patch: conv_halo64_bf16_kernel's loop
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int h = 0; h < 36; ++h) {
+      const int tap = h >> 2, sl = (h >> 1) & 1, pr = h & 1, kh = tap / 3, kw = tap - kh * 3;
+      bf16x8 xf[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+        xf[e] = *reinterpret_cast<const bf16x8*>(lds + sl * PLANE + ((2 * wm + pr + kh) * PITCH + e * 16) * 64 + cq[kw]);
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[2 * pr + e][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tap][sl][j], xf[e], acc[2 * pr + e][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- epilogue: bias + ReLU + bf16, 8-byte stores; the 2x2 max-pool rides along (see conv_halo64_bf16_kernel)
+    float pm[2][2][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const size_t pix = ((size_t)n * a.H + ty * 4 + 2 * wm + (i >> 1)) * a.W + tx * 32 + (i & 1) * 16 + l15;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int co = wn * 32 + j * 16 + quad * 4;
+        const bf16x4 o = {(__bf16)fmaxf(acc[i][j][0] + bv[j][0], 0.f), (__bf16)fmaxf(acc[i][j][1] + bv[j][1], 0.f),
+                          (__bf16)fmaxf(acc[i][j][2] + bv[j][2], 0.f), (__bf16)fmaxf(acc[i][j][3] + bv[j][3], 0.f)};
+        *reinterpret_cast<bf16x4*>(a.out2 + pix * 64 + co) = o;
+        if (POOL) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) pm[i & 1][j][r] = (i >> 1) ? fmaxf(pm[i & 1][j][r], (float)o[r]) : (float)o[r];
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (POOL) {
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const size_t ppix = ((size_t)n * (a.H / 2) + ty * 2 + wm) * (a.W / 2) + tx * 16 + e * 8 + (l15 >> 1);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          float m[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) m[r] = fmaxf(pm[e][j][r], __shfl_xor(pm[e][j][r], 1));
+          if (!(l15 & 1))
+            *reinterpret_cast<bf16x4*>(a.pooled + ppix * 64 + wn * 32 + j * 16 + quad * 4) = bf16x4{(__bf16)m[0], (__bf16)m[1], (__bf16)m[2], (__bf16)m[3]};
+        }
+      }
+    }
+    // the next image patch has landed: vmcnt retires in order and everything younger than its two DMAs is this tile's stores, which may fly on
+    wait_vmcnt_n<(OUT1 ? 20 : 0) + 8 + (POOL ? 4 : 0)>();
+    __builtin_amdgcn_s_barrier();                          // ... and every wave is done with the relu1_1 patch
+  }
+}
+
 static int launch_halo64(const ConvArgsH& c, hipStream_t s, void* pooled = nullptr, int ldPooled = 0) {
   const fo_conv_desc& d = c.d;
   HaloArgs a;
@@ -1616,6 +1821,43 @@ static int conv_bf16_impl(const fo_conv_desc* d, const void* in, const void* wp,
     a.tilesN = 1;
     return launch<32, 4, 1, 1, 1>(a, smallc, s);
   }
+}
+
+// VGG conv1_1 + conv1_2 (+ the 2x2 max-pool) in one launch: vgg_conv1_fused_bf16_kernel.  x8 [N][H][W][8] bf16 (ScalingLayer output), wp1 = fo_pack_conv_bf16
+// of the 64 x 8 x 3 x 3 filter with taps padded to 16 (rows of 128), wp2 = fo_pack_conv_bf16 of the 64 x 64 x 3 x 3 filter; out1 (relu1_1) and pooled may be NULL.
+// Returns FO_E_SHAPE for frames that are not whole 4 x 32 tiles or too few tiles to fill the chip twice (the caller then runs the two layers one by one).
+int fo_vgg_conv1_fused_bf16(const void* x8, const void* wp1, const float* b1, const void* wp2, const float* b2, void* out1, void* out2, void* pooled,
+                            int N, int H, int W, void* stream) {
+  FO_REQUIRE(x8 && wp1 && b1 && wp2 && b2 && out2 && fo_aligned16(x8) && fo_aligned16(wp1) && fo_aligned16(wp2) && fo_aligned16(out2), FO_E_ALIGN,
+             "vgg_conv1_fused: null / unaligned pointer");
+  FO_REQUIRE(N > 0 && H % 4 == 0 && W % 32 == 0 && (!pooled || (H % 2 == 0)), FO_E_SHAPE, "vgg_conv1_fused: frames must be whole 4 x 32 tiles (H %% 4, W %% 32)");
+  const unsigned long long px = (unsigned long long)N * H * W;
+  FO_REQUIRE(px * 128 < (1ull << 31), FO_E_SHAPE, "vgg_conv1_fused: relu1_1 / relu1_2 exceed the 2 GiB buffer window (run in frame chunks)");
+  Vgg1Args a;
+  a.x8 = reinterpret_cast<const __bf16*>(x8); a.wp1 = reinterpret_cast<const __bf16*>(wp1); a.b1 = b1;
+  a.wp2 = reinterpret_cast<const __bf16*>(wp2); a.b2 = b2;
+  a.out1 = reinterpret_cast<__bf16*>(out1); a.out2 = reinterpret_cast<__bf16*>(out2); a.pooled = reinterpret_cast<__bf16*>(pooled);
+  a.N = N; a.H = H; a.W = W; a.tilesX = W / 32; a.tilesY = H / 4; a.ntiles = N * a.tilesX * a.tilesY;
+  a.x8Bytes = (unsigned)(px * 16); a.out1Bytes = (unsigned)(px * 128);
+  const int cus = fo_cu_count();
+  FO_REQUIRE(a.ntiles >= 4 * cus || getenv("FACEOFF_BF16_FORCE_HALO"), FO_E_SHAPE, "vgg_conv1_fused: fewer than 4 tiles per CU");
+  constexpr int ldsBytes = 2 * 6 * 48 * 64 + 2 * 8192 + 64 * 208 + 256;
+  const int grid = std::min(2 * cus, a.ntiles);
+  hipStream_t s = (hipStream_t)stream;
+#define FO_V1(O1_, PL_)                                                                                                              \
+  do {                                                                                                                               \
+    static fo_lds_once once;                                                                                                         \
+    if (!fo_lds_optin(once, reinterpret_cast<const void*>(vgg_conv1_fused_bf16_kernel<O1_, PL_>), ldsBytes, "vgg_conv1_fused")) return FO_E_HIP; \
+    FO_NOTE_T("vgg_conv1_fused_bf16_kernel", O1_, PL_);                                                                              \
+    hipLaunchKernelGGL((vgg_conv1_fused_bf16_kernel<O1_, PL_>), dim3(grid), dim3(256), ldsBytes, s, a);                               \
+  } while (0)
+  if (out1 && pooled) FO_V1(true, true);
+  else if (out1) FO_V1(true, false);
+  else if (pooled) FO_V1(false, true);
+  else FO_V1(false, false);
+#undef FO_V1
+  FO_CHECK_LAUNCH();
+  return FO_OK;
 }
 
 int fo_conv_igemm_bf16(const fo_conv_desc* d, const void* in, const void* wp, const float* bias, const void* mask, void* out,

@@ -82,6 +82,11 @@ class LPIPSEngine:
         self.lin = [sd[f"lin{k}.model.1.weight"].reshape(-1).contiguous() for k in range(5)]
         self.shift, self.scale = _F3(*SHIFT), _F3(*SCALE)
         self.window_bytes = (1 << 31) - 1     # the conv kernel's buffer-descriptor window
+        import os as _os
+        # conv1_1 + conv1_2 in one launch (fo_vgg_conv1_fused_bf16): OPT-IN (FACEOFF_VGG_FUSE=1).  Correct (tests/test_lpips_gpu.py) but it does not pay:
+        # 1.19-1.43 ms against 1.40 ms for the two launches without the relu1_1 output, 1.6-1.7 ms with it (tools/probes/vgg1_kernel_time.py)
+        self.fuse_conv1 = bool(_os.environ.get("FACEOFF_VGG_FUSE"))
+        self.force_fuse_conv1 = _os.environ.get("FACEOFF_BF16_FORCE_HALO", "0") not in ("", "0")     # tests: at any size
 
     # ------------------------------------------------------------------ pieces
     def _prep(self, src, nhwc):
@@ -120,7 +125,24 @@ class LPIPSEngine:
         acts['p<i>'] = pooled input of conv i (only when keep_all)."""
         taps, acts, x = [], {}, x8
         nxt = None                                       # the pooled input of the next conv, when the previous launch already wrote it
+        skip = 0
+        if self.bf16 and self.fuse_conv1:
+            # conv1_1 + conv1_2 (+ the pool in front of conv2_1) in ONE launch where frames are whole 4 x 32 tiles and the launch fills the chip:
+            # relu1_1 is made in LDS, tile by tile, and only written out when the backward will need it as a ReLU mask (keep_all)
+            N, H, W, _ = x8.shape
+            if H % 4 == 0 and W % 32 == 0 and (N * (H // 4) * (W // 32) >= 4 * _lib.cu_count() or self.force_fuse_conv1) and N * H * W * 128 < (1 << 31):
+                a0 = torch.empty((N, H, W, 64), device=self.device, dtype=self.act_dtype) if keep_all else None
+                a1 = torch.empty((N, H, W, 64), device=self.device, dtype=self.act_dtype)
+                nxt = torch.empty((N, H // 2, W // 2, 64), device=self.device, dtype=self.act_dtype)
+                _lib.call("fo_vgg_conv1_fused_bf16", ops._ptr(x8), ops._ptr(self.wp[0]), ops._ptr(self.b[0]), ops._ptr(self.wp[1]), ops._ptr(self.b[1]),
+                          ops._ptr(a0), ops._ptr(a1), ops._ptr(nxt), N, H, W, ops._stream())
+                if keep_all:
+                    acts[0], acts[1] = a0, a1
+                taps.append(a1)
+                x, skip = a1, 2
         for i, (_, ci, co, pool) in enumerate(self.convs):
+            if i < skip:
+                continue
             if pool:
                 x = nxt if nxt is not None else self._pool(x)
                 if keep_all:

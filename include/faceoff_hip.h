@@ -475,6 +475,13 @@ int64_t fo_lpips_tap_ws_bytes_bf16(int N, int H, int W, int C);
 int fo_lpips_tap_fwd_bf16(const void* f0, const void* f1, const float* lin, float* val, int N, int H, int W, int C, float* ws, void* stream);
 int fo_lpips_tap_bwd_bf16(const void* f0, const void* f1, const float* lin, const float* gscale, void* gf1, int N, int H, int W,
                           int C, void* stream);
+/* VGG conv1_1 + ReLU + conv1_2 + ReLU (+ the 2x2 max-pool in front of conv2_1) in ONE launch (models/lpips.py:118-127, slice1 and the head of slice2): the
+ * halo-tile kernel of the 64-channel layers computes its relu1_1 input patch from the scaled image instead of reading it back.  x8 [N][H][W][8] bf16
+ * (fo_lpips_prep_bf16); wp1 = fo_pack_conv_bf16 of the [64][8][3][3] filter with tapsPad 16; wp2 = fo_pack_conv_bf16 of [64][64][3][3].
+ * out1 = relu1_1 [N][H][W][64] (NULL: not stored -- the ground-truth branch), out2 = relu1_2 [N][H][W][64], pooled [N][H/2][W/2][64] or NULL.
+ * FO_E_SHAPE unless H % 4 == 0, W % 32 == 0 and there are >= 4 tiles of 4 x 32 pixels per CU: the caller then runs the layers one by one. */
+int fo_vgg_conv1_fused_bf16(const void* x8, const void* wp1, const float* b1, const void* wp2, const float* b2, void* out1, void* out2, void* pooled,
+                            int N, int H, int W, void* stream);
 /* fo_lpips_tap_fwd_bf16 and fo_lpips_tap_bwd_bf16 in ONE pass over the two feature maps (training: the tap's upstream gradient
  * gscale[0] / (N H W) is known before its value is): val[n] += the tap's value per frame, gf1 = its gradient wrt f1. */
 int fo_lpips_tap_fwd_bwd_bf16(const void* f0, const void* f1, const float* lin, float* val, const float* gscale, void* gf1, int N, int H,

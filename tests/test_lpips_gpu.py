@@ -373,3 +373,73 @@ def test_conv_with_the_max_pool_riding_along_equals_conv_then_pool(monkeypatch):
     y2 = torch.empty((1, 6, 20, 64), device="cuda", dtype=torch.bfloat16); p2 = torch.empty((1, 3, 10, 64), device="cuda", dtype=torch.bfloat16)
     with pytest.raises(RuntimeError):
         ops.conv_bf16(x2, wp, b, y2, cin=64, cout=64, flags=ops.FO_OUT_RELU, pooled=p2)
+
+
+@pytest.mark.parametrize("N,H,W", [(2, 16, 32), (3, 16, 64), (1, 32, 96)])
+def test_vgg_conv1_fused_equals_the_two_layers(N, H, W, monkeypatch):
+    """fo_vgg_conv1_fused_bf16 (conv1_1 + ReLU + conv1_2 + ReLU + max-pool in one launch, models/lpips.py:118-127; relu1_1 made in LDS from the scaled
+    image, tile by tile): relu1_1, relu1_2 and the pooled tensor against torch-CPU on the same bf16 operands (relu1_1 rounded to bf16 once, as a stored
+    tensor) and against the separate launches (conv_rgb_bf16 / halo-tile / pool kernels: same products, another summation order for conv1_1); with and
+    without the relu1_1 output; frames whose tiles touch every border; and LPIPSEngine.features with it gives the taps of the layer-by-layer engine."""
+    import torch.nn.functional as F
+    from faceoff_amd import _lib, ops
+    from faceoff_amd.lpips import LPIPSEngine
+    monkeypatch.setenv("FACEOFF_BF16_FORCE_HALO", "1")
+    g = torch.Generator().manual_seed(N * 100 + W)
+    bf = torch.bfloat16
+    x = torch.zeros((N, 8, H, W))
+    x[:, :3] = torch.randn((N, 3, H, W), generator=g)
+    x = x.to(bf).float()
+    w1 = (torch.randn((64, 3, 3, 3), generator=g) * 0.3).to(bf).float()
+    w2 = (torch.randn((64, 64, 3, 3), generator=g) * 0.06).to(bf).float()
+    b1, b2 = torch.randn(64, generator=g) * 0.1, torch.randn(64, generator=g) * 0.1
+    r1 = F.relu(F.conv2d(x[:, :3], w1, b1, padding=1)).to(bf).float()
+    r2 = F.relu(F.conv2d(r1, w2, b2, padding=1))
+    pool = F.max_pool2d(r2.to(bf).float(), 2)
+    w1p = torch.zeros((64, 8, 3, 3)); w1p[:, :3] = w1
+    wp1, wp2 = ops.pack_conv_bf16(w1p.cuda(), taps_pad=16), ops.pack_conv_bf16(w2.cuda())
+    x8 = x.permute(0, 2, 3, 1).contiguous().to(bf).cuda()
+    b1c, b2c = b1.cuda(), b2.cuda()                  # (kept alive: the launches are asynchronous)
+    nhwc = lambda t: t.permute(0, 2, 3, 1)
+
+    def close(got, ref, what):
+        got, ref = got.float().cpu(), nhwc(ref)
+        tol = ref.abs() * 2.0 ** -7 + 2e-3 * ref.abs().max()
+        bad = (got - ref).abs() > tol
+        assert not bad.any(), f"{what}: {int(bad.sum())} of {bad.numel()} off, worst {((got - ref).abs() / tol).max().item():.2f} x tol"
+    outs = {}
+    for keep in (True, False):
+        o1 = torch.full((N, H, W, 64), 5.0, device="cuda", dtype=bf) if keep else None
+        o2 = torch.empty((N, H, W, 64), device="cuda", dtype=bf)
+        pl = torch.empty((N, H // 2, W // 2, 64), device="cuda", dtype=bf)
+        _lib.call("fo_vgg_conv1_fused_bf16", ops._ptr(x8), ops._ptr(wp1), ops._ptr(b1c), ops._ptr(wp2), ops._ptr(b2c), ops._ptr(o1), ops._ptr(o2),
+                  ops._ptr(pl), N, H, W, ops._stream())
+        torch.cuda.synchronize()
+        if keep:
+            close(o1, r1, "relu1_1")
+        close(o2, r2, "relu1_2")
+        assert torch.equal(pl.float().cpu(), F.max_pool2d(o2.float().cpu().permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1))   # the pool of what was stored
+        close(pl, pool, "pooled")
+        outs[keep] = (o2.clone(), pl.clone())
+    assert torch.equal(outs[True][0], outs[False][0]) and torch.equal(outs[True][1], outs[False][1])
+    # against the separate launches
+    y1 = torch.empty((N, H, W, 64), device="cuda", dtype=bf)
+    ops.conv_bf16(x8, wp1, b1c, y1, cin=8, cout=64, flags=ops.FO_OUT_RELU)
+    y2 = torch.empty_like(y1)
+    ops.conv_bf16(y1, wp2, b2c, y2, cin=64, cout=64, flags=ops.FO_OUT_RELU)
+    torch.cuda.synchronize()
+    d = (outs[True][0].float() - y2.float()).abs()
+    assert bool((d <= y2.float().abs() * 2.0 ** -7 + 2e-3 * y2.float().abs().max()).all()) and (d > 0).float().mean().item() < 5e-2
+    # the engine: fused vs layer by layer
+    sd = make_vgg_lpips_state(3)
+    img = torch.zeros((N, H, W, 8), device="cuda"); img[..., :3] = torch.rand((N, H, W, 3), generator=torch.Generator().manual_seed(1)).cuda() * 2 - 1
+    ta, tb = [], []
+    for fuse, dst in ((True, ta), (False, tb)):
+        eng = LPIPSEngine(sd, "cuda:0", dtype="bf16")
+        eng.fuse_conv1 = fuse
+        taps, acts = eng.features(eng._prep(img, nhwc=True), keep_all=True)
+        assert (0 in acts) and (1 in acts) and "p2" in acts
+        dst.extend(taps)
+    for k, (u, v) in enumerate(zip(ta, tb)):
+        du = (u.float() - v.float()).abs()
+        assert bool((du <= v.float().abs() * 2.0 ** -6 + 4e-3 * v.float().abs().max()).all()), k
