@@ -917,13 +917,15 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_pp16_kernel(const ConvArgsH 
 // conv_bf16_pp16_kernel DMAs a tile's A rows again for every tap: nine 64-byte fetches of the same pixel per 32 input channels, and what
 // bounds that kernel is the LDS-DMA stream, not the matrix pipe (tools/ablate_pp16.sh, 512 x 128 tile on the 64^2 latents: MFMAs alone
 // 0.184 ms, DMAs alone 0.196 ms, both 0.252 ms; with the A fetches of the six off-centre taps turned into zero fills, still issued, 0.220).
-// Here, for 3x3 (x3) pad-1 stride-1 layers whose tiles are whole image rows (W | BMB, BMB | H W), a 32-channel chunk of the tile's pixels PLUS
-// one image row above and below -- BMB + 2 W rows of 64 B, the "extended tile" -- is DMA'd once per (depth tap, chunk) and serves nine phases:
-// tap (kh, kw) reads its fragments at row offset (kh - 1) W + (kw - 1).  kh shifts are multiples of 16 rows (block-uniform, the swizzle does
-// not see them); kw shifts move a lane's row by +-1, so the swizzle is 2 ((row >> 2) & 1), conflict-free for ds_read_b128 at shifts -1, 0, +1
-// (exhaustive search over the instruction's lane groups); a lane whose shifted pixel would wrap into the neighbouring image row -- lane 0 of
-// a block that starts an image row (kw = 0), lane 15 of one that ends it (kw = 2) -- reads a row of zeros instead.  Rows above / below the
-// frame are zero-filled by the DMA (out-of-range offsets), as are depth taps outside the clip (kwalk_range skips those whole).
+// Here, for 3x3 (x3) pad-1 stride-1 layers whose tiles are whole image rows (W | BMB, BMB | H W: W is a power of two), a 32-channel chunk of
+// the tile's pixels PLUS one image row above and below -- BMB + 2 W rows of 64 B, the "extended tile" -- is DMA'd once per (depth tap, chunk)
+// and serves nine phases: tap (kh, kw) reads its fragments at row offset (kh - 1) W + (kw - 1).  kh shifts are multiples of 16 rows
+// (block-uniform, the swizzle does not see them); kw shifts move a lane's row by +-1, so the swizzle is 2 ((row >> 2) & 1), conflict-free for
+// ds_read_b128 at shifts -1, 0, +1 (exhaustive search over the instruction's lane groups).  In LDS every image row of the extended tile is
+// preceded by one 64-byte row of zeros (and the last one followed by one): the pixel left of an image row's first / right of its last is that
+// row, with no per-lane select (16-row DMA pieces never straddle an image row, so a piece lands whole at its padded address; a uniform
+// shift of a 16-row block by a multiple of 64 B does not change its bank pattern).  The zero rows are written once per kernel.  Rows above /
+// below the frame are zero-filled by the DMA (out-of-range offsets), as are depth taps outside the clip (kwalk_range skips those whole).
 // LDS-DMA instructions per wave and nine phases: NPE + 9 NPB instead of 9 (NPA + NPB) -- 512 x 128: 15 instead of 45.
 //
 // Protocol: the B (filter) ring and the two wave groups one barrier apart are conv_bf16_pp16_kernel's.  The extended tiles alternate between
@@ -931,240 +933,413 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_pp16_kernel(const ConvArgsH 
 // of group g - 1: retired two segments before the first issue), each behind that phase's B pieces.  vmcnt is in order, so the counted waits
 // grow by the A pieces of the phases they let fly: G0 (end of phase j) vmcnt(NPB + a(j)), G1 (after its issue in phase j)
 // vmcnt(2 NPB + a(j) + a(j - 1)), a(j) = 1 for 1 <= j <= NPE; the last piece (phase NPE <= 6) has landed by the waits of phase NPE + 2 <= 8.
+//
+// Tiles: a workgroup walks tiles blockIdx.x, + gridDim.x, ... -- the host launches one workgroup per tile, or (FACEOFF_BF16_PPH_PERSIST=1) one per
+// CU.  In the persistent form the NEXT tile's first operands -- extended tile 0 and all four filter-ring slots, free between two tiles -- are
+// DMA'd BEFORE this tile's epilogue issues its stores, and waited for with the stores still in flight (vmcnt(#stores): memory operations retire
+// in order, every lane issues a known number of stores); phases 0..2 of a tile neither issue nor wait for filter tiles (they are there), so the
+// stores drain beside the first three to four phases of the next tile.  Alone on the device that is worth 1-7 % of a launch (conv4_2 0.523 ->
+// 0.518 ms, the 64^2 latent layer 0.190 -> 0.177); in the training step it LOSES 0.5 ms of 36.8 (tools/ab_env.sh, same device): a workgroup holds
+// every register of its CU, and where each CU used to fall free between two tiles -- letting the side streams' workgroups (LPIPS heads, filter
+// gradients, the ground-truth branch) in -- a persistent grid locks them out for the whole launch.  Hence off by default.
+// Everything a tile changes is wave-uniform and lives in SGPRs -- a lane's own part of a DMA offset is the same for every piece (lpA / lpB,
+// the range check sees the VGPR part only) -- and per-lane fragment addresses are re-made per tile from mbcnt: the next tile's setup runs
+// while this tile's 128 accumulators are live, and one spill reload in the K loop is a vmcnt(0) in the middle of the counted waits.
+//
+// Where a launch goes (in-kernel s_memtime stamps, tools/stamp_pph.py, 2.0-2.1 GHz in-kernel clock): a phase takes ~1 300 clocks of which the two
+// groups' 32 MFMAs each are 2 x 512; between two tiles 2-6 thousand clocks of setup + prologue issue and the epilogue -- 10-12 thousand through an fp32
+// patch (round 4's first form), 17 thousand with 8-byte stores straight from the accumulators, 6.6-9 thousand as it is now -- against 47 thousand for the
+// 36-phase K loop of the 64^2 latent layers and 187 thousand for conv4_2's.
 __device__ __forceinline__ int swz2(int row) { return ((row >> 2) & 1) * 2; }
 template <int N> __device__ __forceinline__ void wait_vmcnt_n() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+#ifdef FO_STAMP_PPH   // diagnostic build only (tools/stamp_pph.sh): segment lengths of the K loop in core clocks, workgroup 0, waves 0 (G0) and 4 (G1)
+__device__ unsigned long long fo_pph_stamps[64];
+#define PPH_STAMP(var)                                                                  \
+  if (stamping) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory")
+#else
+#define PPH_STAMP(var)
+#endif
+
+typedef __bf16 pph_bf16x4 __attribute__((ext_vector_type(4)));
+// One output pixel's 4 consecutive channels, straight from a lane's accumulator (the filter is the MFMA's ROW operand, so a lane holds channels
+// 4 quad .. + 3 of pixel lane & 15; the accumulation STARTED from the bias): ReLU-backward mask -> + add -> ReLU -> ONE rounding to bf16 (or kept fp32).  Exactly one store.
+__device__ __forceinline__ void pph_emit4(const ConvArgsH& a, int flags, const f32x4& c, const pph_bf16x4& mk, const pph_bf16x4& ad, size_t opix, int co, bool ok) {
+  float v[4] = {c[0], c[1], c[2], c[3]};
+  if (flags & FO_MASK) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (float)mk[e] > 0.f ? v[e] : 0.f;
+  }
+  if (flags & FO_ADD) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] += (float)ad[e];
+  }
+  if (flags & FO_OUT_RELU) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+  }
+  if (!ok) return;
+  if (flags & FO_OUT_F32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + opix * a.d.ldOut + co) = f32x4{v[0], v[1], v[2], v[3]};
+  else *reinterpret_cast<pph_bf16x4*>(reinterpret_cast<__bf16*>(a.out) + opix * a.d.ldOut + co) = pph_bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+}
+
+template <int BMB, int BN, int WAVES_M, int WAVES_N, int NPE>
+struct PphLds {
+  static constexpr int APAD = (BMB / 16 + 3) * 64;        // zero rows: one per image row of the extended tile + 1 (narrowest frame: W = 16)
+  static constexpr int ASLOT = NPE * 128 * 64 + APAD;     // an extended tile: NPE pieces of 16 rows per wave
+  static constexpr int BSLOT = BN * 64;
+  static constexpr int OFF_B = 2 * ASLOT, OFF_D = OFF_B + 4 * BSLOT;      // OFF_D: where pieces past the extended tile's end go
+  static constexpr int OFF_BIAS = OFF_D + 1024, MAXC = 1024;              // the layer's bias (zeros without FO_BIAS): the accumulators start from it
+  static constexpr int PPITCH = 144;                                      // the epilogue's bf16 patch: 16 pixels x 64 channels per wave, rows of 128 + 16 B
+  static constexpr int OFF_P = OFF_BIAS + MAXC * 4;
+  static constexpr int BYTES = OFF_P + 8 * 16 * PPITCH;
+  static_assert(BYTES <= 160 * 1024, "LDS");
+};
+
 template <int BMB, int BN, int WAVES_M, int WAVES_N, int NPE>
 __global__ __launch_bounds__(512, 1) void conv_bf16_pph_kernel(const ConvArgsH a) {
-  static_assert(WAVES_M * WAVES_N == 8 && (BMB == 256 || BMB == 512) && (BN == 256 || BN == 128) && NPE >= 1 && NPE <= 6, "8 waves");
+  static_assert(WAVES_M * WAVES_N == 8 && (BMB == 256 || BMB == 512) && (BN == 256 || BN == 128) && NPE >= 3 && NPE <= 6, "8 waves");
+  using L = PphLds<BMB, BN, WAVES_M, WAVES_N, NPE>;
   constexpr int TM = BMB / WAVES_M / 16, TN = BN / WAVES_N / 16;
   constexpr int WCOLS = TN * 16;
-  static_assert(WCOLS == 64 || WCOLS == 128, "the epilogue stores 64- or 128-column wave tiles");
-  static_assert(TM % 2 == 0, "the epilogue walks pairs of 16-row blocks");
-  constexpr int ASLOT = NPE * 128 * 64;                   // an extended tile: NPE pieces of 16 rows per wave
-  constexpr int BSLOT = BN * 64;
+  static_assert(WCOLS == 64, "the epilogue stores 64-column wave tiles");
+  constexpr int ASLOT = L::ASLOT, BSLOT = L::BSLOT;
   constexpr int NPB = BN / 128;
-  constexpr int OFF_B = 2 * ASLOT, OFF_Z = OFF_B + 4 * BSLOT;
-  constexpr int C_LD = WCOLS + 4;
+  constexpr int OFF_B = L::OFF_B;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const fo_conv_desc& d = a.d;
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l15 = lane & 15, quad = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const bool g1 = __builtin_amdgcn_readfirstlane(wave >> 2) != 0;
-  const int logical = fo_xcd_remap(blockIdx.x, gridDim.x);
-  const int tile_n = logical % a.tilesN;
-  const int tile_m = logical / a.tilesN;
+  const int ntiles = a.tilesM * a.tilesN;
   const int chunks32 = a.cinChunks;
   const int W = d.Wm;
-  int kd0, kd1;
-  kwalk_range(a, tile_m * BMB, kd0, kd1);
-  const int ng = (kd1 - kd0) * chunks32;                  // extended tiles (groups of nine phases) of this row tile
-  const int nt = ng * 9;
-  // the tile: BMB consecutive pixels of ONE frame starting at an image-row boundary (host: W | BMB, BMB | H W)
-  const int m0 = tile_m * BMB;
-  const int fn = m0 / a.HWm;
-  const int y0 = (m0 - fn * a.HWm) / W;
-  const int drow = lane >> 2, dpos = lane & 3;
-  int rowoffE[NPE];                                       // byte offset of this lane's row of piece k at depth tap 0, chunk 0 (negative for frame 0 when padD = 1)
-  unsigned validE = 0;                                    // bit k: that row is a pixel of the frame (else: zero fill)
-#pragma unroll
-  for (int k = 0; k < NPE; ++k) {
-    const int e = (k * 8 + wave) * 16 + drow;             // extended row: pixel m0 - W + e
-    const int yy = y0 - 1 + e / W, xx = e % W;
-    const bool ok = e < BMB + 2 * W && (unsigned)yy < (unsigned)d.Hin;
-    rowoffE[k] = ((((fn - d.padD) * d.Hin + yy) * d.Win + xx) * d.ldIn) * 2 + (dpos ^ swz2(e)) * 16;
-    validE |= (ok ? 1u : 0u) << k;
-  }
-  unsigned woffB[NPB];
-#pragma unroll
-  for (int i = 0; i < NPB; ++i) {
-    const int row = (i * 8 + wave) * 16 + drow;
-    woffB[i] = (unsigned)(((size_t)(tile_n * BN + row) * a.Ktot) * 2 + (dpos ^ swz2(row)) * 16);
-  }
+  const int wsh = __builtin_ctz((unsigned)W);
+  const int flags = d.flags;
   const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in), 0, a.inBytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rwp = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wp), 0, a.wpBytes, 0x00020000);
   lds_byte* const lds3 = (lds_byte*)lds;
-  if (tid < 16) reinterpret_cast<unsigned*>(lds + OFF_Z)[tid] = 0u;       // the row of zeros (made visible by the barriers below)
+  {   // the zero rows: before image row s of the extended tile, s = 0 .. BMB / W + 2, at byte s (W + 1) 64 of either slot
+    const int nz = (BMB >> wsh) + 3;
+    for (int t = tid; t < 2 * nz * 16; t += 512) {
+      const int slot = t / (nz * 16), r = t % (nz * 16);
+      reinterpret_cast<unsigned*>(lds + slot * ASLOT + (r >> 4) * (W + 1) * 64)[r & 15] = 0u;
+    }
+  }
+  for (int c = tid; c < d.Cout; c += 512) reinterpret_cast<float*>(lds + L::OFF_BIAS)[c] = (flags & FO_BIAS) ? a.bias[c] : 0.f;      // (host: Cout <= MAXC)
+  unsigned lpA, lpB;                                      // a lane's part of every A / B piece's offset (piece bases are multiples of 16 rows: the swizzle sees drow only)
+  {
+    const int lane = tid & 63, drow = lane >> 2, dpos = lane & 3;
+    lpA = (unsigned)(drow * d.ldIn * 2 + (dpos ^ swz2(drow)) * 16);
+    lpB = (unsigned)(drow * a.Ktot * 2 + (dpos ^ swz2(drow)) * 16);
+  }
 
-  // ---- the two DMA streams, each with its own running position
-  int bq = 0, bj = 0, bchunk = 0, bkd = kd0;              // next B tile: phase bq = 9 * group + bj, group = (bkd, bchunk)
+  // ---- per tile: BMB consecutive pixels of ONE frame starting at an image-row boundary, BN filter rows
+  int tile_m, tile_n, kd0, ng, nt;
+  int sA[NPE];                                            // byte offset of piece k's first row at depth tap 0, chunk 0 (negative for frame 0 when padD = 1: with goff it is not)
+  unsigned validE;                                        // bit k: piece k's rows are pixels of the frame (else: zero fill)
+  int sB[NPB];
+  // the two DMA streams, each with its own running position
+  int bq, bj, bchunk, bkd;                                // next B tile: phase bq = 9 * group + bj, group = (bkd, bchunk)
+  int ag, achunk, akd;                                    // next extended tile: group ag = (akd, achunk)
+  auto setup = [&](int vb) {
+    const int logical = fo_xcd_remap(vb, ntiles);         // (a persistent grid is a multiple of 8 workgroups: vb and blockIdx.x sit on the same XCD)
+    tile_n = logical % a.tilesN;
+    tile_m = logical / a.tilesN;
+    int kd1;
+    kwalk_range(a, tile_m * BMB, kd0, kd1);
+    ng = (kd1 - kd0) * chunks32;                          // extended tiles (groups of nine phases) of this row tile
+    nt = ng * 9;
+    const int m0 = tile_m * BMB;
+    const int fn = m0 / a.HWm;
+    const int y0 = (m0 - fn * a.HWm) >> wsh;
+    validE = 0;
+#pragma unroll
+    for (int k = 0; k < NPE; ++k) {
+      const int e = (k * 8 + wave) * 16;                  // extended row of the piece's first row: pixel m0 - W + e
+      const int yy = y0 - 1 + (e >> wsh), xx = e & (W - 1);
+      const bool ok = e < BMB + 2 * W && (unsigned)yy < (unsigned)d.Hin;
+      sA[k] = __builtin_amdgcn_readfirstlane(((((fn - d.padD) * d.Hin + yy) * d.Win + xx) * d.ldIn) * 2);
+      validE |= (ok ? 1u : 0u) << k;
+    }
+    validE = __builtin_amdgcn_readfirstlane(validE);
+#pragma unroll
+    for (int i = 0; i < NPB; ++i) sB[i] = __builtin_amdgcn_readfirstlane((tile_n * BN + (i * 8 + wave) * 16) * a.Ktot * 2);
+    bq = 0; bj = 0; bchunk = 0; bkd = kd0;
+    ag = 0; achunk = 0; akd = kd0;
+  };
   auto dma_b = [&]() {
     const int kpos = (bkd * 9 + bj) * chunks32 + bchunk;  // 32-element position inside a filter row: tap * chunks + chunk
     lds_byte* const sb = lds3 + OFF_B + (bq & 3) * BSLOT;
+    const unsigned vo = lpB | (bq < nt ? 0u : OOB);        // (tiles past the end are zero fills; an OR with an SGPR, not a select between two VGPRs)
 #pragma unroll
-    for (int i = 0; i < NPB; ++i) dma16(rwp, sb + (i * 8 + wave) * 1024, bq < nt ? woffB[i] + kpos * 64 : OOB);
+    for (int i = 0; i < NPB; ++i) dma16s(rwp, sb + (i * 8 + wave) * 1024, vo, (unsigned)(sB[i] + kpos * 64));
     ++bq;
     if (++bj == 9) { bj = 0; if (++bchunk == chunks32) { bchunk = 0; ++bkd; } }
   };
-  int ag = 0, achunk = 0, akd = kd0;                      // next extended tile: group ag = (akd, achunk)
   auto dma_a_piece = [&](int k) {
     const int goff = ((akd * d.Hin * d.Win) * d.ldIn + achunk * 32) * 2;
-    const unsigned pad = (((validE >> k) & 1u) - 1u) & OOB;
-    const unsigned off = ag < ng ? (unsigned)(rowoffE[k] + goff) | pad : OOB;
-    dma16(rin, lds3 + (ag & 1) * ASLOT + (k * 8 + wave) * 1024, off);
+    const bool ok = ag < ng && ((validE >> k) & 1u);
+    const int e = (k * 8 + wave) * 16;
+    const int dst = e < BMB + 2 * W ? (ag & 1) * ASLOT + e * 64 + ((e >> wsh) + 1) * 64 : L::OFF_D;      // (every wave issues every piece: the waits count them)
+    dma16s(rin, lds3 + dst, lpA | (ok ? 0u : OOB), (unsigned)(sA[k] + goff));
   };
   auto a_next = [&]() { ++ag; if (++achunk == chunks32) { achunk = 0; ++akd; } };
+  // a tile's first operands: extended tile 0 whole and the four filter tiles of the ring (every slot is free between two tiles)
+  auto prologue = [&]() {
+#pragma unroll
+    for (int k = 0; k < NPE; ++k) dma_a_piece(k);
+    a_next();
+    dma_b(); dma_b(); dma_b(); dma_b();
+  };
+  // zero rows in front of a wave's 16-row block i at tap row kh: (its image row in the extended tile) + 1
+  int apad[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) apad[i] = __builtin_amdgcn_readfirstlane((((wm * TM + i) * 16 >> wsh) + 1) * 64);
+  const int W65 = (W + 1) * 64;                           // one image row down, in LDS
 
-  f32x4 acc[TM][TN];
+#ifdef FO_STAMP_PPH
+  const bool stamping = blockIdx.x == 0 && (wave & 3) == 0;
+  unsigned long long tS = 0, tA = 0, tM = 0, tK0 = 0, rK0 = 0, sumR = 0, sumM = 0, sumW = 0, nph = 0;
+  unsigned long long sumF[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, tE0 = 0, tE1 = 0, tE2 = 0, tE3 = 0, sumSet = 0, sumEpi = 0, sumWt = 0, ntl = 0;
+  if (stamping) asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(tK0), "=s"(rK0)::"memory");
+#endif
+  int vb = blockIdx.x;
+  setup(vb);
+  prologue();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  for (;;) {
+    // fragment addressing, re-made per tile from the lane id (mbcnt: not a live register).  B: row (lane & 15) of a 16-row block, chunk quad.
+    // A: extended row W + (wave block) + i * 16 + l15 + (kh - 1) W + (kw - 1), + its zero rows
+    int ol = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(ol));                          // (opaque: or everything derived from it is hoisted out of the tile loop)
+    const int l15 = ol & 15, quad = ol >> 4;
+    const int boff = OFF_B + (wn * TN * 16 + l15) * 64 + (quad ^ swz2(l15)) * 16;
+    int aoff[3];                                          // per kw: byte offset of this lane's row in block 0 of the wave at kh = 0, without zero rows
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+    for (int kw = 0; kw < 3; ++kw) {
+      const int r = l15 + kw - 1;                         // -1 .. 16 (block bases and kh shifts are multiples of 16: the swizzle sees r only)
+      aoff[kw] = (wm * TM * 16 + r) * 64 + (quad ^ swz2(r + 16)) * 16;
+    }
+    f32x4 acc[TM][TN];
+    if (vb != (int)blockIdx.x) {                          // (first tile: the bias is not visible before the barrier below)
 #pragma unroll
-    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  // fragment addressing.  B: row (lane & 15) of a 16-row block, chunk quad.  A: extended row W + (wave block) + i * 16 + l15 + (kh - 1) W + (kw - 1)
-  const int boff = OFF_B + (wn * TN * 16 + l15) * 64 + (quad ^ swz2(l15)) * 16;
-  int aoff[3];                                            // per kw: byte offset of this lane's row in block 0 of the wave at kh = 0
+      for (int j = 0; j < TN; ++j) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(lds + L::OFF_BIAS + (tile_n * BN + wn * WCOLS + j * 16 + quad * 4) * 4);
 #pragma unroll
-  for (int kw = 0; kw < 3; ++kw) {
-    const int r = l15 + kw - 1;                           // -1 .. 16 (block bases and kh shifts are multiples of 16: the swizzle sees r only)
-    aoff[kw] = (wm * TM * 16 + r) * 64 + (quad ^ swz2(r + 16)) * 16;
-  }
-  const int zoff = OFF_Z + quad * 16;
-  // blocks whose first pixel starts an image row (lane 0 wraps at kw = 0) / whose last pixel ends one (lane 15 wraps at kw = 2)
-  unsigned wrapL = 0, wrapR = 0;
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const int x0 = (wm * TM * 16 + i * 16) % W;
-    wrapL |= (x0 == 0 ? 1u : 0u) << i;
-    wrapR |= (x0 + 16 == W ? 1u : 0u) << i;
-  }
-  const bool edgeL = l15 == 0, edgeR = l15 == 15;
-  const int W64 = W * 64;
-
-#pragma unroll
-  for (int k = 0; k < NPE; ++k) dma_a_piece(k);           // extended tile 0, whole
-  a_next();
-  dma_b();
-  dma_b();
-  if (g1) {
-    dma_b();
-    wait_vmcnt_n<2 * NPB>();                              // A(0) and B(0) of this wave have landed
-  } else {
-    wait_vmcnt_n<NPB>();
-  }
-  __builtin_amdgcn_s_barrier();
-  if (g1) __builtin_amdgcn_s_barrier();                   // G1 runs one segment behind G0 from here on
-  __builtin_amdgcn_sched_barrier(0);
-
-  for (int g = 0; g < ng; ++g) {
-    const unsigned char* Ag = lds + (g & 1) * ASLOT;
-    // (opaque per iteration: otherwise the nine phases' per-lane addresses -- 9 bases, 2 TM wrap selects -- are hoisted out of the g loop
-    // and the kernel spills)
-    int ao0 = aoff[0], ao1 = aoff[1], ao2 = aoff[2];
-    asm volatile("" : "+v"(ao0), "+v"(ao1), "+v"(ao2));
-#pragma unroll
-    for (int j = 0; j < 9; ++j) {
-      const int kh = j / 3, kw = j % 3;
-      const int p = g * 9 + j;
-      const unsigned char* Bs = lds + (p & 3) * BSLOT + boff;
-      bf16x8 fa[TM], fb[TN];
-#pragma unroll
-      for (int jn = 0; jn < TN; ++jn) fb[jn] = *reinterpret_cast<const bf16x8*>(Bs + jn * 16 * 64);
-      const int abase = (kw == 0 ? ao0 : kw == 1 ? ao1 : ao2) + kh * W64;
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        int ad_ = abase + i * 16 * 64;
-        if (kw == 0) ad_ = (edgeL && ((wrapL >> i) & 1)) ? zoff - (int)((g & 1) * ASLOT) : ad_;
-        if (kw == 2) ad_ = (edgeR && ((wrapR >> i) & 1)) ? zoff - (int)((g & 1) * ASLOT) : ad_;
-        fa[i] = *reinterpret_cast<const bf16x8*>(Ag + ad_);
+        for (int i = 0; i < TM; ++i) acc[i][j] = b4;
       }
-      if (!(FO_ABLATE_PP & 1)) dma_b();                   // G0: B tile p + 2, G1: p + 3
-      if (j >= 1 && j <= NPE) {
-        if (!(FO_ABLATE_PP & 1)) dma_a_piece(j - 1);      // extended tile g + 1, one piece per phase
-        if (j == NPE) a_next();
+    }
+    __builtin_amdgcn_s_barrier();                         // every wave's pieces of A(0), B(0..3) have landed (first tile: and the zero rows are written)
+    if (vb == (int)blockIdx.x) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(lds + L::OFF_BIAS + (tile_n * BN + wn * WCOLS + j * 16 + quad * 4) * 4);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) acc[i][j] = b4;
       }
-      if (g1) {
-        // in flight at most: this phase's and the previous phase's pieces
-        if (j == 0) wait_vmcnt_n<2 * NPB>();
-        else if (j == 1) wait_vmcnt_n<2 * NPB + 1>();
-        else if (j <= NPE) wait_vmcnt_n<2 * NPB + 2>();
-        else if (j == NPE + 1) wait_vmcnt_n<2 * NPB + 1>();
-        else wait_vmcnt_n<2 * NPB>();
+    }
+    if (g1) __builtin_amdgcn_s_barrier();                 // G1 runs one segment behind G0 from here on
+    __builtin_amdgcn_sched_barrier(0);
+
+    for (int g = 0; g < ng; ++g) {
+      const unsigned char* Ag = lds + (g & 1) * ASLOT;
+      const bool first = g == 0;                          // B(0..3) are there: phases 0..2 neither issue them again nor wait (what they would wait
+                                                          // for has landed, and the previous tile's stores may still be in flight in front of the loop's DMAs)
+      // (opaque per iteration: otherwise the nine phases' per-lane addresses are hoisted out of the g loop and the kernel spills)
+      int ao0 = aoff[0], ao1 = aoff[1], ao2 = aoff[2];
+      asm volatile("" : "+v"(ao0), "+v"(ao1), "+v"(ao2));
+#pragma unroll
+      for (int j = 0; j < 9; ++j) {
+        const int kh = j / 3, kw = j % 3;
+        const int p = g * 9 + j;
+        PPH_STAMP(tS);
+        int bslot = (p & 3) * BSLOT;                      // (opaque: one address add per phase, not four rotating base registers)
+        asm volatile("" : "+s"(bslot));
+        const unsigned char* Bs = lds + bslot + boff;
+        bf16x8 fa[TM], fb[TN];
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn) fb[jn] = *reinterpret_cast<const bf16x8*>(Bs + jn * 16 * 64);
+        const int abase = (kw == 0 ? ao0 : kw == 1 ? ao1 : ao2) + kh * W65;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(Ag + abase + i * 16 * 64 + apad[i]);
+        // G0 issues B tile p + 2, G1 p + 3 (tiles 0..3 of a row tile come with its prologue)
+        if (!(FO_ABLATE_PP & 1) && !(first && j < (g1 ? 1 : 2))) dma_b();
+        if (j >= 1 && j <= NPE) {
+          if (!(FO_ABLATE_PP & 1)) dma_a_piece(j - 1);    // extended tile g + 1, one piece per phase
+          if (j == NPE) a_next();
+        }
+        if (g1 && !(first && j <= 2)) {
+          // in flight at most: this phase's and the previous phase's pieces
+          if (j == 0) wait_vmcnt_n<2 * NPB>();
+          else if (j == 1) wait_vmcnt_n<2 * NPB + 1>();
+          else if (j <= NPE) wait_vmcnt_n<2 * NPB + 2>();
+          else if (j == NPE + 1) wait_vmcnt_n<2 * NPB + 1>();
+          else wait_vmcnt_n<2 * NPB>();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        PPH_STAMP(tA);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int jn = 0; jn < TN; ++jn)
+            if (!(FO_ABLATE_PP & 2) || (i == 0 && jn == 0)) acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[jn], fa[i], acc[i][jn], 0, 0, 0);      // rows = channels, columns = pixels
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        PPH_STAMP(tM);
+        if (!g1 && !(first && j <= 2)) {
+          if (j >= 1 && j <= NPE) wait_vmcnt_n<NPB + 1>();
+          else wait_vmcnt_n<NPB>();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef FO_STAMP_PPH
+        if (stamping) {
+          unsigned long long tE;
+          asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tE)::"memory");
+          sumR += tA - tS; sumM += tM - tA; sumW += tE - tM; ++nph;
+          if (first) sumF[j] += tE - tS;
+        }
+#endif
       }
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_setprio(1);
+    }
+    if (!g1) __builtin_amdgcn_s_barrier();                // G0 waits out G1's last segment
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the zero-fill DMAs of tiles past the end
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+
+    PPH_STAMP(tE0);
+    const int ctm = tile_m, ctn = tile_n;
+    // the ReLU-backward mask of the whole tile (bf16 outputs without FO_ADD: 2 TM fragments of 16 B per lane, the layout the stores below have):
+    // issued here, they fly beside the next tile's setup and prologue issue (2-6 thousand clocks) and are older than the prologue's DMAs
+    const bool patch_epi = !(flags & (FO_ADD | FO_OUT_F32));
+    bf16x8 mkA[TM][2] = {};
+    if (patch_epi && (flags & FO_MASK)) {
+      int ml = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+      asm volatile("" : "+v"(ml));
+      const __bf16* mp = reinterpret_cast<const __bf16*>(a.mask) + ((size_t)ctm * BMB + wm * TM * 16 + (ml >> 3)) * d.ldMask + ctn * BN + wn * WCOLS + (ml & 7) * 8;
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int jn = 0; jn < TN; ++jn)
-          if (!(FO_ABLATE_PP & 2) || (i == 0 && jn == 0)) acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[jn], acc[i][jn], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
-      if (!g1) {
-        if (j >= 1 && j <= NPE) wait_vmcnt_n<NPB + 1>();
-        else wait_vmcnt_n<NPB>();
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
+        for (int pp = 0; pp < 2; ++pp) mkA[i][pp] = *reinterpret_cast<const bf16x8*>(mp + (size_t)(i * 16 + pp * 8) * d.ldMask);
     }
-  }
-  if (!g1) __builtin_amdgcn_s_barrier();                  // G0 waits out G1's last segment
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the zero-fill DMAs of tiles past the end
-  __builtin_amdgcn_s_barrier();
-  __builtin_amdgcn_sched_barrier(0);
+    vb += gridDim.x;
+    const bool more = vb < ntiles;
+    if (more) {
+      setup(vb);
+      prologue();
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    PPH_STAMP(tE1);
 
-  // ---- epilogue: as conv_bf16_pp16_kernel
-  if (FO_ABLATE_PP & 16) {                                // diagnostic: no epilogue (one store per lane keeps the accumulators alive)
-    float t = 0.f;
+    // ---- epilogue.  A lane's accumulator is 4 consecutive channels of one pixel per 16 x 16 block (the filter is the MFMA's row operand).
+    // bf16 outputs without FO_ADD (every LPIPS layer, most of the VQ-VAE's): ReLU, ONE rounding, then a 16-pixel block row goes through the wave's
+    // own bf16 patch in LDS (4 ds_write_b64, 2 ds_read_b128 per lane; pitch 144 B: conflict-free writes) so that a store instruction writes whole
+    // 128-byte lines, 16 B per lane -- what the store path is priced by is lines per instruction: 8-byte stores straight from the accumulators
+    // (16 part-lines per instruction) took 17 thousand clocks per tile, an fp32 patch (four times the LDS traffic, a write -> read -> convert chain
+    // per block) 10-12 thousand (tools/stamp_pph.py).  The ReLU-backward mask is applied to the rounded values (a select: exact), its 16-byte
+    // fragments for block row i + 1 loaded before block row i is stored.  FO_ADD / fp32 outputs (a few VQ-VAE layers) store from the accumulators.
+    if (FO_ABLATE_PP & 16) {                              // diagnostic: no epilogue (one store per lane keeps the accumulators alive)
+      float t = 0.f;
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int j = 0; j < TN; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
-    if (t == 12345.678f) reinterpret_cast<float*>(a.out)[tid] = t;
-    return;
-  }
-  float* Cs = reinterpret_cast<float*>(lds) + wave * 32 * C_LD;
-  const int flags = d.flags;
-  constexpr int C8 = WCOLS / 8, RPP = 64 / C8;
-  const int c8 = lane % C8, r0 = lane / C8;
-  const int co = tile_n * BN + wn * WCOLS + c8 * 8;
-  float bv[8];
+        for (int j = 0; j < TN; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+      if (t == 12345.678f) reinterpret_cast<float*>(a.out)[tid] = t;
+    } else if (patch_epi) {
+      int el = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+      asm volatile("" : "+v"(el));
+      unsigned char* const P = lds + L::OFF_P + wave * 16 * L::PPITCH;
+      const int woff = (el & 15) * L::PPITCH + (el >> 4) * 8;               // + j * 32: pixel el & 15, channels j * 16 + 4 (el >> 4) ..
+      const int roff = (el >> 3) * L::PPITCH + (el & 7) * 16;               // + pp * 8 rows: pixel pp * 8 + (el >> 3), channels 8 (el & 7) ..
+      const int co = ctn * BN + wn * WCOLS + (el & 7) * 8;
+      const size_t mb = (size_t)ctm * BMB + wm * TM * 16 + (el >> 3);      // + i * 16 + pp * 8
+      __bf16* const outp = reinterpret_cast<__bf16*>(a.out);
 #pragma unroll
-  for (int e = 0; e < 8; ++e) bv[e] = ((flags & FO_BIAS) && co + e < d.Cout) ? a.bias[co + e] : 0.f;
-  const __bf16* mask = reinterpret_cast<const __bf16*>(a.mask);
-  const __bf16* addp = reinterpret_cast<const __bf16*>(a.add);
+      for (int i = 0; i < TM; ++i) {
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-  for (int i2 = 0; i2 < TM / 2; ++i2) {
-    __builtin_amdgcn_wave_barrier();
+        for (int j = 0; j < TN; ++j) {
+          f32x4 v = acc[i][j];
+          if (flags & FO_OUT_RELU) v = f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+          *reinterpret_cast<pph_bf16x4*>(P + woff + j * 32) = pph_bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+        }
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int ii = 0; ii < 2; ++ii)
+        for (int pp = 0; pp < 2; ++pp) {
+          bf16x8 o = *reinterpret_cast<const bf16x8*>(P + roff + pp * 8 * L::PPITCH);
+          if (flags & FO_MASK) {
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
+            for (int e = 0; e < 8; ++e) o[e] = (float)mkA[i][pp][e] > 0.f ? o[e] : (__bf16)0.f;
+          }
+          const size_t m = mb + i * 16 + pp * 8;
+          // (every row and column of a tile is real -- host: BMB | M, BN | Cout -- so this is exactly one store per lane: the count below depends on it)
+          if (!(FO_ABLATE_PP & 32)) *reinterpret_cast<bf16x8*>(outp + ((FO_ABLATE_PP & 64) ? (m & 511) : m) * d.ldOut + co) = o;
+        }
+      }
+    } else {
+      int el = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+      asm volatile("" : "+v"(el));
+      const int cb = ctn * BN + wn * WCOLS + (el >> 4) * 4;                 // + j * 16
+      const size_t mb = (size_t)ctm * BMB + wm * TM * 16 + (el & 15);      // + i * 16
+      const __bf16* mask = reinterpret_cast<const __bf16*>(a.mask);
+      const __bf16* addp = reinterpret_cast<const __bf16*>(a.add);
+      pph_bf16x4 mk[2][TN] = {}, ad[2][TN] = {};           // (initialised: undefined values would be carried around the tile loop in registers)
+      auto fetch = [&](int i, int buf) {
+        if (flags & FO_MASK) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Cs[(ii * 16 + quad * 4 + r) * C_LD + j * 16 + l15] = acc[i2 * 2 + ii][j][r];
-    __builtin_amdgcn_wave_barrier();
-    const int mbase = tile_m * BMB + wm * TM * 16 + i2 * 32;
-    bf16x8 mk[32 / RPP], ad[32 / RPP];
-    if (flags & FO_MASK) {
+          for (int j = 0; j < TN; ++j) mk[buf][j] = *reinterpret_cast<const pph_bf16x4*>(mask + (mb + i * 16) * d.ldMask + cb + j * 16);
+        }
+        if (flags & FO_ADD) {
 #pragma unroll
-      for (int pp = 0; pp < 32 / RPP; ++pp) {
-        const int m = mbase + pp * RPP + r0;
-        mk[pp] = *reinterpret_cast<const bf16x8*>(mask + (size_t)(m < a.M ? m : 0) * d.ldMask + co);
+          for (int j = 0; j < TN; ++j) ad[buf][j] = *reinterpret_cast<const pph_bf16x4*>(addp + (mb + i * 16) * d.ldAdd + cb + j * 16);
+        }
+      };
+      fetch(0, 0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        if (i + 1 < TM) fetch(i + 1, (i + 1) & 1);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const size_t m = mb + i * 16;
+          pph_emit4(a, flags, acc[i][j], mk[i & 1][j], ad[i & 1][j], (FO_ABLATE_PP & 64) ? (m & 511) : m, cb + j * 16, (FO_ABLATE_PP & 32) ? (flags & 0x4000) != 0 : true);
+        }
       }
     }
-    if (flags & FO_ADD) {
-#pragma unroll
-      for (int pp = 0; pp < 32 / RPP; ++pp) {
-        const int m = mbase + pp * RPP + r0;
-        ad[pp] = *reinterpret_cast<const bf16x8*>(addp + (size_t)(m < a.M ? m : 0) * d.ldAdd + co);
-      }
+    PPH_STAMP(tE2);
+    if (!more) break;
+    __builtin_amdgcn_sched_barrier(0);
+    // the next tile's prologue was issued before this tile's stores (2 TM per lane through the patch, TM TN from the accumulators) and its mask / add
+    // loads (as many each), and memory operations retire in order: once at most that many are outstanding the prologue has landed (vmcnt holds
+    // 6 bits: capped, which only waits for a few stores more)
+    if (patch_epi) {
+      wait_vmcnt_n<2 * TM>();                             // (the mask fragments were issued before the prologue)
+    } else {
+      constexpr int NST = TM * TN;
+      if ((flags & FO_MASK) && (flags & FO_ADD)) wait_vmcnt_n<(3 * NST < 63 ? 3 * NST : 63)>();
+      else if (flags & (FO_MASK | FO_ADD)) wait_vmcnt_n<(2 * NST < 63 ? 2 * NST : 63)>();
+      else wait_vmcnt_n<NST>();
     }
-#pragma unroll
-    for (int pp = 0; pp < 32 / RPP; ++pp) {
-      const int row = pp * RPP + r0;
-      const int m = mbase + row;
-      const float* crow = Cs + row * C_LD + c8 * 8;
-      const f32x4 v0 = *reinterpret_cast<const f32x4*>(crow);
-      const f32x4 v1 = *reinterpret_cast<const f32x4*>(crow + 4);
-      float v[8] = {v0.x + bv[0], v0.y + bv[1], v0.z + bv[2], v0.w + bv[3], v1.x + bv[4], v1.y + bv[5], v1.z + bv[6], v1.w + bv[7]};
-      emit8(a, flags, v, mk[pp], ad[pp], (FO_ABLATE_PP & 64) ? (size_t)(m & 511) : (size_t)(m < a.M ? m : 0), co,
-            (FO_ABLATE_PP & 32) ? (m < a.M && (flags & 0x4000)) : m < a.M);          // (diagnostics: bit 5 no stores, bit 6 every tile stores to the same 512 rows)
-    }
+#ifdef FO_STAMP_PPH
+    PPH_STAMP(tE3);
+    if (stamping) { sumSet += tE1 - tE0; sumEpi += tE2 - tE1; sumWt += tE3 - tE2; ++ntl; }
+#endif
   }
+#ifdef FO_STAMP_PPH
+  if (stamping && (threadIdx.x & 63) == 0) {
+    unsigned long long tK1, rK1;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(tK1), "=s"(rK1)::"memory");
+    unsigned long long* o = fo_pph_stamps + (wave >> 2) * 32;
+    o[0] = sumR; o[1] = sumM; o[2] = sumW; o[3] = nph; o[4] = tK1 - tK0; o[5] = rK1 - rK0;
+    o[6] = sumSet; o[7] = sumEpi; o[8] = sumWt; o[9] = ntl;
+    for (int q = 0; q < 9; ++q) o[10 + q] = sumF[q];
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ 64 input channels, 3x3: halo tiles
@@ -1576,15 +1751,18 @@ int launch_pp16(const ConvArgsH& a, hipStream_t s) {
 
 template <int BMB, int BN, int WAVES_M, int WAVES_N, int NPE>
 int launch_pph(const ConvArgsH& a, hipStream_t s) {
-  constexpr int ring = 2 * NPE * 128 * 64 + 4 * BN * 64 + 64;
-  constexpr int epi = 8 * 32 * (BN / WAVES_N + 4) * 4;
-  constexpr int ldsBytes = (ring > epi ? ring : epi) + 64;
-  static_assert(ldsBytes <= 160 * 1024, "LDS");
+  constexpr int ldsBytes = PphLds<BMB, BN, WAVES_M, WAVES_N, NPE>::BYTES;
   static fo_lds_once once;
   void (*kern)(const ConvArgsH) = conv_bf16_pph_kernel<BMB, BN, WAVES_M, WAVES_N, NPE>;
   if (!fo_lds_optin(once, reinterpret_cast<const void*>(kern), ldsBytes, "conv_bf16 (pph)")) return FO_E_HIP;
+  // one workgroup per tile; FACEOFF_BF16_PPH_PERSIST=1: one per CU walking tiles blockIdx.x, + grid, ... (a multiple of 8 workgroups: the XCD remap
+  // stays consistent) -- faster alone, slower beside the side streams (see the kernel)
+  const char* pe = getenv("FACEOFF_BF16_PPH_PERSIST");
+  const int ntiles = a.tilesM * a.tilesN;
+  const int cus = fo_cu_count() / 8 * 8;
+  const int grid = (pe && atoi(pe)) && cus >= 8 ? std::min(ntiles, cus) : ntiles;
   FO_NOTE_T("conv_bf16_pph_kernel", BMB, BN, WAVES_M, WAVES_N, NPE);
-  hipLaunchKernelGGL(kern, dim3(a.tilesM * a.tilesN), dim3(512), ldsBytes, s, a);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), ldsBytes, s, a);
   FO_CHECK_LAUNCH();
   return FO_OK;
 }
@@ -1596,7 +1774,7 @@ static int pph_pieces(const fo_conv_desc* d, const ConvArgsH& a) {
   if (off && atoi(off)) return 0;
   if (d->KH != 3 || d->KW != 3 || d->padH != 1 || d->padW != 1 || (d->KD != 1 && (d->KD != 3 || d->padD != 1)) || (d->KD == 1 && d->padD != 0)) return 0;
   const int W = d->Wm;
-  if (W % 16 != 0 || BMB % W != 0 || a.HWm % BMB != 0 || a.M % BMB != 0) return 0;
+  if (W % 16 != 0 || BMB % W != 0 || a.HWm % BMB != 0 || a.M % BMB != 0 || d->Cout > 1024) return 0;      // (1024: the bias patch in LDS)
   return (BMB + 2 * W + 127) / 128;
 }
 
@@ -1652,6 +1830,12 @@ __global__ void pack_conv_dgrad_bf16_kernel(const float* __restrict__ w, __bf16*
 inline int grid_for(size_t total) { return (int)std::min<size_t>((total + 255) / 256, 8192); }
 
 }  // namespace
+
+#ifdef FO_STAMP_PPH
+extern "C" int fo_debug_read_pph_stamps(unsigned long long* out, int n) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(fo_pph_stamps), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" {
 

@@ -398,3 +398,49 @@ def test_extended_tile_kernel_vs_torch_and_vs_the_per_tap_kernel(N, H, W, cin, c
     for a_, b_ in zip(outs["pph"], outs["pp16"]):
         diff = (a_ - b_).abs()
         assert (diff > 0).float().mean().item() < 2e-2 and bool((diff <= b_.abs() * 2.0 ** -7 + 1e-3 * b_.abs().max()).all())
+
+
+@pytest.mark.parametrize("N,H,W,cin,cout,T,tile512", [
+    (20, 64, 64, 128, 256, 1, False),     # 320 tiles of 256 x 256 on 256 workgroups: some walk two tiles, some one
+    (36, 64, 64, 128, 128, 3, True),      # 288 tiles of 512 x 128, clips of 3: the tiles of a clip's first / last frame have fewer K groups
+])
+def test_extended_tile_kernel_persistent_grid_equals_one_workgroup_per_tile(N, H, W, cin, cout, T, tile512, monkeypatch):
+    """FACEOFF_BF16_PPH_PERSIST=1: one workgroup per CU walks several tiles, the next tile's first operands in flight while this tile is stored.
+    Same arithmetic as one workgroup per tile, so the results must be BIT-equal -- in every form of the epilogue: bf16 through the LDS patch
+    (forward; masked data gradient) and from the accumulators (fan-in add; fp32 output)."""
+    from faceoff_amd import ops, _lib
+    if tile512:
+        monkeypatch.setenv("FACEOFF_BF16_TILE512", "1")
+    g = gen(N + W + cin)
+    kd = 3 if T > 1 else 1
+    x = (torch.randn((N, H, W, cin), generator=g) * 0.5).to(BF).cuda()
+    w = torch.randn((cout, cin, kd * 9), generator=g) / np.sqrt(9 * kd * cin)
+    wp = packed_bf16(ops.pack_conv(w.cuda()))
+    b = torch.randn(cout, generator=g).cuda()
+    mask = torch.randn((N, H, W, cout), generator=g).to(BF).cuda()
+    add = torch.randn((N, H, W, cout), generator=g).to(BF).cuda()
+    lib = _lib.load()
+    kw = dict(T=T, k=(kd, 3, 3), pad=(kd // 2, 1, 1), cin=cin, cout=cout)
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("FACEOFF_BF16_PPH_PERSIST", mode)
+        outs = [torch.empty((N, H, W, cout), device="cuda", dtype=BF) for _ in range(3)] + [torch.empty((N, H, W, cout), device="cuda", dtype=torch.float32)]
+        lib.fo_kernel_notes(1); lib.fo_last_kernel()
+        ops.conv_bf16g(x, wp, b, outs[0], flags=ops.FO_OUT_RELU, **kw)
+        kern = lib.fo_last_kernel().decode(); lib.fo_kernel_notes(0)
+        assert kern.startswith("conv_bf16_pph_kernel<"), kern
+        ops.conv_bf16g(x, wp, None, outs[1], mask=mask, **kw)
+        ops.conv_bf16g(x, wp, None, outs[2], mask=mask, add=add, **kw)
+        ops.conv_bf16g(x, wp, b, outs[3], **kw)
+        torch.cuda.synchronize()
+        res[mode] = outs
+    for a_, b_ in zip(res["0"], res["1"]):
+        assert torch.equal(a_, b_)
+    # and the values themselves: against the per-tap kernel
+    monkeypatch.setenv("FACEOFF_BF16_NO_PPH", "1")
+    ref = torch.empty((N, H, W, cout), device="cuda", dtype=BF)
+    ops.conv_bf16g(x, wp, None, ref, mask=mask, add=add, **kw)
+    torch.cuda.synchronize()
+    diff = (res["1"][2].float() - ref.float()).abs()
+    assert (diff > 0).float().mean().item() < 2e-2 and bool((diff <= ref.float().abs() * 2.0 ** -7 + 1e-3 * ref.float().abs().max()).all())
+
