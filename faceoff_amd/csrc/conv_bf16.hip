@@ -1396,22 +1396,46 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16_kernel(const HaloArgs
   // position l % 4).  A lane's share of the source address is ONE constant register (pixel and swizzled chunk), the rest is scalar.
   const int dpix = lane >> 2, dpos = lane & 3;
   const unsigned dlane = (unsigned)(dpix * a.ldIn * 2 + ((dpos ^ swz(dpix)) * 16));
-  auto dma_tile = [&](int tile, int stage) {
+  // A workgroup walks a contiguous run of tiles DOWN the columns of 32 pixels (tile = (n, tx, ty), ty fastest): tile s + 1's patch rows 0, 1 are
+  // tile s's rows 4, 5 -- copied LDS -> LDS while tile s computes (12 KB, three 16-byte moves per thread) instead of fetched again.  Only the
+  // four new rows are DMA'd: 24 instructions per tile instead of 36, and 1.07 x the input read from memory instead of 1.59 x (every patch row
+  // fetched per tile; a column walk WITHOUT the copy measured 1.44 x: an XCD's L2 turns over in 1.5 tile times).  The first tile of a run and of
+  // a column fetch all six rows.
+  auto tile_of = [&](int tile, int& n, int& ty, int& tx) {
+    ty = tile % a.tilesY;
+    const int r1 = tile / a.tilesY;
+    tx = r1 % a.tilesX;
+    n = r1 / a.tilesX;
+  };
+  auto dma_tile = [&](int tile, int stage, bool reuse) {
     if (FO_ABLATE_H & 8) return;
     const bool live = tile < a.ntiles;
-    const int tx = tile % a.tilesX, r1 = tile / a.tilesX;
-    const int ty = r1 % a.tilesY, n = r1 / a.tilesY;
+    int n, ty, tx;
+    tile_of(tile, n, ty, tx);
     const int y0 = ty * 4 - 1, x0 = tx * 32;               // (x0: patch column 0 is image column x0 - 1 = descriptor pixel x0)
-#pragma unroll
-    for (int k = 0; k < 9; ++k) {
-      const int id = wave + 4 * k;                         // 0 .. 35
-      const int pl = id / 18, rem = id - pl * 18, r = rem / 3, g = rem - r * 3;
+    auto piece = [&](int pl, int r, int g) {
       const int iy = y0 + r;
       const bool rowok = live & ((unsigned)iy < (unsigned)a.H);
       const int ix = x0 - 1 + g * 16 + dpix;               // image column of this lane's pixel
-      const bool ok = rowok & ((unsigned)ix < (unsigned)a.W);
+      // (the third 16-pixel group holds the patch's last two columns: its other 14 lanes fetch nothing -- they used to read 48 pixels per row for 34)
+      const bool ok = rowok & ((unsigned)ix < (unsigned)a.W) & (g * 16 + dpix < 34);
       const unsigned soff = rowok ? (unsigned)((((size_t)n * a.H + iy) * a.W + x0 + g * 16) * a.ldIn * 2) + pl * 64 : 0u;
       dma16s(rin, lds3 + stage * STAGE + pl * PLANE + (r * PITCH + g * 16) * 64, ok ? dlane : OOB, soff);
+    };
+    if (reuse) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const int id = wave + 4 * k;                       // 0 .. 23: (plane, patch row 2 .. 5, 16-pixel group)
+        const int pl = id / 12, rem = id - pl * 12, r = rem / 3;
+        piece(pl, 2 + r, rem - r * 3);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        const int id = wave + 4 * k;                       // 0 .. 35
+        const int pl = id / 18, rem = id - pl * 18, r = rem / 3;
+        piece(pl, r, rem - r * 3);
+      }
     }
   };
 
@@ -1427,13 +1451,31 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16_kernel(const HaloArgs
 #pragma unroll
     for (int r = 0; r < 4; ++r) bv[j][r] = (a.flags & FO_BIAS) ? a.bias[half * 64 + wn * 32 + j * 16 + quad * 4 + r] : 0.f;
 
-  int tile = wgInHalf;
-  dma_tile(tile, 0);
+  const int per = (a.ntiles + wgsPerHalf - 1) / wgsPerHalf;
+  const int tile_end = min(a.ntiles, (wgInHalf + 1) * per);
+  int tile = wgInHalf * per;
+  if (tile >= tile_end) return;
+  dma_tile(tile, 0, false);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  for (int it = 0; tile < a.ntiles; tile += wgsPerHalf, ++it) {
+  for (int it = 0; tile < tile_end; ++tile, ++it) {
     const int st = it & 1;
-    dma_tile(tile + wgsPerHalf, st ^ 1);                   // next tile's patch: lands during this tile's MFMAs
+    const bool more = tile + 1 < tile_end;
+    const bool reuse = more && (tile + 1) % a.tilesY != 0;  // the next tile is the one below this one
+    if (more) dma_tile(tile + 1, st ^ 1, reuse);          // next tile's patch: lands during this tile's MFMAs
+    if (reuse) {                                           // its rows 0, 1 = this patch's rows 4, 5, both planes (whole 48-pixel rows: same layout, same swizzle)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) {
+        u32x4 t3[2];
+        const int nq = 2 * PITCH * 64 / 16;               // 384 sixteen-byte pieces per plane
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+          if (tid + q * 256 < nq) t3[q] = *reinterpret_cast<const u32x4*>(lds + st * STAGE + pl * PLANE + 4 * PITCH * 64 + (tid + q * 256) * 16);
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+          if (tid + q * 256 < nq) *reinterpret_cast<u32x4*>(lds + (st ^ 1) * STAGE + pl * PLANE + (tid + q * 256) * 16) = t3[q];
+      }
+    }
     f32x4 acc[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -1457,8 +1499,8 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16_kernel(const HaloArgs
       __builtin_amdgcn_sched_barrier(0);
     }
     // ---- epilogue: acc[i][j][r] = channel 16 j + 4 quad + r of pixel (row 2 wm + (i >> 1), column 16 (i & 1) + l15)
-    const int tx = tile % a.tilesX, r1 = tile / a.tilesX;
-    const int ty = r1 % a.tilesY, n = r1 / a.tilesY;
+    int n, ty, tx;
+    tile_of(tile, n, ty, tx);
     typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
     // (max-pool 2x2 riding along: a wave's two tile rows are one pooled row; the vertical partner of a pixel is the same lane's other
     // accumulator, the horizontal one the neighbouring lane.  max commutes with the monotonic bias + ReLU + rounding, so the pooled tensor is
@@ -1505,8 +1547,8 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16_kernel(const HaloArgs
     }
     // the next patch has landed: vmcnt retires in order and the 8 youngest operations are this tile's stores, which may keep flying
     // (nothing reads them; the LDS stage they came from is not involved)
-    if (a.pooled) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      // (+ 4 pooled stores)
-    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if (a.pooled) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");      // (+ 4 pooled stores; lgkmcnt: the row copy's LDS writes)
+    else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   }
 }
