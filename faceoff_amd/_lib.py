@@ -124,6 +124,7 @@ SIGNATURES = {
     "fo_pack_conv_dgrad_bf16": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "fo_conv_igemm_bf16": (_I, [_D, _P, _P, _P, _P, _P, _P]),
     "fo_conv_igemm_bf16_pool": (_I, [_D, _P, _P, _P, _P, _P, _I, _P]),
+    "fo_conv_igemm_bf16_pool_idx": (_I, [_D, _P, _P, _P, _P, _P, _I, _P, _P]),
     "fo_conv_bf16": (_I, [_D, _P, _P, _P, _P, _P, _P, _P]),
     "fo_wgrad_bf16_ws_bytes": (_L, [_D]),
     "fo_conv_wgrad_bf16": (_I, [_D, _P, _P, _P, _I, _I, _P, _P, _L, _P]),
@@ -138,6 +139,8 @@ SIGNATURES = {
     "fo_lpips_prep_bwd_bf16": (_I, [_P, _P, _I, _L, _P, _P, _F, _P]),
     "fo_maxpool2_fwd_bf16": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "fo_maxpool2_bwd_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "fo_maxpool2_fwd_idx_bf16": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "fo_maxpool2_bwd_idx_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "fo_lpips_tap_ws_bytes_bf16": (_L, [_I, _I, _I, _I]),
     "fo_lpips_tap_fwd_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "fo_lpips_tap_bwd_bf16": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),

@@ -1363,6 +1363,7 @@ struct HaloArgs {
   const __bf16* mask;
   __bf16* out;
   __bf16* pooled;           // optional: the 2x2 max-pool of `out` ([N][H/2][W/2][ldPooled]) written from the same accumulators
+  unsigned char* pidx;      // optional, with pooled: its arg-max codes, 2 bits per channel ([N][H/2][W/2][Cout/4] bytes: fo_maxpool2_fwd_idx_bf16)
   int N, H, W, Cout, halves, tilesX, tilesY, ntiles;
   int ldIn, ldOut, ldMask, ldPooled, flags;
   unsigned inBytes;
@@ -1506,6 +1507,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16_kernel(const HaloArgs
     // accumulator, the horizontal one the neighbouring lane.  max commutes with the monotonic bias + ReLU + rounding, so the pooled tensor is
     // bit for bit the pool of the stored one.)
     float pm[2][2][4];
+    unsigned rowbit[2][2] = {{0u, 0u}, {0u, 0u}};            // bit r: the lower pixel of the column is strictly larger (ties: the upper one, first in scan order)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const size_t pix = ((size_t)n * a.H + ty * 4 + 2 * wm + (i >> 1)) * a.W + tx * 32 + (i & 1) * 16 + l15;
@@ -1526,7 +1528,10 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16_kernel(const HaloArgs
         if (!(FO_ABLATE_H & 32)) *reinterpret_cast<bf16x4*>(a.out + pix * a.ldOut + co) = o;
         if (a.pooled) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) pm[i & 1][j][r] = (i >> 1) ? fmaxf(pm[i & 1][j][r], (float)o[r]) : (float)o[r];
+          for (int r = 0; r < 4; ++r) {
+            if (i >> 1) rowbit[i & 1][j] |= ((float)o[r] > pm[i & 1][j][r] ? 1u : 0u) << r;
+            pm[i & 1][j][r] = (i >> 1) ? fmaxf(pm[i & 1][j][r], (float)o[r]) : (float)o[r];
+          }
         }
       }
       __builtin_amdgcn_sched_barrier(0);                  // (one pixel block's mask loads and addresses at a time: the filter holds the registers)
@@ -1540,6 +1545,17 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16_kernel(const HaloArgs
           float m[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) m[r] = fmaxf(pm[e][j][r], __shfl_xor(pm[e][j][r], 1));
+          if (a.pidx) {                                    // even lane = left column: the first maximum in scan order (0,0) (0,1) (1,0) (1,1)
+            const unsigned rbR = (unsigned)__shfl_xor((int)rowbit[e][j], 1);
+            unsigned code = 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float vL = pm[e][j][r], vR = __shfl_xor(pm[e][j][r], 1);
+              const unsigned iL = ((rowbit[e][j] >> r) & 1u) * 2u, iR = ((rbR >> r) & 1u) * 2u + 1u;
+              code |= (vL > vR ? iL : vR > vL ? iR : min(iL, iR)) << (2 * r);
+            }
+            if (!(l15 & 1)) a.pidx[ppix * (a.Cout / 4) + (half * 64 + wn * 32 + j * 16 + quad * 4) / 4] = (unsigned char)code;
+          }
           if (!(l15 & 1))
             *reinterpret_cast<bf16x4*>(a.pooled + ppix * a.ldPooled + half * 64 + wn * 32 + j * 16 + quad * 4) = bf16x4{(__bf16)m[0], (__bf16)m[1], (__bf16)m[2], (__bf16)m[3]};
         }
@@ -1547,7 +1563,8 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16_kernel(const HaloArgs
     }
     // the next patch has landed: vmcnt retires in order and the 8 youngest operations are this tile's stores, which may keep flying
     // (nothing reads them; the LDS stage they came from is not involved)
-    if (a.pooled) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");      // (+ 4 pooled stores; lgkmcnt: the row copy's LDS writes)
+    if (a.pidx) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");        // (+ 4 pooled stores + 4 code bytes; lgkmcnt: the row copy's LDS writes)
+    else if (a.pooled) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   }
@@ -1758,10 +1775,10 @@ __global__ __launch_bounds__(256, 2) void vgg_conv1_fused_bf16_kernel(const Vgg1
   }
 }
 
-static int launch_halo64(const ConvArgsH& c, hipStream_t s, void* pooled = nullptr, int ldPooled = 0) {
+static int launch_halo64(const ConvArgsH& c, hipStream_t s, void* pooled = nullptr, int ldPooled = 0, void* pidx = nullptr) {
   const fo_conv_desc& d = c.d;
   HaloArgs a;
-  a.pooled = reinterpret_cast<__bf16*>(pooled); a.ldPooled = ldPooled;
+  a.pooled = reinterpret_cast<__bf16*>(pooled); a.ldPooled = ldPooled; a.pidx = pooled ? reinterpret_cast<unsigned char*>(pidx) : nullptr;
   a.in = reinterpret_cast<const __bf16*>(c.in); a.wp = reinterpret_cast<const __bf16*>(c.wp); a.bias = c.bias;
   a.mask = reinterpret_cast<const __bf16*>(c.mask); a.out = reinterpret_cast<__bf16*>(c.out);
   a.N = d.N; a.H = d.Hin; a.W = d.Win; a.Cout = d.Cout; a.halves = d.Cout / 64;
@@ -1898,7 +1915,7 @@ int fo_pack_conv_dgrad_bf16(const float* w, void* wp, int O, int I, int taps, in
 }
 
 static int conv_bf16_impl(const fo_conv_desc* d, const void* in, const void* wp, const float* bias, const void* mask, const void* add,
-                          void* out, void* stream, void* pooled = nullptr, int ldPooled = 0) {
+                          void* out, void* stream, void* pooled = nullptr, int ldPooled = 0, void* pidx = nullptr) {
   ConvArgsH a;
   a.d = *d;
   a.in = in; a.wp = wp; a.bias = bias; a.mask = mask; a.add = add; a.out = out;
@@ -1986,7 +2003,7 @@ static int conv_bf16_impl(const fo_conv_desc* d, const void* in, const void* wp,
         d->Hin == d->Hm && d->Win == d->Wm && d->Hm == d->Hout && d->Wm == d->Wout && d->Hin % 4 == 0 && d->Win % 32 == 0 &&
         !(flags & ~(FO_BIAS | FO_MASK | FO_OUT_RELU)) && d->ldOut % 4 == 0 && (!(flags & FO_MASK) || d->ldMask % 4 == 0) &&
         (tiles >= 8LL * fo_cu_count() || (fhalo && atoi(fhalo))) && !(nohalo && atoi(nohalo)))
-      return launch_halo64(a, s, pooled, ldPooled);
+      return launch_halo64(a, s, pooled, ldPooled, pidx);
   }
   FO_REQUIRE(!pooled, FO_E_SHAPE, "conv_bf16: the pooled second output exists for the 64-input-channel halo-tile kernel only (3x3, whole 4 x 32 tiles, >= 8 tiles per CU)");
   // big tiles (one workgroup per CU) where the launch still fills the chip for a few rounds: stride-1 same-size convs.
@@ -2108,5 +2125,15 @@ int fo_conv_igemm_bf16_pool(const fo_conv_desc* d, const void* in, const void* w
   fo_conv_desc e = *d;
   e.T = 1;
   return conv_bf16_impl(&e, in, wp, bias, nullptr, nullptr, out, stream, pooled, ldPooled);
+}
+
+int fo_conv_igemm_bf16_pool_idx(const fo_conv_desc* d, const void* in, const void* wp, const float* bias, void* out, void* pooled, int ldPooled,
+                                void* idx, void* stream) {
+  FO_REQUIRE(d->KD == 1 && d->padD == 0 && !(d->flags & ~(FO_BIAS | FO_OUT_RELU)), FO_E_SHAPE, "conv_igemm_bf16_pool: 2-D, flags BIAS|OUT_RELU only");
+  FO_REQUIRE(pooled && fo_aligned16(pooled) && ldPooled % 4 == 0 && ldPooled >= d->Cout && d->Hout % 2 == 0 && d->Wout % 2 == 0, FO_E_SHAPE,
+             "conv_igemm_bf16_pool: pooled output [N][H/2][W/2][ldPooled >= Cout]");
+  fo_conv_desc e = *d;
+  e.T = 1;
+  return conv_bf16_impl(&e, in, wp, bias, nullptr, nullptr, out, stream, pooled, ldPooled, idx);
 }
 }

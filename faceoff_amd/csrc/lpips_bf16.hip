@@ -67,6 +67,69 @@ __global__ void maxpool2_fwd_bf16_kernel(const bf16x8* __restrict__ x, bf16x8* _
   }
 }
 
+// y = max over the 2x2 window, idx = WHICH of its four pixels (scan order (0,0) (0,1) (1,0) (1,1); the FIRST maximum, as torch's backward) in 2 bits
+// per channel: 8 channels per lane = one uint16, [N][Ho][Wo][C/8] (= bytes [..][C/4], channel c in byte c / 4, bits 2 (c % 4)).  The backward
+// then reads 1/16 of the input's bytes instead of the input (round 4: the pool backwards were 1.43 ms of config 3, all of it HBM time).
+__global__ void maxpool2_fwd_idx_bf16_kernel(const bf16x8* __restrict__ x, bf16x8* __restrict__ y, unsigned short* __restrict__ idx, int N, int Ho, int Wo,
+                                             int C8) {
+  const long long total = (long long)N * Ho * Wo * C8;
+  const int W = Wo * 2;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(e % C8);
+    long long q = e / C8;
+    const int xo = (int)(q % Wo); q /= Wo;
+    const int yo = (int)(q % Ho);
+    const long long n = q / Ho;
+    const bf16x8* base = x + ((n * (2 * Ho) + 2 * yo) * W + 2 * xo) * C8 + c;
+    const bf16x8 a = base[0], b = base[C8], cc = base[(long long)W * C8], d = base[(long long)W * C8 + C8];
+    bf16x8 m;
+    unsigned code = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float fa = (float)a[k], fb = (float)b[k], fc = (float)cc[k], fd = (float)d[k];
+      const float mx = fmaxf(fmaxf(fa, fb), fmaxf(fc, fd));
+      m[k] = (__bf16)mx;
+      code |= (fa == mx ? 0u : fb == mx ? 1u : fc == mx ? 2u : 3u) << (2 * k);
+    }
+    y[e] = m;
+    idx[e] = (unsigned short)code;
+  }
+}
+
+// gx[t] = [t is the window's recorded maximum] * gy + add[t], rounded once.  The ReLU masks are already in: `add` (a tap's head gradient) is zero where
+// the input is, and gy was masked by the POOLED tensor in the data gradient that made it (max <= 0 <=> every input of the window is 0).
+__global__ void maxpool2_bwd_idx_bf16_kernel(const unsigned short* __restrict__ idx, const bf16x8* __restrict__ gy, const bf16x8* __restrict__ add,
+                                             bf16x8* __restrict__ gx, int N, int Ho, int Wo, int C8) {
+  const long long total = (long long)N * Ho * Wo * C8;
+  const int W = Wo * 2;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(e % C8);
+    long long q = e / C8;
+    const int xo = (int)(q % Wo); q /= Wo;
+    const int yo = (int)(q % Ho);
+    const long long n = q / Ho;
+    const long long i00 = ((n * (2 * Ho) + 2 * yo) * W + 2 * xo) * C8 + c;
+    const long long at[4] = {i00, i00 + C8, i00 + (long long)W * C8, i00 + (long long)W * C8 + C8};
+    const unsigned code = idx[e];
+    const bf16x8 g = gy[e];
+    bf16x8 ad[4];
+    if (add) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) ad[t] = add[at[t]];
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      bf16x8 r;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float s = ((code >> (2 * k)) & 3u) == (unsigned)t ? (float)g[k] : 0.f;
+        r[k] = (__bf16)(add ? s + (float)ad[t][k] : s);
+      }
+      gx[at[t]] = r;
+    }
+  }
+}
+
 // gx = relu'(x) * ( [x is the FIRST maximum of its window] * gy + add ), rounded once
 __global__ void maxpool2_bwd_bf16_kernel(const bf16x8* __restrict__ x, const bf16x8* __restrict__ gy, const bf16x8* __restrict__ add,
                                          bf16x8* __restrict__ gx, int N, int Ho, int Wo, int C8) {
@@ -347,6 +410,24 @@ int fo_maxpool2_fwd_bf16(const void* x, void* y, int N, int H, int W, int C, voi
   FO_REQUIRE(H % 2 == 0 && W % 2 == 0 && C % 8 == 0, FO_E_SHAPE, "maxpool2_bf16: even H, W and C %% 8 == 0");
   hipLaunchKernelGGL(maxpool2_fwd_bf16_kernel, dim3(grid_for((long long)N * (H / 2) * (W / 2) * (C / 8), 8192)), dim3(256), 0,
                      (hipStream_t)stream, reinterpret_cast<const bf16x8*>(x), reinterpret_cast<bf16x8*>(y), N, H / 2, W / 2, C / 8);
+  FO_CHECK_LAUNCH();
+  return FO_OK;
+}
+
+int fo_maxpool2_fwd_idx_bf16(const void* x, void* y, void* idx, int N, int H, int W, int C, void* stream) {
+  FO_REQUIRE(H % 2 == 0 && W % 2 == 0 && C % 8 == 0, FO_E_SHAPE, "maxpool2_bf16: even H, W and C %% 8 == 0");
+  hipLaunchKernelGGL(maxpool2_fwd_idx_bf16_kernel, dim3(grid_for((long long)N * (H / 2) * (W / 2) * (C / 8), 8192)), dim3(256), 0,
+                     (hipStream_t)stream, reinterpret_cast<const bf16x8*>(x), reinterpret_cast<bf16x8*>(y), reinterpret_cast<unsigned short*>(idx), N, H / 2,
+                     W / 2, C / 8);
+  FO_CHECK_LAUNCH();
+  return FO_OK;
+}
+
+int fo_maxpool2_bwd_idx_bf16(const void* idx, const void* gy, const void* add, void* gx, int N, int H, int W, int C, void* stream) {
+  FO_REQUIRE(H % 2 == 0 && W % 2 == 0 && C % 8 == 0, FO_E_SHAPE, "maxpool2_bf16: even H, W and C %% 8 == 0");
+  hipLaunchKernelGGL(maxpool2_bwd_idx_bf16_kernel, dim3(grid_for((long long)N * (H / 2) * (W / 2) * (C / 8), 8192)), dim3(256), 0,
+                     (hipStream_t)stream, reinterpret_cast<const unsigned short*>(idx), reinterpret_cast<const bf16x8*>(gy),
+                     reinterpret_cast<const bf16x8*>(add), reinterpret_cast<bf16x8*>(gx), N, H / 2, W / 2, C / 8);
   FO_CHECK_LAUNCH();
   return FO_OK;
 }

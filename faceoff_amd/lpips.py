@@ -87,6 +87,9 @@ class LPIPSEngine:
         # 1.19-1.43 ms against 1.40 ms for the two launches without the relu1_1 output, 1.6-1.7 ms with it (tools/probes/vgg1_kernel_time.py)
         self.fuse_conv1 = bool(_os.environ.get("FACEOFF_VGG_FUSE"))
         self.force_fuse_conv1 = _os.environ.get("FACEOFF_BF16_FORCE_HALO", "0") not in ("", "0")     # tests: at any size
+        # the pools of the reconstruction branch record their arg-max (2 bits per element) and the pool backwards read that instead of the full-size
+        # input: FACEOFF_LPIPS_POOL_IDX=0 switches it off (A/B, tests)
+        self.pool_idx = _os.environ.get("FACEOFF_LPIPS_POOL_IDX", "1") != "0"
 
     # ------------------------------------------------------------------ pieces
     def _prep(self, src, nhwc):
@@ -102,29 +105,35 @@ class LPIPSEngine:
                   self.shift, self.scale, ops._stream())
         return y
 
-    def _conv(self, i, x, pooled=None):
+    def _conv(self, i, x, pooled=None, pool_idx=None):
         _, ci, co, _ = self.convs[i]
         N, H, W, _ = x.shape
         y = torch.empty((N, H, W, co), device=self.device, dtype=self.act_dtype)
         if self.bf16:
-            ops.conv_bf16(x, self.wp[i], self.b[i], y, cin=8 if i == 0 else ci, cout=co, flags=ops.FO_OUT_RELU, pooled=pooled)
+            ops.conv_bf16(x, self.wp[i], self.b[i], y, cin=8 if i == 0 else ci, cout=co, flags=ops.FO_OUT_RELU, pooled=pooled, pool_idx=pool_idx)
         elif i == 0:
             ops.conv_igemm(x, self.wp[0], self.b[0], y, k=(1, 3, 4), pad=(0, 1, 1), cin=8, cout=co, flags=ops.FO_OUT_RELU)
         else:
             ops.conv_igemm(x, self.wp[i], self.b[i], y, k=(1, 3, 3), pad=(0, 1, 1), cin=ci, cout=co, flags=ops.FO_OUT_RELU)
         return y
 
-    def _pool(self, x):
+    def _pool(self, x, want_idx=False):
+        """MaxPool2d(2); with want_idx (bf16 branch) also its arg-max codes, 2 bits per element (the backward then needs no look at x)."""
         N, H, W, Cc = x.shape
         y = torch.empty((N, H // 2, W // 2, Cc), device=self.device, dtype=self.act_dtype)
+        if want_idx and self.bf16:
+            idx = torch.empty((N, H // 2, W // 2, Cc // 4), device=self.device, dtype=torch.uint8)
+            _lib.call("fo_maxpool2_fwd_idx_bf16", ops._ptr(x), ops._ptr(y), ops._ptr(idx), N, H, W, Cc, ops._stream())
+            return y, idx
         _lib.call("fo_maxpool2_fwd_bf16" if self.bf16 else "fo_maxpool2_fwd", ops._ptr(x), ops._ptr(y), N, H, W, Cc, ops._stream())
-        return y
+        return y, None
 
     def features(self, x8, keep_all):
-        """vgg16.forward (lpips.py:139-152).  Returns (taps[5], acts) where acts[i] = ReLU output of conv i and
-        acts['p<i>'] = pooled input of conv i (only when keep_all)."""
+        """vgg16.forward (lpips.py:139-152).  Returns (taps[5], acts) where acts[i] = ReLU output of conv i,
+        acts['p<i>'] = pooled input of conv i and acts['c<i>'] = that pool's arg-max codes or None (only when keep_all)."""
         taps, acts, x = [], {}, x8
-        nxt = None                                       # the pooled input of the next conv, when the previous launch already wrote it
+        use_idx = self.bf16 and keep_all and self.pool_idx
+        nxt = nxt_idx = None                             # the pooled input of the next conv (and its codes), when the previous launch already wrote it
         skip = 0
         if self.bf16 and self.fuse_conv1:
             # conv1_1 + conv1_2 (+ the pool in front of conv2_1) in ONE launch where frames are whole 4 x 32 tiles and the launch fills the chip:
@@ -144,16 +153,18 @@ class LPIPSEngine:
             if i < skip:
                 continue
             if pool:
-                x = nxt if nxt is not None else self._pool(x)
+                x, cidx = (nxt, nxt_idx) if nxt is not None else self._pool(x, use_idx)
                 if keep_all:
-                    acts[f"p{i}"] = x
-            nxt = None
+                    acts[f"p{i}"], acts[f"c{i}"] = x, cidx
+            nxt = nxt_idx = None
             N, H, W, _ = x.shape
             # the max-pool in front of the NEXT conv rides along in this launch where the halo-tile kernel takes it (conv1_2): the pool's own
             # pass would read the full-resolution tap again
             if (self.bf16 and i + 1 < len(self.convs) and self.convs[i + 1][3] and i > 0 and ops.conv_bf16_pool_ok(N, H, W, ci, co)):
                 nxt = torch.empty((N, H // 2, W // 2, co), device=self.device, dtype=self.act_dtype)
-            x = self._conv(i, x, pooled=nxt)
+                if use_idx:
+                    nxt_idx = torch.empty((N, H // 2, W // 2, co // 4), device=self.device, dtype=torch.uint8)
+            x = self._conv(i, x, pooled=nxt, pool_idx=nxt_idx)
             if keep_all:
                 acts[i] = x
             if i in TAP_CONVS:
@@ -270,17 +281,23 @@ class LPIPSEngine:
                 self._dgrad(g, 0, gin, co, 3, None)
                 g = gin
                 break
-            if pool:                                     # conv i reads the pooled tensor: no ReLU mask on its dgrad
+            if pool:                                     # conv i reads the pooled tensor
                 gp = torch.empty_like(acts[f"p{i}"])
-                self._dgrad(g, i, gp, co, ci, None)
+                cidx = acts.get(f"c{i}")
+                # with the pool's arg-max codes the pool backward never looks at its input: the one ReLU mask it applied to the pooled-through
+                # gradient (max > 0) moves into this data gradient's epilogue as mask = the pooled tensor, a quarter of the input's size
+                self._dgrad(g, i, gp, co, ci, acts[f"p{i}"] if cidx is not None else None)
                 x = acts[i - 1]                          # pre-pool tensor = ReLU output of conv i-1 = a LPIPS tap
                 tap = TAP_CONVS.index(i - 1)
                 gx = torch.empty_like(x)
                 n, h, w, c = x.shape
                 if head_ready[tap] is not None:
                     torch.cuda.current_stream(self.device).wait_event(head_ready[tap])
-                _lib.call("fo_maxpool2_bwd_bf16" if self.bf16 else "fo_maxpool2_bwd", ops._ptr(x), ops._ptr(gp), ops._ptr(head[tap]), ops._ptr(gx), n, h, w, c,
-                          ops._stream())
+                if cidx is not None:                     # (head[tap] is zero wherever x is: lpips_head_*_bf16 apply the tap's own ReLU mask)
+                    _lib.call("fo_maxpool2_bwd_idx_bf16", ops._ptr(cidx), ops._ptr(gp), ops._ptr(head[tap]), ops._ptr(gx), n, h, w, c, ops._stream())
+                else:
+                    _lib.call("fo_maxpool2_bwd_bf16" if self.bf16 else "fo_maxpool2_bwd", ops._ptr(x), ops._ptr(gp), ops._ptr(head[tap]), ops._ptr(gx), n, h, w, c,
+                              ops._stream())
                 g = gx
             else:
                 gin = torch.empty_like(acts[i - 1])

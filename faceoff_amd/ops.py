@@ -616,9 +616,9 @@ def conv_bf16_pool_ok(N, H, W, cin, cout):
     return cin == 64 and cout % 64 == 0 and H % 4 == 0 and W % 32 == 0 and (tiles >= 8 * _lib.cu_count() or forced)
 
 
-def conv_bf16(x, wp, bias, out, *, k=(3, 3), stride=1, pad=(1, 1), cin=None, cout=None, flags=0, mask=None, pooled=None):
+def conv_bf16(x, wp, bias, out, *, k=(3, 3), stride=1, pad=(1, 1), cin=None, cout=None, flags=0, mask=None, pooled=None, pool_idx=None):
     """One fo_conv_igemm_bf16 launch.  x/out/mask: bf16 channels-last views; bias fp32.  pooled (optional, only where conv_bf16_pool_ok):
-    receives the 2x2 max-pool of the result from the same launch."""
+    receives the 2x2 max-pool of the result from the same launch, pool_idx (uint8 [N, H/2, W/2, Cout/4]) its arg-max codes."""
     N, Hin, Win, _ = x.shape
     _, Hout, Wout, _ = out.shape
     bf = torch.bfloat16
@@ -639,7 +639,11 @@ def conv_bf16(x, wp, bias, out, *, k=(3, 3), stride=1, pad=(1, 1), cin=None, cou
         prof.begin(kname, flops)
     if pooled is not None:
         assert mask is None
-        _lib.call("fo_conv_igemm_bf16_pool", C.byref(d), _ptr(x), _ptr(wp), _ptr(bias), _ptr(out), _ptr(pooled), ld_of(pooled, bf), _stream())
+        if pool_idx is not None:
+            _lib.call("fo_conv_igemm_bf16_pool_idx", C.byref(d), _ptr(x), _ptr(wp), _ptr(bias), _ptr(out), _ptr(pooled), ld_of(pooled, bf), _ptr(pool_idx),
+                      _stream())
+        else:
+            _lib.call("fo_conv_igemm_bf16_pool", C.byref(d), _ptr(x), _ptr(wp), _ptr(bias), _ptr(out), _ptr(pooled), ld_of(pooled, bf), _stream())
     else:
         _lib.call("fo_conv_igemm_bf16", C.byref(d), _ptr(x), _ptr(wp), _ptr(bias), _ptr(mask), _ptr(out), _stream())
     if prof is not None:

@@ -421,6 +421,9 @@ int fo_conv_igemm_bf16(const fo_conv_desc* d, const void* in, const void* wp, co
  * 64-input-channel halo-tile kernel applies (3x3, frames of whole 4 x 32 tiles, >= 8 tiles per CU): FO_E_SHAPE otherwise -- pool separately. */
 int fo_conv_igemm_bf16_pool(const fo_conv_desc* d, const void* in, const void* wp, const float* bias, void* out, void* pooled, int ldPooled,
                             void* stream);
+/* ... and the pool's arg-max codes (fo_maxpool2_fwd_idx_bf16's idx, [N][Hout/2][Wout/2][Cout/4] bytes; NULL: none). */
+int fo_conv_igemm_bf16_pool_idx(const fo_conv_desc* d, const void* in, const void* wp, const float* bias, void* out, void* pooled, int ldPooled,
+                                void* idx, void* stream);
 /* ---------------------------------------------------------------- bf16-operand VQ-VAE step (BASELINE config 3 as SURVEY 8(d) defines it)
  * The VQ-VAE's own convolutions with bf16 MFMA operands, fp32 accumulation, fp32 master weights and fp32 VQ: activations and
  * activation gradients are STORED as bf16 (rounded once, after bias / ReLU mask / residual or fan-in add / ReLU were applied in
@@ -469,6 +472,13 @@ int fo_lpips_prep_bwd_bf16(const void* g /* [npix][8] */, float* gdec, int ldd, 
                            const float* gscale, float weight, void* stream);
 int fo_maxpool2_fwd_bf16(const void* x, void* y, int N, int H, int W, int C, void* stream);
 int fo_maxpool2_bwd_bf16(const void* x, const void* gy, const void* add, void* gx, int N, int H, int W, int C, void* stream);
+/* The same pool with its arg-max recorded (reference nn.MaxPool2d keeps indices for its backward, models/lpips.py:118-134 via torchvision): idx holds
+ * 2 bits per element of y -- which pixel of the 2x2 window, scan order, the FIRST maximum -- as bytes [N][H/2][W/2][C/4] (channel c in byte c / 4,
+ * bits 2 (c % 4) and up).  fo_maxpool2_bwd_idx_bf16: gx[t] = [t is the recorded pixel] * gy + add[t] (add may be NULL), rounded once; NO ReLU mask is
+ * applied here: add must be zero where x is (the tap heads' gradients are) and gy masked by y > 0 (fo_conv_igemm_bf16 with mask = y).  It reads 1/16 of
+ * x's bytes where fo_maxpool2_bwd_bf16 reads x. */
+int fo_maxpool2_fwd_idx_bf16(const void* x, void* y, void* idx, int N, int H, int W, int C, void* stream);
+int fo_maxpool2_bwd_idx_bf16(const void* idx, const void* gy, const void* add, void* gx, int N, int H, int W, int C, void* stream);
 /* ws: fo_lpips_tap_ws_bytes_bf16(N, H, W, C) of scratch (both head entry points): every wave leaves its per-frame sums in its own slots and a
  * finish launch adds a frame's slots in wave order -- val[] is reproducible bit for bit (it met in float atomics before round 4). */
 int64_t fo_lpips_tap_ws_bytes_bf16(int N, int H, int W, int C);

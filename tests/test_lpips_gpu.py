@@ -443,3 +443,77 @@ def test_vgg_conv1_fused_equals_the_two_layers(N, H, W, monkeypatch):
     for k, (u, v) in enumerate(zip(ta, tb)):
         du = (u.float() - v.float()).abs()
         assert bool((du <= v.float().abs() * 2.0 ** -6 + 4e-3 * v.float().abs().max()).all()), k
+
+
+def _first_max_codes(x):
+    """[N, H, W, C] float -> [N, H/2, W/2, C] int: index of the FIRST maximum of each 2x2 window in scan order (0,0) (0,1) (1,0) (1,1)."""
+    w = torch.stack([x[:, 0::2, 0::2], x[:, 0::2, 1::2], x[:, 1::2, 0::2], x[:, 1::2, 1::2]], dim=-1)
+    m = w.max(dim=-1, keepdim=True).values
+    return (w == m).float().argmax(dim=-1)               # (argmax of a 0/1 tensor returns the first 1)
+
+
+def _unpack_codes(idx, C):
+    b = idx.long()                                       # [N, Ho, Wo, C/4] bytes, channel c in byte c / 4, bits 2 (c % 4)
+    return torch.stack([(b >> (2 * k)) & 3 for k in range(4)], dim=-1).reshape(*idx.shape[:3], C)
+
+
+def test_pool_argmax_codes_and_the_backward_that_reads_them(monkeypatch):
+    """fo_maxpool2_fwd_idx_bf16 / fo_maxpool2_bwd_idx_bf16 and the codes fo_conv_igemm_bf16_pool_idx writes from the conv's accumulators:
+    y as the plain pool; codes = the first maximum in scan order, on data FULL of ties (ReLU zeros, few distinct values); the backward bit for
+    bit fo_maxpool2_bwd_bf16 when it is handed what LPIPSEngine hands it (gy masked by y > 0, add zero where x is)."""
+    from faceoff_amd import _lib, ops
+    bf = torch.bfloat16
+    g = torch.Generator().manual_seed(11)
+    N, H, W, C = 3, 12, 20, 64
+    x = torch.relu(torch.randint(-3, 4, (N, H, W, C), generator=g).float() * 0.5).to(bf).cuda()       # 4 distinct positive values and many zeros
+    y0 = torch.empty((N, H // 2, W // 2, C), device="cuda", dtype=bf)
+    _lib.call("fo_maxpool2_fwd_bf16", ops._ptr(x), ops._ptr(y0), N, H, W, C, ops._stream())
+    y1 = torch.empty_like(y0)
+    idx = torch.empty((N, H // 2, W // 2, C // 4), device="cuda", dtype=torch.uint8)
+    _lib.call("fo_maxpool2_fwd_idx_bf16", ops._ptr(x), ops._ptr(y1), ops._ptr(idx), N, H, W, C, ops._stream())
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1)
+    assert torch.equal(_unpack_codes(idx, C), _first_max_codes(x.float()))
+    gy = torch.randn((N, H // 2, W // 2, C), generator=g).to(bf).cuda()
+    add = (torch.randn((N, H, W, C), generator=g).cuda() * (x.float() > 0)).to(bf)
+    want = torch.empty_like(x)
+    _lib.call("fo_maxpool2_bwd_bf16", ops._ptr(x), ops._ptr(gy), ops._ptr(add), ops._ptr(want), N, H, W, C, ops._stream())
+    gym = (gy.float() * (y0.float() > 0)).to(bf)
+    got = torch.empty_like(x)
+    _lib.call("fo_maxpool2_bwd_idx_bf16", ops._ptr(idx), ops._ptr(gym), ops._ptr(add), ops._ptr(got), N, H, W, C, ops._stream())
+    torch.cuda.synchronize()
+    assert torch.equal(want, got)
+    # the codes the 64-channel halo-tile kernel writes beside its pooled output
+    monkeypatch.setenv("FACEOFF_BF16_FORCE_HALO", "1")
+    N, H, W = 2, 16, 64
+    xin = torch.randint(-2, 3, (N, H, W, 64), generator=g).to(bf).cuda()
+    w = (torch.randint(-1, 2, (64, 64, 3, 3), generator=g).float() * 0.25).cuda()                   # small integers: exact products, many equal outputs
+    b = torch.zeros(64).cuda()
+    wp = ops.pack_conv_bf16(w)
+    y = torch.empty((N, H, W, 64), device="cuda", dtype=bf)
+    p = torch.empty((N, H // 2, W // 2, 64), device="cuda", dtype=bf)
+    pidx = torch.empty((N, H // 2, W // 2, 16), device="cuda", dtype=torch.uint8)
+    ops.conv_bf16(xin, wp, b, y, cin=64, cout=64, flags=ops.FO_OUT_RELU, pooled=p, pool_idx=pidx)
+    torch.cuda.synchronize()
+    assert (y == 0).float().mean().item() > 0.2 and torch.equal(_unpack_codes(pidx, 64), _first_max_codes(y.float()))
+
+
+def test_lpips_gradient_does_not_change_with_the_pool_codes(monkeypatch):
+    """The reconstruction branch with arg-max codes (pool backwards read 2 bits per element, the pooled-through ReLU mask moves into the data
+    gradient in front) against the same branch with the pool backwards reading their full-size inputs: the gradient is the same to the bit."""
+    from faceoff_amd.lpips import LPIPSEngine
+    monkeypatch.setenv("FACEOFF_BF16_FORCE_HALO", "1")   # conv1_2 on the halo-tile kernel with the pool (and its codes) riding along
+    rng = np.random.default_rng(4)
+    tgt = torch.from_numpy(rng.uniform(-1, 1, (2, 3, 32, 64)).astype(np.float32)).cuda()
+    dec = torch.zeros((2, 32, 64, 8), device="cuda")
+    dec[..., :3] = tgt.permute(0, 2, 3, 1) + 0.3 * torch.from_numpy(rng.standard_normal((2, 32, 64, 3)).astype(np.float32)).cuda()
+    out = {}
+    for on in (True, False):
+        eng = LPIPSEngine(make_vgg_lpips_state(5), "cuda:0", dtype="bf16")
+        eng.pool_idx = on
+        gd = torch.zeros_like(dec)
+        loss = eng.loss_and_grad(tgt, dec, gd)
+        _, acts = eng.features(eng._prep(dec, nhwc=True), keep_all=True)
+        assert all((acts[f"c{i}"] is not None) == on for i in (2, 4, 7, 10))
+        out[on] = (loss.item(), gd)
+    assert out[True][0] == out[False][0] and torch.equal(out[True][1], out[False][1])
