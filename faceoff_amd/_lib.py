@@ -47,6 +47,15 @@ _L = C.c_int64
 _F = C.c_float
 _D = C.POINTER(ConvDesc)
 
+
+class ConvExtra(C.Structure):
+    """Mirror of `fo_conv_extra` (include/faceoff_hip.h): the optional outputs / bit-plane mask of fo_conv_bf16_ex."""
+    _fields_ = [("pooled", C.c_void_p), ("ldPooled", C.c_int32), ("pool_idx", C.c_void_p), ("mask_bits", C.c_void_p), ("out_bits", C.c_void_p),
+                ("pooled_bits", C.c_void_p)]
+
+
+_X = C.POINTER(ConvExtra)
+
 # name -> (restype, argtypes); must list every symbol include/faceoff_hip.h declares
 SIGNATURES = {
     "fo_version": (_I, []),
@@ -126,6 +135,7 @@ SIGNATURES = {
     "fo_conv_igemm_bf16_pool": (_I, [_D, _P, _P, _P, _P, _P, _I, _P]),
     "fo_conv_igemm_bf16_pool_idx": (_I, [_D, _P, _P, _P, _P, _P, _I, _P, _P]),
     "fo_conv_bf16": (_I, [_D, _P, _P, _P, _P, _P, _P, _P]),
+    "fo_conv_bf16_ex": (_I, [_D, _P, _P, _P, _P, _P, _P, _X, _P]),
     "fo_wgrad_bf16_ws_bytes": (_L, [_D]),
     "fo_conv_wgrad_bf16": (_I, [_D, _P, _P, _P, _I, _I, _P, _P, _L, _P]),
     "fo_bias_grad_bf16_ws_bytes": (_L, [_I]),
@@ -139,7 +149,7 @@ SIGNATURES = {
     "fo_lpips_prep_bwd_bf16": (_I, [_P, _P, _I, _L, _P, _P, _F, _P]),
     "fo_maxpool2_fwd_bf16": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "fo_maxpool2_bwd_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
-    "fo_maxpool2_fwd_idx_bf16": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "fo_maxpool2_fwd_idx_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "fo_maxpool2_bwd_idx_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "fo_lpips_tap_ws_bytes_bf16": (_L, [_I, _I, _I, _I]),
     "fo_lpips_tap_fwd_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),

@@ -34,6 +34,11 @@ struct ConvArgsH {
   const void* mask;
   const void* add;
   void* out;
+  // ReLU masks as bit planes (fo_conv_bf16_ex): [pixel][ldBits = Cout / 8] bytes, bit c % 8 of byte c / 8 = (value > 0).  maskBits replaces the FO_MASK
+  // read of the bf16 tensor `mask` (1/16 of its bytes); outBits receives the plane of this launch's bf16 result.
+  const unsigned char* maskBits;
+  unsigned char* outBits;
+  int ldBits;
   int M, HWm, tilesM, tilesN;
   int cinChunks;   // K chunks per tap: Cin/64 (128-row kernels), Cin/32 (256-row kernels); SMALLC: unused
   int Ktot;        // elements per filter row (multiple of 64; 256-row kernels: of 32)
@@ -106,6 +111,33 @@ __device__ __forceinline__ u32x4 bufload16(__amdgpu_buffer_rsrc_t r, unsigned of
   return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
 }
 
+// bit e = (o[e] > 0) of eight packed bf16 (bit patterns 0x0001 .. 0x7fff)
+__device__ __forceinline__ unsigned pos_bits8(const bf16x8& o) {
+  const u32x4 w = __builtin_bit_cast(u32x4, o);
+  unsigned b = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    b |= ((((w[q] & 0xffffu) - 1u) < 0x7fffu) ? 1u : 0u) << (2 * q);
+    b |= ((((w[q] >> 16) - 1u) < 0x7fffu) ? 1u : 0u) << (2 * q + 1);
+  }
+  return b;
+}
+__device__ __forceinline__ unsigned pos_bits4(float v0, float v1, float v2, float v3) {
+  return (v0 > 0.f ? 1u : 0u) | (v1 > 0.f ? 2u : 0u) | (v2 > 0.f ? 4u : 0u) | (v3 > 0.f ? 8u : 0u);
+}
+// 1.0 where the bit is set, 0 elsewhere: what the epilogues' (mask > 0) tests read
+__device__ __forceinline__ bf16x8 bits_to_mask8(unsigned b) {
+  u32x4 w;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) w[q] = (((b >> (2 * q)) & 1u) ? 0x3f80u : 0u) | (((b >> (2 * q + 1)) & 1u) ? 0x3f800000u : 0u);
+  return __builtin_bit_cast(bf16x8, w);
+}
+// the FO_MASK fragment of 8 channels co .. co + 7 (co % 8 == 0) of output pixel opix: from the bf16 tensor or from its bit plane
+__device__ __forceinline__ bf16x8 load_mask8(const ConvArgsH& a, size_t opix, int co) {
+  if (a.maskBits) return bits_to_mask8(a.maskBits[opix * a.ldBits + (co >> 3)]);
+  return *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(a.mask) + opix * a.d.ldMask + co);
+}
+
 // One output row's 8 consecutive channels: v = fp32 accumulators + bias -> ReLU-backward mask -> + add (residual / gradient fan-in)
 // -> ReLU -> ONE rounding to bf16 (or kept fp32: FO_OUT_F32, the quantisers' inputs and the decoder output)
 __device__ __forceinline__ void emit8(const ConvArgsH& a, int flags, float (&v)[8], const bf16x8& mk, const bf16x8& ad, size_t opix, int co, bool ok) {
@@ -131,6 +163,7 @@ __device__ __forceinline__ void emit8(const ConvArgsH& a, int flags, float (&v)[
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e];
     *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(a.out) + opix * a.d.ldOut + co) = o;
+    if (a.outBits) a.outBits[opix * a.ldBits + (co >> 3)] = (unsigned char)pos_bits8(o);
   }
 }
 
@@ -191,7 +224,7 @@ __device__ __forceinline__ void store_c_tile(const ConvArgsH& a, const float* Cs
     bf16x8 mk[R], ad[R];
     if (flags & FO_MASK) {
 #pragma unroll
-      for (int r = 0; r < R; ++r) mk[r] = *reinterpret_cast<const bf16x8*>(mask + opix[r] * d.ldMask + co);
+      for (int r = 0; r < R; ++r) mk[r] = load_mask8(a, opix[r], co);
     }
     if (flags & FO_ADD) {
 #pragma unroll
@@ -515,6 +548,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_dma_kernel(const ConvArgsH a
 // channels of ONE pixel: bias + ReLU + bf16 pack per lane, a wave-local 4.5 KB LDS patch turns that into 16-byte stores of
 // whole 128-byte pixel lines.  0.92 -> 0.44 ms.  (The same trick does NOT carry to the layer's 64 -> 3 data gradient: there a
 // pixel is 128 B, adjacent lanes of a fragment load are 128 B apart, and the L1 serves one line per lane: 1.28 vs 1.18 ms tiled.)
+template <bool BITS>      // BITS: also the bit plane of the result (a.outBits): one byte per lane and store, through its own descriptor (no branch in the loop)
 __global__ __launch_bounds__(256) void conv_rgb_bf16_kernel(const ConvArgsH a, int nblocks) {
   constexpr int PITCH = 128 + 16;                         // patch row: one pixel's 64 bf16 + pad
   __shared__ __attribute__((aligned(16))) unsigned char patch_all[4][32 * PITCH];
@@ -567,6 +601,7 @@ __global__ __launch_bounds__(256) void conv_rgb_bf16_kernel(const ConvArgsH a, i
   // No data-dependent branch in the loop (hipcc otherwise drains every outstanding load, vmcnt(0), in front of each store): blocks
   // past the end load zeros through out-of-range offsets (load_block's pv) and their stores are dropped the same way.
   const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (unsigned)(((size_t)(a.M - 1) * d.ldOut + 64) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rbits = __builtin_amdgcn_make_buffer_rsrc(BITS ? a.outBits : nullptr, 0, BITS ? (unsigned)((size_t)a.M * 8) : 0u, 0x00020000);
   const float lo = relu ? 0.f : -__builtin_inff();
   bf16x8 xa[5], xb[5];
   load_block(gw, xa);
@@ -608,6 +643,7 @@ __global__ __launch_bounds__(256) void conv_rgb_bf16_kernel(const ConvArgsH a, i
         const u32x4 v = *reinterpret_cast<const u32x4*>(patch + pix * PITCH + piece * 16);
         const long long m = (long long)cur * 32 + pix;
         __builtin_amdgcn_raw_buffer_store_b128(v, rout, m < a.M ? (unsigned)((m * d.ldOut + piece * 8) * 2) : OOB, 0, 0);
+        if (BITS) __builtin_amdgcn_raw_buffer_store_b8((unsigned char)pos_bits8(__builtin_bit_cast(bf16x8, v)), rbits, m < a.M ? (unsigned)(m * 8 + piece) : OOB, 0, 0);
       }
     }
   }
@@ -890,7 +926,7 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_pp16_kernel(const ConvArgsH 
 #pragma unroll
       for (int pp = 0; pp < 32 / RPP; ++pp) {
         const int m = mbase + pp * RPP + r0;
-        mk[pp] = *reinterpret_cast<const bf16x8*>(mask + (size_t)(m < a.M ? m : 0) * d.ldMask + co);
+        mk[pp] = load_mask8(a, (size_t)(m < a.M ? m : 0), co);
       }
     }
     if (flags & FO_ADD) {
@@ -1222,11 +1258,25 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_pph_kernel(const ConvArgsH a
     if (patch_epi && (flags & FO_MASK)) {
       int ml = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
       asm volatile("" : "+v"(ml));
-      const __bf16* mp = reinterpret_cast<const __bf16*>(a.mask) + ((size_t)ctm * BMB + wm * TM * 16 + (ml >> 3)) * d.ldMask + ctn * BN + wn * WCOLS + (ml & 7) * 8;
+      const size_t mp0 = (size_t)ctm * BMB + wm * TM * 16 + (ml >> 3);
+      const int mco = ctn * BN + wn * WCOLS + (ml & 7) * 8;
+      if (a.maskBits) {                                    // bit plane: one byte per fragment (all loads first, then the expansions)
+        unsigned mb8[TM][2];
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int pp = 0; pp < 2; ++pp) mkA[i][pp] = *reinterpret_cast<const bf16x8*>(mp + (size_t)(i * 16 + pp * 8) * d.ldMask);
+          for (int pp = 0; pp < 2; ++pp) mb8[i][pp] = a.maskBits[(mp0 + i * 16 + pp * 8) * a.ldBits + (mco >> 3)];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int pp = 0; pp < 2; ++pp) mkA[i][pp] = bits_to_mask8(mb8[i][pp]);
+      } else {
+        const __bf16* mp = reinterpret_cast<const __bf16*>(a.mask) + mp0 * d.ldMask + mco;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int pp = 0; pp < 2; ++pp) mkA[i][pp] = *reinterpret_cast<const bf16x8*>(mp + (size_t)(i * 16 + pp * 8) * d.ldMask);
+      }
     }
     vb += gridDim.x;
     const bool more = vb < ntiles;
@@ -1280,6 +1330,7 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_pph_kernel(const ConvArgsH a
           const size_t m = mb + i * 16 + pp * 8;
           // (every row and column of a tile is real -- host: BMB | M, BN | Cout -- so this is exactly one store per lane: the count below depends on it)
           if (!(FO_ABLATE_PP & 32)) *reinterpret_cast<bf16x8*>(outp + ((FO_ABLATE_PP & 64) ? (m & 511) : m) * d.ldOut + co) = o;
+          if (a.outBits) a.outBits[m * a.ldBits + (co >> 3)] = (unsigned char)pos_bits8(o);          // (+ one byte store per lane: counted below)
         }
       }
     } else {
@@ -1293,7 +1344,14 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_pph_kernel(const ConvArgsH a
       auto fetch = [&](int i, int buf) {
         if (flags & FO_MASK) {
 #pragma unroll
-          for (int j = 0; j < TN; ++j) mk[buf][j] = *reinterpret_cast<const pph_bf16x4*>(mask + (mb + i * 16) * d.ldMask + cb + j * 16);
+          for (int j = 0; j < TN; ++j) {
+            if (a.maskBits) {
+              const unsigned nb = (a.maskBits[(mb + i * 16) * a.ldBits + ((cb + j * 16) >> 3)] >> (((cb >> 2) & 1) * 4)) & 15u;
+              mk[buf][j] = pph_bf16x4{(__bf16)(float)(nb & 1u), (__bf16)(float)((nb >> 1) & 1u), (__bf16)(float)((nb >> 2) & 1u), (__bf16)(float)((nb >> 3) & 1u)};
+            } else {
+              mk[buf][j] = *reinterpret_cast<const pph_bf16x4*>(mask + (mb + i * 16) * d.ldMask + cb + j * 16);
+            }
+          }
         }
         if (flags & FO_ADD) {
 #pragma unroll
@@ -1318,7 +1376,8 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_pph_kernel(const ConvArgsH a
     // loads (as many each), and memory operations retire in order: once at most that many are outstanding the prologue has landed (vmcnt holds
     // 6 bits: capped, which only waits for a few stores more)
     if (patch_epi) {
-      wait_vmcnt_n<2 * TM>();                             // (the mask fragments were issued before the prologue)
+      if (a.outBits) wait_vmcnt_n<4 * TM>();              // (+ the bit plane's byte stores)
+      else wait_vmcnt_n<2 * TM>();                        // (the mask fragments were issued before the prologue)
     } else {
       constexpr int NST = TM * TN;
       if ((flags & FO_MASK) && (flags & FO_ADD)) wait_vmcnt_n<(3 * NST < 63 ? 3 * NST : 63)>();
@@ -1364,11 +1423,17 @@ struct HaloArgs {
   __bf16* out;
   __bf16* pooled;           // optional: the 2x2 max-pool of `out` ([N][H/2][W/2][ldPooled]) written from the same accumulators
   unsigned char* pidx;      // optional, with pooled: its arg-max codes, 2 bits per channel ([N][H/2][W/2][Cout/4] bytes: fo_maxpool2_fwd_idx_bf16)
+  const unsigned char* maskBits;   // optional: the FO_MASK tensor as a bit plane [pixel][Cout/8] (ConvArgsH)
+  unsigned char* outBits;          // optional: the plane of `out`
+  unsigned char* pooledBits;       // optional, with pooled: the plane of the pooled output [N][H/2][W/2][Cout/8]
   int N, H, W, Cout, halves, tilesX, tilesY, ntiles;
   int ldIn, ldOut, ldMask, ldPooled, flags;
   unsigned inBytes;
 };
 
+// MASKT / MASKB: FO_MASK from the bf16 tensor / from its bit plane; POOL: the pooled output (its codes and plane where given); OBITS: the result's plane.
+// (compile-time: with all of it behind run-time tests the kernel spills -- 144 registers hold the filter)
+template <bool MASKT, bool MASKB, bool POOL, bool OBITS>
 __global__ __launch_bounds__(256, 2) void conv_halo64_bf16_kernel(const HaloArgs a) {
   constexpr int PITCH = 48, ROWS = 6, PLANE = ROWS * PITCH * 64, STAGE = 2 * PLANE;     // bytes
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -1477,6 +1542,19 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16_kernel(const HaloArgs
           if (tid + q * 256 < nq) *reinterpret_cast<u32x4*>(lds + (st ^ 1) * STAGE + pl * PLANE + (tid + q * 256) * 16) = t3[q];
       }
     }
+    // the tile's ReLU mask from its bit plane: one dword per pixel block holds the nibbles of both channel blocks; loaded HERE, the four loads land
+    // under the MFMAs (as 8-byte fragments of the bf16 tensor, fetched block by block in the epilogue, the mask made conv1_2's data gradient
+    // 1.26 ms against 0.90 for the forward)
+    unsigned mw[4] = {0u, 0u, 0u, 0u};
+    if (MASKB) {
+      int n_, ty_, tx_;
+      tile_of(tile, n_, ty_, tx_);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const size_t pix = ((size_t)n_ * a.H + ty_ * 4 + 2 * wm + (i >> 1)) * a.W + tx_ * 32 + (i & 1) * 16 + l15;
+        mw[i] = *reinterpret_cast<const unsigned*>(a.maskBits + pix * (a.Cout / 8) + half * 8 + wn * 4);
+      }
+    }
     f32x4 acc[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -1515,10 +1593,16 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16_kernel(const HaloArgs
       for (int j = 0; j < 2; ++j) {
         const int co = half * 64 + wn * 32 + j * 16 + quad * 4;
         float v[4] = {acc[i][j][0] + bv[j][0], acc[i][j][1] + bv[j][1], acc[i][j][2] + bv[j][2], acc[i][j][3] + bv[j][3]};
-        if (a.flags & FO_MASK) {
-          const bf16x4 mk = *reinterpret_cast<const bf16x4*>(a.mask + pix * a.ldMask + co);
+        if (MASKT || MASKB) {
+          if (MASKB) {                                // the lane's 4 channels are one nibble: byte j * 2 + quad / 2 of the block's dword
+            const unsigned nb = mw[i] >> (j * 16 + (quad >> 1) * 8 + (quad & 1) * 4);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = (float)mk[r] > 0.f ? v[r] : 0.f;
+            for (int r = 0; r < 4; ++r) v[r] = ((nb >> r) & 1u) ? v[r] : 0.f;
+          } else {
+            const bf16x4 mk = *reinterpret_cast<const bf16x4*>(a.mask + pix * a.ldMask + co);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = (float)mk[r] > 0.f ? v[r] : 0.f;
+          }
         }
         if (a.flags & FO_OUT_RELU) {
 #pragma unroll
@@ -1526,7 +1610,12 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16_kernel(const HaloArgs
         }
         const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
         if (!(FO_ABLATE_H & 32)) *reinterpret_cast<bf16x4*>(a.out + pix * a.ldOut + co) = o;
-        if (a.pooled) {
+        if (OBITS) {                                       // quads 2q, 2q + 1 hold the two nibbles of a byte
+          const unsigned nb = pos_bits4((float)o[0], (float)o[1], (float)o[2], (float)o[3]);
+          const unsigned other = (unsigned)__shfl_xor((int)nb, 16);
+          if (!(quad & 1)) a.outBits[pix * (a.Cout / 8) + (co >> 3)] = (unsigned char)(nb | (other << 4));
+        }
+        if (POOL) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             if (i >> 1) rowbit[i & 1][j] |= ((float)o[r] > pm[i & 1][j][r] ? 1u : 0u) << r;
@@ -1536,7 +1625,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16_kernel(const HaloArgs
       }
       __builtin_amdgcn_sched_barrier(0);                  // (one pixel block's mask loads and addresses at a time: the filter holds the registers)
     }
-    if (a.pooled) {
+    if (POOL) {
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
         const size_t ppix = ((size_t)n * (a.H / 2) + ty * 2 + wm) * (a.W / 2) + tx * 16 + e * 8 + (l15 >> 1);
@@ -1556,6 +1645,11 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16_kernel(const HaloArgs
             }
             if (!(l15 & 1)) a.pidx[ppix * (a.Cout / 4) + (half * 64 + wn * 32 + j * 16 + quad * 4) / 4] = (unsigned char)code;
           }
+          if (a.pooledBits) {
+            const unsigned nb = pos_bits4((float)(__bf16)m[0], (float)(__bf16)m[1], (float)(__bf16)m[2], (float)(__bf16)m[3]);
+            const unsigned other = (unsigned)__shfl_xor((int)nb, 16);
+            if (!(l15 & 1) && !(quad & 1)) a.pooledBits[ppix * (a.Cout / 8) + ((half * 64 + wn * 32 + j * 16 + quad * 4) >> 3)] = (unsigned char)(nb | (other << 4));
+          }
           if (!(l15 & 1))
             *reinterpret_cast<bf16x4*>(a.pooled + ppix * a.ldPooled + half * 64 + wn * 32 + j * 16 + quad * 4) = bf16x4{(__bf16)m[0], (__bf16)m[1], (__bf16)m[2], (__bf16)m[3]};
         }
@@ -1563,9 +1657,16 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16_kernel(const HaloArgs
     }
     // the next patch has landed: vmcnt retires in order and the 8 youngest operations are this tile's stores, which may keep flying
     // (nothing reads them; the LDS stage they came from is not involved)
-    if (a.pidx) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");        // (+ 4 pooled stores + 4 code bytes; lgkmcnt: the row copy's LDS writes)
-    else if (a.pooled) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    // (8 result stores per lane; + 8 bit-plane bytes; + 4 pooled stores, + 4 code bytes, + 4 pooled-plane bytes.  A count that is too SMALL only
+    // waits for a few of the stores as well; lgkmcnt: the row copy's LDS writes)
+    {
+      const int nst = 8 + (OBITS ? 8 : 0) + (POOL ? 4 : 0) + (POOL && a.pidx ? 4 : 0) + (POOL && a.pooledBits ? 4 : 0);
+      if (nst >= 28) asm volatile("s_waitcnt vmcnt(28) lgkmcnt(0)" ::: "memory");
+      else if (nst >= 20) asm volatile("s_waitcnt vmcnt(20) lgkmcnt(0)" ::: "memory");
+      else if (nst >= 16) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+      else if (nst >= 12) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
   }
 }
@@ -1775,23 +1876,36 @@ __global__ __launch_bounds__(256, 2) void vgg_conv1_fused_bf16_kernel(const Vgg1
   }
 }
 
-static int launch_halo64(const ConvArgsH& c, hipStream_t s, void* pooled = nullptr, int ldPooled = 0, void* pidx = nullptr) {
+static int launch_halo64(const ConvArgsH& c, hipStream_t s, void* pooled = nullptr, int ldPooled = 0, void* pidx = nullptr, void* pooledBits = nullptr) {
   const fo_conv_desc& d = c.d;
   HaloArgs a;
   a.pooled = reinterpret_cast<__bf16*>(pooled); a.ldPooled = ldPooled; a.pidx = pooled ? reinterpret_cast<unsigned char*>(pidx) : nullptr;
+  a.maskBits = c.maskBits; a.outBits = c.outBits; a.pooledBits = pooled ? reinterpret_cast<unsigned char*>(pooledBits) : nullptr;
   a.in = reinterpret_cast<const __bf16*>(c.in); a.wp = reinterpret_cast<const __bf16*>(c.wp); a.bias = c.bias;
   a.mask = reinterpret_cast<const __bf16*>(c.mask); a.out = reinterpret_cast<__bf16*>(c.out);
   a.N = d.N; a.H = d.Hin; a.W = d.Win; a.Cout = d.Cout; a.halves = d.Cout / 64;
   a.tilesX = d.Win / 32; a.tilesY = d.Hin / 4; a.ntiles = d.N * a.tilesX * a.tilesY;
   a.ldIn = d.ldIn; a.ldOut = d.ldOut; a.ldMask = d.ldMask; a.flags = d.flags; a.inBytes = c.inBytes;
   constexpr int ldsBytes = 2 * 2 * 6 * 48 * 64;            // two stages of two planes
-  static fo_lds_once once;
-  if (!fo_lds_optin(once, reinterpret_cast<const void*>(conv_halo64_bf16_kernel), ldsBytes, "conv_bf16 (halo64)")) return FO_E_HIP;
+  const bool maskt = (d.flags & FO_MASK) && !a.maskBits, maskb = (d.flags & FO_MASK) && a.maskBits;
+  FO_REQUIRE(!(a.pooled && ((d.flags & FO_MASK) || a.outBits)), FO_E_SHAPE, "conv_bf16 (halo64): pooled output with a mask or out_bits is not built");
   const int cus = fo_cu_count();
   int grid = std::min(2 * cus / a.halves * a.halves, a.ntiles * a.halves);          // two workgroups per CU
   grid = std::max(a.halves, grid / a.halves * a.halves);
-  FO_NOTE("conv_halo64_bf16_kernel");
-  hipLaunchKernelGGL(conv_halo64_bf16_kernel, dim3(grid), dim3(256), ldsBytes, s, a);
+#define FO_HALO64(MT, MB, PL, OB)                                                                                                            \
+  do {                                                                                                                                       \
+    static fo_lds_once once;                                                                                                                 \
+    void (*kern)(const HaloArgs) = conv_halo64_bf16_kernel<MT, MB, PL, OB>;                                                                   \
+    if (!fo_lds_optin(once, reinterpret_cast<const void*>(kern), ldsBytes, "conv_bf16 (halo64)")) return FO_E_HIP;                          \
+    FO_NOTE_T("conv_halo64_bf16_kernel", MT, MB, PL, OB);                                                                                    \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), ldsBytes, s, a);                                                                         \
+  } while (0)
+  if (a.pooled) FO_HALO64(false, false, true, false);
+  else if (maskt) { if (a.outBits) FO_HALO64(true, false, false, true); else FO_HALO64(true, false, false, false); }
+  else if (maskb) { if (a.outBits) FO_HALO64(false, true, false, true); else FO_HALO64(false, true, false, false); }
+  else if (a.outBits) FO_HALO64(false, false, false, true);
+  else FO_HALO64(false, false, false, false);
+#undef FO_HALO64
   FO_CHECK_LAUNCH();
   return FO_OK;
 }
@@ -1915,9 +2029,18 @@ int fo_pack_conv_dgrad_bf16(const float* w, void* wp, int O, int I, int taps, in
 }
 
 static int conv_bf16_impl(const fo_conv_desc* d, const void* in, const void* wp, const float* bias, const void* mask, const void* add,
-                          void* out, void* stream, void* pooled = nullptr, int ldPooled = 0, void* pidx = nullptr) {
+                          void* out, void* stream, void* pooled = nullptr, int ldPooled = 0, void* pidx = nullptr, const void* maskBits = nullptr,
+                          void* outBits = nullptr, void* pooledBits = nullptr) {
   ConvArgsH a;
   a.d = *d;
+  a.maskBits = reinterpret_cast<const unsigned char*>(maskBits);
+  a.outBits = reinterpret_cast<unsigned char*>(outBits);
+  a.ldBits = d->Cout / 8;
+  {   // diagnostics (timing only, WRONG gradients): no ReLU-mask reads at all -- what a bit plane in their place could save at most
+    static const char* nomask = getenv("FACEOFF_DIAG_BF16_NO_MASK");
+    if (nomask && atoi(nomask)) { a.d.flags &= ~FO_MASK; a.maskBits = nullptr; maskBits = nullptr; }
+  }
+  d = &a.d;
   a.in = in; a.wp = wp; a.bias = bias; a.mask = mask; a.add = add; a.out = out;
   const int flags = d->flags;
   const bool f32out = flags & FO_OUT_F32, d2s = flags & FO_DEPTH2SPACE;
@@ -1933,7 +2056,12 @@ static int conv_bf16_impl(const fo_conv_desc* d, const void* in, const void* wp,
   } else {
     FO_REQUIRE(d->ldOut >= (d->Cout + 7) / 8 * 8, FO_E_ALIGN, "conv_bf16: ldOut must hold Cout rounded up to 8");
   }
-  FO_REQUIRE(!(flags & FO_MASK) || (mask && fo_aligned16(mask) && d->ldMask % 8 == 0), FO_E_ALIGN, "conv_bf16: mask alignment");
+  FO_REQUIRE(!(flags & FO_MASK) || maskBits || (mask && fo_aligned16(mask) && d->ldMask % 8 == 0), FO_E_ALIGN, "conv_bf16: mask alignment");
+  FO_REQUIRE((!maskBits && !outBits && !pooledBits) || (d->Cout % 8 == 0 && !d2s && !f32out), FO_E_SHAPE,
+             "conv_bf16: bit planes need Cout %% 8 == 0, a bf16 result and no FO_DEPTH2SPACE");
+  FO_REQUIRE(!maskBits || (flags & FO_MASK), FO_E_SHAPE, "conv_bf16: mask_bits without FO_MASK");
+  FO_REQUIRE(!outBits || !(flags & FO_ADD), FO_E_SHAPE, "conv_bf16: out_bits with FO_ADD is not built");
+  FO_REQUIRE(!pooledBits || pooled, FO_E_SHAPE, "conv_bf16: pooled_bits without pooled");
   FO_REQUIRE(!(flags & FO_ADD) || (add && fo_aligned16(add) && d->ldAdd % 8 == 0), FO_E_ALIGN, "conv_bf16: add alignment");
   FO_REQUIRE(!(flags & FO_BIAS) || bias, FO_E_SHAPE, "conv_bf16: FO_BIAS without bias");
   const int taps = d->KD * d->KH * d->KW;
@@ -1968,14 +2096,19 @@ static int conv_bf16_impl(const fo_conv_desc* d, const void* in, const void* wp,
       a.Ktot == 128 && inBytes < (1ull << 31) && !(norgb && atoi(norgb))) {
     const int nblocks = (a.M + 31) / 32;
     const int grid = std::min((nblocks + 3) / 4, fo_cu_count() * 3);
-    FO_NOTE("conv_rgb_bf16_kernel");
-    hipLaunchKernelGGL(conv_rgb_bf16_kernel, dim3(grid), dim3(256), 0, s, a, nblocks);
+    if (a.outBits) {
+      FO_NOTE("conv_rgb_bf16_kernel<true>");
+      hipLaunchKernelGGL(conv_rgb_bf16_kernel<true>, dim3(grid), dim3(256), 0, s, a, nblocks);
+    } else {
+      FO_NOTE("conv_rgb_bf16_kernel<false>");
+      hipLaunchKernelGGL(conv_rgb_bf16_kernel<false>, dim3(grid), dim3(256), 0, s, a, nblocks);
+    }
     FO_CHECK_LAUNCH();
     return FO_OK;
   }
   if (!smallc && d->KD == 1 && d->Cin == 64 && d->ldIn == 64 && d->Cout <= 8 && d->ldOut == 8 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->ostride == 1 &&
       d->padH == 1 && d->padW == 1 && d->Hin == d->Hm && d->Win == d->Wm && d->Hm == d->Hout && d->Wm == d->Wout && flags == 0 &&
-      d->Win % 64 == 0 && a.M >= 64 * 1024 && !(norgb && atoi(norgb))) {
+      d->Win % 64 == 0 && a.M >= 64 * 1024 && !(norgb && atoi(norgb)) && !outBits) {
     constexpr int ldsBytes = 2 * 28 * 1024;
     static fo_lds_once once;
     if (!fo_lds_optin(once, reinterpret_cast<const void*>(conv_rgb_dgrad_bf16_kernel), ldsBytes, "conv_bf16 (rgb dgrad)")) return FO_E_HIP;
@@ -1986,11 +2119,12 @@ static int conv_bf16_impl(const fo_conv_desc* d, const void* in, const void* wp,
     return FO_OK;
   }
   // a ResBlock's 3x3 128 -> 32 (ReLU in, bias, ReLU out): its own halo-tile kernel (resblock_bf16.hip)
-  if (!mask && !add && !pooled && d->Cin == 128 && d->Cout == 32 && fo_conv3x3_c128to32_halo_bf16_try(d, in, wp, bias, out, s)) {
+  const bool planes = maskBits || outBits || pooledBits;
+  if (!planes && !mask && !add && !pooled && d->Cin == 128 && d->Cout == 32 && fo_conv3x3_c128to32_halo_bf16_try(d, in, wp, bias, out, s)) {
     FO_CHECK_LAUNCH();
     return FO_OK;
   }
-  if (!bias && !pooled && d->Cin == 32 && d->Cout == 128 && fo_conv3x3_c32to128_halo_bf16_try(d, in, wp, mask, add, out, s)) {   // ... and its data gradient
+  if (!planes && !bias && !pooled && d->Cin == 32 && d->Cout == 128 && fo_conv3x3_c32to128_halo_bf16_try(d, in, wp, mask, add, out, s)) {   // ... and its data gradient
     FO_CHECK_LAUNCH();
     return FO_OK;
   }
@@ -2003,9 +2137,9 @@ static int conv_bf16_impl(const fo_conv_desc* d, const void* in, const void* wp,
         d->Hin == d->Hm && d->Win == d->Wm && d->Hm == d->Hout && d->Wm == d->Wout && d->Hin % 4 == 0 && d->Win % 32 == 0 &&
         !(flags & ~(FO_BIAS | FO_MASK | FO_OUT_RELU)) && d->ldOut % 4 == 0 && (!(flags & FO_MASK) || d->ldMask % 4 == 0) &&
         (tiles >= 8LL * fo_cu_count() || (fhalo && atoi(fhalo))) && !(nohalo && atoi(nohalo)))
-      return launch_halo64(a, s, pooled, ldPooled, pidx);
+      return launch_halo64(a, s, pooled, ldPooled, pidx, pooledBits);
   }
-  FO_REQUIRE(!pooled, FO_E_SHAPE, "conv_bf16: the pooled second output exists for the 64-input-channel halo-tile kernel only (3x3, whole 4 x 32 tiles, >= 8 tiles per CU)");
+  FO_REQUIRE(!pooled && !pooledBits, FO_E_SHAPE, "conv_bf16: the pooled second output exists for the 64-input-channel halo-tile kernel only (3x3, whole 4 x 32 tiles, >= 8 tiles per CU)");
   // big tiles (one workgroup per CU) where the launch still fills the chip for a few rounds: stride-1 same-size convs.
   // Measured at the C3 shapes and at a fifth of them (tools/ab_bf16.py): 256-column tiles +22...30 % over conv_bf16_kernel
   // on conv3_x / conv4_x, 128-column tiles +5...10 % on conv2_x and +12...15 % on 2-round launches, the 512 x 128 tile (32 MFMAs per
@@ -2125,6 +2259,17 @@ int fo_conv_igemm_bf16_pool(const fo_conv_desc* d, const void* in, const void* w
   fo_conv_desc e = *d;
   e.T = 1;
   return conv_bf16_impl(&e, in, wp, bias, nullptr, nullptr, out, stream, pooled, ldPooled);
+}
+
+int fo_conv_bf16_ex(const fo_conv_desc* d, const void* in, const void* wp, const float* bias, const void* mask, const void* add, void* out,
+                    const fo_conv_extra* ex, void* stream) {
+  FO_REQUIRE(ex, FO_E_SHAPE, "conv_bf16_ex: ex == NULL (use fo_conv_bf16)");
+  if (ex->pooled) {
+    FO_REQUIRE(d->KD == 1 && d->padD == 0 && !(d->flags & ~(FO_BIAS | FO_OUT_RELU)) && !add, FO_E_SHAPE, "conv_bf16_ex: pooled: 2-D, flags BIAS|OUT_RELU only");
+    FO_REQUIRE(fo_aligned16(ex->pooled) && ex->ldPooled % 4 == 0 && ex->ldPooled >= d->Cout && d->Hout % 2 == 0 && d->Wout % 2 == 0, FO_E_SHAPE,
+               "conv_bf16_ex: pooled output [N][H/2][W/2][ldPooled >= Cout]");
+  }
+  return conv_bf16_impl(d, in, wp, bias, mask, add, out, stream, ex->pooled, ex->ldPooled, ex->pool_idx, ex->mask_bits, ex->out_bits, ex->pooled_bits);
 }
 
 int fo_conv_igemm_bf16_pool_idx(const fo_conv_desc* d, const void* in, const void* wp, const float* bias, void* out, void* pooled, int ldPooled,

@@ -70,8 +70,8 @@ __global__ void maxpool2_fwd_bf16_kernel(const bf16x8* __restrict__ x, bf16x8* _
 // y = max over the 2x2 window, idx = WHICH of its four pixels (scan order (0,0) (0,1) (1,0) (1,1); the FIRST maximum, as torch's backward) in 2 bits
 // per channel: 8 channels per lane = one uint16, [N][Ho][Wo][C/8] (= bytes [..][C/4], channel c in byte c / 4, bits 2 (c % 4)).  The backward
 // then reads 1/16 of the input's bytes instead of the input (round 4: the pool backwards were 1.43 ms of config 3, all of it HBM time).
-__global__ void maxpool2_fwd_idx_bf16_kernel(const bf16x8* __restrict__ x, bf16x8* __restrict__ y, unsigned short* __restrict__ idx, int N, int Ho, int Wo,
-                                             int C8) {
+__global__ void maxpool2_fwd_idx_bf16_kernel(const bf16x8* __restrict__ x, bf16x8* __restrict__ y, unsigned short* __restrict__ idx,
+                                             unsigned char* __restrict__ ybits, int N, int Ho, int Wo, int C8) {
   const long long total = (long long)N * Ho * Wo * C8;
   const int W = Wo * 2;
   for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
@@ -83,16 +83,18 @@ __global__ void maxpool2_fwd_idx_bf16_kernel(const bf16x8* __restrict__ x, bf16x
     const bf16x8* base = x + ((n * (2 * Ho) + 2 * yo) * W + 2 * xo) * C8 + c;
     const bf16x8 a = base[0], b = base[C8], cc = base[(long long)W * C8], d = base[(long long)W * C8 + C8];
     bf16x8 m;
-    unsigned code = 0;
+    unsigned code = 0, pos = 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const float fa = (float)a[k], fb = (float)b[k], fc = (float)cc[k], fd = (float)d[k];
       const float mx = fmaxf(fmaxf(fa, fb), fmaxf(fc, fd));
       m[k] = (__bf16)mx;
       code |= (fa == mx ? 0u : fb == mx ? 1u : fc == mx ? 2u : 3u) << (2 * k);
+      pos |= (mx > 0.f ? 1u : 0u) << k;
     }
     y[e] = m;
     idx[e] = (unsigned short)code;
+    if (ybits) ybits[e] = (unsigned char)pos;              // the pooled tensor's ReLU-mask bit plane: [pixel][C/8] bytes
   }
 }
 
@@ -414,11 +416,11 @@ int fo_maxpool2_fwd_bf16(const void* x, void* y, int N, int H, int W, int C, voi
   return FO_OK;
 }
 
-int fo_maxpool2_fwd_idx_bf16(const void* x, void* y, void* idx, int N, int H, int W, int C, void* stream) {
+int fo_maxpool2_fwd_idx_bf16(const void* x, void* y, void* idx, void* ybits, int N, int H, int W, int C, void* stream) {
   FO_REQUIRE(H % 2 == 0 && W % 2 == 0 && C % 8 == 0, FO_E_SHAPE, "maxpool2_bf16: even H, W and C %% 8 == 0");
   hipLaunchKernelGGL(maxpool2_fwd_idx_bf16_kernel, dim3(grid_for((long long)N * (H / 2) * (W / 2) * (C / 8), 8192)), dim3(256), 0,
-                     (hipStream_t)stream, reinterpret_cast<const bf16x8*>(x), reinterpret_cast<bf16x8*>(y), reinterpret_cast<unsigned short*>(idx), N, H / 2,
-                     W / 2, C / 8);
+                     (hipStream_t)stream, reinterpret_cast<const bf16x8*>(x), reinterpret_cast<bf16x8*>(y), reinterpret_cast<unsigned short*>(idx),
+                     reinterpret_cast<unsigned char*>(ybits), N, H / 2, W / 2, C / 8);
   FO_CHECK_LAUNCH();
   return FO_OK;
 }

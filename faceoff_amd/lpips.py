@@ -90,6 +90,9 @@ class LPIPSEngine:
         # the pools of the reconstruction branch record their arg-max (2 bits per element) and the pool backwards read that instead of the full-size
         # input: FACEOFF_LPIPS_POOL_IDX=0 switches it off (A/B, tests)
         self.pool_idx = _os.environ.get("FACEOFF_LPIPS_POOL_IDX", "1") != "0"
+        # ... and its convolutions leave the SIGN of every activation a data gradient will mask by as a bit plane (FACEOFF_LPIPS_MASK_BITS=0: the
+        # data gradients read the bf16 activations themselves)
+        self.mask_bits = _os.environ.get("FACEOFF_LPIPS_MASK_BITS", "1") != "0"
 
     # ------------------------------------------------------------------ pieces
     def _prep(self, src, nhwc):
@@ -105,35 +108,40 @@ class LPIPSEngine:
                   self.shift, self.scale, ops._stream())
         return y
 
-    def _conv(self, i, x, pooled=None, pool_idx=None):
+    def _conv(self, i, x, pooled=None, pool_idx=None, out_bits=None, pooled_bits=None):
         _, ci, co, _ = self.convs[i]
         N, H, W, _ = x.shape
         y = torch.empty((N, H, W, co), device=self.device, dtype=self.act_dtype)
         if self.bf16:
-            ops.conv_bf16(x, self.wp[i], self.b[i], y, cin=8 if i == 0 else ci, cout=co, flags=ops.FO_OUT_RELU, pooled=pooled, pool_idx=pool_idx)
+            ops.conv_bf16(x, self.wp[i], self.b[i], y, cin=8 if i == 0 else ci, cout=co, flags=ops.FO_OUT_RELU, pooled=pooled, pool_idx=pool_idx,
+                          out_bits=out_bits, pooled_bits=pooled_bits)
         elif i == 0:
             ops.conv_igemm(x, self.wp[0], self.b[0], y, k=(1, 3, 4), pad=(0, 1, 1), cin=8, cout=co, flags=ops.FO_OUT_RELU)
         else:
             ops.conv_igemm(x, self.wp[i], self.b[i], y, k=(1, 3, 3), pad=(0, 1, 1), cin=ci, cout=co, flags=ops.FO_OUT_RELU)
         return y
 
-    def _pool(self, x, want_idx=False):
-        """MaxPool2d(2); with want_idx (bf16 branch) also its arg-max codes, 2 bits per element (the backward then needs no look at x)."""
+    def _pool(self, x, want_idx=False, want_bits=False):
+        """MaxPool2d(2); with want_idx (bf16 branch) also its arg-max codes, 2 bits per element (the backward then needs no look at x), with
+        want_bits the ReLU-mask bit plane of the pooled tensor.  Returns (y, idx, bits)."""
         N, H, W, Cc = x.shape
         y = torch.empty((N, H // 2, W // 2, Cc), device=self.device, dtype=self.act_dtype)
         if want_idx and self.bf16:
             idx = torch.empty((N, H // 2, W // 2, Cc // 4), device=self.device, dtype=torch.uint8)
-            _lib.call("fo_maxpool2_fwd_idx_bf16", ops._ptr(x), ops._ptr(y), ops._ptr(idx), N, H, W, Cc, ops._stream())
-            return y, idx
+            bits = torch.empty((N, H // 2, W // 2, Cc // 8), device=self.device, dtype=torch.uint8) if want_bits else None
+            _lib.call("fo_maxpool2_fwd_idx_bf16", ops._ptr(x), ops._ptr(y), ops._ptr(idx), ops._ptr(bits), N, H, W, Cc, ops._stream())
+            return y, idx, bits
         _lib.call("fo_maxpool2_fwd_bf16" if self.bf16 else "fo_maxpool2_fwd", ops._ptr(x), ops._ptr(y), N, H, W, Cc, ops._stream())
-        return y, None
+        return y, None, None
 
     def features(self, x8, keep_all):
         """vgg16.forward (lpips.py:139-152).  Returns (taps[5], acts) where acts[i] = ReLU output of conv i,
-        acts['p<i>'] = pooled input of conv i and acts['c<i>'] = that pool's arg-max codes or None (only when keep_all)."""
+        acts['p<i>'] = pooled input of conv i, acts['c<i>'] = that pool's arg-max codes or None, acts['b<i>'] / acts['pb<i>'] = the ReLU-mask
+        bit planes of acts[i] / acts['p<i>'] or None (only when keep_all)."""
         taps, acts, x = [], {}, x8
         use_idx = self.bf16 and keep_all and self.pool_idx
-        nxt = nxt_idx = None                             # the pooled input of the next conv (and its codes), when the previous launch already wrote it
+        use_bits = use_idx and self.mask_bits             # (the planes replace the masks of the backward that also uses the codes)
+        nxt = nxt_idx = nxt_bits = None                  # the pooled input of the next conv (its codes, its plane), when the previous launch already wrote it
         skip = 0
         if self.bf16 and self.fuse_conv1:
             # conv1_1 + conv1_2 (+ the pool in front of conv2_1) in ONE launch where frames are whole 4 x 32 tiles and the launch fills the chip:
@@ -153,10 +161,10 @@ class LPIPSEngine:
             if i < skip:
                 continue
             if pool:
-                x, cidx = (nxt, nxt_idx) if nxt is not None else self._pool(x, use_idx)
+                x, cidx, pbits = (nxt, nxt_idx, nxt_bits) if nxt is not None else self._pool(x, use_idx, use_bits)
                 if keep_all:
-                    acts[f"p{i}"], acts[f"c{i}"] = x, cidx
-            nxt = nxt_idx = None
+                    acts[f"p{i}"], acts[f"c{i}"], acts[f"pb{i}"] = x, cidx, pbits
+            nxt = nxt_idx = nxt_bits = None
             N, H, W, _ = x.shape
             # the max-pool in front of the NEXT conv rides along in this launch where the halo-tile kernel takes it (conv1_2): the pool's own
             # pass would read the full-resolution tap again
@@ -164,9 +172,16 @@ class LPIPSEngine:
                 nxt = torch.empty((N, H // 2, W // 2, co), device=self.device, dtype=self.act_dtype)
                 if use_idx:
                     nxt_idx = torch.empty((N, H // 2, W // 2, co // 4), device=self.device, dtype=torch.uint8)
-            x = self._conv(i, x, pooled=nxt, pool_idx=nxt_idx)
+                if use_bits:
+                    nxt_bits = torch.empty((N, H // 2, W // 2, co // 8), device=self.device, dtype=torch.uint8)
+            # this activation's sign plane, where a data gradient will ask for it: conv i + 1 follows without a pool (a tap in front of a pool is
+            # only ever looked at through the pool's codes)
+            obits = None
+            if use_bits and i + 1 < len(self.convs) and not self.convs[i + 1][3]:
+                obits = torch.empty((N, H, W, co // 8), device=self.device, dtype=torch.uint8)
+            x = self._conv(i, x, pooled=nxt, pool_idx=nxt_idx, out_bits=obits, pooled_bits=nxt_bits)
             if keep_all:
-                acts[i] = x
+                acts[i], acts[f"b{i}"] = x, obits
             if i in TAP_CONVS:
                 taps.append(x)
         return taps, acts
@@ -286,7 +301,7 @@ class LPIPSEngine:
                 cidx = acts.get(f"c{i}")
                 # with the pool's arg-max codes the pool backward never looks at its input: the one ReLU mask it applied to the pooled-through
                 # gradient (max > 0) moves into this data gradient's epilogue as mask = the pooled tensor, a quarter of the input's size
-                self._dgrad(g, i, gp, co, ci, acts[f"p{i}"] if cidx is not None else None)
+                self._dgrad(g, i, gp, co, ci, acts[f"p{i}"] if cidx is not None else None, acts.get(f"pb{i}"))
                 x = acts[i - 1]                          # pre-pool tensor = ReLU output of conv i-1 = a LPIPS tap
                 tap = TAP_CONVS.index(i - 1)
                 gx = torch.empty_like(x)
@@ -301,7 +316,7 @@ class LPIPSEngine:
                 g = gx
             else:
                 gin = torch.empty_like(acts[i - 1])
-                self._dgrad(g, i, gin, co, ci, acts[i - 1])
+                self._dgrad(g, i, gin, co, ci, acts[i - 1], acts.get(f"b{i - 1}"))
                 g = gin
         one = torch.ones(1, device=self.device)          # gscale already went into the tap gradients
         if self.bf16:
@@ -316,9 +331,13 @@ class LPIPSEngine:
             self.last_per_image = val
         return loss
 
-    def _dgrad(self, g, i, out, cin, cout, mask):
-        """Data gradient of conv i: the same 3x3 contraction with the flipped / channel-swapped filter."""
+    def _dgrad(self, g, i, out, cin, cout, mask, mask_bits=None):
+        """Data gradient of conv i: the same 3x3 contraction with the flipped / channel-swapped filter; the ReLU mask from its bit plane where
+        the forward left one (1/16 of the activation's bytes)."""
         if self.bf16:
-            ops.conv_bf16(g, self.wpd[i], None, out, cin=cin, cout=cout, mask=mask)
+            if mask_bits is not None:
+                ops.conv_bf16(g, self.wpd[i], None, out, cin=cin, cout=cout, mask_bits=mask_bits)
+            else:
+                ops.conv_bf16(g, self.wpd[i], None, out, cin=cin, cout=cout, mask=mask)
         else:
             ops.conv_igemm(g, self.wpd[i], None, out, k=(1, 3, 3), pad=(0, 1, 1), cin=cin, cout=cout, mask=mask)

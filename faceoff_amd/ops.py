@@ -616,15 +616,18 @@ def conv_bf16_pool_ok(N, H, W, cin, cout):
     return cin == 64 and cout % 64 == 0 and H % 4 == 0 and W % 32 == 0 and (tiles >= 8 * _lib.cu_count() or forced)
 
 
-def conv_bf16(x, wp, bias, out, *, k=(3, 3), stride=1, pad=(1, 1), cin=None, cout=None, flags=0, mask=None, pooled=None, pool_idx=None):
+def conv_bf16(x, wp, bias, out, *, k=(3, 3), stride=1, pad=(1, 1), cin=None, cout=None, flags=0, mask=None, pooled=None, pool_idx=None,
+              mask_bits=None, out_bits=None, pooled_bits=None):
     """One fo_conv_igemm_bf16 launch.  x/out/mask: bf16 channels-last views; bias fp32.  pooled (optional, only where conv_bf16_pool_ok):
-    receives the 2x2 max-pool of the result from the same launch, pool_idx (uint8 [N, H/2, W/2, Cout/4]) its arg-max codes."""
+    receives the 2x2 max-pool of the result from the same launch, pool_idx (uint8 [N, H/2, W/2, Cout/4]) its arg-max codes.
+    Bit planes (uint8 [N, H, W, Cout/8], bit c % 8 of byte c / 8 = value > 0; fo_conv_bf16_ex): mask_bits = the ReLU-backward mask instead of the
+    tensor `mask`, out_bits / pooled_bits receive the planes of the result / of the pooled result."""
     N, Hin, Win, _ = x.shape
     _, Hout, Wout, _ = out.shape
     bf = torch.bfloat16
     if bias is not None:
         flags |= FO_BIAS
-    if mask is not None:
+    if mask is not None or mask_bits is not None:
         flags |= FO_MASK
     d = _desc(N=N, T=1, Hin=Hin, Win=Win, Hm=Hout, Wm=Wout, Hout=Hout, Wout=Wout,
               Cin=cin if cin is not None else x.shape[-1], Cout=cout if cout is not None else out.shape[-1],
@@ -637,7 +640,12 @@ def conv_bf16(x, wp, bias, out, *, k=(3, 3), stride=1, pad=(1, 1), cin=None, cou
         if prof.detail:
             kname += f" [{N}x{Hout}x{Wout} {d.Cin}->{d.Cout} f{flags}]"
         prof.begin(kname, flops)
-    if pooled is not None:
+    if mask_bits is not None or out_bits is not None or pooled_bits is not None:
+        assert pooled is None or mask is None
+        ex = _lib.ConvExtra(pooled=_ptr(pooled).value, ldPooled=ld_of(pooled, bf) if pooled is not None else 0, pool_idx=_ptr(pool_idx).value,
+                            mask_bits=_ptr(mask_bits).value, out_bits=_ptr(out_bits).value, pooled_bits=_ptr(pooled_bits).value)
+        _lib.call("fo_conv_bf16_ex", C.byref(d), _ptr(x), _ptr(wp), _ptr(bias), _ptr(mask), None, _ptr(out), C.byref(ex), _stream())
+    elif pooled is not None:
         assert mask is None
         if pool_idx is not None:
             _lib.call("fo_conv_igemm_bf16_pool_idx", C.byref(d), _ptr(x), _ptr(wp), _ptr(bias), _ptr(out), _ptr(pooled), ld_of(pooled, bf), _ptr(pool_idx),

@@ -421,6 +421,24 @@ int fo_conv_igemm_bf16(const fo_conv_desc* d, const void* in, const void* wp, co
  * 64-input-channel halo-tile kernel applies (3x3, frames of whole 4 x 32 tiles, >= 8 tiles per CU): FO_E_SHAPE otherwise -- pool separately. */
 int fo_conv_igemm_bf16_pool(const fo_conv_desc* d, const void* in, const void* wp, const float* bias, void* out, void* pooled, int ldPooled,
                             void* stream);
+/* fo_conv_bf16 with optional extras.  ReLU masks as BIT PLANES: a data gradient needs the sign of the forward activation only, and reads 1/16 of its
+ * bytes from a plane [pixel][Cout/8] bytes, bit c % 8 of byte c / 8 = (value[pixel][c] > 0) -- config 3's masked data gradients read 3.7 GB of
+ * activations for their signs, 1.2 ms of its 36.7 ms step (round 4, measured with the mask reads switched off).
+ *   pooled / ldPooled / pool_idx  as fo_conv_igemm_bf16_pool_idx (NULL: none);
+ *   mask_bits    FO_MASK from a plane of the OUTPUT's geometry instead of the bf16 tensor `mask` (which may then be NULL);
+ *   out_bits     receives the plane of this launch's bf16 result (not with FO_ADD / FO_OUT_F32 / FO_DEPTH2SPACE);
+ *   pooled_bits  receives the plane of the pooled output [N][Hout/2][Wout/2][Cout/8].
+ * Cout % 8 == 0.  Reference: the ReLUs of models/lpips.py:118-134 under loss.backward() (train_faceoff_perceptual.py:100). */
+typedef struct fo_conv_extra {
+  void* pooled;
+  int32_t ldPooled;
+  void* pool_idx;
+  const void* mask_bits;
+  void* out_bits;
+  void* pooled_bits;
+} fo_conv_extra;
+int fo_conv_bf16_ex(const fo_conv_desc* d, const void* in, const void* wp, const float* bias, const void* mask, const void* add, void* out,
+                    const fo_conv_extra* ex, void* stream);
 /* ... and the pool's arg-max codes (fo_maxpool2_fwd_idx_bf16's idx, [N][Hout/2][Wout/2][Cout/4] bytes; NULL: none). */
 int fo_conv_igemm_bf16_pool_idx(const fo_conv_desc* d, const void* in, const void* wp, const float* bias, void* out, void* pooled, int ldPooled,
                                 void* idx, void* stream);
@@ -477,7 +495,8 @@ int fo_maxpool2_bwd_bf16(const void* x, const void* gy, const void* add, void* g
  * bits 2 (c % 4) and up).  fo_maxpool2_bwd_idx_bf16: gx[t] = [t is the recorded pixel] * gy + add[t] (add may be NULL), rounded once; NO ReLU mask is
  * applied here: add must be zero where x is (the tap heads' gradients are) and gy masked by y > 0 (fo_conv_igemm_bf16 with mask = y).  It reads 1/16 of
  * x's bytes where fo_maxpool2_bwd_bf16 reads x. */
-int fo_maxpool2_fwd_idx_bf16(const void* x, void* y, void* idx, int N, int H, int W, int C, void* stream);
+int fo_maxpool2_fwd_idx_bf16(const void* x, void* y, void* idx, void* ybits /* NULL or the bit plane of y (fo_conv_bf16_ex) */, int N, int H, int W, int C,
+                             void* stream);
 int fo_maxpool2_bwd_idx_bf16(const void* idx, const void* gy, const void* add, void* gx, int N, int H, int W, int C, void* stream);
 /* ws: fo_lpips_tap_ws_bytes_bf16(N, H, W, C) of scratch (both head entry points): every wave leaves its per-frame sums in its own slots and a
  * finish launch adds a frame's slots in wave order -- val[] is reproducible bit for bit (it met in float atomics before round 4). */

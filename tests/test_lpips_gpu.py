@@ -470,10 +470,12 @@ def test_pool_argmax_codes_and_the_backward_that_reads_them(monkeypatch):
     _lib.call("fo_maxpool2_fwd_bf16", ops._ptr(x), ops._ptr(y0), N, H, W, C, ops._stream())
     y1 = torch.empty_like(y0)
     idx = torch.empty((N, H // 2, W // 2, C // 4), device="cuda", dtype=torch.uint8)
-    _lib.call("fo_maxpool2_fwd_idx_bf16", ops._ptr(x), ops._ptr(y1), ops._ptr(idx), N, H, W, C, ops._stream())
+    ybits = torch.empty((N, H // 2, W // 2, C // 8), device="cuda", dtype=torch.uint8)
+    _lib.call("fo_maxpool2_fwd_idx_bf16", ops._ptr(x), ops._ptr(y1), ops._ptr(idx), ops._ptr(ybits), N, H, W, C, ops._stream())
     torch.cuda.synchronize()
     assert torch.equal(y0, y1)
     assert torch.equal(_unpack_codes(idx, C), _first_max_codes(x.float()))
+    assert torch.equal(ybits, _plane(y1))
     gy = torch.randn((N, H // 2, W // 2, C), generator=g).to(bf).cuda()
     add = (torch.randn((N, H, W, C), generator=g).cuda() * (x.float() > 0)).to(bf)
     want = torch.empty_like(x)
@@ -498,22 +500,86 @@ def test_pool_argmax_codes_and_the_backward_that_reads_them(monkeypatch):
     assert (y == 0).float().mean().item() > 0.2 and torch.equal(_unpack_codes(pidx, 64), _first_max_codes(y.float()))
 
 
-def test_lpips_gradient_does_not_change_with_the_pool_codes(monkeypatch):
+def _plane(x):
+    """[N, H, W, C] -> uint8 [N, H, W, C/8]: bit c % 8 of byte c / 8 = x > 0."""
+    b = (x.float() > 0).reshape(*x.shape[:3], x.shape[3] // 8, 8).long()
+    return (b << torch.arange(8, device=x.device)).sum(-1).to(torch.uint8)
+
+
+@pytest.mark.parametrize("cin,cout,H,W,env", [
+    (8, 64, 16, 32, {}),                                                  # the RGB layer's kernel
+    (64, 64, 16, 64, {"FACEOFF_BF16_FORCE_HALO": "1"}),                   # the 64-input-channel halo-tile kernel (4 channels per lane: nibbles)
+    (64, 128, 16, 64, {"FACEOFF_BF16_FORCE_HALO": "1"}),
+    (128, 256, 16, 16, {"FACEOFF_BF16_BIG_TILES": "1"}),                  # the extended-tile kernel, 256 x 256
+    (128, 128, 32, 32, {"FACEOFF_BF16_BIG_TILES": "1", "FACEOFF_BF16_TILE512": "1"}),
+    (256, 128, 12, 20, {}),                                               # the 128-row tiled kernels
+    (128, 64, 12, 20, {}),
+])
+def test_relu_masks_as_bit_planes(cin, cout, H, W, env, monkeypatch):
+    """fo_conv_bf16_ex: out_bits is the sign plane of the stored result, and a masked data gradient gives the same bits whether it reads the
+    bf16 mask tensor or its plane -- in every kernel family the LPIPS branch lands on."""
+    from faceoff_amd import _lib, ops
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    bf = torch.bfloat16
+    g = torch.Generator().manual_seed(cin + cout)
+    N = 3
+    x = (torch.randn((N, H, W, cin), generator=g) * 0.5).to(bf).cuda()
+    wraw = torch.randn((cout, cin, 3, 3), generator=g) / np.sqrt(9 * cin)
+    if cin == 8:
+        wraw[:, 3:] = 0
+        wp = ops.pack_conv_bf16(wraw.cuda(), taps_pad=16)
+    else:
+        wp = ops.pack_conv_bf16(wraw.cuda())
+    b = torch.randn(cout, generator=g).cuda()
+    lib = _lib.load()
+    y0 = torch.empty((N, H, W, cout), device="cuda", dtype=bf)
+    ops.conv_bf16(x, wp, b, y0, cin=cin, cout=cout, flags=ops.FO_OUT_RELU)
+    y1 = torch.empty_like(y0)
+    bits = torch.full((N, H, W, cout // 8), 0xAA, device="cuda", dtype=torch.uint8)
+    lib.fo_kernel_notes(1); lib.fo_last_kernel()
+    ops.conv_bf16(x, wp, b, y1, cin=cin, cout=cout, flags=ops.FO_OUT_RELU, out_bits=bits)
+    kern = lib.fo_last_kernel().decode(); lib.fo_kernel_notes(0)
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1), kern
+    assert torch.equal(bits, _plane(y1)), kern
+    assert 0.2 < (y1 > 0).float().mean().item() < 0.8
+    if cin == 8:
+        return
+    mask = torch.relu(torch.randn((N, H, W, cout), generator=g)).to(bf).cuda()
+    o0, o1 = torch.empty_like(y0), torch.empty_like(y0)
+    ops.conv_bf16(x, wp, None, o0, cin=cin, cout=cout, mask=mask)
+    ops.conv_bf16(x, wp, None, o1, cin=cin, cout=cout, mask_bits=_plane(mask))
+    torch.cuda.synchronize()
+    assert torch.equal(o0, o1), kern
+
+
+def test_lpips_gradient_does_not_change_with_the_pool_codes_and_mask_planes(monkeypatch):
     """The reconstruction branch with arg-max codes (pool backwards read 2 bits per element, the pooled-through ReLU mask moves into the data
-    gradient in front) against the same branch with the pool backwards reading their full-size inputs: the gradient is the same to the bit."""
+    gradient in front) and with the ReLU masks of its data gradients as bit planes, against the same branch reading full-size activations for
+    both: the loss and the gradient are the same to the bit."""
     from faceoff_amd.lpips import LPIPSEngine
-    monkeypatch.setenv("FACEOFF_BF16_FORCE_HALO", "1")   # conv1_2 on the halo-tile kernel with the pool (and its codes) riding along
+    monkeypatch.setenv("FACEOFF_BF16_FORCE_HALO", "1")   # conv1_2 on the halo-tile kernel with the pool (its codes, its plane) riding along
     rng = np.random.default_rng(4)
     tgt = torch.from_numpy(rng.uniform(-1, 1, (2, 3, 32, 64)).astype(np.float32)).cuda()
     dec = torch.zeros((2, 32, 64, 8), device="cuda")
     dec[..., :3] = tgt.permute(0, 2, 3, 1) + 0.3 * torch.from_numpy(rng.standard_normal((2, 32, 64, 3)).astype(np.float32)).cuda()
     out = {}
-    for on in (True, False):
+    for idx, bits in ((True, True), (True, False), (False, False)):
         eng = LPIPSEngine(make_vgg_lpips_state(5), "cuda:0", dtype="bf16")
-        eng.pool_idx = on
+        eng.pool_idx, eng.mask_bits = idx, bits
         gd = torch.zeros_like(dec)
         loss = eng.loss_and_grad(tgt, dec, gd)
         _, acts = eng.features(eng._prep(dec, nhwc=True), keep_all=True)
-        assert all((acts[f"c{i}"] is not None) == on for i in (2, 4, 7, 10))
-        out[on] = (loss.item(), gd)
-    assert out[True][0] == out[False][0] and torch.equal(out[True][1], out[False][1])
+        assert all((acts[f"c{i}"] is not None) == idx for i in (2, 4, 7, 10))
+        assert all((acts[f"pb{i}"] is not None) == bits for i in (2, 4, 7, 10))
+        assert all((acts[f"b{i}"] is not None) == bits for i in (0, 2, 4, 5, 7, 8, 10, 11)) and all(acts[f"b{i}"] is None for i in (1, 3, 6, 9, 12))
+        if bits:
+            for i in (0, 2, 5, 11):
+                assert torch.equal(acts[f"b{i}"], _plane(acts[i]))
+            for i in (2, 4, 7, 10):
+                assert torch.equal(acts[f"pb{i}"], _plane(acts[f"p{i}"]))
+        out[(idx, bits)] = (loss.item(), gd)
+    ref = out[(False, False)]
+    for k in ((True, True), (True, False)):
+        assert out[k][0] == ref[0] and torch.equal(out[k][1], ref[1]), k
