@@ -1589,6 +1589,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16_kernel(const HaloArgs
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const size_t pix = ((size_t)n * a.H + ty * 4 + 2 * wm + (i >> 1)) * a.W + tx * 32 + (i & 1) * 16 + l15;
+      unsigned obw = 0;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int co = half * 64 + wn * 32 + j * 16 + quad * 4;
@@ -1610,11 +1611,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16_kernel(const HaloArgs
         }
         const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
         if (!(FO_ABLATE_H & 32)) *reinterpret_cast<bf16x4*>(a.out + pix * a.ldOut + co) = o;
-        if (OBITS) {                                       // quads 2q, 2q + 1 hold the two nibbles of a byte
-          const unsigned nb = pos_bits4((float)o[0], (float)o[1], (float)o[2], (float)o[3]);
-          const unsigned other = (unsigned)__shfl_xor((int)nb, 16);
-          if (!(quad & 1)) a.outBits[pix * (a.Cout / 8) + (co >> 3)] = (unsigned char)(nb | (other << 4));
-        }
+        if (OBITS) obw |= pos_bits4((float)o[0], (float)o[1], (float)o[2], (float)o[3]) << (j * 16 + quad * 4);      // the wave's 32 channels of this pixel: one dword
         if (POOL) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -1623,12 +1620,18 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16_kernel(const HaloArgs
           }
         }
       }
+      if (OBITS) {                                         // the four quads' nibbles meet in one dword (two shuffles): one 4-byte store per pixel
+        obw |= (unsigned)__shfl_xor((int)obw, 16);
+        obw |= (unsigned)__shfl_xor((int)obw, 32);
+        if (quad == 0) *reinterpret_cast<unsigned*>(a.outBits + pix * (a.Cout / 8) + half * 8 + wn * 4) = obw;
+      }
       __builtin_amdgcn_sched_barrier(0);                  // (one pixel block's mask loads and addresses at a time: the filter holds the registers)
     }
     if (POOL) {
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
         const size_t ppix = ((size_t)n * (a.H / 2) + ty * 2 + wm) * (a.W / 2) + tx * 16 + e * 8 + (l15 >> 1);
+        unsigned cw[2] = {0u, 0u}, pw = 0;                 // this lane's share of the pooled pixel's codes (8 bytes per wave) and sign plane (4 bytes)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           float m[4];
@@ -1643,27 +1646,40 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16_kernel(const HaloArgs
               const unsigned iL = ((rowbit[e][j] >> r) & 1u) * 2u, iR = ((rbR >> r) & 1u) * 2u + 1u;
               code |= (vL > vR ? iL : vR > vL ? iR : min(iL, iR)) << (2 * r);
             }
-            if (!(l15 & 1)) a.pidx[ppix * (a.Cout / 4) + (half * 64 + wn * 32 + j * 16 + quad * 4) / 4] = (unsigned char)code;
+            cw[j] = code << (8 * quad);                    // byte j * 4 + quad of the wave's eight
           }
-          if (a.pooledBits) {
-            const unsigned nb = pos_bits4((float)(__bf16)m[0], (float)(__bf16)m[1], (float)(__bf16)m[2], (float)(__bf16)m[3]);
-            const unsigned other = (unsigned)__shfl_xor((int)nb, 16);
-            if (!(l15 & 1) && !(quad & 1)) a.pooledBits[ppix * (a.Cout / 8) + ((half * 64 + wn * 32 + j * 16 + quad * 4) >> 3)] = (unsigned char)(nb | (other << 4));
-          }
+          if (a.pooledBits) pw |= pos_bits4((float)(__bf16)m[0], (float)(__bf16)m[1], (float)(__bf16)m[2], (float)(__bf16)m[3]) << (j * 16 + quad * 4);
           if (!(l15 & 1))
             *reinterpret_cast<bf16x4*>(a.pooled + ppix * a.ldPooled + half * 64 + wn * 32 + j * 16 + quad * 4) = bf16x4{(__bf16)m[0], (__bf16)m[1], (__bf16)m[2], (__bf16)m[3]};
+        }
+        // the four quads' bytes / nibbles meet by two shuffles each: ONE 8-byte and ONE 4-byte store per pooled pixel instead of eight 1-byte stores
+        // scattered over the wave (those made the launch 1.26 ms against 0.90 without them)
+        if (a.pidx) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            cw[j] |= (unsigned)__shfl_xor((int)cw[j], 16);
+            cw[j] |= (unsigned)__shfl_xor((int)cw[j], 32);
+          }
+          if (!(l15 & 1) && quad == 0) {
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            *reinterpret_cast<u32x2*>(a.pidx + ppix * (a.Cout / 4) + half * 16 + wn * 8) = u32x2{cw[0], cw[1]};
+          }
+        }
+        if (a.pooledBits) {
+          pw |= (unsigned)__shfl_xor((int)pw, 16);
+          pw |= (unsigned)__shfl_xor((int)pw, 32);
+          if (!(l15 & 1) && quad == 0) *reinterpret_cast<unsigned*>(a.pooledBits + ppix * (a.Cout / 8) + half * 8 + wn * 4) = pw;
         }
       }
     }
     // the next patch has landed: vmcnt retires in order and the 8 youngest operations are this tile's stores, which may keep flying
     // (nothing reads them; the LDS stage they came from is not involved)
-    // (8 result stores per lane; + 8 bit-plane bytes; + 4 pooled stores, + 4 code bytes, + 4 pooled-plane bytes.  A count that is too SMALL only
+    // (8 result stores per lane; + 4 bit-plane dwords; + 4 pooled stores, + 2 code stores, + 2 pooled-plane dwords.  A count that is too SMALL only
     // waits for a few of the stores as well; lgkmcnt: the row copy's LDS writes)
     {
-      const int nst = 8 + (OBITS ? 8 : 0) + (POOL ? 4 : 0) + (POOL && a.pidx ? 4 : 0) + (POOL && a.pooledBits ? 4 : 0);
-      if (nst >= 28) asm volatile("s_waitcnt vmcnt(28) lgkmcnt(0)" ::: "memory");
-      else if (nst >= 20) asm volatile("s_waitcnt vmcnt(20) lgkmcnt(0)" ::: "memory");
-      else if (nst >= 16) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+      const int nst = 8 + (OBITS ? 4 : 0) + (POOL ? 4 : 0) + (POOL && a.pidx ? 2 : 0) + (POOL && a.pooledBits ? 2 : 0);
+      if (nst >= 16) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+      else if (nst >= 14) asm volatile("s_waitcnt vmcnt(14) lgkmcnt(0)" ::: "memory");
       else if (nst >= 12) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
     }

@@ -10,8 +10,10 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/c5" -o c5 -- pytho
 python3 - "$OUT" "$TAG" <<'PY'
 import csv, glob, os, re, sys
 out, tag = sys.argv[1], sys.argv[2]
+sys.path.insert(0, "profiles")
+from summarize import demangle
 def short(n):
-    n = re.sub(r"\(anonymous namespace\)::", "", n); n = re.sub(r"^void ", "", n); return re.sub(r"\(.*\)$", "", n).strip()
+    n = demangle(n); n = re.sub(r"\(anonymous namespace\)::", "", n); n = re.sub(r"^void ", "", n); return re.sub(r"\(.*\)$", "", n).strip()
 for leg, title in (("c3", "bench.py --perceptual --vqvae-dtype bf16 --serial-streams --steps 2 --warmup 1 (C3, bf16 MFMA operands throughout: 3 steps traced)"), ("c5", "tools/bench_gan.py 6 (C5: 2 warm-up + 7-8 GAN iterations traced)")):
     rows = []
     for f in glob.glob(os.path.join(out, leg, "**", "*kernel_stats.csv"), recursive=True):

@@ -19,7 +19,33 @@ from collections import defaultdict
 CUS, SIMDS = 256, 4
 
 
+_DEMANGLED = {}
+
+
+def demangle(name):
+    """rocprofv3 leaves some symbols mangled (a kernel whose parameter list names a vector type): llvm-cxxfilt, where the ROCm image has it."""
+    if not name.startswith("_Z"):
+        return name
+    if name not in _DEMANGLED:
+        out = name
+        for tool in ("/opt/rocm/lib/llvm/bin/llvm-cxxfilt", "c++filt"):
+            try:
+                import subprocess
+                out = subprocess.run([tool, name], capture_output=True, text=True, timeout=10).stdout.strip() or name
+                break
+            except Exception:
+                continue
+        if out.startswith("_Z"):                           # (llvm-cxxfilt does not know the __bf16 vector mangling): the identifier at least
+            m = re.match(r"_ZN12_GLOBAL__N_1(\d+)", out) or re.match(r"_Z(\d+)", out)
+            if m:
+                n0 = m.end()
+                out = out[n0:n0 + int(m.group(1))]
+        _DEMANGLED[name] = out
+    return _DEMANGLED[name]
+
+
 def short(name):
+    name = demangle(name)
     name = re.sub(r"\(anonymous namespace\)::", "", name)
     name = re.sub(r"^void ", "", name)
     name = re.sub(r"\(.*\)$", "", name)
