@@ -432,10 +432,19 @@ def test_extended_tile_kernel_persistent_grid_equals_one_workgroup_per_tile(N, H
         ops.conv_bf16g(x, wp, None, outs[1], mask=mask, **kw)
         ops.conv_bf16g(x, wp, None, outs[2], mask=mask, add=add, **kw)
         ops.conv_bf16g(x, wp, b, outs[3], **kw)
+        if T == 1:                                       # the bit-plane forms (fo_conv_bf16_ex): the result's sign plane, the mask from a plane
+            plane = torch.empty((N, H, W, cout // 8), device="cuda", dtype=torch.uint8)
+            o5, o6 = torch.empty_like(outs[0]), torch.empty_like(outs[0])
+            ops.conv_bf16(x, wp, b, o5, cin=cin, cout=cout, flags=ops.FO_OUT_RELU, out_bits=plane)
+            mplane = ((mask.float() > 0).reshape(N, H, W, cout // 8, 8).long() << torch.arange(8, device="cuda")).sum(-1).to(torch.uint8)
+            ops.conv_bf16(x, wp, None, o6, cin=cin, cout=cout, mask_bits=mplane)
+            outs += [o5, o6, plane]
         torch.cuda.synchronize()
         res[mode] = outs
     for a_, b_ in zip(res["0"], res["1"]):
         assert torch.equal(a_, b_)
+    if T == 1:
+        assert torch.equal(res["1"][4], res["1"][0]) and torch.equal(res["1"][5], res["1"][1])       # planes change nothing in the values
     # and the values themselves: against the per-tap kernel
     monkeypatch.setenv("FACEOFF_BF16_NO_PPH", "1")
     ref = torch.empty((N, H, W, cout), device="cuda", dtype=BF)
