@@ -1431,6 +1431,14 @@ struct HaloArgs {
   unsigned inBytes;
 };
 
+#ifdef FO_STAMP_H64   // diagnostic build only (tools/stamp_h64.sh): where a tile of the halo-tile kernel goes, in core clocks (workgroup 0, wave 0)
+__device__ unsigned long long fo_h64_stamps[16];
+#define H64_STAMP(var)                                                                  \
+  if (stamping) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory")
+#else
+#define H64_STAMP(var)
+#endif
+
 // MASKT / MASKB: FO_MASK from the bf16 tensor / from its bit plane; POOL: the pooled output (its codes and plane where given); OBITS: the result's plane.
 // (compile-time: with all of it behind run-time tests the kernel spills -- 144 registers hold the filter)
 template <bool MASKT, bool MASKB, bool POOL, bool OBITS>
@@ -1524,10 +1532,16 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16_kernel(const HaloArgs
   dma_tile(tile, 0, false);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+#ifdef FO_STAMP_H64
+  const bool stamping = blockIdx.x == 0 && wave == 0;
+  unsigned long long h0 = 0, h1 = 0, h2 = 0, h3 = 0, h4 = 0, sIssue = 0, sMfma = 0, sEpi = 0, sWait = 0, nT = 0, hK0 = 0, hR0 = 0;
+  if (stamping) asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(hK0), "=s"(hR0)::"memory");
+#endif
   for (int it = 0; tile < tile_end; ++tile, ++it) {
     const int st = it & 1;
     const bool more = tile + 1 < tile_end;
     const bool reuse = more && (tile + 1) % a.tilesY != 0;  // the next tile is the one below this one
+    H64_STAMP(h0);
     if (more) dma_tile(tile + 1, st ^ 1, reuse);          // next tile's patch: lands during this tile's MFMAs
     if (reuse) {                                           // its rows 0, 1 = this patch's rows 4, 5, both planes (whole 48-pixel rows: same layout, same swizzle)
 #pragma unroll
@@ -1555,28 +1569,42 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16_kernel(const HaloArgs
         mw[i] = *reinterpret_cast<const unsigned*>(a.maskBits + pix * (a.Cout / 8) + half * 8 + wn * 4);
       }
     }
+    H64_STAMP(h1);
     f32x4 acc[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const unsigned char* const base = lds + st * STAGE;
-    // 36 half-steps h = (tap, K-slice, pair of pixel blocks): two fragment reads, four MFMAs (no registers to read ahead: 144 hold the
-    // filter; the SIMD's other wave belongs to the CU's other workgroup, in another phase, and covers the wait)
-#pragma unroll
-    for (int h = 0; h < ((FO_ABLATE_H & 16) ? 0 : 36); ++h) {
+    // 36 half-steps h = (tap, K-slice, pair of pixel blocks): two fragment reads, four MFMAs.  The reads run AHEAD half-steps in front of their
+    // MFMAs (a ring of AHEAD + 1 fragment pairs): in-kernel stamps (tools/stamp_h64.py) put the loop at 5 900-6 000 clocks per tile against 2 304 of
+    // MFMA issue -- each half-step waited out its own LDS round trip whenever the SIMD's other wave (the CU's other workgroup) was not in its
+    // MFMA loop too.
+#ifndef FO_H64_AHEAD
+#define FO_H64_AHEAD 2
+#endif
+    constexpr int AHEAD = FO_H64_AHEAD, NH = (FO_ABLATE_H & 16) ? 0 : 36;
+    bf16x8 xf[AHEAD + 1][2];
+    auto frag = [&](int h, bf16x8 (&x)[2]) {
       const int tap = h >> 2, sl = (h >> 1) & 1, pr = h & 1, kh = tap / 3, kw = tap - kh * 3;
-      bf16x8 xf[2];
 #pragma unroll
       for (int e = 0; e < 2; ++e)        // block i = 2 pr + e: tile row 2 wm + pr, pixels 16 e .. + 15
-        xf[e] = *reinterpret_cast<const bf16x8*>(base + sl * PLANE + ((2 * wm + pr + kh) * PITCH + e * 16) * 64 + cq[kw]);
+        x[e] = *reinterpret_cast<const bf16x8*>(base + sl * PLANE + ((2 * wm + pr + kh) * PITCH + e * 16) * 64 + cq[kw]);
+    };
+#pragma unroll
+    for (int h = 0; h < AHEAD && h < NH; ++h) frag(h, xf[h]);
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      const int tap = h >> 2, sl = (h >> 1) & 1, pr = h & 1;
+      if (h + AHEAD < NH) frag(h + AHEAD, xf[(h + AHEAD) % (AHEAD + 1)]);
 #pragma unroll
       for (int e = 0; e < 2; ++e)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          acc[2 * pr + e][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tap][sl][j], xf[e], acc[2 * pr + e][j], 0, 0, 0);
+          acc[2 * pr + e][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tap][sl][j], xf[h % (AHEAD + 1)][e], acc[2 * pr + e][j], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
+    H64_STAMP(h2);
     // ---- epilogue: acc[i][j][r] = channel 16 j + 4 quad + r of pixel (row 2 wm + (i >> 1), column 16 (i & 1) + l15)
     int n, ty, tx;
     tile_of(tile, n, ty, tx);
@@ -1674,6 +1702,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16_kernel(const HaloArgs
     }
     // the next patch has landed: vmcnt retires in order and the 8 youngest operations are this tile's stores, which may keep flying
     // (nothing reads them; the LDS stage they came from is not involved)
+    H64_STAMP(h3);
     // (8 result stores per lane; + 4 bit-plane dwords; + 4 pooled stores, + 2 code stores, + 2 pooled-plane dwords.  A count that is too SMALL only
     // waits for a few of the stores as well; lgkmcnt: the row copy's LDS writes)
     {
@@ -1684,7 +1713,19 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16_kernel(const HaloArgs
       else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
+#ifdef FO_STAMP_H64
+    H64_STAMP(h4);
+    if (stamping) { sIssue += h1 - h0; sMfma += h2 - h1; sEpi += h3 - h2; sWait += h4 - h3; ++nT; }
+#endif
   }
+#ifdef FO_STAMP_H64
+  if (stamping && (threadIdx.x & 63) == 0) {
+    unsigned long long k1, r1;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(k1), "=s"(r1)::"memory");
+    fo_h64_stamps[0] = sIssue; fo_h64_stamps[1] = sMfma; fo_h64_stamps[2] = sEpi; fo_h64_stamps[3] = sWait; fo_h64_stamps[4] = nT;
+    fo_h64_stamps[5] = k1 - hK0; fo_h64_stamps[6] = r1 - hR0;
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ VGG conv1_1 + conv1_2 in one launch
@@ -1918,7 +1959,7 @@ static int launch_halo64(const ConvArgsH& c, hipStream_t s, void* pooled = nullp
   } while (0)
   if (a.pooled) FO_HALO64(false, false, true, false);
   else if (maskt) { if (a.outBits) FO_HALO64(true, false, false, true); else FO_HALO64(true, false, false, false); }
-  else if (maskb) { if (a.outBits) FO_HALO64(false, true, false, true); else FO_HALO64(false, true, false, false); }
+  else if (maskb) FO_HALO64(false, true, false, false);
   else if (a.outBits) FO_HALO64(false, false, false, true);
   else FO_HALO64(false, false, false, false);
 #undef FO_HALO64
@@ -2020,6 +2061,11 @@ inline int grid_for(size_t total) { return (int)std::min<size_t>((total + 255) /
 
 }  // namespace
 
+#ifdef FO_STAMP_H64
+extern "C" int fo_debug_read_h64_stamps(unsigned long long* out, int n) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(fo_h64_stamps), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -1;
+}
+#endif
 #ifdef FO_STAMP_PPH
 extern "C" int fo_debug_read_pph_stamps(unsigned long long* out, int n) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(fo_pph_stamps), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -1;
@@ -2152,7 +2198,8 @@ static int conv_bf16_impl(const fo_conv_desc* d, const void* in, const void* wp,
     if (!smallc && d->KD == 1 && d->Cin == 64 && d->Cout % 64 == 0 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->ostride == 1 && d->padH == 1 && d->padW == 1 &&
         d->Hin == d->Hm && d->Win == d->Wm && d->Hm == d->Hout && d->Wm == d->Wout && d->Hin % 4 == 0 && d->Win % 32 == 0 &&
         !(flags & ~(FO_BIAS | FO_MASK | FO_OUT_RELU)) && d->ldOut % 4 == 0 && (!(flags & FO_MASK) || d->ldMask % 4 == 0) &&
-        (tiles >= 8LL * fo_cu_count() || (fhalo && atoi(fhalo))) && !(nohalo && atoi(nohalo)))
+        (tiles >= 8LL * fo_cu_count() || (fhalo && atoi(fhalo))) && !(nohalo && atoi(nohalo)) &&
+        !(maskBits && outBits))                            // (that instantiation spills; nothing asks for it: a data gradient writes no plane)
       return launch_halo64(a, s, pooled, ldPooled, pidx, pooledBits);
   }
   FO_REQUIRE(!pooled && !pooledBits, FO_E_SHAPE, "conv_bf16: the pooled second output exists for the 64-input-channel halo-tile kernel only (3x3, whole 4 x 32 tiles, >= 8 tiles per CU)");
