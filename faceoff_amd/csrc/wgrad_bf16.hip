@@ -235,8 +235,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_bf16_kernel(const WArgs a) {
   // one run on the matrix pipe: ALL of its fragments are read first (20 transposing reads in flight at once: their latency is paid once
   // per run, not once per group of MFMAs -- the two waves of a SIMD leave the barrier together, so neither covers the other's waits),
   // then the MFMAs issue back to back
-  auto compute = [&](int st, int rr) {
-    if (FO_ABLATE_W & 4) return;
+  auto compute = [&](int st, int rr, auto&& mid) {     // mid(): issued after the first third of the MFMAs (the next step's LDS stores and requests)
+    if (FO_ABLATE_W & 4) { mid(); return; }
     bf16x8 fa[MA], fb[NKW][MB];
 #pragma unroll
     for (int i = 0; i < MA; ++i) {
@@ -259,11 +259,17 @@ __global__ __launch_bounds__(512, 1) void wgrad_bf16_kernel(const WArgs a) {
         if (i % WB == wb % (MA < WB ? MA : WB) && wb < (MA < WB ? MA : WB)) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], ones, accb[i], 0, 0, 0);
     }
 #pragma unroll
-    for (int k = 0; k < NKW; ++k)
+    for (int k = 0; k < NKW; ++k) {
 #pragma unroll
       for (int j = 0; j < MB; ++j)
 #pragma unroll
         for (int i = 0; i < MA; ++i) acc[k][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[k][j], acc[k][i][j], 0, 0, 0);
+      if (k == 0) {
+        __builtin_amdgcn_sched_barrier(0);
+        mid();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
     __builtin_amdgcn_sched_barrier(0);
   };
 
@@ -289,16 +295,26 @@ __global__ __launch_bounds__(512, 1) void wgrad_bf16_kernel(const WArgs a) {
         if (u >= u1) break;
         constexpr int dummy = 0; (void)dummy;
         const int st = sl & 1;
+        // the next step's LDS stores and the request for the step after are issued INSIDE this step's MFMAs (after the first tap's): as a phase
+        // of their own behind the MFMAs -- all eight waves are in the same phase -- they left the matrix pipe idle (tools/ablate_wgrad.sh, 64^2
+        // Conv3d: 0.74 ms with, 0.41 ms without the stores)
+        auto stage_next = [&]() {
+          if (u + KR < u1) {
 #pragma unroll
-        for (int rr = 0; rr < KR; ++rr)
-          if (u + rr < u1) compute(st, rr);
-        if (u + KR < u1) {
+            for (int rr = 0; rr < KR; ++rr) store(st ^ 1, rr, rp[(sl + 1) % D][rr], rq[(sl + 1) % D][rr]);
+            if (u + (D + 1) * KR < u1) {
 #pragma unroll
-          for (int rr = 0; rr < KR; ++rr) store(st ^ 1, rr, rp[(sl + 1) % D][rr], rq[(sl + 1) % D][rr]);
-          if (u + (D + 1) * KR < u1) {
-#pragma unroll
-            for (int rr = 0; rr < KR; ++rr) load(u + (D + 1) * KR + rr, rp[(sl + 1) % D][rr], rq[(sl + 1) % D][rr]);
+              for (int rr = 0; rr < KR; ++rr) load(u + (D + 1) * KR + rr, rp[(sl + 1) % D][rr], rq[(sl + 1) % D][rr]);
+            }
           }
+        };
+        if (KR == 1) {                           // (two thin runs per step: measured slower with the stores inside, +8 % on the ResBlock 3x3)
+          compute(st, 0, stage_next);
+        } else {
+#pragma unroll
+          for (int rr = 0; rr < KR; ++rr)
+            if (u + rr < u1) compute(st, rr, [] {});
+          stage_next();
         }
         __syncthreads();
         u += KR;
