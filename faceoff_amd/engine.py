@@ -367,6 +367,7 @@ class VQVAEEngine:
         if self.device.type == "cuda" and not _os.environ.get("FACEOFF_NO_VQ_OVERLAP"):
             self.vq_stream = torch.cuda.Stream(device=self.device)
         self._streams = (self.wgrad_stream, self.aux_stream, self.pack_stream, self.vq_stream)
+        self.tail_wgrads = int(_os.environ.get("FACEOFF_TAIL_WGRADS", "2"))     # how many of the last filter gradients run on the caller's stream (backward())
         self._pack_events = None
         # Conv3d forward / data gradient as Winograd F(2x2,3x3) + a (3,1,1) implicit GEMM (FACEOFF_NO_WINOGRAD=1: direct)
         self.winograd = not _os.environ.get("FACEOFF_NO_WINOGRAD")
@@ -770,11 +771,26 @@ class VQVAEEngine:
         g_a3 = new_like(S["a3"]); self._resblock_bwd("enc_b.blocks.6", g_a4, S["a3"], S["h_eb6"], g_a3)
         g_a2 = new_like(S["a2"]); self._resblock_bwd("enc_b.blocks.5", g_a3, S["a2"], S["h_eb5"], g_a2)
         b4, b2, b0 = L["enc_b.blocks.4"], L["enc_b.blocks.2"], L["enc_b.blocks.0"]
-        b4.wgrad(S["a1"], g_a2)
+        # The last layers' filter gradients on the CALLER's stream, behind the last data gradient: the side stream reaches the end of the backward
+        # with a backlog (bf16 engine at config 3: 1.15 ms of filter gradients and their reduce launches after the main stream's last kernel;
+        # fp32 engine: 1.85 ms; tools/timeline.py, per-queue ends), and the main stream has nothing left to do but wait for it.  Two layers
+        # (FACEOFF_TAIL_WGRADS): same-device A/B config 2 39.67 -> 39.57 ms, config 3 34.84 -> 34.48; three puts the main stream 1.6 ms behind.
+        n_tail = self.tail_wgrads if self.wgrad_stream is not None else 0
+        tail = []
+
+        def wgrad_or_tail(layer, x, g, rank):
+            if rank < n_tail:
+                tail.append((layer, x, g))
+            else:
+                layer.wgrad(x, g)
+        wgrad_or_tail(b4, S["a1"], g_a2, 2)
         g_a1 = new_like(S["a1"]); b4.dgrad(g_a2, g_a1, mask=S["a1"])
-        b2.wgrad(S["a0"], g_a1)
+        wgrad_or_tail(b2, S["a0"], g_a1, 1)
         g_a0 = new_like(S["a0"]); b2.dgrad(g_a1, g_a0, mask=S["a0"])
-        b0.wgrad(S["x8"], g_a0)
+        wgrad_or_tail(b0, S["x8"], g_a0, 0)
+        for layer, x, g in reversed(tail):               # (newest gradient first: its operands are the hottest in L2)
+            layer._wgrad(x, g, 1, False)
+            self._ready(layer.name)
         ops.AFTER_GEMM = None
         if self.wgrad_stream is not None and self._pending_wgrad:
             self._flush_wgrad(everything=True)
