@@ -122,6 +122,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-x6-leg", action="store_true", help="skip the leg with the Winograd-domain GEMMs on the bf16 matrix pipe")
     ap.add_argument("--no-direct-leg", action="store_true", help="skip the short direct-convolution leg")
     ap.add_argument("--no-c5", action="store_true", help="skip the short config-5 (GAN iteration) leg")
+    ap.add_argument("--c3-sustained", type=int, default=100,
+                    help="steps of the sustained config-3 measurement (c3.ms_per_step_sustained: one timed region of this many steps right after "
+                         "the c3 leg's own --steps; 0 = skip)")
     ap.add_argument("--no-h2d-leg", action="store_true", help="skip the short host-fed leg")
     ap.add_argument("--lpips-dtype", choices=("bf16", "fp32"), default="bf16",
                     help="arithmetic of the LPIPS / VGG-16 branch (BASELINE config 3 = bf16)")
@@ -326,6 +329,11 @@ def main():
                 "algorithmic_gflop_per_launch": round(d["flops_per_launch"] / 1e9, 3),
                 "share_of_step_time": round(d["total_ms"] / (ms_serial * steps), 4)}
 
+    # every leg below honours --steps / --warmup (they ran 5-step bursts after 1-2 warm-ups of a fresh engine, whose
+    # Winograd filter banks and workspaces are made lazily -- the host-fed leg came out "faster than resident").  At least 3 warm-ups
+    # after every fresh engine.
+    k_leg, w_leg = max(2, args.steps), max(3, args.warmup)
+
     # ------------------------------------------------------------------ the timed workload
     eng, trainer = make_trainer(winograd=not args.direct_conv, perceptual=args.perceptual, dtype=args.vqvae_dtype)
     issued0 = abi_comm.issued if abi_comm is not None else 0
@@ -432,8 +440,8 @@ def main():
     # ------------------------------------------------------------------ the same step on direct convolutions
     if winograd_on and not args.no_direct_leg and not args.no_kernel_events and not args.perceptual and args.vqvae_dtype == "fp32":
         eng_d, tr_d = make_trainer(winograd=False)
-        k_d = max(2, min(args.steps, 5))
-        dt_d, _, _ = timed(tr_d, k_d, 2)
+        k_d = k_leg
+        dt_d, _, _ = timed(tr_d, k_d, w_leg)
         summ_d, ms_serial_d = per_kernel(eng_d, tr_d, k_d)
         dd = dominant(summ_d, k_d, ms_serial_d)
         dd.pop("traffic")
@@ -457,8 +465,8 @@ def main():
     if winograd_on and not args.no_x6_leg and not args.perceptual and not ops.BF16X6 and args.vqvae_dtype == "fp32":
         ops.BF16X6 = True
         eng_x, tr_x = make_trainer(winograd=True)
-        k_x = max(2, min(args.steps, 5))
-        dt_x, _, (r_x, l_x, _) = timed(tr_x, k_x, 2)
+        k_x = k_leg
+        dt_x, _, (r_x, l_x, _) = timed(tr_x, k_x, w_leg)
         kern_x = None
         if not args.no_kernel_events:
             summ_x, _ = per_kernel(eng_x, tr_x, k_x)
@@ -477,7 +485,7 @@ def main():
                      "(csrc/wino_wgrad_split.hip) -- form each fp32 product as six bf16 MFMA partial products of an exact three-way "
                      "bf16 split of both operands, accumulated in fp32: relative error 2^-23 per product (tests/test_split_gpu.py: "
                      "closer to an fp64 product than the fp32 MFMA kernels). Everything else unchanged."),
-            "value": round(world * frames * k_x / dt_x, 2), "unit": "frames/s", "ms_per_step": round(dt_x / k_x * 1e3, 3), "steps": k_x, "warmup": 2,
+            "value": round(world * frames * k_x / dt_x, 2), "unit": "frames/s", "ms_per_step": round(dt_x / k_x * 1e3, 3), "steps": k_x, "warmup": w_leg,
             "loss": {"recon": round(r_x.item(), 6), "latent": round(l_x.item(), 6)}}
         if kern_x:
             out["bf16x6"]["kernels"] = kern_x
@@ -491,16 +499,23 @@ def main():
     if not args.no_c3 and not args.perceptual and not args.direct_conv:
         ideal_c = lambda vq_peak: FLOP_PER_FRAME / (vq_peak * 1e12) + LPIPS_FLOP_PER_FRAME / (
             (BF16_MFMA_PEAK_TFLOPS if args.lpips_dtype == "bf16" else FP32_MFMA_PEAK_TFLOPS) * 1e12)
-        k_c = max(2, min(args.steps, 5))
+        k_c = k_leg
         eng_c, tr_c = make_trainer(perceptual=True, dtype="bf16")
-        dt_c, _, (r_c, l_c, p_c) = timed(tr_c, k_c, 2)
+        dt_c, _, (r_c, l_c, p_c) = timed(tr_c, k_c, w_leg)
         fps_c = world * frames * k_c / dt_c
         out["c3"] = {"workload": f"C3: C2 + LPIPS/VGG-16 perceptual loss, bf16 MFMA operands / fp32 accumulate & master weights for the VQ-VAE and the LPIPS "
                                  f"branch alike (fp32 VQ, losses, Adam; seeded VGG weights), {H}x{H}, T={T}, {B} clips/GPU",
-                     "value": round(fps_c, 2), "unit": "frames/s", "ms_per_step": round(dt_c / k_c * 1e3, 3), "steps": k_c, "warmup": 2,
+                     "value": round(fps_c, 2), "unit": "frames/s", "ms_per_step": round(dt_c / k_c * 1e3, 3), "steps": k_c, "warmup": w_leg,
                      "dtype": "bf16 (VQ-VAE convolutions and LPIPS: bf16 operands, fp32 accumulate; VQ, losses, master weights, Adam fp32)",
                      "speed_vs_ideal_direct_conv": round(ideal_c(BF16_MFMA_PEAK_TFLOPS) * fps_c / world, 4),
                      "loss": {"recon": round(r_c.item(), 6), "latent": round(l_c.item(), 6), "perceptual": round(p_c.item(), 6)}}
+        if args.c3_sustained > 0:
+            # a --steps burst right after the warm-ups runs at the clock the chip still holds; over 100+ steps it settles ~2 % lower
+            # (tools/soak_c3.py: 35.6 ms sustained where the 5-step burst of round 4 printed 34.9): both are on the line
+            dt_s, _, _ = timed(tr_c, args.c3_sustained, 0)
+            out["c3"]["ms_per_step_sustained"] = round(dt_s / args.c3_sustained * 1e3, 3)
+            out["c3"]["value_sustained"] = round(world * frames * args.c3_sustained / dt_s, 2)
+            out["c3"]["sustained_steps"] = args.c3_sustained
         if not args.no_kernel_events:
             summ_c, ms_serial_c = per_kernel(eng_c, tr_c, k_c)
             rc = dominant(summ_c, k_c, ms_serial_c)
@@ -528,7 +543,7 @@ def main():
         torch.cuda.empty_cache()
         # the bf16 VQ-VAE step alone (recon + VQ loss, no LPIPS): what the bf16 matrix pipe does to config 2's workload
         eng_b, tr_b = make_trainer(dtype="bf16")
-        dt_b, _, (r_b, l_b, _) = timed(tr_b, k_c, 2)
+        dt_b, _, (r_b, l_b, _) = timed(tr_b, k_c, w_leg)
         out["c3"]["vqvae_only_bf16"] = {"value": round(world * frames * k_c / dt_b, 2), "unit": "frames/s", "ms_per_step": round(dt_b / k_c * 1e3, 3),
                                         "loss": {"recon": round(r_b.item(), 6), "latent": round(l_b.item(), 6)},
                                         "note": "config 2's step with bf16 MFMA operands (no LPIPS); `value` of this line stays the fp32 step"}
@@ -536,7 +551,7 @@ def main():
         torch.cuda.empty_cache()
         # round 2's form of config 3: fp32 VQ-VAE + bf16 LPIPS
         eng_f, tr_f = make_trainer(winograd=True, perceptual=True)
-        dt_f, _, (r_f, l_f, p_f) = timed(tr_f, k_c, 2)
+        dt_f, _, (r_f, l_f, p_f) = timed(tr_f, k_c, w_leg)
         out["c3"]["fp32_vqvae"] = {"value": round(world * frames * k_c / dt_f, 2), "unit": "frames/s", "ms_per_step": round(dt_f / k_c * 1e3, 3),
                                    "dtype": "f32 (VQ-VAE) + %s (LPIPS)" % args.lpips_dtype,
                                    "loss": {"recon": round(r_f.item(), 6), "latent": round(l_f.item(), 6), "perceptual": round(p_f.item(), 6)}}
@@ -548,13 +563,13 @@ def main():
     # yields them) are copied by faceoff_amd.feeder.HostFedBatches on a copy stream beside the previous step: 377 MB per step over PCIe
     if not args.no_h2d_leg and not args.perceptual and not args.direct_conv:
         eng_h, tr_h = make_trainer(winograd=True)
-        k_h = max(2, min(args.steps, 5))
+        k_h = k_leg
         gcpu = torch.Generator().manual_seed(4321 + rank)
         host = [tuple((torch.rand((B, T, 3, H, H), generator=gcpu) * 2 - 1).pin_memory() if i != 4 else torch.empty(0) for i in range(5)) for _ in range(2)]
-        loader = [host[i % 2] for i in range(3 + k_h)]
+        loader = [host[i % 2] for i in range(w_leg + k_h)]
         sync()
         it = tr_h.run_host_fed(loader)
-        for _ in range(3):
+        for _ in range(w_leg):
             next(it)
         sync()
         t0 = time.perf_counter()
@@ -564,10 +579,10 @@ def main():
         dt_h = max_over_ranks(time.perf_counter() - t0)
         it.close()
         # the same trainer, same process state, with its inputs resident: the ratio of the two is the cost of feeding
-        dt_r, _, _ = timed(tr_h, k_h, 1)
+        dt_r, _, _ = timed(tr_h, k_h, w_leg)
         out["h2d_fed"] = {"what": "the headline step with every batch copied from pinned host memory (source, background, source_images: "
                                   f"{3 * frames * 3 * H * H * 4 / 1e6:.0f} MB per step) by a double-buffered copy stream beside the previous step; `value` keeps inputs resident",
-                          "value": round(world * frames * k_h / dt_h, 2), "unit": "frames/s", "ms_per_step": round(dt_h / k_h * 1e3, 3), "steps": k_h,
+                          "value": round(world * frames * k_h / dt_h, 2), "unit": "frames/s", "ms_per_step": round(dt_h / k_h * 1e3, 3), "steps": k_h, "warmup": w_leg,
                           "resident_ms_per_step_same_trainer": round(dt_r / k_h * 1e3, 3), "slowdown_vs_resident": round(dt_h / dt_r - 1.0, 4),
                           "loss": {"recon": round(r_h.item(), 6), "latent": round(l_h.item(), 6)}}
         del eng_h, tr_h, host, loader
@@ -584,11 +599,11 @@ def main():
         gan = GANTrainer(eng_g, DiscEngine(make_disc_state(1, 3), dev, dims=3, n_frames=win - 1), DiscEngine(make_disc_state(2, 2), dev, dims=2),
                          window=win, rng=_random.Random(7 + rank), comm=abi_comm)
         cimg, cgt = img[:clip].contiguous(), gt[:clip].contiguous()
-        for _ in range(2):
+        iters = 2 * ((k_leg + 1) // 2)          # generator and discriminator iterations alternate: an even count, --steps of them
+        for _ in range(2 * ((w_leg + 1) // 2)):
             gan.step(cimg, cgt)
         sync()
         t0 = time.perf_counter()
-        iters = 6                     # 3 generator + 3 discriminator iterations
         for _ in range(iters):
             o5 = gan.step(cimg, cgt)
         sync()
@@ -596,7 +611,7 @@ def main():
         out["c5"] = {"workload": f"C5: GAN iteration of disc_trainers/train_vqvae_mocoganhd_disc.py on one {clip}-frame clip per GPU, {H}x{H}: "
                                  f"VQ-VAE generator + MoCoGAN-HD video (15 frame pairs) and image discriminators, RaLSGAN, alternating G / D updates",
                      "value": round(world * clip * iters / dt5, 2), "unit": "frames/s", "ms_per_iteration": round(dt5 / iters * 1e3, 3),
-                     "iterations": iters, "dtype": "f32", "loss": {k: round(v.item(), 6) for k, v in o5.items()}}
+                     "iterations": iters, "warmup": 2 * ((w_leg + 1) // 2), "dtype": "f32", "loss": {k: round(v.item(), 6) for k, v in o5.items()}}
         if not args.no_kernel_events:
             # per-kernel timing as for `roofline`: side streams folded, HIP events per launch, two generator + two discriminator iterations
             eng_g.set_stream_overlap(False)

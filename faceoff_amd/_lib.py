@@ -12,6 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FACEOFF_HIP_LIB", os.path.join(_HERE, "libfaceoff_hip.so"))   # override: A/B kernel builds
 
+ABI_VERSION = 101          # == FO_ABI_VERSION of include/faceoff_hip.h (tests/test_host_cpu.py reads the header); load() refuses any other library
 FO_IN_RELU, FO_BIAS, FO_MASK, FO_ADD, FO_OUT_RELU, FO_DEPTH2SPACE, FO_OUT_F32 = 1, 2, 4, 8, 16, 32, 64
 
 
@@ -222,6 +223,11 @@ def load():
         fn = getattr(lib, name)   # AttributeError if the .so is stale
         fn.restype = res
         fn.argtypes = args
+    got = lib.fo_version()
+    if got != ABI_VERSION:
+        raise FaceoffHipError(
+            f"{LIB_PATH} reports ABI version {got}, this binding is written against {ABI_VERSION} (include/faceoff_hip.h FO_ABI_VERSION): "
+            "argument lists differ between the two -- rebuild the library from this tree (`make -C faceoff_amd/csrc`).")
     _lib = lib
     return lib
 

@@ -44,7 +44,7 @@ int fo_cu_count() {
 }
 
 extern "C" {
-int fo_version(void) { return 100; }
+int fo_version(void) { return FO_ABI_VERSION; }
 const char* fo_last_error(void) { return g_err; }
 int fo_kernel_notes(int enable) { return faceoff_notes_on.exchange(enable ? 1 : 0); }
 const char* fo_last_kernel(void) {

@@ -52,6 +52,11 @@ extern "C" {
 #define FO_OUT_F32 64  /* fo_conv_bf16 only: the result is stored as fp32 (ldOut in floats) instead of being rounded to bf16 -- the
                           quantisers' inputs (quantize_conv_t / _b, :208,213: VQ distances and arg-min stay fp32) and the decoder output */
 
+/* ABI version: bumped whenever an exported signature or the meaning of an argument changes (101: the loss kernels take a caller-owned
+   partial-sum workspace `ws` in front of `stream` and OVERWRITE their scalars -- round 4).  The Python binding refuses a library whose
+   fo_version() differs from the FO_ABI_VERSION it was written against (faceoff_amd/_lib.py), so an older .so handed in through
+   FACEOFF_HIP_LIB is a clean error and not a stream pointer read as a workspace. */
+#define FO_ABI_VERSION 101
 int fo_version(void);
 const char* fo_last_error(void);
 /* Kernel notes (measurement plumbing, off by default).  fo_kernel_notes(1): from now on every entry point records the symbol of the MAIN kernel

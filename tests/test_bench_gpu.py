@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_bench_emits_one_valid_json_line():
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--c3-sustained", "6"],
                          capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
@@ -42,6 +42,10 @@ def test_bench_emits_one_valid_json_line():
     # comparison steps (bf16 VQ-VAE without LPIPS; round 2's fp32 VQ-VAE + bf16 LPIPS)
     c3 = d["c3"]
     assert c3["value"] > 0 and abs(c3["value"] - 160 / (c3["ms_per_step"] * 1e-3)) < 1e-2 * c3["value"] and c3["dtype"].startswith("bf16")
+    # every leg honours --steps (and warms a fresh engine at least three times); config 3 also carries a sustained figure
+    assert c3["steps"] == 2 and c3["warmup"] == 3 and d["h2d_fed"]["steps"] == 2 and d["bf16x6"]["steps"] == 2 and d["roofline"]["direct_conv"]["steps"] == 2
+    assert c3["sustained_steps"] == 6 and 0.7 * c3["ms_per_step"] < c3["ms_per_step_sustained"] < 1.3 * c3["ms_per_step"]
+    assert d["c5"]["iterations"] == 2 and d["c5"]["warmup"] == 4
     r3 = c3["roofline"]
     assert r3["peak"] == 2500.0 and r3["bound"] == "mfma" and 0 < r3["frac"] <= 1.0 and abs(r3["frac"] - r3["achieved"] / r3["peak"]) < 1e-3
     assert c3["vqvae_only_bf16"]["value"] > c3["value"] and c3["fp32_vqvae"]["value"] > 0

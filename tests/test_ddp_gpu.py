@@ -31,7 +31,8 @@ def _worker(outdir, own_device=False):
     sl = slice(rank * B, (rank + 1) * B)
     recon, latent, _ = tr.step(torch.from_numpy(img[sl]).cuda(), torch.from_numpy(gt[sl]).cuda())
     torch.cuda.synchronize()
-    torch.save({"params": eng.flat_params.cpu(), "grads": eng.flat_grads.cpu(),
+    torch.save({"params": eng.flat_params.cpu(), "grads": eng.flat_grads.cpu(), "offsets": dict(eng.offsets),
+                "buffers": {k: v.cpu() for k, v in eng.buffers.items()}, "ids": tuple(t.cpu() for t in tr.last_ids),
                 "embed_b": eng.buffers["quantize_b.embed"].cpu(), "recon": recon.cpu(), "latent": latent.cpu()},
                os.path.join(outdir, f"rank{rank}.pt"))
 
@@ -95,6 +96,35 @@ def _two_ranks_vs_serial(backend):
     assert dpar.max().item() <= 2.1 * 3e-4, dpar.max().item()
     assert off.float().mean().item() < 1e-3, off.float().mean().item()
     assert (g_serial.abs()[off] <= 1e-3 * g_serial.abs().max()).all()
+    _two_ranks_vs_oracle(r, sd, img, gt)
+
+
+def _two_ranks_vs_oracle(r, sd, img, gt):
+    """The third party: the data-parallel step against the CPU ORACLE, not only against the engine's own serial step.
+    What two ranks compute is, by the reference's semantics, one step on the concatenated batch: DDP averages the per-rank gradients of
+    per-rank MEAN losses over equal shards (= the gradient of the global mean, train_faceoff_perceptual.py:164-169) and Quantize sums its
+    EMA statistics over the ranks before the update (vqvae_conv3d_latent.py:59-64: oracle.quantize_forward's `all_reduce` argument is that
+    sum; on the concatenated batch the oracle forms the same global statistics directly).  So oracle.train_step on all 2B clips gives the
+    gradients (arena / 2), the six EMA buffers and the mean of the two ranks' losses, each at the north-star 1e-3."""
+    from oracle import faceoff_oracle as O
+    p = O.to_torch_state(sd)
+    o = O.train_step(torch.from_numpy(img), torch.from_numpy(gt), p)
+    ids = [torch.cat([r[i]["ids"][l] for i in range(2)]) for l in range(2)]          # rank-major = batch order
+    assert torch.equal(ids[0], o["fw"]["id_t"]) and torch.equal(ids[1], o["fw"]["id_b"]), "two-rank code indices differ from the oracle's"
+    np.testing.assert_allclose((r[0]["recon"] + r[1]["recon"]).item() / 2, o["recon"].item(), rtol=1e-3)
+    np.testing.assert_allclose((r[0]["latent"] + r[1]["latent"]).item() / 2, o["latent"].item(), rtol=1e-3)
+    worst = (0.0, "")
+    for n, g in o["grads"].items():
+        off, cnt = r[0]["offsets"][n]
+        got = r[0]["grads"][off:off + cnt].reshape(g.shape) / 2
+        err = (got - g).abs().max().item() / (g.abs().max().item() + 1e-30)
+        worst = max(worst, (err, n))
+        assert err <= 1e-3, (n, err)
+    for k, v in r[0]["buffers"].items():                      # `p` holds the oracle's post-EMA buffers (global statistics)
+        assert torch.equal(v, r[1]["buffers"][k]), k
+        err = (v - p[k]).abs().max().item() / (p[k].abs().max().item() + 1e-30)
+        assert err <= 1e-3, (k, err)
+    print(f"[two ranks vs CPU oracle on the concatenated batch] code indices equal; worst gradient rel err {worst}")
 
 
 _RCCL_SCRIPT = r"""

@@ -123,3 +123,13 @@ def test_module_wrapped_in_torch_ddp_averages_gradients_and_sums_vq_statistics()
         assert torch.equal(r[0]["grads"][k], r[1]["grads"][k]), k
         assert (r[0]["grads"][k] - want).abs().max().item() <= 1e-5 * want.abs().max().item() + 1e-12, k
     assert torch.equal(r[0]["embed_b"], r[1]["embed_b"])
+    # ... and against the CPU ORACLE on the two clips as one batch: DDP's average of two per-clip mean losses is the
+    # gradient of the global mean, and the in-forward all-reduce makes the EMA statistics those of both clips (vqvae_conv3d_latent.py:59-64)
+    from oracle import faceoff_oracle as O
+    p = O.to_torch_state(sd)
+    o = O.train_step(torch.from_numpy(img), torch.from_numpy(gt), p)
+    worst = max(((r[0]["grads"][k] - g).abs().max().item() / (g.abs().max().item() + 1e-30), k) for k, g in o["grads"].items())
+    print(f"[DDP-wrapped module, two ranks vs CPU oracle on both clips] worst gradient rel err {worst}")
+    assert worst[0] <= 1e-3, worst
+    e = p["quantize_b.embed"]
+    assert (r[0]["embed_b"] - e).abs().max().item() <= 1e-3 * e.abs().max().item()

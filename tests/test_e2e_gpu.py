@@ -28,7 +28,8 @@ def _rel(got, want):
     return np.abs(got - want).max() / (np.abs(want).max() + 1e-30)
 
 
-def _engine_step(g, T=None):
+def _engine_step(g, T=None, forced=False):
+    """forced: the engine runs on the REFERENCE's code indices (VQVAEEngine.forward(force_ids=...): the search is skipped)"""
     from faceoff_amd.engine import VQVAEEngine
     B, T_, H, W = (int(g[k]) for k in "BTHW")
     sd = golden_state(g)
@@ -36,44 +37,69 @@ def _engine_step(g, T=None):
     img, gt = make_batch(int(g["seed_x"]), B, T_, H, W)
     img = torch.from_numpy(img).reshape(B * T_, 6, H, W).cuda()
     gt = torch.from_numpy(gt).reshape(B * T_, 3, H, W).cuda()
-    recon, diff, S = eng.loss_and_backward(img, gt, T=T or T_)
+    force = None
+    if forced:
+        force = tuple(torch.from_numpy(g["id_" + l].astype(np.int64)).reshape(B * T_, H // s, W // s).cuda() for l, s in (("t", 8), ("b", 4)))
+    recon, diff, S = eng.loss_and_backward(img, gt, T=T or T_, force_ids=force)
     torch.cuda.synchronize()
     return eng, recon, diff, S, img, gt
 
 
+def _dilate(m, r):
+    return torch.nn.functional.max_pool2d(m.float().unsqueeze(1), 2 * r + 1, 1, r).squeeze(1) > 0
+
+
+def _outside_flipped_receptive_fields(bad_t, bad_b):
+    """bool [N,H,W] at image resolution: the pixels of `dec` no flipped code can reach (derivation: tests/test_bf16_engine_gpu.py -- a top
+    code enters through upsample_t's k4 s2 p1, then three 3x3 stages + one latent pixel per transposed stage: 5 latent pixels each side)."""
+    up = _dilate(bad_t, 1).repeat_interleave(2, 1).repeat_interleave(2, 2)
+    reach = _dilate(bad_b | up, 5)
+    return ~reach.repeat_interleave(4, 1).repeat_interleave(4, 2)
+
+
 def _check_against_golden(g, eng, recon, diff, S, literal=False, what="", expect_flips=None, tol0=1e-3):
-    """Bounds: 1e-3 of each tensor's scale (BASELINE.json north_star) whenever every code index equals the reference's.
-    An index may differ only where the REFERENCE's own top-2 distance margin is below 1e-4 (an fp32 near-tie: any
-    summation order may flip it); a flipped code changes `dec` locally by O(1), so only then the bounds widen."""
+    """Bounds: 1e-3 of each tensor's scale (BASELINE.json north_star), always.  An index may differ only where the REFERENCE's own top-2
+    distance margin is below 1e-4 (an fp32 near-tie: any summation order may flip it).  A flipped code changes `dec` locally by O(1), so
+    when that happens nothing is widened (round 4 had a 1e-1 fallback here): `dec` is held to the same bound OUTSIDE the flipped codes'
+    receptive fields, and losses, all 70 gradients and the EMA buffers are checked on a second step that runs on the reference's codes
+    (teacher-forced: the search is skipped, everything else is the same launches)."""
     from faceoff_amd import ops
     dec = ops.nhwc_to_nchw(S["dec"], 6)
-    flips = 0
+    flips, bad = 0, {}
     for lvl in "tb":
         got = S["id_" + lvl].cpu().numpy().astype(np.int16).reshape(-1)
-        bad = got != g["id_" + lvl].reshape(-1)
-        assert np.all(g["margin_" + lvl][bad] < 1e-4), f"id_{lvl}: {int(bad.sum())} mismatches outside the near-tie gate"
-        assert bad.mean() < 2e-3
-        flips += int(bad.sum())
+        b = got != g["id_" + lvl].reshape(-1)
+        assert np.all(g["margin_" + lvl][b] < 1e-4), f"id_{lvl}: {int(b.sum())} mismatches outside the near-tie gate"
+        assert b.mean() < 2e-3
+        flips += int(b.sum())
+        bad[lvl] = torch.from_numpy(b).reshape(S["id_" + lvl].shape)
     # the fixtures whose reference margins leave no near-tie (b1_literal, c1, c1w: smallest top-2 margin >> fp32 error) must
-    # reproduce EVERY index: a flip there is a bug, not rounding, and the widened bounds below must never apply to them
+    # reproduce EVERY index: a flip there is a bug, not rounding
     if expect_flips is not None:
         assert flips == expect_flips, f"{what}: {flips} code-index flips, expected {expect_flips}"
-    tol = tol0 if flips == 0 else 1e-1           # one flipped code moves a first-layer gradient by a few per cent
-    got_dec = dec.cpu().numpy() if g["dec"].ndim == 4 else _sub(dec)
-    obs = {"dec": _rel(got_dec, g["dec"])}
-    if flips == 0:
-        assert obs["dec"] < tol0
-    else:   # a flipped top-level code reaches a 40x40-pixel patch of one 64x64 frame through dec_t + dec
-        frac_bad = (np.abs(got_dec - g["dec"]) > 1e-3 * np.abs(g["dec"]).max()).mean()
-        assert frac_bad < 0.12 * flips, (flips, frac_bad)
+    keep = _outside_flipped_receptive_fields(bad["t"], bad["b"]).unsqueeze(1).expand(-1, 6, -1, -1)
+    assert keep.float().mean().item() > 0.5, "the flipped codes' receptive fields cover most of the fixture"
+    if g["dec"].ndim == 4:
+        got_dec, want_dec, keep = dec.cpu().numpy(), g["dec"], keep.numpy()
+    else:
+        got_dec, want_dec, keep = _sub(dec), g["dec"], keep.reshape(-1)[::SUB].numpy()
+    obs = {"dec": float(np.abs(got_dec - want_dec)[keep].max() / (np.abs(want_dec).max() + 1e-30))}
+    assert obs["dec"] < tol0, obs
+    if flips:
+        eng, recon, diff, S, *_ = _engine_step(g, forced=True)
+        assert all(np.array_equal(S["id_" + lvl].cpu().numpy().reshape(-1), g["id_" + lvl].reshape(-1)) for lvl in "tb")
+        dec = ops.nhwc_to_nchw(S["dec"], 6)
+        obs["dec_forced"] = _rel(dec.cpu().numpy() if g["dec"].ndim == 4 else _sub(dec), g["dec"])
+        assert obs["dec_forced"] < tol0, obs
+    tol = tol0
     np.testing.assert_allclose(recon.item(), float(g["recon"]), rtol=1e-3)
     np.testing.assert_allclose(diff.item(), float(g["latent"]), rtol=1e-3)
     names = [str(n) for n in g["param_names"]]
     gs = np.stack([_stats(eng.grads[n]) for n in names])
     l2, want_l2 = np.sqrt(gs[:, 1]), np.sqrt(g["grad_stats"][:, 1])
     obs["grad_l2"] = float(np.max(np.abs(l2 - want_l2) / want_l2))
-    bad = [(n, a, b) for n, a, b in zip(names, l2, want_l2) if abs(a - b) > tol * abs(b)]
-    assert not bad, f"gradient L2 norms off: {bad}"
+    off_l2 = [(n, a, b) for n, a, b in zip(names, l2, want_l2) if abs(a - b) > tol * abs(b)]
+    assert not off_l2, f"gradient L2 norms off: {off_l2}"
     # every tensor's strided subsample against the tensor's own scale
     off, worst = 0, (0.0, "")
     for i, n in enumerate(names):
@@ -87,10 +113,10 @@ def _check_against_golden(g, eng, recon, diff, S, literal=False, what="", expect
     obs["grad_sub"] = worst
     for n in names:
         if "grad_full." + n in g.files:
-            assert _rel(eng.grads[n].cpu().numpy(), g["grad_full." + n]) < (tol0 if flips == 0 else 0.1), n
+            assert _rel(eng.grads[n].cpu().numpy(), g["grad_full." + n]) < tol0, n
     for k, b in eng.buffers.items():
-        np.testing.assert_allclose(_stats(b)[1], g["buf_stats." + k][1], rtol=1e-3 if flips == 0 else 2e-3)
-    print(f"[parity {what}] index flips {flips}; observed max rel err: {obs}")
+        np.testing.assert_allclose(_stats(b)[1], g["buf_stats." + k][1], rtol=1e-3)
+    print(f"[parity {what}] index flips {flips}{' (gradients / buffers from the step on the reference codes)' if flips else ''}; observed max rel err: {obs}")
     return flips, obs
 
 
@@ -191,9 +217,12 @@ def test_e2e_vs_oracle_ragged():
         margin = O.vq_margin(r["fw"][f"q{lvl}_in"].detach(), torch.from_numpy(sd[f"quantize_{lvl}.embed"]))
         assert bool((margin[bad] < 1e-4).all()) and bad.float().mean().item() < 2e-3, (lvl, int(bad.sum()))
         flips += int(bad.sum())
-    if flips == 0:
-        assert _rel(dec.numpy(), r["fw"]["dec"].detach().numpy()) < 1e-3
-    tol, worst = (1e-3 if flips == 0 else 2e-2), (0.0, "")
+    if flips:          # never a wider bound: the step again on the oracle's codes (teacher-forced), then everything at 1e-3
+        eng = VQVAEEngine(sd, "cuda:0")
+        recon, diff, S = eng.loss_and_backward(x, y, T=T, force_ids=(r["fw"]["id_t"].cuda(), r["fw"]["id_b"].cuda()))
+        dec = ops.nhwc_to_nchw(S["dec"], 6).cpu()
+    assert _rel(dec.numpy(), r["fw"]["dec"].detach().numpy()) < 1e-3
+    tol, worst = 1e-3, (0.0, "")
     for n, gref in r["grads"].items():
         got = eng.grads[n].cpu().numpy()
         rms = gref.pow(2).mean().sqrt().item()
@@ -201,7 +230,7 @@ def test_e2e_vs_oracle_ragged():
         worst = max(worst, (float(err), n))
         assert err <= tol, (n, err)
     for k in eng.buffers:
-        assert _rel(eng.buffers[k].cpu().numpy(), p[k].numpy()) < (1e-3 if flips == 0 else 2e-2), k
+        assert _rel(eng.buffers[k].cpu().numpy(), p[k].numpy()) < 1e-3, k
     print(f"[parity ragged] index flips {flips}; worst gradient rel err {worst}")
 
 

@@ -27,7 +27,26 @@ def test_library_exports_every_declared_symbol():
     nm = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
     exported = sorted(ln.split()[-1] for ln in nm.splitlines() if ln.strip())
     assert exported == declared, set(exported) ^ set(declared)
-    assert _lib.load().fo_version() >= 100            # no compute calls without a GPU
+    assert _lib.load().fo_version() == _lib.ABI_VERSION            # no compute calls without a GPU
+    assert int(re.search(r"#define\s+FO_ABI_VERSION\s+(\d+)", hdr).group(1)) == _lib.ABI_VERSION
+
+
+def test_binding_refuses_a_library_of_another_abi_version(tmp_path):
+    """signatures changed (the loss kernels' `ws` argument) while fo_version() still said 100 -- an older .so handed in through
+    FACEOFF_HIP_LIB would have read a stream pointer as a workspace.  Now the version is part of the contract: a library whose
+    fo_version() is not the binding's ABI_VERSION is refused at load time (checked here with a stub library, in a fresh interpreter)."""
+    import subprocess
+    import sys
+    from faceoff_amd import _lib
+    src = tmp_path / "stub.c"
+    names = [n for n in _lib.SIGNATURES if n != "fo_version"]
+    src.write_text("int fo_version(void) { return 100; }\n" + "".join(f"int {n}(void) {{ return 0; }}\n" for n in names))
+    so = tmp_path / "libstub.so"
+    subprocess.run(["gcc", "-shared", "-fPIC", str(src), "-o", str(so)], check=True)
+    code = ("import sys; sys.path.insert(0, %r)\nfrom faceoff_amd import _lib\n"
+            "try:\n    _lib.load()\nexcept _lib.FaceoffHipError as e:\n    print('REFUSED', e)\n" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, FACEOFF_HIP_LIB=str(so)), timeout=300)
+    assert "REFUSED" in out.stdout and "ABI version 100" in out.stdout, (out.stdout, out.stderr[-500:])
 
 
 def test_state_dict_layout_matches_reference_inventory():
