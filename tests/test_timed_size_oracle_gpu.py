@@ -139,8 +139,8 @@ def test_c3_as_timed_full_size_teacher_forced_vs_cpu_oracle():
           f"(oracle {ref['recon']:.6f} / {ref['latent']:.6f} / {ref['perceptual']:.6f}); gradients rel-L2: worst {errs[0]}, second {errs[1]}, "
           f"median {errs[len(errs) // 2][0]:.3e}, best {errs[-1]}")
     obs = Observed(f"c3_as_timed_full_{B}x{T}x{H}x{W}")
-    for e, n in errs:
-        obs.check("grad:" + n, e, cap=8e-2)
+    for e, n in errs:       # recorded (profiles/r05_parity_timed_size.log): worst 2.3e-3 (enc_b.blocks.0.weight), median 8e-5 -- the cap is 4x the worst
+        obs.check("grad:" + n, e, cap=1e-2)
     for k, v in ref["buffers"].items():
         obs.check("buf:" + k, rl2(eng.buffers[k].cpu(), v), cap=5e-3)
     obs.flush()
