@@ -636,6 +636,17 @@ def main():
             r5["measured"] = ("HIP events per launch over 2 generator + 2 discriminator iterations with the side streams joined; algorithmic FLOP of the launches "
                               "(taps that only reach padding excluded) against the fp32 MFMA peak")
             r5["ms_per_iteration_serial"] = round(ms_serial5, 3)
+            pmc5 = os.path.join(ROOT, "profiles", "pmc_traffic_c5.json")        # CONFIG=c5 bash profiles/collect.sh <tag>: the counters on tools/bench_gan.py --serial
+            if os.path.exists(pmc5):
+                try:
+                    tj = json.load(open(pmc5))
+                    from faceoff_amd._lib import kernel_source_sha16
+                    r5["traffic"] = tj.get(r5["kernel"])
+                    r5["traffic_source"] = (f"HBM bytes per launch from the committed rocprofv3 --pmc passes ({tj.get('_source')}), measured on kernel sources "
+                                            f"{tj.get('_kernel_source_sha16')}" + (" = this run's sources" if tj.get("_kernel_source_sha16") == kernel_source_sha16()
+                                                                                    else f", this run's sources {kernel_source_sha16()}"))
+                except Exception:
+                    pass
             out["c5"]["roofline"] = r5
             out["c5"]["kernels"] = {k: {"launches_per_iteration": v["launches"] / k5, "avg_ms": round(v["avg_ms"], 4), "tflops": round(v["tflops"], 2),
                                         "tflops_padded_taps_counted": round(v["tflops_nominal"], 2), "ms_per_iteration": round(v["total_ms"] / k5, 3)}

@@ -242,7 +242,10 @@ class LPIPSEngine:
             # in a fixed order afterwards, so the loss does not depend on how the streams interleave.
             import os as _os
             main = torch.cuda.current_stream(self.device)
-            overlap = not _os.environ.get("FACEOFF_NO_LPIPS_HEAD_OVERLAP")
+            # (head_overlap: the trainer switches it off together with the engine's side streams -- bench.py's per-kernel region and
+            # `--serial-streams` traces want every launch alone on the GPU; round 4's profiles had conv5_x's data gradients stretched 2.5-7x
+            # by the heads running beside them, which the serialised --pmc passes did not show)
+            overlap = getattr(self, "head_overlap", True) and not _os.environ.get("FACEOFF_NO_LPIPS_HEAD_OVERLAP")
             if overlap and getattr(self, "_head_stream", None) is None:
                 self._head_stream = torch.cuda.Stream(device=self.device)
             vals = torch.zeros((5, N), device=self.device)

@@ -119,6 +119,7 @@ class FaceOffTrainer:
         if self.vqlpips is not None:
             if taps0 is not None:
                 torch.cuda.current_stream().wait_stream(self.lpips_stream)
+            self.vqlpips._bind(dec.device).head_overlap = eng.wgrad_stream is not None      # side streams folded (set_stream_overlap(False)): the heads too
             perceptual = self.vqlpips.loss_and_grad(ground_truth, dec, g_dec, PERCEPTUAL_LOSS_WEIGHT, taps0=taps0)
         eng.backward(S, g_dec, one * LATENT_LOSS_WEIGHT)
         if self.reducer is not None:

@@ -18,6 +18,10 @@ BENCH="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-event
 if [ "${CONFIG:-c2}" = "c3" ]; then
   BENCH="python3 bench.py --steps 2 --warmup 1 --perceptual --vqvae-dtype bf16 --no-cpu-baseline --no-kernel-events --no-c5 --no-h2d-leg --serial-streams"
 fi
+# config 5 (GAN iteration, one 30-frame clip), side streams folded:  CONFIG=c5 bash profiles/collect.sh r05_c5
+if [ "${CONFIG:-c2}" = "c5" ]; then
+  BENCH="python3 tools/bench_gan.py 6 --serial"
+fi
 
 if [ "$WHAT" = "trace" ] || [ "$WHAT" = "all" ]; then
   rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace -- $BENCH > "$OUT/trace.log" 2>&1
@@ -31,4 +35,5 @@ if [ "$WHAT" = "pmc" ] || [ "$WHAT" = "all" ]; then
   rocprofv3 --kernel-trace --output-format csv -d "$OUT/pmc_l2" -o pmc --pmc TCC_HIT_sum TCC_MISS_sum -- $BENCH > "$OUT/pmc_l2.log" 2>&1
 fi
 python3 profiles/summarize.py "$OUT" "$SUM" "$TAG" "${CONFIG:-c2}"
+echo "summarize rc=$?  (3 = a kernel's --pmc and trace durations disagree by more than 10 %: see the *_pmc.md table)"
 ls -la "$SUM"

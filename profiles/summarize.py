@@ -84,8 +84,9 @@ def read_counters(raw, sub):
 def main():
     raw, out, tag = sys.argv[1], sys.argv[2], sys.argv[3]
     config = sys.argv[4] if len(sys.argv) > 4 else "c2"       # c3: the traced command is bench.py --perceptual --vqvae-dtype bf16 (profiles/collect.sh)
-    what = ("bench.py --steps 2 --warmup 1 --serial-streams" if config == "c2" else
-            "bench.py --perceptual --vqvae-dtype bf16 --serial-streams --steps 2 --warmup 1 (config 3 as timed: bf16 MFMA operands for the VQ-VAE and LPIPS)")
+    what = {"c2": "bench.py --steps 2 --warmup 1 --serial-streams",
+            "c3": "bench.py --perceptual --vqvae-dtype bf16 --serial-streams --steps 2 --warmup 1 (config 3 as timed: bf16 MFMA operands for the VQ-VAE and LPIPS)",
+            "c5": "tools/bench_gan.py 6 --serial (config 5: GAN iterations on one 30-frame clip, generator and discriminator alternating, side streams folded)"}[config]
     os.makedirs(out, exist_ok=True)
     # ---- kernel stats
     stats = []
@@ -93,19 +94,32 @@ def main():
         with open(f, newline="") as fh:
             for r in csv.DictReader(fh):
                 stats.append(r)
-    trace_avg = {}
+    trace_avg, trace_share = {}, {}
     if stats:
         tot = sum(float(r["TotalDurationNs"]) for r in stats) or 1.0
         stats.sort(key=lambda r: -float(r["TotalDurationNs"]))
         with open(os.path.join(out, f"{tag}_kernel_stats.md"), "w") as fh:
-            fh.write(f"# rocprofv3 --kernel-trace --stats: {what} (3 steps traced), tag {tag}\n\n")
+            fh.write(f"# rocprofv3 --kernel-trace --stats: {what} ({'3 steps' if config != 'c5' else '2 warm-up + 7-8 iterations'} traced), tag {tag}\n\n")
             fh.write("| kernel | calls | total ms | avg us | min us | max us | % of GPU time |\n|---|---|---|---|---|---|---|\n")
             for r in stats[:40]:
                 n = short(r["Name"])
                 trace_avg[n] = float(r["AverageNs"])
+                trace_share[n] = float(r["TotalDurationNs"]) / tot
                 fh.write(f"| `{n}` | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.3f} | {float(r['AverageNs'])/1e3:.1f} | "
                          f"{float(r['MinNs'])/1e3:.1f} | {float(r['MaxNs'])/1e3:.1f} | {100*float(r['TotalDurationNs'])/tot:.2f} |\n")
             fh.write(f"\nTotal GPU kernel time: {tot/1e6:.2f} ms over the traced run.\n")
+    # per-dispatch durations of the trace run, first dispatch of each kernel dropped (code-object load / cold caches: a 3-call kernel's
+    # average is otherwise its first call) -- the figure the consistency check below compares
+    trace_warm = {}
+    per = defaultdict(list)
+    for f in find(raw, "trace", "*kernel_trace.csv"):
+        with open(f, newline="") as fh:
+            for r in csv.DictReader(fh):
+                per[short(r["Kernel_Name"])].append((int(r["Start_Timestamp"]), float(r["End_Timestamp"]) - float(r["Start_Timestamp"])))
+    for k, v in per.items():
+        v = [d for _, d in sorted(v)]
+        v = v[1:] if len(v) > 1 else v
+        trace_warm[k] = sum(v) / len(v)
     # ---- counters
     sq, sq_d = read_counters(raw, "pmc_sq")
     fe, fe_d = read_counters(raw, "pmc_fetch")
@@ -113,14 +127,18 @@ def main():
     l2, _ = read_counters(raw, "pmc_l2")
     kernels = sorted(set(sq) | set(fe) | set(wr) | set(l2), key=lambda k: -sum(sq_d.get(k, {}).values()))
     traffic = {}
+    disagree = []
     if kernels:
         with open(os.path.join(out, f"{tag}_pmc.md"), "w") as fh:
             fh.write(f"# rocprofv3 --pmc passes (separate runs) of {what}, per-dispatch averages, tag {tag}\n\n")
             fh.write("MFMA busy share = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 4 SIMD * 256 CU); effective clock = "
                      "GRBM_GUI_ACTIVE / 8 / duration.  HBM read = 2 x FETCH_SIZE KB (gfx950 counts 128-B requests of wide "
                      "streams as 64 B; MI355X_MICROARCH.md, HBM), HBM write = WRITE_SIZE KB.\n\n")
-            fh.write("| kernel | dispatches | avg ms (profiled) | MFMA busy share | eff. clock GHz | wave cycles waiting (WAIT_ANY/WAVE_CYCLES) | "
-                     "LDS bank-conflict cycles / wave cycles | HBM read MB/launch | HBM write MB/launch | L2 hit rate |\n|" + "---|" * 10 + "\n")
+            fh.write("Consistency (round 5): `trace avg ms` is the same kernel's average in the --kernel-trace --stats run of the same command (both columns without the kernel's first dispatch); a row whose two "
+                     "averages differ by more than 10 % (kernels with >= 1 % of the GPU time) is flagged and makes this script exit non-zero -- the counters "
+                     "of such a row do not describe the launches that cost the time (round 4: conv5_x data gradients beside the LPIPS heads).\n\n")
+            fh.write("| kernel | dispatches | avg ms (profiled) | trace avg ms | MFMA busy share | eff. clock GHz | wave cycles waiting (WAIT_ANY/WAVE_CYCLES) | "
+                     "LDS bank-conflict cycles / wave cycles | HBM read MB/launch | HBM write MB/launch | L2 hit rate |\n|" + "---|" * 11 + "\n")
             for k in kernels[:30]:
                 def avg(src, c):
                     v = src.get(k, {}).get(c)
@@ -139,7 +157,15 @@ def main():
                 if lab and rd is not None:
                     traffic[lab] = int(rd + (wrb or 0))
                 fmt = lambda v, s="{:.3f}": s.format(v) if v is not None else "-"
-                fh.write(f"| `{k}` | {len(dl)} | {fmt(dur/1e6 if dur else None)} | {fmt(share)} | {fmt(clk)} | "
+                tavg = trace_warm.get(k, trace_avg.get(k))
+                if dl and len(dl) > 1:              # the same rule on this side: without the kernel's first dispatch
+                    ids = sorted((sq_d.get(k) or fe_d.get(k)).items(), key=lambda kv: int(kv[0]))
+                    dur = sum(d for _, d in ids[1:]) / (len(ids) - 1)
+                flag = ""
+                if tavg and dur and trace_share.get(k, 0) >= 0.01 and abs(dur - tavg) > 0.10 * tavg:
+                    flag = " **DISAGREES**"
+                    disagree.append((k, dur / 1e6, tavg / 1e6))
+                fh.write(f"| `{k}` | {len(dl)} | {fmt(dur/1e6 if dur else None)} | {fmt(tavg/1e6 if tavg else None)}{flag} | {fmt(share)} | {fmt(clk)} | "
                          f"{fmt(wa/wc if wa and wc else None)} | {fmt(ldsb/wc if ldsb is not None and wc else None, '{:.4f}')} | "
                          f"{fmt(rd/1e6 if rd is not None else None, '{:.1f}')} | {fmt(wrb/1e6 if wrb is not None else None, '{:.1f}')} | "
                          f"{fmt(hit/(hit+miss) if hit is not None and miss is not None and hit+miss > 0 else None)} |\n")
@@ -151,6 +177,10 @@ def main():
         with open(os.path.join(out, "pmc_traffic.json" if config == "c2" else f"pmc_traffic_{config}.json"), "w") as fh:
             json.dump(traffic, fh, indent=1)
     print("summaries written to", out)
+    if disagree:
+        for k, a, b in disagree:
+            print(f"INCONSISTENT: {k}: {a:.3f} ms under --pmc vs {b:.3f} ms in the kernel trace (> 10 %)")
+        sys.exit(3)
 
 
 if __name__ == "__main__":
