@@ -69,7 +69,7 @@ __global__ __launch_bounds__(512, 1) void vq_assign_kernel(const float* __restri
     float best_d = INFINITY;
     int best_i = 0;
     if (forced) {       // teacher-forced codes (wave-uniform branch): gather, straight-through and commitment sum on the GIVEN indices
-      best_i = valid ? (int)forced[v] : 0;
+      best_i = valid ? (int)forced[v] & (VQ_K - 1) : 0;      // (memory-safe whatever the caller hands in; the binding validates under FACEOFF_DEBUG)
     } else
     for (int ct = 0; ct < VQ_K / 32; ++ct) {
       f32x16 acc;

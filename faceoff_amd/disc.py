@@ -95,7 +95,7 @@ class DiscEngine:
         """torch.optim.Adam(netD.parameters(), lr, betas=(0.5, 0.999)) (mocoganhd_video_disc.py:24-26) as one launch."""
         self.t += 1
         ops.adam_flat(self.flat_params, self.flat_grads, self.m, self.v, lr, self.t, betas, eps, grad_scale)
-        self._packs_stale = True              # (the launch writes the arena through a raw pointer: torch's version counter does not see it)
+        self.mark_params_dirty()              # (the launch writes the arena through a raw pointer: torch's version counter does not see it)
 
     # ------------------------------------------------------------------ helpers
     def _desc(self, N, src_dims, cs, ld_s, dst_dims, cd, ld_d, stride, flags=0, ld_mask=0):
@@ -131,6 +131,11 @@ class DiscEngine:
             return xs
         _lib.call("fo_space_to_depth2", ops._ptr(inverse_into), ld, ops._ptr(x), ldxs, N, D, H, W, self.nc, int(three), 1, ops._stream())
         return inverse_into
+
+    def mark_params_dirty(self):
+        """Tell the engine its parameter arena was written by something torch's version counter cannot see: a raw-pointer launch (fo_adam_flat,
+        a communicator broadcast / all-reduce of parameters) or a `.data` alias.  Every such writer must call this; the next forward re-packs."""
+        self._packs_stale = True
 
     def pack_filters(self):
         """Checkpoint-layout filters -> forward and data-gradient packs.  Re-packed only when the weights have changed since the last pack:
@@ -426,6 +431,13 @@ def ralsgan_pair(logits, ia, ib, target_a, target_b, weight, loss_acc, want_ga=T
         loss_acc += weight * (MSE(a - mean(b), target_a) + MSE(b - mean(a), target_b))
     i.e. Relativistic_Average_LSGAN both ways, summed over scales (mocoganhd_losses.py:113-126; trainer :359-360,372-373,
     404-408,416-420 with weight 0.5).  Returns per-scale gradients shaped like the logits (zero for samples not wanted)."""
+    # fo_ralsgan adds into loss_acc with a plain read-modify-write from its only workgroup (no float atomic: the loss is the same bits every
+    # run).  That is correct only while every launch sharing one accumulator is ordered on ONE stream -- asserted here, since the per-scale and
+    # per-discriminator side streams of round 4 made the contract easy to break: an accumulator is bound to the stream it is first used on.
+    st = torch.cuda.current_stream(loss_acc.device)
+    bound = getattr(loss_acc, "_fo_stream", None)
+    assert bound is None or bound == st, "ralsgan_pair: one loss accumulator used from two streams (its adds are not atomic)"
+    loss_acc._fo_stream = st
     grads = []
     for lg in logits:
         g = torch.zeros_like(lg)

@@ -70,10 +70,23 @@ class GANTrainer:
             if side is None:
                 yield (lambda: None)
                 return
+            # Lifetime rule for everything that crosses: tensors made inside the block live in the side stream's allocator pool and are read on
+            # the main stream only after joined(); tensors of the main stream read inside were made before side.wait_stream(main).  No
+            # record_stream is needed while BOTH edges hold -- so the join is not left to the caller alone: if the body raises (or a caller
+            # returns early without calling the handle), the main stream still waits for the side stream on the way out.
             main = torch.cuda.current_stream(self.engine.device)
             side.wait_stream(main)
-            with torch.cuda.stream(side):
-                yield (lambda: main.wait_stream(side))
+
+            def joined():
+                self._pending_join = None
+                main.wait_stream(side)
+            self._pending_join = joined                 # step() calls it on the way out if its body did not (early return, exception)
+            try:
+                with torch.cuda.stream(side):
+                    yield joined
+            except BaseException:
+                joined()
+                raise
         return cm()
 
     def _sum_over_ranks(self, flat):
@@ -119,6 +132,15 @@ class GANTrainer:
 
     # ------------------------------------------------------------------ one iteration
     def step(self, img, ground_truth, choices=None):
+        """One GAN iteration (see _step).  Whatever happens inside -- an exception, an early return -- the image discriminator's side stream is
+        joined into the main stream before control leaves: the tensors that cross between the two rely on that edge (see _beside)."""
+        try:
+            return self._step(img, ground_truth, choices)
+        finally:
+            if getattr(self, "_pending_join", None) is not None:
+                self._pending_join()
+
+    def _step(self, img, ground_truth, choices=None):
         """img [N,6,H,W] (one clip of N >= window frames, utils.py:29-38), ground_truth [N,3,H,W].  Returns a dict of
         device scalars; which keys depends on the iteration's parity (generator: recon, latent, g_loss_2d, g_loss_3d;
         discriminator: recon, latent, d_loss_3d, d_loss_2d)."""

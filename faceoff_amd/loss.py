@@ -33,6 +33,51 @@ class _LPIPSFunction(torch.autograd.Function):
         return None, None, grad
 
 
+class _LPIPSPerImageFunction(torch.autograd.Function):
+    """`models.lpips.LPIPS.forward(input, target)` (reference models/lpips.py:80-93) -> [N,1,1,1], differentiable in both arguments like the
+    reference's (the shim used to hand out a detached tensor).  The distance is symmetric in its two images, and the kernels
+    produce d mean(val) / d (one image) in the same pass as the values: one pass per argument that requires a gradient, with that argument in
+    the reconstruction slot.  A backward whose incoming gradient is the same for every image -- `.mean()`, `.sum()`, a scalar weight: every use
+    in the reference tree -- is that tensor rescaled; any other incoming gradient is served image by image (one single-frame pass each:
+    correct, not fast)."""
+
+    @staticmethod
+    def forward(ctx, module, inp, target):
+        eng = module._bind(inp.device)
+        imgs = (inp.float().contiguous(), target.float().contiguous())
+        ctx.module, ctx.n, ctx.g_mean, ctx.nhwc = module, inp.shape[0], [None, None], [None, None]
+        vals = None
+        for slot in (0, 1):
+            if not (inp, target)[slot].requires_grad and (slot == 1 or vals is not None or target.requires_grad):
+                continue                     # (with no gradient asked for at all, slot 0 runs once for the values)
+            ctx.nhwc[slot] = ops.nchw_to_nhwc(imgs[slot], cpad=8)
+            need = (inp, target)[slot].requires_grad
+            ctx.g_mean[slot] = torch.zeros_like(ctx.nhwc[slot]) if need else None
+            eng.loss_and_grad(imgs[1 - slot], ctx.nhwc[slot], ctx.g_mean[slot])
+            if vals is None:
+                vals = eng.last_per_image.clone()
+        ctx.other = imgs
+        return vals.reshape(-1, 1, 1, 1)
+
+    @staticmethod
+    def backward(ctx, g):
+        flat = g.reshape(-1).float()
+        uniform = bool((flat == flat[0]).all())
+        out = [None, None]
+        for slot in (0, 1):
+            if ctx.g_mean[slot] is None:
+                continue
+            if uniform:
+                out[slot] = ops.nhwc_to_nchw(ctx.g_mean[slot], 3) * (flat[0] * ctx.n)
+                continue
+            eng = ctx.module._bind(g.device)
+            acc = torch.zeros_like(ctx.nhwc[slot])
+            for n in range(ctx.n):          # d val[n] / d image[n], one frame at a time
+                eng.loss_and_grad(ctx.other[1 - slot][n:n + 1], ctx.nhwc[slot][n:n + 1], acc[n:n + 1])
+            out[slot] = ops.nhwc_to_nchw(acc, 3) * flat.reshape(-1, 1, 1, 1)
+        return None, out[0], out[1]
+
+
 class VQLPIPS(nn.Module):
     def __init__(self, state_dict=None, dtype="fp32"):
         """dtype: "fp32" (reference arithmetic) or "bf16" (BASELINE config 3: bf16 storage / MFMA operands, fp32
@@ -76,6 +121,10 @@ class VQLPIPS(nn.Module):
 
     def forward(self, targets, reconstructions):
         return _LPIPSFunction.apply(self, targets.contiguous(), reconstructions.contiguous())
+
+    def per_image(self, inp, target):
+        """LPIPS.forward of the reference (lpips.py:80-93): [N,1,1,1], differentiable in `inp`."""
+        return _LPIPSPerImageFunction.apply(self, inp.contiguous(), target.contiguous())
 
     # trainer fast path: loss + gradient accumulated straight into the NHWC decoder-output gradient
     def loss_and_grad(self, gt_nchw, dec_nhwc, g_dec, weight=1.0, taps0=None):

@@ -33,7 +33,7 @@ class _DiscFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, x, *params):
         eng = model._bind(x.device)
-        eng._packs_stale = True       # the module's parameters are stepped by torch.optim through .data aliases of the arena: always re-pack here
+        eng.mark_params_dirty()       # the module's parameters are stepped by torch.optim through .data aliases of the arena: always re-pack here
         five = x if x.dim() == 5 else x.unsqueeze(2)                  # [N,C,D,H,W]
         N, Cc, D, H, W = five.shape
         xc = torch.zeros((N, D, H, W, 32), device=x.device)

@@ -1,7 +1,6 @@
 """`models.lpips.LPIPS` of the reference (models/lpips.py:53-93) on the gfx950 kernels: `LPIPS()(input, target)` ->
 [N,1,1,1] per-image distances.  Weights are loaded with `load_state_dict` (reference key names); the reference's
 download (lpips.py:12-48) has no counterpart here."""
-import torch
 from torch import nn
 
 from faceoff_amd.loss import VQLPIPS as _VQLPIPS
@@ -19,6 +18,5 @@ class LPIPS(nn.Module):
         return {k[len("perceptual_loss."):]: v for k, v in self._impl.state_dict(*a, **kw).items()}
 
     def forward(self, input, target):
-        self._impl(input, target)                       # runs the kernels; keeps the per-image values
-        eng = self._impl._bind(target.device)
-        return eng.last_per_image.reshape(-1, 1, 1, 1)
+        """[N,1,1,1], differentiable in `input` and `target` as the reference's (faceoff_amd.loss._LPIPSPerImageFunction)."""
+        return self._impl.per_image(input, target)

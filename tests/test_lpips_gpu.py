@@ -583,3 +583,43 @@ def test_lpips_gradient_does_not_change_with_the_pool_codes_and_mask_planes(monk
     ref = out[(False, False)]
     for k in ((True, True), (True, False)):
         assert out[k][0] == ref[0] and torch.equal(out[k][1], ref[1]), k
+
+
+def test_models_lpips_LPIPS_is_differentiable_in_its_input_like_the_reference():
+    """`models.lpips.LPIPS()(input, target)` -> [N,1,1,1] (reference models/lpips.py:80-93) through the root drop-in path: per-image values and
+    the gradient w.r.t. `input` for (a) a uniform incoming gradient (.mean(): the fast path, one pass) and (b) a different weight per image (the
+    image-by-image path), both against the oracle's autograd (the shim returned a detached tensor)."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    from models.lpips import LPIPS
+    from oracle import faceoff_oracle as O
+    sd = make_vgg_lpips_state(5)
+    rng = np.random.default_rng(9)
+    tgt = rng.uniform(-1, 1, (3, 3, 32, 48)).astype(np.float32)
+    rec = (tgt + 0.4 * rng.standard_normal(tgt.shape)).astype(np.float32)
+    lp = {k: torch.from_numpy(v) for k, v in sd.items()}
+    m = LPIPS()
+    m.load_state_dict(sd)
+    m = m.cuda()
+    for wts in (np.full(3, 1.0 / 3, np.float32), np.array([0.2, -1.0, 3.0], np.float32)):
+        r = torch.from_numpy(rec).requires_grad_(True)
+        ref = O.lpips_forward(r, torch.from_numpy(tgt), lp)                     # LPIPS.forward(input, target)
+        (ref.reshape(-1) * torch.from_numpy(wts)).sum().backward()
+        x = torch.from_numpy(rec).cuda().requires_grad_(True)
+        val = m(x, torch.from_numpy(tgt).cuda())
+        assert val.shape == (3, 1, 1, 1) and val.requires_grad
+        np.testing.assert_allclose(val.detach().cpu().numpy(), ref.detach().numpy(), rtol=1e-3)
+        (val.reshape(-1) * torch.from_numpy(wts).cuda()).sum().backward()
+        got, want = x.grad.cpu().numpy(), r.grad.numpy()
+        assert np.linalg.norm(got - want) <= 2e-2 * np.linalg.norm(want), wts
+        assert (np.abs(got - want) > 1e-3 * np.abs(want).max()).mean() < 0.05
+    # the second argument too (loss.VQLPIPS differentiates THAT one, loss.py:33), and both at once
+    r0, r1 = torch.from_numpy(rec).requires_grad_(True), torch.from_numpy(tgt).requires_grad_(True)
+    O.lpips_forward(r0, r1, lp).mean().backward()
+    x0, x1 = torch.from_numpy(rec).cuda().requires_grad_(True), torch.from_numpy(tgt).cuda().requires_grad_(True)
+    m(x0, x1).mean().backward()
+    for got, want in ((x0.grad, r0.grad), (x1.grad, r1.grad)):
+        assert np.linalg.norm(got.cpu().numpy() - want.numpy()) <= 2e-2 * np.linalg.norm(want.numpy())
+    with torch.no_grad():                                                       # no graph asked for: values only
+        assert not m(torch.from_numpy(rec).cuda(), torch.from_numpy(tgt).cuda()).requires_grad

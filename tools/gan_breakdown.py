@@ -31,6 +31,7 @@ for kind in ("generator", "discriminator"):
     tr.step(img, gt)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) * 1e3
     ops.PROFILER = None
+    prof.close()                    # kernel notes off again (fo_kernel_notes(0)): they stay on for the rest of the process otherwise
     summ = prof.summary()
     tot = sum(v["total_ms"] for v in summ.values())
     print(f"== {kind} iteration {dt:.2f} ms; profiled conv launches {tot:.2f} ms; other {dt - tot:.2f} ms")
