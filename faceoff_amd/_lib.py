@@ -108,7 +108,6 @@ SIGNATURES = {
     "fo_wino_wgrad_out": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "fo_wino_filter": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "fo_wino_input": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P]),
-    "fo_wino_input_rows": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P]),
     "fo_wino_output": (_I, [_P, _P, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "fo_wgrad_ws_bytes": (_L, [_D]),
     "fo_conv_wgrad": (_I, [_D, _P, _P, _P, _I, _I, _P, _P, _L, _P]),

@@ -143,55 +143,6 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
   }
 }
 
-// The same transform for plane rows R0 <= r < R1 only (planes xi = A r + s): the round-5 experiment that splits a layer's 36 planes over two
-// streams, so that the second half's input transform runs beside the first half's GEMM (ops.conv3d_winograd, FACEOFF_WINO_PLANE_SPLIT=1).
-// Each half reads the whole 6 x 6 patch (the row transform t = B^T d needs every row of d): x is read twice, V written once.
-template <int MT, int R0, int R1>
-__global__ __launch_bounds__(256) void wino_input_rows_kernel(const float* __restrict__ x, int ldx, float* __restrict__ V, int N, int H, int W, int C4) {
-  using Wn = Wino<MT>;
-  constexpr int A = Wn::A;
-  const int Ht = H / MT, Wt = W / MT;
-  const long long total = (long long)N * Ht * Wt * C4;
-  const size_t plane = (size_t)N * Ht * Wt * C4 * 4;
-  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(e % C4);
-    long long q = e / C4;
-    const int tx = (int)(q % Wt); q /= Wt;
-    const int ty = (int)(q % Ht);
-    const long long n = q / Ht;
-    f32x4 d[A][A];
-#pragma unroll
-    for (int r = 0; r < A; ++r) {
-      const int y = MT * ty - 1 + r;
-#pragma unroll
-      for (int s = 0; s < A; ++s) {
-        const int xx = MT * tx - 1 + s;
-        const bool ok = (unsigned)y < (unsigned)H && (unsigned)xx < (unsigned)W;
-        d[r][s] = ok ? ld4(x + ((n * H + y) * (long long)W + xx) * ldx + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-    }
-    float* dst = V + (size_t)e * 4;
-#pragma unroll
-    for (int r = R0; r < R1; ++r) {
-      f32x4 t[A];
-#pragma unroll
-      for (int s = 0; s < A; ++s) {   // rows: t = B^T d (the same operation order as wino_input_kernel: identical bits)
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f}; bool first = true;
-#pragma unroll
-        for (int k = 0; k < A; ++k) axpy(acc, Wn::BT[r][k], d[k][s], first);
-        t[s] = acc;
-      }
-#pragma unroll
-      for (int s = 0; s < A; ++s) {   // columns: v = t B
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f}; bool first = true;
-#pragma unroll
-        for (int k = 0; k < A; ++k) axpy(acc, Wn::BT[s][k], t[k], first);
-        st4(dst + (size_t)(A * r + s) * plane, acc);
-      }
-    }
-  }
-}
-
 // out = epilogue(A^T M A).  One thread: one tile (m x m output pixels), 4 channels.
 // epilogue order as in the conv kernels: (+ bias) -> ReLU mask -> + residual -> ReLU.
 template <int MT>
@@ -371,17 +322,6 @@ int fo_wino_input(const float* x, int ldx, float* V, int N, int H, int W, int C,
   const dim3 grid(grid_for((long long)N * (H / m) * (W / m) * (C / 4)));
   if (m == 2) hipLaunchKernelGGL(wino_input_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, V, N, H, W, C / 4);
   else hipLaunchKernelGGL(wino_input_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, V, N, H, W, C / 4);
-  FO_CHECK_LAUNCH();
-  return FO_OK;
-}
-
-int fo_wino_input_rows(const float* x, int ldx, float* V, int N, int H, int W, int C, int half, void* stream) {
-  FO_REQUIRE(half == 0 || half == 1, FO_E_SHAPE, "wino_input_rows: half must be 0 (plane rows 0..2) or 1 (3..5)");
-  FO_REQUIRE(H % 4 == 0 && W % 4 == 0 && C % 4 == 0 && ldx % 4 == 0 && fo_aligned16(x) && fo_aligned16(V), FO_E_SHAPE,
-             "wino_input_rows: F(4x4,3x3) only; H, W multiples of 4; C, ld %% 4 == 0; 16-byte alignment");
-  const dim3 grid(grid_for((long long)N * (H / 4) * (W / 4) * (C / 4)));
-  if (half == 0) hipLaunchKernelGGL((wino_input_rows_kernel<4, 0, 3>), grid, dim3(256), 0, (hipStream_t)stream, x, ldx, V, N, H, W, C / 4);
-  else hipLaunchKernelGGL((wino_input_rows_kernel<4, 3, 6>), grid, dim3(256), 0, (hipStream_t)stream, x, ldx, V, N, H, W, C / 4);
   FO_CHECK_LAUNCH();
   return FO_OK;
 }

@@ -320,18 +320,6 @@ def wino_wgrad_gemm_split(dM, V, planes, N, T, P, cin, cout, kd):
     return dU
 
 
-PLANE_SPLIT = bool(_os.environ.get("FACEOFF_WINO_PLANE_SPLIT"))     # round-5 experiment, off by default (conv3d_winograd)
-_plane_streams = {}
-
-
-def _plane_side_stream(device, main):
-    key = (device, main.cuda_stream)
-    st = _plane_streams.get(key)
-    if st is None:
-        st = _plane_streams[key] = torch.cuda.Stream(device=device)
-    return st
-
-
 AFTER_GEMM = None      # hook called right after a Winograd-domain GEMM launch of a forward / data-gradient pass (engine: deferred wgrads)
 
 
@@ -353,27 +341,8 @@ def conv3d_winograd(x, U, bias, out, *, T, cin, cout, flags=0, mask=None, add=No
     V, M = _wino_buffers((0 if keep_v else P * plane_v, P * plane_m), x.device)
     if keep_v:
         V = torch.empty(P * plane_v, device=x.device, dtype=torch.float32)
-    bank = pad_out(cout) * kd * cin                                 # floats per filter bank
-    if (PLANE_SPLIT and m == 4 and not BF16X6 and (N * Ht * Wt) % 128 == 0 and cin >= 64 and cout % 128 == 0
-            and P * plane_v * 4 + 2 * (kd // 2) * Ht * Wt * cin * 4 < (1 << 31) and P * plane_m * 4 < (1 << 31)):
-        # EXPERIMENT (FACEOFF_WINO_PLANE_SPLIT=1; results identical bit for bit): the 36 planes as two halves of 18
-        # on two streams -- plane rows 3..5 are transformed on a side stream while the GEMM of rows 0..2 runs, then the two GEMM halves
-        # share the chip; the output transform needs all 36 planes and waits for both.
-        main = torch.cuda.current_stream(x.device)
-        side = _plane_side_stream(x.device, main)
-        side.wait_stream(main)                                      # x (and the scratch's previous readers) are ordered before both halves
-        _lib.call("fo_wino_input_rows", _ptr(x), ld_of(x), _ptr(V), N, H, W, cin, 0, _stream())
-        with torch.cuda.stream(side):
-            _lib.call("fo_wino_input_rows", _ptr(x), ld_of(x), _ptr(V), N, H, W, cin, 1, _stream())
-            wino_gemm(V[18 * plane_v:], U[18 * bank:], M[18 * plane_m:], 18, N, T if kd > 1 else 1, Ht * Wt, cin, cout, kd)
-        wino_gemm(V, U, M, 18, N, T if kd > 1 else 1, Ht * Wt, cin, cout, kd)
-        if AFTER_GEMM is not None:
-            AFTER_GEMM()
-        main.wait_stream(side)
-        _lib.call("fo_wino_output", _ptr(M), _ptr(bias), _ptr(mask), ld_of(mask) if mask is not None else 0, _ptr(add),
-                  ld_of(add) if add is not None else 0, _ptr(out), ld_of(out), N, H, W, cout, flags, m, _stream())
-        return V if keep_v else None
     _lib.call("fo_wino_input", _ptr(x), ld_of(x), _ptr(V), N, H, W, cin, m, _stream())
+    bank = pad_out(cout) * kd * cin                                 # floats per filter bank
     banked = (N * Ht * Wt) % 128 == 0
     per = max(1, min(P, ((1 << 31) - 1) // max(plane_v * 4, plane_m * 4))) if banked else 1   # planes per launch (2 GiB window)
     # fo_wino_gemm addresses the whole V stack through one buffer descriptor and reaches kd/2 frames past either end of it (those

@@ -251,9 +251,6 @@ int fo_lpips_tap_bwd(const float* f0, const float* f1, const float* lin, const f
 int fo_wino_filter(const float* w, float* U, int O, int I, int KD, int Opad, int Ipad, int dgrad, int m, void* stream);
 /* V[(m+2)^2][N][H/m][W/m][C] = B^T d B of the zero-padded (m+2)x(m+2) patches of x [N,H,W,ldx]. */
 int fo_wino_input(const float* x, int ldx, float* V, int N, int H, int W, int C, int m, void* stream);
-/* The F(4x4,3x3) input transform for plane rows 3*half .. 3*half+2 only (planes xi = 6 r + s; bit-identical to fo_wino_input's): lets a caller
-   run a layer's two plane halves on two streams -- the measured experiment of DESIGN section 5 (round 5), not the default path. */
-int fo_wino_input_rows(const float* x, int ldx, float* V, int N, int H, int W, int C, int half, void* stream);
 /* out [N,H,W,ldOut] = epilogue(A^T M A), M[(m+2)^2][N][H/m][W/m][C]; flags: FO_BIAS | FO_MASK | FO_ADD | FO_OUT_RELU. */
 int fo_wino_output(const float* M, const float* bias, const float* mask, int ldMask, const float* add, int ldAdd, float* out,
                    int ldOut, int N, int H, int W, int C, int flags, int m, void* stream);

@@ -269,31 +269,3 @@ print(json.dumps(rep))
         a, b = outs["halo"][k].double(), outs["tiled"][k].double()
         assert (a - b).abs().max().item() <= tol * b.abs().max().item(), (k, (a - b).abs().max().item(), b.abs().max().item())
 
-
-def test_winograd_plane_split_experiment_is_bit_equal_to_the_default_path():
-    """FACEOFF_WINO_PLANE_SPLIT (round 5's measured experiment, off by default): the 36 planes of an F(4x4,3x3) layer as two halves on two
-    streams -- fo_wino_input_rows + two 18-plane fo_wino_gemm launches.  The forward (bias + ReLU) and the masked data gradient against the
-    default path at the C2 latent shapes (to an ulp of the transformed planes)."""
-    from faceoff_amd import ops
-    from faceoff_amd.ops import FO_OUT_RELU
-    for H, kd in ((64, 3), (32, 3), (64, 1)):
-        ci = co = 128
-        Tt = T if kd == 3 else 1
-        x, g, msk = _rand((N, H, H, ci), 21), _rand((N, H, H, co), 22), _rand((N, H, H, ci), 23)
-        w = _rand((co, ci, 3, 3, 3) if kd == 3 else (co, ci, 3, 3), 24, scale=0.05)
-        b = _rand((co,), 25)
-        outs = []
-        for split in (False, True):
-            ops.PLANE_SPLIT = split
-            try:
-                y, gx = torch.empty((N, H, H, co), device="cuda"), torch.empty_like(x)
-                ops.conv3d_winograd(x, ops.wino_filter(w, m=4), b, y, T=Tt, cin=ci, cout=co, flags=FO_OUT_RELU, m=4, kd=kd)
-                ops.conv3d_winograd(g, ops.wino_filter(w, dgrad=True, m=4), None, gx, T=Tt, cin=co, cout=ci, mask=msk, m=4, kd=kd)
-                torch.cuda.synchronize()
-            finally:
-                ops.PLANE_SPLIT = False
-            outs.append((y, gx))
-        # (the two 18-plane GEMM launches equal the 36-plane launch bit for bit; the row-half input transform is compiled on its own and hipcc
-        # contracts 4 d1 - 5 d3 the other way round in plane row 5: one ulp of V -- tools/probes/plane_split_debug.py)
-        for a, b in zip(outs[0], outs[1]):
-            assert (a - b).abs().max().item() <= 1e-5 * a.abs().max().item(), (H, kd)
