@@ -1441,9 +1441,13 @@ __device__ unsigned long long fo_h64_stamps[16];
 
 // MASKT / MASKB: FO_MASK from the bf16 tensor / from its bit plane; POOL: the pooled output (its codes and plane where given); OBITS: the result's plane.
 // (compile-time: with all of it behind run-time tests the kernel spills -- 144 registers hold the filter)
-template <bool MASKT, bool MASKB, bool POOL, bool OBITS>
+// LINES (round 5): a 16-pixel block's result goes through a wave-private 1.25 KB patch in LDS (2 ds_write_b64, 1 ds_read_b128 per lane) so that a
+// store is 16 B per lane and a pixel's 64 bytes (the wave's 32 channels) leave in ONE piece -- 4 store instructions of 16 half-lines per tile and
+// wave instead of 8 of 16 quarter-lines (the store path is priced by line pieces per instruction: the extended-tile kernel's epilogue, above).
+template <bool MASKT, bool MASKB, bool POOL, bool OBITS, bool LINES>
 __global__ __launch_bounds__(256, 2) void conv_halo64_bf16_kernel(const HaloArgs a) {
   constexpr int PITCH = 48, ROWS = 6, PLANE = ROWS * PITCH * 64, STAGE = 2 * PLANE;     // bytes
+  constexpr int EPITCH = 80, EPATCH = 16 * EPITCH;         // the epilogue patch: 16 pixels x (64 + 16) B per wave, behind the two stages
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // (uniform: the DMA destinations and scalar offsets are derived from it)
@@ -1638,7 +1642,8 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16_kernel(const HaloArgs
           for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
         }
         const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-        if (!(FO_ABLATE_H & 32)) *reinterpret_cast<bf16x4*>(a.out + pix * a.ldOut + co) = o;
+        if (LINES) *reinterpret_cast<bf16x4*>(lds + 2 * STAGE + wave * EPATCH + l15 * EPITCH + (j * 16 + quad * 4) * 2) = o;
+        else if (!(FO_ABLATE_H & 32)) *reinterpret_cast<bf16x4*>(a.out + pix * a.ldOut + co) = o;
         if (OBITS) obw |= pos_bits4((float)o[0], (float)o[1], (float)o[2], (float)o[3]) << (j * 16 + quad * 4);      // the wave's 32 channels of this pixel: one dword
         if (POOL) {
 #pragma unroll
@@ -1647,6 +1652,13 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16_kernel(const HaloArgs
             pm[i & 1][j][r] = (i >> 1) ? fmaxf(pm[i & 1][j][r], (float)o[r]) : (float)o[r];
           }
         }
+      }
+      if (LINES) {                                         // lane = (pixel lane / 4 of the block, 16-byte piece lane % 4 of its 64 bytes)
+        __builtin_amdgcn_wave_barrier();
+        const bf16x8 ln = *reinterpret_cast<const bf16x8*>(lds + 2 * STAGE + wave * EPATCH + (lane >> 2) * EPITCH + (lane & 3) * 16);
+        const size_t pix2 = pix - l15 + (lane >> 2);
+        if (!(FO_ABLATE_H & 32)) *reinterpret_cast<bf16x8*>(a.out + pix2 * a.ldOut + half * 64 + wn * 32 + (lane & 3) * 8) = ln;
+        __builtin_amdgcn_wave_barrier();                  // (the next block's writes stay behind this read: LDS operations of a wave execute in order)
       }
       if (OBITS) {                                         // the four quads' nibbles meet in one dword (two shuffles): one 4-byte store per pixel
         obw |= (unsigned)__shfl_xor((int)obw, 16);
@@ -1706,11 +1718,13 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16_kernel(const HaloArgs
     // (8 result stores per lane; + 4 bit-plane dwords; + 4 pooled stores, + 2 code stores, + 2 pooled-plane dwords.  A count that is too SMALL only
     // waits for a few of the stores as well; lgkmcnt: the row copy's LDS writes)
     {
-      const int nst = 8 + (OBITS ? 4 : 0) + (POOL ? 4 : 0) + (POOL && a.pidx ? 2 : 0) + (POOL && a.pooledBits ? 2 : 0);
+      const int nst = (LINES ? 4 : 8) + (OBITS ? 4 : 0) + (POOL ? 4 : 0) + (POOL && a.pidx ? 2 : 0) + (POOL && a.pooledBits ? 2 : 0);
       if (nst >= 16) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
       else if (nst >= 14) asm volatile("s_waitcnt vmcnt(14) lgkmcnt(0)" ::: "memory");
       else if (nst >= 12) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+      else if (nst >= 10) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
+      else if (nst >= 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
 #ifdef FO_STAMP_H64
@@ -1943,7 +1957,8 @@ static int launch_halo64(const ConvArgsH& c, hipStream_t s, void* pooled = nullp
   a.N = d.N; a.H = d.Hin; a.W = d.Win; a.Cout = d.Cout; a.halves = d.Cout / 64;
   a.tilesX = d.Win / 32; a.tilesY = d.Hin / 4; a.ntiles = d.N * a.tilesX * a.tilesY;
   a.ldIn = d.ldIn; a.ldOut = d.ldOut; a.ldMask = d.ldMask; a.flags = d.flags; a.inBytes = c.inBytes;
-  constexpr int ldsBytes = 2 * 2 * 6 * 48 * 64;            // two stages of two planes
+  const bool lines = !getenv("FACEOFF_H64_NO_LINES");       // (read per call: tools/ab_bf16.py A/Bs the two epilogues in one process)
+  const int ldsBytes = 2 * 2 * 6 * 48 * 64 + (lines ? 4 * 16 * 80 : 0);            // two stages of two planes (+ the four waves' epilogue patches)
   const bool maskt = (d.flags & FO_MASK) && !a.maskBits, maskb = (d.flags & FO_MASK) && a.maskBits;
   FO_REQUIRE(!(a.pooled && ((d.flags & FO_MASK) || a.outBits)), FO_E_SHAPE, "conv_bf16 (halo64): pooled output with a mask or out_bits is not built");
   const int cus = fo_cu_count();
@@ -1952,10 +1967,12 @@ static int launch_halo64(const ConvArgsH& c, hipStream_t s, void* pooled = nullp
 #define FO_HALO64(MT, MB, PL, OB)                                                                                                            \
   do {                                                                                                                                       \
     static fo_lds_once once;                                                                                                                 \
-    void (*kern)(const HaloArgs) = conv_halo64_bf16_kernel<MT, MB, PL, OB>;                                                                   \
-    if (!fo_lds_optin(once, reinterpret_cast<const void*>(kern), ldsBytes, "conv_bf16 (halo64)")) return FO_E_HIP;                          \
-    FO_NOTE_T("conv_halo64_bf16_kernel", MT, MB, PL, OB);                                                                                    \
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), ldsBytes, s, a);                                                                         \
+    static fo_lds_once once0;                                                                                                                \
+    void (*kern)(const HaloArgs) = conv_halo64_bf16_kernel<MT, MB, PL, OB, true>;                                                             \
+    void (*kern0)(const HaloArgs) = conv_halo64_bf16_kernel<MT, MB, PL, OB, false>;                                                           \
+    if (!fo_lds_optin(lines ? once : once0, reinterpret_cast<const void*>(lines ? kern : kern0), ldsBytes, "conv_bf16 (halo64)")) return FO_E_HIP; \
+    if (lines) FO_NOTE_T("conv_halo64_bf16_kernel", MT, MB, PL, OB, true); else FO_NOTE_T("conv_halo64_bf16_kernel", MT, MB, PL, OB, false);  \
+    hipLaunchKernelGGL(lines ? kern : kern0, dim3(grid), dim3(256), ldsBytes, s, a);                                                          \
   } while (0)
   if (a.pooled) FO_HALO64(false, false, true, false);
   else if (maskt) { if (a.outBits) FO_HALO64(true, false, false, true); else FO_HALO64(true, false, false, false); }

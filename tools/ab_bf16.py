@@ -17,7 +17,7 @@ dev = torch.device("cuda:0")
 N = int(os.environ.get("FRAMES", "160"))
 ROUNDS = int(os.environ.get("ROUNDS", "9"))
 bf = torch.bfloat16
-ENVS = ("FACEOFF_BF16_SMALL_TILES", "FACEOFF_BF16_BIG_TILES", "FACEOFF_BF16_NO_DMA", "FACEOFF_BF16_TILE512", "FACEOFF_BF16_NO_PPH", "FACEOFF_BF16_NO_HALO", "FACEOFF_BF16_PPH_PERSIST")
+ENVS = ("FACEOFF_BF16_SMALL_TILES", "FACEOFF_BF16_BIG_TILES", "FACEOFF_BF16_NO_DMA", "FACEOFF_BF16_TILE512", "FACEOFF_BF16_NO_PPH", "FACEOFF_BF16_NO_HALO", "FACEOFF_BF16_PPH_PERSIST", "FACEOFF_H64_NO_LINES")
 
 
 def main():
