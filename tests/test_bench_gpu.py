@@ -67,7 +67,7 @@ def test_bench_multi_gpu_code_path_with_one_rank():
     with a single rank: still exactly one JSON line on stdout (RCCL writes its banner to stdout) and a sane value."""
     env = dict(os.environ, FACEOFF_BENCH_FORCE_DDP="1", MASTER_PORT="29577")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
-                          "--no-kernel-events"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+                          "--no-kernel-events", "--c3-sustained", "4"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, lines
@@ -108,7 +108,7 @@ def test_bench_two_rank_control_flow_on_one_gpu():
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    FACEOFF_BENCH_SHARE_GPU="1", FACEOFF_BENCH_BACKEND="gloo")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--clips", "8",
-                                       "--no-cpu-baseline"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT, env=env))
+                                       "--no-cpu-baseline", "--c3-sustained", "4"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT, env=env))
     outs = [p.communicate(timeout=900) for p in procs]
     assert all(p.returncode == 0 for p in procs), [o[1][-1500:] for o in outs]
     lines0 = [l for l in outs[0][0].splitlines() if l.strip()]
