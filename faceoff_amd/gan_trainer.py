@@ -131,16 +131,16 @@ class GANTrainer:
         return x
 
     # ------------------------------------------------------------------ one iteration
-    def step(self, img, ground_truth, choices=None):
+    def step(self, img, ground_truth, choices=None, force_ids=None):
         """One GAN iteration (see _step).  Whatever happens inside -- an exception, an early return -- the image discriminator's side stream is
         joined into the main stream before control leaves: the tensors that cross between the two rely on that edge (see _beside)."""
         try:
-            return self._step(img, ground_truth, choices)
+            return self._step(img, ground_truth, choices, force_ids)
         finally:
             if getattr(self, "_pending_join", None) is not None:
                 self._pending_join()
 
-    def _step(self, img, ground_truth, choices=None):
+    def _step(self, img, ground_truth, choices=None, force_ids=None):
         """img [N,6,H,W] (one clip of N >= window frames, utils.py:29-38), ground_truth [N,3,H,W].  Returns a dict of
         device scalars; which keys depends on the iteration's parity (generator: recon, latent, g_loss_2d, g_loss_3d;
         discriminator: recon, latent, d_loss_3d, d_loss_2d)."""
@@ -156,7 +156,10 @@ class GANTrainer:
         c = choices if choices is not None else self.draw(N, gen_iter)
         w, r = self.window, c["random_idx"]
         assert N >= w and 0 <= r <= N - w
-        S = eng.forward(img, training=True, T=N)
+        S = eng.forward(img, training=True, T=N, force_ids=force_ids)          # (force_ids: teacher-forced codes, parity tests: VQVAEEngine.forward)
+        self.last_ids = (S["id_t"], S["id_b"])
+        if getattr(self, "keep_states", False):                               # parity tests only: the generator's forward state stays alive
+            self.last_gen_state = S                                           # (its ReLU branches are read back: tests/_fullsize_oracle.py)
         dec = S["dec"]
         acc = torch.zeros(1, device=eng.device)
         ops.mse_slice_fwd(dec, ground_truth, acc)
@@ -180,10 +183,12 @@ class GANTrainer:
             l3 = torch.zeros(1, device=eng.device)
             g3 = ralsgan_pair(S3["logits"], 0, 1, 1.0, 0.0, 0.5, l3, want_gb=False)
             gx3 = self.d3.backward(S3, g3, param_grads=False, input_grad=True, samples=(0, 1))
+            self.last_disc_states = (S2, S3)                                  # (what the discriminators kept for their backward: parity tests read the LeakyReLU masks)
             joined()                                                          # both input gradients add into g_win: on this stream, image then video
             pairs_backward(gx2[0], 0, c["frame_id"], 1, 1, g_win)
             first, step = (w - 1, -1) if c["flip_fake"] else (1, 1)
             pairs_backward(gx3[0], 0, first, step, w - 1, g_win)
+            self.last_g_dec = g_dec                                           # (d G_loss / d dec before the engine's backward consumes it: parity tests)
             eng.backward(S, g_dec, one * LATENT_LOSS_WEIGHT)                  # G_loss = recon + latent + G_2d + G_3d (:375)
             if self.scheduler is not None:
                 self.scheduler.step()                                         # :380-381, before the optimiser
@@ -205,6 +210,7 @@ class GANTrainer:
             l3 = torch.zeros(1, device=eng.device)
             g3 = ralsgan_pair(S3["logits"], 1, 0, 1.0, 0.0, 0.5, l3)
             self.d3.backward(S3, g3, param_grads=True, input_grad=False)
+            self.last_disc_states = (S2, S3)
             self.d3.adam_step(self.d_lr, grad_scale=self._sum_over_ranks(self.d3.flat_grads))
             joined()
             out.update(d_loss_3d=l3, d_loss_2d=l2)

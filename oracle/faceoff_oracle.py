@@ -147,62 +147,92 @@ class _NoSim:
     act = grad = w = staticmethod(_identity)
 
 
+class ForcedReLU:
+    """Teacher-forced ReLU branches (parity tests at the timed sizes only; the default everywhere is plain F.relu = the reference's
+    arithmetic): `relu(x, name)` takes the branch `masks[name]` says (x where True, 0 where False) instead of testing x > 0, and records
+    every unit where that differs from its own x > 0 with |x| relative to the tensor's scale -- the near-tie evidence.  Why: ReLU's
+    derivative jumps at zero, a pre-activation within fp32 rounding of zero (there are hundreds of millions of units in a 160-frame step:
+    a few dozen always are) lets two fp32 implementations take different branches, and a filter or bias gradient -- a sum of ~10^5..10^6
+    terms of random sign -- moves by that unit's whole contribution.  With the branches of the implementation under test forced, and each
+    difference asserted to be such a near-tie, what is compared is the arithmetic.  The counterpart of `quantize_forward(force_ind=...)`
+    and `disc_oracle` `force_masks`.  Site names: see `relu_sites`."""
+
+    def __init__(self, masks):
+        self.masks, self.diffs = masks, []
+
+    def __call__(self, x, name):
+        m = self.masks.get(name)
+        if m is None:
+            return F.relu(x)
+        xd = x.detach()
+        d = m != (xd > 0)
+        if d.any():
+            self.diffs.append((name, int(d.sum()), float(xd[d].abs().max() / xd.abs().max())))
+        return torch.where(m, x, torch.zeros_like(x))
+
+
+def _plain_relu(x, name):
+    return F.relu(x)
+
+
 # --------------------------------------------------------------------------- conv stacks
-def _res_block(x, p, prefix, r=_NoSim, out_relu=False):
+def _res_block(x, p, prefix, r=_NoSim, out_relu=False, relu=_plain_relu):
     """ResBlock.forward (:97-101): ReLU -> Conv3x3 -> ReLU -> Conv1x1, out += input.  (out_relu: the Encoder's / Decoder's
-    trailing ReLU (:126,145), which the engine applies before the block's output is stored -- the same values either way.)"""
-    h = F.relu(x)
+    trailing ReLU (:126,145), which the engine applies before the block's output is stored -- the same values either way.)
+    relu(x, site): F.relu by default; ForcedReLU in the timed-size parity tests (sites `<prefix>.in`, `.hid`, `.out`)."""
+    h = relu(x, prefix + ".in")
     h = F.conv2d(h, r.w(p[prefix + ".conv.1.weight"]), p[prefix + ".conv.1.bias"], padding=1)
-    h = r.act(F.relu(h))
+    h = r.act(relu(h, prefix + ".hid"))
     h = F.conv2d(h, r.w(p[prefix + ".conv.3.weight"]), p[prefix + ".conv.3.bias"])
     h = h + x
-    return r.act(F.relu(h) if out_relu else h)
+    return r.act(relu(h, prefix + ".out") if out_relu else h)
 
 
-def encoder(x, p, prefix, stride, n_res_block=2, r=_NoSim):
-    """Encoder (:103-131)."""
+def encoder(x, p, prefix, stride, n_res_block=2, r=_NoSim, relu=_plain_relu):
+    """Encoder (:103-131).  (relu sites: `<prefix>.blocks.0`, `.2` and the ResBlocks')"""
     b = prefix + ".blocks."
     if stride == 4:
-        x = r.act(F.relu(F.conv2d(x, r.w(p[b + "0.weight"]), p[b + "0.bias"], stride=2, padding=1)))
-        x = r.act(F.relu(F.conv2d(x, r.w(p[b + "2.weight"]), p[b + "2.bias"], stride=2, padding=1)))
+        x = r.act(relu(F.conv2d(x, r.w(p[b + "0.weight"]), p[b + "0.bias"], stride=2, padding=1), b + "0"))
+        x = r.act(relu(F.conv2d(x, r.w(p[b + "2.weight"]), p[b + "2.bias"], stride=2, padding=1), b + "2"))
         x = r.act(F.conv2d(x, r.w(p[b + "4.weight"]), p[b + "4.bias"], padding=1))
         first = 5
     else:
-        x = r.act(F.relu(F.conv2d(x, r.w(p[b + "0.weight"]), p[b + "0.bias"], stride=2, padding=1)))
+        x = r.act(relu(F.conv2d(x, r.w(p[b + "0.weight"]), p[b + "0.bias"], stride=2, padding=1), b + "0"))
         x = r.act(F.conv2d(x, r.w(p[b + "2.weight"]), p[b + "2.bias"], padding=1))
         first = 3
     for i in range(n_res_block):
-        x = _res_block(x, p, f"{b}{first + i}", r, out_relu=(i == n_res_block - 1))
+        x = _res_block(x, p, f"{b}{first + i}", r, out_relu=(i == n_res_block - 1), relu=relu)
     return x if n_res_block else F.relu(x)
 
 
-def decoder(x, p, prefix, stride, n_res_block=2, r=_NoSim):
-    """Decoder (:134-166).  (bf16 policy: the last layer's output is left to the caller -- `dec` itself stays fp32.)"""
+def decoder(x, p, prefix, stride, n_res_block=2, r=_NoSim, relu=_plain_relu):
+    """Decoder (:134-166).  (bf16 policy: the last layer's output is left to the caller -- `dec` itself stays fp32.)
+    (relu sites: the ResBlocks' and, stride 4, `<prefix>.blocks.<k>` behind the first transposed convolution)"""
     b = prefix + ".blocks."
     x = r.act(F.conv2d(x, r.w(p[b + "0.weight"]), p[b + "0.bias"], padding=1))
     for i in range(n_res_block):
-        x = _res_block(x, p, f"{b}{1 + i}", r, out_relu=(i == n_res_block - 1))
+        x = _res_block(x, p, f"{b}{1 + i}", r, out_relu=(i == n_res_block - 1), relu=relu)
     if not n_res_block:
         x = F.relu(x)
     k = 1 + n_res_block + 1
     x = F.conv_transpose2d(x, r.w(p[f"{b}{k}.weight"]), p[f"{b}{k}.bias"], stride=2, padding=1)
     if stride == 4:
-        x = r.act(F.relu(x))
+        x = r.act(relu(x, f"{b}{k}"))
         x = F.conv_transpose2d(x, r.w(p[f"{b}{k + 2}.weight"]), p[f"{b}{k + 2}.bias"], stride=2, padding=1)
     return x
 
 
-def conv3d_postnet(x5, p, prefix, r=_NoSim):
-    """Conv3dLatentPostnet (:169-190) on [B,C,T,H,W]."""
+def conv3d_postnet(x5, p, prefix, r=_NoSim, relu=_plain_relu):
+    """Conv3dLatentPostnet (:169-190) on [B,C,T,H,W].  (relu sites `<prefix>.conv3d.0`, `.1`)"""
     for i in range(3):
         x5 = F.conv3d(x5, r.w(p[f"{prefix}.conv3d.{i}.0.weight"]), p[f"{prefix}.conv3d.{i}.0.bias"], padding=1)
         if i < 2:
-            x5 = F.relu(x5)
+            x5 = relu(x5, f"{prefix}.conv3d.{i}")
         x5 = r.act(x5)
     return x5
 
 
-def vqvae_forward(x, p, training=True, all_reduce=None, T=None, bf16sim=False, force_ids=None):
+def vqvae_forward(x, p, training=True, all_reduce=None, T=None, bf16sim=False, force_ids=None, relu=None):
     """VQVAE.forward (:243-259) generalised to clips.
 
     x: [B,T,6,H,W] (or [N,6,H,W] with T=None => one clip of N frames, the literal reference).
@@ -216,8 +246,9 @@ def vqvae_forward(x, p, training=True, all_reduce=None, T=None, bf16sim=False, f
         T_ = T if T is not None else x.shape[0]
         B = x.shape[0] // T_
     r = _BF16Sim if bf16sim else _NoSim      # (bf16sim: the rounding points of the bf16-operand engine, see _BF16Sim)
-    enc_b = encoder(r.act(frames) if bf16sim else frames, p, "enc_b", 4, r=r)                    # :237-241
-    enc_t = encoder(r.act(enc_b), p, "enc_t", 2, r=r)        # (r.act on a stored tensor: a no-op forward; backward it rounds THIS consumer's gradient, which the engine stores before the fan-in add)
+    relu = relu or _plain_relu               # (a ForcedReLU in the timed-size parity tests; F.relu = the reference otherwise)
+    enc_b = encoder(r.act(frames) if bf16sim else frames, p, "enc_b", 4, r=r, relu=relu)                    # :237-241
+    enc_t = encoder(r.act(enc_b), p, "enc_t", 2, r=r, relu=relu)        # (r.act on a stored tensor: a no-op forward; backward it rounds THIS consumer's gradient, which the engine stores before the fan-in add)
 
     def clips(t):   # :247  [N,C,h,w] -> [B,C,T,h,w]
         n, c, h, w = t.shape
@@ -227,8 +258,8 @@ def vqvae_forward(x, p, training=True, all_reduce=None, T=None, bf16sim=False, f
         b, c, tt, h, w = t5.shape
         return t5.permute(0, 2, 1, 3, 4).reshape(b * tt, c, h, w)
 
-    enc_b_conv = frames_of(conv3d_postnet(clips(enc_b), p, "conv3d_encoded_b", r))   # :250
-    enc_t_conv = frames_of(conv3d_postnet(clips(enc_t), p, "conv3d_encoded_t", r))
+    enc_b_conv = frames_of(conv3d_postnet(clips(enc_b), p, "conv3d_encoded_b", r, relu))   # :250
+    enc_t_conv = frames_of(conv3d_postnet(clips(enc_t), p, "conv3d_encoded_t", r, relu))
 
     # encode_quantized (:261-278)
     qt_in = r.grad(F.conv2d(enc_t_conv, r.w(p["quantize_conv_t.weight"]), p["quantize_conv_t.bias"]).permute(0, 2, 3, 1))
@@ -236,7 +267,7 @@ def vqvae_forward(x, p, training=True, all_reduce=None, T=None, bf16sim=False, f
         qt_in, p["quantize_t.embed"], p["quantize_t.cluster_size"], p["quantize_t.embed_avg"],
         training, all_reduce, force_ind=None if force_ids is None else force_ids[0])
     quant_t = r.act(quant_t.permute(0, 3, 1, 2))
-    dec_t = r.act(decoder(quant_t, p, "dec_t", 2, r=r))
+    dec_t = r.act(decoder(quant_t, p, "dec_t", 2, r=r, relu=relu))
     cat_b = torch.cat([dec_t, enc_b_conv], 1)
     qb_in = r.grad(F.conv2d(cat_b, r.w(p["quantize_conv_b.weight"]), p["quantize_conv_b.bias"]).permute(0, 2, 3, 1))
     quant_b, diff_b, id_b, new_b = quantize_forward(
@@ -247,7 +278,7 @@ def vqvae_forward(x, p, training=True, all_reduce=None, T=None, bf16sim=False, f
 
     # decode (:280-285)
     upsample_t = r.act(F.conv_transpose2d(r.act(quant_t), r.w(p["upsample_t.weight"]), p["upsample_t.bias"], stride=2, padding=1))
-    dec = r.grad(decoder(torch.cat([upsample_t, quant_b], 1), p, "dec", 4, r=r))
+    dec = r.grad(decoder(torch.cat([upsample_t, quant_b], 1), p, "dec", 4, r=r, relu=relu))
     new_buffers = None
     if training:
         new_buffers = {f"quantize_t.{k}": v for k, v in new_t.items()}
@@ -310,13 +341,13 @@ def lpips_forward(inp, target, lp, per_tap=False, bf16sim=False):
 
 # --------------------------------------------------------------------------- the step
 def run_step(x, ground_truth, p, lpips_state=None, training=True, all_reduce=None, lpips_bf16sim=False, bf16sim=False, force_ids=None,
-             weights=(1.0, LATENT_LOSS_WEIGHT, PERCEPTUAL_LOSS_WEIGHT)):
+             weights=(1.0, LATENT_LOSS_WEIGHT, PERCEPTUAL_LOSS_WEIGHT), relu=None):
     """run_step + loss composition (train_faceoff_perceptual.py:32-47,97-98).
 
     x[B,T,6,H,W], ground_truth[B,T,3,H,W].  Returns dict with recon/latent/perceptual/loss
     and the forward dict.  perceptual is 0 when lpips_state is None (BASELINE config 2).
     """
-    fw = vqvae_forward(x, p, training=training, all_reduce=all_reduce, bf16sim=bf16sim, force_ids=force_ids)
+    fw = vqvae_forward(x, p, training=training, all_reduce=all_reduce, bf16sim=bf16sim, force_ids=force_ids, relu=relu)
     gt = ground_truth.reshape(-1, *ground_truth.shape[-3:])
     out = fw["dec"][:, :3]                                   # :37
     recon = F.mse_loss(out, gt)                              # :21,39

@@ -31,11 +31,48 @@ def cgroup_cpus():
     return os.cpu_count() or 1
 
 
+# oracle ReLU site (oracle.faceoff_oracle.ForcedReLU) -> the tensor of VQVAEEngine's forward state S whose sign is that ReLU's branch:
+# post-ReLU outputs, and for a ResBlock's leading ReLU the block's raw input (engine.stage_encode / stage_conv3d / stage_quantize / stage_decode)
+RELU_SITES = {
+    "enc_b.blocks.0": "a0", "enc_b.blocks.2": "a1",
+    "enc_b.blocks.5.in": "a2", "enc_b.blocks.5.hid": "h_eb5", "enc_b.blocks.6.in": "a3", "enc_b.blocks.6.hid": "h_eb6", "enc_b.blocks.6.out": "eb",
+    "enc_t.blocks.0": "t0", "enc_t.blocks.3.in": "t1", "enc_t.blocks.3.hid": "h_et3", "enc_t.blocks.4.in": "t2", "enc_t.blocks.4.hid": "h_et4",
+    "enc_t.blocks.4.out": "et",
+    "conv3d_encoded_b.conv3d.0": "c1", "conv3d_encoded_b.conv3d.1": "c2", "conv3d_encoded_t.conv3d.0": "d1", "conv3d_encoded_t.conv3d.1": "d2",
+    "dec_t.blocks.1.in": "u0", "dec_t.blocks.1.hid": "h_dt1", "dec_t.blocks.2.in": "u1", "dec_t.blocks.2.hid": "h_dt2", "dec_t.blocks.2.out": "u2",
+    "dec.blocks.1.in": "v0", "dec.blocks.1.hid": "h_d1", "dec.blocks.2.in": "v1", "dec.blocks.2.hid": "h_d2", "dec.blocks.2.out": "v2",
+    "dec.blocks.4": "w1",
+}
+
+
+def engine_relu_masks(S):
+    """The ReLU branches the engine took in the forward that left S (fp32 engine): site -> bool [N,C,H,W] on the CPU."""
+    out = {}
+    for site, key in RELU_SITES.items():
+        t = S[key]
+        out[site] = (t > 0).permute(0, 3, 1, 2).contiguous().cpu()
+    return out
+
+
+def forced_relu(masks, f0, f1, T):
+    """oracle.ForcedReLU for frames f0..f1 of the batch (clips of T frames); the Conv3d sites see [B,C,T,H,W]"""
+    sl = {}
+    for site, m in masks.items():
+        m = m[f0:f1]
+        if site.startswith("conv3d_"):
+            n, c, h, w = m.shape
+            m = m.reshape(n // T, T, c, h, w).permute(0, 2, 1, 3, 4)
+        sl[site] = m
+    return O.ForcedReLU(sl)
+
+
 def oracle_step_chunked(img, gt, sd, lpips_state=None, bf16sim=False, lpips_bf16sim=False, force_ids=None, clips_per_chunk=4,
-                        keep_dec=True, threads=None):
+                        keep_dec=True, threads=None, relu_masks=None):
     """img [B,T,6,H,W], gt [B,T,3,H,W] (CPU float tensors), sd = reference-keyed numpy state dict.
     Returns dict(recon, latent, perceptual: python floats; grads {name: tensor}; id_t, id_b; qt_in, qb_in (fp32, detached);
-    dec [N,6,H,W] or None; buffers {name: tensor} = the six EMA buffers after the step)."""
+    dec [N,6,H,W] or None; buffers {name: tensor} = the six EMA buffers after the step; relu_diffs: with relu_masks (engine_relu_masks of the
+    engine's forward state: the oracle takes the ENGINE's ReLU branches) the list of (site, units, largest |x| / tensor scale) where those
+    differ from the oracle's own x > 0)."""
     prev = torch.get_num_threads()
     torch.set_num_threads(threads or min(cgroup_cpus(), 32))
     try:
@@ -46,6 +83,7 @@ def oracle_step_chunked(img, gt, sd, lpips_state=None, bf16sim=False, lpips_bf16
         acc = {k: torch.zeros_like(v) for k, v in p.items() if v.requires_grad}
         tot = dict(recon=0.0, latent=0.0, perceptual=0.0)
         parts = dict(id_t=[], id_b=[], qt_in=[], qb_in=[], dec=[])
+        relu_diffs = []
         for c0 in range(0, B, clips_per_chunk):
             c1 = min(B, c0 + clips_per_chunk)
             wgt = (c1 - c0) / B
@@ -54,7 +92,10 @@ def oracle_step_chunked(img, gt, sd, lpips_state=None, bf16sim=False, lpips_bf16
                 fi = tuple(f.reshape(B, T, *f.shape[-2:])[c0:c1].reshape(-1, *f.shape[-2:]) for f in force_ids)
             for v in p.values():
                 v.grad = None
-            r = O.run_step(img[c0:c1], gt[c0:c1], p, lpt, training=True, lpips_bf16sim=lpips_bf16sim, bf16sim=bf16sim, force_ids=fi)
+            fr = None if relu_masks is None else forced_relu(relu_masks, c0 * T, c1 * T, T)
+            r = O.run_step(img[c0:c1], gt[c0:c1], p, lpt, training=True, lpips_bf16sim=lpips_bf16sim, bf16sim=bf16sim, force_ids=fi, relu=fr)
+            if fr is not None:
+                relu_diffs += fr.diffs
             (r["loss"] * wgt).backward()
             for k in acc:
                 acc[k] += p[k].grad
@@ -72,6 +113,7 @@ def oracle_step_chunked(img, gt, sd, lpips_state=None, bf16sim=False, lpips_bf16
         out.setdefault("dec", None)
         out.update(tot)
         out["grads"] = acc
+        out["relu_diffs"] = relu_diffs
         # EMA buffers from the statistics of ALL vectors: the oracle's own Quantize restatement on the concatenated inputs, codes forced
         # to the ones the chunks chose (identical to what it would choose: same distances) -- in slices of vectors, because the EMA update
         # is linear in the two statistics and a [655 360, 512] one-hot + distance matrix pair is 2.7 GB
