@@ -732,6 +732,109 @@ __global__ __launch_bounds__(256, 2) void conv_rgb_dgrad_bf16_kernel(const ConvA
   }
 }
 
+// Round 5: the same contraction with every gradient row fetched ONCE.  The kernel above re-fetches the three rows of each 64-pixel segment
+// (2.98 GB read per launch for a 1.34 GB operand, profiles/r05_c3_pmc.md).  Here a workgroup walks a contiguous run of output rows DOWN a
+// 64-pixel column strip; the rows of the gradient live in a ring of RS = 8 LDS slots (72 pixels x 128 B each), every step DMAs ONE new row --
+// AHEAD = 5 rows in front of the row the step needs last, so that ~45 KB per workgroup stay in flight (one row ahead, as the per-segment
+// prefetch above, would be 9 KB: latency-bound) -- waits with a counted vmcnt (loads, LDS-DMAs and stores retire in order) and one raw
+// s_barrier per step, and reads the three rows of its output row from their slots.  Strips are laid end to end as VIRTUAL rows: strip
+// (frame, 64-pixel column) contributes H + 2 of them (a zero row above and below), so a step always advances by one row; the two centre
+// rows per strip that are padding store nothing.  Same MFMA order per pixel as the kernel above: bit-identical results.
+__global__ __launch_bounds__(256, 2) void conv_rgb_dgrad_ring_bf16_kernel(const ConvArgsH a, int nstrips, int segsPerRow) {
+  constexpr int SEG = 64, PPR = 9, ROWB = PPR * 1024, RS = 8, AHEAD = 5;      // a row slot: 9 pieces of 8 pixels x 128 B
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];       // RS * ROWB
+  const fo_conv_desc& d = a.d;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, quad = lane >> 4;
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in), 0, a.inBytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (unsigned)(((size_t)(a.M - 1) * d.ldOut + 8) * 2), 0x00020000);
+  lds_byte* const lds3 = (lds_byte*)lds;
+  bf16x8 wf[18];
+#pragma unroll
+  for (int st = 0; st < 18; ++st)
+    wf[st] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(a.wp) + (size_t)l15 * a.Ktot + st * 32 + quad * 8);
+  // DMA roles: piece id = i * 4 + wave of a row's nine: wave 0 issues three per row, waves 1-3 two (an LDS-DMA costs its wave 100+ clocks of issue
+  // whether it fetches or zero-fills, so there are no dummy pieces: the counted waits below differ by wave instead)
+  const int npw = wave == 0 ? 3 : 2;
+  int ppix[3];
+  unsigned pchunk[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int id = i * 4 + wave;
+    ppix[i] = id * 8 + (lane >> 3);
+    pchunk[i] = (unsigned)(((lane & 7) ^ ((ppix[i] >> 1) & 7)) * 16);
+  }
+  const int VH = d.Hin + 2;                                                 // virtual rows per strip
+  const int G = nstrips * VH;
+  auto issue_row = [&](int g) {                                              // virtual row g -> slot g % RS
+    const int strip = g / VH, v = g - strip * VH;
+    const int n = strip / segsPerRow, xs = (strip - n * segsPerRow) * SEG;
+    const int iy = v - 1;
+    const bool rowok = (g >= 0) & (g < G) & ((unsigned)iy < (unsigned)d.Hin);
+    const int slot = ((g % RS) + RS) % RS;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      if (i < npw) {                                                         // (wave-uniform)
+        const int ix = xs - 1 + ppix[i];
+        const bool ok = rowok & ((unsigned)ix < (unsigned)d.Win);
+        dma16(rin, lds3 + slot * ROWB + (i * 4 + wave) * 1024, ok ? (unsigned)(((n * d.Hin + iy) * d.Win + ix) * 128) + pchunk[i] : OOB);
+      }
+    }
+  };
+  const int px = wave * 16 + l15;
+  int foff[3][2];
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int p = px + kw;
+      foff[kw][h] = p * 128 + (((h * 4 + quad) ^ ((p >> 1) & 7)) * 16);
+    }
+  // this workgroup's centres [cA, cB): centre c reads virtual rows c - 1, c, c + 1
+  const int per = (G + gridDim.x - 1) / gridDim.x;
+  const int cA = blockIdx.x * per, cB = min(G, cA + per);
+  if (cA >= cB) return;
+#pragma unroll 1
+  for (int g = cA - 1; g < cA + AHEAD; ++g) issue_row(g);                    // rows cA - 1 .. cA + 4: AHEAD + 1 rows
+  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll 1
+  for (int c = cA; c < cB; ++c) {
+    issue_row(c + AHEAD);
+    // behind row c + 1's pieces this wave has issued: rows c + 2 .. c + 5 (4 npw) and, from the fifth step on, the stores of steps c - 4 .. c - 1 (4)
+    if (wave == 0) {
+      if (c - cA >= 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    } else {
+      if (c - cA >= 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();                                            // every wave's pieces of row c + 1 have landed; everybody is done with row c - 2's slot
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int g = c - 1 + kh;
+      const unsigned char* S = lds + (((g % RS) + RS) % RS) * ROWB;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const bf16x8 xf = *reinterpret_cast<const bf16x8*>(S + foff[kw][h]);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[(kh * 3 + kw) * 2 + h], xf, acc, 0, 0, 0);
+        }
+    }
+    const int strip = c / VH, v = c - strip * VH;
+    const int n = strip / segsPerRow, xs = (strip - n * segsPerRow) * SEG, y = v - 1;
+    const bool rowok = (unsigned)y < (unsigned)d.Hin;
+    const long long m = ((long long)n * d.Hin + (rowok ? y : 0)) * d.Win + xs + px;
+    const bf16x4 o = {(__bf16)acc[0], (__bf16)acc[1], (__bf16)acc[2], (__bf16)acc[3]};
+    // (exactly one store per lane and step, real or out of range: the counted wait above depends on it)
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rout, (rowok && quad < 2) ? (unsigned)((m * d.ldOut + quad * 4) * 2) : OOB, 0, 0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                           // (the zero-fill DMAs of the rows past the run's end)
+}
+
 // ------------------------------------------------------------------------------------------------ big tiles: LDS-DMA ring + ping-pong
 // 256 x BN output tile (BN = 256 or 128), 8 waves, one workgroup per CU, for the layers with >= 128 output channels and a
 // launch of >= 2-3 rounds of tiles.  What it changes against conv_bf16_kernel above, each measured in one process on one device
@@ -2188,6 +2291,17 @@ static int conv_bf16_impl(const fo_conv_desc* d, const void* in, const void* wp,
   if (!smallc && d->KD == 1 && d->Cin == 64 && d->ldIn == 64 && d->Cout <= 8 && d->ldOut == 8 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->ostride == 1 &&
       d->padH == 1 && d->padW == 1 && d->Hin == d->Hm && d->Win == d->Wm && d->Hm == d->Hout && d->Wm == d->Wout && flags == 0 &&
       d->Win % 64 == 0 && a.M >= 64 * 1024 && !(norgb && atoi(norgb)) && !outBits) {
+    const bool ring = !getenv("FACEOFF_RGB_DGRAD_NO_RING");          // (read per call: tests compare the two kernels in one process)
+    if (ring) {                                                              // round 5: every gradient row fetched once (ring of eight rows in LDS)
+      constexpr int ringBytes = 8 * 9 * 1024;
+      static fo_lds_once once_r;
+      if (!fo_lds_optin(once_r, reinterpret_cast<const void*>(conv_rgb_dgrad_ring_bf16_kernel), ringBytes, "conv_bf16 (rgb dgrad, ring)")) return FO_E_HIP;
+      const int spr = d->Win / 64, nstrips = d->N * spr;
+      FO_NOTE("conv_rgb_dgrad_ring_bf16_kernel");
+      hipLaunchKernelGGL(conv_rgb_dgrad_ring_bf16_kernel, dim3(2 * fo_cu_count()), dim3(256), ringBytes, s, a, nstrips, spr);
+      FO_CHECK_LAUNCH();
+      return FO_OK;
+    }
     constexpr int ldsBytes = 2 * 28 * 1024;
     static fo_lds_once once;
     if (!fo_lds_optin(once, reinterpret_cast<const void*>(conv_rgb_dgrad_bf16_kernel), ldsBytes, "conv_bf16 (rgb dgrad)")) return FO_E_HIP;

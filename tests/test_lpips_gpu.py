@@ -623,3 +623,34 @@ def test_models_lpips_LPIPS_is_differentiable_in_its_input_like_the_reference():
         assert np.linalg.norm(got.cpu().numpy() - want.numpy()) <= 2e-2 * np.linalg.norm(want.numpy())
     with torch.no_grad():                                                       # no graph asked for: values only
         assert not m(torch.from_numpy(rec).cuda(), torch.from_numpy(tgt).cuda()).requires_grad
+
+
+def test_rgb_data_gradient_ring_kernel_equals_the_segment_kernel_and_torch():
+    """conv_rgb_dgrad_ring_bf16_kernel (round 5: VGG conv1_1's data gradient, 64 -> 3 channels, with every gradient row fetched once through a ring of
+    eight LDS row slots) against the per-segment kernel it replaces (FACEOFF_RGB_DGRAD_NO_RING=1) -- bit for bit, same MFMA order per pixel -- and
+    against torch on the same bf16 operands, at sizes whose strips end inside a workgroup's run, frames of 2 and 4 strips, and the timed 160 x 256 x 256."""
+    import torch.nn.functional as F
+    from faceoff_amd import ops
+    bf = torch.bfloat16
+    for n, h, w in ((5, 128, 128), (3, 64, 256), (160, 256, 256)):
+        g = torch.Generator(device="cuda").manual_seed(n)
+        gr = (torch.randn((n, h, w, 64), device="cuda", generator=g) * 0.5).to(bf)
+        wt = torch.randn((64, 3, 3, 3), device="cuda", generator=g) * 0.1            # conv1_1's filter [Cout=64][Cin=3][3][3]
+        wpd = ops.pack_conv_dgrad_bf16(wt)
+        outs = []
+        for old in (False, True):
+            if old:
+                os.environ["FACEOFF_RGB_DGRAD_NO_RING"] = "1"
+            try:
+                out = torch.full((n, h, w, 8), float("nan"), device="cuda", dtype=bf)
+                ops.conv_bf16(gr, wpd, None, out, cin=64, cout=3)
+                torch.cuda.synchronize()
+            finally:
+                os.environ.pop("FACEOFF_RGB_DGRAD_NO_RING", None)
+            outs.append(out)
+        assert torch.equal(outs[0][..., :3], outs[1][..., :3]), (n, h, w)
+        if n <= 5:
+            wq = wt.to(bf).float()
+            want = F.conv_transpose2d(gr.float().permute(0, 3, 1, 2), wq, padding=1).permute(0, 2, 3, 1)
+            err = (outs[0][..., :3].float() - want).abs().max().item() / want.abs().max().item()
+            assert err <= 1e-2, (n, h, w, err)
