@@ -52,5 +52,33 @@ for name, H, ci, co in shapes:
         torch.cuda.synchronize()
         bad += diffs + int(dev_max > 2.0 ** -7)
         print(f"{name} {kind:5s}: {REPS} launches, {diffs} differ from the first; first vs register-staged kernel: max |diff| / max |ref| = {dev_max:.2e}", flush=True)
+# round 5: the row-ring kernel of VGG conv1_1's data gradient (64 -> 3 channels; counted vmcnt waits over a ring of LDS row slots) against the
+# per-segment kernel it replaces (bit-identical by construction) and against itself under load
+x = (torch.randn((N, 256, 256, 64), device=dev) * 0.5).to(bf)
+wpd = ops.pack_conv_dgrad_bf16(torch.randn((64, 3, 3, 3), device=dev) * 0.1)
+
+
+def run_rgb():
+    out = torch.zeros((N, 256, 256, 8), device=dev, dtype=bf)
+    ops.conv_bf16(x, wpd, None, out, cin=64, cout=3)
+    return out
+
+
+os.environ["FACEOFF_RGB_DGRAD_NO_RING"] = "1"
+ref = run_rgb()
+os.environ.pop("FACEOFF_RGB_DGRAD_NO_RING")
+first = run_rgb()
+torch.cuda.synchronize()
+same = torch.equal(first[..., :3], ref[..., :3])
+diffs = 0
+for r in range(REPS):
+    if r & 1:
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            noise.mul_(1.0001)
+    diffs += int(not torch.equal(run_rgb(), first))
+torch.cuda.synchronize()
+bad += diffs + int(not same)
+print(f"conv1_1 dgrad (row ring): {REPS} launches, {diffs} differ from the first; equal to the per-segment kernel: {same}", flush=True)
 print("RACE SCREEN", "FAILED" if bad else "clean")
 sys.exit(1 if bad else 0)
