@@ -549,7 +549,9 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_dma_kernel(const ConvArgsH a
 // whole 128-byte pixel lines.  0.92 -> 0.44 ms.  (The same trick does NOT carry to the layer's 64 -> 3 data gradient: there a
 // pixel is 128 B, adjacent lanes of a fragment load are 128 B apart, and the L1 serves one line per lane: 1.28 vs 1.18 ms tiled.)
 template <bool BITS>      // BITS: also the bit plane of the result (a.outBits): one byte per lane and store, through its own descriptor (no branch in the loop)
-__global__ __launch_bounds__(256) void conv_rgb_bf16_kernel(const ConvArgsH a, int nblocks) {
+// (launch bound: the host launches THREE workgroups per CU; without the second argument the kernel compiled to 177-189 VGPRs = two per CU, the third
+// queued behind them -- round 5: 159-162 VGPRs, no spills, 0.430 -> 0.391 ms and 0.465 -> 0.414 with the bit plane; four per CU spills 80 registers)
+__global__ __launch_bounds__(256, 3) void conv_rgb_bf16_kernel(const ConvArgsH a, int nblocks) {
   constexpr int PITCH = 128 + 16;                         // patch row: one pixel's 64 bf16 + pad
   __shared__ __attribute__((aligned(16))) unsigned char patch_all[4][32 * PITCH];
   __shared__ __attribute__((aligned(16))) float bias_s[64];
