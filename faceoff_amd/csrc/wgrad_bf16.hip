@@ -70,8 +70,13 @@ constexpr int row_pitch(int C, int S) { return S == 2 ? (C <= 64 ? 160 : 288) : 
 
 // TA x TB block, WA x (8 / WA) waves, NKW taps per workgroup (1, 3 or 4), KR runs per barrier pair (thin blocks: more MFMAs per step).
 // FAST: row-run form.  SMALLC: the image layers (Cb = 8, k4 s2): b' = kw * 8 + c, and the NKW = 4 taps of the workgroup are the four kh.
+// THIN blocks (two runs per barrier and at most 3 x 32 x 128 accumulator elements per workgroup): the kernel is bound by load -> LDS -> barrier
+// latency, not by the matrix pipe (MFMA-busy 0.11 on the ResBlocks' 3x3 128 -> 32 filter gradient), so TWO workgroups share a CU -- the launch
+// bound keeps them at <= 128 VGPRs (they compiled to 85-130), and the planner hands out two rounds of slabs where their LDS fits twice (round 5).
+constexpr bool wgrad_thin(int TA, int TB, int NKW, int KR) { return KR == 2 && NKW * TA * TB <= 3 * 32 * 128; }
+
 template <int TA, int TB, int WA, int NKW, int KR, bool FAST, bool SMALLC>
-__global__ __launch_bounds__(512, 1) void wgrad_bf16_kernel(const WArgs a) {
+__global__ __launch_bounds__(512, (wgrad_thin(TA, TB, NKW, KR) ? 4 : 2)) void wgrad_bf16_kernel(const WArgs a) {
   constexpr int WB = 8 / WA;
   constexpr int MA = TA / WA / 16, MB = TB / WB / 16;                // 16 x 16 tiles per wave
   static_assert(MA >= 1 && MB >= 1 && TA % (WA * 16) == 0 && TB % (WB * 16) == 0, "wave tiling");
@@ -441,7 +446,7 @@ struct WPlan {
   int TA, TB, WA, NKW, KR;
   bool fast, smallc;
   int tilesA, tilesB, tapRows, taps, units, Apad, Bpad, biasTapRow;
-  int X, wgPerX, maxSlabs;
+  int X, wgPerX, maxSlabs, perCU;
   short mOf[32];
 };
 
@@ -491,7 +496,18 @@ int make_plan(const fo_conv_desc* d, WPlan* p) {
     total += work[tr];
   }
   const int tiles = p->tilesA * p->tilesB;
-  const int budget = std::max(p->tapRows, fo_cu_count() / tiles);     // workgroups per tile: one round, one workgroup per CU
+  // workgroups per CU: two for the thin blocks whose LDS fits twice (wgrad_thin; FACEOFF_WGRAD_ONE_PER_CU=1: round 4's one)
+  {
+    const int S = (p->NKW == 4 && !p->smallc) ? 2 : 1;
+    const int NQ = p->smallc ? 128 : (p->fast ? 32 * S + p->NKW - S : 32);
+    const int lds = 2 * p->KR * (32 * row_pitch(p->TA, 1) + NQ * row_pitch(p->TB, S));
+    static const bool one = getenv("FACEOFF_WGRAD_ONE_PER_CU") != nullptr;
+    // (measured, tools/bench_wgrad_bf16.py, same device: the ResBlocks' 3x3 128 -> 32 0.152 -> 0.114 ms, the image layers 0.182 -> 0.141; the 1x1
+    // forms get nothing from it -- 0.050 -> 0.054 with twice the slabs to reduce -- and keep one)
+    p->perCU = (!one && p->NKW >= 3 && wgrad_thin(p->TA, p->TB, p->NKW, p->KR) && 2 * lds <= 160 * 1024) ? 2 : 1;
+  }
+  const int slots = p->perCU * fo_cu_count();
+  const int budget = std::max(p->tapRows, slots / tiles);             // workgroups per tile: one round of the chip's resident slots
   p->X = budget >= 8 * p->tapRows ? 8 : 1;
   int sum = 0;
   for (int tr = 0; tr < p->tapRows; ++tr) {
@@ -502,7 +518,7 @@ int make_plan(const fo_conv_desc* d, WPlan* p) {
     sum += p->mOf[tr];
   }
   // never a second, nearly empty round of workgroups: trim the tap rows with the least work per slab
-  while ((long long)sum * p->X * tiles > fo_cu_count() && sum > p->tapRows) {
+  while ((long long)sum * p->X * tiles > slots && sum > p->tapRows) {
     int best = -1;
     for (int tr = 0; tr < p->tapRows; ++tr)
       if (p->mOf[tr] > 1 && (best < 0 || work[tr] * p->mOf[best] < work[best] * p->mOf[tr])) best = tr;
