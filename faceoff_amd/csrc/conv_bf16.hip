@@ -1794,8 +1794,12 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16_kernel(const HaloArgs
             cw[j] = code << (8 * quad);                    // byte j * 4 + quad of the wave's eight
           }
           if (a.pooledBits) pw |= pos_bits4((float)(__bf16)m[0], (float)(__bf16)m[1], (float)(__bf16)m[2], (float)(__bf16)m[3]) << (j * 16 + quad * 4);
-          if (!(l15 & 1))
-            *reinterpret_cast<bf16x4*>(a.pooled + ppix * a.ldPooled + half * 64 + wn * 32 + j * 16 + quad * 4) = bf16x4{(__bf16)m[0], (__bf16)m[1], (__bf16)m[2], (__bf16)m[3]};
+          if (!(l15 & 1)) {
+            const bf16x4 mo = {(__bf16)m[0], (__bf16)m[1], (__bf16)m[2], (__bf16)m[3]};
+            // LINES: the wave's 16 pooled pixels (8 per e) through its patch, stored below as ONE instruction of 16-byte pieces instead of four of 8 bytes
+            if (LINES) *reinterpret_cast<bf16x4*>(lds + 2 * STAGE + wave * EPATCH + (e * 8 + (l15 >> 1)) * EPITCH + (j * 16 + quad * 4) * 2) = mo;
+            else *reinterpret_cast<bf16x4*>(a.pooled + ppix * a.ldPooled + half * 64 + wn * 32 + j * 16 + quad * 4) = mo;
+          }
         }
         // the four quads' bytes / nibbles meet by two shuffles each: ONE 8-byte and ONE 4-byte store per pooled pixel instead of eight 1-byte stores
         // scattered over the wave (those made the launch 1.26 ms against 0.90 without them)
@@ -1816,6 +1820,14 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16_kernel(const HaloArgs
           if (!(l15 & 1) && quad == 0) *reinterpret_cast<unsigned*>(a.pooledBits + ppix * (a.Cout / 8) + half * 8 + wn * 4) = pw;
         }
       }
+      if (LINES) {                                         // lane = (pooled pixel lane / 4 of the wave's 16, 16-byte piece lane % 4 of its 64 bytes)
+        __builtin_amdgcn_wave_barrier();
+        const int pp = lane >> 2;
+        const bf16x8 ln = *reinterpret_cast<const bf16x8*>(lds + 2 * STAGE + wave * EPATCH + pp * EPITCH + (lane & 3) * 16);
+        const size_t ppix2 = ((size_t)n * (a.H / 2) + ty * 2 + wm) * (a.W / 2) + tx * 16 + pp;       // (e = pp / 8, pooled column e * 8 + pp % 8 = pp)
+        *reinterpret_cast<bf16x8*>(a.pooled + ppix2 * a.ldPooled + half * 64 + wn * 32 + (lane & 3) * 8) = ln;
+        __builtin_amdgcn_wave_barrier();
+      }
     }
     // the next patch has landed: vmcnt retires in order and the 8 youngest operations are this tile's stores, which may keep flying
     // (nothing reads them; the LDS stage they came from is not involved)
@@ -1823,7 +1835,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16_kernel(const HaloArgs
     // (8 result stores per lane; + 4 bit-plane dwords; + 4 pooled stores, + 2 code stores, + 2 pooled-plane dwords.  A count that is too SMALL only
     // waits for a few of the stores as well; lgkmcnt: the row copy's LDS writes)
     {
-      const int nst = (LINES ? 4 : 8) + (OBITS ? 4 : 0) + (POOL ? 4 : 0) + (POOL && a.pidx ? 2 : 0) + (POOL && a.pooledBits ? 2 : 0);
+      const int nst = (LINES ? 4 : 8) + (OBITS ? 4 : 0) + (POOL ? (LINES ? 1 : 4) : 0) + (POOL && a.pidx ? 2 : 0) + (POOL && a.pooledBits ? 2 : 0);
       if (nst >= 16) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
       else if (nst >= 14) asm volatile("s_waitcnt vmcnt(14) lgkmcnt(0)" ::: "memory");
       else if (nst >= 12) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
