@@ -109,6 +109,8 @@ class FaceOffTrainer:
                     t.record_stream(main)        # allocated on the side stream, read (and freed) on the main one
         S = eng.forward(img, training=True, T=T, force_ids=force_ids)
         self.last_ids = (S["id_t"], S["id_b"])           # the codes of the step just enqueued (two small int64 tensors)
+        if getattr(self, "keep_states", False):          # parity tests only: the forward state (9.6 GB at C2) stays alive until the next step
+            self.last_state = S                          # (its ReLU branches are read back: tests/_fullsize_oracle.py engine_relu_masks)
         dec = S["dec"]
         acc = torch.zeros(1, device=eng.device)
         one = torch.ones(1, device=eng.device)

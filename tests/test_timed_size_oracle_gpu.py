@@ -144,6 +144,7 @@ def test_c3_as_timed_full_size_teacher_forced_vs_cpu_oracle():
     tr = FaceOffTrainer(eng, lr=3e-4, vqlpips=VQLPIPS(lp, dtype="bf16").cuda())
     assert tr.lpips_stream is not None                       # the overlapped form, as timed
     tr.optimizer.step = lambda grad_scale=1.0: None          # keep the gradients, skip the update
+    tr.keep_states = True
     recon, latent, perceptual = tr.step(img.reshape(N, 6, H, W).cuda(), gt.reshape(N, 3, H, W).cuda(), T=T, force_ids=ids)
     torch.cuda.synchronize()
     assert torch.equal(tr.last_ids[0], ids[0]) and torch.equal(tr.last_ids[1], ids[1])
@@ -161,3 +162,19 @@ def test_c3_as_timed_full_size_teacher_forced_vs_cpu_oracle():
     for k, v in ref["buffers"].items():
         obs.check("buf:" + k, rl2(eng.buffers[k].cpu(), v), cap=5e-3)
     obs.flush()
+    # ... and with the VQ-VAE's ReLU branches forced onto the engine's as well (the LPIPS branch's are not): in bf16 a branch differs wherever an
+    # upstream activation was rounded the other way (one ulp = 0.4 %), so far more units than fp32's near-ties -- and forcing them shows how much of
+    # the figures above is branches rather than arithmetic
+    masks = engine_relu_masks(tr.last_state)
+    ref2 = oracle_step_chunked(img, gt, sd, lpips_state=lp, bf16sim=True, lpips_bf16sim=True, clips_per_chunk=2, keep_dec=False,
+                               force_ids=(ref["id_t"], ref["id_b"]), relu_masks=masks)
+    units = sum(d[1] for d in ref2["relu_diffs"])
+    worst_tie = max((d[2] for d in ref2["relu_diffs"]), default=0.0)
+    errs2 = sorted(((rl2(eng.grads[n].cpu(), g), n) for n, g in ref2["grads"].items()), reverse=True)
+    print(f"[C3 as timed, full size, codes AND the VQ-VAE's ReLU branches teacher-forced] {units} ReLU units took the other branch in the oracle (largest |x| there "
+          f"{worst_tie:.1e} of its tensor's scale); gradients rel-L2: worst {errs2[0]}, second {errs2[1]}, median {errs2[len(errs2) // 2][0]:.3e}")
+    assert worst_tie <= 2e-2, sorted(ref2["relu_diffs"], key=lambda d: -d[2])[:3]      # (recorded: 4.9e-3; 142 298 of 1.2e9 units)
+    obs2 = Observed(f"c3_as_timed_full_relu_forced_{B}x{T}x{H}x{W}")
+    for e, n in errs2:       # recorded: worst 3.6e-4 (enc_b.blocks.0.weight), median 2.8e-5
+        obs2.check("grad:" + n, e, cap=2e-3)
+    obs2.flush()
