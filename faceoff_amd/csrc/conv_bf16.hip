@@ -1549,6 +1549,12 @@ __device__ unsigned long long fo_h64_stamps[16];
 // LINES (round 5): a 16-pixel block's result goes through a wave-private 1.25 KB patch in LDS (2 ds_write_b64, 1 ds_read_b128 per lane) so that a
 // store is 16 B per lane and a pixel's 64 bytes (the wave's 32 channels) leave in ONE piece -- 4 store instructions of 16 half-lines per tile and
 // wave instead of 8 of 16 quarter-lines (the store path is priced by line pieces per instruction: the extended-tile kernel's epilogue, above).
+// Patch swizzle: chunk c of patch pixel p sits at position c ^ H64_SWZ(p), on the DMA source side and in the fragment reads.  Round 5: the extended-tile
+// kernel's 2 ((p >> 2) & 1), conflict-free for ds_read_b128 at the three tap shifts kw = 0, 1, 2 (exhaustive search over the instruction's lane groups),
+// instead of {0, 2, 3, 1}[(p >> 2) & 3], which is conflict-free at kw = 0 only (SQ_LDS_BANK_CONFLICT 6-7.7 % of the wave cycles, profiles/r04_c3_pmc.md).
+#ifndef H64_SWZ
+#define H64_SWZ(p) swz2(p)
+#endif
 template <bool MASKT, bool MASKB, bool POOL, bool OBITS, bool LINES>
 __global__ __launch_bounds__(256, 2) void conv_halo64_bf16_kernel(const HaloArgs a) {
   constexpr int PITCH = 48, ROWS = 6, PLANE = ROWS * PITCH * 64, STAGE = 2 * PLANE;     // bytes
@@ -1578,7 +1584,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16_kernel(const HaloArgs
   // ---- DMA roles: instruction id = (plane, patch row, 16-pixel group) = 36 per tile, dealt over the 4 waves; lane = (pixel l / 4, chunk
   // position l % 4).  A lane's share of the source address is ONE constant register (pixel and swizzled chunk), the rest is scalar.
   const int dpix = lane >> 2, dpos = lane & 3;
-  const unsigned dlane = (unsigned)(dpix * a.ldIn * 2 + ((dpos ^ swz(dpix)) * 16));
+  const unsigned dlane = (unsigned)(dpix * a.ldIn * 2 + ((dpos ^ H64_SWZ(dpix)) * 16));
   // A workgroup walks a contiguous run of tiles DOWN the columns of 32 pixels (tile = (n, tx, ty), ty fastest): tile s + 1's patch rows 0, 1 are
   // tile s's rows 4, 5 -- copied LDS -> LDS while tile s computes (12 KB, three 16-byte moves per thread) instead of fetched again.  Only the
   // four new rows are DMA'd: 24 instructions per tile instead of 36, and 1.07 x the input read from memory instead of 1.59 x (every patch row
@@ -1625,7 +1631,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16_kernel(const HaloArgs
   // ---- fragment addressing: pixel column l15 of a 16-pixel block at tap shift kw: patch pixel x16 + l15 + kw, chunk quad ^ swz
   int cq[3];
 #pragma unroll
-  for (int kw = 0; kw < 3; ++kw) cq[kw] = (l15 + kw) * 64 + ((quad ^ swz(l15 + kw)) * 16);
+  for (int kw = 0; kw < 3; ++kw) cq[kw] = (l15 + kw) * 64 + ((quad ^ H64_SWZ(l15 + kw)) * 16);
 
 
   float bv[2][4];
