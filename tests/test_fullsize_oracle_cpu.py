@@ -44,3 +44,53 @@ def test_chunked_oracle_equals_the_oracle_on_the_whole_batch(mode):
     assert errs[len(errs) // 2][0] <= (2e-2 if bf16 else 5e-6)
     for n, b in got["buffers"].items():                        # `p` holds the whole-batch step's post-EMA buffers
         assert rl2(b, p[n]) <= (2e-3 if bf16 else 1e-5), n
+
+
+def test_forced_branches_are_the_identity_on_the_oracles_own_branches_and_only_move_near_ties():
+    """oracle.ForcedReLU / disc_oracle force_masks (the teacher-forced branches of the timed-size GPU tests): (1) the site names the engine-side table uses
+    are exactly the ReLU sites of the oracle's forward; (2) forcing the oracle's OWN branches changes nothing (values and gradients, chunked evaluation
+    with the Conv3d sites' [B,C,T,H,W] slicing included); (3) a forced branch that differs from x > 0 is recorded with |x| relative to the tensor's
+    scale; (4) the same for the discriminators' LeakyReLU."""
+    import _fullsize_oracle as Fo
+    from faceoff_amd.synth import make_disc_state
+    from oracle import disc_oracle as D
+    sd = make_state_dict(3, codebook_scale=0.3, gain=2.0)
+    img, gt = (torch.from_numpy(a) for a in make_batch(77, 3, 2, 32, 32))
+    rec = {}
+
+    def recording(x, name):
+        rec[name] = x.detach() > 0
+        return torch.nn.functional.relu(x)
+    p = O.to_torch_state(sd)
+    r0 = O.run_step(img, gt, p, relu=recording)
+    r0["loss"].backward()
+    g0 = {k: v.grad.clone() for k, v in p.items() if v.requires_grad}
+    assert sorted(rec) == sorted(Fo.RELU_SITES) and len(rec) == 28
+    masks = {}
+    for k, m in rec.items():                                   # frame-major [N,C,H,W], as engine_relu_masks hands them over
+        if k.startswith("conv3d_"):
+            b, c, t, h, w = m.shape
+            m = m.permute(0, 2, 1, 3, 4).reshape(b * t, c, h, w)
+        masks[k] = m
+    out = oracle_step_chunked(img, gt, sd, clips_per_chunk=2, threads=4, relu_masks=masks)
+    assert out["relu_diffs"] == []
+    assert max(float((out["grads"][k] - g0[k]).abs().max() / (g0[k].abs().max() + 1e-30)) for k in g0) <= 2e-5
+    flipped = {k: v.clone() for k, v in masks.items()}
+    site = "enc_b.blocks.2"
+    flipped[site][0, 0, 0, 0] = ~flipped[site][0, 0, 0, 0]
+    out2 = oracle_step_chunked(img, gt, sd, clips_per_chunk=2, threads=4, relu_masks=flipped)
+    d2 = out2["relu_diffs"]        # the flipped unit first (a real value, not a near-tie: everything downstream of it moves, and is recorded too)
+    assert d2[0][0] == site and d2[0][1] == 1 and d2[0][2] > 1e-3 and all(k != "enc_b.blocks.0" for k, _, _ in d2)
+    # the discriminators
+    sdd = make_disc_state(2, 2)
+    x = torch.rand((1, 6, 32, 32), generator=torch.Generator().manual_seed(1)) * 2 - 1
+    pd = D.to_torch_state(sdd)
+    f0 = D.multiscale_discriminator(x, pd, buffers={})
+    own = [[(f0[i][j].detach() > 0) for j in range(4)] for i in range(2)]
+    f1 = D.multiscale_discriminator(x, D.to_torch_state(sdd), buffers={}, force_masks=own)
+    assert all(torch.equal(a, b) for i in range(2) for a, b in zip(f0[i], f1[i]))
+    assert all(D.mask_differences(f1[i], own[i]) == [] for i in range(2))
+    own[0][1][0, 0, 0, 0] = ~own[0][1][0, 0, 0, 0]
+    f2 = D.multiscale_discriminator(x, D.to_torch_state(sdd), buffers={}, force_masks=own)
+    d = D.mask_differences(f2[0], own[0])
+    assert d[0][0] == 1 and d[0][1] == 1 and all(j >= 1 for j, _, _ in d)
