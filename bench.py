@@ -42,6 +42,10 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0         # dense (same table)
 FLOP_PER_FRAME = 64.1e9                # 63.77 GFLOP conv + 0.34 GFLOP VQ distance per frame
 VQ_FLOP_PER_FRAME = 0.34e9             # 2 * (32*32 + 64*64) vectors * 64 * 512 at 256x256
 LPIPS_FLOP_PER_FRAME = 120.3e9         # 20.04 GMAC x (2 forward + 1 dgrad)
+HBM_BW_ACHIEVABLE = 6.29e12            # B/s, measured float4 copy (same guide, chip-level parameters / HBM): the bandwidth a floor is priced at
+# the clock the chip HOLDS under each matrix-kernel class (GRBM_GUI_ACTIVE / wall in the committed --pmc passes: profiles/r05_pmc.md 2.19 GHz under the
+# fp32 Winograd GEMMs, profiles/r05_c3_pmc.md 1.94-1.96 GHz under the bf16 extended-tile kernels; the nameplate peaks assume 2.4 GHz -- guide, DVFS)
+HELD_CLOCK_GHZ = {"f32": 2.19, "bf16": 1.95}
 
 
 def _cpu_oracle_rate(T, H, W, cores, steps, warm=2):
@@ -317,6 +321,33 @@ def main():
     def is_bf16_kernel(name):          # (kernel symbols as rocprofv3 prints them: the library reports them, ops.KernelProfiler)
         return "bf16" in name
 
+    def step_floor(run_step, steps, ms_step, fold):
+        """The step's ATTAINABLE FLOOR given each launch's own bound: `steps` more steps with the side streams folded and an
+        ops.StepLedger on every C-ABI call; per launch max(algorithmic bytes / 6.29 TB/s, algorithmic FLOP / (dense peak of its type x held clock /
+        2.4 GHz)), summed.  `step_floor_ms` lets no two launches overlap (each at its own bound, back to back); `step_floor_perfect_overlap_ms` =
+        max(sum of the HBM times, sum of the matrix times) is what perfect overlap of memory-bound beside matrix-bound launches could reach at best.
+        Both are floors of THIS design's launches (Winograd-domain GEMMs counted as the GEMMs they are, transforms as the bytes they move)."""
+        fold(True)
+        run_step()
+        led = ops.StepLedger().open()
+        try:
+            sync()
+            for _ in range(steps):
+                run_step()
+            sync()
+        finally:
+            led.close()
+            fold(False)
+        f = led.floor(steps, HBM_BW_ACHIEVABLE, lambda k: BF16_MFMA_PEAK_TFLOPS if is_bf16_kernel(k) else FP32_MFMA_PEAK_TFLOPS,
+                      lambda k: HELD_CLOCK_GHZ["bf16" if is_bf16_kernel(k) else "f32"])
+        f["step_frac_of_floor"] = round(f["step_floor_ms"] / ms_step, 4)
+        f["priced_at"] = {"hbm_TBps": HBM_BW_ACHIEVABLE / 1e12, "fp32_mfma_tflops": FP32_MFMA_PEAK_TFLOPS, "bf16_mfma_tflops": BF16_MFMA_PEAK_TFLOPS,
+                          "held_clock_ghz": HELD_CLOCK_GHZ, "nameplate_clock_ghz": 2.4}
+        f["what"] = ("sum over every C-ABI launch of one step of max(bytes / HBM, FLOP / (peak x held clock / 2.4)); bytes = the distinct tensors handed to the "
+                     "launch, each once, scratch excluded (errs low); step_frac_of_floor = step_floor_ms / the timed ms per step (1.0 = every launch at its "
+                     "own bound, no overlap); largest_gaps: kernels by measured (launch alone on the GPU) minus floor")
+        return f
+
     def dominant(summ, steps, ms_serial):
         dom = max(summ, key=lambda k: summ[k]["total_ms"])
         d = summ[dom]
@@ -365,9 +396,11 @@ def main():
                 "exposed_ms": None if exposed is None else round(max_over_ranks(exposed), 4),
                 "exposed_ms_what": "HIP events on the compute stream around its wait for the all-reduce side stream in reducer.finish(), mean over the timed steps, max over ranks",
                 "ms_per_step_min_rank": round(min_over_ranks(my_ms), 3), "ms_per_step_max_rank": round(max_over_ranks(my_ms), 3)}
-    summ = ms_serial = None
+    summ = ms_serial = floor_main = None
     if not args.no_kernel_events:
         summ, ms_serial = per_kernel(eng, trainer, args.steps)
+        floor_main = step_floor(lambda: trainer.step(img, gt, T=T), min(args.steps, 3), dt / args.steps * 1e3,
+                                lambda on, e=eng: e.set_stream_overlap(not on and not args.serial_streams))
     winograd_on = eng.winograd
     wino_max_tile = eng.winograd_max_tile
     del trainer, eng
@@ -412,6 +445,7 @@ def main():
         out["roofline"]["measured"] = ("HIP events per launch over a second K-step region with the side streams joined "
                                        "(kernels run alone; ms_per_step_serial is that region's step time incl. event overhead)")
         out["ms_per_step_serial"] = round(ms_serial, 3)
+        out["step_floor"] = floor_main
         out["kernels"] = {k: {"launches_per_step": v["launches"] / args.steps, "avg_ms": round(v["avg_ms"], 4),
                               "tflops": round(v["tflops"], 2), "tflops_padded_taps_counted": round(v["tflops_nominal"], 2),
                               "ms_per_step": round(v["total_ms"] / args.steps, 3)}
@@ -539,6 +573,8 @@ def main():
             bf16_flop = sum(v["flops_per_launch"] * v["launches"] for k, v in summ_c.items()) / k_c
             out["c3"]["executed_matrix_tflop_per_step"] = round(bf16_flop / 1e12, 3)
             out["c3"]["step_frac_executed_flop_of_bf16_peak"] = round(bf16_flop / (dt_c / k_c) / (BF16_MFMA_PEAK_TFLOPS * 1e12), 4)
+            out["c3"]["step_floor"] = step_floor(lambda: tr_c.step(img, gt, T=T), min(k_c, 3), out["c3"].get("ms_per_step_sustained", dt_c / k_c * 1e3),
+                                                 lambda on, e=eng_c: e.set_stream_overlap(not on and not args.serial_streams))
         del eng_c, tr_c
         torch.cuda.empty_cache()
         # the bf16 VQ-VAE step alone (recon + VQ loss, no LPIPS): what the bf16 matrix pipe does to config 2's workload
@@ -654,6 +690,8 @@ def main():
             exec5 = sum(v["flops_per_launch"] * v["launches"] for v in summ5.values()) / k5 + VQ_FLOP_PER_FRAME * clip
             out["c5"]["executed_matrix_tflop_per_iteration"] = round(exec5 / 1e12, 4)
             out["c5"]["iteration_frac_executed_flop"] = round(exec5 / (dt5 / iters) / (FP32_MFMA_PEAK_TFLOPS * 1e12), 4)
+            f5 = step_floor(lambda: gan.step(cimg, cgt), 4, dt5 / iters * 1e3, lambda on: None)          # (streams are still folded from the block above)
+            out["c5"]["iteration_floor"] = {("iteration" + k[4:] if k.startswith("step_") else k): v for k, v in f5.items()}
         del gan, eng_g
         torch.cuda.empty_cache()
 

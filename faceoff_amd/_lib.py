@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FACEOFF_HIP_LIB", os.path.join(_HERE, "libfaceoff_hip.so"))   # override: A/B kernel builds
 
-ABI_VERSION = 101          # == FO_ABI_VERSION of include/faceoff_hip.h (tests/test_host_cpu.py reads the header); load() refuses any other library
+ABI_VERSION = 102          # == FO_ABI_VERSION of include/faceoff_hip.h (tests/test_host_cpu.py reads the header); load() refuses any other library
 FO_IN_RELU, FO_BIAS, FO_MASK, FO_ADD, FO_OUT_RELU, FO_DEPTH2SPACE, FO_OUT_F32 = 1, 2, 4, 8, 16, 32, 64
 
 
@@ -66,6 +66,7 @@ SIGNATURES = {
     "fo_comm_world": (_I, [_P]),
     "fo_comm_issued": (_L, [_P]),
     "fo_comm_allreduce_async": (_I, [_P, _P, _L, _P]),
+    "fo_comm_broadcast_async": (_I, [_P, _P, _L, _I, _P]),
     "fo_comm_wait": (_I, [_P, _P]),
     "fo_comm_destroy": (_I, [_P]),
     "fo_last_error": (C.c_char_p, []),

@@ -19,6 +19,7 @@ struct Rccl {
   decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
   decltype(&ncclCommInitRank) CommInitRank = nullptr;
   decltype(&ncclAllReduce) AllReduce = nullptr;
+  decltype(&ncclBroadcast) Broadcast = nullptr;
   decltype(&ncclCommDestroy) CommDestroy = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
 };
@@ -48,10 +49,11 @@ bool load_rccl() {
     FO_SYM(GetUniqueId, "ncclGetUniqueId");
     FO_SYM(CommInitRank, "ncclCommInitRank");
     FO_SYM(AllReduce, "ncclAllReduce");
+    FO_SYM(Broadcast, "ncclBroadcast");
     FO_SYM(CommDestroy, "ncclCommDestroy");
     FO_SYM(GetErrorString, "ncclGetErrorString");
 #undef FO_SYM
-    g_ok = g_rccl.GetUniqueId && g_rccl.CommInitRank && g_rccl.AllReduce && g_rccl.CommDestroy && g_rccl.GetErrorString;
+    g_ok = g_rccl.GetUniqueId && g_rccl.CommInitRank && g_rccl.AllReduce && g_rccl.Broadcast && g_rccl.CommDestroy && g_rccl.GetErrorString;
   });
   return g_ok;
 }
@@ -134,7 +136,18 @@ int fo_comm_allreduce_async(fo_comm* c, float* buf, int64_t count, void* after_s
   return FO_OK;
 }
 
-/* `stream` waits (on the device) for every all-reduce issued so far. */
+/* buf[0..count) on every rank := rank `root`'s buf (fp32, in place), ordered like fo_comm_allreduce_async.  What DistributedDataParallel's
+ * broadcast_buffers does for module buffers that are NOT summed over ranks (the discriminators' InstanceNorm running statistics,
+ * mocoganhd_video_disc.py:139-147): rank 0's copy is the one every rank carries on.  Not counted by fo_comm_issued. */
+int fo_comm_broadcast_async(fo_comm* c, float* buf, int64_t count, int root, void* after_stream) {
+  FO_REQUIRE(c && buf && count > 0 && root >= 0 && root < c->world, FO_E_SHAPE, "comm_broadcast: null communicator / buffer, empty message or bad root");
+  FO_HIP(hipEventRecord(c->ev, (hipStream_t)after_stream));
+  FO_HIP(hipStreamWaitEvent(c->stream, c->ev, 0));
+  FO_NCCL(g_rccl.Broadcast(buf, buf, (size_t)count, ncclFloat, root, c->comm, c->stream));
+  return FO_OK;
+}
+
+/* `stream` waits (on the device) for every collective issued so far. */
 int fo_comm_wait(fo_comm* c, void* stream) {
   FO_REQUIRE(c, FO_E_SHAPE, "comm_wait: null communicator");
   FO_HIP(hipEventRecord(c->ev, c->stream));

@@ -51,11 +51,15 @@ class DiscEngine:
             self.grads[k] = self.flat_grads[off:off + n].view(s)
             off += (n + 3) // 4 * 4
         self.buffers = OrderedDict()
+        # every layer's [running_mean | running_var] in ONE arena: data parallel, rank 0's copy is broadcast in one message (GANTrainer)
+        self.flat_buffers = torch.zeros(sum(2 * s[0] for k, s in self.specs if k.endswith("running_mean")), device=self.device)
+        boff = 0
         for k, s in self.specs:
             if k.endswith("running_mean"):
                 # [running_mean | running_var] of a layer live side by side (one kernel argument)
                 base = k[:-len("running_mean")]
-                both = torch.zeros(2 * s[0], device=self.device)
+                both = self.flat_buffers[boff:boff + 2 * s[0]]
+                boff += 2 * s[0]
                 both[s[0]:] = 1.0
                 self.buffers[base + "running_mean"] = both[:s[0]]
                 self.buffers[base + "running_var"] = both[s[0]:]

@@ -61,6 +61,13 @@ class AbiComm:
         s = after_stream if after_stream is not None else torch.cuda.current_stream(t.device)
         _lib.call("fo_comm_allreduce_async", self._h, C.c_void_p(t.data_ptr()), C.c_int64(t.numel()), C.c_void_p(s.cuda_stream))
 
+    def broadcast_async(self, t, root=0, after_stream=None):
+        """t on every rank := rank `root`'s t (contiguous fp32 CUDA tensor), ordered like allreduce_async.  DDP's broadcast_buffers for the
+        buffers that are not summed over ranks (the discriminators' InstanceNorm running statistics)."""
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+        s = after_stream if after_stream is not None else torch.cuda.current_stream(t.device)
+        _lib.call("fo_comm_broadcast_async", self._h, C.c_void_p(t.data_ptr()), C.c_int64(t.numel()), int(root), C.c_void_p(s.cuda_stream))
+
     def wait(self, stream=None):
         s = stream if stream is not None else torch.cuda.current_stream(self.device)
         _lib.call("fo_comm_wait", self._h, C.c_void_p(s.cuda_stream))

@@ -28,9 +28,10 @@ from .trainer import FlatAdam, LATENT_LOSS_WEIGHT
 
 class GANTrainer:
     def __init__(self, engine: VQVAEEngine, disc3d: DiscEngine, disc2d: DiscEngine, lr=3e-4, d_lr=1e-4, scheduler=None, window=16,
-                 rng=None, comm=None):
-        """comm: a distributed.comm.AbiComm -- the three gradient arenas and the VQ statistics then travel through the C-ABI communicator
-        (fo_comm_*) instead of torch.distributed."""
+                 rng=None, comm=None, force_collectives=False):
+        """comm: a distributed.comm.AbiComm -- the three gradient arenas, the VQ statistics and the discriminators' running statistics then
+        travel through the C-ABI communicator (fo_comm_*) instead of torch.distributed.  force_collectives: issue every collective even in a
+        one-rank world (tests: the RCCL / fo_comm path on a single GPU)."""
         self.engine, self.d3, self.d2 = engine, disc3d, disc2d
         self.comm = comm
         self.optimizer = FlatAdam(engine, lr=lr)
@@ -50,14 +51,17 @@ class GANTrainer:
         # flat gradient arenas are summed over ranks in one all-reduce each and averaged inside the Adam launch; the VQ
         # statistics are summed in the forward (vqvae_conv3d_latent.py:63-64)
         self.world = comm.world if comm is not None else get_world_size()
-        if comm is not None and self.world > 1:
+        self.collectives = self.world > 1 or force_collectives
+        self.collectives_issued = 0                # gradient-arena all-reduces + running-statistics broadcasts (the VQ statistics count in the engine's hook)
+        if comm is not None and self.collectives:
             def vq_ar_abi(st):
                 comm.allreduce_async(st)
                 comm.wait()
                 return st
             engine.vq_allreduce = vq_ar_abi
-        elif self.world > 1:
-            engine.vq_allreduce = fused_vq_allreduce()
+        elif self.collectives:
+            vq_ar = fused_vq_allreduce()
+            engine.vq_allreduce = (lambda st: vq_ar(st, always=True)) if force_collectives else vq_ar
 
     def _beside(self):
         """Context manager: the body runs on the image discriminator's side stream behind everything enqueued so far on the current stream
@@ -90,13 +94,34 @@ class GANTrainer:
         return cm()
 
     def _sum_over_ranks(self, flat):
-        if self.world > 1:
+        """DistributedDataParallel's gradient all-reduce for one flat arena (the reference wraps the generator and both discriminators,
+        train_faceoff_perceptual.py:164-169 / disc trainer `modelD.module`): SUM in place behind the current stream, which then waits for it;
+        returns the 1 / world the Adam launch folds in (DDP averages)."""
+        if self.collectives:
             if self.comm is not None:
                 self.comm.allreduce_async(flat)
                 self.comm.wait()
             else:
                 torch.distributed.all_reduce(flat)
+            self.collectives_issued += 1
         return 1.0 / self.world
+
+    def _broadcast_disc_buffers(self):
+        """DDP's broadcast_buffers=True (the default the reference's wrap takes): module buffers that no collective sums -- the discriminators'
+        InstanceNorm running statistics, each rank's moved by its OWN clip -- are overwritten with rank 0's at the start of every forward.
+        Here: one broadcast of each discriminator's buffer arena at the END of the iteration (same state on rank 0, whose checkpoint is the
+        one written; the other ranks hold rank 0's chain instead of diverging until their next forward).  Training-mode InstanceNorm never reads
+        these statistics, so gradients do not depend on it."""
+        if not self.collectives:
+            return
+        for d in (self.d3, self.d2):
+            if self.comm is not None:
+                self.comm.broadcast_async(d.flat_buffers, 0)
+            else:
+                torch.distributed.broadcast(d.flat_buffers, 0)
+            self.collectives_issued += 1
+        if self.comm is not None:
+            self.comm.wait()
 
     # ------------------------------------------------------------------ the random choices, in the reference's call order
     def draw(self, num_frames, generator_iteration):
@@ -183,12 +208,14 @@ class GANTrainer:
             l3 = torch.zeros(1, device=eng.device)
             g3 = ralsgan_pair(S3["logits"], 0, 1, 1.0, 0.0, 0.5, l3, want_gb=False)
             gx3 = self.d3.backward(S3, g3, param_grads=False, input_grad=True, samples=(0, 1))
-            self.last_disc_states = (S2, S3)                                  # (what the discriminators kept for their backward: parity tests read the LeakyReLU masks)
+            if getattr(self, "keep_states", False):
+                self.last_disc_states = (S2, S3)                              # (what the discriminators kept for their backward: parity tests read the LeakyReLU masks)
             joined()                                                          # both input gradients add into g_win: on this stream, image then video
             pairs_backward(gx2[0], 0, c["frame_id"], 1, 1, g_win)
             first, step = (w - 1, -1) if c["flip_fake"] else (1, 1)
             pairs_backward(gx3[0], 0, first, step, w - 1, g_win)
-            self.last_g_dec = g_dec                                           # (d G_loss / d dec before the engine's backward consumes it: parity tests)
+            if getattr(self, "keep_states", False):
+                self.last_g_dec = g_dec                                       # (d G_loss / d dec before the engine's backward consumes it: parity tests)
             eng.backward(S, g_dec, one * LATENT_LOSS_WEIGHT)                  # G_loss = recon + latent + G_2d + G_3d (:375)
             if self.scheduler is not None:
                 self.scheduler.step()                                         # :380-381, before the optimiser
@@ -210,8 +237,10 @@ class GANTrainer:
             l3 = torch.zeros(1, device=eng.device)
             g3 = ralsgan_pair(S3["logits"], 1, 0, 1.0, 0.0, 0.5, l3)
             self.d3.backward(S3, g3, param_grads=True, input_grad=False)
-            self.last_disc_states = (S2, S3)
+            if getattr(self, "keep_states", False):
+                self.last_disc_states = (S2, S3)
             self.d3.adam_step(self.d_lr, grad_scale=self._sum_over_ranks(self.d3.flat_grads))
             joined()
             out.update(d_loss_3d=l3, d_loss_2d=l2)
+        self._broadcast_disc_buffers()
         return out

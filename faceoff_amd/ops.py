@@ -67,6 +67,91 @@ class KernelProfiler:
 
 
 PROFILER = None   # set to a KernelProfiler to time conv launches
+LEDGER = None     # set by StepLedger.open(): _ptr() then notes every tensor handed to the library
+
+
+class StepLedger:
+    """EVERY C-ABI call of a step with what bounds it (bench.py's step-level attainable floor): per call the entry point, the
+    kernel symbol the library noted, the ALGORITHMIC bytes -- the distinct tensors (views: their own elements) handed to the call, each counted
+    once, scratch workspaces excluded; an in-place operand counts once, so the figure errs low -- the algorithmic FLOP where the wrapper declares
+    them (the KernelProfiler.begin() protocol: a ledger is installed as ops.PROFILER too), and HIP events around the call on its stream.
+
+        floor(call) = max(bytes / HBM_BW, flop / (peak(dtype) * held_clock / 2.4 GHz))
+
+    is what that launch could take at best given its own bound; bench.py sums it over the step.  Use with the side streams folded
+    (engine.set_stream_overlap(False)) so that the events bracket a launch that has the GPU to itself."""
+
+    def __init__(self):
+        self.calls = []          # dict(entry, symbol, bytes, flops, ev0, ev1)
+        self._touched = {}
+        self._pending = None
+        self.detail = False
+        self._lib = _lib.load()
+        self._orig_call = None
+
+    def open(self):
+        global LEDGER, PROFILER
+        self._lib.fo_kernel_notes(1)
+        self._orig_call = _lib.call
+        LEDGER = PROFILER = self
+        _lib.call = self._call
+        return self
+
+    def close(self):
+        global LEDGER, PROFILER
+        _lib.call = self._orig_call
+        LEDGER = PROFILER = None
+        self._lib.fo_kernel_notes(0)
+
+    # -- the KernelProfiler protocol the wrappers speak: flops of the call(s) that follow
+    def begin(self, label, flops, nominal=None):
+        self._pending = float(flops)
+
+    def end(self):
+        self._pending = None
+
+    def touch(self, t):
+        if t.is_cuda:
+            self._touched[(t.data_ptr(), t.numel() * t.element_size())] = True
+
+    def _call(self, name, *args):
+        scratch = {b.data_ptr() for b in _ws_cache.values()}
+        nbytes = sum(n for (ptr, n) in self._touched if ptr not in scratch)
+        self._touched = {}
+        flops, self._pending = self._pending or 0.0, None
+        self._lib.fo_last_kernel()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        st = torch.cuda.current_stream()
+        e0.record(st)
+        self._orig_call(name, *args)
+        e1.record(st)
+        self.calls.append(dict(entry=name, symbol=self._lib.fo_last_kernel().decode() or name, bytes=nbytes, flops=flops, ev0=e0, ev1=e1))
+
+    def floor(self, steps, hbm_bw, peak_of, held_clock_of):
+        """-> dict for bench.py's JSON line.  peak_of(symbol) -> dense MFMA TFLOP/s at 2.4 GHz; held_clock_of(symbol) -> GHz the chip holds under
+        that kernel class (profiles/*_pmc.md); hbm_bw in B/s.  Synchronises."""
+        torch.cuda.synchronize()
+        tot = tb = tf = meas = 0.0
+        rows = {}
+        for c in self.calls:
+            t_b = c["bytes"] / hbm_bw
+            t_f = c["flops"] / (peak_of(c["symbol"]) * 1e12 * held_clock_of(c["symbol"]) / 2.4) if c["flops"] else 0.0
+            fl = max(t_b, t_f)
+            ms = c["ev0"].elapsed_time(c["ev1"])
+            tot, tb, tf, meas = tot + fl, tb + t_b, tf + t_f, meas + ms
+            r = rows.setdefault(c["symbol"], dict(launches=0, floor_ms=0.0, measured_ms=0.0, bound_hbm=0, bound_mfma=0))
+            r["launches"] += 1
+            r["floor_ms"] += fl * 1e3
+            r["measured_ms"] += ms
+            r["bound_hbm" if t_b >= t_f else "bound_mfma"] += 1
+        k = 1.0 / steps
+        gaps = sorted(rows.items(), key=lambda kv: -(kv[1]["measured_ms"] - kv[1]["floor_ms"]))
+        return {"step_floor_ms": round(tot * 1e3 * k, 3), "step_floor_perfect_overlap_ms": round(max(tb, tf) * 1e3 * k, 3),
+                "sum_hbm_ms": round(tb * 1e3 * k, 3), "sum_mfma_ms": round(tf * 1e3 * k, 3), "launches_per_step": round(len(self.calls) * k, 1),
+                "measured_serial_launch_ms": round(meas * k, 3),
+                "largest_gaps": [{"kernel": n, "launches_per_step": round(r["launches"] * k, 1), "measured_ms": round(r["measured_ms"] * k, 3),
+                                  "floor_ms": round(r["floor_ms"] * k, 3), "bound": "hbm" if r["bound_hbm"] >= r["bound_mfma"] else "mfma"}
+                                 for n, r in gaps[:8]]}
 
 
 _logged = set()
@@ -91,6 +176,8 @@ def _stream():
 
 
 def _ptr(t):
+    if LEDGER is not None and t is not None:
+        LEDGER.touch(t)
     return C.c_void_p(0 if t is None else t.data_ptr())
 
 

@@ -53,10 +53,10 @@ extern "C" {
                           quantisers' inputs (quantize_conv_t / _b, :208,213: VQ distances and arg-min stay fp32) and the decoder output */
 
 /* ABI version: bumped whenever an exported signature or the meaning of an argument changes (101: the loss kernels take a caller-owned
-   partial-sum workspace `ws` in front of `stream` and OVERWRITE their scalars -- round 4).  The Python binding refuses a library whose
+   partial-sum workspace `ws` in front of `stream` and OVERWRITE their scalars -- round 4; 102: fo_comm_broadcast_async added -- round 6).  The Python binding refuses a library whose
    fo_version() differs from the FO_ABI_VERSION it was written against (faceoff_amd/_lib.py), so an older .so handed in through
    FACEOFF_HIP_LIB is a clean error and not a stream pointer read as a workspace. */
-#define FO_ABI_VERSION 101
+#define FO_ABI_VERSION 102
 int fo_version(void);
 const char* fo_last_error(void);
 /* Kernel notes (measurement plumbing, off by default).  fo_kernel_notes(1): from now on every entry point records the symbol of the MAIN kernel
@@ -555,7 +555,10 @@ int fo_comm_world(const fo_comm* c);
 int64_t fo_comm_issued(const fo_comm* c);   /* all-reduces enqueued so far */
 /* buf[0..count) := sum over ranks, enqueued BEHIND everything enqueued so far on after_stream (the stream that produced buf) */
 int fo_comm_allreduce_async(fo_comm* c, float* buf, int64_t count, void* after_stream);
-/* `stream` waits on the device for every all-reduce issued so far */
+/* buf[0..count) on every rank := rank root's buf, ordered like the all-reduce (DDP's broadcast_buffers for buffers that are not summed:
+   the discriminators' InstanceNorm running statistics); not counted by fo_comm_issued */
+int fo_comm_broadcast_async(fo_comm* c, float* buf, int64_t count, int root, void* after_stream);
+/* `stream` waits on the device for every collective issued so far */
 int fo_comm_wait(fo_comm* c, void* stream);
 int fo_comm_destroy(fo_comm* c);
 

@@ -36,10 +36,12 @@ EMA_DECAY = 0.99              # Quantize.__init__ default (vqvae_conv3d_latent.p
 EMA_EPS = 1e-5
 
 
-def to_torch_state(sd, requires_grad=True):
+def to_torch_state(sd, requires_grad=True, dtype=torch.float32):
+    """dtype: torch.float64 evaluates the SAME restatement in double precision (every function here takes its dtype from its arguments) -- the
+    yardstick the timed-size parity tests measure the fp32 reference arithmetic itself against (tests/test_fp64_anchor_gpu.py)."""
     out = OrderedDict()
     for k, v in sd.items():
-        t = torch.as_tensor(np.asarray(v)).clone().float() if not torch.is_tensor(v) else v.detach().clone().float().cpu()
+        t = torch.as_tensor(np.asarray(v)).clone().to(dtype) if not torch.is_tensor(v) else v.detach().clone().to(dtype).cpu()
         is_buf = k.endswith((".embed", ".cluster_size", ".embed_avg"))
         if requires_grad and not is_buf:
             t.requires_grad_(True)
@@ -99,11 +101,11 @@ class _RoundBF16(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x):
-        return x.bfloat16().float()
+        return x.bfloat16().to(x.dtype)          # (.to(x.dtype): fp32 as ever; the fp64 evaluation keeps its dtype)
 
     @staticmethod
     def backward(ctx, g):
-        return g.bfloat16().float()
+        return g.bfloat16().to(g.dtype)
 
 
 def _identity(x):
@@ -120,13 +122,13 @@ class _RoundGradBF16(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        return g.bfloat16().float()
+        return g.bfloat16().to(g.dtype)
 
 
 def _round_weight(w):
     """bf16 operand copy of an fp32 master filter: value rounded (exactly: the difference is representable), gradient passed
     through unrounded (filter gradients are accumulated and kept in fp32)."""
-    return w + (w.bfloat16().float() - w).detach()
+    return w + (w.bfloat16().to(w.dtype) - w).detach()
 
 
 class _BF16Sim:
@@ -313,7 +315,7 @@ def vgg16_taps(x, lp, bf16sim=False):
         s = _VGG_SLICE_OF[idx]
         w = lp[f"net.slice{s}.{idx}.weight"]
         if bf16sim:
-            w = w.bfloat16().float()
+            w = w.bfloat16().to(w.dtype)
         x = rnd(F.relu(F.conv2d(x, w, lp[f"net.slice{s}.{idx}.bias"], padding=1)))
         idx += 2
         if idx - 1 in tap_after:
@@ -355,7 +357,7 @@ def run_step(x, ground_truth, p, lpips_state=None, training=True, all_reduce=Non
     if lpips_state is not None:
         perceptual = lpips_forward(gt.contiguous(), out.contiguous(), lpips_state, bf16sim=lpips_bf16sim).mean()   # loss.py:33
     else:
-        perceptual = torch.zeros(())
+        perceptual = torch.zeros((), dtype=recon.dtype)
     loss = weights[0] * recon + weights[1] * latent + weights[2] * perceptual   # :98 (weights: (1, 1, 1) in the reference; tests isolate a term)
     return dict(recon=recon, latent=latent, perceptual=perceptual, loss=loss, fw=fw)
 

@@ -272,3 +272,270 @@ def test_gan_iterations_at_the_benched_size_vs_oracle():
             torch.cuda.empty_cache()
     finally:
         torch.set_num_threads(prev)
+
+
+# ---------------------------------------------------------------------------------------------------------------- data parallel (config 5 x N ranks)
+# The reference wraps the generator and both discriminators in DistributedDataParallel (train_faceoff_perceptual.py:164-169; the disc trainer's
+# `modelD.module` presumes the wrap): per rank ONE clip, its own random choices, its own RaLSGAN averages (mocoganhd_losses.py:108-126: the mean
+# of the OTHER logits is over that rank's logits only, so two ranks are NOT one concatenated batch for the adversarial terms); gradients are
+# averaged over ranks, the quantisers' EMA statistics are SUMMED over ranks inside the forward (vqvae_conv3d_latent.py:63-64), and the
+# discriminators' InstanceNorm running statistics are rank 0's (DDP broadcast_buffers).
+_DP_CHOICES = {True: [dict(random_idx=1, frame_id=3, flip_real=True, flip_fake=False), dict(random_idx=0, frame_id=5, flip_real=False, flip_fake=False)],
+               False: [dict(random_idx=2, frame_id=4, flip_real=False, flip_fake=True), dict(random_idx=1, frame_id=2, flip_real=True, flip_fake=True)]}
+
+
+def _dp_snapshot(eng, d3, d2, out):
+    snap = {"g.params": eng.flat_params, "g.grads": eng.flat_grads, "d3.params": d3.flat_params, "d3.grads": d3.flat_grads, "d3.buffers": d3.flat_buffers,
+            "d2.params": d2.flat_params, "d2.grads": d2.flat_grads, "d2.buffers": d2.flat_buffers}
+    snap.update({"g.buf." + k: v for k, v in eng.buffers.items()})
+    snap.update({"loss." + k: v for k, v in out.items()})
+    return {k: v.detach().cpu().clone() for k, v in snap.items()}
+
+
+def _dp_worker(outdir):
+    from faceoff_amd import distributed as dist
+    from faceoff_amd.disc import DiscEngine
+    from faceoff_amd.engine import VQVAEEngine
+    from faceoff_amd.gan_trainer import GANTrainer
+    rank = dist.get_rank()
+    torch.cuda.set_device(0)
+    eng = VQVAEEngine(make_state_dict(2, codebook_scale=0.3, gain=2.0), "cuda:0")
+    d3 = DiscEngine(make_disc_state(8, 3), "cuda:0", dims=3, n_frames=WIN - 1)
+    d2 = DiscEngine(make_disc_state(9, 2), "cuda:0", dims=2)
+    tr = GANTrainer(eng, d3, d2, lr=3e-4, d_lr=1e-4, window=WIN)
+    assert tr.world == 2 and tr.collectives
+    img, gt = make_batch(77, 2, N, H, W)                                      # clip `rank` of a two-clip batch
+    x = torch.from_numpy(img[rank]).reshape(N, 6, H, W).cuda()
+    y = torch.from_numpy(gt[rank]).reshape(N, 3, H, W).cuda()
+    snaps = []
+    init = {"d3.params": d3.flat_params.cpu().clone(), "d2.params": d2.flat_params.cpu().clone()}
+    for gen_iter in (True, False):
+        o = tr.step(x, y, _DP_CHOICES[gen_iter][rank])
+        torch.cuda.synchronize()
+        snaps.append(_dp_snapshot(eng, d3, d2, o))
+    assert tr.collectives_issued == (1 + 2) + (2 + 2)                         # arenas: G | D_img, D_3d; two running-statistics broadcasts per iteration
+    torch.save({"snaps": snaps, "init": init, "offsets": dict(eng.offsets), "d3.keys": [(k, tuple(v.shape)) for k, v in d3.params.items()],
+                "d2.keys": [(k, tuple(v.shape)) for k, v in d2.params.items()]}, f"{outdir}/rank{rank}.pt")
+
+
+def _oracle_rank_iteration(p, p3, p2, img_r, gt_r, c, gen_iter, summed_stats, rec, b3=None, b2=None):
+    """One rank's iteration on the oracle: generator forward with the ranks' SUMMED EMA statistics (summed_stats: per all_reduce call in call
+    order, None on the recording pass, which appends this rank's own to `rec`), then the iteration's losses, backward into p / p3 / p2 .grad."""
+    from oracle import disc_oracle as D
+    from oracle import faceoff_oracle as O
+    calls = [0]
+
+    def all_reduce(t):
+        i = calls[0]
+        calls[0] += 1
+        if summed_stats is None:
+            rec.append(t.clone())
+            return t
+        return summed_stats[i]
+    fw = O.vqvae_forward(torch.from_numpy(img_r), p, training=True, all_reduce=all_reduce)
+    out = fw["dec"][:, :3]
+    gtt = torch.from_numpy(gt_r).reshape(N, 3, H, W)
+    recon, latent = torch.nn.functional.mse_loss(out, gtt), fw["diff"].mean()
+    r = c["random_idx"]
+    x_fake, x = out[r:r + WIN].unsqueeze(0), gtt[r:r + WIN].unsqueeze(0)
+    b3, b2 = ({} if b3 is None else b3), ({} if b2 is None else b2)           # the discriminators' running statistics: read from and moved in these dicts
+    if gen_iter:
+        g2d, g3d = D.generator_gan_losses(x_fake, x, p3, p2, c["frame_id"], c["flip_real"], c["flip_fake"], b3, b2)
+        losses = dict(recon=recon, latent=latent, g_loss_2d=g2d, g_loss_3d=g3d)
+        if summed_stats is not None:
+            (recon + latent + g2d + g3d).backward()
+    else:
+        dl3, dl2 = D.discriminator_losses(x_fake, x, p3, p2, c["frame_id"], c["flip_real"], c["flip_fake"], b3, b2)
+        losses = dict(recon=recon, latent=latent, d_loss_3d=dl3, d_loss_2d=dl2)
+        if summed_stats is not None:
+            dl3.backward()
+            dl2.backward()
+    return fw, losses, b3, b2
+
+
+def _rel(got, want):
+    return float((got - want).abs().max().item() / (want.abs().max().item() + 1e-30))
+
+
+def test_two_rank_gan_iterations_vs_oracle(tmp_path):
+    """gan_trainer.py's data-parallel branches (VERDICT r05 'missing' 1): two gloo ranks on cuda:0, one clip and one set of random choices each,
+    a generator and then a discriminator iteration with the real optimisers.  The oracle side: per rank the iteration of oracle/disc_oracle.py
+    on that rank's clip with the quantisers' statistics summed over the ranks; gradients = the MEAN over ranks of the per-rank oracle gradients
+    (arena / 2 at 1e-3), losses per rank, the six EMA buffers from the summed statistics, the discriminators' running statistics = rank 0's;
+    Adam on the mean gradients.  Afterwards the two ranks hold bit-identical generator, discriminators, codebooks and running statistics."""
+    from faceoff_amd import distributed as dist
+    from faceoff_amd.synth import make_disc_state as mds
+    from oracle import disc_oracle as D
+    from oracle import faceoff_oracle as O
+    dist.launch(_dp_worker, 2, 1, 0, "auto", args=(str(tmp_path),), backend="gloo")
+    r = [torch.load(tmp_path / f"rank{i}.pt") for i in range(2)]
+    for it in range(2):                                                       # bit-identical ranks after each iteration (losses are per rank)
+        for k, v in r[0]["snaps"][it].items():
+            if not k.startswith("loss."):
+                assert torch.equal(v, r[1]["snaps"][it][k]), (it, k)
+    img, gt = make_batch(77, 2, N, H, W)
+    sd, sd3, sd2 = make_state_dict(2, codebook_scale=0.3, gain=2.0), mds(8, 3), mds(9, 2)
+    offsets = r[0]["offsets"]
+    p = O.to_torch_state(sd)
+    worst_all = {}
+    chain3, chain2 = {}, {}                                                   # rank 0's running statistics, carried from iteration to iteration
+    for it, gen_iter in enumerate((True, False)):
+        snap = r[0]["snaps"][it]
+        p3, p2 = D.to_torch_state(sd3), D.to_torch_state(sd2)
+        if it == 1:
+            # the second iteration starts from the ENGINE's state after the first (compared with the oracle's own just below): Adam moves a parameter
+            # whose gradient is rounding noise by +-lr whatever its sign, which would otherwise seed this comparison with 6e-4 steps of random sign
+            prev = r[0]["snaps"][0]
+            for n_, (off, cnt) in offsets.items():
+                p[n_] = prev["g.params"][off:off + cnt].reshape(p[n_].shape).clone().requires_grad_(True)
+            for k in list(p):
+                if "g.buf." + k in prev:
+                    p[k] = prev["g.buf." + k].clone()
+        # pass 1 records every rank's statistics, pass 2 is the iteration with their sums
+        recs = [[], []]
+        with torch.no_grad():
+            for rk in range(2):
+                _oracle_rank_iteration(p, p3, p2, img[rk], gt[rk], _DP_CHOICES[gen_iter][rk], gen_iter, None, recs[rk])
+        summed = [a + b for a, b in zip(*recs)]
+        assert len(summed) == 4                                               # [512] and [64,512] per quantiser
+        # (rank 1 starts every forward from rank 0's statistics -- DDP broadcasts them -- and its own update is overwritten by the next broadcast)
+        res = [_oracle_rank_iteration(p, p3, p2, img[rk], gt[rk], _DP_CHOICES[gen_iter][rk], gen_iter, summed, None,
+                                      *((chain3, chain2) if rk == 0 else (dict(chain3), dict(chain2)))) for rk in (1, 0)][::-1]
+        for rk in range(2):                                                   # per-rank losses
+            for k, v in res[rk][1].items():
+                np.testing.assert_allclose(r[rk]["snaps"][it]["loss." + k].item(), v.item(), rtol=1e-3, err_msg=f"rank {rk} {k}")
+        for k, v in res[0][0]["new_buffers"].items():                        # EMA buffers from the SUMMED statistics (same on both oracle ranks)
+            assert torch.equal(v, res[1][0]["new_buffers"][k])
+            assert _rel(snap["g.buf." + k], v) <= 1e-3, (it, k)
+        for name, b in (("d3", res[0][2]), ("d2", res[0][3])):               # running statistics: rank 0's chain
+            got = _unflatten_disc_buffers(snap[name + ".buffers"], name)
+            for k, v in b.items():
+                assert _rel(got[k], v) <= 1e-3, (it, name, k)
+        if gen_iter:
+            worst = (0.0, "")
+            for n_, (off, cnt) in offsets.items():
+                want = p[n_].grad / 2                                        # DDP: the mean over ranks
+                worst = max(worst, (_rel(snap["g.grads"][off:off + cnt].reshape(want.shape) / 2, want), n_))
+            assert worst[0] <= 1e-3, worst
+            assert torch.equal(snap["d3.params"], r[0]["init"]["d3.params"]) and torch.equal(snap["d2.params"], r[0]["init"]["d2.params"])   # D does not move
+            grads = {n_: (p[n_].grad / 2).clone() for n_ in offsets}
+            pa = {n_: p[n_].detach().clone() for n_ in offsets}
+            O.adam_step(pa, grads, {}, lr=3e-4)
+            dpar = torch.cat([(snap["g.params"][off:off + cnt] - pa[n_].reshape(-1)).abs() for n_, (off, cnt) in offsets.items()])
+            gabs = torch.cat([grads[n_].reshape(-1).abs() for n_ in offsets])
+            off_ = dpar > 1e-4
+            assert dpar.max().item() <= 2.1 * 3e-4 and off_.float().mean().item() < 1e-3 and (gabs[off_] <= 1e-3 * gabs.max()).all()
+            worst_all["generator"] = worst
+        else:
+            assert torch.equal(snap["g.params"], r[0]["snaps"][0]["g.params"])          # the generator does not move on a discriminator iteration
+            for name, pd, sdd in (("d3", p3, sd3), ("d2", p2, sd2)):
+                want = {k: v.grad / 2 for k, v in pd.items() if v.requires_grad}
+                got_g = _unflatten(snap[name + ".grads"], r[0][name + ".keys"])
+                got_p = _unflatten(snap[name + ".params"], r[0][name + ".keys"])
+                tot = max(w.abs().max().item() for w in want.values())
+                worst = (0.0, "")
+                for k, w in want.items():
+                    g = got_g[k] / 2
+                    if w.abs().max().item() < 1e-4 * tot:                     # bias in front of an InstanceNorm: zero up to rounding
+                        assert g.abs().max().item() <= 2e-4 * tot, k
+                        continue
+                    worst = max(worst, (_rel(g, w), k))
+                assert worst[0] <= 1e-3, (name, worst)
+                worst_all[name] = worst
+                D.adam_step(pd, {k: w.clone() for k, w in want.items()}, {}, lr=1e-4, betas=(0.5, 0.999))
+                for k, w in want.items():
+                    big = w.abs() > 1e-3 * max(w.abs().max().item(), 1e-4 * tot)
+                    if w.abs().max().item() >= 1e-4 * tot and big.any():
+                        assert (got_p[k] - pd[k].detach())[big].abs().max().item() <= 5e-6, (name, k)
+    print(f"[two-rank GAN iterations vs per-rank oracle, mean over ranks] ranks bit-identical after both iterations; worst gradient rel err {worst_all}")
+
+
+def _unflatten(flat, keys):
+    out, off = {}, 0
+    for k, shape in keys:
+        n = int(np.prod(shape)) if len(shape) else 1
+        out[k] = flat[off:off + n].reshape(shape)
+        off += (n + 3) // 4 * 4
+    return out
+
+
+def _unflatten_disc_buffers(flat, name):
+    """DiscEngine.flat_buffers -> {reference key: tensor}: [running_mean | running_var] per layer in spec order."""
+    from faceoff_amd.synth import disc_param_specs
+    out, off = {}, 0
+    for k, s in disc_param_specs(3 if name == "d3" else 2, 6, 2):
+        if k.endswith("running_mean"):
+            base = k[:-len("running_mean")]
+            out[base + "running_mean"], out[base + "running_var"] = flat[off:off + s[0]], flat[off + s[0]:off + 2 * s[0]]
+            off += 2 * s[0]
+    return out
+
+
+_GAN_ONE_RANK_SCRIPT = r"""
+import os, random, sys, torch
+sys.path.insert(0, os.getcwd())
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+mode = sys.argv[1]
+torch.cuda.set_device(0)
+from faceoff_amd.disc import DiscEngine
+from faceoff_amd.engine import VQVAEEngine
+from faceoff_amd.gan_trainer import GANTrainer
+from faceoff_amd.synth import make_state_dict, make_batch, make_disc_state
+comm = None
+if mode == "abi":
+    from faceoff_amd.distributed.comm import AbiComm
+    comm = AbiComm.create(0, 1, "cuda:0")
+else:
+    torch.distributed.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % int(sys.argv[2]), rank=0, world_size=1,
+                                         device_id=torch.device("cuda", 0))
+N, H, W, WIN = 8, 32, 32, 6
+img, gt = make_batch(77, 1, N, H, W)
+x, y = torch.from_numpy(img).reshape(N, 6, H, W).cuda(), torch.from_numpy(gt).reshape(N, 3, H, W).cuda()
+out = []
+for force in (True, False):
+    eng = VQVAEEngine(make_state_dict(2, codebook_scale=0.3, gain=2.0), "cuda:0")
+    d3 = DiscEngine(make_disc_state(8, 3), "cuda:0", dims=3, n_frames=WIN - 1)
+    d2 = DiscEngine(make_disc_state(9, 2), "cuda:0", dims=2)
+    tr = GANTrainer(eng, d3, d2, lr=3e-4, d_lr=1e-4, window=WIN, rng=random.Random(3), comm=comm if force else None, force_collectives=force)
+    assert tr.collectives == force
+    before = comm.issued if comm is not None else 0
+    losses = []
+    for it in range(4):                                     # generator, discriminator, generator, discriminator
+        losses.append({k: v.clone() for k, v in tr.step(x, y).items()})
+    torch.cuda.synchronize()
+    if force:
+        assert tr.collectives_issued == 2 * ((1 + 2) + (2 + 2)), tr.collectives_issued
+        if comm is not None:                                # all-reduces through fo_comm_*: per iteration two quantisers' statistics + the arenas (broadcasts are not counted)
+            assert comm.issued - before == 2 * ((2 + 1) + (2 + 2)), comm.issued - before
+    st = {"g": eng.flat_params.clone(), "d3": d3.flat_params.clone(), "d2": d2.flat_params.clone(), "b3": d3.flat_buffers.clone(), "b2": d2.flat_buffers.clone()}
+    st.update({"buf." + k: v.clone() for k, v in eng.buffers.items()})
+    for i, l in enumerate(losses):
+        st.update({f"loss{i}.{k}": v for k, v in l.items()})
+    out.append(st)
+bad = [k for k in out[0] if not torch.equal(out[0][k], out[1][k])]
+assert not bad, "one-rank collectives changed the result: %s" % bad[:6]
+if comm is not None:
+    comm.destroy()
+else:
+    torch.distributed.destroy_process_group()
+print("GAN_ONE_RANK_OK")
+"""
+
+
+@pytest.mark.parametrize("mode", ["abi", "nccl"])
+def test_gan_collectives_in_a_one_rank_world(mode):
+    """The transports the two-rank test cannot use on a one-GPU box (RCCL refuses two ranks on one device): GANTrainer with every collective forced
+    through (abi) the C-ABI communicator fo_comm_{allreduce,broadcast}_async / fo_comm_wait and (nccl) a one-rank torch.distributed "nccl" group --
+    gradient arenas of the generator and of both discriminators (the image discriminator's on its side stream), the quantisers' statistics, the
+    running-statistics broadcast.  Four iterations must equal the plain trainer's bit for bit (a one-rank SUM / broadcast is the identity; what
+    is exercised is the ordering against the compute streams), with the expected number of collectives issued."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", _GAN_ONE_RANK_SCRIPT, mode, str(port)], capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0 and "GAN_ONE_RANK_OK" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])

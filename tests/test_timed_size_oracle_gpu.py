@@ -173,7 +173,7 @@ def test_c3_as_timed_full_size_teacher_forced_vs_cpu_oracle():
     errs2 = sorted(((rl2(eng.grads[n].cpu(), g), n) for n, g in ref2["grads"].items()), reverse=True)
     print(f"[C3 as timed, full size, codes AND the VQ-VAE's ReLU branches teacher-forced] {units} ReLU units took the other branch in the oracle (largest |x| there "
           f"{worst_tie:.1e} of its tensor's scale); gradients rel-L2: worst {errs2[0]}, second {errs2[1]}, median {errs2[len(errs2) // 2][0]:.3e}")
-    assert worst_tie <= 2e-2, sorted(ref2["relu_diffs"], key=lambda d: -d[2])[:3]      # (recorded: 4.9e-3; 142 298 of 1.2e9 units)
+    assert worst_tie <= 1e-2, sorted(ref2["relu_diffs"], key=lambda d: -d[2])[:3]      # (2 x recorded: 4.9e-3 -- about one bf16 ulp (0.4 %) of the tensor's scale; 142 298 of 1.2e9 units)
     obs2 = Observed(f"c3_as_timed_full_relu_forced_{B}x{T}x{H}x{W}")
     for e, n in errs2:       # recorded: worst 3.6e-4 (enc_b.blocks.0.weight), median 2.8e-5
         obs2.check("grad:" + n, e, cap=2e-3)

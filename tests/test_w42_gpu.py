@@ -86,12 +86,17 @@ def test_engine_with_the_stems_on_winograd_equals_the_direct_engine(fixture, gol
     """The golden fixtures' inputs through the engine twice: k4 s2 stems on the direct kernels, and forced onto the F(4x4, 2x2)
     form at these small sizes (by default it is taken from 1024 tiles per plane up: the 256x256 one-clip golden of
     tests/test_e2e_gpu.py runs it).  Forward: every saved activation within 2e-5, code indices equal, the reference golden's
-    forward bounds hold.  Backward: all 70 gradients within 1e-3 of the direct engine's -- unless the 1e-6 forward
-    difference flips a ReLU mask (an activation within rounding of zero: one such element in `d2` of the 64x64 fixture moves a
-    top-level Conv3d filter gradient by 8e-3), in which case the flips are counted and the bound widens, as for VQ near-ties."""
+    forward bounds hold.  Backward: all 70 gradients within 1e-3 of the direct engine's when no ReLU branch differs between the two
+    forwards.  When one does (an activation within rounding of zero: one such element in `d2` of the 64x64 fixture moves a top-level
+    Conv3d filter gradient by 8e-3) NOTHING IS WIDENED (round 5 had a 5e-2 fallback here): each engine is then held to the CPU oracle
+    with ITS OWN branches forced (oracle.ForcedReLU, codes forced too) at 2e-4, and every unit where the forced branch differs from
+    the oracle's own x > 0 is asserted to be a near-tie (|x| <= 1e-4 of its tensor's scale) -- the two engines differ by the branch
+    of near-tie units and by nothing else."""
     import os
     from faceoff_amd import ops
-    from test_e2e_gpu import _engine_step
+    from test_e2e_gpu import _engine_step, golden_state
+    from _fullsize_oracle import engine_relu_masks, oracle_step_chunked, rel_to_scale
+    from faceoff_amd.synth import make_batch
     g = np.load(os.path.join(golden_dir, fixture))
     monkeypatch.setattr(ops, "W42_MIN_ROWS", 1 << 30)
     e0, r0, d0, S0, *_ = _engine_step(g)
@@ -109,10 +114,23 @@ def test_engine_with_the_stems_on_winograd_equals_the_direct_engine(fixture, gol
             flips += int(((a > 0) != (b > 0)).sum().item())
     assert torch.equal(S0["id_t"], S1["id_t"]) and torch.equal(S0["id_b"], S1["id_b"])
     np.testing.assert_allclose([r1.item(), d1.item()], [float(g["recon"]), float(g["latent"])], rtol=1e-3)
-    tol = 1e-3 if flips == 0 else 5e-2
     worst = max(((e1.grads[k] - v).abs().max().item() / (v.abs().max().item() + 1e-30), k) for k, v in e0.grads.items())
     print(f"[{fixture}: stems on F(4x4,2x2) vs direct] ReLU-mask flips {flips}, worst gradient rel diff {worst}")
-    assert worst[0] <= tol, (worst, flips)
+    if flips == 0:
+        assert worst[0] <= 1e-3, worst
+        return
+    B, T_, H, W = (int(g[k]) for k in "BTHW")
+    img, gt = make_batch(int(g["seed_x"]), B, T_, H, W)
+    img, gt = torch.from_numpy(img).reshape(B, T_, 6, H, W), torch.from_numpy(gt).reshape(B, T_, 3, H, W)
+    ids = (S0["id_t"].cpu(), S0["id_b"].cpu())
+    for name, eng, S in (("direct", e0, S0), ("F(4x4,2x2)", e1, S1)):
+        ref = oracle_step_chunked(img, gt, golden_state(g), force_ids=ids, relu_masks=engine_relu_masks(S), keep_dec=False, clips_per_chunk=B)
+        tie = max((d[2] for d in ref["relu_diffs"]), default=0.0)
+        assert tie <= 1e-4, sorted(ref["relu_diffs"], key=lambda d: -d[2])[:3]
+        w = max((rel_to_scale(eng.grads[n].cpu().numpy(), gr.numpy()), n) for n, gr in ref["grads"].items())
+        print(f"[{fixture}: {name} engine vs the oracle on its own branches] {sum(d[1] for d in ref['relu_diffs'])} near-tie units forced "
+              f"(largest |x| / scale {tie:.1e}); worst gradient rel err {w}")
+        assert w[0] <= 2e-4, (name, w)
 
 
 @pytest.mark.parametrize("mode", ["forward", "dgrad"])

@@ -29,5 +29,12 @@ for kind in ("generator", "discriminator"):
             tr.step(img, gt)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         tr.step(img, gt)
-        torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
-    print(f"{kind} iteration: {min(ts):.2f} ms (min of {len(ts)})")
+        th = time.perf_counter()
+        torch.cuda.synchronize(); ts.append(((time.perf_counter() - t0) * 1e3, (th - t0) * 1e3))
+    print(f"{kind} iteration: {min(t for t, _ in ts):.2f} ms (min of {len(ts)}); host enqueue {min(h for _, h in ts):.2f} ms (the step() call returning, nothing awaited)")
+# back to back (what bench.py's c5 leg times): the host runs ahead of the GPU, an iteration's enqueue hides behind the previous one's kernels
+torch.cuda.synchronize(); t0 = time.perf_counter(); hs = []
+for _ in range(iters):
+    a = time.perf_counter(); tr.step(img, gt); hs.append((time.perf_counter() - a) * 1e3)
+torch.cuda.synchronize()
+print(f"back to back: {(time.perf_counter() - t0) * 1e3 / iters:.2f} ms per iteration; host enqueue per iteration {sum(hs) / len(hs):.2f} ms (max {max(hs):.2f})")

@@ -54,6 +54,7 @@ codes = (fw0["id_t"], fw0["id_b"])
 eng = VQVAEEngine(sd, "cuda:0")
 tr = GANTrainer(eng, DiscEngine(sd3, "cuda:0", dims=3, n_frames=win - 1), DiscEngine(sd2, "cuda:0", dims=2), lr=3e-4, d_lr=1e-4, window=win)
 tr.optimizer.step = lambda grad_scale=1.0: None
+tr.keep_states = True
 o = tr.step(x_img, x_gt, c, force_ids=tuple(t.cuda() for t in codes))
 torch.cuda.synchronize()
 g_dec_engine = ops.nhwc_to_nchw(tr.last_g_dec, 6).cpu()[:, :3]
