@@ -142,6 +142,10 @@ def parse_args(argv=None):
                     help="multi-rank gradient / VQ-statistics exchange: `abi` = the C-ABI communicator (fo_comm_* over RCCL, csrc/comm.cpp; "
                          "torch.distributed only does the rendezvous and the bench's own barriers), `torch` = torch.distributed all-reduces. "
                          "Default: abi whenever the process group is RCCL, torch over gloo (tests sharing one GPU)")
+    ap.add_argument("--host-cpus", type=int, default=0,
+                    help="rehearsal of the 8-rank host budget on one GPU (VERDICT r05 item 5): confine this process to the first K CPUs it may use "
+                         "(os.sched_setaffinity, before any GPU call) and run torch with one intra-op thread -- on the pool a rank of an 8-GPU job "
+                         "gets ~2 of the 16 CPUs the cgroup quota allows.  The CPU baseline is skipped (it would time 2 CPUs)")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-launch HIP-event timing")
     ap.add_argument("--serial-streams", action="store_true",
                     help="run the step without side-stream overlap (what profiles/collect.sh traces: kernels run alone)")
@@ -187,6 +191,10 @@ def launch_ranks(n, argv):
 
 def main():
     args = parse_args()
+    if args.host_cpus > 0:             # before anything touches the GPU (and before the ranks are spawned: children inherit the mask)
+        os.sched_setaffinity(0, set(sorted(os.sched_getaffinity(0))[:args.host_cpus]))
+        torch.set_num_threads(1)
+        args.no_cpu_baseline = True
     if args.direct_conv:
         os.environ["FACEOFF_NO_WINOGRAD"] = "1"
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -422,6 +430,9 @@ def main():
                                         if winograd_on else "direct")},
         "loss": {"recon": round(recon.item(), 6), "latent": round(latent.item(), 6)},
     }
+    if args.host_cpus > 0:
+        out["host"] = {"confined_to_cpus": sorted(os.sched_getaffinity(0)), "torch_threads": torch.get_num_threads(),
+                       "what": "--host-cpus: the whole process (launch thread, torch's helper threads, RCCL proxies if any) shares these CPUs"}
     if comm is not None:
         out["comm"] = comm
     if args.perceptual:
@@ -633,7 +644,7 @@ def main():
         clip, win = 30, 16            # one clip of up to 30 frames per iteration (TemporalAlignmentDataset('train', 30)), 16-frame window
         eng_g = VQVAEEngine(make_state_dict(0, codebook_scale=0.3, gain=2.0), dev)
         gan = GANTrainer(eng_g, DiscEngine(make_disc_state(1, 3), dev, dims=3, n_frames=win - 1), DiscEngine(make_disc_state(2, 2), dev, dims=2),
-                         window=win, rng=_random.Random(7 + rank), comm=abi_comm)
+                         window=win, rng=_random.Random(7 + rank), comm=abi_comm, force_collectives=ddp and world == 1)
         cimg, cgt = img[:clip].contiguous(), gt[:clip].contiguous()
         iters = 2 * ((k_leg + 1) // 2)          # generator and discriminator iterations alternate: an even count, --steps of them
         for _ in range(2 * ((w_leg + 1) // 2)):
@@ -648,6 +659,10 @@ def main():
                                  f"VQ-VAE generator + MoCoGAN-HD video (15 frame pairs) and image discriminators, RaLSGAN, alternating G / D updates",
                      "value": round(world * clip * iters / dt5, 2), "unit": "frames/s", "ms_per_iteration": round(dt5 / iters * 1e3, 3),
                      "iterations": iters, "warmup": 2 * ((w_leg + 1) // 2), "dtype": "f32", "loss": {k: round(v.item(), 6) for k, v in o5.items()}}
+        if gan.collectives:         # data parallel: per iteration (1 + 2) [generator: G arena, two running-statistics broadcasts] or (2 + 2) [discriminators]
+            out["c5"]["comm"] = {"collectives_per_iteration": round(gan.collectives_issued / float(iters + 2 * ((w_leg + 1) // 2)), 3),
+                                 "what": "gradient-arena all-reduces + running-statistics broadcasts (the quantisers' statistics all-reduces count in `comm`)",
+                                 "path": "fo_comm" if abi_comm is not None else "torch.distributed"}
         if not args.no_kernel_events:
             # per-kernel timing as for `roofline`: side streams folded, HIP events per launch, two generator + two discriminator iterations
             eng_g.set_stream_overlap(False)

@@ -186,8 +186,9 @@ SIGNATURES.update({
     "fo_wgradnd": (_I, [_ND, _P, _P, _P, _I, _P, C.c_int64, _P]),
     "fo_instnorm_lrelu_fwd": (_I, [_P, _I, _P, _I, _L, _I, _F, _F, _P, _P, _F, _I, _P]),
     "fo_instnorm_lrelu_bwd": (_I, [_P, _I, _P, _I, _P, _P, _I, _L, _I, _F, _P]),
-    "fo_instnorm_lrelu_fwd_batch": (_I, [_P, _I, _P, _I, _I, _L, _I, _F, _F, _P, _P, _P, _F, _I, _P]),
-    "fo_instnorm_lrelu_bwd_batch": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _L, _I, _F, _P]),
+    "fo_instnorm_ws_bytes": (_L, [_I, _L, _I]),
+    "fo_instnorm_lrelu_fwd_batch": (_I, [_P, _I, _P, _I, _I, _L, _I, _F, _F, _P, _P, _P, _F, _I, _P, _L, _P]),
+    "fo_instnorm_lrelu_bwd_batch": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _L, _I, _F, _P, _L, _P]),
     "fo_avgpool3_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "fo_avgpool3_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "fo_disc_pairs": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P]),

@@ -1555,6 +1555,9 @@ __device__ unsigned long long fo_h64_stamps[16];
 #ifndef H64_SWZ
 #define H64_SWZ(p) swz2(p)
 #endif
+#ifndef FO_H64_PRIO
+#define FO_H64_PRIO 0
+#endif
 template <bool MASKT, bool MASKB, bool POOL, bool OBITS, bool LINES>
 __global__ __launch_bounds__(256, 2) void conv_halo64_bf16_kernel(const HaloArgs a) {
   constexpr int PITCH = 48, ROWS = 6, PLANE = ROWS * PITCH * 64, STAGE = 2 * PLANE;     // bytes
@@ -1596,11 +1599,9 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16_kernel(const HaloArgs
     tx = r1 % a.tilesX;
     n = r1 / a.tilesX;
   };
-  auto dma_tile = [&](int tile, int stage, bool reuse) {
+  auto dma_tile = [&](int tile, int stage, bool reuse, int n, int ty, int tx) {      // (n, ty, tx) = tile_of(tile)
     if (FO_ABLATE_H & 8) return;
     const bool live = tile < a.ntiles;
-    int n, ty, tx;
-    tile_of(tile, n, ty, tx);
     const int y0 = ty * 4 - 1, x0 = tx * 32;               // (x0: patch column 0 is image column x0 - 1 = descriptor pixel x0)
     auto piece = [&](int pl, int r, int g) {
       const int iy = y0 + r;
@@ -1644,7 +1645,10 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16_kernel(const HaloArgs
   const int tile_end = min(a.ntiles, (wgInHalf + 1) * per);
   int tile = wgInHalf * per;
   if (tile >= tile_end) return;
-  dma_tile(tile, 0, false);
+  // this tile's coordinates, stepped from tile to tile (tile_of costs two integer divisions, and the loop needed it three times per tile)
+  int n, ty, tx;
+  tile_of(tile, n, ty, tx);
+  dma_tile(tile, 0, false, n, ty, tx);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 #ifdef FO_STAMP_H64
@@ -1655,9 +1659,11 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16_kernel(const HaloArgs
   for (int it = 0; tile < tile_end; ++tile, ++it) {
     const int st = it & 1;
     const bool more = tile + 1 < tile_end;
-    const bool reuse = more && (tile + 1) % a.tilesY != 0;  // the next tile is the one below this one
+    int n1 = n, ty1 = ty + 1, tx1 = tx;                     // the next tile: down the column, then the next column, then the next image
+    if (ty1 == a.tilesY) { ty1 = 0; if (++tx1 == a.tilesX) { tx1 = 0; ++n1; } }
+    const bool reuse = more && ty1 != 0;                    // the next tile is the one below this one
     H64_STAMP(h0);
-    if (more) dma_tile(tile + 1, st ^ 1, reuse);          // next tile's patch: lands during this tile's MFMAs
+    if (more) dma_tile(tile + 1, st ^ 1, reuse, n1, ty1, tx1);          // next tile's patch: lands during this tile's MFMAs
     if (reuse) {                                           // its rows 0, 1 = this patch's rows 4, 5, both planes (whole 48-pixel rows: same layout, same swizzle)
 #pragma unroll
       for (int pl = 0; pl < 2; ++pl) {
@@ -1676,11 +1682,9 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16_kernel(const HaloArgs
     // 1.26 ms against 0.90 for the forward)
     unsigned mw[4] = {0u, 0u, 0u, 0u};
     if (MASKB) {
-      int n_, ty_, tx_;
-      tile_of(tile, n_, ty_, tx_);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const size_t pix = ((size_t)n_ * a.H + ty_ * 4 + 2 * wm + (i >> 1)) * a.W + tx_ * 32 + (i & 1) * 16 + l15;
+        const size_t pix = ((size_t)n * a.H + ty * 4 + 2 * wm + (i >> 1)) * a.W + tx * 32 + (i & 1) * 16 + l15;
         mw[i] = *reinterpret_cast<const unsigned*>(a.maskBits + pix * (a.Cout / 8) + half * 8 + wn * 4);
       }
     }
@@ -1708,6 +1712,9 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16_kernel(const HaloArgs
     };
 #pragma unroll
     for (int h = 0; h < AHEAD && h < NH; ++h) frag(h, xf[h]);
+#if FO_H64_PRIO
+    __builtin_amdgcn_s_setprio(1);                         // (diagnostic variant: the wave in its MFMA loop outranks its SIMD partner's epilogue)
+#endif
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
       const int tap = h >> 2, sl = (h >> 1) & 1, pr = h & 1;
@@ -1719,10 +1726,11 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16_kernel(const HaloArgs
           acc[2 * pr + e][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tap][sl][j], xf[h % (AHEAD + 1)][e], acc[2 * pr + e][j], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
+#if FO_H64_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     H64_STAMP(h2);
     // ---- epilogue: acc[i][j][r] = channel 16 j + 4 quad + r of pixel (row 2 wm + (i >> 1), column 16 (i & 1) + l15)
-    int n, ty, tx;
-    tile_of(tile, n, ty, tx);
     typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
     // (max-pool 2x2 riding along: a wave's two tile rows are one pooled row; the vertical partner of a pixel is the same lane's other
     // accumulator, the horizontal one the neighbouring lane.  max commutes with the monotonic bias + ReLU + rounding, so the pooled tensor is
@@ -1850,6 +1858,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16_kernel(const HaloArgs
       else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
+    n = n1; ty = ty1; tx = tx1;
 #ifdef FO_STAMP_H64
     H64_STAMP(h4);
     if (stamping) { sIssue += h1 - h0; sMfma += h2 - h1; sEpi += h3 - h2; sWait += h4 - h3; ++nT; }

@@ -102,6 +102,173 @@ __global__ __launch_bounds__(256) void instnorm_lrelu_bwd_kernel(const float* __
   }
 }
 
+// ---------------------------------------------------------------------------------------------------- chunked InstanceNorm (round 6)
+// The one-workgroup-per-8-channels kernels above put 16 .. 128 workgroups on 256 CUs, read 32 bytes of every 512 .. 2048-byte row per
+// instruction and pass over x three times: 37 us per launch on tensors that move in 5 (config 5: 24 launches per generator + discriminator
+// pair).  Here the statistics are made in three launches that each fill the chip with whole-row accesses:
+//   (A) partial:  a workgroup takes a chunk of R = 16 * 1024 / C consecutive rows (every thread 16 rows of one float4 channel group, the
+//                 values stay in registers) and writes the chunk's (mean, M2 = sum of squared deviations from ITS mean) -- two-pass inside
+//                 the chunk, so no E[x^2] - mean^2 cancellation -- or, backward, its (sum gz, sum gz z);
+//   (B) merge:    one workgroup per 32 channels folds the chunks in a FIXED order (eight interleaved chains, then the eight in order; Chan's
+//                 pairwise update for (count, mean, M2)): bit-reproducible, no atomics; writes stats = [mean | rstd] and moves the running
+//                 statistics sample by sample in `order`;
+//   (C) apply:    a grid-stride elementwise pass.
+// Taken for C / 4 a power of two between 8 and 256 (the discriminators: 128, 256, 512 channels) in training mode; anything else runs the kernels above.
+constexpr int IN_RPT = 16;              // rows per thread and chunk
+
+__device__ __forceinline__ f32x4 reduce_cg(f32x4 v, f32x4* sh, int tid, int cg) {      // thread = slot * cg + group: sum over the slots
+  sh[tid] = v;
+  __syncthreads();
+  for (int s = 128; s >= cg; s >>= 1) {
+    if (tid < s) sh[tid] += sh[tid + s];
+    __syncthreads();
+  }
+  const f32x4 r = sh[tid & (cg - 1)];
+  __syncthreads();
+  return r;
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void instnorm_partial_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ y, int ldy, long long rows,
+                                                               int C, int cg, float slope, float* __restrict__ part, int nchunk) {
+  __shared__ f32x4 sh[256];
+  const int tid = threadIdx.x, g = tid & (cg - 1), slot = tid / cg, slots = 256 / cg, R = IN_RPT * slots;
+  const int chunk = blockIdx.x, n = blockIdx.y;
+  const long long r0 = (long long)chunk * R;
+  x += (long long)n * rows * ldx;
+  if (BWD) y += (long long)n * rows * ldy;
+  f32x4 v[IN_RPT], z[BWD ? IN_RPT : 1];
+  const float inv_slope = 1.f / slope;
+#pragma unroll
+  for (int i = 0; i < IN_RPT; ++i) {
+    const long long r = r0 + slot + i * slots;
+    v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (BWD) z[i] = v[i];
+    if (r < rows) {
+      v[i] = ld4(x + r * ldx + g * 4);
+      if (BWD) {                              // v = gz = gy * lrelu'(z), z recovered from y
+        const f32x4 yv = ld4(y + r * ldy + g * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const bool pos = yv[e] > 0.f;
+          z[i][e] = pos ? yv[e] : yv[e] * inv_slope;
+          v[i][e] = pos ? v[i][e] : v[i][e] * slope;
+        }
+      }
+    }
+  }
+  f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+  if (BWD) {
+#pragma unroll
+    for (int i = 0; i < IN_RPT; ++i) { a += v[i]; b += v[i] * z[i]; }
+    a = reduce_cg(a, sh, tid, cg);
+    b = reduce_cg(b, sh, tid, cg);
+  } else {
+    const float cnt = (float)min((long long)R, rows - r0);
+#pragma unroll
+    for (int i = 0; i < IN_RPT; ++i) a += v[i];
+    a = reduce_cg(a, sh, tid, cg) * (1.f / cnt);                      // the chunk's mean
+#pragma unroll
+    for (int i = 0; i < IN_RPT; ++i)
+      if (r0 + slot + i * slots < rows) { const f32x4 dlt = v[i] - a; b += dlt * dlt; }
+    b = reduce_cg(b, sh, tid, cg);                                   // its M2
+  }
+  if (slot == 0) {
+    float* o = part + ((long long)n * nchunk + chunk) * 2 * C + g * 4;
+    st4(o, a);
+    st4(o + C, b);
+  }
+}
+
+// grid = C / 32; thread = (chain tid / 32, channel tid % 32)
+template <bool BWD>
+__global__ __launch_bounds__(256) void instnorm_merge_kernel(const float* __restrict__ part, int nchunk, int N, long long rows, int R, int C, float eps,
+                                                             float* __restrict__ stats, float* __restrict__ running, const int* __restrict__ order,
+                                                             float momentum) {
+  __shared__ float shc[8][32], shm[8][32], shq[8][32];
+  const int tid = threadIdx.x, ch = tid & 31, chain = tid >> 5, c = blockIdx.x * 32 + ch;
+  for (int n = 0; n < N; ++n) {
+    const float* p = part + (long long)n * nchunk * 2 * C + c;
+    float cnt = 0.f, mean = 0.f, m2 = 0.f;
+#pragma unroll 4
+    for (int k = chain; k < nchunk; k += 8) {
+      const float a = p[(long long)k * 2 * C], b = p[(long long)k * 2 * C + C];
+      if (BWD) { mean += a; m2 += b; continue; }
+      const float cb = (float)min((long long)R, rows - (long long)k * R), tot = cnt + cb, dlt = a - mean;
+      mean += dlt * (cb / tot);
+      m2 += b + dlt * dlt * (cnt * cb / tot);
+      cnt = tot;
+    }
+    shc[chain][ch] = cnt; shm[chain][ch] = mean; shq[chain][ch] = m2;
+    __syncthreads();
+    if (chain == 0) {
+      for (int j = 1; j < 8; ++j) {
+        const float cb = shc[j][ch], a = shm[j][ch], b = shq[j][ch];
+        if (BWD) { mean += a; m2 += b; continue; }
+        if (cb == 0.f) continue;
+        const float tot = cnt + cb, dlt = a - mean;
+        mean += dlt * (cb / tot);
+        m2 += b + dlt * dlt * (cnt * cb / tot);
+        cnt = tot;
+      }
+      float* st = stats + (long long)n * 2 * C;
+      if (BWD) { st[c] = mean / (float)rows; st[C + c] = m2 / (float)rows; }                 // m1 = mean(gz), m2 = mean(gz z)
+      else { st[c] = mean; st[C + c] = 1.f / sqrtf(m2 / (float)rows + eps); }                // biased variance, as F.instance_norm normalises
+    }
+    __syncthreads();
+  }
+  if (!BWD && running && chain == 0) {       // as instnorm_running_kernel: sample by sample in `order`, the variance recovered from rstd
+    float rm = running[c], rv = running[C + c];
+    const float unb = rows > 1 ? (float)rows / (float)(rows - 1) : 1.f;
+    for (int i = 0; i < N; ++i) {
+      const float* st = stats + (long long)order[i] * 2 * C;
+      const float rstd = st[C + c];
+      rm = rm * (1.f - momentum) + st[c] * momentum;
+      rv = rv * (1.f - momentum) + (1.f / (rstd * rstd) - eps) * unb * momentum;
+    }
+    running[c] = rm;
+    running[C + c] = rv;
+  }
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void instnorm_apply_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ yin, int ldyin,
+                                                             float* __restrict__ out, int ldo, long long rows, int N, int C, int cg, float slope,
+                                                             const float* __restrict__ stats, const float* __restrict__ m12) {
+  const long long total = (long long)N * rows * cg;
+  const float inv_slope = 1.f / slope;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int g = (int)(e & (cg - 1));
+    const long long r = e / cg;                       // row over all samples
+    const int n = (int)(r / rows);
+    const float* st = stats + (long long)n * 2 * C + g * 4;
+    if (BWD) {
+      const f32x4 rstd = ld4(st + C), m1 = ld4(m12 + (long long)n * 2 * C + g * 4), m2 = ld4(m12 + (long long)n * 2 * C + C + g * 4);
+      const f32x4 yv = ld4(yin + r * ldyin + g * 4);
+      f32x4 gv = ld4(x + r * ldx + g * 4), o;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const bool pos = yv[k] > 0.f;
+        const float z = pos ? yv[k] : yv[k] * inv_slope;
+        const float gz = pos ? gv[k] : gv[k] * slope;
+        o[k] = rstd[k] * (gz - m1[k] - z * m2[k]);
+      }
+      st4(out + r * ldo + g * 4, o);
+    } else {
+      f32x4 z = (ld4(x + r * ldx + g * 4) - ld4(st)) * ld4(st + C);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) z[k] = z[k] > 0.f ? z[k] : z[k] * slope;
+      st4(out + r * ldo + g * 4, z);
+    }
+  }
+}
+
+inline bool instnorm_chunked_ok(int C) {
+  const int cg = C / 4;
+  return C % 4 == 0 && cg >= 8 && cg <= 256 && (cg & (cg - 1)) == 0;
+}
+inline int instnorm_chunk_rows(int C) { return IN_RPT * (256 / (C / 4)); }
+
 // running statistics of a batch of samples normalised in one launch: the reference calls the module once per sample, in
 // `order`, and each call moves running_mean / running_var by `momentum` (unbiased variance) -- applied here in that order
 __global__ void instnorm_running_kernel(const float* __restrict__ stats, int N, const int* __restrict__ order, int C, float rows, float eps,
@@ -318,16 +485,38 @@ int fo_instnorm_lrelu_fwd(const float* x, int ldx, float* y, int ldy, int64_t ro
   return FO_OK;
 }
 
+int64_t fo_instnorm_ws_bytes(int N, int64_t rows, int C) {
+  if (N <= 0 || rows <= 0 || !instnorm_chunked_ok(C)) return 0;
+  const int64_t nchunk = (rows + instnorm_chunk_rows(C) - 1) / instnorm_chunk_rows(C);
+  return ((int64_t)N * nchunk * 2 * C + (int64_t)N * 2 * C) * 4;
+}
+
 int fo_instnorm_lrelu_fwd_batch(const float* x, int ldx, float* y, int ldy, int N, int64_t rows, int C, float eps, float slope,
-                                float* stats, float* running, const int32_t* order, float momentum, int use_running, void* stream) {
+                                float* stats, float* running, const int32_t* order, float momentum, int use_running, float* ws, int64_t ws_bytes,
+                                void* stream) {
   FO_REQUIRE(x && y && stats && N > 0 && rows > 0 && C > 0 && C % 8 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && fo_aligned16(x) && fo_aligned16(y),
              FO_E_SHAPE, "instnorm_batch: C %% 8 == 0, ld %% 4 == 0, 16-byte alignment");
   FO_REQUIRE(!use_running || running, FO_E_SHAPE, "instnorm_batch: eval mode needs the running statistics");
+  FO_REQUIRE(use_running || !running || order, FO_E_SHAPE, "instnorm_batch: the sample order of the running-statistics updates is required");
+  const int64_t need = fo_instnorm_ws_bytes(N, rows, C);
+  if (!use_running && need > 0 && ws && ws_bytes >= need) {          // the chunked form (see the kernels)
+    const int R = instnorm_chunk_rows(C), nchunk = (int)((rows + R - 1) / R), cg = C / 4;
+    hipLaunchKernelGGL(instnorm_partial_kernel<false>, dim3(nchunk, N), dim3(256), 0, (hipStream_t)stream, x, ldx, (const float*)nullptr, 0, (long long)rows, C,
+                       cg, slope, ws, nchunk);
+    FO_CHECK_LAUNCH();
+    hipLaunchKernelGGL(instnorm_merge_kernel<false>, dim3(C / 32), dim3(256), 0, (hipStream_t)stream, ws, nchunk, N, (long long)rows, R, C, eps, stats,
+                       running, order, momentum);
+    FO_CHECK_LAUNCH();
+    hipLaunchKernelGGL(instnorm_apply_kernel<false>, dim3(grid_for((long long)N * rows * cg)), dim3(256), 0, (hipStream_t)stream, x, ldx,
+                       (const float*)nullptr, 0, y, ldy, (long long)rows, N, C, cg, slope, stats, (const float*)nullptr);
+    FO_CHECK_LAUNCH();
+    FO_NOTE_T("instnorm_partial_kernel", false);
+    return FO_OK;
+  }
   hipLaunchKernelGGL(instnorm_lrelu_fwd_kernel, dim3(C / 8, N), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, (long long)rows, C, eps,
                      slope, stats, use_running ? running : nullptr, momentum, use_running);
   FO_CHECK_LAUNCH();
   if (!use_running && running) {
-    FO_REQUIRE(order, FO_E_SHAPE, "instnorm_batch: the sample order of the running-statistics updates is required");
     hipLaunchKernelGGL(instnorm_running_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats, N, order, C, (float)rows, eps,
                        momentum, running);
     FO_CHECK_LAUNCH();
@@ -336,9 +525,25 @@ int fo_instnorm_lrelu_fwd_batch(const float* x, int ldx, float* y, int ldy, int 
 }
 
 int fo_instnorm_lrelu_bwd_batch(const float* gy, int ldg, const float* y, int ldy, const float* stats, float* gx, int ldgx, int N,
-                                int64_t rows, int C, float slope, void* stream) {
+                                int64_t rows, int C, float slope, float* ws, int64_t ws_bytes, void* stream) {
   FO_REQUIRE(gy && y && stats && gx && N > 0 && rows > 0 && C % 8 == 0 && ldg % 4 == 0 && ldy % 4 == 0 && ldgx % 4 == 0 && slope != 0.f, FO_E_SHAPE,
              "instnorm_bwd_batch: C %% 8 == 0, ld %% 4 == 0, slope != 0");
+  const int64_t need = fo_instnorm_ws_bytes(N, rows, C);
+  if (need > 0 && ws && ws_bytes >= need) {
+    const int R = instnorm_chunk_rows(C), nchunk = (int)((rows + R - 1) / R), cg = C / 4;
+    float* m12 = ws + (int64_t)N * nchunk * 2 * C;                  // [N][mean(gz) | mean(gz z)]
+    hipLaunchKernelGGL(instnorm_partial_kernel<true>, dim3(nchunk, N), dim3(256), 0, (hipStream_t)stream, gy, ldg, y, ldy, (long long)rows, C, cg, slope,
+                       ws, nchunk);
+    FO_CHECK_LAUNCH();
+    hipLaunchKernelGGL(instnorm_merge_kernel<true>, dim3(C / 32), dim3(256), 0, (hipStream_t)stream, ws, nchunk, N, (long long)rows, R, C, 0.f, m12,
+                       (float*)nullptr, (const int*)nullptr, 0.f);
+    FO_CHECK_LAUNCH();
+    hipLaunchKernelGGL(instnorm_apply_kernel<true>, dim3(grid_for((long long)N * rows * cg)), dim3(256), 0, (hipStream_t)stream, gy, ldg, y, ldy, gx, ldgx,
+                       (long long)rows, N, C, cg, slope, stats, m12);
+    FO_CHECK_LAUNCH();
+    FO_NOTE_T("instnorm_partial_kernel", true);
+    return FO_OK;
+  }
   hipLaunchKernelGGL(instnorm_lrelu_bwd_kernel, dim3(C / 8, N), dim3(256), 0, (hipStream_t)stream, gy, ldg, y, ldy, stats, gx, ldgx,
                      (long long)rows, C, slope);
   FO_CHECK_LAUNCH();

@@ -235,6 +235,14 @@ class DiscEngine:
             _lib.call("fo_avgpool3_fwd", ops._ptr(h[n]), ops._ptr(out[n]), D, H, W, Cc, Cc, kD, sD, sH, sW, ops._stream())
         return out
 
+    def _instnorm_ws(self, N, rows, co):
+        """(workspace, bytes) of the chunked InstanceNorm launches (fo_instnorm_ws_bytes; FACEOFF_INSTNORM_ONE_LAUNCH=1: the one-workgroup-per-8-channels
+        kernels): the current stream's scratch buffer (ops._workspace)."""
+        nb = 0 if _os.environ.get("FACEOFF_INSTNORM_ONE_LAUNCH") else int(_lib.load().fo_instnorm_ws_bytes(N, C.c_int64(rows), co))
+        if nb <= 0:
+            return None, 0
+        return ops._workspace(nb, self.device), nb
+
     def _scale_fwd(self, x, prefix, training, order):
         N = x.shape[0]
         # (cached: a host list -> device tensor copy is a synchronous H2D transfer that drains the stream -- 3 ms per call here)
@@ -277,8 +285,10 @@ class DiscEngine:
                 st = torch.empty((N, 2 * co), device=self.device)
                 z = torch.empty_like(y)
                 run = self.buffers[key + ".1._both"]
+                ws, wsb = self._instnorm_ws(N, rows, co)
                 _lib.call("fo_instnorm_lrelu_fwd_batch", ops._ptr(y), ld_out, ops._ptr(z), ld_out, N, C.c_int64(rows), co, C.c_float(IN_EPS),
-                          C.c_float(SLOPE), ops._ptr(st), ops._ptr(run), ops._ptr(order_t), C.c_float(IN_MOMENTUM), int(not training), ops._stream())
+                          C.c_float(SLOPE), ops._ptr(st), ops._ptr(run), ops._ptr(order_t), C.c_float(IN_MOMENTUM), int(not training), ops._ptr(ws),
+                          C.c_int64(wsb), ops._stream())
                 stats[j] = st
                 y = z
             feat.append(y)
@@ -389,8 +399,9 @@ class DiscEngine:
             if 1 <= j <= 3:              # g is wrt the post-activation output: through LeakyReLU and InstanceNorm
                 rows = dd[0] * dd[1] * dd[2]
                 gc = torch.empty_like(g)
+                ws, wsb = self._instnorm_ws(N, rows, co)
                 _lib.call("fo_instnorm_lrelu_bwd_batch", ops._ptr(g), g.shape[-1], ops._ptr(feat[j]), feat[j].shape[-1], ops._ptr(stats[j]),
-                          ops._ptr(gc), gc.shape[-1], N, C.c_int64(rows), co, C.c_float(SLOPE), ops._stream())
+                          ops._ptr(gc), gc.shape[-1], N, C.c_int64(rows), co, C.c_float(SLOPE), ops._ptr(ws), C.c_int64(wsb), ops._stream())
                 g = gc
             if j == 0:
                 # first layer on the space-to-depth image (x_in = xs): filter gradient in the k2 layout, mapped back to k4

@@ -369,6 +369,7 @@ class VQVAEEngine:
         self._streams = (self.wgrad_stream, self.aux_stream, self.pack_stream, self.vq_stream)
         self.tail_wgrads = int(_os.environ.get("FACEOFF_TAIL_WGRADS", "2"))     # how many of the last filter gradients run on the caller's stream (backward())
         self._pack_events = None
+        self._packs_stale, self._packed_version = True, -1      # pack_filters(): skip when the weights have not changed since the last pack
         # Conv3d forward / data gradient as Winograd F(2x2,3x3) + a (3,1,1) implicit GEMM (FACEOFF_NO_WINOGRAD=1: direct)
         self.winograd = not _os.environ.get("FACEOFF_NO_WINOGRAD")
         self.winograd_max_tile = int(_os.environ.get("FACEOFF_WINOGRAD_TILE", "4"))   # 2: F(2x2,3x3) everywhere
@@ -489,6 +490,14 @@ class VQVAEEngine:
         the first two layers' filters, an event, the rest, a second event; with defer=True (forward()) the caller's stream waits
         for the first before enc_b.blocks.0 and for the second before enc_b.blocks.4 (stage_encode), otherwise right here."""
         self._pack_events = None
+        # Nothing to do when the checkpoint-layout weights have not changed since the last pack: a forward that follows a forward (validation,
+        # the GAN loop's discriminator iterations -- the generator only moves on every other one) re-used to repack ~80 filters per call.
+        # Who can write the arena: in-place torch ops (they bump the version counter the parameter views share with it) and raw-pointer kernels
+        # (fo_adam_flat: FlatAdam.step calls mark_params_dirty()).  FACEOFF_ALWAYS_PACK=1 switches the check off.
+        ver = self.flat_params._version
+        if not self._packs_stale and self._packed_version == ver and not _os.environ.get("FACEOFF_ALWAYS_PACK"):
+            return
+        self._packs_stale, self._packed_version = False, ver
         ps = self.pack_stream
         if ps is None:
             for layer in self.layers.values():
@@ -509,6 +518,10 @@ class VQVAEEngine:
         if not defer:
             self._await_pack(1)
             self._pack_events = None
+
+    def mark_params_dirty(self):
+        """The parameter arena was written through a raw pointer (the Adam launch): the packed filters are stale."""
+        self._packs_stale = True
 
     def _await_pack(self, which):
         if self._pack_events is not None and self._pack_events[which] is not None:

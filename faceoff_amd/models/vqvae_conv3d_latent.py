@@ -50,6 +50,10 @@ class _VQVAEFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, img, T, *params):
         eng = model._engine
+        # this module's nn.Parameters are `.data` aliases of the engine's arena (their own version counters): whoever steps or loads them --
+        # torch.optim, load_state_dict, DDP's broadcast of module states -- writes around the counter engine.pack_filters() watches, so a
+        # forward through the MODULE always repacks its filters (the engine-level trainers, which own their optimiser, skip unchanged weights)
+        eng.mark_params_dirty()
         S = eng.forward(img, training=model.training, T=T)
         ctx.model, ctx.S = model, S
         dec = ops.nhwc_to_nchw(S["dec"], model.in_channel)
@@ -219,11 +223,15 @@ class VQVAE(nn.Module):
     def _act_out(t, c):
         return ops.nhwc_to_nchw(ops.to_f32(t) if t.dtype == torch.bfloat16 else t, c)
 
+    def _pack(self, eng):
+        eng.mark_params_dirty()           # (see _VQVAEFunction.forward: the module never trusts the arena's version counter)
+        eng.pack_filters()
+
     @torch.no_grad()
     def only_encode(self, input):
         """:237-241 -> (enc_b [N,128,H/4,W/4], enc_t [N,128,H/8,W/8])."""
         eng = self._bind(input.device)
-        eng.pack_filters()
+        self._pack(eng)
         S = {"T": self.clip_len or input.shape[0], "x8": self._act_in(eng, ops.nchw_to_nhwc(input.float().contiguous(), cpad=8))}
         eng.stage_encode(S)
         return self._act_out(S["eb"], 128), self._act_out(S["et"], 128)
@@ -232,7 +240,7 @@ class VQVAE(nn.Module):
     def encode_quantized(self, enc_b, enc_t):
         """:261-278 -> (quant_t, quant_b, diff, id_t, id_b).  Inference entry point (no autograd)."""
         eng = self._bind(enc_b.device)
-        eng.pack_filters()
+        self._pack(eng)
         N, _, h4, w4 = enc_b.shape
         S = {"T": self.clip_len or N, "d3": self._act_in(eng, ops.nchw_to_nhwc(enc_t.float().contiguous()))}
         cat_b = torch.empty((N, h4, w4, 192), device=eng.device, dtype=eng.act_dtype)
@@ -248,7 +256,7 @@ class VQVAE(nn.Module):
     def decode(self, quant_t, quant_b):
         """:280-285 -> dec [N,6,H,W]."""
         eng = self._bind(quant_t.device)
-        eng.pack_filters()
+        self._pack(eng)
         N, _, h4, w4 = quant_b.shape
         cat_d = torch.empty((N, h4, w4, 128), device=eng.device, dtype=eng.act_dtype)
         cat_d[..., 64:128] = self._act_in(eng, ops.nchw_to_nhwc(quant_b.float().contiguous()))

@@ -896,6 +896,8 @@ def vq_assign_bf16out(x, embedT, enorm, q_f32, q_bf16, stats, train, stats_strea
     nvec = x.shape[0] * x.shape[1] * x.shape[2]
     ind = torch.empty(x.shape[:-1], device=x.device, dtype=torch.int64)
     f = _forced(force_ind, ind.shape, x.device)
+    if LEDGER is not None and f is None:
+        LEDGER.begin("vq_assign", 2.0 * nvec * 64 * 512)          # (the ledger's floor only: bench.py adds the VQ distance FLOP to its totals itself)
     _lib.call("fo_vq_assign2", _ptr(x), ld_of(x), C.c_int64(nvec), _ptr(embedT), _ptr(enorm), _ptr(ind), _ptr(q_f32), ld_of(q_f32), _ptr(stats[0:1]),
               _ptr(q_bf16), ld_of(q_bf16, BF), _ptr(f) if f is not None else None, _ptr(_workspace(4096, x.device)), _stream())
     if train:
@@ -1027,6 +1029,8 @@ def vq_assign(x, embedT, enorm, q_out, stats, train, stats_stream=None, force_in
     f = _forced(force_ind, ind.shape, x.device)
     ws = _workspace(4096, x.device)
     if f is None:
+        if LEDGER is not None:
+            LEDGER.begin("vq_assign", 2.0 * nvec * 64 * 512)
         _lib.call("fo_vq_assign", _ptr(x), ld_of(x), C.c_int64(nvec), _ptr(embedT), _ptr(enorm), _ptr(ind), _ptr(q_out),
                   ld_of(q_out), _ptr(stats[0:1]), _ptr(ws), _stream())
     else:
@@ -1089,6 +1093,10 @@ def adam_flat(p, g, m, v, lr, step, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0
     _lib.call("fo_adam_flat", _ptr(p), _ptr(g), _ptr(m), _ptr(v), C.c_int64(p.numel()), C.c_float(lr), C.c_float(b1),
               C.c_float(b2), C.c_float(eps), C.c_float(1 - b1 ** step), C.c_float(1 - b2 ** step), C.c_float(grad_scale),
               _stream())
+    # the launch wrote p, m and v through raw pointers: tell torch's version counters (the engines skip repacking their filters while the
+    # parameter arena's counter stands still -- VQVAEEngine.pack_filters, DiscEngine.pack_filters)
+    for t in (p, m, v):
+        torch.autograd.graph.increment_version(t)
 
 
 def zero_(t):

@@ -34,6 +34,7 @@ class FlatAdam:
         self.t += 1
         ops.adam_flat(self.engine.flat_params, self.engine.flat_grads, self.m, self.v, g["lr"], self.t, g["betas"],
                       g["eps"], grad_scale)
+        self.engine.mark_params_dirty()          # (the launch writes the arena through a raw pointer: torch's version counter does not see it)
 
     def state_dict(self):
         return dict(m=self.m, v=self.v, t=self.t, param_groups=self.param_groups)

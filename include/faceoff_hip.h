@@ -53,7 +53,7 @@ extern "C" {
                           quantisers' inputs (quantize_conv_t / _b, :208,213: VQ distances and arg-min stay fp32) and the decoder output */
 
 /* ABI version: bumped whenever an exported signature or the meaning of an argument changes (101: the loss kernels take a caller-owned
-   partial-sum workspace `ws` in front of `stream` and OVERWRITE their scalars -- round 4; 102: fo_comm_broadcast_async added -- round 6).  The Python binding refuses a library whose
+   partial-sum workspace `ws` in front of `stream` and OVERWRITE their scalars -- round 4; 102: fo_comm_broadcast_async added; fo_instnorm_lrelu_{fwd,bwd}_batch take a workspace -- round 6).  The Python binding refuses a library whose
    fo_version() differs from the FO_ABI_VERSION it was written against (faceoff_amd/_lib.py), so an older .so handed in through
    FACEOFF_HIP_LIB is a clean error and not a stream pointer read as a workspace. */
 #define FO_ABI_VERSION 102
@@ -373,13 +373,17 @@ int fo_instnorm_lrelu_fwd(const float* x, int ldx, float* y, int ldy, int64_t ro
 /* gx = d loss / d x given gy = d loss / d y and the saved y, stats (training-mode statistics). */
 int fo_instnorm_lrelu_bwd(const float* gy, int ldg, const float* y, int ldy, const float* stats, float* gx, int ldgx, int64_t rows,
                           int C, float slope, void* stream);
-/* The same for N samples stored one after the other ([N][rows][ld]) in ONE launch; stats [N][2C].  Training mode moves the
+/* The same for N samples stored one after the other ([N][rows][ld]) in ONE call; stats [N][2C].  Training mode moves the
  * running statistics once per sample in the order given by `order` (device int32[N]: the reference calls the module sample by
- * sample). */
+ * sample).  With a workspace of fo_instnorm_ws_bytes(N, rows, C) > 0 bytes (C / 4 a power of two in 8 .. 256: the discriminators' 128, 256 and
+ * 512 channels) the training-mode statistics are made in three chip-filling launches -- per-chunk (mean, M2), a fixed-order merge, an
+ * elementwise pass: bit-reproducible, no atomics -- instead of one workgroup per 8 channels; ws == NULL (or eval mode) runs the latter. */
+int64_t fo_instnorm_ws_bytes(int N, int64_t rows, int C);
 int fo_instnorm_lrelu_fwd_batch(const float* x, int ldx, float* y, int ldy, int N, int64_t rows, int C, float eps, float slope,
-                                float* stats, float* running, const int32_t* order, float momentum, int use_running, void* stream);
+                                float* stats, float* running, const int32_t* order, float momentum, int use_running, float* ws, int64_t ws_bytes,
+                                void* stream);
 int fo_instnorm_lrelu_bwd_batch(const float* gy, int ldg, const float* y, int ldy, const float* stats, float* gx, int ldgx, int N,
-                                int64_t rows, int C, float slope, void* stream);
+                                int64_t rows, int C, float slope, float* ws, int64_t ws_bytes, void* stream);
 /* AvgPool(k = 3 in every pooled dimension, padding 1, count_include_pad = False) of [D][H][W][C] with strides (sD, sH, sW);
  * kD = 1 leaves the depth axis alone (2-D pooling).  _bwd ADDS the gradient into gx (zero it first). */
 int fo_avgpool3_fwd(const float* x, float* y, int D, int H, int W, int C, int ld, int kD, int sD, int sH, int sW, void* stream);

@@ -340,3 +340,47 @@ def test_module_mirror_runs_the_reference_discriminator_update(golden_dir, tag, 
     after = np.concatenate([_sub(params[n]) for n in names])
     big = np.abs(want) > 1e-3 * np.abs(want).max()
     assert np.abs(after - g[f"{tag}_param_after_sub"])[big].max() <= 5e-6
+
+
+@pytest.mark.parametrize("Cc,dims", [(128, (5, 33, 31)), (256, (3, 17, 19)), (512, (4, 9, 10))])
+def test_chunked_instnorm_vs_torch(Cc, dims):
+    """fo_instnorm_lrelu_{fwd,bwd}_batch with a workspace (csrc/disc_ops.hip, round 6: per-chunk (mean, M2) -> fixed-order merge -> elementwise pass) at
+    the discriminators' channel counts, ragged row counts (the last chunk is partial), two samples whose running-statistics updates are applied in
+    REVERSED order, a large mean against the spread (what E[x^2] - mean^2 would lose): against nn.InstanceNorm3d + LeakyReLU on the CPU, against the
+    one-launch kernels (same arithmetic up to summation order), and bit-reproducible."""
+    from faceoff_amd import _lib, ops
+    g = torch.Generator().manual_seed(Cc)
+    N, rows = 2, dims[0] * dims[1] * dims[2]
+    x = (torch.randn((N, Cc) + dims, generator=g) * 0.5 + 3.0).requires_grad_(True)
+    inorm = torch.nn.InstanceNorm3d(Cc, affine=False, track_running_stats=True)
+    outs = [None, None]
+    for n in (1, 0):                                                   # module calls: sample 1 first
+        outs[n] = torch.nn.functional.leaky_relu(inorm(x[n:n + 1]), 0.2)
+    yy = torch.cat(outs)
+    gyy = torch.randn(yy.shape, generator=g)
+    yy.backward(gyy)
+    cl = lambda t: t.detach().permute(0, 2, 3, 4, 1).reshape(N, rows, Cc).contiguous().cuda()
+    xc, gc = cl(x), cl(gyy)
+    order = torch.tensor([1, 0], dtype=torch.int32, device="cuda")
+    nb = int(_lib.load().fo_instnorm_ws_bytes(N, C.c_int64(rows), Cc))
+    assert nb > 0
+    res = []
+    for use_ws in (True, True, False):
+        ws = torch.empty(nb // 4, device="cuda") if use_ws else None
+        yc, st, gx = torch.empty_like(xc), torch.empty((N, 2 * Cc), device="cuda"), torch.empty_like(xc)
+        run = torch.cat([torch.zeros(Cc), torch.ones(Cc)]).cuda()
+        _lib.call("fo_instnorm_lrelu_fwd_batch", ops._ptr(xc), Cc, ops._ptr(yc), Cc, N, C.c_int64(rows), Cc, C.c_float(1e-5), C.c_float(0.2), ops._ptr(st),
+                  ops._ptr(run), ops._ptr(order), C.c_float(0.1), 0, ops._ptr(ws), C.c_int64(nb if use_ws else 0), ops._stream())
+        _lib.call("fo_instnorm_lrelu_bwd_batch", ops._ptr(gc), Cc, ops._ptr(yc), Cc, ops._ptr(st), ops._ptr(gx), Cc, N, C.c_int64(rows), Cc, C.c_float(0.2),
+                  ops._ptr(ws), C.c_int64(nb if use_ws else 0), ops._stream())
+        torch.cuda.synchronize()
+        res.append((yc.cpu(), st.cpu(), run.cpu(), gx.cpu()))
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b)                                       # bit-reproducible
+    want, wantg = cl(yy).cpu(), cl(x.grad).cpu()
+    for yc, st, run, gx in (res[0], res[2]):
+        assert (yc - want).abs().max().item() <= 2e-5 * want.abs().max().item()
+        np.testing.assert_allclose(run[:Cc].numpy(), inorm.running_mean.numpy(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(run[Cc:].numpy(), inorm.running_var.numpy(), rtol=2e-5)
+        assert (gx - wantg).abs().max().item() <= 5e-5 * wantg.abs().max().item()
+    assert (res[0][0] - res[2][0]).abs().max().item() <= 1e-5 * want.abs().max().item()       # chunked vs one-launch kernels

@@ -4,12 +4,14 @@ where RCCL refuses two ranks on one device):
 
     python tools/ddp_selfcheck.py [--gpus N] [--steps K] [--warmup W]
 
-1. the three `-m gpu` tests that skip on one device -- two real RCCL ranks against one process on the concatenated batch AND against the
-   CPU oracle (tests/test_ddp_gpu.py), `bench.py --gpus 2` launching its own ranks;
+1. the `-m gpu` tests that skip on one device -- two real RCCL ranks against one process on the concatenated batch AND against the
+   CPU oracle (tests/test_ddp_gpu.py), `bench.py --gpus 2` launching its own ranks, two fo_comm ranks -- and config 5's data-parallel tests
+   (tests/test_gan_gpu.py: two ranks against the per-rank oracle, the fo_comm / RCCL transports);
 2. `bench.py --gpus N` for N = 2 .. the number of visible devices (powers of two), and from each line: `comm.ranks_in_group` (max-reduced
    over the process group: what the group REALLY had), `comm.path` / `fo_comm_issued_per_step` (the C-ABI communicator carried every
    bucket + both quantisers' statistics), `comm.exposed_ms` (all-reduce time left behind backward), slowest / fastest rank, and the
-   weak-scaling ratio against this script's own N = 1 run.
+   weak-scaling ratio against this script's own N = 1 run; asserted: ranks_in_group == N, fo_comm_issued_per_step == buckets + 2, slowest and fastest
+   rank within 3 %, config 5's collectives per iteration.
 
 Every rank is a fresh interpreter started before this process makes any HIP call (`torch.cuda.device_count()` does not initialise the
 runtime; bench.py's launch_ranks / faceoff_amd.distributed.launch spawn children, nothing re-execs with a live GPU context).
@@ -42,7 +44,11 @@ def main():
     if not args.skip_tests:
         sel = ["tests/test_ddp_gpu.py::test_two_rccl_ranks_on_two_gpus_equal_one_process_on_the_concatenated_batch",
                "tests/test_ddp_gpu.py::test_bench_launches_its_own_two_ranks",
-               "tests/test_ddp_gpu.py::test_two_ranks_equal_one_process_on_the_concatenated_batch"]
+               "tests/test_ddp_gpu.py::test_two_ranks_equal_one_process_on_the_concatenated_batch",
+               "tests/test_ddp_gpu.py::test_c_abi_communicator_two_ranks_on_two_gpus",
+               # config 5's data-parallel half: two ranks (gloo on one device: the semantics) against the per-rank oracle, and the fo_comm / RCCL transports
+               "tests/test_gan_gpu.py::test_two_rank_gan_iterations_vs_oracle",
+               "tests/test_gan_gpu.py::test_gan_collectives_in_a_one_rank_world"]
         r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-s", "-m", "gpu", "-rs", *sel], cwd=ROOT, env=env)
         print(f"ddp_selfcheck: multi-GPU tests rc={r.returncode}")
         rc = rc or r.returncode
@@ -72,7 +78,17 @@ def main():
         if n > 1:
             ok = c.get("ranks_in_group") == n and c.get("path") == "fo_comm" and c.get("fo_comm_issued_per_step") == (c.get("buckets") or 0) + 2
             if not ok:
-                print(f"ddp_selfcheck: bench.py --gpus {n}: the comm block does not show {n} RCCL ranks through fo_comm_*")
+                print(f"ddp_selfcheck: bench.py --gpus {n}: the comm block does not show {n} RCCL ranks through fo_comm_* "
+                      f"(ranks_in_group {c.get('ranks_in_group')}, path {c.get('path')}, issued per step {c.get('fo_comm_issued_per_step')} vs buckets + 2 = {(c.get('buckets') or 0) + 2})")
+                rc = rc or 1
+            lo, hi = c.get("ms_per_step_min_rank"), c.get("ms_per_step_max_rank")
+            if lo and hi and hi > 1.03 * lo:               # a straggler: every rank waits for it in the all-reduce
+                print(f"ddp_selfcheck: bench.py --gpus {n}: slowest rank {hi} ms vs fastest {lo} ms per step (> 3 % apart)")
+                rc = rc or 1
+            c5 = d.get("c5") or {}
+            if c5 and (c5.get("comm") or {}).get("collectives_per_iteration") not in (None, 3.5):
+                print(f"ddp_selfcheck: bench.py --gpus {n}: config 5 issued {c5['comm']['collectives_per_iteration']} arena all-reduces + statistics broadcasts "
+                      "per iteration, expected (1 + 2 + 2 + 2) / 2 = 3.5")
                 rc = rc or 1
     return rc
 
