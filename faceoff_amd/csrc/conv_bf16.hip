@@ -1506,6 +1506,19 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_pph_kernel(const ConvArgsH a
 #endif
 }
 
+// Cross-lane moves on the VECTOR ALU (no LDS round trip: __shfl_xor compiles to ds_bpermute_b32, an LDS-pipeline instruction with its latency --
+// the pooled epilogue of the halo-tile kernel issued ~48 of them per tile, each feeding the next: in-kernel stamps, round 6, put that epilogue at
+// 64 % of a tile).  lane ^ 1 is a DPP quad permutation; the OR over the four 16-lane rows (lanes l, l + 16, l + 32, l + 48) is two of gfx950's row
+// swaps: v_permlane16_swap exchanges the odd rows of one operand with the even rows of the other, v_permlane32_swap the upper half with the lower.
+__device__ __forceinline__ int lane_xor1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true); }
+__device__ __forceinline__ float lane_xor1(float v) { return __int_as_float(lane_xor1(__float_as_int(v))); }
+__device__ __forceinline__ unsigned or_rows(unsigned v) {
+  const auto a = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+  v = a[0] | a[1];
+  const auto b = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+  return b[0] | b[1];
+}
+
 // ------------------------------------------------------------------------------------------------ 64 input channels, 3x3: halo tiles
 // The short-K layers (VGG conv1_2 64 -> 64 at full resolution, conv2_1 64 -> 128, reference models/lpips.py:118-134, and their data
 // gradients where the gradient has 64 channels; K = 576) spend a tiled implicit GEMM mostly outside its K loop, and the tile's A operand
@@ -1558,6 +1571,9 @@ __device__ unsigned long long fo_h64_stamps[16];
 #ifndef FO_H64_PRIO
 #define FO_H64_PRIO 0
 #endif
+#ifndef FO_H64_EPI_DEAD
+#define FO_H64_EPI_DEAD 1
+#endif
 template <bool MASKT, bool MASKB, bool POOL, bool OBITS, bool LINES>
 __global__ __launch_bounds__(256, 2) void conv_halo64_bf16_kernel(const HaloArgs a) {
   constexpr int PITCH = 48, ROWS = 6, PLANE = ROWS * PITCH * 64, STAGE = 2 * PLANE;     // bytes
@@ -1599,33 +1615,34 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16_kernel(const HaloArgs
     tx = r1 % a.tilesX;
     n = r1 / a.tilesX;
   };
+  // DMA roles (round 6): a wave fetches whole patch ROWS -- row 2 + wave of a tile that continues its column (rows 0, 1 are copied), rows wave and
+  // wave + 4 of a tile that starts one -- so a piece's (plane, 16-pixel group) is a compile-time constant: per row ONE scalar base offset and three lane
+  // predicates, per piece one scalar add.  (Pieces dealt round-robin over the waves made every piece's row / group / plane a run-time scalar: 76 SGPRs
+  // spilled into VGPR lanes and ~20 scalar instructions + 4 v_readlane per piece -- in-kernel stamps put the issue phase at a quarter of a tile.)
+  const unsigned gB = (unsigned)(16 * a.ldIn * 2);        // bytes between the 16-pixel groups of a row
+  auto dma_row = [&](int stage, int r, int n, int iy, int x0, bool live) {
+    const bool rowok = live & ((unsigned)iy < (unsigned)a.H);
+    const unsigned srow = rowok ? (unsigned)((((size_t)n * a.H + iy) * a.W + x0) * a.ldIn * 2) : 0u;
+    lds_byte* const drow = lds3 + stage * STAGE + r * (PITCH * 64);
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      const int ix = x0 - 1 + g * 16 + dpix;               // image column of this lane's pixel
+      // (the third 16-pixel group holds the patch's last two columns: its other 14 lanes fetch nothing)
+      const bool ok = rowok & ((unsigned)ix < (unsigned)a.W) & (g * 16 + dpix < 34);
+      const unsigned vo = ok ? dlane : OOB;
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) dma16s(rin, drow + pl * PLANE + g * (16 * 64), vo, srow + g * gB + pl * 64);
+    }
+  };
   auto dma_tile = [&](int tile, int stage, bool reuse, int n, int ty, int tx) {      // (n, ty, tx) = tile_of(tile)
     if (FO_ABLATE_H & 8) return;
     const bool live = tile < a.ntiles;
     const int y0 = ty * 4 - 1, x0 = tx * 32;               // (x0: patch column 0 is image column x0 - 1 = descriptor pixel x0)
-    auto piece = [&](int pl, int r, int g) {
-      const int iy = y0 + r;
-      const bool rowok = live & ((unsigned)iy < (unsigned)a.H);
-      const int ix = x0 - 1 + g * 16 + dpix;               // image column of this lane's pixel
-      // (the third 16-pixel group holds the patch's last two columns: its other 14 lanes fetch nothing -- they used to read 48 pixels per row for 34)
-      const bool ok = rowok & ((unsigned)ix < (unsigned)a.W) & (g * 16 + dpix < 34);
-      const unsigned soff = rowok ? (unsigned)((((size_t)n * a.H + iy) * a.W + x0 + g * 16) * a.ldIn * 2) + pl * 64 : 0u;
-      dma16s(rin, lds3 + stage * STAGE + pl * PLANE + (r * PITCH + g * 16) * 64, ok ? dlane : OOB, soff);
-    };
     if (reuse) {
-#pragma unroll
-      for (int k = 0; k < 6; ++k) {
-        const int id = wave + 4 * k;                       // 0 .. 23: (plane, patch row 2 .. 5, 16-pixel group)
-        const int pl = id / 12, rem = id - pl * 12, r = rem / 3;
-        piece(pl, 2 + r, rem - r * 3);
-      }
+      dma_row(stage, 2 + wave, n, y0 + 2 + wave, x0, live);
     } else {
-#pragma unroll
-      for (int k = 0; k < 9; ++k) {
-        const int id = wave + 4 * k;                       // 0 .. 35
-        const int pl = id / 18, rem = id - pl * 18, r = rem / 3;
-        piece(pl, r, rem - r * 3);
-      }
+      dma_row(stage, wave, n, y0 + wave, x0, live);
+      if (wave < 2) dma_row(stage, 4 + wave, n, y0 + 4 + wave, x0, live);
     }
   };
 
@@ -1663,19 +1680,24 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16_kernel(const HaloArgs
     if (ty1 == a.tilesY) { ty1 = 0; if (++tx1 == a.tilesX) { tx1 = 0; ++n1; } }
     const bool reuse = more && ty1 != 0;                    // the next tile is the one below this one
     H64_STAMP(h0);
+    // the next tile's rows 0, 1 = this patch's rows 4, 5, both planes (whole 48-pixel rows: same layout, same swizzle).  The reads are issued FIRST and
+    // land under the DMA issue's scalar work; the writes follow it (read -> wait -> write per plane ahead of everything else was two exposed LDS round trips)
+    constexpr int NQ = 2 * PITCH * 64 / 16;                 // 384 sixteen-byte pieces per plane
+    u32x4 t3[2][2];
+    if (reuse) {
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+          if (tid + q * 256 < NQ) t3[pl][q] = *reinterpret_cast<const u32x4*>(lds + st * STAGE + pl * PLANE + 4 * PITCH * 64 + (tid + q * 256) * 16);
+    }
     if (more) dma_tile(tile + 1, st ^ 1, reuse, n1, ty1, tx1);          // next tile's patch: lands during this tile's MFMAs
-    if (reuse) {                                           // its rows 0, 1 = this patch's rows 4, 5, both planes (whole 48-pixel rows: same layout, same swizzle)
+    if (reuse) {
 #pragma unroll
-      for (int pl = 0; pl < 2; ++pl) {
-        u32x4 t3[2];
-        const int nq = 2 * PITCH * 64 / 16;               // 384 sixteen-byte pieces per plane
+      for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
         for (int q = 0; q < 2; ++q)
-          if (tid + q * 256 < nq) t3[q] = *reinterpret_cast<const u32x4*>(lds + st * STAGE + pl * PLANE + 4 * PITCH * 64 + (tid + q * 256) * 16);
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-          if (tid + q * 256 < nq) *reinterpret_cast<u32x4*>(lds + (st ^ 1) * STAGE + pl * PLANE + (tid + q * 256) * 16) = t3[q];
-      }
+          if (tid + q * 256 < NQ) *reinterpret_cast<u32x4*>(lds + (st ^ 1) * STAGE + pl * PLANE + (tid + q * 256) * 16) = t3[pl][q];
     }
     // the tile's ReLU mask from its bit plane: one dword per pixel block holds the nibbles of both channel blocks; loaded HERE, the four loads land
     // under the MFMAs (as 8-byte fragments of the bf16 tensor, fetched block by block in the epilogue, the mask made conv1_2's data gradient
@@ -1732,6 +1754,16 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16_kernel(const HaloArgs
     H64_STAMP(h2);
     // ---- epilogue: acc[i][j][r] = channel 16 j + 4 quad + r of pixel (row 2 wm + (i >> 1), column 16 (i & 1) + l15)
     typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+#if FO_H64_EPI_DEAD
+    // (round 6) the four pixel blocks' line patches live in THIS tile's input stage, which is dead once every wave has left the MFMA loop (its rows 4, 5
+    // were copied at the top; the next DMA goes to the other stage): all eight ds_write_b64 first, then the four ds_read_b128 + stores -- ONE LDS round
+    // trip per tile instead of four (write -> read -> store per block through a single 1.25 KB patch: the epilogue was 37 % of a tile in the stamps)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    unsigned char* const epatch = lds + st * STAGE + wave * (4 * EPATCH);
+#else
+    unsigned char* const epatch = lds + 2 * STAGE + wave * EPATCH;
+#endif
     // (max-pool 2x2 riding along: a wave's two tile rows are one pooled row; the vertical partner of a pixel is the same lane's other
     // accumulator, the horizontal one the neighbouring lane.  max commutes with the monotonic bias + ReLU + rounding, so the pooled tensor is
     // bit for bit the pool of the stored one.)
@@ -1761,7 +1793,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16_kernel(const HaloArgs
           for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
         }
         const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-        if (LINES) *reinterpret_cast<bf16x4*>(lds + 2 * STAGE + wave * EPATCH + l15 * EPITCH + (j * 16 + quad * 4) * 2) = o;
+        if (LINES) *reinterpret_cast<bf16x4*>(epatch + (FO_H64_EPI_DEAD ? i * EPATCH : 0) + l15 * EPITCH + (j * 16 + quad * 4) * 2) = o;
         else if (!(FO_ABLATE_H & 32)) *reinterpret_cast<bf16x4*>(a.out + pix * a.ldOut + co) = o;
         if (OBITS) obw |= pos_bits4((float)o[0], (float)o[1], (float)o[2], (float)o[3]) << (j * 16 + quad * 4);      // the wave's 32 channels of this pixel: one dword
         if (POOL) {
@@ -1772,19 +1804,29 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16_kernel(const HaloArgs
           }
         }
       }
-      if (LINES) {                                         // lane = (pixel lane / 4 of the block, 16-byte piece lane % 4 of its 64 bytes)
+      if (LINES && !FO_H64_EPI_DEAD) {                     // lane = (pixel lane / 4 of the block, 16-byte piece lane % 4 of its 64 bytes)
         __builtin_amdgcn_wave_barrier();
-        const bf16x8 ln = *reinterpret_cast<const bf16x8*>(lds + 2 * STAGE + wave * EPATCH + (lane >> 2) * EPITCH + (lane & 3) * 16);
+        const bf16x8 ln = *reinterpret_cast<const bf16x8*>(epatch + (lane >> 2) * EPITCH + (lane & 3) * 16);
         const size_t pix2 = pix - l15 + (lane >> 2);
         if (!(FO_ABLATE_H & 32)) *reinterpret_cast<bf16x8*>(a.out + pix2 * a.ldOut + half * 64 + wn * 32 + (lane & 3) * 8) = ln;
         __builtin_amdgcn_wave_barrier();                  // (the next block's writes stay behind this read: LDS operations of a wave execute in order)
       }
       if (OBITS) {                                         // the four quads' nibbles meet in one dword (two shuffles): one 4-byte store per pixel
-        obw |= (unsigned)__shfl_xor((int)obw, 16);
-        obw |= (unsigned)__shfl_xor((int)obw, 32);
+        obw = or_rows(obw);
         if (quad == 0) *reinterpret_cast<unsigned*>(a.outBits + pix * (a.Cout / 8) + half * 8 + wn * 4) = obw;
       }
       __builtin_amdgcn_sched_barrier(0);                  // (one pixel block's mask loads and addresses at a time: the filter holds the registers)
+    }
+    if (LINES && FO_H64_EPI_DEAD) {                        // lane = (pixel lane / 4 of a block, 16-byte piece lane % 4 of its 64 bytes)
+      __builtin_amdgcn_wave_barrier();
+      bf16x8 ln[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ln[i] = *reinterpret_cast<const bf16x8*>(epatch + i * EPATCH + (lane >> 2) * EPITCH + (lane & 3) * 16);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const size_t pix2 = ((size_t)n * a.H + ty * 4 + 2 * wm + (i >> 1)) * a.W + tx * 32 + (i & 1) * 16 + (lane >> 2);
+        if (!(FO_ABLATE_H & 32)) *reinterpret_cast<bf16x8*>(a.out + pix2 * a.ldOut + half * 64 + wn * 32 + (lane & 3) * 8) = ln[i];
+      }
     }
     if (POOL) {
 #pragma unroll
@@ -1794,14 +1836,15 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16_kernel(const HaloArgs
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           float m[4];
+          float pmR[4];                                    // the horizontal partner's column maximum
 #pragma unroll
-          for (int r = 0; r < 4; ++r) m[r] = fmaxf(pm[e][j][r], __shfl_xor(pm[e][j][r], 1));
+          for (int r = 0; r < 4; ++r) { pmR[r] = lane_xor1(pm[e][j][r]); m[r] = fmaxf(pm[e][j][r], pmR[r]); }
           if (a.pidx) {                                    // even lane = left column: the first maximum in scan order (0,0) (0,1) (1,0) (1,1)
-            const unsigned rbR = (unsigned)__shfl_xor((int)rowbit[e][j], 1);
+            const unsigned rbR = (unsigned)lane_xor1((int)rowbit[e][j]);
             unsigned code = 0;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const float vL = pm[e][j][r], vR = __shfl_xor(pm[e][j][r], 1);
+              const float vL = pm[e][j][r], vR = pmR[r];
               const unsigned iL = ((rowbit[e][j] >> r) & 1u) * 2u, iR = ((rbR >> r) & 1u) * 2u + 1u;
               code |= (vL > vR ? iL : vR > vL ? iR : min(iL, iR)) << (2 * r);
             }
@@ -1820,8 +1863,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16_kernel(const HaloArgs
         if (a.pidx) {
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
-            cw[j] |= (unsigned)__shfl_xor((int)cw[j], 16);
-            cw[j] |= (unsigned)__shfl_xor((int)cw[j], 32);
+            cw[j] = or_rows(cw[j]);
           }
           if (!(l15 & 1) && quad == 0) {
             typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -1829,8 +1871,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16_kernel(const HaloArgs
           }
         }
         if (a.pooledBits) {
-          pw |= (unsigned)__shfl_xor((int)pw, 16);
-          pw |= (unsigned)__shfl_xor((int)pw, 32);
+          pw = or_rows(pw);
           if (!(l15 & 1) && quad == 0) *reinterpret_cast<unsigned*>(a.pooledBits + ppix * (a.Cout / 8) + half * 8 + wn * 4) = pw;
         }
       }
@@ -2067,7 +2108,7 @@ __global__ __launch_bounds__(256, 2) void vgg_conv1_fused_bf16_kernel(const Vgg1
         for (int j = 0; j < 2; ++j) {
           float m[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) m[r] = fmaxf(pm[e][j][r], __shfl_xor(pm[e][j][r], 1));
+          for (int r = 0; r < 4; ++r) m[r] = fmaxf(pm[e][j][r], lane_xor1(pm[e][j][r]));
           if (!(l15 & 1))
             *reinterpret_cast<bf16x4*>(a.pooled + ppix * 64 + wn * 32 + j * 16 + quad * 4) = bf16x4{(__bf16)m[0], (__bf16)m[1], (__bf16)m[2], (__bf16)m[3]};
         }
