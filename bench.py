@@ -353,7 +353,8 @@ def main():
                           "held_clock_ghz": HELD_CLOCK_GHZ, "nameplate_clock_ghz": 2.4}
         f["what"] = ("sum over every C-ABI launch of one step of max(bytes / HBM, FLOP / (peak x held clock / 2.4)); bytes = the distinct tensors handed to the "
                      "launch, each once, scratch excluded (errs low); step_frac_of_floor = step_floor_ms / the timed ms per step (1.0 = every launch at its "
-                     "own bound, no overlap); largest_gaps: kernels by measured (launch alone on the GPU) minus floor")
+                     "own bound, no overlap); largest_gaps: kernels by measured (launch alone on the GPU) minus floor; floor_above_measured_ms: launches whose floor "
+                     "exceeds their own measured time, summed -- the byte model counting too much (0 = it never does)")
         return f
 
     def dominant(summ, steps, ms_serial):

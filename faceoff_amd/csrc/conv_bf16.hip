@@ -1574,6 +1574,9 @@ __device__ unsigned long long fo_h64_stamps[16];
 #ifndef FO_H64_EPI_DEAD
 #define FO_H64_EPI_DEAD 1
 #endif
+#ifndef FO_H64_STAGGER
+#define FO_H64_STAGGER 0
+#endif
 template <bool MASKT, bool MASKB, bool POOL, bool OBITS, bool LINES>
 __global__ __launch_bounds__(256, 2) void conv_halo64_bf16_kernel(const HaloArgs a) {
   constexpr int PITCH = 48, ROWS = 6, PLANE = ROWS * PITCH * 64, STAGE = 2 * PLANE;     // bytes
@@ -1662,6 +1665,13 @@ __global__ __launch_bounds__(256, 2) void conv_halo64_bf16_kernel(const HaloArgs
   const int tile_end = min(a.ntiles, (wgInHalf + 1) * per);
   int tile = wgInHalf * per;
   if (tile >= tile_end) return;
+#if FO_H64_STAGGER
+  // (diagnostic variants) the CU's two workgroups run the same program from the same start: hold one of them back by about half a tile so that
+  // one's epilogue / issue phases fall beside the other's MFMA loop instead of beside its epilogue
+  if (FO_H64_STAGGER == 1 ? (blockIdx.x & 1) : FO_H64_STAGGER == 2 ? (blockIdx.x >= gridDim.x / 2) : ((blockIdx.x >> 3) & 1)) {
+    __builtin_amdgcn_s_sleep(100);
+  }
+#endif
   // this tile's coordinates, stepped from tile to tile (tile_of costs two integer divisions, and the loop needed it three times per tile)
   int n, ty, tx;
   tile_of(tile, n, ty, tx);

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(512, 1) void vq_assign_kernel(const float* __restri
 #pragma unroll
     for (int u = 0; u < 32; ++u) {
       if (u < nhere) {
-        const int idx = __shfl(best_i, u);
+        const int idx = __builtin_amdgcn_readlane(best_i, u);     // (wave-uniform: v_readlane, not the ds_bpermute __shfl compiles to; the codebook row's LDS address is then scalar + lane)
         const size_t vj = (size_t)(tile * 32 + u);
         const float diff = E[idx * VQ_LD + lane] - xg[u];
         const float ste = xg[u] + diff;        // input + (quantize - input).detach()   (:78)

@@ -67,6 +67,11 @@ __device__ __forceinline__ bf16x4 tr_read(const unsigned char* p) {
 // LDS row pitch for C channels whose rows are read at a row stride S (1, or 2 for the k4 s2 stems' Q): the four rows a 16-lane
 // block reads (k, k+1, k+2, k+3 times S) must sit in four different 64-byte bank groups: pitch * S = 64 (mod 256).
 constexpr int row_pitch(int C, int S) { return S == 2 ? (C <= 64 ? 160 : 288) : (C == 32 ? 64 : 320); }
+constexpr int wgrad_lds_bytes_rt(int TA, int TB, int NKW, int KR, bool fast, bool smallc) {
+  const int S = (NKW == 4 && !smallc) ? 2 : 1;                       // row stride of Q in LDS (k4 s2)
+  const int NQ = smallc ? 128 : (fast ? 32 * S + NKW - S : 32);      // rows of Q staged per run
+  return 2 * KR * (32 * row_pitch(TA, 1) + NQ * row_pitch(TB, S));   // two stages
+}
 
 // TA x TB block, WA x (8 / WA) waves, NKW taps per workgroup (1, 3 or 4), KR runs per barrier pair (thin blocks: more MFMAs per step).
 // FAST: row-run form.  SMALLC: the image layers (Cb = 8, k4 s2): b' = kw * 8 + c, and the NKW = 4 taps of the workgroup are the four kh.
@@ -74,9 +79,15 @@ constexpr int row_pitch(int C, int S) { return S == 2 ? (C <= 64 ? 160 : 288) : 
 // latency, not by the matrix pipe (MFMA-busy 0.11 on the ResBlocks' 3x3 128 -> 32 filter gradient), so TWO workgroups share a CU -- the launch
 // bound keeps them at <= 128 VGPRs (they compiled to 85-130), and the planner hands out two rounds of slabs where their LDS fits twice (round 5).
 constexpr bool wgrad_thin(int TA, int TB, int NKW, int KR) { return KR == 2 && NKW * TA * TB <= 3 * 32 * 128; }
+// ... and of those the forms the planner really hands two workgroups per CU (make_plan: NKW >= 3 -- the 1x1 forms measured nothing from it and keep one):
+// only they carry the 128-VGPR launch bound (a 1x1 thin variant above 128 registers would have spilled for no occupancy gain)
+constexpr bool wgrad_two_per_cu(int TA, int TB, int NKW, int KR) { return NKW >= 3 && wgrad_thin(TA, TB, NKW, KR); }
+// LDS bytes of an instantiation: ONE formula for the kernel's launch (launch_w) and the planner (make_plan)
+constexpr int row_pitch(int C, int S);
+constexpr int wgrad_lds_bytes_rt(int TA, int TB, int NKW, int KR, bool fast, bool smallc);
 
 template <int TA, int TB, int WA, int NKW, int KR, bool FAST, bool SMALLC>
-__global__ __launch_bounds__(512, (wgrad_thin(TA, TB, NKW, KR) ? 4 : 2)) void wgrad_bf16_kernel(const WArgs a) {
+__global__ __launch_bounds__(512, (wgrad_two_per_cu(TA, TB, NKW, KR) ? 4 : 2)) void wgrad_bf16_kernel(const WArgs a) {
   constexpr int WB = 8 / WA;
   constexpr int MA = TA / WA / 16, MB = TB / WB / 16;                // 16 x 16 tiles per wave
   static_assert(MA >= 1 && MB >= 1 && TA % (WA * 16) == 0 && TB % (WB * 16) == 0, "wave tiling");
@@ -410,12 +421,23 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const __bf16* __restri
   const int c = cblk * 64 + c8 * 8;
   const long long ra = rows * slab / slabs, rb = rows * (slab + 1) / slabs;
   float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (c < C)
-    for (long long r = ra + r0; r < rb; r += 32) {
+  if (c < C) {
+    long long r = ra + r0;
+    for (; r + 96 < rb; r += 128) {                     // four rows' loads in flight per thread (one was 16 KB per CU: 2 TB/s); the adds keep their order
+      bf16x8 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const bf16x8*>(g + (r + 32 * u) * ld + c);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] += (float)v[u][e];
+    }
+    for (; r < rb; r += 32) {
       const bf16x8 v = *reinterpret_cast<const bf16x8*>(g + r * ld + c);
 #pragma unroll
       for (int e = 0; e < 8; ++e) s[e] += (float)v[e];
     }
+  }
   // reduce the 32 row-lanes of each channel group: within a wave (8 rows) by shuffles, across the 4 waves through LDS
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -429,17 +451,26 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const __bf16* __restri
     ws[(long long)slab * ((C + 63) / 64 * 64) + cblk * 64 + threadIdx.x] = v;
   }
 }
-// db[c] = sum over the slabs of ws[slab][c]: one block per 64 channels, four groups of lanes each take every fourth slab
-__global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restrict__ ws, float* __restrict__ db, int slabs, int Cpad, int Creal) {
-  __shared__ float red[4][64];
+// db[c] = sum over the slabs of ws[slab][c]: one block per 64 channels, sixteen groups of lanes each take every sixteenth slab, four loads in
+// flight (four groups x two loads walked 1024 slabs in 128 dependent steps: 32 us per bias gradient), fixed order
+__global__ __launch_bounds__(1024) void colsum_reduce_kernel(const float* __restrict__ ws, float* __restrict__ db, int slabs, int Cpad, int Creal) {
+  __shared__ float red[16][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
-  float s0 = 0.f, s1 = 0.f;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   int k = part;
-  for (; k + 4 < slabs; k += 8) { s0 += ws[(long long)k * Cpad + c]; s1 += ws[(long long)(k + 4) * Cpad + c]; }
-  if (k < slabs) s0 += ws[(long long)k * Cpad + c];
-  red[part][threadIdx.x & 63] = s0 + s1;
+  for (; k + 48 < slabs; k += 64) {
+    s0 += ws[(long long)k * Cpad + c]; s1 += ws[(long long)(k + 16) * Cpad + c];
+    s2 += ws[(long long)(k + 32) * Cpad + c]; s3 += ws[(long long)(k + 48) * Cpad + c];
+  }
+  for (; k < slabs; k += 16) s0 += ws[(long long)k * Cpad + c];
+  red[part][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  if (part == 0 && c < Creal) db[c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+  if (part == 0 && c < Creal) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += red[q][threadIdx.x];
+    db[c] = t;
+  }
 }
 
 struct WPlan {
@@ -498,13 +529,11 @@ int make_plan(const fo_conv_desc* d, WPlan* p) {
   const int tiles = p->tilesA * p->tilesB;
   // workgroups per CU: two for the thin blocks whose LDS fits twice (wgrad_thin; FACEOFF_WGRAD_ONE_PER_CU=1: round 4's one)
   {
-    const int S = (p->NKW == 4 && !p->smallc) ? 2 : 1;
-    const int NQ = p->smallc ? 128 : (p->fast ? 32 * S + p->NKW - S : 32);
-    const int lds = 2 * p->KR * (32 * row_pitch(p->TA, 1) + NQ * row_pitch(p->TB, S));
-    static const bool one = getenv("FACEOFF_WGRAD_ONE_PER_CU") != nullptr;
+    const int lds = wgrad_lds_bytes_rt(p->TA, p->TB, p->NKW, p->KR, p->fast, p->smallc);
+    const bool one = getenv("FACEOFF_WGRAD_ONE_PER_CU") != nullptr;        // (read per call, like the other A/B switches)
     // (measured, tools/bench_wgrad_bf16.py, same device: the ResBlocks' 3x3 128 -> 32 0.152 -> 0.114 ms, the image layers 0.182 -> 0.141; the 1x1
     // forms get nothing from it -- 0.050 -> 0.054 with twice the slabs to reduce -- and keep one)
-    p->perCU = (!one && p->NKW >= 3 && wgrad_thin(p->TA, p->TB, p->NKW, p->KR) && 2 * lds <= 160 * 1024) ? 2 : 1;
+    p->perCU = (!one && wgrad_two_per_cu(p->TA, p->TB, p->NKW, p->KR) && 2 * lds <= 160 * 1024) ? 2 : 1;
   }
   const int slots = p->perCU * fo_cu_count();
   const int budget = std::max(p->tapRows, slots / tiles);             // workgroups per tile: one round of the chip's resident slots
@@ -533,11 +562,7 @@ int make_plan(const fo_conv_desc* d, WPlan* p) {
 }
 
 template <int TA, int TB, int NKW, int KR, bool FAST, bool SMALLC>
-constexpr int wgrad_lds_bytes() {
-  constexpr int S = (NKW == 4 && !SMALLC) ? 2 : 1;
-  constexpr int NQ = SMALLC ? 128 : (FAST ? 32 * S + NKW - S : 32);
-  return 2 * KR * (32 * row_pitch(TA, 1) + NQ * row_pitch(TB, S));
-}
+constexpr int wgrad_lds_bytes() { return wgrad_lds_bytes_rt(TA, TB, NKW, KR, FAST, SMALLC); }
 
 template <int TA, int TB, int WA, int NKW, int KR, bool FAST, bool SMALLC>
 int launch_w(const WArgs& a, int grid, hipStream_t s) {       // 1 = launched, -1 = the LDS opt-in failed (fo_last_error says why)
@@ -628,7 +653,7 @@ extern "C" int fo_bias_grad_bf16(const void* g, float* db, int64_t rows, int C, 
   hipLaunchKernelGGL(colsum_bf16_kernel, dim3(cblks * slabs), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const __bf16*>(g), (long long)rows, C, ld, ws,
                      slabs);
   FO_CHECK_LAUNCH();
-  hipLaunchKernelGGL(colsum_reduce_kernel, dim3(cblks), dim3(256), 0, (hipStream_t)stream, ws, db, slabs, cblks * 64, Creal);
+  hipLaunchKernelGGL(colsum_reduce_kernel, dim3(cblks), dim3(1024), 0, (hipStream_t)stream, ws, db, slabs, cblks * 64, Creal);
   FO_CHECK_LAUNCH();
   return FO_OK;
 }

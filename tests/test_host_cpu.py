@@ -193,3 +193,14 @@ def test_bench_refuses_to_run_fewer_gpus_than_asked():
     out = subprocess.run([sys.executable, bench, "--gpus", "2"], capture_output=True, text=True, timeout=300,
                          env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
     assert out.returncode != 0 and out.stdout.strip() == "" and "WORLD_SIZE" in out.stderr
+
+
+def test_counted_vmcnt_kernels_have_no_scratch_and_the_ring_kernel_its_verified_instruction_mix():
+    """tools/check_isa.py: conv_rgb_dgrad_ring_bf16_kernel / conv_halo64_bf16_kernel / conv_bf16_pph_kernel wait on hand-counted
+    `s_waitcnt vmcnt(N)`; a compiler bump that adds a scratch spill or splits a store between the counted operations must fail HERE, at build time,
+    not as a flaky bit-equality test on the GPU.  (Cross-compiles csrc/conv_bf16.hip to assembly: ~25 s, no GPU.)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_isa.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

@@ -628,11 +628,16 @@ def test_models_lpips_LPIPS_is_differentiable_in_its_input_like_the_reference():
 def test_rgb_data_gradient_ring_kernel_equals_the_segment_kernel_and_torch():
     """conv_rgb_dgrad_ring_bf16_kernel (round 5: VGG conv1_1's data gradient, 64 -> 3 channels, with every gradient row fetched once through a ring of
     eight LDS row slots) against the per-segment kernel it replaces (FACEOFF_RGB_DGRAD_NO_RING=1) -- bit for bit, same MFMA order per pixel -- and
-    against torch on the same bf16 operands, at sizes whose strips end inside a workgroup's run, frames of 2 and 4 strips, and the timed 160 x 256 x 256."""
+    against torch on the same bf16 operands, at sizes whose strips end inside a workgroup's run, frames of 2 and 4 strips (the 4-strip ones against torch too), and the timed 160 x 256 x 256."""
     import torch.nn.functional as F
     from faceoff_amd import ops
     bf = torch.bfloat16
-    for n, h, w in ((5, 128, 128), (3, 64, 256), (160, 256, 256)):
+    from faceoff_amd import _lib
+    lib = _lib.load()
+    lib.fo_kernel_notes(1)
+    # (every case has >= 64 * 1024 pixels: below that the dispatch keeps the generic kernel and the comparison would be of a kernel with itself -- ADVICE r05;
+    # which kernel ran is asserted from the library's own note of the launch)
+    for n, h, w in ((5, 128, 128), (4, 64, 256), (2, 128, 256), (160, 256, 256)):
         g = torch.Generator(device="cuda").manual_seed(n)
         gr = (torch.randn((n, h, w, 64), device="cuda", generator=g) * 0.5).to(bf)
         wt = torch.randn((64, 3, 3, 3), device="cuda", generator=g) * 0.1            # conv1_1's filter [Cout=64][Cin=3][3][3]
@@ -643,8 +648,11 @@ def test_rgb_data_gradient_ring_kernel_equals_the_segment_kernel_and_torch():
                 os.environ["FACEOFF_RGB_DGRAD_NO_RING"] = "1"
             try:
                 out = torch.full((n, h, w, 8), float("nan"), device="cuda", dtype=bf)
+                lib.fo_last_kernel()
                 ops.conv_bf16(gr, wpd, None, out, cin=64, cout=3)
                 torch.cuda.synchronize()
+                ran = lib.fo_last_kernel().decode()
+                assert ran.startswith("conv_rgb_dgrad_bf16_kernel" if old else "conv_rgb_dgrad_ring_bf16_kernel"), (n, h, w, old, ran)
             finally:
                 os.environ.pop("FACEOFF_RGB_DGRAD_NO_RING", None)
             outs.append(out)
@@ -654,3 +662,4 @@ def test_rgb_data_gradient_ring_kernel_equals_the_segment_kernel_and_torch():
             want = F.conv_transpose2d(gr.float().permute(0, 3, 1, 2), wq, padding=1).permute(0, 2, 3, 1)
             err = (outs[0][..., :3].float() - want).abs().max().item() / want.abs().max().item()
             assert err <= 1e-2, (n, h, w, err)
+    lib.fo_kernel_notes(0)
