@@ -107,7 +107,8 @@ def cpu_baseline(T, H, W, steps=20, all_cores_budget_s=40):
     return {"value": runs[best]["frames_per_s"], "unit": "frames/s", "cores": best, "host_cores": host, "cgroup_cpu_quota": quota, "kind": "port",
             "by_threads": {str(c): v for c, v in sorted(runs.items())},
             "sample": f"1 clip x {T} frames {H}x{W}, fwd+bwd+Adam, torch-CPU oracle, {steps} timed steps after 2 warm-ups at each of " +
-                      ", ".join(f"{c} threads (~{v['seconds']:.0f} s)" for c, v in sorted(done.items())) + "; value = the faster"}
+                      ", ".join(f"{c} threads (~{v['seconds']:.0f} s)" for c, v in sorted(done.items())) + "; value = the faster.  frames/s of ONE clip: the "
+                      f"{32 * T}-frame step of the GPU workload is not run on the CPU -- its rate is an extrapolation from this sample (the step is linear in clips)"}
 
 
 def parse_args(argv=None):
