@@ -158,6 +158,7 @@ SIGNATURES = {
     "fo_lpips_tap_bwd_bf16": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "fo_vgg_conv1_fused_bf16": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "fo_lpips_tap_fwd_bwd_bf16": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
+    "fo_lpips_tap_fwd_bwd_unpool_bf16": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "fo_adam_flat": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _F, _P]),
     "fo_zero": (_I, [_P, _L, _P]),
     "fo_relu": (_I, [_P, _I, _P, _I, _L, _I, _P]),

@@ -279,10 +279,15 @@ __global__ void lpips_head_bwd_bf16_kernel(const bf16x8* __restrict__ f0, const 
 // Forward AND backward of one tap's head in ONE pass over the two feature maps (the upstream gradient of a tap's value is a known constant,
 // gscale * weight / (H W N): nothing of the backward waits for the loss): the per-frame sums of lpips_head_fwd_bf16_kernel and the gradient of
 // lpips_head_bwd_bf16_kernel from the same loads.  Saves one read of both maps per tap (2.7 GB at relu1_2).
-template <int LPP>
+// UNPOOL (round 6, `fo_lpips_tap_fwd_bwd_unpool_bf16`): the tap also feeds a 2x2 max-pool, and the launch runs in the BACKWARD, when the gradient of the
+// pooled tensor is known: gf1 = head gradient + [this pixel is its window's recorded maximum] * gpool, summed in fp32 and rounded ONCE (what autograd
+// does for a tensor with two consumers) -- the pool backward's pass (read head gradient + pooled gradient, write the sum) and the head gradient's own
+// round trip through memory disappear: 2 x the tap's size less traffic per tap.
+template <int LPP, bool UNPOOL = false>
 __global__ void lpips_head_fwd_bwd_bf16_kernel(const bf16x8* __restrict__ f0, const bf16x8* __restrict__ f1, const float* __restrict__ lin,
                                                float* __restrict__ slot, const float* __restrict__ gscale, bf16x8* __restrict__ gf1, int HW,
-                                               long long npix, int S, float k_scale) {
+                                               long long npix, int S, float k_scale, const bf16x8* __restrict__ gpool = nullptr,
+                                               const unsigned short* __restrict__ codes = nullptr, int W = 0) {
   constexpr int PPW = 64 / LPP;
   const int lane = threadIdx.x & 63;
   const int sub = lane % LPP, pl = lane / LPP;
@@ -319,8 +324,22 @@ __global__ void lpips_head_fwd_bwd_bf16_kernel(const bf16x8* __restrict__ f0, co
     dot = group_sum<LPP>(dot);
     const float c2 = nb > 0.f ? dot * ib * ib / nb : 0.f;
     bf16x8 rr;
+    if (UNPOOL) {
+      const long long row = pp / W;                        // n * H + y (H is even: row >> 1 = n * H / 2 + y / 2)
+      const int x = (int)(pp - row * W);
+      const long long pq = (row >> 1) * (W >> 1) + (x >> 1);
+      const unsigned pos = (unsigned)((row & 1) * 2 + (x & 1));
+      const bf16x8 gq = gpool[pq * LPP + sub];
+      const unsigned code = codes[pq * LPP + sub];         // 2 bits per channel: which pixel of the window is its first maximum
 #pragma unroll
-    for (int k = 0; k < 8; ++k) rr[k] = (__bf16)((float)b[k] > 0.f ? gn[k] * ib - (float)b[k] * c2 : 0.f);
+      for (int k = 0; k < 8; ++k) {
+        const float hg = (float)b[k] > 0.f ? gn[k] * ib - (float)b[k] * c2 : 0.f;
+        rr[k] = (__bf16)(hg + (((code >> (2 * k)) & 3u) == pos ? (float)gq[k] : 0.f));
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) rr[k] = (__bf16)((float)b[k] > 0.f ? gn[k] * ib - (float)b[k] * c2 : 0.f);
+    }
     if (ok) gf1[p * LPP + sub] = rr;
     acc = ok ? acc : 0.f;
     if (HW < 64) {   // tiny maps: a pass may span several frames -- one value per pixel (there are few)
@@ -486,6 +505,30 @@ int fo_lpips_tap_fwd_bwd_bf16(const void* f0, const void* f1, const float* lin, 
   else if (C == 256) FO_HEAD_FB(32);
   else FO_HEAD_FB(64);
 #undef FO_HEAD_FB
+  FO_CHECK_LAUNCH();
+  hipLaunchKernelGGL(lpips_val_finish_kernel, dim3(N), dim3(64), 0, (hipStream_t)stream, ws, val, H * W, npix, h.per, h.S, 1.f / (float)(H * W));
+  FO_CHECK_LAUNCH();
+  return FO_OK;
+}
+
+int fo_lpips_tap_fwd_bwd_unpool_bf16(const void* f0, const void* f1, const float* lin, float* val, const float* gscale, const void* gpool,
+                                     const void* codes, void* gf1, int N, int H, int W, int C, float* ws, void* stream) {
+  FO_REQUIRE(ws && gpool && codes && (C == 64 || C == 128 || C == 256 || C == 512) && H % 2 == 0 && W % 2 == 0, FO_E_SHAPE,
+             "lpips_tap_unpool_bf16: C must be 64/128/256/512 (got %d), even H and W, a workspace, the pooled gradient and the pool's codes", C);
+  const long long npix = (long long)N * H * W;
+  const int grid = grid_for(npix * (C / 8), 4096);
+  const HeadPlan h = head_plan(npix, H * W, grid, 64 / (C / 8));
+  const float ks = 1.f / ((float)(H * W) * (float)N);
+#define FO_HEAD_FBU(LPP_)                                                                                                \
+  hipLaunchKernelGGL((lpips_head_fwd_bwd_bf16_kernel<LPP_, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream,        \
+                     reinterpret_cast<const bf16x8*>(f0), reinterpret_cast<const bf16x8*>(f1), lin, ws, gscale,           \
+                     reinterpret_cast<bf16x8*>(gf1), H * W, npix, h.S, ks, reinterpret_cast<const bf16x8*>(gpool),        \
+                     reinterpret_cast<const unsigned short*>(codes), W)
+  if (C == 64) FO_HEAD_FBU(8);
+  else if (C == 128) FO_HEAD_FBU(16);
+  else if (C == 256) FO_HEAD_FBU(32);
+  else FO_HEAD_FBU(64);
+#undef FO_HEAD_FBU
   FO_CHECK_LAUNCH();
   hipLaunchKernelGGL(lpips_val_finish_kernel, dim3(N), dim3(64), 0, (hipStream_t)stream, ws, val, H * W, npix, h.per, h.S, 1.f / (float)(H * W));
   FO_CHECK_LAUNCH();

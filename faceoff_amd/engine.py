@@ -497,6 +497,8 @@ class VQVAEEngine:
         ver = self.flat_params._version
         if not self._packs_stale and self._packed_version == ver and not _os.environ.get("FACEOFF_ALWAYS_PACK"):
             return
+        if _os.environ.get("FACEOFF_DIAG_NO_REPACK") and self._packed_version != -1:
+            return            # DIAGNOSTIC (stale filters, timing only): what the ~130 pack / convert launches of a step cost the timed step
         self._packs_stale, self._packed_version = False, ver
         ps = self.pack_stream
         if ps is None:

@@ -36,6 +36,9 @@ SCALE = (.458, .448, .450)              # lpips.py:100
 _F3 = C.c_float * 3
 
 
+LATE_HEADS_DEFAULT = "1"      # measured (tools/ab_env.sh 3, round 6, one box): config 3 33.80 / 33.84 / 33.85 -> 33.45 / 33.70 / 33.26 ms
+
+
 def conv_keys():
     """[(state_dict prefix, Cin, Cout, pool_before)] for the 13 convs."""
     out, idx, cin, pool = [], 0, 3, False
@@ -90,6 +93,11 @@ class LPIPSEngine:
         # the pools of the reconstruction branch record their arg-max (2 bits per element) and the pool backwards read that instead of the full-size
         # input: FACEOFF_LPIPS_POOL_IDX=0 switches it off (A/B, tests)
         self.pool_idx = _os.environ.get("FACEOFF_LPIPS_POOL_IDX", "1") != "0"
+        # round 6: the heads of the four taps that feed a max-pool run in the BACKWARD, fused with that pool's backward (fo_lpips_tap_fwd_bwd_unpool_bf16:
+        # head gradient + un-pooled gradient summed in fp32, rounded once) instead of on a side stream at forward time followed by a pool-backward
+        # pass: 2 x the tap's size less traffic per tap (5 GB per config-3 step), four launches fewer -- but the heads then sit IN the chain instead of
+        # beside its first matrix-bound convolutions: measured -0.36 ms on config 3.  FACEOFF_LPIPS_LATE_HEADS=0: the side-stream heads + pool backwards
+        self.late_heads = _os.environ.get("FACEOFF_LPIPS_LATE_HEADS", LATE_HEADS_DEFAULT) != "0"
         # ... and its convolutions leave the SIGN of every activation a data gradient will mask by as a bit plane (FACEOFF_LPIPS_MASK_BITS=0: the
         # data gradients read the bf16 activations themselves)
         self.mask_bits = _os.environ.get("FACEOFF_LPIPS_MASK_BITS", "1") != "0"
@@ -235,6 +243,7 @@ class LPIPSEngine:
         if gscale is None:
             gscale = torch.ones(1, device=self.device)
         head, head_ready = [], [None] * 5
+        late = False
         if fused:
             # The backward chain starts at the deepest tap and meets the shallower taps' gradients only in the pool backwards, much later: only
             # tap 5's head runs in the chain's way.  The other four -- HBM-bound passes over the big feature maps, 1.5 ms at C3 -- run on a side
@@ -249,7 +258,8 @@ class LPIPSEngine:
             if overlap and getattr(self, "_head_stream", None) is None:
                 self._head_stream = torch.cuda.Stream(device=self.device)
             vals = torch.zeros((5, N), device=self.device)
-            head = [torch.empty_like(t) for t in taps1]
+            late = self.late_heads and self.pool_idx and all(acts.get(f"c{i}") is not None for i, cv in enumerate(self.convs) if cv[3])
+            head = [torch.empty_like(t) if (k == 4 or not late) else None for k, t in enumerate(taps1)]
 
             def run_head(k):
                 n, h, w, c = taps1[k].shape
@@ -257,7 +267,9 @@ class LPIPSEngine:
                 _lib.call("fo_lpips_tap_fwd_bwd_bf16", ops._ptr(taps0[k]), ops._ptr(taps1[k]), ops._ptr(self.lin[k]), ops._ptr(vals[k]), ops._ptr(gscale),
                           ops._ptr(head[k]), n, h, w, c, ops._ptr(ws), ops._stream())
             run_head(4)
-            if overlap:
+            if late:
+                pass                                     # taps 1-4: in the backward, with their pools' backward (below)
+            elif overlap:
                 side = self._head_stream
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
@@ -311,7 +323,11 @@ class LPIPSEngine:
                 n, h, w, c = x.shape
                 if head_ready[tap] is not None:
                     torch.cuda.current_stream(self.device).wait_event(head_ready[tap])
-                if cidx is not None:                     # (head[tap] is zero wherever x is: lpips_head_*_bf16 apply the tap's own ReLU mask)
+                if fused and late:                       # this tap's head and its pool's backward in one pass over the two feature maps
+                    ws = ops._workspace(_lib.load().fo_lpips_tap_ws_bytes_bf16(n, h, w, c), self.device)
+                    _lib.call("fo_lpips_tap_fwd_bwd_unpool_bf16", ops._ptr(taps0[tap]), ops._ptr(x), ops._ptr(self.lin[tap]), ops._ptr(vals[tap]),
+                              ops._ptr(gscale), ops._ptr(gp), ops._ptr(cidx), ops._ptr(gx), n, h, w, c, ops._ptr(ws), ops._stream())
+                elif cidx is not None:                   # (head[tap] is zero wherever x is: lpips_head_*_bf16 apply the tap's own ReLU mask)
                     _lib.call("fo_maxpool2_bwd_idx_bf16", ops._ptr(cidx), ops._ptr(gp), ops._ptr(head[tap]), ops._ptr(gx), n, h, w, c, ops._stream())
                 else:
                     _lib.call("fo_maxpool2_bwd_bf16" if self.bf16 else "fo_maxpool2_bwd", ops._ptr(x), ops._ptr(gp), ops._ptr(head[tap]), ops._ptr(gx), n, h, w, c,

@@ -53,7 +53,7 @@ extern "C" {
                           quantisers' inputs (quantize_conv_t / _b, :208,213: VQ distances and arg-min stay fp32) and the decoder output */
 
 /* ABI version: bumped whenever an exported signature or the meaning of an argument changes (101: the loss kernels take a caller-owned
-   partial-sum workspace `ws` in front of `stream` and OVERWRITE their scalars -- round 4; 102: fo_comm_broadcast_async added; fo_instnorm_lrelu_{fwd,bwd}_batch take a workspace -- round 6).  The Python binding refuses a library whose
+   partial-sum workspace `ws` in front of `stream` and OVERWRITE their scalars -- round 4; 102: fo_comm_broadcast_async added; fo_instnorm_lrelu_{fwd,bwd}_batch take a workspace, fo_lpips_tap_fwd_bwd_unpool_bf16 -- round 6).  The Python binding refuses a library whose
    fo_version() differs from the FO_ABI_VERSION it was written against (faceoff_amd/_lib.py), so an older .so handed in through
    FACEOFF_HIP_LIB is a clean error and not a stream pointer read as a workspace. */
 #define FO_ABI_VERSION 102
@@ -524,6 +524,12 @@ int fo_vgg_conv1_fused_bf16(const void* x8, const void* wp1, const float* b1, co
  * gscale[0] / (N H W) is known before its value is): val[n] += the tap's value per frame, gf1 = its gradient wrt f1. */
 int fo_lpips_tap_fwd_bwd_bf16(const void* f0, const void* f1, const float* lin, float* val, const float* gscale, void* gf1, int N, int H,
                               int W, int C, float* ws, void* stream);
+/* The same for a tap that also feeds a 2x2 max-pool, launched in the BACKWARD: gf1 = head gradient + the pool's backward of gpool
+ * ([N][H/2][W/2][C] bf16) by its recorded arg-max `codes` (fo_maxpool2_fwd_idx_bf16 / fo_conv_igemm_bf16_pool_idx: 2 bits per channel), summed in
+ * fp32 and rounded once -- replaces fo_lpips_tap_fwd_bwd_bf16 + fo_maxpool2_bwd_idx_bf16 for that tap (LPIPS.forward lpips.py:80-93 under
+ * loss.backward(), train_faceoff_perceptual.py:100). */
+int fo_lpips_tap_fwd_bwd_unpool_bf16(const void* f0, const void* f1, const float* lin, float* val, const float* gscale, const void* gpool,
+                                     const void* codes, void* gf1, int N, int H, int W, int C, float* ws, void* stream);
 
 /* ---------------------------------------------------------------- optimiser + utilities */
 /* torch.optim.Adam defaults (train_faceoff_perceptual.py:190) over one flat parameter arena. */

@@ -568,6 +568,7 @@ def test_lpips_gradient_does_not_change_with_the_pool_codes_and_mask_planes(monk
     for idx, bits in ((True, True), (True, False), (False, False)):
         eng = LPIPSEngine(make_vgg_lpips_state(5), "cuda:0", dtype="bf16")
         eng.pool_idx, eng.mask_bits = idx, bits
+        eng.late_heads = False        # (round 6's fused head + pool backward needs the codes and rounds once instead of twice: its own test below)
         gd = torch.zeros_like(dec)
         loss = eng.loss_and_grad(tgt, dec, gd)
         _, acts = eng.features(eng._prep(dec, nhwc=True), keep_all=True)
@@ -663,3 +664,77 @@ def test_rgb_data_gradient_ring_kernel_equals_the_segment_kernel_and_torch():
             err = (outs[0][..., :3].float() - want).abs().max().item() / want.abs().max().item()
             assert err <= 1e-2, (n, h, w, err)
     lib.fo_kernel_notes(0)
+
+
+@pytest.mark.parametrize("Cc", [64, 128, 256, 512])
+def test_head_with_unpool_equals_head_then_pool_backward(Cc):
+    """fo_lpips_tap_fwd_bwd_unpool_bf16 (round 6: a tap's head and its max-pool's backward in ONE pass, the sum rounded once) against the two launches it
+    replaces (fo_lpips_tap_fwd_bwd_bf16 -> bf16 head gradient -> fo_maxpool2_bwd_idx_bf16): the per-frame values are the same bits; the gradient is the
+    same bits wherever only one of the two terms is non-zero (one rounding either way) and within one bf16 ulp of the two-launch result elsewhere (which
+    rounds the head gradient before adding)."""
+    from faceoff_amd import _lib, ops
+    import ctypes as C
+    bf = torch.bfloat16
+    g = torch.Generator(device="cuda").manual_seed(Cc)
+    N, H, W = 3, 24, 40
+    f0 = torch.relu(torch.randn((N, H, W, Cc), device="cuda", generator=g)).to(bf)
+    f1 = torch.relu(torch.randn((N, H, W, Cc), device="cuda", generator=g) + 0.3).to(bf)      # ReLU outputs: ~38 % zeros (the head gradient is zero there)
+    lin = torch.rand(Cc, device="cuda", generator=g)
+    gp = (torch.randn((N, H // 2, W // 2, Cc), device="cuda", generator=g) * 1e-4).to(bf)
+    gp[:, ::3] = 0                                                                         # rows of windows with no pooled gradient
+    gscale = torch.ones(1, device="cuda")
+    pooled = torch.empty((N, H // 2, W // 2, Cc), device="cuda", dtype=bf)
+    idx = torch.empty((N, H // 2, W // 2, Cc // 4), device="cuda", dtype=torch.uint8)
+    _lib.call("fo_maxpool2_fwd_idx_bf16", ops._ptr(f1), ops._ptr(pooled), ops._ptr(idx), None, N, H, W, Cc, ops._stream())
+    nb = _lib.load().fo_lpips_tap_ws_bytes_bf16(N, H, W, Cc)
+    ws = torch.empty(nb // 4 + 16, device="cuda")
+    v1, v2 = torch.zeros(N, device="cuda"), torch.zeros(N, device="cuda")
+    head, two, one = (torch.empty_like(f1) for _ in range(3))
+    _lib.call("fo_lpips_tap_fwd_bwd_bf16", ops._ptr(f0), ops._ptr(f1), ops._ptr(lin), ops._ptr(v1), ops._ptr(gscale), ops._ptr(head), N, H, W, Cc, ops._ptr(ws),
+              ops._stream())
+    _lib.call("fo_maxpool2_bwd_idx_bf16", ops._ptr(idx), ops._ptr(gp), ops._ptr(head), ops._ptr(two), N, H, W, Cc, ops._stream())
+    _lib.call("fo_lpips_tap_fwd_bwd_unpool_bf16", ops._ptr(f0), ops._ptr(f1), ops._ptr(lin), ops._ptr(v2), ops._ptr(gscale), ops._ptr(gp), ops._ptr(idx),
+              ops._ptr(one), N, H, W, Cc, ops._ptr(ws), ops._stream())
+    torch.cuda.synchronize()
+    assert torch.equal(v1, v2)
+    unpooled = torch.empty_like(f1)
+    _lib.call("fo_maxpool2_bwd_idx_bf16", ops._ptr(idx), ops._ptr(gp), None, ops._ptr(unpooled), N, H, W, Cc, ops._stream())      # the pool's backward alone
+    torch.cuda.synchronize()
+    only_one = (head == 0) | (unpooled == 0)
+    assert torch.equal(one[only_one], two[only_one])
+    both = ~only_one
+    assert both.float().mean().item() > 0.05                                                 # (the interesting case is exercised)
+    a, b = one[both].float(), two[both].float()
+    # the two-launch form rounds the head gradient before adding: it is off by up to half a unit in the last place OF THE LARGER OPERAND (not of the sum:
+    # the two terms may cancel), plus the final rounding both forms share
+    # |one - two| <= half a unit of the head gradient (its early rounding) + the two final roundings <= 2^-8 m + 2 * 2^-8 * 2 m with m = the larger operand
+    m = torch.maximum(head[both].float().abs(), unpooled[both].float().abs())
+    assert ((a - b).abs() <= 1.25 * 2.0 ** -6 * m).all()
+    assert ((a - b).abs() <= 2.0 ** -8 * m).float().mean().item() > 0.9                       # ... and almost always far inside it
+    exact = head[both].float() + unpooled[both].float()                                       # two-launch operands: `two` is this sum rounded
+    assert torch.equal(two[both], exact.to(bf))
+
+
+def test_late_heads_equal_early_heads_up_to_one_rounding():
+    """LPIPSEngine.late_heads (round 6, default): the four pooled taps' heads run in the backward, fused with their pools' backward -- the same loss to
+    the bit (the per-frame values are the same arithmetic), the image gradient equal up to the one bf16 rounding the fused form saves (the two-launch form
+    rounds a tap's head gradient before the pool backward adds to it), and itself bit-reproducible."""
+    from faceoff_amd.lpips import LPIPSEngine
+    rng = np.random.default_rng(14)
+    tgt = torch.from_numpy(rng.uniform(-1, 1, (3, 3, 64, 64)).astype(np.float32)).cuda()
+    dec = torch.zeros((3, 64, 64, 8), device="cuda")
+    dec[..., :3] = tgt.permute(0, 2, 3, 1) + 0.3 * torch.from_numpy(rng.standard_normal((3, 64, 64, 3)).astype(np.float32)).cuda()
+    out = []
+    for late in (True, True, False):
+        eng = LPIPSEngine(make_vgg_lpips_state(5), "cuda:0", dtype="bf16")
+        eng.late_heads = late
+        gd = torch.zeros_like(dec)
+        loss = eng.loss_and_grad(tgt, dec, gd)
+        torch.cuda.synchronize()
+        out.append((loss.item(), gd))
+    assert out[0][0] == out[1][0] and torch.equal(out[0][1], out[1][1])
+    assert out[0][0] == out[2][0]
+    a, b = out[0][1][..., :3].double(), out[2][1][..., :3].double()
+    rel = float((a - b).norm() / b.norm())
+    print(f"[late vs early LPIPS heads] image-gradient rel-L2 difference {rel:.2e}")
+    assert 0 < rel <= 5e-3
