@@ -58,6 +58,14 @@ def test_bench_emits_one_valid_json_line():
     assert "conv_gen_kernel" in c5["kernels"] and any(k.startswith("wgrad_gen_kernel<") for k in c5["kernels"]) and 0 < c5["iteration_frac_executed_flop"] < 1
     x = d["bf16x6"]
     assert any(k.startswith("wino_gemm_split") for k in x["kernels"]), list(x["kernels"])
+    # the step-level attainable floor (round 6): every launch of a step at its own bound, summed -- below the timed step, above the perfect-overlap
+    # figure, the byte model never counting a launch above its own measured time, the gaps named by kernel symbol
+    for leg, f, key in ((d, d["step_floor"], "step"), (c3, c3["step_floor"], "step"), (c5, c5["iteration_floor"], "iteration")):
+        assert 0 < f[f"{key}_floor_perfect_overlap_ms"] <= f[f"{key}_floor_ms"] and 0 < f[f"{key}_frac_of_floor"] <= 1.0, (key, f)
+        assert abs(f[f"{key}_floor_perfect_overlap_ms"] - max(f["sum_hbm_ms"], f["sum_mfma_ms"])) < 1e-2
+        assert f["floor_above_measured_ms"] <= 0.02 * f[f"{key}_floor_ms"], f["floor_above_measured_ms"]
+        assert f["launches_per_step"] > 100 and len(f["largest_gaps"]) >= 4 and all(g["measured_ms"] >= g["floor_ms"] * 0.98 for g in f["largest_gaps"])
+    assert d["step_floor"]["largest_gaps"][0]["kernel"] in d["kernels"] or d["step_floor"]["largest_gaps"][0]["kernel"].startswith(("fo_", "wino_", "conv_"))
     assert x["value"] > 0 and abs(x["value"] - 160 / (x["ms_per_step"] * 1e-3)) < 1e-2 * x["value"]
     assert 0 < x["loss"]["recon"] < 1 and 0 < x["loss"]["latent"] < 1
 
@@ -83,15 +91,21 @@ def test_bench_multi_gpu_code_path_with_one_rank():
     assert c["buckets"] == len(c["bucket_bytes"]) >= 3 and sum(c["bucket_bytes"]) == c["grad_allreduce_bytes_per_step"]
     assert c["exposed_ms"] is not None and 0 <= c["exposed_ms"] < d["ms_per_step"]
     assert c["ms_per_step_min_rank"] <= c["ms_per_step_max_rank"] and abs(c["ms_per_step_max_rank"] - d["ms_per_step"]) < 1e-2 * d["ms_per_step"]
+    # config 5's data-parallel branches ride along (round 6): per iteration (1 + 2) [generator arena + two running-statistics broadcasts] or (2 + 2)
+    c5 = d["c5"]["comm"]
+    assert c5["path"] == "fo_comm" and c5["collectives_per_iteration"] == 3.5, c5
 
 
 def test_bench_multi_gpu_code_path_over_torch_distributed():
     """--comm torch: the same forced one-rank run with the all-reduces issued through torch.distributed (round 3's path)."""
     env = dict(os.environ, FACEOFF_BENCH_FORCE_DDP="1", MASTER_PORT="29578")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-kernel-events",
-                          "--no-c3", "--no-c5", "--no-x6-leg", "--no-h2d-leg", "--comm", "torch"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+                          "--no-c3", "--no-c5", "--no-x6-leg", "--no-h2d-leg", "--comm", "torch", "--host-cpus", "2"], capture_output=True, text=True,
+                         timeout=600, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
-    c = json.loads([l for l in out.stdout.splitlines() if l.strip()][0])["comm"]
+    d = json.loads([l for l in out.stdout.splitlines() if l.strip()][0])
+    assert len(d["host"]["confined_to_cpus"]) == 2 and d["host"]["torch_threads"] == 1 and "cpu_baseline" not in d      # (--host-cpus: the 8-rank host budget rehearsal)
+    c = d["comm"]
     assert c["path"] == "torch.distributed" and c["fo_comm_issued_per_step"] is None and c["buckets"] >= 3
 
 
