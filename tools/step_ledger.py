@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Every C-ABI launch of one training step in launch order with its own bound (ops.StepLedger: algorithmic bytes / FLOP -> floor) beside the time
 it took alone on the GPU -- where a step stands above its attainable floor, launch by launch.
-    python tools/step_ledger.py [--bf16] [--lpips] [--gan] [--top N]        (C2 fp32 by default; --bf16 --lpips = config 3; --gan = config 5)"""
+    python tools/step_ledger.py [--bf16] [--lpips] [--gan] [--top N | --by-kernel]     (C2 fp32 by default; --bf16 --lpips = config 3; --gan = config 5;
+                                                                                        --by-kernel: one markdown row per kernel symbol, for profiles/)"""
 import os
 import sys
 
@@ -56,6 +57,21 @@ for i, c in enumerate(led.calls):
     rows.append((i, c["symbol"], c["entry"], c["bytes"] / 1e6, c["flops"] / 1e9, c["ev0"].elapsed_time(c["ev1"]), max(t_b, t_f), "hbm" if t_b >= t_f else "mfma"))
 tot_m, tot_f = sum(r[5] for r in rows), sum(r[6] for r in rows)
 print(f"{len(rows)} launches; measured (alone) {tot_m:.2f} ms; floor {tot_f:.2f} ms; gap {tot_m - tot_f:.2f} ms")
+if "--by-kernel" in sys.argv:
+    agg = {}
+    for i, sym, ent, mb, gf, ms, fl, b in rows:
+        a = agg.setdefault(sym, [0, 0.0, 0.0, 0.0, 0.0, {"hbm": 0, "mfma": 0}])
+        a[0] += 1; a[1] += ms; a[2] += fl; a[3] += mb; a[4] += gf; a[5][b] += 1
+    k = 1.0 / per
+    print(f"\n| kernel | launches | measured ms (alone) | floor ms | measured / floor | bound | algorithmic MB | algorithmic GFLOP |\n|---|---|---|---|---|---|---|---|")
+    for sym, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        if a[1] * k < 0.02:
+            continue
+        print(f"| `{sym}` | {a[0] * k:g} | {a[1] * k:.3f} | {a[2] * k:.3f} | {a[1] / max(a[2], 1e-9):.2f} | {'hbm' if a[5]['hbm'] >= a[5]['mfma'] else 'mfma'} | {a[3] * k:.0f} | {a[4] * k:.1f} |")
+    rest = [a for a in agg.values() if a[1] * k < 0.02]
+    print(f"| ({len(rest)} kernels under 0.02 ms) | {sum(a[0] for a in rest) * k:g} | {sum(a[1] for a in rest) * k:.3f} | {sum(a[2] for a in rest) * k:.3f} | | | | |")
+    print(f"| **total** | {len(rows) * k:g} | {tot_m * k:.2f} | {tot_f * k:.2f} | {tot_m / tot_f:.2f} | | | |")
+    raise SystemExit(0)
 top = int(sys.argv[sys.argv.index("--top") + 1]) if "--top" in sys.argv else 0
 order = sorted(rows, key=lambda r: -(r[5] - r[6]))[:top] if top else rows
 print(f"{'#':>4} {'measured':>9} {'floor':>8} {'gap':>8} bound {'MB':>9} {'GFLOP':>9}  kernel (entry)")
