@@ -12,7 +12,7 @@ its dtype from its arguments), and
 -- for config 3 per tensor (bf16 rounding flips are so many that every tensor sees their average); for config 5 on the worst tensor and on the median
 tensor (fp32: a handful of near-tie units, each of which moves ONE tensor by its whole contribution in whichever implementation happens to flip it -- a
 per-tensor ratio compares two draws of a lottery; round 6 measured ratios up to 12 on single tensors with the two distributions within 2x of each other).
-K = 2 where the engine's forward is as accurate as torch's direct convolutions (the direct kernels, 1e-6 of scale; the discriminators); K = 4 for the
+K = 2 where the engine's forward is as accurate as torch's direct convolutions (the direct kernels, 1e-6 of scale; the discriminators); K = 4.5 for the
 default generator engine: its Winograd F(4x4) forwards are 2e-5 of scale, the number of near-tie ReLU units that flip grows with the forward
 error, a gradient's error with the square root of the flips (contributions of random sign): sqrt(2e-5 / 1e-6) = 4.5.  Nothing is forced on the engine's side; the oracle runs take the ENGINE's code indices (index near-ties are gated on the oracle's fp64 top-2 margin by the
 tests named above -- a flipped code is an O(1) local change of the function, not a rounding effect).  The figures are printed."""
@@ -40,8 +40,10 @@ def _rel_l2(got, want):
 
 
 def _threads():
+    """CPU threads of the oracle runs: at most 16 (the pool's cgroup quota), so that the fp32 oracle's own summation order -- and with it WHICH near-tie
+    units it flips -- is the same wherever the quota allows 16 (oneDNN partitions reductions by thread count)."""
     from _fullsize_oracle import cgroup_cpus
-    return min(cgroup_cpus(), 32)
+    return min(cgroup_cpus(), 16)
 
 
 def _report(tag, e_eng, e_32, floor, k):
@@ -144,7 +146,7 @@ def test_c5_free_running_at_the_benched_size_vs_fp64(gen_iter, monkeypatch):
         assert max(e_eng.values()) <= C5_CAP, (mode, max(e_eng.items(), key=lambda kv: kv[1]))
 
 
-C5_FLOOR, C5_K, C5_K_WINOGRAD, C5_CAP = 1e-3, 2.0, 4.0, 1e-2
+C5_FLOOR, C5_K, C5_K_WINOGRAD, C5_CAP = 1e-3, 2.0, 4.5, 1e-2
 
 
 B3, T3 = 2, 5                                 # two of config 3's 32 clips: the fp64 evaluation of the LPIPS branch is ~20 s of host time per clip
