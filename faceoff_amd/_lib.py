@@ -73,6 +73,7 @@ SIGNATURES = {
     "fo_kernel_notes": (_I, [_I]),
     "fo_last_kernel": (C.c_char_p, []),
     "fo_device_info": (_I, [C.POINTER(C.c_int32)]),
+    "fo_selftest_lane_moves": (_I, [_P, _P]),
     "fo_nchw_to_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "fo_nchw2_to_nhwc8": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _P]),
     "fo_nhwc_to_nchw": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),

@@ -11,6 +11,46 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 void fo_set_error(const char* fmt, ...);
 
+// lane_xor<K>(v): the value of lane (l ^ K) -- what __shfl_xor(v, K) returns -- on the VECTOR ALU.  hipcc compiles __shfl_xor to ds_bpermute_b32, an
+// LDS-pipeline instruction with its round trip; a butterfly reduction is a chain of them.  gfx950 has the moves on the VALU: K = 1, 2 are DPP quad
+// permutations, K = 4 two bank-masked DPP row shifts (banks of four lanes: even banks take lane + 4, odd banks lane - 4), K = 8 a rotation of the
+// 16-lane row by eight, K = 16 / 32 the row swaps v_permlane16_swap / v_permlane32_swap (swap(v, v): one result holds the lower partner's rows, the
+// other the upper's; each lane picks the one that is not its own).  Same partner, same bits as the shuffle (round 6: the pooled epilogue of the
+// halo-tile kernel, the LPIPS heads' group sums, the discriminator heads' wave sums).
+template <int K> __device__ __forceinline__ int lane_xor_i(int v) {
+  static_assert(K == 1 || K == 2 || K == 4 || K == 8 || K == 16 || K == 32, "lane_xor: a power of two below 64");
+#ifdef FO_LANE_XOR_SHFL                                                                         // A/B build: the ds_bpermute form (tools/r06 A/B)
+  return __shfl_xor(v, K);
+#endif
+  if constexpr (K == 1) return __builtin_amdgcn_update_dpp(0, v, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
+  else if constexpr (K == 2) return __builtin_amdgcn_update_dpp(0, v, 0x4E /* quad_perm [2,3,0,1] */, 0xF, 0xF, true);
+  else if constexpr (K == 4) {
+    const int up = __builtin_amdgcn_update_dpp(0, v, 0x104 /* row_shl:4: lane l takes l + 4 */, 0xF, 0x5, false);
+    return __builtin_amdgcn_update_dpp(up, v, 0x114 /* row_shr:4: lane l takes l - 4 */, 0xF, 0xA, false);
+  } else if constexpr (K == 8) return __builtin_amdgcn_update_dpp(0, v, 0x128 /* row_ror:8 */, 0xF, 0xF, true);
+  else if constexpr (K == 16) {
+    const auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);     // r[0]: rows 0 0 2 2, r[1]: rows 1 1 3 3
+    return (__lane_id() & 16) ? (int)r[0] : (int)r[1];
+  } else {
+    const auto r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);     // r[0]: lower half twice, r[1]: upper half twice
+    return (__lane_id() & 32) ? (int)r[0] : (int)r[1];
+  }
+}
+template <int K> __device__ __forceinline__ float lane_xor(float v) { return __int_as_float(lane_xor_i<K>(__float_as_int(v))); }
+template <int K> __device__ __forceinline__ int lane_xor(int v) { return lane_xor_i<K>(v); }
+// v + the values of the other lanes of its aligned group of W lanes, by the xor butterfly W/2, W/4, .., 1: the association order of
+// `for (o = W / 2; o > 0; o >>= 1) v += __shfl_xor(v, o)`, hence the same bits
+template <int W> __device__ __forceinline__ float group_sum_valu(float v) {
+  if constexpr (W >= 64) v += lane_xor<32>(v);
+  if constexpr (W >= 32) v += lane_xor<16>(v);
+  if constexpr (W >= 16) v += lane_xor<8>(v);
+  if constexpr (W >= 8) v += lane_xor<4>(v);
+  if constexpr (W >= 4) v += lane_xor<2>(v);
+  if constexpr (W >= 2) v += lane_xor<1>(v);
+  return v;
+}
+
+
 // Kernel notes (fo_kernel_notes / fo_last_kernel, include/faceoff_hip.h): while enabled, every launcher records the symbol of the MAIN kernel it
 // launches -- name and template arguments exactly as rocprofv3 prints them -- so that bench.py's per-kernel entries carry the names found in
 // profiles/*_kernel_stats.md.  FO_NOTE("wino_gemm_kernel"); FO_NOTE_T("conv_bf16_pp16_kernel", BMB, BN, WAVES_M, WAVES_N) -> "...<256, 256, 2, 4>".

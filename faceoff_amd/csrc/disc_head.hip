@@ -37,11 +37,7 @@ __device__ __forceinline__ void stage_filter(const HeadArgs& a, float* wl, int t
   }
 }
 
-__device__ __forceinline__ float wave_sum64(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
+__device__ __forceinline__ float wave_sum64(float v) { return group_sum_valu<64>(v); }     // (xor butterfly on the vector ALU: common.h)
 
 template <int CPL>
 __global__ __launch_bounds__(256) void disc_head_fwd_kernel(const HeadArgs a) {

@@ -5,10 +5,28 @@
 
 namespace {
 
-__device__ __forceinline__ float wave_sum(float v) {
+__device__ __forceinline__ float wave_sum(float v) { return group_sum_valu<64>(v); }      // (the xor butterfly 32, 16, .., 1 on the vector ALU: common.h)
+
+// fo_selftest_lane_moves: lane_xor<K> (common.h) against __shfl_xor for every K, on one wave of distinct values: bad[lane] = bit mask of the K that differ
+__global__ __launch_bounds__(64) void lane_moves_selftest_kernel(int* __restrict__ bad) {
+  const float v = 1.5f + 0.37f * (float)threadIdx.x;
+  const int i = 1000 + 17 * (int)threadIdx.x;
+  int b = 0;
+  b |= (lane_xor<1>(v) != __shfl_xor(v, 1) || lane_xor<1>(i) != __shfl_xor(i, 1)) << 0;
+  b |= (lane_xor<2>(v) != __shfl_xor(v, 2) || lane_xor<2>(i) != __shfl_xor(i, 2)) << 1;
+  b |= (lane_xor<4>(v) != __shfl_xor(v, 4) || lane_xor<4>(i) != __shfl_xor(i, 4)) << 2;
+  b |= (lane_xor<8>(v) != __shfl_xor(v, 8) || lane_xor<8>(i) != __shfl_xor(i, 8)) << 3;
+  b |= (lane_xor<16>(v) != __shfl_xor(v, 16) || lane_xor<16>(i) != __shfl_xor(i, 16)) << 4;
+  b |= (lane_xor<32>(v) != __shfl_xor(v, 32) || lane_xor<32>(i) != __shfl_xor(i, 32)) << 5;
+  float t = v, u = v;
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
+  for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+  b |= (group_sum_valu<64>(u) != t) << 6;
+  t = v;
+#pragma unroll
+  for (int o = 4; o > 0; o >>= 1) t += __shfl_xor(t, o);
+  b |= (group_sum_valu<8>(u) != t) << 7;
+  bad[threadIdx.x] = b;
 }
 
 // A workgroup's share of a loss sum without float atomics: wave sums (shuffle tree), added in wave order by thread 0, written to part[blockIdx.x];
@@ -225,6 +243,14 @@ int fo_bias_grad(const float* g, float* dbias, int64_t M, int C, int Creal, int 
   hipLaunchKernelGGL(colsum_stage1, dim3(nblk), dim3(256), 0, (hipStream_t)stream, g, ws, (long long)M, C, ld);
   FO_CHECK_LAUNCH();
   hipLaunchKernelGGL(colsum_stage2, dim3((Creal + 63) / 64), dim3(1024), 0, (hipStream_t)stream, ws, dbias, nblk, C, Creal);
+  FO_CHECK_LAUNCH();
+  return FO_OK;
+}
+
+/* diagnostic: bad64[lane] = 0 where the vector-ALU lane moves of common.h (lane_xor<1..32>, group_sum_valu) return what __shfl_xor returns */
+int fo_selftest_lane_moves(int32_t* bad64, void* stream) {
+  FO_REQUIRE(bad64, FO_E_SHAPE, "selftest_lane_moves: null output");
+  hipLaunchKernelGGL(lane_moves_selftest_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, bad64);
   FO_CHECK_LAUNCH();
   return FO_OK;
 }

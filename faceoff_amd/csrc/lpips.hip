@@ -8,11 +8,7 @@
 
 namespace {
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
+__device__ __forceinline__ float wave_sum(float v) { return group_sum_valu<64>(v); }
 
 // ScalingLayer (lpips.py:96-103): y[n][h][w][c] = (x_c - shift_c) / scale_c for c < 3, 0 for c in 3..7.
 // src is either NCHW [N,3,H,W] (the loader's ground truth) or NHWC with pixel stride ld (the decoder output).

@@ -9,11 +9,7 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 template <int W>
-__device__ __forceinline__ float group_sum(float v) {   // sum over aligned groups of W lanes
-#pragma unroll
-  for (int o = W / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
+__device__ __forceinline__ float group_sum(float v) { return group_sum_valu<W>(v); }   // sum over aligned groups of W lanes (xor butterfly on the vector ALU: common.h)
 
 // ScalingLayer (lpips.py:96-103) + layout + rounding: y[p][c] = bf16((x_c - shift_c) / scale_c), c < 3; 0 for c in 3..7
 __global__ void lpips_prep_bf16_kernel(const float* __restrict__ src, int src_is_nhwc, int ld, bf16x8* __restrict__ y, int HW,

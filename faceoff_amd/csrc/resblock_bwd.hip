@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256, 2) void resblock_bwd_conv3_kernel(const RB3Arg
   float* const slab = a.ws + (size_t)blockIdx.x * (128 * 32 + 128);
 #pragma unroll
   for (int r = 0; r < 16; ++r) slab[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * 32 + l31] = accw[r];
-  dbp += __shfl_xor(dbp, 32);
+  dbp += lane_xor<32>(dbp);
   if (half == 0) slab[128 * 32 + wave * 32 + l31] = dbp;
 }
 
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(256, 2) void resblock_wgrad1_halo_kernel(const W1Ar
   for (int t = 0; t < 9; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) slab[(t * 128 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * 32 + l31] = acc[t][r];
-  dbp += __shfl_xor(dbp, 32);
+  dbp += lane_xor<32>(dbp);
   if (wave == 0 && half == 0) slab[9 * 128 * 32 + l31] = dbp;
 }
 

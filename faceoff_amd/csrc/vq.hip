@@ -64,7 +64,7 @@ __global__ __launch_bounds__(512, 1) void vq_assign_kernel(const float* __restri
     float xh = 0.f;
 #pragma unroll
     for (int s = 0; s < 32; ++s) xh = fmaf(xr[s], xr[s], xh);
-    const float xx = xh + __shfl_xor(xh, 32);
+    const float xx = xh + lane_xor<32>(xh);
 
     float best_d = INFINITY;
     int best_i = 0;
@@ -86,8 +86,8 @@ __global__ __launch_bounds__(512, 1) void vq_assign_kernel(const float* __restri
       }
     }
     if (!forced) {
-      const float od = __shfl_xor(best_d, 32);
-      const int oi = __shfl_xor(best_i, 32);
+      const float od = lane_xor<32>(best_d);
+      const int oi = lane_xor<32>(best_i);
       if (od < best_d || (od == best_d && oi < best_i)) { best_d = od; best_i = oi; }
     }
     if (half == 0 && valid) ind[v] = best_i;
@@ -110,8 +110,7 @@ __global__ __launch_bounds__(512, 1) void vq_assign_kernel(const float* __restri
   }
   // commitment sum without atomics: wave reduce, the eight waves' sums added in wave order, one partial per workgroup; fo_ordered_sum
   // adds the partials in workgroup order -- the printed latent loss is the same bits run after run
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+  sq = group_sum_valu<64>(sq);
   if (lane == 0) wave_sq[wave] = sq;
   __syncthreads();
   if (tid == 0) {

@@ -442,7 +442,7 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const __bf16* __restri
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     float v = s[e];
-    v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+    v += lane_xor<8>(v); v += lane_xor<16>(v); v += lane_xor<32>(v);
     if ((threadIdx.x & 63) < 8) red[threadIdx.x >> 6][c8 * 8 + e] = v;
   }
   __syncthreads();

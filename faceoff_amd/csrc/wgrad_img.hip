@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_img_kernel(const WImgArgs a) {
             slab[row * 128 + cb * 32 + l31] += acc[rb][cb][r];
           }
       // column sums of P: the two lane halves hold the same channel
-      const float b0 = bsum[0] + __shfl_xor(bsum[0], 32), b1 = bsum[1] + __shfl_xor(bsum[1], 32);
+      const float b0 = bsum[0] + lane_xor<32>(bsum[0]), b1 = bsum[1] + lane_xor<32>(bsum[1]);
       if (half == 0) {
         slab[64 * 128 + l31] += b0;
         slab[64 * 128 + 32 + l31] += b1;

@@ -53,7 +53,7 @@ extern "C" {
                           quantisers' inputs (quantize_conv_t / _b, :208,213: VQ distances and arg-min stay fp32) and the decoder output */
 
 /* ABI version: bumped whenever an exported signature or the meaning of an argument changes (101: the loss kernels take a caller-owned
-   partial-sum workspace `ws` in front of `stream` and OVERWRITE their scalars -- round 4; 102: fo_comm_broadcast_async added; fo_instnorm_lrelu_{fwd,bwd}_batch take a workspace, fo_lpips_tap_fwd_bwd_unpool_bf16 -- round 6).  The Python binding refuses a library whose
+   partial-sum workspace `ws` in front of `stream` and OVERWRITE their scalars -- round 4; 102: fo_comm_broadcast_async added; fo_instnorm_lrelu_{fwd,bwd}_batch take a workspace, fo_lpips_tap_fwd_bwd_unpool_bf16, fo_selftest_lane_moves added -- round 6).  The Python binding refuses a library whose
    fo_version() differs from the FO_ABI_VERSION it was written against (faceoff_amd/_lib.py), so an older .so handed in through
    FACEOFF_HIP_LIB is a clean error and not a stream pointer read as a workspace. */
 #define FO_ABI_VERSION 102
@@ -67,6 +67,9 @@ int fo_kernel_notes(int enable);
 const char* fo_last_kernel(void);
 /* device properties the host needs for the roofline report: [0]=CU count, [1]=clock kHz, [2]=is gfx950 */
 int fo_device_info(int32_t* out3);
+/* diagnostic: bad64[lane] = 0 where the library's vector-ALU lane moves (DPP / v_permlane swaps in place of ds_bpermute shuffles) return what
+   __shfl_xor returns for every distance 1 .. 32 and for the 8- and 64-lane butterfly sums (tests/test_ops_gpu.py) */
+int fo_selftest_lane_moves(int32_t* bad64, void* stream);
 
 /* ---------------------------------------------------------------- layout transforms */
 /* [N,C,H,W] -> [N,H,W,ldy] (channels >= C zero-filled up to Cpad).  Replaces the implicit NCHW

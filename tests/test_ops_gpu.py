@@ -432,6 +432,16 @@ def test_layout_mse_adam():
     np.testing.assert_allclose(p.cpu().numpy(), p_ref.detach().numpy(), rtol=1e-5, atol=1e-7)
 
 
+def test_vector_alu_lane_moves_equal_the_shuffles():
+    """common.h lane_xor<K> / group_sum_valu (DPP quad_perm / row_shl+row_shr / row_ror, v_permlane16/32_swap) against __shfl_xor (ds_bpermute) on
+    one wave of distinct floats and ints, every distance 1..32 and the 8- and 64-lane butterfly sums: the reductions that were switched to them
+    (LPIPS heads, discriminator head, VQ, weight-gradient column sums) keep their bits."""
+    from faceoff_amd import _lib, ops
+    bad = torch.full((64,), -1, dtype=torch.int32, device=_dev())
+    _lib.call("fo_selftest_lane_moves", ops._ptr(bad), ops._stream())
+    assert bad.cpu().tolist() == [0] * 64, bad.cpu().tolist()
+
+
 @pytest.mark.parametrize("N,T,Ht,Wt,kd,ci,co", [(10, 5, 8, 8, 3, 128, 128), (4, 2, 16, 16, 3, 128, 128), (8, 4, 12, 12, 3, 64, 128),
                                                  (6, 1, 8, 8, 3, 128, 128), (8, 1, 16, 8, 1, 128, 128), (32, 4, 4, 4, 3, 96, 256)])
 def test_wino_gemm_equals_the_banked_implicit_gemm(N, T, Ht, Wt, kd, ci, co):
