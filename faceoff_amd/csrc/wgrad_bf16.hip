@@ -41,6 +41,7 @@ struct WArgs {
   fo_conv_desc d;            // Cout = channels of P (a), Cin = channels of Q (b); ldOut = ldP, ldIn = ldQ; Hm/Wm = grid of P
   const __bf16* P;
   const __bf16* Q;
+  unsigned Pbytes, Qbytes;   // extents of P and Q (< 2^31: the loads are buffer loads with 32-bit byte offsets; a masked element asks for offset WOOB and gets zeros)
   float* ws;                 // [slabs][taps][Apad][Bpad]
   int tilesA, tilesB, tapRows, taps;
   int Apad, Bpad;
@@ -58,6 +59,9 @@ struct WArgs {
 };
 
 __device__ __forceinline__ unsigned relu_pk(unsigned w) { return w & ~(((w & 0x80008000u) >> 15) * 0xffffu); }
+
+constexpr unsigned WOOB = 0x80000000u;
+__device__ __forceinline__ u32x4 wbufload16(__amdgpu_buffer_rsrc_t r, unsigned off) { return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0); }
 
 __device__ __forceinline__ bf16x4 tr_read(const unsigned char* p) {
   typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
@@ -159,35 +163,41 @@ __global__ __launch_bounds__(512, (wgrad_two_per_cu(TA, TB, NKW, KR) ? 4 : 2)) v
   int offP[NPA], offQ[NPB];
   bool okP[NPA], okQ[NPB];
 #pragma unroll
-  for (int i = 0; i < NPA; ++i) { offP[i] = prow[i] * d.ldOut + a0 + pcol[i] * 8; okP[i] = prow[i] < 32 && a0 + pcol[i] * 8 < d.Cout; }
+  for (int i = 0; i < NPA; ++i) { offP[i] = (prow[i] * d.ldOut + a0 + pcol[i] * 8) * 2; okP[i] = prow[i] < 32 && a0 + pcol[i] * 8 < d.Cout; }     // (bytes)
 #pragma unroll
   for (int i = 0; i < NPB; ++i) {
-    if (SMALLC) { offQ[i] = ((qrow[i] >> 5) * d.Win + (qrow[i] & 31) * d.stride + qcol[i]) * d.ldIn; okQ[i] = qrow[i] < NQ; }
-    else { offQ[i] = qrow[i] * d.ldIn + b0 + qcol[i] * 8; okQ[i] = qrow[i] < NQ && b0 + qcol[i] * 8 < d.Cin; }
+    if (SMALLC) { offQ[i] = ((qrow[i] >> 5) * d.Win + (qrow[i] & 31) * d.stride + qcol[i]) * d.ldIn * 2; okQ[i] = qrow[i] < NQ; }
+    else { offQ[i] = (qrow[i] * d.ldIn + b0 + qcol[i] * 8) * 2; okQ[i] = qrow[i] < NQ && b0 + qcol[i] * 8 < d.Cin; }
   }
+  // Buffer loads, no branches: a masked element (padding column, channel tail, a unit past the slab's end) asks for offset WOOB and the hardware's
+  // range check returns zeros.  The loads of a step are then straight-line code and the compiler COUNTS them (s_waitcnt vmcnt(N) before the LDS
+  // stores of the step requested D - 1 steps earlier); with a branch around every load it could not, and every step drained the whole ring
+  // (vmcnt(0): one step of latency hidden instead of D - 1 -- round 6).
+  const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.P), 0, a.Pbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rQ = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.Q), 0, a.Qbytes, 0x00020000);
   auto load = [&](int u, u32x4 (&xp)[NPA], u32x4 (&xq)[NPB]) {       // u >= u1: zeros (a K-step's unused run)
     const bool live = u < u1 && !(FO_ABLATE_W & 1);
     if (FAST) {
       const int n = c_clip * d.T + tlo + c_t, y = ylo + c_y, x0 = c_run * 32;
       if (++c_run == a.runsPerRow) { c_run = 0; if (++c_y == Hv) { c_y = 0; if (++c_t == Tv) { c_t = 0; ++c_clip; } } }
-      const __bf16* const pb = a.P + (((long long)n * d.Hm + y) * d.Wm + x0) * d.ldOut;
+      const int pb = (((n * d.Hm + y) * d.Wm + x0) * d.ldOut) * 2;                    // byte offsets (wave-uniform part); a dead unit's may be anything
       const int qx0 = x0 * d.stride - d.padW, qy0 = y * d.stride + kh - d.padH;     // (image layers: kh = 0, the thread's own kh is in offQ)
-      const __bf16* const qb = a.Q + (((long long)(n + kd - d.padD) * d.Hin + qy0) * d.Win + qx0) * d.ldIn;
+      const int qb = ((((n + kd - d.padD) * d.Hin + qy0) * d.Win + qx0) * d.ldIn) * 2;
 #pragma unroll
-      for (int i = 0; i < NPA; ++i) xp[i] = (live && okP[i]) ? *reinterpret_cast<const u32x4*>(pb + offP[i]) : u32x4{0, 0, 0, 0};
+      for (int i = 0; i < NPA; ++i) xp[i] = wbufload16(rP, (live && okP[i]) ? (unsigned)(pb + offP[i]) : WOOB);
 #pragma unroll
       for (int i = 0; i < NPB; ++i) {
         bool ok = live && okQ[i];
         if (SMALLC) ok = ok && (unsigned)(qy0 + (qrow[i] >> 5)) < (unsigned)d.Hin && (unsigned)(qx0 + (qrow[i] & 31) * d.stride + qcol[i]) < (unsigned)d.Win;
         else ok = ok && (unsigned)(qx0 + qrow[i]) < (unsigned)d.Win;
-        xq[i] = ok ? *reinterpret_cast<const u32x4*>(qb + offQ[i]) : u32x4{0, 0, 0, 0};
+        xq[i] = wbufload16(rQ, ok ? (unsigned)(qb + offQ[i]) : WOOB);
       }
     } else {
 #pragma unroll
       for (int i = 0; i < NPA; ++i) {
         const int m = u * 32 + prow[i];
         const bool ok = live && prow[i] < 32 && m < M && a0 + pcol[i] * 8 < d.Cout;
-        xp[i] = ok ? *reinterpret_cast<const u32x4*>(a.P + (long long)m * d.ldOut + a0 + pcol[i] * 8) : u32x4{0, 0, 0, 0};
+        xp[i] = wbufload16(rP, ok ? (unsigned)((m * d.ldOut + a0 + pcol[i] * 8) * 2) : WOOB);
       }
 #pragma unroll
       for (int i = 0; i < NPB; ++i) {
@@ -198,8 +208,7 @@ __global__ __launch_bounds__(512, (wgrad_two_per_cu(TA, TB, NKW, KR) ? 4 : 2)) v
         const int qy = y * d.stride + kh - d.padH, qx = x * d.stride + kw0 - d.padW;
         const bool ok = live && qrow[i] < 32 && m < M && ((unsigned)(t + kd - d.padD) < (unsigned)d.T) && ((unsigned)qy < (unsigned)d.Hin) &&
                         ((unsigned)qx < (unsigned)d.Win) && b0 + qcol[i] * 8 < d.Cin;
-        xq[i] = ok ? *reinterpret_cast<const u32x4*>(a.Q + (((long long)(n + kd - d.padD) * d.Hin + qy) * d.Win + qx) * d.ldIn + b0 + qcol[i] * 8)
-                   : u32x4{0, 0, 0, 0};
+        xq[i] = wbufload16(rQ, ok ? (unsigned)(((((n + kd - d.padD) * d.Hin + qy) * d.Win + qx) * d.ldIn + b0 + qcol[i] * 8) * 2) : WOOB);
       }
     }
   };
@@ -298,11 +307,10 @@ __global__ __launch_bounds__(512, (wgrad_two_per_cu(TA, TB, NKW, KR) ? 4 : 2)) v
 #pragma unroll
     for (int rr = 0; rr < KR; ++rr) store(0, rr, rp[0][rr], rq[0][rr]);
 #pragma unroll
-    for (int k = 1; k <= D; ++k)                                      // steps 1 .. D -> slots 1, 2, .., 0
-      if (u0 + k * KR < u1) {
+    for (int k = 1; k <= D; ++k) {                                    // steps 1 .. D -> slots 1, 2, .., 0
 #pragma unroll
-        for (int rr = 0; rr < KR; ++rr) load(u0 + k * KR + rr, rp[k % D][rr], rq[k % D][rr]);
-      }
+      for (int rr = 0; rr < KR; ++rr) load(u0 + k * KR + rr, rp[k % D][rr], rq[k % D][rr]);
+    }
     __syncthreads();
     int u = u0;
     while (u < u1) {
@@ -314,15 +322,11 @@ __global__ __launch_bounds__(512, (wgrad_two_per_cu(TA, TB, NKW, KR) ? 4 : 2)) v
         // the next step's LDS stores and the request for the step after are issued INSIDE this step's MFMAs (after the first tap's): as a phase
         // of their own behind the MFMAs -- all eight waves are in the same phase -- they left the matrix pipe idle (tools/ablate_wgrad.sh, 64^2
         // Conv3d: 0.74 ms with, 0.41 ms without the stores)
-        auto stage_next = [&]() {
-          if (u + KR < u1) {
+        auto stage_next = [&]() {              // (unconditional: units past the slab's end load zeros from WOOB and nobody reads their stage)
 #pragma unroll
-            for (int rr = 0; rr < KR; ++rr) store(st ^ 1, rr, rp[(sl + 1) % D][rr], rq[(sl + 1) % D][rr]);
-            if (u + (D + 1) * KR < u1) {
+          for (int rr = 0; rr < KR; ++rr) store(st ^ 1, rr, rp[(sl + 1) % D][rr], rq[(sl + 1) % D][rr]);
 #pragma unroll
-              for (int rr = 0; rr < KR; ++rr) load(u + (D + 1) * KR + rr, rp[(sl + 1) % D][rr], rq[(sl + 1) % D][rr]);
-            }
-          }
+          for (int rr = 0; rr < KR; ++rr) load(u + (D + 1) * KR + rr, rp[(sl + 1) % D][rr], rq[(sl + 1) % D][rr]);
         };
         if (KR == 1) {                           // (two thin runs per step: measured slower with the stores inside, +8 % on the ResBlock 3x3)
           compute(st, 0, stage_next);
@@ -358,6 +362,251 @@ __global__ __launch_bounds__(512, (wgrad_two_per_cu(TA, TB, NKW, KR) ? 4 : 2)) v
 #pragma unroll
         for (int r = 0; r < 4; ++r) ob[i * 16 + kg * 4 + r] = accb[i][r];
       }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ all nine taps of a 3x3 (x KD) filter per workgroup
+// The row-run form above gives a workgroup the three kw taps of ONE (kd, kh): the three kh of a plane are three workgroups that each stream P
+// and Q from memory (rocprofv3 --pmc, 128 x 128 at 64^2: 770 MB fetched per launch for 336 MB of operands, L2 hit 0.23), and the launch is as long
+// as its loads and its MFMAs added up (ablations: loads + LDS stores alone 0.146 ms, fragment reads + MFMAs alone 0.151, together 0.26).  Here a
+// workgroup owns a 128 (channels of P) x 64 (channels of Q) block of ALL NINE taps of one depth plane -- 9 x 128 x 64 fp32 accumulators, 144
+// registers per lane -- so P is streamed once per 64 channels of Q and the three rows of Q a run needs (y - 1, y, y + 1) come out of L2 two times
+// in three (the same workgroup asked for them one and two rows earlier).  36 MFMAs per wave and K-step instead of 24.
+//   * Staging is LDS-DMA (buffer_load .. lds): no staging registers, no ds_write, nothing between a tile's request and its use but a counted
+//     s_waitcnt vmcnt.  The LDS image is therefore lane-linear (1 KB per wave instruction); the conflict-free placement the transposing read
+//     needs -- the four rows k .. k+3 of a 16-lane block in four different 64-byte bank groups, rows k + 8 .. in the other 32-byte half -- is
+//     an XOR of the 16-byte chunk index by a function of the row, applied to the DMA's SOURCE address and to the fragment address:
+//     P (256-byte rows): chunk ^ (4 (r & 3) ^ 2 ((r >> 3) & 1));  Q (128-byte rows): chunk ^ (2 ((r >> 1) & 1) + 4 ((r >> 3) & 1)).
+//     Padding (rows of Q above / below the image, the pixels left and right of a row, channel tails, units past the slab) is an out-of-range
+//     offset: the DMA writes zeros.
+//   * Two wave groups one barrier apart, as conv_bf16_pp16_kernel: while G0 (waves 0-3, channels 0-63 of P) issues its 36 MFMAs, G1 reads
+//     its fragments (26 transposing reads) and issues its DMAs, and vice versa -- each SIMD holds one wave of either group.  Ring of W9_NSLOT tiles,
+//     requested W9_NSLOT - 2 (G0) / - 1 (G1) K-steps ahead; raw s_barrier, no vmcnt(0) in the loop.
+// Units, slabs, the X-way interleave of the planes' slabs and the scratch layout are the row-run form's (tap row = depth plane, nine taps each):
+// wgrad_bf16_reduce_kernel sums the slabs.
+typedef __attribute__((address_space(3))) unsigned char w9_lds_byte;
+__device__ __forceinline__ void w9_dma16(__amdgpu_buffer_rsrc_t r, w9_lds_byte* dst, unsigned voffset) {      // (outside the kernel: see conv_bf16.hip dma16)
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)dst, 16, voffset, 0, 0, 0);
+}
+template <int N> __device__ __forceinline__ void w9_wait_vmcnt();
+template <> __device__ __forceinline__ void w9_wait_vmcnt<3>() { asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
+template <> __device__ __forceinline__ void w9_wait_vmcnt<6>() { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+template <> __device__ __forceinline__ void w9_wait_vmcnt<9>() { asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); }
+template <> __device__ __forceinline__ void w9_wait_vmcnt<12>() { asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); }
+template <> __device__ __forceinline__ void w9_wait_vmcnt<15>() { asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); }
+// The transposing read as inline assembly: behind the builtin (no memory operand the waitcnt pass could tell from the DMAs' LDS writes) hipcc puts
+// s_waitcnt vmcnt(0) in front of the first fragment read of every K-step, i.e. drains the ring.  Issued here, awaited by w9_wait_frags().
+template <int OFF> __device__ __forceinline__ bf16x4 w9_tr(unsigned addr) {
+  bf16x4 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+__device__ __forceinline__ void w9_wait_frags() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+constexpr int W9_A = 32 * 256;                    // P tile: 32 positions x 128 channels
+constexpr int W9_BROW = 40 * 128;                 // one row of Q: 34 pixels (40 staged: five 1-KB pieces) x 64 channels
+constexpr int W9_SLOT = W9_A + 3 * W9_BROW;       // 23 552 bytes
+#ifndef W9_NSLOT
+#define W9_NSLOT 6                                // ring slots: G0 requests W9_NSLOT - 2 tiles ahead, G1 one more
+#endif
+constexpr int W9_AHEAD = W9_NSLOT - 2;
+constexpr int W9_LDS = W9_NSLOT * W9_SLOT + 1024; // + the KB the odd sixteenth piece of Q (there are fifteen) is written to
+constexpr int W9_NP = 3;                          // DMAs per wave and tile: one piece of P, two of Q
+
+__global__ __launch_bounds__(512, 2) void wgrad9_bf16_kernel(const WArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const fo_conv_desc& d = a.d;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wa = wave >> 2, wb = wave & 3;                           // wave tile: channels 64 wa .. of P x channels 16 wb .. of Q, nine taps
+  const bool g1 = wa != 0;
+  const int l15 = lane & 15, kg = lane >> 4;
+
+  // ---- this workgroup: tile (a, b), depth plane, slab (as the row-run form)
+  int w = blockIdx.x;
+  const int perTile = a.X * a.wgPerX;
+  const int tile = w / perTile; w -= tile * perTile;
+  const int tb = tile % a.tilesB, ta = tile / a.tilesB;
+  const int xcd = w % a.X;
+  int li = w / a.X, kd = 0;
+  while (li >= a.mOf[kd]) { li -= a.mOf[kd]; ++kd; }
+  const int slab = xcd * a.mOf[kd] + li, nslab = a.X * a.mOf[kd];
+  const int tlo = max(0, d.padD - kd);
+  const int Tv = min(d.T - 1, d.T - 1 + d.padD - kd) - tlo + 1;
+  const int vunits = Tv > 0 ? (d.N / d.T) * Tv * d.Hm * a.runsPerRow : 0;
+  const int u0 = (int)((long long)vunits * slab / nslab), u1 = (int)((long long)vunits * (slab + 1) / nslab);
+  const int nt = u1 - u0;
+  const int a0 = ta * 128, b0 = tb * 64;
+  const bool bias_wg = tb == 0 && kd == a.biasTapRow;
+
+  // ---- DMA roles.  P: piece `wave` = rows 4 wave .. + 3, lane -> (row, LDS chunk position); the chunk it FETCHES is position ^ swizzle(row)
+  // (offsets of masked lanes are 0 and their kill word is WOOB: `(base + offset) | kill` is branch-free and lands at or above 2^31, out of range)
+  unsigned offA, killA;
+  {
+    const int row = 4 * wave + (lane >> 4), pc = lane & 15;
+    const int c = pc ^ ((4 * (row & 3)) ^ (2 * ((row >> 3) & 1)));
+    const bool ok = a0 + 8 * c < d.Cout;
+    offA = ok ? (unsigned)((row * d.ldOut + a0 + 8 * c) * 2) : 0u;
+    killA = ok ? 0u : WOOB;
+  }
+  // Q: pieces `wave` and `wave + 8` of fifteen (piece p = row tile p / 5, rows 8 (p % 5) .. + 7 of its forty; the sixteenth goes to the spare KB as zeros)
+  unsigned offB[2], killB[2], left[2], right[2];                     // left / right: WOOB on the lane that holds the pixel left of / right of the run
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int pce = wave + 8 * j;
+    const int row = 8 * (pce % 5) + (lane >> 3), pc = lane & 7;
+    const int c = pc ^ (2 * ((row >> 1) & 1) + 4 * ((row >> 3) & 1));
+    const bool ok = pce < 15 && row < 34 && b0 + 8 * c < d.Cin;
+    offB[j] = ok ? (unsigned)((row * d.ldIn + b0 + 8 * c) * 2) : 0u;
+    killB[j] = ok ? 0u : WOOB;
+    left[j] = row == 0 ? WOOB : 0u;
+    right[j] = row == 33 ? WOOB : 0u;
+  }
+  const int khB0 = wave / 5, khB1 = (wave + 8) / 5;                    // the row tile (kh) of either piece; (wave + 8) / 5 == 3: the spare
+  const int dstA = wave * 1024;
+  const int dstB0 = W9_A + khB0 * W9_BROW + (wave % 5) * 1024;
+  const int dstB1 = (wave + 8 < 15) ? W9_A + khB1 * W9_BROW + ((wave + 8) % 5) * 1024 : -1;
+  const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.P), 0, a.Pbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rQ = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.Q), 0, a.Qbytes, 0x00020000);
+  w9_lds_byte* const lds3 = (w9_lds_byte*)lds;
+
+  // cursor = virtual unit (clip, t', y, run) of the next tile to request; tiles past the slab's end are requested as zeros (constant DMA counts)
+  int c_run, c_y, c_t, c_clip, q = 0, qslot = 0;
+  {
+    int v = u0;
+    c_run = v % a.runsPerRow; v /= a.runsPerRow;
+    c_y = v % d.Hm; v /= d.Hm;
+    c_t = v % max(Tv, 1); c_clip = v / max(Tv, 1);
+  }
+  const int lastRun = a.runsPerRow - 1;
+  auto dma_tile = [&]() {
+    const bool live = q < nt && !(FO_ABLATE_W & 1);
+    const int n = c_clip * d.T + tlo + c_t, y = c_y, x0 = c_run * 32;
+    const bool first = c_run == 0, last = c_run == lastRun;
+    if (++c_run == a.runsPerRow) { c_run = 0; if (++c_y == d.Hm) { c_y = 0; if (++c_t == Tv) { c_t = 0; ++c_clip; } } }
+    w9_lds_byte* const slot = lds3 + qslot * W9_SLOT;
+    qslot = qslot + 1 == W9_NSLOT ? 0 : qslot + 1;
+    const unsigned pb = live ? (unsigned)((((n * d.Hm + y) * d.Wm + x0) * d.ldOut) * 2) : WOOB;
+    w9_dma16(rP, slot + dstA, (pb + offA) | killA);
+    const int qrow0 = ((n + kd - d.padD) * d.Hin + y - 1) * d.Win + x0 - 1;         // pixel index of row tile 0's first staged pixel (may be negative: a killed lane)
+    const unsigned fm = first ? WOOB : 0u, lm = last ? WOOB : 0u;                   // the run touches the left / right edge of the image row
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int kh = j == 0 ? khB0 : khB1;
+      const bool rowok = live && (unsigned)(y + kh - 1) < (unsigned)d.Hin;
+      const unsigned qb = rowok ? (unsigned)(((qrow0 + kh * d.Win) * d.ldIn) * 2) : WOOB;
+      const unsigned off = (qb + offB[j]) | killB[j] | (left[j] & fm) | (right[j] & lm);
+      w9_lds_byte* const dst = (j == 0) ? slot + dstB0 : (dstB1 >= 0 ? slot + dstB1 : lds3 + W9_NSLOT * W9_SLOT);
+      w9_dma16(rQ, dst, off);
+    }
+    ++q;
+  };
+
+  f32x4 acc[9][4], accb = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bf16x8 ones = {(__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f};
+
+  // ---- fragment addressing (see the header: same lane -> (row, 4 channels) map as the row-run form, swizzled instead of padded): LDS byte
+  // addresses inside slot 0; rows k and k + 4 of P share (r & 3) and (r >> 3) & 1, so the upper half of a fragment is + 4 rows
+  const unsigned ldsbase = (unsigned)(size_t)lds3;
+  const int krow = kg * 8 + (l15 >> 2);
+  const int xa = (64 * (l15 >> 2)) ^ (32 * (kg & 1));
+  unsigned fA[4], fB[3][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) fA[i] = ldsbase + krow * 256 + (l15 & 3) * 8 + ((128 * wa + 32 * i) ^ xa);
+#pragma unroll
+  for (int k = 0; k < 3; ++k)                                         // tap kw, half h: row r = krow + 4 h + kw of the 34
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int r = krow + 4 * h + k;
+      fB[k][h] = ldsbase + r * 128 + ((32 * wb) ^ (32 * (((r >> 1) & 1) + 2 * ((r >> 3) & 1)))) + (l15 & 3) * 8;
+    }
+
+  if (nt > 0) {
+#pragma unroll
+    for (int i = 0; i < W9_AHEAD; ++i) dma_tile();
+    if (g1) { dma_tile(); w9_wait_vmcnt<W9_AHEAD * W9_NP>(); } else w9_wait_vmcnt<(W9_AHEAD - 1) * W9_NP>();
+    __builtin_amdgcn_s_barrier();
+    if (g1) __builtin_amdgcn_s_barrier();                             // G1 runs one segment behind G0 from here on
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned sl = 0;                                                  // byte offset of tile p's slot
+    for (int p = 0; p < nt; ++p) {
+      bf16x4 la[4], ha[4], lb[9], hb[9];
+      if (FO_ABLATE_W & 16) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { la[i] = bf16x4{(__bf16)(float)p, 0, 0, 0}; ha[i] = la[i]; }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) { lb[t] = la[0]; hb[t] = la[0]; }
+      }
+      if (!(FO_ABLATE_W & 20)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { la[i] = w9_tr<0>(fA[i] + sl); ha[i] = w9_tr<4 * 256>(fA[i] + sl); }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const unsigned b0a = fB[k][0] + sl, b1a = fB[k][1] + sl;
+          lb[k] = w9_tr<W9_A>(b0a); hb[k] = w9_tr<W9_A>(b1a);
+          lb[3 + k] = w9_tr<W9_A + W9_BROW>(b0a); hb[3 + k] = w9_tr<W9_A + W9_BROW>(b1a);
+          lb[6 + k] = w9_tr<W9_A + 2 * W9_BROW>(b0a); hb[6 + k] = w9_tr<W9_A + 2 * W9_BROW>(b1a);
+        }
+      }
+      sl = sl + W9_SLOT == W9_NSLOT * W9_SLOT ? 0u : sl + W9_SLOT;
+      dma_tile();                                                    // G0: tile p + W9_AHEAD, G1: one more
+      if (g1) w9_wait_vmcnt<W9_AHEAD * W9_NP>();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(FO_ABLATE_W & 4)) {
+        w9_wait_frags();                                             // (issued a segment ago, beside the other group's MFMAs)
+        __builtin_amdgcn_sched_barrier(0);
+        bf16x8 fa[4], fb[9];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[i] = bf16x8{la[i][0], la[i][1], la[i][2], la[i][3], ha[i][0], ha[i][1], ha[i][2], ha[i][3]};
+#pragma unroll
+        for (int t = 0; t < 9; ++t) fb[t] = bf16x8{lb[t][0], lb[t][1], lb[t][2], lb[t][3], hb[t][0], hb[t][1], hb[t][2], hb[t][3]};
+        if (a.inrelu) {
+#pragma unroll
+          for (int t = 0; t < 9; ++t) {
+            u32x4 v = __builtin_bit_cast(u32x4, fb[t]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = relu_pk(v[e]);
+            fb[t] = __builtin_bit_cast(bf16x8, v);
+          }
+        }
+        __builtin_amdgcn_s_setprio(1);
+        if (bias_wg) {                                                // column sums of P: tile wb of the wave's four (a scalar select, not an indexed register)
+          const bf16x8 fs = wb == 0 ? fa[0] : (wb == 1 ? fa[1] : (wb == 2 ? fa[2] : fa[3]));
+          accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fs, ones, accb, 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < ((FO_ABLATE_W & 32) ? 1 : 9); ++t)
+#pragma unroll
+          for (int i = 0; i < ((FO_ABLATE_W & 32) ? 1 : 4); ++i) acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[t], acc[t][i], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+      }
+      if (!g1) w9_wait_vmcnt<(W9_AHEAD - 1) * W9_NP>();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (!g1) __builtin_amdgcn_s_barrier();                            // G0 waits out G1's last segment
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the zero-fill DMAs of the tiles past the end
+  }
+
+  // ---- partial blocks -> ws[slab][tap][a][b]: accumulator register r of lane l = (a = 4 (l >> 4) + r, b = l & 15)
+  if ((FO_ABLATE_W & 8) && acc[0][0][0] != 12345.f) return;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    float* o = a.ws + (((long long)slab * a.taps + kd * 9 + t) * a.Apad + a0 + wa * 64) * a.Bpad + b0 + wb * 16;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[(long long)(i * 16 + kg * 4 + r) * a.Bpad + l15] = acc[t][i][r];
+  }
+  if (bias_wg && l15 == 0) {
+    float* ob = a.wsBias + (long long)slab * a.Apad + a0 + wa * 64 + wb * 16;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ob[kg * 4 + r] = accb[r];
   }
 }
 
@@ -475,7 +724,7 @@ __global__ __launch_bounds__(1024) void colsum_reduce_kernel(const float* __rest
 
 struct WPlan {
   int TA, TB, WA, NKW, KR;
-  bool fast, smallc;
+  bool fast, smallc, all9;   // all9: wgrad9_bf16_kernel (a workgroup = 128 x 64 x the nine taps of one depth plane; NKW = 9, tap rows = planes)
   int tilesA, tilesB, tapRows, taps, units, Apad, Bpad, biasTapRow;
   int X, wgPerX, maxSlabs, perCU;
   short mOf[32];
@@ -504,9 +753,14 @@ int make_plan(const fo_conv_desc* d, WPlan* p) {
     p->tapRows = p->fast ? d->KD * d->KH : p->taps;
     // the centre tap's row reads a real pixel of Q for EVERY position of P: its workgroups see every row of P
     p->biasTapRow = p->fast ? d->padD * d->KH + d->padH : (d->padD * d->KH + d->padH) * d->KW + d->padW;
+    // 3x3 (x KD) pad-1 stride-1 filters between >= 128 and >= 64 channels: all nine taps of a plane per workgroup (FACEOFF_WGRAD_ROWS=1: the row-run form)
+    p->all9 = p->fast && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->padH == 1 && d->padW == 1 && d->Hm == d->Hin && d->Wm == d->Win && A >= 128 &&
+              B >= 64 && d->padD < d->KD && getenv("FACEOFF_WGRAD_ROWS") == nullptr;
+    if (p->all9) { p->TA = 128; p->TB = 64; p->NKW = 9; p->tapRows = d->KD; p->biasTapRow = d->padD; }
   }
+  if (p->smallc) p->all9 = false;
   // waves: WA x (8 / WA) with at least one 16 x 16 tile per wave in either direction
-  p->WA = (p->TA == 128 && p->TB == 128) ? 2 : (p->TA == 128 ? 4 : (p->TA == 64 ? (p->TB == 32 ? 4 : 2) : (p->TB == 128 ? 1 : 2)));
+  p->WA = (p->all9 || (p->TA == 128 && p->TB == 128)) ? 2 : (p->TA == 128 ? 4 : (p->TA == 64 ? (p->TB == 32 ? 4 : 2) : (p->TB == 128 ? 1 : 2)));
   const int perRun = p->NKW * (p->TA / p->WA / 16) * (p->TB / (8 / p->WA) / 16);      // MFMAs per wave and run
   p->KR = perRun <= 8 ? 2 : 1;                                       // thin blocks: two runs per barrier
   p->tilesA = (A + p->TA - 1) / p->TA;
@@ -518,7 +772,10 @@ int make_plan(const fo_conv_desc* d, WPlan* p) {
   long long work[32], total = 0;
   for (int tr = 0; tr < p->tapRows; ++tr) {
     work[tr] = p->units;
-    if (p->fast && !p->smallc) {
+    if (p->all9) {
+      const int tlo = std::max(0, d->padD - tr), thi = std::min(d->T - 1, d->T - 1 + d->padD - tr);
+      work[tr] = thi >= tlo ? (long long)(d->N / d->T) * (thi - tlo + 1) * d->Hm * (d->Wm / 32) : 0;
+    } else if (p->fast && !p->smallc) {
       const int kd = tr / d->KH, kh = tr % d->KH;
       const int tlo = std::max(0, d->padD - kd), thi = std::min(d->T - 1, d->T - 1 + d->padD - kd);
       const int ylo = std::max(0, (d->padH - kh + d->stride - 1) / d->stride), yhi = std::min(d->Hm - 1, (d->Hin - 1 + d->padH - kh) / d->stride);
@@ -529,11 +786,11 @@ int make_plan(const fo_conv_desc* d, WPlan* p) {
   const int tiles = p->tilesA * p->tilesB;
   // workgroups per CU: two for the thin blocks whose LDS fits twice (wgrad_thin; FACEOFF_WGRAD_ONE_PER_CU=1: round 4's one)
   {
-    const int lds = wgrad_lds_bytes_rt(p->TA, p->TB, p->NKW, p->KR, p->fast, p->smallc);
+    const int lds = p->all9 ? W9_LDS : wgrad_lds_bytes_rt(p->TA, p->TB, p->NKW, p->KR, p->fast, p->smallc);
     const bool one = getenv("FACEOFF_WGRAD_ONE_PER_CU") != nullptr;        // (read per call, like the other A/B switches)
     // (measured, tools/bench_wgrad_bf16.py, same device: the ResBlocks' 3x3 128 -> 32 0.152 -> 0.114 ms, the image layers 0.182 -> 0.141; the 1x1
     // forms get nothing from it -- 0.050 -> 0.054 with twice the slabs to reduce -- and keep one)
-    p->perCU = (!one && wgrad_two_per_cu(p->TA, p->TB, p->NKW, p->KR) && 2 * lds <= 160 * 1024) ? 2 : 1;
+    p->perCU = (!one && !p->all9 && wgrad_two_per_cu(p->TA, p->TB, p->NKW, p->KR) && 2 * lds <= 160 * 1024) ? 2 : 1;
   }
   const int slots = p->perCU * fo_cu_count();
   const int budget = std::max(p->tapRows, slots / tiles);             // workgroups per tile: one round of the chip's resident slots
@@ -572,6 +829,14 @@ int launch_w(const WArgs& a, int grid, hipStream_t s) {       // 1 = launched, -
   if (ldsBytes > 48 * 1024 && !fo_lds_optin(once, reinterpret_cast<const void*>(kern), ldsBytes, "wgrad_bf16")) return -1;
   FO_NOTE_T("wgrad_bf16_kernel", TA, TB, WA, NKW, KR, FAST, SMALLC);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), ldsBytes, s, a);
+  return 1;
+}
+
+int launch_w9(const WArgs& a, int grid, hipStream_t s) {
+  static fo_lds_once once;
+  if (!fo_lds_optin(once, reinterpret_cast<const void*>(wgrad9_bf16_kernel), W9_LDS, "wgrad9_bf16")) return -1;
+  FO_NOTE("wgrad9_bf16_kernel");
+  hipLaunchKernelGGL(wgrad9_bf16_kernel, dim3(grid), dim3(512), W9_LDS, s, a);
   return 1;
 }
 
@@ -614,6 +879,10 @@ extern "C" int fo_conv_wgrad_bf16(const fo_conv_desc* d, const void* P, const vo
   WArgs a;
   a.d = *d;
   a.P = reinterpret_cast<const __bf16*>(P); a.Q = reinterpret_cast<const __bf16*>(Q); a.ws = ws;
+  const int64_t pbytes = (int64_t)d->N * d->Hm * d->Wm * d->ldOut * 2, qbytes = (int64_t)d->N * d->Hin * d->Win * d->ldIn * 2;
+  FO_REQUIRE(pbytes < (1LL << 31) && qbytes < (1LL << 31), FO_E_SHAPE, "wgrad_bf16: operands of %lld / %lld bytes (32-bit buffer offsets: < 2 GiB each)",
+             (long long)pbytes, (long long)qbytes);
+  a.Pbytes = (unsigned)pbytes; a.Qbytes = (unsigned)qbytes;
   a.tilesA = p.tilesA; a.tilesB = p.tilesB; a.tapRows = p.tapRows; a.taps = p.taps;
   a.X = p.X; a.wgPerX = p.wgPerX;
   for (int i = 0; i < 32; ++i) a.mOf[i] = p.mOf[i];
@@ -624,7 +893,8 @@ extern "C" int fo_conv_wgrad_bf16(const fo_conv_desc* d, const void* P, const vo
   const int grid = p.tilesA * p.tilesB * p.X * p.wgPerX;
   hipStream_t s = (hipStream_t)stream;
   int ok;
-  if (p.smallc) ok = launch_w<64, 32, 4, 4, 2, true, true>(a, grid, s);
+  if (p.all9) ok = launch_w9(a, grid, s);
+  else if (p.smallc) ok = launch_w<64, 32, 4, 4, 2, true, true>(a, grid, s);
   else if (p.fast && p.NKW == 3) ok = dispatch<3, true>(p, a, grid, s);
   else if (p.fast && p.NKW == 4) ok = dispatch<4, true>(p, a, grid, s);
   else if (p.fast) ok = dispatch<1, true>(p, a, grid, s);

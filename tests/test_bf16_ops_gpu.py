@@ -228,6 +228,35 @@ def test_wgrad_3x3_row_runs(ca, cb, in_relu):
     _wgrad_case(30 + ca + cb, 3, 1, ca, cb, (1, 3, 3), 1, (0, 1, 1), 12, 64, in_relu=in_relu)
 
 
+@pytest.mark.parametrize("ca,cb,k,T,N,Hm,Wm,in_relu", [
+    (128, 128, (1, 3, 3), 1, 3, 12, 64, False),      # the 128 -> 128 layers
+    (256, 64, (1, 3, 3), 1, 2, 5, 32, False),        # two tiles of P's channels, one of Q's
+    (136, 96, (1, 3, 3), 1, 2, 6, 96, True),         # channel tails in both tiles (masked lanes), three runs per row, ReLU applied to the fragments
+    (128, 192, (1, 3, 3), 1, 2, 1, 32, False),       # one-row images: both neighbour rows are padding
+    (128, 128, (3, 3, 3), 5, 10, 8, 32, False),      # Conv3d: three depth planes, the outer ones skip a frame of each clip
+    (128, 64, (3, 3, 3), 1, 3, 4, 32, False),        # Conv3d on one-frame clips: the outer planes have no work at all
+    (128, 128, (1, 3, 3), 1, 40, 32, 64, False),     # enough units for several K-steps per slab on every CU (ring wrap-around)
+])
+def test_wgrad_all_nine_taps_form(ca, cb, k, T, N, Hm, Wm, in_relu, monkeypatch):
+    """wgrad9_bf16_kernel (3x3 pad-1 stride-1 filters between >= 128 and >= 64 channels: a workgroup holds all nine taps of a depth plane, LDS-DMA staging,
+    swizzled tiles) against torch's fp32 filter gradient, and the row-run form it replaced (FACEOFF_WGRAD_ROWS=1) on the same operands: two summation orders
+    of the same products.  The library reports which kernel ran."""
+    from faceoff_amd import _lib
+    lib = _lib.load()
+    seed = 90 + ca + cb + k[0] + Hm
+    lib.fo_kernel_notes(1); lib.fo_last_kernel()
+    _wgrad_case(seed, N, T, ca, cb, k, 1, (k[0] // 2, 1, 1), Hm, Wm, in_relu=in_relu)
+    torch.cuda.synchronize()
+    kern = lib.fo_last_kernel().decode()
+    assert "wgrad9_bf16_kernel" in kern, kern
+    monkeypatch.setenv("FACEOFF_WGRAD_ROWS", "1")
+    lib.fo_last_kernel()
+    _wgrad_case(seed, N, T, ca, cb, k, 1, (k[0] // 2, 1, 1), Hm, Wm, in_relu=in_relu)
+    torch.cuda.synchronize()
+    kern = lib.fo_last_kernel().decode(); lib.fo_kernel_notes(0)
+    assert "wgrad9" not in kern and "wgrad_bf16_kernel" in kern, kern
+
+
 @pytest.mark.parametrize("ca,cb", [(128, 32), (64, 128), (64, 192)])
 def test_wgrad_1x1(ca, cb):
     _wgrad_case(40 + ca + cb, 2, 1, ca, cb, (1, 1, 1), 1, (0, 0, 0), 16, 32)
