@@ -25,6 +25,7 @@
 // channel counts and writes [a][b][taps].
 #include <stdlib.h>
 #include <algorithm>
+#include <type_traits>
 #include "common.h"
 
 #ifndef FO_ABLATE_W   // diagnostic builds (tools/ablate_wgrad.sh): bit 0 no global loads, 1 no LDS stores, 2 no fragment reads / MFMAs
@@ -379,9 +380,16 @@ __global__ __launch_bounds__(512, (wgrad_two_per_cu(TA, TB, NKW, KR) ? 4 : 2)) v
 //     P (256-byte rows): chunk ^ (4 (r & 3) ^ 2 ((r >> 3) & 1));  Q (128-byte rows): chunk ^ (2 ((r >> 1) & 1) + 4 ((r >> 3) & 1)).
 //     Padding (rows of Q above / below the image, the pixels left and right of a row, channel tails, units past the slab) is an out-of-range
 //     offset: the DMA writes zeros.
-//   * Two wave groups one barrier apart, as conv_bf16_pp16_kernel: while G0 (waves 0-3, channels 0-63 of P) issues its 36 MFMAs, G1 reads
-//     its fragments (26 transposing reads) and issues its DMAs, and vice versa -- each SIMD holds one wave of either group.  Ring of W9_NSLOT tiles,
-//     requested W9_NSLOT - 2 (G0) / - 1 (G1) K-steps ahead; raw s_barrier, no vmcnt(0) in the loop.
+//   * One barrier per K-step, every wave the same program, software-pipelined over the three rows of taps: while the 12 MFMAs of row kh issue,
+//     the six fragment reads of row kh + 1 are in flight; behind the barrier (after row 1) the next K-step's fragments of P and of row 0 are
+//     requested, under the MFMAs of row 2.  Two fragment sets of P and two of Q's rows alternate (the loop body is two K-steps), so nothing
+//     waits for a read it has just issued, and the two waves of a SIMD interleave freely.  (A first version ran two wave groups one barrier
+//     apart as conv_bf16_pp16_kernel does: with ONE wave per SIMD issuing MFMAs at a time the matrix pipe stayed below 0.6 busy, and the
+//     ~120 scalar / address instructions a wave spends per tile request were as long as the other group's MFMAs.)
+//     The transposing reads are inline assembly (see w9_tr) with hand-counted s_waitcnt lgkmcnt(N): LDS returns in order.
+//   * Ring of W9_NSLOT tiles requested W9_NSLOT - 1 K-steps ahead; a wave waits for ITS pieces of the next tile (counted vmcnt) in front of
+//     the barrier; raw s_barrier, no vmcnt(0) in the loop.  The position of the next tile is a byte offset advanced by a constant (P and Q have
+//     the same pixel grid; frames a plane skips are a jump at the clip boundary).
 // Units, slabs, the X-way interleave of the planes' slabs and the scratch layout are the row-run form's (tap row = depth plane, nine taps each):
 // wgrad_bf16_reduce_kernel sums the slabs.
 typedef __attribute__((address_space(3))) unsigned char w9_lds_byte;
@@ -389,35 +397,51 @@ __device__ __forceinline__ void w9_dma16(__amdgpu_buffer_rsrc_t r, w9_lds_byte* 
   __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)dst, 16, voffset, 0, 0, 0);
 }
 template <int N> __device__ __forceinline__ void w9_wait_vmcnt();
+template <> __device__ __forceinline__ void w9_wait_vmcnt<0>() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 template <> __device__ __forceinline__ void w9_wait_vmcnt<3>() { asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
 template <> __device__ __forceinline__ void w9_wait_vmcnt<6>() { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
 template <> __device__ __forceinline__ void w9_wait_vmcnt<9>() { asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); }
 template <> __device__ __forceinline__ void w9_wait_vmcnt<12>() { asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); }
-template <> __device__ __forceinline__ void w9_wait_vmcnt<15>() { asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); }
 // The transposing read as inline assembly: behind the builtin (no memory operand the waitcnt pass could tell from the DMAs' LDS writes) hipcc puts
-// s_waitcnt vmcnt(0) in front of the first fragment read of every K-step, i.e. drains the ring.  Issued here, awaited by w9_wait_frags().
-template <int OFF> __device__ __forceinline__ bf16x4 w9_tr(unsigned addr) {
-  bf16x4 v;
+// s_waitcnt vmcnt(0) in front of the first fragment read of every K-step, i.e. drains the ring.  The compiler does not know that the result
+// arrives later: every use sits behind a w9_wait_* that names the registers as in/out operands (nothing can be scheduled, copied or folded
+// across it) and carries the count.
+template <int OFF> __device__ __forceinline__ void w9_tr(bf16x4& v, unsigned addr) {
   asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
-  return v;
 }
-__device__ __forceinline__ void w9_wait_frags() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// a kernel argument the loop needs, made resident in an SGPR HERE: left to itself hipcc waits for the argument's scalar load at its first use -- inside
+// the loop, with s_waitcnt lgkmcnt(0), which also drains the fragment reads in flight
+__device__ __forceinline__ int w9_pin(int x) { asm volatile("" : "+s"(x)); return x; }
+__device__ __forceinline__ unsigned w9_pin(unsigned x) { asm volatile("" : "+s"(x)); return x; }
+struct W9Frag { bf16x4 lo, hi; };                 // rows k .. k+3 and k+4 .. k+7 of one 16-channel fragment
+#define W9_TIE(f) "+v"((f).lo), "+v"((f).hi)
+// wait until at most N of the LDS reads issued so far are outstanding: the fragments named have landed
+template <int N> __device__ __forceinline__ void w9_wait_a_b(W9Frag (&fa)[4], W9Frag (&fb)[3]) {
+  asm volatile("s_waitcnt lgkmcnt(%14)" : W9_TIE(fa[0]), W9_TIE(fa[1]), W9_TIE(fa[2]), W9_TIE(fa[3]), W9_TIE(fb[0]), W9_TIE(fb[1]), W9_TIE(fb[2]) : "n"(N) : "memory");
+}
+template <int N> __device__ __forceinline__ void w9_wait_b(W9Frag (&fb)[3]) {
+  asm volatile("s_waitcnt lgkmcnt(%6)" : W9_TIE(fb[0]), W9_TIE(fb[1]), W9_TIE(fb[2]) : "n"(N) : "memory");
+}
+__device__ __forceinline__ bf16x8 w9_join(const W9Frag& f) { return bf16x8{f.lo[0], f.lo[1], f.lo[2], f.lo[3], f.hi[0], f.hi[1], f.hi[2], f.hi[3]}; }
 constexpr int W9_A = 32 * 256;                    // P tile: 32 positions x 128 channels
 constexpr int W9_BROW = 40 * 128;                 // one row of Q: 34 pixels (40 staged: five 1-KB pieces) x 64 channels
 constexpr int W9_SLOT = W9_A + 3 * W9_BROW;       // 23 552 bytes
-#ifndef W9_NSLOT
-#define W9_NSLOT 6                                // ring slots: G0 requests W9_NSLOT - 2 tiles ahead, G1 one more
+#ifndef W9_CLUSTER
+#define W9_CLUSTER 1                              // (experiment: where a row's side work goes: 0 one piece behind each MFMA, 1 all in front of the row, 2 all behind it, 3 behind each four)
 #endif
-constexpr int W9_AHEAD = W9_NSLOT - 2;
+#ifndef W9_NSLOT
+#define W9_NSLOT 4                                // ring slots; tiles are requested W9_NSLOT - 1 K-steps ahead
+#endif
+constexpr int W9_AHEAD = W9_NSLOT - 1;
 constexpr int W9_LDS = W9_NSLOT * W9_SLOT + 1024; // + the KB the odd sixteenth piece of Q (there are fifteen) is written to
 constexpr int W9_NP = 3;                          // DMAs per wave and tile: one piece of P, two of Q
 
+template <bool RELU>                                 // RELU: Q is the INPUT of a ReLU -> conv pair (the fragments of Q are clamped as they are used)
 __global__ __launch_bounds__(512, 2) void wgrad9_bf16_kernel(const WArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const fo_conv_desc& d = a.d;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wa = wave >> 2, wb = wave & 3;                           // wave tile: channels 64 wa .. of P x channels 16 wb .. of Q, nine taps
-  const bool g1 = wa != 0;
   const int l15 = lane & 15, kg = lane >> 4;
 
   // ---- this workgroup: tile (a, b), depth plane, slab (as the row-run form)
@@ -464,41 +488,55 @@ __global__ __launch_bounds__(512, 2) void wgrad9_bf16_kernel(const WArgs a) {
   const int dstA = wave * 1024;
   const int dstB0 = W9_A + khB0 * W9_BROW + (wave % 5) * 1024;
   const int dstB1 = (wave + 8 < 15) ? W9_A + khB1 * W9_BROW + ((wave + 8) % 5) * 1024 : -1;
+  const unsigned khOff0 = (unsigned)(khB0 * d.Win * d.ldIn * 2), khOff1 = (unsigned)(khB1 * d.Win * d.ldIn * 2);
   const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.P), 0, a.Pbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rQ = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.Q), 0, a.Qbytes, 0x00020000);
   w9_lds_byte* const lds3 = (w9_lds_byte*)lds;
 
-  // cursor = virtual unit (clip, t', y, run) of the next tile to request; tiles past the slab's end are requested as zeros (constant DMA counts)
-  int c_run, c_y, c_t, c_clip, q = 0, qslot = 0;
+  // cursor = virtual unit (clip, t', y, run) of the next tile to request, as byte offsets of its first position in P and of the pixel above-left of it
+  // in Q (modular: the lanes that would read in front of the tensor are killed); tiles past the slab's end are requested as zeros (constant DMA counts)
+  int c_run, c_y, c_t, q = 0, qslot = 0;
+  unsigned pOff, qOff;
   {
     int v = u0;
     c_run = v % a.runsPerRow; v /= a.runsPerRow;
     c_y = v % d.Hm; v /= d.Hm;
-    c_t = v % max(Tv, 1); c_clip = v / max(Tv, 1);
+    c_t = v % max(Tv, 1);
+    const int clip = v / max(Tv, 1), n = clip * d.T + tlo + c_t;
+    pOff = (unsigned)((((n * d.Hm + c_y) * d.Wm + c_run * 32) * d.ldOut) * 2);
+    qOff = (unsigned)(((((n + kd - d.padD) * d.Hin + c_y - 1) * d.Win + c_run * 32 - 1) * d.ldIn) * 2);
   }
-  const int lastRun = a.runsPerRow - 1;
-  auto dma_tile = [&]() {
-    const bool live = q < nt && !(FO_ABLATE_W & 1);
-    const int n = c_clip * d.T + tlo + c_t, y = c_y, x0 = c_run * 32;
-    const bool first = c_run == 0, last = c_run == lastRun;
-    if (++c_run == a.runsPerRow) { c_run = 0; if (++c_y == d.Hm) { c_y = 0; if (++c_t == Tv) { c_t = 0; ++c_clip; } } }
-    w9_lds_byte* const slot = lds3 + qslot * W9_SLOT;
-    qslot = qslot + 1 == W9_NSLOT ? 0 : qslot + 1;
-    const unsigned pb = live ? (unsigned)((((n * d.Hm + y) * d.Wm + x0) * d.ldOut) * 2) : WOOB;
-    w9_dma16(rP, slot + dstA, (pb + offA) | killA);
-    const int qrow0 = ((n + kd - d.padD) * d.Hin + y - 1) * d.Win + x0 - 1;         // pixel index of row tile 0's first staged pixel (may be negative: a killed lane)
-    const unsigned fm = first ? WOOB : 0u, lm = last ? WOOB : 0u;                   // the run touches the left / right edge of the image row
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int kh = j == 0 ? khB0 : khB1;
-      const bool rowok = live && (unsigned)(y + kh - 1) < (unsigned)d.Hin;
-      const unsigned qb = rowok ? (unsigned)(((qrow0 + kh * d.Win) * d.ldIn) * 2) : WOOB;
-      const unsigned off = (qb + offB[j]) | killB[j] | (left[j] & fm) | (right[j] & lm);
-      w9_lds_byte* const dst = (j == 0) ? slot + dstB0 : (dstB1 >= 0 ? slot + dstB1 : lds3 + W9_NSLOT * W9_SLOT);
-      w9_dma16(rQ, dst, off);
-    }
-    ++q;
+  const unsigned stepP = (unsigned)(32 * d.ldOut * 2), stepQ = (unsigned)(32 * d.ldIn * 2);
+  const unsigned jumpP = w9_pin((unsigned)((d.T - Tv) * d.Hm * d.Wm * d.ldOut * 2)), jumpQ = w9_pin((unsigned)((d.T - Tv) * d.Hin * d.Win * d.ldIn * 2));
+  const int runs = w9_pin(a.runsPerRow), Hm = w9_pin(d.Hm), TvP = w9_pin(Tv), ntP = nt;       // (the operands of the cursor's rarely taken branches)
+  const int lastRun = runs - 1, lastY = Hm - 1;
+  const unsigned kOff0 = khOff0, kOff1 = khOff1;
+  // one tile request = three DMAs + the cursor's advance, as four pieces the loop drops between MFMAs (dma_tile(): all four)
+  w9_lds_byte* slotq = lds3;                                         // the slot of tile q
+  auto dma_p = [&]() {
+    const bool live = q < ntP && !(FO_ABLATE_W & 1);
+    w9_dma16(rP, slotq + dstA, ((live ? pOff : WOOB) + offA) | killA);
   };
+  auto dma_q0 = [&]() {                                               // rows of Q: kh = 0 needs y > 0, kh = 2 needs y < H - 1
+    const bool live = q < ntP && !(FO_ABLATE_W & 1);
+    const bool rowok = live && (khB0 == 0 ? c_y > 0 : (khB0 == 2 ? c_y < lastY : true));
+    const unsigned edge = killB[0] | (left[0] & (c_run == 0 ? WOOB : 0u)) | (right[0] & (c_run == lastRun ? WOOB : 0u));
+    w9_dma16(rQ, slotq + dstB0, ((rowok ? qOff + kOff0 : WOOB) + offB[0]) | edge);
+  };
+  auto dma_q1 = [&]() {                                               // (khB1 is 1, 2 or 3 -- 3: the spare piece, killed anyway)
+    const bool live = q < ntP && !(FO_ABLATE_W & 1);
+    const bool rowok = live && (khB1 == 2 ? c_y < lastY : true);
+    const unsigned edge = killB[1] | (left[1] & (c_run == 0 ? WOOB : 0u)) | (right[1] & (c_run == lastRun ? WOOB : 0u));
+    w9_dma16(rQ, dstB1 >= 0 ? slotq + dstB1 : lds3 + W9_NSLOT * W9_SLOT, ((rowok ? qOff + kOff1 : WOOB) + offB[1]) | edge);
+  };
+  auto dma_next = [&]() {
+    pOff += stepP; qOff += stepQ;
+    if (++c_run == runs) { c_run = 0; if (++c_y == Hm) { c_y = 0; if (++c_t == TvP) { c_t = 0; pOff += jumpP; qOff += jumpQ; } } }
+    ++q;
+    qslot = qslot + 1 == W9_NSLOT ? 0 : qslot + 1;
+    slotq = lds3 + qslot * W9_SLOT;
+  };
+  auto dma_tile = [&]() { dma_p(); dma_q0(); dma_q1(); dma_next(); };
 
   f32x4 acc[9][4], accb = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -523,74 +561,134 @@ __global__ __launch_bounds__(512, 2) void wgrad9_bf16_kernel(const WArgs a) {
       fB[k][h] = ldsbase + r * 128 + ((32 * wb) ^ (32 * (((r >> 1) & 1) + 2 * ((r >> 3) & 1)))) + (l15 & 3) * 8;
     }
 
+  const unsigned bm0 = wb == 0 ? ~0u : 0u, bm1 = wb == 1 ? ~0u : 0u, bm2 = wb == 2 ? ~0u : 0u, bm3 = wb == 3 ? ~0u : 0u;      // bias: tile wb of the wave's four
+  W9Frag fa[2][4], fb[3][3];                                          // two sets of P's fragments (even / odd K-steps), one per row of Q's taps
+  unsigned bq[3][2], aq[4];                                           // fB, fA + a tile's slot
+  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+  auto join_b = [&](const W9Frag& f) {
+    bf16x8 v = w9_join(f);
+    if (RELU) {
+      u32x4 u = __builtin_bit_cast(u32x4, v);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) u[e] = relu_pk(u[e]);
+      v = __builtin_bit_cast(bf16x8, u);
+    }
+    return v;
+  };
+  // the 12 MFMAs of one row of taps, work(j) dropped behind MFMA j: every MFMA is 16 cycles of matrix pipe in which the wave issues a few
+  // reads / address instructions / a DMA -- the order is pinned (sched_barrier), nothing is left to pile up in front of or behind a row
+  auto mfma_row = [&](const W9Frag (&A)[4], const W9Frag (&B)[3], auto KH, auto&& work) {
+    constexpr int kh = decltype(KH)::value;
+    if (FO_ABLATE_W & 4) {
+#pragma unroll
+      for (int j = 0; j < 12; ++j) work(j);
+      return;
+    }
+    bf16x8 va[4], vb[3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) va[i] = w9_join(A[i]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) vb[k] = join_b(B[k]);
+    __builtin_amdgcn_sched_barrier(0);
+#if W9_CLUSTER == 1
+#pragma unroll
+    for (int j = 0; j < 12; ++j) work(j);
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        acc[kh * 3 + k][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va[i], vb[k], acc[kh * 3 + k][i], 0, 0, 0);
+#if W9_CLUSTER == 0
+        __builtin_amdgcn_sched_barrier(0);
+        work(k * 4 + i);
+        __builtin_amdgcn_sched_barrier(0);
+#elif W9_CLUSTER == 3
+        if (i == 3) {
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) work(k * 4 + j);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#endif
+      }
+#if W9_CLUSTER == 2
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 12; ++j) work(j);
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+  };
+
   if (nt > 0) {
 #pragma unroll
     for (int i = 0; i < W9_AHEAD; ++i) dma_tile();
-    if (g1) { dma_tile(); w9_wait_vmcnt<W9_AHEAD * W9_NP>(); } else w9_wait_vmcnt<(W9_AHEAD - 1) * W9_NP>();
+    w9_wait_vmcnt<(W9_AHEAD - 1) * W9_NP>();                          // this wave's pieces of tile 0
     __builtin_amdgcn_s_barrier();
-    if (g1) __builtin_amdgcn_s_barrier();                             // G1 runs one segment behind G0 from here on
     __builtin_amdgcn_sched_barrier(0);
-    unsigned sl = 0;                                                  // byte offset of tile p's slot
-    for (int p = 0; p < nt; ++p) {
-      bf16x4 la[4], ha[4], lb[9], hb[9];
-      if (FO_ABLATE_W & 16) {
+    unsigned sl = 0;                                                  // byte offset of the current tile's slot
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { la[i] = bf16x4{(__bf16)(float)p, 0, 0, 0}; ha[i] = la[i]; }
+    for (int k = 0; k < 3; ++k) { bq[k][0] = fB[k][0]; bq[k][1] = fB[k][1]; }
 #pragma unroll
-        for (int t = 0; t < 9; ++t) { lb[t] = la[0]; hb[t] = la[0]; }
+    for (int i = 0; i < 4; ++i) { w9_tr<0>(fa[0][i].lo, fA[i]); w9_tr<4 * 256>(fa[0][i].hi, fA[i]); }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { w9_tr<W9_A>(fb[0][k].lo, bq[k][0]); w9_tr<W9_A>(fb[0][k].hi, bq[k][1]); }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { w9_tr<W9_A + W9_BROW>(fb[1][k].lo, bq[k][0]); w9_tr<W9_A + W9_BROW>(fb[1][k].hi, bq[k][1]); }
+    w9_wait_a_b<6>(fa[0], fb[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    // One K-step, PAR = its parity.  Row kh of Q lives in fb[kh], P in fa[PAR]; every fragment is requested TWO rows (24 MFMAs) before the row that uses it:
+    //   on entry   P and row 0 have landed, row 1 is in flight
+    //   row 0      the six reads of row 2 (fb[2]: the previous step's row 2 has issued); the next slot's addresses; then this wave's pieces of the next tile
+    //              are awaited and the barrier taken (everybody's pieces have landed; everybody has finished with the tile before this one, whose slot the
+    //              next request overwrites)
+    //   row 1      the next tile's row 0 -> fb[0] and its eight of P -> fa[PAR ^ 1]
+    //   row 2      the next tile's row 1 -> fb[1]; the request of tile p + W9_AHEAD
+    auto kstep = [&](auto PAR) {
+      constexpr int par = decltype(PAR)::value;
+      if (bias_wg && !(FO_ABLATE_W & 4)) {                            // column sums of P: tile wb of the wave's four
+        const u32x4 x0 = __builtin_bit_cast(u32x4, w9_join(fa[par][0])), x1 = __builtin_bit_cast(u32x4, w9_join(fa[par][1]));
+        const u32x4 x2 = __builtin_bit_cast(u32x4, w9_join(fa[par][2])), x3 = __builtin_bit_cast(u32x4, w9_join(fa[par][3]));
+        u32x4 r;                                                      // (mask arithmetic: a select between the register sets -- ?: or branches -- hipcc turns into an indexed scratch array)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = (x0[e] & bm0) | (x1[e] & bm1) | (x2[e] & bm2) | (x3[e] & bm3);
+        accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, r), ones, accb, 0, 0, 0);
       }
-      if (!(FO_ABLATE_W & 20)) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { la[i] = w9_tr<0>(fA[i] + sl); ha[i] = w9_tr<4 * 256>(fA[i] + sl); }
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          const unsigned b0a = fB[k][0] + sl, b1a = fB[k][1] + sl;
-          lb[k] = w9_tr<W9_A>(b0a); hb[k] = w9_tr<W9_A>(b1a);
-          lb[3 + k] = w9_tr<W9_A + W9_BROW>(b0a); hb[3 + k] = w9_tr<W9_A + W9_BROW>(b1a);
-          lb[6 + k] = w9_tr<W9_A + 2 * W9_BROW>(b0a); hb[6 + k] = w9_tr<W9_A + 2 * W9_BROW>(b1a);
-        }
-      }
-      sl = sl + W9_SLOT == W9_NSLOT * W9_SLOT ? 0u : sl + W9_SLOT;
-      dma_tile();                                                    // G0: tile p + W9_AHEAD, G1: one more
-      if (g1) w9_wait_vmcnt<W9_AHEAD * W9_NP>();
-      __builtin_amdgcn_sched_barrier(0);
+      mfma_row(fa[par], fb[0], I0{}, [&](int j) {
+        if (j < 6) { if (j & 1) w9_tr<W9_A + 2 * W9_BROW>(fb[2][j >> 1].hi, bq[j >> 1][1]); else w9_tr<W9_A + 2 * W9_BROW>(fb[2][j >> 1].lo, bq[j >> 1][0]); }
+        if (j == 6) sl = sl + W9_SLOT == W9_NSLOT * W9_SLOT ? 0u : sl + W9_SLOT;
+        if (j >= 7 && j < 10) { bq[j - 7][0] = fB[j - 7][0] + sl; bq[j - 7][1] = fB[j - 7][1] + sl; }
+        if (j == 10) { aq[0] = fA[0] + sl; aq[1] = fA[1] + sl; }
+        if (j == 11) { aq[2] = fA[2] + sl; aq[3] = fA[3] + sl; }
+      });
+      w9_wait_vmcnt<(W9_AHEAD - 2) * W9_NP>();                        // this wave's pieces of the next tile (tiles p + 2 .. may fly)
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
-      if (!(FO_ABLATE_W & 4)) {
-        w9_wait_frags();                                             // (issued a segment ago, beside the other group's MFMAs)
-        __builtin_amdgcn_sched_barrier(0);
-        bf16x8 fa[4], fb[9];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) fa[i] = bf16x8{la[i][0], la[i][1], la[i][2], la[i][3], ha[i][0], ha[i][1], ha[i][2], ha[i][3]};
-#pragma unroll
-        for (int t = 0; t < 9; ++t) fb[t] = bf16x8{lb[t][0], lb[t][1], lb[t][2], lb[t][3], hb[t][0], hb[t][1], hb[t][2], hb[t][3]};
-        if (a.inrelu) {
-#pragma unroll
-          for (int t = 0; t < 9; ++t) {
-            u32x4 v = __builtin_bit_cast(u32x4, fb[t]);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = relu_pk(v[e]);
-            fb[t] = __builtin_bit_cast(bf16x8, v);
-          }
-        }
-        __builtin_amdgcn_s_setprio(1);
-        if (bias_wg) {                                                // column sums of P: tile wb of the wave's four (a scalar select, not an indexed register)
-          const bf16x8 fs = wb == 0 ? fa[0] : (wb == 1 ? fa[1] : (wb == 2 ? fa[2] : fa[3]));
-          accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fs, ones, accb, 0, 0, 0);
-        }
-#pragma unroll
-        for (int t = 0; t < ((FO_ABLATE_W & 32) ? 1 : 9); ++t)
-#pragma unroll
-          for (int i = 0; i < ((FO_ABLATE_W & 32) ? 1 : 4); ++i) acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[t], acc[t][i], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-      }
-      if (!g1) w9_wait_vmcnt<(W9_AHEAD - 1) * W9_NP>();
+      w9_wait_b<6>(fb[1]);                                             // row 1 (requested two rows ago; row 2's six may fly)
       __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
+      mfma_row(fa[par], fb[1], I1{}, [&](int j) {
+        if (j < 6) { if (j & 1) w9_tr<W9_A>(fb[0][j >> 1].hi, bq[j >> 1][1]); else w9_tr<W9_A>(fb[0][j >> 1].lo, bq[j >> 1][0]); }
+        if (j >= 6 && j < 10) { w9_tr<0>(fa[par ^ 1][j - 6].lo, aq[j - 6]); w9_tr<4 * 256>(fa[par ^ 1][j - 6].hi, aq[j - 6]); }
+        if (j == 10) dma_p();
+      });
+      w9_wait_b<14>(fb[2]);                                            // row 2 (the next tile's row 0 and P may fly)
       __builtin_amdgcn_sched_barrier(0);
+      mfma_row(fa[par], fb[2], I2{}, [&](int j) {
+        if (j < 6) { if (j & 1) w9_tr<W9_A + W9_BROW>(fb[1][j >> 1].hi, bq[j >> 1][1]); else w9_tr<W9_A + W9_BROW>(fb[1][j >> 1].lo, bq[j >> 1][0]); }
+        if (j == 6) dma_q0();
+        if (j == 8) dma_q1();
+        if (j == 10) dma_next();
+      });
+      w9_wait_a_b<6>(fa[par ^ 1], fb[0]);                              // the next step's P and row 0 (its row 1 may fly)
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    for (int p = 0; p < ntP; p += 2) {
+      kstep(I0{});
+      if (p + 1 >= ntP) break;
+      kstep(I1{});
     }
-    if (!g1) __builtin_amdgcn_s_barrier();                            // G0 waits out G1's last segment
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the zero-fill DMAs of the tiles past the end
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       // the zero-fill DMAs of the tiles past the end, the reads requested for a step that does not exist
   }
 
   // ---- partial blocks -> ws[slab][tap][a][b]: accumulator register r of lane l = (a = 4 (l >> 4) + r, b = l & 15)
@@ -834,9 +932,11 @@ int launch_w(const WArgs& a, int grid, hipStream_t s) {       // 1 = launched, -
 
 int launch_w9(const WArgs& a, int grid, hipStream_t s) {
   static fo_lds_once once;
-  if (!fo_lds_optin(once, reinterpret_cast<const void*>(wgrad9_bf16_kernel), W9_LDS, "wgrad9_bf16")) return -1;
-  FO_NOTE("wgrad9_bf16_kernel");
-  hipLaunchKernelGGL(wgrad9_bf16_kernel, dim3(grid), dim3(512), W9_LDS, s, a);
+  static fo_lds_once once_relu;
+  void (*kern)(const WArgs) = a.inrelu ? wgrad9_bf16_kernel<true> : wgrad9_bf16_kernel<false>;
+  if (!fo_lds_optin(a.inrelu ? once_relu : once, reinterpret_cast<const void*>(kern), W9_LDS, "wgrad9_bf16")) return -1;
+  if (a.inrelu) FO_NOTE_T("wgrad9_bf16_kernel", true); else FO_NOTE_T("wgrad9_bf16_kernel", false);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), W9_LDS, s, a);
   return 1;
 }
 
