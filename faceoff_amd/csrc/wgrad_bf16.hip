@@ -59,7 +59,12 @@ struct WArgs {
   short mOf[32];
 };
 
-__device__ __forceinline__ unsigned relu_pk(unsigned w) { return w & ~(((w & 0x80008000u) >> 15) * 0xffffu); }
+// relu() of two packed bf16: as 16-bit integers the negative patterns are exactly those with the sign bit, so it is one v_pk_max_i16 against 0
+// (the same bits as `w & ~(((w & 0x80008000u) >> 15) * 0xffffu)`, four instructions)
+__device__ __forceinline__ unsigned relu_pk(unsigned w) {
+  typedef short s16x2 __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, w), s16x2{0, 0}));
+}
 
 constexpr unsigned WOOB = 0x80000000u;
 __device__ __forceinline__ u32x4 wbufload16(__amdgpu_buffer_rsrc_t r, unsigned off) { return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0); }
@@ -399,7 +404,9 @@ __device__ __forceinline__ void w9_dma16(__amdgpu_buffer_rsrc_t r, w9_lds_byte* 
 template <int N> __device__ __forceinline__ void w9_wait_vmcnt();
 template <> __device__ __forceinline__ void w9_wait_vmcnt<0>() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 template <> __device__ __forceinline__ void w9_wait_vmcnt<3>() { asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
+template <> __device__ __forceinline__ void w9_wait_vmcnt<4>() { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
 template <> __device__ __forceinline__ void w9_wait_vmcnt<6>() { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+template <> __device__ __forceinline__ void w9_wait_vmcnt<8>() { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
 template <> __device__ __forceinline__ void w9_wait_vmcnt<9>() { asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); }
 template <> __device__ __forceinline__ void w9_wait_vmcnt<12>() { asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); }
 // The transposing read as inline assembly: behind the builtin (no memory operand the waitcnt pass could tell from the DMAs' LDS writes) hipcc puts
@@ -419,29 +426,46 @@ struct W9Frag { bf16x4 lo, hi; };                 // rows k .. k+3 and k+4 .. k+
 template <int N> __device__ __forceinline__ void w9_wait_a_b(W9Frag (&fa)[4], W9Frag (&fb)[3]) {
   asm volatile("s_waitcnt lgkmcnt(%14)" : W9_TIE(fa[0]), W9_TIE(fa[1]), W9_TIE(fa[2]), W9_TIE(fa[3]), W9_TIE(fb[0]), W9_TIE(fb[1]), W9_TIE(fb[2]) : "n"(N) : "memory");
 }
+template <int N> __device__ __forceinline__ void w9_wait_a_b(W9Frag (&fa)[2], W9Frag (&fb)[3]) {
+  asm volatile("s_waitcnt lgkmcnt(%10)" : W9_TIE(fa[0]), W9_TIE(fa[1]), W9_TIE(fb[0]), W9_TIE(fb[1]), W9_TIE(fb[2]) : "n"(N) : "memory");
+}
 template <int N> __device__ __forceinline__ void w9_wait_b(W9Frag (&fb)[3]) {
   asm volatile("s_waitcnt lgkmcnt(%6)" : W9_TIE(fb[0]), W9_TIE(fb[1]), W9_TIE(fb[2]) : "n"(N) : "memory");
 }
 __device__ __forceinline__ bf16x8 w9_join(const W9Frag& f) { return bf16x8{f.lo[0], f.lo[1], f.lo[2], f.lo[3], f.hi[0], f.hi[1], f.hi[2], f.hi[3]}; }
-constexpr int W9_A = 32 * 256;                    // P tile: 32 positions x 128 channels
-constexpr int W9_BROW = 40 * 128;                 // one row of Q: 34 pixels (40 staged: five 1-KB pieces) x 64 channels
-constexpr int W9_SLOT = W9_A + 3 * W9_BROW;       // 23 552 bytes
-#ifndef W9_CLUSTER
-#define W9_CLUSTER 1                              // (experiment: where a row's side work goes: 0 one piece behind each MFMA, 1 all in front of the row, 2 all behind it, 3 behind each four)
-#endif
 #ifndef W9_NSLOT
 #define W9_NSLOT 4                                // ring slots; tiles are requested W9_NSLOT - 1 K-steps ahead
 #endif
 constexpr int W9_AHEAD = W9_NSLOT - 1;
-constexpr int W9_LDS = W9_NSLOT * W9_SLOT + 1024; // + the KB the odd sixteenth piece of Q (there are fifteen) is written to
-constexpr int W9_NP = 3;                          // DMAs per wave and tile: one piece of P, two of Q
+// Block shapes: 128 x 64 (the 128 -> 128 / 64 -> 128 layers: 8 waves as 2 x 4, a wave holds 64 x 16 x nine taps) and 32 x 128 (the ResBlocks'
+// 3x3 128 -> 32: 1 x 8 waves, 32 x 16 x nine taps).  Geometry of a ring slot, in 1-KB DMA pieces (64 lanes x 16 bytes, lane-linear):
+template <int TA, int TB> struct W9Geo {
+  static constexpr int RA = TA * 2, RB = TB * 2;                     // bytes per row of the P tile / of a row tile of Q
+  static constexpr int A_BYTES = 32 * RA, BROW = 40 * RB;            // 32 positions of P; 34 pixels of Q (40 staged)
+  static constexpr int SLOT = A_BYTES + 3 * BROW;
+  static constexpr int PA = A_BYTES / 1024, PQ = BROW / 1024;        // pieces of P, pieces per row tile of Q
+  static constexpr int NPIECE = PA + 3 * PQ;
+  static constexpr int NP = (NPIECE + 7) / 8;                        // DMAs per wave and tile (pieces wave, wave + 8, ..; past NPIECE: zeros to the spare KB)
+  static constexpr int LDS = W9_NSLOT * SLOT + 1024;
+  static constexpr int WA = TA >= 128 ? 2 : 1, WB = 8 / WA;          // waves along P's / Q's channels
+  static constexpr int MA = TA / WA / 16;                            // 16-channel tiles of P per wave (Q: one)
+  static_assert(TB / WB == 16 && (TA == 128 || TA == 32) && (TB == 64 || TB == 128), "wave tiling");
+};
+// chunk swizzle of a row of RBYTES bytes (see the header): the 16-byte chunk at position c of row r holds chunk c ^ swz(r)
+template <int RBYTES> __device__ __forceinline__ int w9_swz(int r) {
+  if constexpr (RBYTES == 256) return (4 * (r & 3)) ^ (2 * ((r >> 3) & 1));
+  else if constexpr (RBYTES == 128) return 2 * ((r >> 1) & 1) + 4 * ((r >> 3) & 1);
+  else return 2 * ((r >> 3) & 1);                                    // 64-byte rows: four rows fill the 64 banks, rows + 8 take the other 32-byte half
+}
 
-template <bool RELU>                                 // RELU: Q is the INPUT of a ReLU -> conv pair (the fragments of Q are clamped as they are used)
+template <int TA, int TB, bool RELU>                  // RELU: Q is the INPUT of a ReLU -> conv pair (the fragments of Q are clamped as they are used)
 __global__ __launch_bounds__(512, 2) void wgrad9_bf16_kernel(const WArgs a) {
+  using G = W9Geo<TA, TB>;
+  constexpr int NP = G::NP, MA = G::MA, SLOT = G::SLOT;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const fo_conv_desc& d = a.d;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wa = wave >> 2, wb = wave & 3;                           // wave tile: channels 64 wa .. of P x channels 16 wb .. of Q, nine taps
+  const int wa = wave / G::WB, wb = wave % G::WB;                    // wave tile: channels 16 MA wa .. of P x channels 16 wb .. of Q, nine taps
   const int l15 = lane & 15, kg = lane >> 4;
 
   // ---- this workgroup: tile (a, b), depth plane, slab (as the row-run form)
@@ -458,37 +482,41 @@ __global__ __launch_bounds__(512, 2) void wgrad9_bf16_kernel(const WArgs a) {
   const int vunits = Tv > 0 ? (d.N / d.T) * Tv * d.Hm * a.runsPerRow : 0;
   const int u0 = (int)((long long)vunits * slab / nslab), u1 = (int)((long long)vunits * (slab + 1) / nslab);
   const int nt = u1 - u0;
-  const int a0 = ta * 128, b0 = tb * 64;
+  const int a0 = ta * TA, b0 = tb * TB;
   const bool bias_wg = tb == 0 && kd == a.biasTapRow;
 
-  // ---- DMA roles.  P: piece `wave` = rows 4 wave .. + 3, lane -> (row, LDS chunk position); the chunk it FETCHES is position ^ swizzle(row)
-  // (offsets of masked lanes are 0 and their kill word is WOOB: `(base + offset) | kill` is branch-free and lands at or above 2^31, out of range)
-  unsigned offA, killA;
-  {
-    const int row = 4 * wave + (lane >> 4), pc = lane & 15;
-    const int c = pc ^ ((4 * (row & 3)) ^ (2 * ((row >> 3) & 1)));
-    const bool ok = a0 + 8 * c < d.Cout;
-    offA = ok ? (unsigned)((row * d.ldOut + a0 + 8 * c) * 2) : 0u;
-    killA = ok ? 0u : WOOB;
-  }
-  // Q: pieces `wave` and `wave + 8` of fifteen (piece p = row tile p / 5, rows 8 (p % 5) .. + 7 of its forty; the sixteenth goes to the spare KB as zeros)
-  unsigned offB[2], killB[2], left[2], right[2];                     // left / right: WOOB on the lane that holds the pixel left of / right of the run
+  // ---- DMA roles: pieces wave, wave + 8, .. of the slot's NPIECE (P's first, then the three row tiles of Q).  A lane of a piece = (row, LDS chunk
+  // position); the chunk it FETCHES is position ^ swizzle(row).  Offsets of masked lanes are 0 and their kill word is WOOB: `(base + offset) | kill`
+  // is branch-free and lands at or above 2^31, out of range.  left / right: WOOB on the lane that holds the pixel left of / right of the run.
+  unsigned off[NP], kill[NP], left[NP], right[NP];
+  int khOf[NP], dst[NP];                                             // row tile of a Q piece (-1: a piece of P, 3: the spare), byte offset inside the slot
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
+  for (int j = 0; j < NP; ++j) {
     const int pce = wave + 8 * j;
-    const int row = 8 * (pce % 5) + (lane >> 3), pc = lane & 7;
-    const int c = pc ^ (2 * ((row >> 1) & 1) + 4 * ((row >> 3) & 1));
-    const bool ok = pce < 15 && row < 34 && b0 + 8 * c < d.Cin;
-    offB[j] = ok ? (unsigned)((row * d.ldIn + b0 + 8 * c) * 2) : 0u;
-    killB[j] = ok ? 0u : WOOB;
-    left[j] = row == 0 ? WOOB : 0u;
-    right[j] = row == 33 ? WOOB : 0u;
+    left[j] = right[j] = 0u;
+    if (pce < G::PA) {
+      constexpr int CPR = G::RA / 16, RPP = 64 / CPR;                // chunks per row, rows per piece
+      const int row = RPP * pce + lane / CPR, pc = lane % CPR;
+      const int c = pc ^ w9_swz<G::RA>(row);
+      const bool ok = a0 + 8 * c < d.Cout;
+      off[j] = ok ? (unsigned)((row * d.ldOut + a0 + 8 * c) * 2) : 0u;
+      kill[j] = ok ? 0u : WOOB;
+      khOf[j] = -1;
+      dst[j] = pce * 1024;
+    } else {
+      constexpr int CPR = G::RB / 16, RPP = 64 / CPR;
+      const int pq = pce - G::PA, kh = pq / G::PQ, part = pq % G::PQ;
+      const int row = RPP * part + lane / CPR, pc = lane % CPR;
+      const int c = pc ^ w9_swz<G::RB>(row);
+      const bool ok = pce < G::NPIECE && row < 34 && b0 + 8 * c < d.Cin;
+      off[j] = ok ? (unsigned)((row * d.ldIn + b0 + 8 * c) * 2) : 0u;
+      kill[j] = ok ? 0u : WOOB;
+      left[j] = row == 0 ? WOOB : 0u;
+      right[j] = row == 33 ? WOOB : 0u;
+      khOf[j] = kh;
+      dst[j] = pce < G::NPIECE ? G::A_BYTES + kh * G::BROW + part * 1024 : -1;
+    }
   }
-  const int khB0 = wave / 5, khB1 = (wave + 8) / 5;                    // the row tile (kh) of either piece; (wave + 8) / 5 == 3: the spare
-  const int dstA = wave * 1024;
-  const int dstB0 = W9_A + khB0 * W9_BROW + (wave % 5) * 1024;
-  const int dstB1 = (wave + 8 < 15) ? W9_A + khB1 * W9_BROW + ((wave + 8) % 5) * 1024 : -1;
-  const unsigned khOff0 = (unsigned)(khB0 * d.Win * d.ldIn * 2), khOff1 = (unsigned)(khB1 * d.Win * d.ldIn * 2);
   const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.P), 0, a.Pbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rQ = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.Q), 0, a.Qbytes, 0x00020000);
   w9_lds_byte* const lds3 = (w9_lds_byte*)lds;
@@ -510,61 +538,78 @@ __global__ __launch_bounds__(512, 2) void wgrad9_bf16_kernel(const WArgs a) {
   const unsigned jumpP = w9_pin((unsigned)((d.T - Tv) * d.Hm * d.Wm * d.ldOut * 2)), jumpQ = w9_pin((unsigned)((d.T - Tv) * d.Hin * d.Win * d.ldIn * 2));
   const int runs = w9_pin(a.runsPerRow), Hm = w9_pin(d.Hm), TvP = w9_pin(Tv), ntP = nt;       // (the operands of the cursor's rarely taken branches)
   const int lastRun = runs - 1, lastY = Hm - 1;
-  const unsigned kOff0 = khOff0, kOff1 = khOff1;
-  // one tile request = three DMAs + the cursor's advance, as four pieces the loop drops between MFMAs (dma_tile(): all four)
+  const unsigned rowBytesQ = (unsigned)(d.Win * d.ldIn * 2);
   w9_lds_byte* slotq = lds3;                                         // the slot of tile q
-  auto dma_p = [&]() {
+  auto dma_piece = [&](auto J) {                                      // one of the NP DMAs of a tile request
+    constexpr int j = decltype(J)::value;
     const bool live = q < ntP && !(FO_ABLATE_W & 1);
-    w9_dma16(rP, slotq + dstA, ((live ? pOff : WOOB) + offA) | killA);
-  };
-  auto dma_q0 = [&]() {                                               // rows of Q: kh = 0 needs y > 0, kh = 2 needs y < H - 1
-    const bool live = q < ntP && !(FO_ABLATE_W & 1);
-    const bool rowok = live && (khB0 == 0 ? c_y > 0 : (khB0 == 2 ? c_y < lastY : true));
-    const unsigned edge = killB[0] | (left[0] & (c_run == 0 ? WOOB : 0u)) | (right[0] & (c_run == lastRun ? WOOB : 0u));
-    w9_dma16(rQ, slotq + dstB0, ((rowok ? qOff + kOff0 : WOOB) + offB[0]) | edge);
-  };
-  auto dma_q1 = [&]() {                                               // (khB1 is 1, 2 or 3 -- 3: the spare piece, killed anyway)
-    const bool live = q < ntP && !(FO_ABLATE_W & 1);
-    const bool rowok = live && (khB1 == 2 ? c_y < lastY : true);
-    const unsigned edge = killB[1] | (left[1] & (c_run == 0 ? WOOB : 0u)) | (right[1] & (c_run == lastRun ? WOOB : 0u));
-    w9_dma16(rQ, dstB1 >= 0 ? slotq + dstB1 : lds3 + W9_NSLOT * W9_SLOT, ((rowok ? qOff + kOff1 : WOOB) + offB[1]) | edge);
+    if (khOf[j] < 0) {
+      w9_dma16(rP, slotq + dst[j], ((live ? pOff : WOOB) + off[j]) | kill[j]);
+    } else {                                                          // rows of Q: kh = 0 needs y > 0, kh = 2 needs y < H - 1 (kh = 3: the spare piece, killed anyway)
+      const bool rowok = live && (khOf[j] == 0 ? c_y > 0 : (khOf[j] == 2 ? c_y < lastY : true));
+      const unsigned edge = kill[j] | (left[j] & (c_run == 0 ? WOOB : 0u)) | (right[j] & (c_run == lastRun ? WOOB : 0u));
+      w9_dma16(rQ, dst[j] >= 0 ? slotq + dst[j] : lds3 + W9_NSLOT * SLOT, ((rowok ? qOff + (unsigned)khOf[j] * rowBytesQ : WOOB) + off[j]) | edge);
+    }
   };
   auto dma_next = [&]() {
     pOff += stepP; qOff += stepQ;
     if (++c_run == runs) { c_run = 0; if (++c_y == Hm) { c_y = 0; if (++c_t == TvP) { c_t = 0; pOff += jumpP; qOff += jumpQ; } } }
     ++q;
     qslot = qslot + 1 == W9_NSLOT ? 0 : qslot + 1;
-    slotq = lds3 + qslot * W9_SLOT;
+    slotq = lds3 + qslot * SLOT;
   };
-  auto dma_tile = [&]() { dma_p(); dma_q0(); dma_q1(); dma_next(); };
+  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+  using I3 = std::integral_constant<int, 3>;
+  auto dma_tile = [&]() {
+    dma_piece(I0{}); dma_piece(I1{}); dma_piece(I2{});
+    if constexpr (NP == 4) dma_piece(I3{});
+    dma_next();
+  };
 
-  f32x4 acc[9][4], accb = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 acc[9][MA], accb = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < MA; ++i) acc[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
   const bf16x8 ones = {(__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f};
 
   // ---- fragment addressing (see the header: same lane -> (row, 4 channels) map as the row-run form, swizzled instead of padded): LDS byte
-  // addresses inside slot 0; rows k and k + 4 of P share (r & 3) and (r >> 3) & 1, so the upper half of a fragment is + 4 rows
+  // addresses inside slot 0; rows k and k + 4 of P share the swizzle (same r & 3 and (r >> 3) & 1), so the upper half of a fragment is + 4 rows
   const unsigned ldsbase = (unsigned)(size_t)lds3;
   const int krow = kg * 8 + (l15 >> 2);
-  const int xa = (64 * (l15 >> 2)) ^ (32 * (kg & 1));
-  unsigned fA[4], fB[3][2];
+  unsigned fA[MA], fB[3][2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) fA[i] = ldsbase + krow * 256 + (l15 & 3) * 8 + ((128 * wa + 32 * i) ^ xa);
+  for (int i = 0; i < MA; ++i) fA[i] = ldsbase + krow * G::RA + (((wa * MA + i) * 32) ^ (16 * w9_swz<G::RA>(krow))) + (l15 & 3) * 8;
 #pragma unroll
   for (int k = 0; k < 3; ++k)                                         // tap kw, half h: row r = krow + 4 h + kw of the 34
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int r = krow + 4 * h + k;
-      fB[k][h] = ldsbase + r * 128 + ((32 * wb) ^ (32 * (((r >> 1) & 1) + 2 * ((r >> 3) & 1)))) + (l15 & 3) * 8;
+      fB[k][h] = ldsbase + r * G::RB + ((32 * wb) ^ (16 * w9_swz<G::RB>(r))) + (l15 & 3) * 8;
     }
+  unsigned bm[MA];                                                    // bias: tile wb of the wave's MA (waves wb < MA)
+#pragma unroll
+  for (int i = 0; i < MA; ++i) bm[i] = wb == i ? ~0u : 0u;
 
-  const unsigned bm0 = wb == 0 ? ~0u : 0u, bm1 = wb == 1 ? ~0u : 0u, bm2 = wb == 2 ? ~0u : 0u, bm3 = wb == 3 ? ~0u : 0u;      // bias: tile wb of the wave's four
-  W9Frag fa[2][4], fb[3][3];                                          // two sets of P's fragments (even / odd K-steps), one per row of Q's taps
-  unsigned bq[3][2], aq[4];                                           // fB, fA + a tile's slot
-  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+  W9Frag fa[2][MA], fb[3][3];                                         // two sets of P's fragments (even / odd K-steps), one per row of Q's taps
+  unsigned bq[3][2], aq[MA];                                          // fB, fA + a tile's slot
+  auto read_a = [&](W9Frag (&f)[MA], const unsigned (&ad)[MA]) {      // 2 MA reads
+#pragma unroll
+    for (int i = 0; i < MA; ++i) { w9_tr<0>(f[i].lo, ad[i]); w9_tr<4 * G::RA>(f[i].hi, ad[i]); }
+  };
+  auto read_b = [&](W9Frag (&f)[3], auto KH) {                        // 6 reads: the three kw fragments of row kh of the tile bq points into
+    constexpr int kh = decltype(KH)::value;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { w9_tr<G::A_BYTES + kh * G::BROW>(f[k].lo, bq[k][0]); w9_tr<G::A_BYTES + kh * G::BROW>(f[k].hi, bq[k][1]); }
+  };
+  auto set_aq = [&](unsigned sl) {
+#pragma unroll
+    for (int i = 0; i < MA; ++i) aq[i] = fA[i] + sl;
+  };
+  auto set_bq = [&](unsigned sl) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { bq[k][0] = fB[k][0] + sl; bq[k][1] = fB[k][1] + sl; }
+  };
   auto join_b = [&](const W9Frag& f) {
     bf16x8 v = w9_join(f);
     if (RELU) {
@@ -575,112 +620,76 @@ __global__ __launch_bounds__(512, 2) void wgrad9_bf16_kernel(const WArgs a) {
     }
     return v;
   };
-  // the 12 MFMAs of one row of taps, work(j) dropped behind MFMA j: every MFMA is 16 cycles of matrix pipe in which the wave issues a few
-  // reads / address instructions / a DMA -- the order is pinned (sched_barrier), nothing is left to pile up in front of or behind a row
-  auto mfma_row = [&](const W9Frag (&A)[4], const W9Frag (&B)[3], auto KH, auto&& work) {
+  // the 3 MA MFMAs of one row of taps, back to back (the side work of a row -- reads, addresses, the request -- is issued in front of it: dropped
+  // between the MFMAs one piece at a time it measured 5 % slower, behind the row 5 % slower still)
+  auto mfma_row = [&](const W9Frag (&A)[MA], const W9Frag (&B)[3], auto KH) {
     constexpr int kh = decltype(KH)::value;
-    if (FO_ABLATE_W & 4) {
+    if (FO_ABLATE_W & 4) return;
+    bf16x8 va[MA], vb[3];
 #pragma unroll
-      for (int j = 0; j < 12; ++j) work(j);
-      return;
-    }
-    bf16x8 va[4], vb[3];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) va[i] = w9_join(A[i]);
+    for (int i = 0; i < MA; ++i) va[i] = w9_join(A[i]);
 #pragma unroll
     for (int k = 0; k < 3; ++k) vb[k] = join_b(B[k]);
-    __builtin_amdgcn_sched_barrier(0);
-#if W9_CLUSTER == 1
-#pragma unroll
-    for (int j = 0; j < 12; ++j) work(j);
-    __builtin_amdgcn_sched_barrier(0);
-#endif
 #pragma unroll
     for (int k = 0; k < 3; ++k)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        acc[kh * 3 + k][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va[i], vb[k], acc[kh * 3 + k][i], 0, 0, 0);
-#if W9_CLUSTER == 0
-        __builtin_amdgcn_sched_barrier(0);
-        work(k * 4 + i);
-        __builtin_amdgcn_sched_barrier(0);
-#elif W9_CLUSTER == 3
-        if (i == 3) {
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) work(k * 4 + j);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-#endif
-      }
-#if W9_CLUSTER == 2
+      for (int i = 0; i < MA; ++i) acc[kh * 3 + k][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va[i], vb[k], acc[kh * 3 + k][i], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int j = 0; j < 12; ++j) work(j);
-    __builtin_amdgcn_sched_barrier(0);
-#endif
   };
 
   if (nt > 0) {
 #pragma unroll
     for (int i = 0; i < W9_AHEAD; ++i) dma_tile();
-    w9_wait_vmcnt<(W9_AHEAD - 1) * W9_NP>();                          // this wave's pieces of tile 0
+    w9_wait_vmcnt<(W9_AHEAD - 1) * NP>();                             // this wave's pieces of tile 0
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     unsigned sl = 0;                                                  // byte offset of the current tile's slot
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { bq[k][0] = fB[k][0]; bq[k][1] = fB[k][1]; }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { w9_tr<0>(fa[0][i].lo, fA[i]); w9_tr<4 * 256>(fa[0][i].hi, fA[i]); }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { w9_tr<W9_A>(fb[0][k].lo, bq[k][0]); w9_tr<W9_A>(fb[0][k].hi, bq[k][1]); }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { w9_tr<W9_A + W9_BROW>(fb[1][k].lo, bq[k][0]); w9_tr<W9_A + W9_BROW>(fb[1][k].hi, bq[k][1]); }
+    set_bq(0); set_aq(0);
+    read_a(fa[0], aq);
+    read_b(fb[0], I0{});
+    read_b(fb[1], I1{});
     w9_wait_a_b<6>(fa[0], fb[0]);
     __builtin_amdgcn_sched_barrier(0);
-    // One K-step, PAR = its parity.  Row kh of Q lives in fb[kh], P in fa[PAR]; every fragment is requested TWO rows (24 MFMAs) before the row that uses it:
+    // One K-step, PAR = its parity.  Row kh of Q lives in fb[kh], P in fa[PAR]; every fragment is requested about two rows before the row that uses it:
     //   on entry   P and row 0 have landed, row 1 is in flight
-    //   row 0      the six reads of row 2 (fb[2]: the previous step's row 2 has issued); the next slot's addresses; then this wave's pieces of the next tile
-    //              are awaited and the barrier taken (everybody's pieces have landed; everybody has finished with the tile before this one, whose slot the
-    //              next request overwrites)
-    //   row 1      the next tile's row 0 -> fb[0] and its eight of P -> fa[PAR ^ 1]
-    //   row 2      the next tile's row 1 -> fb[1]; the request of tile p + W9_AHEAD
+    //   row 0      in front of it: the six reads of row 2 (fb[2]: the previous step's row 2 has issued), the next slot's addresses.  Behind it this wave's
+    //              pieces of the next tile are awaited and the barrier taken (everybody's pieces have landed; everybody has finished with the tile
+    //              before this one, whose slot the next request overwrites)
+    //   row 1      in front of it (once row 1 itself has landed): the next tile's row 0 -> fb[0] and its fragments of P -> fa[PAR ^ 1]
+    //   row 2      in front of it (once row 2 has landed): the next tile's row 1 -> fb[1]; the request of tile p + W9_AHEAD
     auto kstep = [&](auto PAR) {
       constexpr int par = decltype(PAR)::value;
-      if (bias_wg && !(FO_ABLATE_W & 4)) {                            // column sums of P: tile wb of the wave's four
-        const u32x4 x0 = __builtin_bit_cast(u32x4, w9_join(fa[par][0])), x1 = __builtin_bit_cast(u32x4, w9_join(fa[par][1]));
-        const u32x4 x2 = __builtin_bit_cast(u32x4, w9_join(fa[par][2])), x3 = __builtin_bit_cast(u32x4, w9_join(fa[par][3]));
-        u32x4 r;                                                      // (mask arithmetic: a select between the register sets -- ?: or branches -- hipcc turns into an indexed scratch array)
+      read_b(fb[2], I2{});
+      sl = sl + SLOT == W9_NSLOT * SLOT ? 0u : sl + SLOT;
+      set_bq(sl); set_aq(sl);
+      __builtin_amdgcn_sched_barrier(0);
+      if (bias_wg && !(FO_ABLATE_W & 4)) {                            // column sums of P (mask arithmetic: a select between the register sets -- ?: or
+        u32x4 r = {0u, 0u, 0u, 0u};                                   // branches -- hipcc turns into an indexed scratch array)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) r[e] = (x0[e] & bm0) | (x1[e] & bm1) | (x2[e] & bm2) | (x3[e] & bm3);
+        for (int i = 0; i < MA; ++i) {
+          const u32x4 x = __builtin_bit_cast(u32x4, w9_join(fa[par][i]));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) r[e] |= x[e] & bm[i];
+        }
         accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, r), ones, accb, 0, 0, 0);
       }
-      mfma_row(fa[par], fb[0], I0{}, [&](int j) {
-        if (j < 6) { if (j & 1) w9_tr<W9_A + 2 * W9_BROW>(fb[2][j >> 1].hi, bq[j >> 1][1]); else w9_tr<W9_A + 2 * W9_BROW>(fb[2][j >> 1].lo, bq[j >> 1][0]); }
-        if (j == 6) sl = sl + W9_SLOT == W9_NSLOT * W9_SLOT ? 0u : sl + W9_SLOT;
-        if (j >= 7 && j < 10) { bq[j - 7][0] = fB[j - 7][0] + sl; bq[j - 7][1] = fB[j - 7][1] + sl; }
-        if (j == 10) { aq[0] = fA[0] + sl; aq[1] = fA[1] + sl; }
-        if (j == 11) { aq[2] = fA[2] + sl; aq[3] = fA[3] + sl; }
-      });
-      w9_wait_vmcnt<(W9_AHEAD - 2) * W9_NP>();                        // this wave's pieces of the next tile (tiles p + 2 .. may fly)
+      mfma_row(fa[par], fb[0], I0{});
+      w9_wait_vmcnt<(W9_AHEAD - 2) * NP>();                           // this wave's pieces of the next tile (tiles p + 2 .. may fly)
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
-      w9_wait_b<6>(fb[1]);                                             // row 1 (requested two rows ago; row 2's six may fly)
+      w9_wait_b<6>(fb[1]);                                             // row 1 (requested two rows ago; row 2's six may fly) -- lgkmcnt is a 4-bit count:
+      __builtin_amdgcn_sched_barrier(0);                              // never more than 15 reads behind the one awaited
+      read_b(fb[0], I0{});                                            // (bq: the next tile's slot)
+      read_a(fa[par ^ 1], aq);
       __builtin_amdgcn_sched_barrier(0);
-      mfma_row(fa[par], fb[1], I1{}, [&](int j) {
-        if (j < 6) { if (j & 1) w9_tr<W9_A>(fb[0][j >> 1].hi, bq[j >> 1][1]); else w9_tr<W9_A>(fb[0][j >> 1].lo, bq[j >> 1][0]); }
-        if (j >= 6 && j < 10) { w9_tr<0>(fa[par ^ 1][j - 6].lo, aq[j - 6]); w9_tr<4 * 256>(fa[par ^ 1][j - 6].hi, aq[j - 6]); }
-        if (j == 10) dma_p();
-      });
-      w9_wait_b<14>(fb[2]);                                            // row 2 (the next tile's row 0 and P may fly)
+      mfma_row(fa[par], fb[1], I1{});
+      w9_wait_b<6 + 2 * MA>(fb[2]);                                    // row 2 (the next tile's row 0 and P may fly)
       __builtin_amdgcn_sched_barrier(0);
-      mfma_row(fa[par], fb[2], I2{}, [&](int j) {
-        if (j < 6) { if (j & 1) w9_tr<W9_A + W9_BROW>(fb[1][j >> 1].hi, bq[j >> 1][1]); else w9_tr<W9_A + W9_BROW>(fb[1][j >> 1].lo, bq[j >> 1][0]); }
-        if (j == 6) dma_q0();
-        if (j == 8) dma_q1();
-        if (j == 10) dma_next();
-      });
-      w9_wait_a_b<6>(fa[par ^ 1], fb[0]);                              // the next step's P and row 0 (its row 1 may fly)
+      read_b(fb[1], I1{});
+      dma_tile();                                                     // tile p + W9_AHEAD, into the slot of tile p - 1
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_row(fa[par], fb[2], I2{});
+      w9_wait_a_b<6>(fa[par ^ 1], fb[0]);                             // the next step's P and row 0 (its row 1 may fly)
       __builtin_amdgcn_sched_barrier(0);
     };
     for (int p = 0; p < ntP; p += 2) {
@@ -695,14 +704,14 @@ __global__ __launch_bounds__(512, 2) void wgrad9_bf16_kernel(const WArgs a) {
   if ((FO_ABLATE_W & 8) && acc[0][0][0] != 12345.f) return;
 #pragma unroll
   for (int t = 0; t < 9; ++t) {
-    float* o = a.ws + (((long long)slab * a.taps + kd * 9 + t) * a.Apad + a0 + wa * 64) * a.Bpad + b0 + wb * 16;
+    float* o = a.ws + (((long long)slab * a.taps + kd * 9 + t) * a.Apad + a0 + wa * MA * 16) * a.Bpad + b0 + wb * 16;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MA; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) o[(long long)(i * 16 + kg * 4 + r) * a.Bpad + l15] = acc[t][i][r];
   }
-  if (bias_wg && l15 == 0) {
-    float* ob = a.wsBias + (long long)slab * a.Apad + a0 + wa * 64 + wb * 16;
+  if (bias_wg && l15 == 0 && wb < MA) {
+    float* ob = a.wsBias + (long long)slab * a.Apad + a0 + wa * MA * 16 + wb * 16;
 #pragma unroll
     for (int r = 0; r < 4; ++r) ob[kg * 4 + r] = accb[r];
   }
@@ -852,13 +861,14 @@ int make_plan(const fo_conv_desc* d, WPlan* p) {
     // the centre tap's row reads a real pixel of Q for EVERY position of P: its workgroups see every row of P
     p->biasTapRow = p->fast ? d->padD * d->KH + d->padH : (d->padD * d->KH + d->padH) * d->KW + d->padW;
     // 3x3 (x KD) pad-1 stride-1 filters between >= 128 and >= 64 channels: all nine taps of a plane per workgroup (FACEOFF_WGRAD_ROWS=1: the row-run form)
-    p->all9 = p->fast && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->padH == 1 && d->padW == 1 && d->Hm == d->Hin && d->Wm == d->Win && A >= 128 &&
-              B >= 64 && d->padD < d->KD && getenv("FACEOFF_WGRAD_ROWS") == nullptr;
-    if (p->all9) { p->TA = 128; p->TB = 64; p->NKW = 9; p->tapRows = d->KD; p->biasTapRow = d->padD; }
+    const bool wide = A >= 128 && B >= 64, thin = A <= 32 && B >= 128 && getenv("FACEOFF_WGRAD_THIN_ROWS") == nullptr;   // 128 x 64 blocks; 32 x 128 (the ResBlocks' 128 -> 32)
+    p->all9 = p->fast && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->padH == 1 && d->padW == 1 && d->Hm == d->Hin && d->Wm == d->Win &&
+              (wide || thin) && d->padD < d->KD && getenv("FACEOFF_WGRAD_ROWS") == nullptr;
+    if (p->all9) { p->TA = wide ? 128 : 32; p->TB = wide ? 64 : 128; p->NKW = 9; p->tapRows = d->KD; p->biasTapRow = d->padD; }
   }
   if (p->smallc) p->all9 = false;
   // waves: WA x (8 / WA) with at least one 16 x 16 tile per wave in either direction
-  p->WA = (p->all9 || (p->TA == 128 && p->TB == 128)) ? 2 : (p->TA == 128 ? 4 : (p->TA == 64 ? (p->TB == 32 ? 4 : 2) : (p->TB == 128 ? 1 : 2)));
+  p->WA = p->all9 ? (p->TA == 128 ? 2 : 1) : (p->TA == 128 && p->TB == 128) ? 2 : (p->TA == 128 ? 4 : (p->TA == 64 ? (p->TB == 32 ? 4 : 2) : (p->TB == 128 ? 1 : 2)));
   const int perRun = p->NKW * (p->TA / p->WA / 16) * (p->TB / (8 / p->WA) / 16);      // MFMAs per wave and run
   p->KR = perRun <= 8 ? 2 : 1;                                       // thin blocks: two runs per barrier
   p->tilesA = (A + p->TA - 1) / p->TA;
@@ -884,7 +894,7 @@ int make_plan(const fo_conv_desc* d, WPlan* p) {
   const int tiles = p->tilesA * p->tilesB;
   // workgroups per CU: two for the thin blocks whose LDS fits twice (wgrad_thin; FACEOFF_WGRAD_ONE_PER_CU=1: round 4's one)
   {
-    const int lds = p->all9 ? W9_LDS : wgrad_lds_bytes_rt(p->TA, p->TB, p->NKW, p->KR, p->fast, p->smallc);
+    const int lds = p->all9 ? (p->TA == 128 ? W9Geo<128, 64>::LDS : W9Geo<32, 128>::LDS) : wgrad_lds_bytes_rt(p->TA, p->TB, p->NKW, p->KR, p->fast, p->smallc);
     const bool one = getenv("FACEOFF_WGRAD_ONE_PER_CU") != nullptr;        // (read per call, like the other A/B switches)
     // (measured, tools/bench_wgrad_bf16.py, same device: the ResBlocks' 3x3 128 -> 32 0.152 -> 0.114 ms, the image layers 0.182 -> 0.141; the 1x1
     // forms get nothing from it -- 0.050 -> 0.054 with twice the slabs to reduce -- and keep one)
@@ -930,14 +940,19 @@ int launch_w(const WArgs& a, int grid, hipStream_t s) {       // 1 = launched, -
   return 1;
 }
 
-int launch_w9(const WArgs& a, int grid, hipStream_t s) {
+template <int TA, int TB, bool RELU>
+int launch_w9_t(const WArgs& a, int grid, hipStream_t s) {
   static fo_lds_once once;
-  static fo_lds_once once_relu;
-  void (*kern)(const WArgs) = a.inrelu ? wgrad9_bf16_kernel<true> : wgrad9_bf16_kernel<false>;
-  if (!fo_lds_optin(a.inrelu ? once_relu : once, reinterpret_cast<const void*>(kern), W9_LDS, "wgrad9_bf16")) return -1;
-  if (a.inrelu) FO_NOTE_T("wgrad9_bf16_kernel", true); else FO_NOTE_T("wgrad9_bf16_kernel", false);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), W9_LDS, s, a);
+  void (*kern)(const WArgs) = wgrad9_bf16_kernel<TA, TB, RELU>;
+  constexpr int ldsBytes = W9Geo<TA, TB>::LDS;
+  if (!fo_lds_optin(once, reinterpret_cast<const void*>(kern), ldsBytes, "wgrad9_bf16")) return -1;
+  FO_NOTE_T("wgrad9_bf16_kernel", TA, TB, RELU);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), ldsBytes, s, a);
   return 1;
+}
+int launch_w9(const WPlan& p, const WArgs& a, int grid, hipStream_t s) {
+  if (p.TA == 128) return a.inrelu ? launch_w9_t<128, 64, true>(a, grid, s) : launch_w9_t<128, 64, false>(a, grid, s);
+  return a.inrelu ? launch_w9_t<32, 128, true>(a, grid, s) : launch_w9_t<32, 128, false>(a, grid, s);
 }
 
 // (block shape, taps per workgroup) -> instantiation; KR and WA follow from them (make_plan)
@@ -993,7 +1008,7 @@ extern "C" int fo_conv_wgrad_bf16(const fo_conv_desc* d, const void* P, const vo
   const int grid = p.tilesA * p.tilesB * p.X * p.wgPerX;
   hipStream_t s = (hipStream_t)stream;
   int ok;
-  if (p.all9) ok = launch_w9(a, grid, s);
+  if (p.all9) ok = launch_w9(p, a, grid, s);
   else if (p.smallc) ok = launch_w<64, 32, 4, 4, 2, true, true>(a, grid, s);
   else if (p.fast && p.NKW == 3) ok = dispatch<3, true>(p, a, grid, s);
   else if (p.fast && p.NKW == 4) ok = dispatch<4, true>(p, a, grid, s);

@@ -236,10 +236,14 @@ def test_wgrad_3x3_row_runs(ca, cb, in_relu):
     (128, 128, (3, 3, 3), 5, 10, 8, 32, False),      # Conv3d: three depth planes, the outer ones skip a frame of each clip
     (128, 64, (3, 3, 3), 1, 3, 4, 32, False),        # Conv3d on one-frame clips: the outer planes have no work at all
     (128, 128, (1, 3, 3), 1, 40, 32, 64, False),     # enough units for several K-steps per slab on every CU (ring wrap-around)
+    (32, 128, (1, 3, 3), 1, 3, 12, 64, True),        # the 32 x 128 block: the ResBlocks' 128 -> 32 with its input ReLU
+    (24, 256, (1, 3, 3), 1, 2, 5, 32, False),        # ... a channel tail in P's tile, two tiles of Q's channels
+    (32, 128, (3, 3, 3), 2, 4, 6, 32, True),         # ... as a Conv3d
+    (32, 128, (1, 3, 3), 1, 48, 32, 64, True),       # ... several K-steps per slab
 ])
 def test_wgrad_all_nine_taps_form(ca, cb, k, T, N, Hm, Wm, in_relu, monkeypatch):
-    """wgrad9_bf16_kernel (3x3 pad-1 stride-1 filters between >= 128 and >= 64 channels: a workgroup holds all nine taps of a depth plane, LDS-DMA staging,
-    swizzled tiles) against torch's fp32 filter gradient, and the row-run form it replaced (FACEOFF_WGRAD_ROWS=1) on the same operands: two summation orders
+    """wgrad9_bf16_kernel (3x3 pad-1 stride-1 filters between >= 128 and >= 64 channels, or <= 32 and >= 128: a workgroup holds all nine taps of a depth
+    plane, LDS-DMA staging, swizzled tiles) against torch's fp32 filter gradient, and the row-run form it replaced (FACEOFF_WGRAD_ROWS=1) on the same operands: two summation orders
     of the same products.  The library reports which kernel ran."""
     from faceoff_amd import _lib
     lib = _lib.load()
