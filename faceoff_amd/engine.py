@@ -366,6 +366,7 @@ class VQVAEEngine:
         self.vq_stream = None
         if self.device.type == "cuda" and not _os.environ.get("FACEOFF_NO_VQ_OVERLAP"):
             self.vq_stream = torch.cuda.Stream(device=self.device)
+        self._vq_done = None        # event behind the last codebook update on vq_stream (_quantize)
         self._streams = (self.wgrad_stream, self.aux_stream, self.pack_stream, self.vq_stream)
         self.tail_wgrads = int(_os.environ.get("FACEOFF_TAIL_WGRADS", "2"))     # how many of the last filter gradients run on the caller's stream (backward())
         self._pack_events = None
@@ -611,6 +612,9 @@ class VQVAEEngine:
                         self.vq_allreduce(st[1:])
                     ops.vq_ema(self.buffers[f"quantize_{lvl}.embed"], self.buffers[f"quantize_{lvl}.cluster_size"],
                                self.buffers[f"quantize_{lvl}.embed_avg"], st)
+                if self.vq_stream is not None:
+                    self._vq_done = torch.cuda.Event()
+                    self._vq_done.record(self.vq_stream)
             if join and self.vq_stream is not None:
                 torch.cuda.current_stream().wait_stream(self.vq_stream)
 
@@ -662,7 +666,13 @@ class VQVAEEngine:
         return S
 
     def _quantize(self, name, x, q_out, training, force_ind=None):
-        if self.vq_stream is not None:       # the previous step's codebook update (long finished; the join is what orders it)
+        # The previous step's codebook update: long finished, and every path that launches it joins the side stream before it returns (stage_quantize /
+        # forward) -- what is awaited here is the EVENT recorded behind that update, not the stream: wait_stream() would drop a fresh marker into
+        # vq_stream's hardware queue, which HIP shares with other streams (six streams, four queues by default), and the main stream then sat behind
+        # whatever the neighbour had queued: 0.86 ms of config 3's forward behind the bottom Conv3d chain (tools/stream_timeline.py, round 6).
+        if self.vq_stream is not None and self._vq_done is not None and not _os.environ.get("FACEOFF_VQ_WAIT_STREAM"):
+            torch.cuda.current_stream().wait_event(self._vq_done)
+        elif self.vq_stream is not None:
             torch.cuda.current_stream().wait_stream(self.vq_stream)
         embedT, enorm = ops.vq_prepare(self.buffers[name + ".embed"])
         stats = torch.zeros(1 + 512 + 512 * 64, device=self.device)
