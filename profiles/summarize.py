@@ -56,7 +56,7 @@ def label(name):
     """bench.py's per-kernel key for a rocprof kernel name: since round 4 that IS the short symbol (ops.KernelProfiler keys launches by what
     the library reports through fo_last_kernel, which is what rocprofv3 prints).  Small reduce / layout kernels are left out of the table."""
     n = short(name)
-    if re.search(r"(conv_|wgrad_|wino_gemm|wino_wgrad|resblock_|vq_assign|disc_head)", n) and "reduce" not in n and "pack" not in n:
+    if re.search(r"(conv_|wgrad\d*_|wino_gemm|wino_wgrad|resblock_|vq_assign|disc_head)", n) and "reduce" not in n and "pack" not in n:
         return n
     return None
 

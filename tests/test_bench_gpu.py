@@ -50,7 +50,7 @@ def test_bench_emits_one_valid_json_line():
     assert r3["peak"] == 2500.0 and r3["bound"] == "mfma" and 0 < r3["frac"] <= 1.0 and abs(r3["frac"] - r3["achieved"] / r3["peak"]) < 1e-3
     assert c3["vqvae_only_bf16"]["value"] > c3["value"] and c3["fp32_vqvae"]["value"] > 0
     assert 0 < c3["loss"]["perceptual"] and 0 < c3["loss"]["recon"] < 1
-    assert r3["kernel"].startswith(("conv_bf16_", "wgrad_bf16_kernel<", "conv_halo64_bf16")) and not any(k.startswith(("conv_bf16_bn", "conv_bf16_big")) for k in c3["kernels"])
+    assert r3["kernel"].startswith(("conv_bf16_", "wgrad_bf16_kernel<", "wgrad9_bf16_kernel<", "conv_halo64_bf16")) and not any(k.startswith(("conv_bf16_bn", "conv_bf16_big")) for k in c3["kernels"])
     # config 5: its own roofline / kernels block
     c5 = d["c5"]
     r5 = c5["roofline"]

@@ -13,7 +13,7 @@ for f in glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
 rows.sort()
 MATRIX = ("wino_gemm", "wino_wgrad_split", "conv_igemm", "conv_wgrad_kernel", "vq_assign", "conv_gen_kernel", "wgrad_gen_kernel", "conv_bf16", "conv_img_kernel",
-          "wgrad_img_kernel", "conv_rgb", "resblock_halo", "resblock_wgrad1", "conv3x3_c32", "conv3x3_c128", "conv_halo64", "wgrad_bf16_kernel")
+          "wgrad_img_kernel", "conv_rgb", "resblock_halo", "resblock_wgrad1", "conv3x3_c32", "conv3x3_c128", "conv_halo64", "wgrad_bf16_kernel", "wgrad9_bf16_kernel")
 # the last full step: find adam kernels
 adam = [i for i, r in enumerate(rows) if "adam_kernel" in r[2]]
 back = int(sys.argv[2]) if len(sys.argv) > 2 else 1            # window = the last `back` optimiser launches (GAN: 3 per G+D pair)
