@@ -2,15 +2,16 @@
 """Per-stream view of one OVERLAPPED step from a rocprofv3 --kernel-trace CSV: for the last full step (between the last two Adam launches) the busy time of
 every HIP stream / queue, when each goes quiet, the time nothing runs, and the kernels of the busiest stream in order with the gaps in front of them.
     rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tl -o tl -- python3 bench.py --perceptual --vqvae-dtype bf16 --steps 3 --warmup 2 \\
-        --no-cpu-baseline --no-kernel-events --no-c5 --no-h2d-leg ;  python tools/stream_timeline.py gpurun_out/tl [top]"""
+        --no-cpu-baseline --no-kernel-events --no-c5 --no-h2d-leg ;  python tools/stream_timeline.py gpurun_out/tl [top [optimiser launches in the window]]"""
 import csv, glob, re, sys, collections
 rows = []
 for f in glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Stream_Id") or r.get("Queue_Id")))
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], f"{r.get('Stream_Id')} (queue {r.get('Queue_Id')})"))
 rows.sort()
 adam = [i for i, r in enumerate(rows) if "adam_kernel" in r[2]]
-lo, hi = rows[adam[-2]][1], rows[adam[-1]][1]
+back = int(sys.argv[3]) if len(sys.argv) > 3 else 1                 # window = the last `back` optimiser launches (GAN: 3 per generator + discriminator pair)
+lo, hi = rows[adam[-1 - back]][1], rows[adam[-1]][1]
 step = [(max(s, lo), min(e, hi), n, q) for s, e, n, q in rows if e > lo and s < hi]
 print(f"step {(hi - lo) / 1e6:.3f} ms, {len(step)} launches")
 byq = collections.defaultdict(list)
