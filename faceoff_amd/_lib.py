@@ -82,6 +82,7 @@ SIGNATURES = {
     "fo_pack_convT_k4s2": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "fo_pack_convT_k4s2_fused": (_I, [_P, _P, _I, _I, _I, _P]),
     "fo_pack_convT_k4s2_cells": (_I, [_P, _P, _I, _I, _I, _P]),
+    "fo_pack_convT_k4s2_cells_n": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "fo_conv_igemm": (_I, [_D, _P, _P, _P, _P, _P, _P, _P]),
     "fo_conv_igemm_variant": (_I, [_D]),
     "fo_resblock_fwd": (_I, [_D, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),

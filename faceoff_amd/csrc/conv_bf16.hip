@@ -178,20 +178,20 @@ __device__ __forceinline__ void store_c_tile(const ConvArgsH& a, const float* Cs
   const int c8 = tid % C8;
   const int co = tile_n * BN + c8 * 8;
   if (co >= d.Cout) return;
-  // FO_DEPTH2SPACE (the k4 s2 p1 transposed conv with <= 8 output channels as ONE GEMM, reference :152): GEMM column = phase * 8 +
-  // channel, so a lane's 8 columns are ONE output pixel's 8 channels: pixel (2y + ph/2 - ophH, 2x + ph%2 - ophH), d.ophW real channels
+  // FO_DEPTH2SPACE (a k4 s2 p1 transposed conv as ONE GEMM, reference :147-152,222): GEMM column = phase * Cpp + channel (Cpp = Cout / 4 columns per
+  // phase, a multiple of 8), so a lane's 8 columns are 8 channels of ONE output pixel: pixel (2y + ph/2 - ophH, 2x + ph%2 - ophH), d.ophW real channels
   const bool d2s = flags & FO_DEPTH2SPACE;
-  const int ph = co >> 3;
+  const int cpp = d.Cout >> 2;
+  const int ph = d2s ? co / cpp : 0;
+  const int cc = d2s ? co - ph * cpp : co;      // channel of the OUTPUT tensor (bias, mask, add, store)
+  if (d2s && cc >= ((d.ophW + 7) & ~7)) return;
   float bv[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const int cb = d2s ? e : co + e;
-    bv[e] = ((flags & FO_BIAS) && cb < (d2s ? d.ophW : d.Cout)) ? a.bias[cb] : 0.f;
-  }
+  for (int e = 0; e < 8; ++e) bv[e] = ((flags & FO_BIAS) && cc + e < (d2s ? d.ophW : d.Cout)) ? a.bias[cc + e] : 0.f;
   const bool identity_pix = (d.ostride == 1) & (d.Hm == d.Hout) & (d.Wm == d.Wout) & !d2s;
   const __bf16* mask = reinterpret_cast<const __bf16*>(a.mask);
   const __bf16* addp = reinterpret_cast<const __bf16*>(a.add);
-  const int cst = d2s ? 0 : co;               // channel offset of the store
+  const int cst = cc;                         // channel offset of the store
   // rows in batches: all mask / add loads of a batch are in flight before the first is used (see conv_igemm.hip store_tile)
   constexpr int ROWS = BM / RPP, R = ROWS < 8 ? ROWS : 8;
   const int r0 = tid / C8;
@@ -224,11 +224,11 @@ __device__ __forceinline__ void store_c_tile(const ConvArgsH& a, const float* Cs
     bf16x8 mk[R], ad[R];
     if (flags & FO_MASK) {
 #pragma unroll
-      for (int r = 0; r < R; ++r) mk[r] = load_mask8(a, opix[r], co);
+      for (int r = 0; r < R; ++r) mk[r] = load_mask8(a, opix[r], cc);
     }
     if (flags & FO_ADD) {
 #pragma unroll
-      for (int r = 0; r < R; ++r) ad[r] = *reinterpret_cast<const bf16x8*>(addp + opix[r] * d.ldAdd + co);
+      for (int r = 0; r < R; ++r) ad[r] = *reinterpret_cast<const bf16x8*>(addp + opix[r] * d.ldAdd + cc);
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -2312,9 +2312,10 @@ static int conv_bf16_impl(const fo_conv_desc* d, const void* in, const void* wp,
   FO_REQUIRE(d->ldIn % 8 == 0 && fo_aligned16(in) && fo_aligned16(wp) && fo_aligned16(out) && d->ldOut % (f32out ? 4 : 8) == 0, FO_E_ALIGN,
              "conv_bf16: 16-byte alignment (bf16 ld %% 8 == 0, fp32 ld %% 4 == 0)");
   if (d2s) {
-    FO_REQUIRE(d->Cout == 32 && d->ldOut >= 8 && (d->ophH == 0 || d->ophH == 1) && d->Hout == 2 * (d->Hm - d->ophH) && d->Wout == 2 * (d->Wm - d->ophH) &&
-                   !(flags & (FO_MASK | FO_ADD)) && d->ophW >= 1 && d->ophW <= 8,
-               FO_E_SHAPE, "conv_bf16: FO_DEPTH2SPACE needs Cout == 32 (4 phases x 8), ldOut >= 8, a 2x output grid, no mask/add");
+    FO_REQUIRE(d->Cout % 32 == 0 && d->ldOut >= (d->ophW + 7) / 8 * 8 && (d->ophH == 0 || d->ophH == 1) && d->Hout == 2 * (d->Hm - d->ophH) &&
+                   d->Wout == 2 * (d->Wm - d->ophH) && d->ophW >= 1 && d->ophW <= d->Cout / 4 && (d->Cout == 32 || d->ophH == 1),
+               FO_E_SHAPE, "conv_bf16: FO_DEPTH2SPACE needs Cout = 4 x (a multiple of 8) columns, 1 <= ophW <= Cout / 4 real channels, ldOut >= ophW rounded up to 8, "
+               "a 2x output grid (more than 8 columns per phase: the cell form, ophH = 1)");
   } else {
     FO_REQUIRE(d->ldOut >= (d->Cout + 7) / 8 * 8, FO_E_ALIGN, "conv_bf16: ldOut must hold Cout rounded up to 8");
   }

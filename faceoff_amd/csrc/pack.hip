@@ -69,13 +69,13 @@ __global__ void pack_convT_fused_kernel(const float* __restrict__ w, float* __re
 // producing 2x2-pixel cells -- cell (i, j), phase (a, b), is output pixel (2i + a - 1, 2j + b - 1) = sum over ei, ej in {0,1} of
 // x[i + ei - 1][j + ej - 1] . w[ci][co][2 (1 - ei) + a][2 (1 - ej) + b]:  wp[(a*2+b)*8 + co][ei*2 + ej][ci].  K = 4 Ci instead
 // of the 9 Ci of the 3x3 form above (whose filter is 5/9 zeros).
-__global__ void pack_convT_cells_kernel(const float* __restrict__ w, float* __restrict__ wp, int Ci, int Co, int Cipad) {
-  const size_t total = (size_t)32 * 4 * Cipad;
+__global__ void pack_convT_cells_kernel(const float* __restrict__ w, float* __restrict__ wp, int Ci, int Co, int Cpp, int Cipad) {      // Cpp: columns per phase
+  const size_t total = (size_t)4 * Cpp * 4 * Cipad;
   for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
     const int ci = e % Cipad;
     const int t = (e / Cipad) & 3;
     const int col = e / ((size_t)Cipad * 4);
-    const int ph = col >> 3, co = col & 7, a = ph >> 1, b = ph & 1, ei = t >> 1, ej = t & 1;
+    const int ph = col / Cpp, co = col - ph * Cpp, a = ph >> 1, b = ph & 1, ei = t >> 1, ej = t & 1;
     wp[e] = (ci < Ci && co < Co) ? w[(((size_t)ci * Co + co) * 4 + 2 * (1 - ei) + a) * 4 + 2 * (1 - ej) + b] : 0.f;
   }
 }
@@ -184,7 +184,15 @@ int fo_pack_convT_k4s2_fused(const float* w, float* wp, int Ci, int Co, int Cipa
 int fo_pack_convT_k4s2_cells(const float* w, float* wp, int Ci, int Co, int Cipad, void* stream) {
   FO_REQUIRE(Cipad >= Ci && Co <= 8, FO_E_SHAPE, "pack_convT_cells: Co <= 8");
   hipLaunchKernelGGL(pack_convT_cells_kernel, dim3(grid_for((size_t)32 * 4 * Cipad)), dim3(256), 0, (hipStream_t)stream, w, wp, Ci, Co,
-                     Cipad);
+                     8, Cipad);
+  FO_CHECK_LAUNCH();
+  return FO_OK;
+}
+
+int fo_pack_convT_k4s2_cells_n(const float* w, float* wp, int Ci, int Co, int Cpp, int Cipad, void* stream) {
+  FO_REQUIRE(Cipad >= Ci && Cpp >= Co && Cpp % 8 == 0, FO_E_SHAPE, "pack_convT_cells_n: Cpp >= Co, a multiple of 8");
+  hipLaunchKernelGGL(pack_convT_cells_kernel, dim3(grid_for((size_t)4 * Cpp * 4 * Cipad)), dim3(256), 0, (hipStream_t)stream, w, wp, Ci, Co,
+                     Cpp, Cipad);
   FO_CHECK_LAUNCH();
   return FO_OK;
 }

@@ -237,6 +237,9 @@ class _Layer:
                            in_relu=in_relu, **geo)
 
 
+BF16_CONVT_CELLS = not _os.environ.get("FACEOFF_BF16_CONVT_PHASES")     # (read at import, like ops.CONVT_CELLS: the packs and the launches must agree)
+
+
 class _LayerBF16(_Layer):
     """The same layer with bf16 MFMA operands (BASELINE config 3 as SURVEY.md section 8(d) defines it): the fp32 master filter is packed
     and rounded to bf16 every step, activations and their gradients are bf16 tensors, accumulation, bias, filter / bias gradients fp32.
@@ -249,8 +252,9 @@ class _LayerBF16(_Layer):
             out = ops.to_bf16(f32, buf)
             setattr(self, key, out)
             return out
+        cells = BF16_CONVT_CELLS                  # k4 s2 transposed forms as one cell-form launch instead of four sub-pixel phases (round 6)
         if self.kind == "convT":
-            self._p32 = (ops.pack_convT_fused if self.co <= 8 else ops.pack_convT)(self.w, getattr(self, "_p32", None))
+            self._p32 = (ops.pack_convT_fused if self.co <= 8 else (ops.pack_convT_cells if cells else ops.pack_convT))(self.w, getattr(self, "_p32", None))
             self.wp = r16(self._p32, "_wp16")
             if self.need_dgrad:                      # dgrad = conv k4s2p1 with O:=ci, I:=co
                 self._pd32 = ops.pack_conv(self.w, getattr(self, "_pd32", None))
@@ -261,7 +265,7 @@ class _LayerBF16(_Layer):
             if not self.need_dgrad:
                 return
             if self.k[-1] == 4:                      # dgrad of k4s2p1 conv = transposed conv, Ci_T:=co, Co_T:=ci
-                self._pd32 = ops.pack_convT(self.w, getattr(self, "_pd32", None))
+                self._pd32 = (ops.pack_convT_cells if cells else ops.pack_convT)(self.w, getattr(self, "_pd32", None))
             else:
                 self._pd32 = ops.pack_conv_dgrad(self.w.reshape(self.co, self.ci, -1), getattr(self, "_pd32", None))
             self.wpd = r16(self._pd32, "_wpd16")
@@ -271,7 +275,7 @@ class _LayerBF16(_Layer):
             assert add is None
             ops.convT_fused_bf16(x, self.wp, self.b, out, cin=self.cip, cout=self.co, flags=flags)
         elif self.kind == "convT":
-            ops.convT_phases_bf16(x, self.wp, self.b, out, cin=self.cip, cout=self.co, flags=flags, add=add)
+            (ops.convT_cells_bf16 if BF16_CONVT_CELLS else ops.convT_phases_bf16)(x, self.wp, self.b, out, cin=self.cip, cout=self.co, flags=flags, add=add)
         else:
             ops.conv_bf16g(x, self.wp, self.b, out, T=T if self.kind == "conv3d" else 1, cin=self.cip, cout=self.co, flags=flags, add=add,
                            **self._geom())
@@ -280,7 +284,7 @@ class _LayerBF16(_Layer):
         if self.kind == "convT":                     # conv k4 s2 p1 over g
             ops.conv_bf16g(g, self.wpd, None, gin, k=(1, 4, 4), stride=2, pad=(0, 1, 1), cin=ops.pad_in(self.co), cout=self.ci, mask=mask, add=add)
         elif self.k[-1] == 4:                        # transposed conv over g
-            ops.convT_phases_bf16(g, self.wpd, None, gin, cin=self.co, cout=self.ci, mask=mask, add=add)
+            (ops.convT_cells_bf16 if BF16_CONVT_CELLS else ops.convT_phases_bf16)(g, self.wpd, None, gin, cin=self.co, cout=self.ci, mask=mask, add=add)
         else:
             geo = self._geom()
             pad = tuple(kk - 1 - p for kk, p in zip(geo["k"], geo["pad"]))

@@ -838,6 +838,26 @@ def convT_fused_bf16(x, wpf, bias, out, *, cin, cout, flags=0):
                oph=(1, cout))
 
 
+def pack_convT_cells(w, out=None):
+    """[Ci][Co][4][4] -> the cell form of the k4 s2 p1 transposed conv at any width: [4 phases x Cpp][4 taps][Cipad], Cpp = Co rounded up to 32
+    (fo_pack_convT_k4s2_cells_n; fp32, rounded to bf16 by the caller)."""
+    Ci, Co = w.shape[:2]
+    Cip, Cpp = pad_in(Ci), (Co + 31) // 32 * 32
+    if out is None:
+        out = torch.empty(4 * Cpp * 4 * Cip, device=w.device, dtype=torch.float32)
+    _lib.call("fo_pack_convT_k4s2_cells_n", _ptr(w), _ptr(out), Ci, Co, Cpp, Cip, _stream())
+    return out
+
+
+def convT_cells_bf16(x, wc, bias, out, *, cin, cout, flags=0, mask=None, add=None):
+    """k4 s2 p1 transposed conv (or the dgrad of a k4 s2 p1 conv) as ONE launch: a k2 p1 conv over the (H+1) x (W+1) grid of 2x2-pixel cells whose
+    4 Cpp GEMM columns are the four sub-pixel phases (FO_DEPTH2SPACE); the input is read once instead of once per phase.  mask / add at the output pixel."""
+    N, Hi, Wi, _ = x.shape
+    cpp = (cout + 31) // 32 * 32
+    conv_bf16g(x, wc, bias, out, k=(1, 2, 2), stride=1, pad=(0, 1, 1), cin=cin, cout=4 * cpp, flags=flags | FO_DEPTH2SPACE, mask=mask, add=add,
+               mgrid=(Hi + 1, Wi + 1), oph=(1, cout))
+
+
 def convT_phases_bf16(x, wp4, bias, out, *, cin, cout, flags=0, mask=None, add=None):
     """k4 s2 p1 transposed conv (or the dgrad of a k4 s2 p1 conv) as 4 sub-pixel launches (bf16 operands)."""
     N, Hi, Wi, _ = x.shape

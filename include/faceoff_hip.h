@@ -48,12 +48,14 @@ extern "C" {
                              3x3 conv over the INPUT grid whose 32 GEMM columns are 4 sub-pixel phases x 8 channels
                              (fo_pack_convT_k4s2_fused); column ph*8+c of input pixel (y,x) lands at output pixel
                              (2y+ph/2, 2x+ph%2), channel c.  desc: Cout=32, Hout=2*Hm, ldOut>=8, ophW = real channels; ophH = 1: the cell form
-                             (fo_pack_convT_k4s2_cells), Hout = 2*(Hm-1) */
+                             (fo_pack_convT_k4s2_cells), Hout = 2*(Hm-1).  fo_conv_bf16 takes the cell form at any width: Cout = 4 Cpp GEMM
+                             columns, Cpp (a multiple of 8) per phase, ophW <= Cpp real channels, FO_MASK / FO_ADD at the OUTPUT pixel
+                             (fo_pack_convT_k4s2_cells_n) */
 #define FO_OUT_F32 64  /* fo_conv_bf16 only: the result is stored as fp32 (ldOut in floats) instead of being rounded to bf16 -- the
                           quantisers' inputs (quantize_conv_t / _b, :208,213: VQ distances and arg-min stay fp32) and the decoder output */
 
 /* ABI version: bumped whenever an exported signature or the meaning of an argument changes (101: the loss kernels take a caller-owned
-   partial-sum workspace `ws` in front of `stream` and OVERWRITE their scalars -- round 4; 102: fo_comm_broadcast_async added; fo_instnorm_lrelu_{fwd,bwd}_batch take a workspace, fo_lpips_tap_fwd_bwd_unpool_bf16, fo_selftest_lane_moves added -- round 6).  The Python binding refuses a library whose
+   partial-sum workspace `ws` in front of `stream` and OVERWRITE their scalars -- round 4; 102: fo_comm_broadcast_async added; fo_instnorm_lrelu_{fwd,bwd}_batch take a workspace, fo_lpips_tap_fwd_bwd_unpool_bf16, fo_selftest_lane_moves, fo_pack_convT_k4s2_cells_n added -- round 6).  The Python binding refuses a library whose
    fo_version() differs from the FO_ABI_VERSION it was written against (faceoff_amd/_lib.py), so an older .so handed in through
    FACEOFF_HIP_LIB is a clean error and not a stream pointer read as a workspace. */
 #define FO_ABI_VERSION 102
@@ -100,6 +102,11 @@ int fo_pack_convT_k4s2_fused(const float* w, float* wp, int Ci, int Co, int Cipa
  * cells, wp[32 = 4 phases x 8][4 taps][Cipad]; cell (i,j), phase (a,b) lands at output pixel (2i+a-1, 2j+b-1) (the border cells'
  * outside pixels are dropped).  K = 4 Ci instead of 9 Ci. */
 int fo_pack_convT_k4s2_cells(const float* w, float* wp, int Ci, int Co, int Cipad, void* stream);
+/* ... with Cpp >= Co columns per phase (a multiple of 8): wp[4 Cpp][4 taps][Cipad] -- the cell form of ANY k4 s2 p1 transposed convolution, and of
+ * the data gradient of a k4 s2 p1 convolution (dec.blocks.4, dec_t.blocks.4, upsample_t :147-151,222; the gradients of enc_b.blocks.2 / enc_t.blocks.0
+ * :104-126 under loss.backward()) as ONE fo_conv_bf16 launch with FO_DEPTH2SPACE (desc.Cout = 4 Cpp) instead of four sub-pixel phase launches that each
+ * read the whole input (round 6). */
+int fo_pack_convT_k4s2_cells_n(const float* w, float* wp, int Ci, int Co, int Cpp, int Cipad, void* stream);
 
 /* ---------------------------------------------------------------- convolution (implicit GEMM, fp32 MFMA) */
 typedef struct fo_conv_desc {

@@ -123,6 +123,44 @@ def test_transposed_conv_phases_into_a_channel_slice_and_its_data_gradient():
     close_bf16(back(gin), gref, "convT data gradient")
 
 
+@pytest.mark.parametrize("ci,co,h,w", [(128, 64, 16, 16), (64, 64, 5, 7), (64, 128, 6, 10), (128, 40, 4, 4)])
+def test_transposed_conv_as_one_cell_form_launch_at_any_width(ci, co, h, w):
+    """The k4 s2 p1 transposed convolutions with more than 8 output channels (dec.blocks.4, dec_t.blocks.4, upsample_t :147-151,222) and the data gradients
+    of the k4 s2 convolutions (enc_b.blocks.2, enc_t.blocks.0) as ONE launch: a k2 p1 conv over the (H+1) x (W+1) cell grid, 4 x Cpp GEMM columns,
+    depth-to-space in the epilogue (fo_pack_convT_k4s2_cells_n + FO_DEPTH2SPACE).  Forward use: bias + ReLU into a channel slice of a wider buffer; gradient
+    use: ReLU mask and fan-in add at the output pixel.  Against torch on the same bf16 operands, and against the four sub-pixel phase launches."""
+    from faceoff_amd import ops
+    g = gen(300 + ci + co + h)
+    N = 2
+    x = rb(torch.randn((N, ci, h, w), generator=g))
+    wt = rb(torch.randn((ci, co, 4, 4), generator=g) / np.sqrt(4 * ci))
+    b = torch.randn(co, generator=g)
+    wc = packed_bf16(ops.pack_convT_cells(wt.cuda()))
+    ld = (co + 7) // 8 * 8 + 64
+    ref = F.relu(F.conv_transpose2d(x, wt, b, stride=2, padding=1))
+    cat = torch.full((N, 2 * h, 2 * w, ld), 7.0, device="cuda", dtype=BF)
+    ops.convT_cells_bf16(nhwc(x), wc, b.cuda(), cat[..., 0:(co + 7) // 8 * 8], cin=ci, cout=co, flags=ops.FO_OUT_RELU)
+    close_bf16(back(cat[..., 0:co]), ref, "convT cells forward")
+    assert bool((cat[..., (co + 7) // 8 * 8:] == 7.0).all())
+    # gradient use: masked, added to a fan-in gradient
+    mask = rb(torch.randn((N, co, 2 * h, 2 * w), generator=g))
+    addt = rb(torch.randn((N, co, 2 * h, 2 * w), generator=g))
+    gref = F.conv_transpose2d(x, wt, None, stride=2, padding=1) * (mask > 0) + addt
+    def pad8(t):          # NHWC with the channel count rounded up to 8
+        o = torch.zeros((N, 2 * h, 2 * w, (co + 7) // 8 * 8), device="cuda", dtype=BF)
+        o[..., :co] = nhwc(t)
+        return o
+    gin = torch.empty((N, 2 * h, 2 * w, (co + 7) // 8 * 8), device="cuda", dtype=BF)
+    ops.convT_cells_bf16(nhwc(x), wc, None, gin, cin=ci, cout=co, mask=pad8(mask), add=pad8(addt))
+    close_bf16(back(gin[..., :co]), gref, "convT cells as a data gradient")
+    if co % 32 == 0:      # the phase launches on the same operands: the same products in another order
+        gin4 = torch.empty_like(gin)
+        ops.convT_phases_bf16(nhwc(x), packed_bf16(ops.pack_convT(wt.cuda())), None, gin4, cin=ci, cout=co, mask=pad8(mask), add=pad8(addt))
+        d = (gin.float() - gin4.float()).abs()
+        tol = gin4.float().abs() * 2.0 ** -7 + 1e-3 * gin4.float().abs().max()
+        assert not bool((d > tol).any()), f"cells vs phases: worst {float((d / tol).max()):.2f} x tol"
+
+
 def test_resblock_pair_of_launches():
     """ResBlock (:86-101): h = relu(conv3x3(relu(x)) + b1) with the leading ReLU applied as the operand is staged (FO_IN_RELU, 128 -> 32),
     out = relu(conv1x1(h) + b3 + x) (32 input channels: the 256-row kernel's 32-deep K tiles; residual add + trailing ReLU in the epilogue)."""
