@@ -470,7 +470,7 @@ int fo_conv_igemm_bf16_pool_idx(const fo_conv_desc* d, const void* in, const voi
  * nn.Conv3d :181,185; the taps of a row tile that see nothing but clip padding are skipped), stride 2, sub-pixel phases
  * (ostride / oph*), Cin % 32 == 0 for the same-size stride-1 forms with Cout % 128 == 0 (else Cin % 64 == 0, or 8), and the flags
  * FO_IN_RELU (Cout <= 32 forms only: the operand is staged through registers), FO_BIAS, FO_MASK, FO_ADD (bf16 tensor, ldAdd),
- * FO_OUT_RELU, FO_DEPTH2SPACE (Cout == 32) and FO_OUT_F32.  Replaces the cuDNN kernels torch.autocast(bfloat16) would pick for
+ * FO_OUT_RELU, FO_DEPTH2SPACE (Cout = 4 x a multiple of 8 columns: see the flag) and FO_OUT_F32.  Replaces the cuDNN kernels torch.autocast(bfloat16) would pick for
  * models/vqvae_conv3d_latent.py:92-190 and their autograd data gradients. */
 int fo_conv_bf16(const fo_conv_desc* d, const void* in, const void* wp, const float* bias, const void* mask, const void* add, void* out,
                  void* stream);
@@ -479,7 +479,10 @@ int fo_conv_bf16(const fo_conv_desc* d, const void* in, const void* wp, const fl
  * d->Hm x d->Wm) and bf16 Q (d->Cin channels, d->ldIn, d->Hin x d->Win), fp32 accumulation (csrc/wgrad_bf16.hip).  Same descriptor
  * convention as fo_conv_wgrad; FO_IN_RELU applies relu() to Q as it is staged.  Channel counts are multiples of 8; an 8-channel Q
  * (the image layers) takes a form of its own at the k4 s2 geometry.  dbias (may be NULL): [Areal] column sums of P, formed by the
- * same launch (one extra MFMA per K-step against a fragment of ones in the workgroups of the centre tap).
+ * same launch (one extra MFMA per K-step against a fragment of ones in the workgroups of the centre tap).  P and Q are read through
+ * 32-bit buffer offsets: each must be smaller than 2 GiB (FO_E_SHAPE otherwise).  3x3 (x KD) pad-1 stride-1 layers whose rows are
+ * multiples of 32 pixels run wgrad9_bf16_kernel (all nine taps of a depth plane per workgroup, LDS-DMA staging: both operands fetched
+ * about once) when P has >= 128 and Q >= 64 channels, or P <= 32 and Q >= 128; everything else the row-run / gather forms.
  * ws: fo_wgrad_bf16_ws_bytes(d) bytes of scratch, private to the stream. */
 int64_t fo_wgrad_bf16_ws_bytes(const fo_conv_desc* d);
 int fo_conv_wgrad_bf16(const fo_conv_desc* d, const void* P, const void* Q, float* dw, int Areal, int Breal, float* dbias, float* ws,
