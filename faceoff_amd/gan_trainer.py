@@ -15,6 +15,7 @@ window-2 instead of window-1 times (:364, a shape error at run time); `modelD.mo
 Random choices are drawn from a `random.Random` in the reference's call order, or passed in explicitly (tests)."""
 from __future__ import annotations
 
+import os as _os
 import random as _random
 
 import torch
@@ -24,6 +25,26 @@ from .distributed import fused_vq_allreduce, get_world_size
 from .disc import DiscEngine, make_pairs, pairs_backward, ralsgan_pair
 from .engine import VQVAEEngine
 from .trainer import FlatAdam, LATENT_LOSS_WEIGHT
+
+
+def _runs_beside_current(stream, dev):
+    """True when a launch on `stream` starts while a long launch occupies the current stream -- i.e. the two do not share a hardware queue (packets of one queue
+    are dispatched in order: the second would start when the first has handed out its last workgroup).  ~1 ms, once per trainer."""
+    buf = torch.empty(1 << 27, device=dev)                      # 512 MB: one elementwise pass over it is ~0.08 ms of a many-workgroup launch
+    beside = False
+    for _ in range(2):                                          # (the first round warms the launch paths up; the second one counts)
+        t0, t_side, t_main = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        torch.cuda.synchronize(dev)
+        t0.record()
+        for _ in range(4):
+            buf.fill_(1.0)
+        t_main.record()
+        with torch.cuda.stream(stream):
+            torch.zeros(1, device=dev)
+            t_side.record(stream)
+        torch.cuda.synchronize(dev)
+        beside = t0.elapsed_time(t_side) < 0.5 * t0.elapsed_time(t_main)     # done well before the long launches were (measured: 0.06 against 0.33 ms)
+    return beside
 
 
 class GANTrainer:
@@ -42,7 +63,6 @@ class GANTrainer:
         self.iteration = 0
         # the image discriminator (two samples of ONE frame pair: launches of a few hundred workgroups) runs on its own stream beside the video
         # discriminator -- the two are independent until their input gradients meet in the decoder-output gradient (FACEOFF_NO_D2_OVERLAP=1: serial)
-        import os as _os
         self.d2_stream = None
         if engine.device.type == "cuda" and not _os.environ.get("FACEOFF_NO_D2_OVERLAP"):
             self.d2_stream = torch.cuda.Stream(device=engine.device)
@@ -62,6 +82,32 @@ class GANTrainer:
         elif self.collectives:
             vq_ar = fused_vq_allreduce()
             engine.vq_allreduce = (lambda st: vq_ar(st, always=True)) if force_collectives else vq_ar
+        self.claim_queues()
+
+    def claim_queues(self):
+        """HIP hands a stream its hardware queue at first use, from a pool of GPU_MAX_HW_QUEUES = 4 (the null stream has its own: queue 1; then 2, 3, 4, 4, 3, 2,
+        1, ...: tools/stream_timeline.py).  This iteration uses seven side streams, so left to the order in which the code happens to reach them, the generator's
+        filter-gradient stream -- the last one used -- landed on the MAIN stream's queue and its launches queued up behind the data-gradient chain they were meant
+        to run beside (13.6 ms per iteration).  One empty launch per stream, in an order that pairs streams which are never busy together and leaves the main
+        stream's queue to the quantiser statistics (six tiny launches): packs 2, bottom Conv3d chain 3, filter gradients 4, image discriminator 4, the
+        discriminators' coarse scales 3 and 2, statistics 1.  13.1-13.3 ms.  That order only holds in a process whose streams are fresh (torch hands out pooled
+        streams that keep their queues): the filter-gradient stream is therefore CHECKED -- a launch on it must start while a long launch occupies the current
+        stream -- and replaced by the next pooled stream until one does (at most 8 tries).  FACEOFF_NO_QUEUE_PLAN=1: streams as they come."""
+        eng = self.engine
+        if eng.device.type != "cuda" or _os.environ.get("FACEOFF_NO_QUEUE_PLAN"):
+            return
+        for st in (eng.pack_stream, eng.aux_stream, eng.wgrad_stream, self.d2_stream, self.d3._side(), self.d2._side(), eng.vq_stream):
+            if st is not None:
+                with torch.cuda.stream(st):
+                    torch.zeros(1, device=eng.device)
+        if eng.wgrad_stream is None:
+            return
+        for _ in range(8):
+            if _runs_beside_current(eng.wgrad_stream, eng.device):
+                break
+            eng.wgrad_stream = torch.cuda.Stream(device=eng.device)
+        eng._streams = (eng.wgrad_stream,) + tuple(eng._streams[1:])       # (set_stream_overlap(True) restores from this tuple)
+
 
     def _beside(self):
         """Context manager: the body runs on the image discriminator's side stream behind everything enqueued so far on the current stream
