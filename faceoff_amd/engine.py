@@ -300,6 +300,27 @@ class _LayerBF16(_Layer):
                                 **self._geom())
 
 
+def _runs_beside_current(stream, dev):
+    """True when a launch on `stream` starts while a long launch occupies the current stream -- i.e. the two do not share a hardware queue (packets of one queue
+    are dispatched in order: the second would start when the first has handed out its last workgroup).  ~1 ms, once per trainer."""
+    buf = torch.empty(1 << 27, device=dev)                      # 512 MB: one elementwise pass over it is ~0.08 ms of a many-workgroup launch
+    beside = False
+    for _ in range(2):                                          # (the first round warms the launch paths up; the second one counts)
+        t0, t_side, t_main = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        torch.cuda.synchronize(dev)
+        t0.record()
+        for _ in range(4):
+            buf.fill_(1.0)
+        t_main.record()
+        with torch.cuda.stream(stream):
+            torch.zeros(1, device=dev)
+            t_side.record(stream)
+        torch.cuda.synchronize(dev)
+        beside = t0.elapsed_time(t_side) < 0.5 * t0.elapsed_time(t_main)     # done well before the long launches were (measured: 0.06 against 0.33 ms)
+    return beside
+
+
+
 class VQVAEEngine:
     """Owns the flat parameter / gradient arenas and runs forward / backward on `device`."""
 
@@ -668,6 +689,32 @@ class VQVAEEngine:
         if self.vq_stream is not None and training:      # the codebook update ran beside the decoder; whoever reads the buffers next is behind it
             torch.cuda.current_stream().wait_stream(self.vq_stream)
         return S
+
+    def keep_wgrad_off_main_queue(self):
+        """HIP gives a stream its hardware queue at first use, from a pool of GPU_MAX_HW_QUEUES = 4; in order of first use the queues go 2, 3, 4, 4, 3, 2, 1, 4, 3 ..
+        (queue 1 is the null stream's).  Which queue the filter-gradient stream gets therefore depends on how many streams the PROCESS has used before this engine's
+        -- another engine's, a communicator's -- and when it is queue 1 its launches line up behind the data-gradient chain they are meant to run beside: config 2
+        39.7 -> 41.2 ms, config 3 32.3 -> 34.0, config 5 13.2 -> 13.6 (three throw-away streams in front).  Checked here, once, by the trainers at
+        construction: a small launch on the stream must finish while long launches occupy the current stream; if it does not, the next pooled stream takes its
+        place (at most 8 tries).  ~2 ms and a transient 512 MB.  FACEOFF_NO_QUEUE_CHECK=1: as it comes."""
+        if self.device.type != "cuda" or self.wgrad_stream is None:
+            return
+        if _os.environ.get("FACEOFF_DIAG_QUEUE_SHIFT"):        # diagnostics: n throw-away streams take the next hardware queues first (what a communicator's would do)
+            self._shift = [torch.cuda.Stream(device=self.device) for _ in range(int(_os.environ["FACEOFF_DIAG_QUEUE_SHIFT"]))]
+            for st in self._shift:
+                with torch.cuda.stream(st):
+                    torch.zeros(1, device=self.device)
+        if _os.environ.get("FACEOFF_NO_QUEUE_CHECK"):
+            return
+        for st in (self.pack_stream, self.aux_stream, self.vq_stream, self.wgrad_stream):       # (the order a step reaches them in)
+            if st is not None:
+                with torch.cuda.stream(st):
+                    torch.zeros(1, device=self.device)
+        for _ in range(8):
+            if _runs_beside_current(self.wgrad_stream, self.device):
+                break
+            self.wgrad_stream = torch.cuda.Stream(device=self.device)
+        self._streams = (self.wgrad_stream,) + tuple(self._streams[1:])       # (set_stream_overlap(True) restores from this tuple)
 
     def _quantize(self, name, x, q_out, training, force_ind=None):
         # The previous step's codebook update: long finished, and every path that launches it joins the side stream before it returns (stage_quantize /

@@ -27,26 +27,6 @@ from .engine import VQVAEEngine
 from .trainer import FlatAdam, LATENT_LOSS_WEIGHT
 
 
-def _runs_beside_current(stream, dev):
-    """True when a launch on `stream` starts while a long launch occupies the current stream -- i.e. the two do not share a hardware queue (packets of one queue
-    are dispatched in order: the second would start when the first has handed out its last workgroup).  ~1 ms, once per trainer."""
-    buf = torch.empty(1 << 27, device=dev)                      # 512 MB: one elementwise pass over it is ~0.08 ms of a many-workgroup launch
-    beside = False
-    for _ in range(2):                                          # (the first round warms the launch paths up; the second one counts)
-        t0, t_side, t_main = (torch.cuda.Event(enable_timing=True) for _ in range(3))
-        torch.cuda.synchronize(dev)
-        t0.record()
-        for _ in range(4):
-            buf.fill_(1.0)
-        t_main.record()
-        with torch.cuda.stream(stream):
-            torch.zeros(1, device=dev)
-            t_side.record(stream)
-        torch.cuda.synchronize(dev)
-        beside = t0.elapsed_time(t_side) < 0.5 * t0.elapsed_time(t_main)     # done well before the long launches were (measured: 0.06 against 0.33 ms)
-    return beside
-
-
 class GANTrainer:
     def __init__(self, engine: VQVAEEngine, disc3d: DiscEngine, disc2d: DiscEngine, lr=3e-4, d_lr=1e-4, scheduler=None, window=16,
                  rng=None, comm=None, force_collectives=False):
@@ -91,8 +71,7 @@ class GANTrainer:
         to run beside (13.6 ms per iteration).  One empty launch per stream, in an order that pairs streams which are never busy together and leaves the main
         stream's queue to the quantiser statistics (six tiny launches): packs 2, bottom Conv3d chain 3, filter gradients 4, image discriminator 4, the
         discriminators' coarse scales 3 and 2, statistics 1.  13.1-13.3 ms.  That order only holds in a process whose streams are fresh (torch hands out pooled
-        streams that keep their queues): the filter-gradient stream is therefore CHECKED -- a launch on it must start while a long launch occupies the current
-        stream -- and replaced by the next pooled stream until one does (at most 8 tries).  FACEOFF_NO_QUEUE_PLAN=1: streams as they come."""
+        streams that keep their queues): the filter-gradient stream is therefore CHECKED (VQVAEEngine.keep_wgrad_off_main_queue).  FACEOFF_NO_QUEUE_PLAN=1: streams as they come."""
         eng = self.engine
         if eng.device.type != "cuda" or _os.environ.get("FACEOFF_NO_QUEUE_PLAN"):
             return
@@ -100,13 +79,7 @@ class GANTrainer:
             if st is not None:
                 with torch.cuda.stream(st):
                     torch.zeros(1, device=eng.device)
-        if eng.wgrad_stream is None:
-            return
-        for _ in range(8):
-            if _runs_beside_current(eng.wgrad_stream, eng.device):
-                break
-            eng.wgrad_stream = torch.cuda.Stream(device=eng.device)
-        eng._streams = (eng.wgrad_stream,) + tuple(eng._streams[1:])       # (set_stream_overlap(True) restores from this tuple)
+        eng.keep_wgrad_off_main_queue()
 
 
     def _beside(self):

@@ -66,6 +66,10 @@ class FaceOffTrainer:
         # one (their uses are still pending): the pool grew by 20-60 GB a few steps into a run -- device mallocs of gigabytes in the middle
         # of training (tools/probes/c3_steps_probe.py).  Two steps in flight keep the GPU fed; the wait costs nothing when it is the bottleneck.
         self.max_inflight_steps = int(_os.environ.get("FACEOFF_MAX_INFLIGHT_STEPS", "2"))
+        if self.lpips_stream is not None:                  # (first use, in the order a step reaches the streams: the ground-truth branch comes first)
+            with torch.cuda.stream(self.lpips_stream):
+                torch.zeros(1, device=engine.device)
+        engine.keep_wgrad_off_main_queue()
         self._inflight = []
         self.reducer = None
         if self.world > 1 or force_collectives:

@@ -177,3 +177,24 @@ def test_u8_frames_to_normalised_tensors():
     m, s = 0.485, 0.229
     want = t.sub(torch.tensor(m)).div(torch.tensor(s))
     assert torch.equal(P.to_normalized(xg, mean=m, std=s).cpu(), want)
+
+
+def test_filter_gradient_stream_is_kept_off_the_main_streams_hardware_queue(monkeypatch):
+    """HIP hands out hardware queues in order of first use (2, 3, 4, 4, 3, 2, 1, ..; 1 is the null stream's), so with other streams used first -- another
+    engine's, a communicator's -- the engine's filter-gradient stream can land on the main stream's queue, where its launches line up behind the chain they are
+    meant to run beside (config 2 +3.6 %).  Emulated with three throw-away streams in front: the trainer's check replaces the stream until a launch on it
+    finishes while long launches occupy the main stream."""
+    from faceoff_amd.engine import VQVAEEngine, _runs_beside_current
+    from faceoff_amd.synth import make_state_dict
+    from faceoff_amd.trainer import FaceOffTrainer
+    dev = torch.device("cuda:0")
+    monkeypatch.setenv("FACEOFF_DIAG_QUEUE_SHIFT", "3")
+    monkeypatch.setenv("FACEOFF_NO_QUEUE_CHECK", "1")
+    eng = VQVAEEngine(make_state_dict(0, codebook_scale=0.3, gain=2.0), dev)
+    FaceOffTrainer(eng, lr=3e-4)
+    unchecked = _runs_beside_current(eng.wgrad_stream, dev)          # (whatever the process history made of it: recorded, not asserted)
+    monkeypatch.delenv("FACEOFF_NO_QUEUE_CHECK")
+    eng2 = VQVAEEngine(make_state_dict(0, codebook_scale=0.3, gain=2.0), dev)
+    FaceOffTrainer(eng2, lr=3e-4)
+    assert _runs_beside_current(eng2.wgrad_stream, dev), f"the checked stream still shares the main stream's queue (unchecked engine: beside = {unchecked})"
+    assert eng2._streams[0] is eng2.wgrad_stream
