@@ -300,25 +300,55 @@ class _LayerBF16(_Layer):
                                 **self._geom())
 
 
-def _runs_beside_current(stream, dev):
-    """True when a launch on `stream` starts while a long launch occupies the current stream -- i.e. the two do not share a hardware queue (packets of one queue
-    are dispatched in order: the second would start when the first has handed out its last workgroup).  ~1 ms, once per trainer."""
+def _runs_beside(stream, dev, busy=None):
+    """True when a launch on `stream` finishes while long launches occupy `busy` (default: the current stream) -- i.e. the two do not share a hardware queue
+    (packets of one queue are dispatched in order: the second would start when the first has handed out its last workgroup).  ~1 ms."""
+    busy = busy if busy is not None else torch.cuda.current_stream(dev)
     buf = torch.empty(1 << 27, device=dev)                      # 512 MB: one elementwise pass over it is ~0.08 ms of a many-workgroup launch
     beside = False
     for _ in range(2):                                          # (the first round warms the launch paths up; the second one counts)
-        t0, t_side, t_main = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        t0, t_side, t_busy = (torch.cuda.Event(enable_timing=True) for _ in range(3))
         torch.cuda.synchronize(dev)
-        t0.record()
-        for _ in range(4):
-            buf.fill_(1.0)
-        t_main.record()
+        with torch.cuda.stream(busy):
+            t0.record(busy)
+            for _ in range(4):
+                buf.fill_(1.0)
+            t_busy.record(busy)
         with torch.cuda.stream(stream):
             torch.zeros(1, device=dev)
             t_side.record(stream)
         torch.cuda.synchronize(dev)
-        beside = t0.elapsed_time(t_side) < 0.5 * t0.elapsed_time(t_main)     # done well before the long launches were (measured: 0.06 against 0.33 ms)
+        beside = t0.elapsed_time(t_side) < 0.5 * t0.elapsed_time(t_busy)     # done well before the long launches were (measured: 0.06 against 0.33 ms)
     return beside
 
+
+def _runs_beside_current(stream, dev):
+    return _runs_beside(stream, dev)
+
+
+def streams_by_queue(dev, classes=3, per_class=2, max_draw=24):
+    """Pooled streams sorted by the hardware queue HIP gave them: `classes` lists of `per_class` streams each, every list on its own queue, none on the current
+    stream's; plus the streams that were found on the current stream's queue.  Queues are told apart by _runs_beside (a process cannot ask for a stream's queue).
+    None when the pool does not yield that many (fewer hardware queues than expected)."""
+    main = torch.cuda.current_stream(dev)
+    groups, on_main = [], []
+    for _ in range(max_draw):
+        st = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(st):
+            torch.zeros(1, device=dev)                          # (first use: the stream takes its queue)
+        if not _runs_beside(st, dev, main):
+            on_main.append(st)
+            continue
+        for g in groups:
+            if not _runs_beside(st, dev, g[0]):
+                g.append(st)
+                break
+        else:
+            groups.append([st])
+        full = [g for g in groups if len(g) >= per_class]
+        if len(full) >= classes:
+            return [g[:per_class] for g in full[:classes]], on_main
+    return None
 
 
 class VQVAEEngine:

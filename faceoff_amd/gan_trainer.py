@@ -65,22 +65,33 @@ class GANTrainer:
         self.claim_queues()
 
     def claim_queues(self):
-        """HIP hands a stream its hardware queue at first use, from a pool of GPU_MAX_HW_QUEUES = 4 (the null stream has its own: queue 1; then 2, 3, 4, 4, 3, 2,
-        1, ...: tools/stream_timeline.py).  This iteration uses seven side streams, so left to the order in which the code happens to reach them, the generator's
-        filter-gradient stream -- the last one used -- landed on the MAIN stream's queue and its launches queued up behind the data-gradient chain they were meant
-        to run beside (13.6 ms per iteration).  One empty launch per stream, in an order that pairs streams which are never busy together and leaves the main
-        stream's queue to the quantiser statistics (six tiny launches): packs 2, bottom Conv3d chain 3, filter gradients 4, image discriminator 4, the
-        discriminators' coarse scales 3 and 2, statistics 1.  13.1-13.3 ms.  That order only holds in a process whose streams are fresh (torch hands out pooled
-        streams that keep their queues): the filter-gradient stream is therefore CHECKED (VQVAEEngine.keep_wgrad_off_main_queue).  FACEOFF_NO_QUEUE_PLAN=1: streams as they come."""
+        """HIP hands a stream its hardware queue at first use, from a pool of GPU_MAX_HW_QUEUES = 4 (queue 1 is the null stream's; then 2, 3, 4, 4, 3, 2, 1, 4, 3 ..
+        in order of first use: tools/stream_timeline.py), and torch hands out pooled streams that keep theirs.  This iteration uses seven side streams: left to the
+        order in which the code reaches them -- and to whatever the process used before -- the generator's filter-gradient stream landed on the MAIN stream's queue
+        (its launches queue up behind the data-gradient chain they are meant to run beside: 13.6 ms per iteration) or two streams that are busy together shared
+        one.  The queues are therefore handed out explicitly: pooled streams are drawn and sorted by queue (engine.streams_by_queue tells queues apart by whether a
+        launch on one stream waits for a long launch on the other), and the roles paired so that streams sharing a queue are never busy together --
+        packs + the image discriminator's coarse scales, bottom Conv3d chain + the video discriminator's coarse scales, filter gradients + image discriminator --
+        with the quantiser statistics (six tiny launches) on a stream of the main queue when one turned up.  13.1-13.2 ms in any process; ~40 ms and a transient
+        512 MB at construction.  FACEOFF_NO_QUEUE_PLAN=1: streams as they come (the filter-gradient stream is still checked)."""
         eng = self.engine
-        if eng.device.type != "cuda" or _os.environ.get("FACEOFF_NO_QUEUE_PLAN"):
+        if eng.device.type != "cuda":
             return
-        for st in (eng.pack_stream, eng.aux_stream, eng.wgrad_stream, self.d2_stream, self.d3._side(), self.d2._side(), eng.vq_stream):
-            if st is not None:
-                with torch.cuda.stream(st):
-                    torch.zeros(1, device=eng.device)
-        eng.keep_wgrad_off_main_queue()
-
+        plan = None
+        if (not _os.environ.get("FACEOFF_NO_QUEUE_PLAN") and self.d2_stream is not None and None not in (eng.pack_stream, eng.aux_stream, eng.wgrad_stream, eng.vq_stream)
+                and self.d3._side() is not None and self.d2._side() is not None):
+            from .engine import streams_by_queue
+            plan = streams_by_queue(eng.device)
+        if plan is None:
+            eng.keep_wgrad_off_main_queue()
+            return
+        (a, b, c), on_main = plan
+        eng.pack_stream, self.d2._scale_stream = a
+        eng.aux_stream, self.d3._scale_stream = b
+        eng.wgrad_stream, self.d2_stream = c
+        if on_main:
+            eng.vq_stream = on_main[0]
+        eng._streams = (eng.wgrad_stream, eng.aux_stream, eng.pack_stream, eng.vq_stream)       # (set_stream_overlap(True) restores from this tuple)
 
     def _beside(self):
         """Context manager: the body runs on the image discriminator's side stream behind everything enqueued so far on the current stream
