@@ -71,8 +71,8 @@ class GANTrainer:
         (its launches queue up behind the data-gradient chain they are meant to run beside: 13.6 ms per iteration) or two streams that are busy together shared
         one.  The queues are therefore handed out explicitly: pooled streams are drawn and sorted by queue (engine.streams_by_queue tells queues apart by whether a
         launch on one stream waits for a long launch on the other), and the roles paired so that streams sharing a queue are never busy together --
-        packs + the image discriminator's coarse scales, bottom Conv3d chain + the video discriminator's coarse scales, filter gradients + image discriminator --
-        with the quantiser statistics (six tiny launches) on a stream of the main queue when one turned up.  13.1-13.2 ms in any process; ~40 ms and a transient
+        packs + the image discriminator's coarse scales + the quantiser statistics, bottom Conv3d chain + the video discriminator's coarse scales, filter
+        gradients + image discriminator; nothing on the main stream's queue (the statistics there: 13.2).  13.1 ms in any process; ~50 ms and a transient
         512 MB at construction.  FACEOFF_NO_QUEUE_PLAN=1: streams as they come (the filter-gradient stream is still checked)."""
         eng = self.engine
         if eng.device.type != "cuda":
@@ -81,16 +81,14 @@ class GANTrainer:
         if (not _os.environ.get("FACEOFF_NO_QUEUE_PLAN") and self.d2_stream is not None and None not in (eng.pack_stream, eng.aux_stream, eng.wgrad_stream, eng.vq_stream)
                 and self.d3._side() is not None and self.d2._side() is not None):
             from .engine import streams_by_queue
-            plan = streams_by_queue(eng.device)
+            plan = streams_by_queue(eng.device, per_class=3)
         if plan is None:
             eng.keep_wgrad_off_main_queue()
             return
-        (a, b, c), on_main = plan
-        eng.pack_stream, self.d2._scale_stream = a
-        eng.aux_stream, self.d3._scale_stream = b
-        eng.wgrad_stream, self.d2_stream = c
-        if on_main:
-            eng.vq_stream = on_main[0]
+        (a, b, c), _ = plan
+        eng.pack_stream, self.d2._scale_stream, eng.vq_stream = a
+        eng.aux_stream, self.d3._scale_stream = b[:2]
+        eng.wgrad_stream, self.d2_stream = c[:2]
         eng._streams = (eng.wgrad_stream, eng.aux_stream, eng.pack_stream, eng.vq_stream)       # (set_stream_overlap(True) restores from this tuple)
 
     def _beside(self):
