@@ -214,14 +214,16 @@ class GANTrainer:
         if getattr(self, "keep_states", False):                               # parity tests only: the generator's forward state stays alive
             self.last_gen_state = S                                           # (its ReLU branches are read back: tests/_fullsize_oracle.py)
         dec = S["dec"]
-        acc = torch.zeros(1, device=eng.device)
-        ops.mse_slice_fwd(dec, ground_truth, acc)
+        acc = torch.empty(1, device=eng.device)                               # (overwritten by either MSE launch)
+        if gen_iter:                                                          # loss value and gradient in one pass over dec and gt (as FaceOffTrainer.step)
+            one = torch.ones(1, device=eng.device)
+            g_dec = torch.empty_like(dec)
+            ops.mse_slice_fwd_bwd(dec, ground_truth, acc, one, g_dec)
+        else:
+            ops.mse_slice_fwd(dec, ground_truth, acc)
         out = {"recon": acc / float(ground_truth.numel()), "latent": S["diff"]}
         dec_win, gt_win = dec[r:r + w], ground_truth[r:r + w]
         if gen_iter:
-            one = torch.ones(1, device=eng.device)
-            g_dec = torch.empty_like(dec)
-            ops.mse_slice_bwd(dec, ground_truth, one, g_dec)
             g_win = g_dec[r:r + w]
             # image discriminator: module calls fake, then real (:354,357); only the fake logits reach the generator
             with self._beside() as joined:
