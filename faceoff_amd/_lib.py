@@ -62,6 +62,7 @@ SIGNATURES = {
     "fo_version": (_I, []),
     "fo_comm_unique_id": (_I, [_P]),
     "fo_comm_init": (_I, [C.POINTER(C.c_void_p), _I, _I, _P, _I]),
+    "fo_comm_set_stream": (_I, [_P, _P]),
     "fo_comm_rank": (_I, [_P]),
     "fo_comm_world": (_I, [_P]),
     "fo_comm_issued": (_L, [_P]),

@@ -63,6 +63,7 @@ bool load_rccl() {
 struct fo_comm {
   ncclComm_t comm;
   hipStream_t stream;      // every collective of this communicator runs here, in issue order
+  bool own_stream;         // created here (destroyed with the communicator) -- false after fo_comm_set_stream
   hipEvent_t ev;           // re-recorded per call (ordering only)
   int rank, world, device;
   long long issued;        // all-reduces enqueued so far
@@ -117,7 +118,20 @@ int fo_comm_init(fo_comm** out, int rank, int world, const void* id128, int devi
     delete c;
     return FO_E_HIP;
   }
+  c->own_stream = true;
   *out = c;
+  return FO_OK;
+}
+
+/* The communicator's collectives run on `stream` (the caller's, kept alive by the caller) from now on instead of on the stream fo_comm_init created: HIP gives a
+ * stream its hardware queue at first use, and a caller that can tell queues apart (faceoff_amd.engine.streams_by_queue) hands in one that does not share the compute
+ * stream's -- on a shared queue every all-reduce lines up behind the kernels it is meant to run beside.  Everything issued so far is waited for first. */
+int fo_comm_set_stream(fo_comm* c, void* stream) {
+  FO_REQUIRE(c && stream, FO_E_SHAPE, "comm_set_stream: null communicator / stream");
+  FO_HIP(hipStreamSynchronize(c->stream));
+  if (c->own_stream) (void)hipStreamDestroy(c->stream);
+  c->stream = (hipStream_t)stream;
+  c->own_stream = false;
   return FO_OK;
 }
 
@@ -160,7 +174,7 @@ int fo_comm_destroy(fo_comm* c) {
   (void)hipStreamSynchronize(c->stream);
   ncclResult_t r = g_rccl.CommDestroy(c->comm);
   (void)hipEventDestroy(c->ev);
-  (void)hipStreamDestroy(c->stream);
+  if (c->own_stream) (void)hipStreamDestroy(c->stream);
   delete c;
   if (r != ncclSuccess) {
     fo_set_error("comm_destroy: %s", g_rccl.GetErrorString(r));

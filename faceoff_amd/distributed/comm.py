@@ -48,7 +48,27 @@ class AbiComm:
         assert idb is not None and len(idb) == 128
         h = C.c_void_p()
         _lib.call("fo_comm_init", C.byref(h), rank, world, C.create_string_buffer(idb, 128), device.index or 0)
-        return cls(h, rank, world, device)
+        self = cls(h, rank, world, device)
+        self._place_stream()
+        return self
+
+    def _place_stream(self):
+        """The collectives' stream must not share the compute stream's hardware queue (HIP hands queues out at first use, four by default: on a shared queue an
+        all-reduce lines up behind the kernels it is meant to overlap).  A pooled torch stream is checked with the engine's launch-overlap probe and handed to
+        the communicator; the next one is tried if it fails (at most 8).  FACEOFF_NO_QUEUE_CHECK=1: the communicator keeps the stream it created."""
+        import os
+        if os.environ.get("FACEOFF_NO_QUEUE_CHECK") or self.device.type != "cuda":
+            return
+        from ..engine import _runs_beside
+        with torch.cuda.device(self.device):
+            for _ in range(8):
+                st = torch.cuda.Stream(device=self.device)
+                with torch.cuda.stream(st):
+                    torch.zeros(1, device=self.device)              # (first use: the stream takes its queue)
+                if _runs_beside(st, self.device):
+                    self._stream = st                                # (kept alive with the communicator)
+                    _lib.call("fo_comm_set_stream", self._h, C.c_void_p(st.cuda_stream))
+                    return
 
     @property
     def issued(self):

@@ -55,7 +55,7 @@ extern "C" {
                           quantisers' inputs (quantize_conv_t / _b, :208,213: VQ distances and arg-min stay fp32) and the decoder output */
 
 /* ABI version: bumped whenever an exported signature or the meaning of an argument changes (101: the loss kernels take a caller-owned
-   partial-sum workspace `ws` in front of `stream` and OVERWRITE their scalars -- round 4; 102: fo_comm_broadcast_async added; fo_instnorm_lrelu_{fwd,bwd}_batch take a workspace, fo_lpips_tap_fwd_bwd_unpool_bf16, fo_selftest_lane_moves, fo_pack_convT_k4s2_cells_n added -- round 6).  The Python binding refuses a library whose
+   partial-sum workspace `ws` in front of `stream` and OVERWRITE their scalars -- round 4; 102: fo_comm_broadcast_async added; fo_instnorm_lrelu_{fwd,bwd}_batch take a workspace, fo_lpips_tap_fwd_bwd_unpool_bf16, fo_selftest_lane_moves, fo_pack_convT_k4s2_cells_n, fo_comm_set_stream added -- round 6).  The Python binding refuses a library whose
    fo_version() differs from the FO_ABI_VERSION it was written against (faceoff_amd/_lib.py), so an older .so handed in through
    FACEOFF_HIP_LIB is a clean error and not a stream pointer read as a workspace. */
 #define FO_ABI_VERSION 102
@@ -573,6 +573,10 @@ int fo_disc_head_wgrad(const fo_convnd_desc* d, const float* g, const float* x, 
 typedef struct fo_comm fo_comm;
 int fo_comm_unique_id(void* id128);
 int fo_comm_init(fo_comm** out, int rank, int world, const void* id128, int device);
+/* From now on the collectives run on `stream` (the caller's; it must outlive the communicator) instead of the stream fo_comm_init created.  Why: HIP gives a
+   stream its hardware queue at first use (four queues by default), and on the compute stream's queue every all-reduce lines up behind the kernels it is meant
+   to overlap; the Python side hands in a stream it has checked (faceoff_amd.distributed.comm.AbiComm.create). */
+int fo_comm_set_stream(fo_comm* c, void* stream);
 int fo_comm_rank(const fo_comm* c);
 int fo_comm_world(const fo_comm* c);
 int64_t fo_comm_issued(const fo_comm* c);   /* all-reduces enqueued so far */
