@@ -28,8 +28,9 @@
 #include <type_traits>
 #include "common.h"
 
-#ifndef FO_ABLATE_W   // diagnostic builds (tools/ablate_wgrad.sh): bit 0 no global loads, 1 no LDS stores, 2 no fragment reads / MFMAs
-#define FO_ABLATE_W 0 // (results are wrong, only the timing is of interest)
+#ifndef FO_ABLATE_W   // diagnostic builds (hipcc -DFO_ABLATE_W=<bits>, a library per variant handed in through FACEOFF_HIP_LIB; profiles/r06_experiments.md): bit 0 no
+#define FO_ABLATE_W 0 // global loads / out-of-range DMAs only, 1 no LDS stores (row-run form), 2 no fragment reads / MFMAs, 3 no epilogue stores (wgrad9).  Results are
+                      // wrong, only the timing is of interest
 #endif
 
 namespace {
