@@ -720,6 +720,14 @@ class VQVAEEngine:
             torch.cuda.current_stream().wait_stream(self.vq_stream)
         return S
 
+    def diag_queue_shift(self):
+        """Diagnostics: FACEOFF_DIAG_QUEUE_SHIFT=n throw-away streams take the next hardware queues first (what a communicator's or another engine's would do)."""
+        if _os.environ.get("FACEOFF_DIAG_QUEUE_SHIFT") and self.device.type == "cuda" and not getattr(self, "_shift", None):
+            self._shift = [torch.cuda.Stream(device=self.device) for _ in range(int(_os.environ["FACEOFF_DIAG_QUEUE_SHIFT"]))]
+            for st in self._shift:
+                with torch.cuda.stream(st):
+                    torch.zeros(1, device=self.device)
+
     def keep_wgrad_off_main_queue(self):
         """HIP gives a stream its hardware queue at first use, from a pool of GPU_MAX_HW_QUEUES = 4; in order of first use the queues go 2, 3, 4, 4, 3, 2, 1, 4, 3 ..
         (queue 1 is the null stream's).  Which queue the filter-gradient stream gets therefore depends on how many streams the PROCESS has used before this engine's
@@ -729,11 +737,7 @@ class VQVAEEngine:
         place (at most 8 tries).  ~2 ms and a transient 512 MB.  FACEOFF_NO_QUEUE_CHECK=1: as it comes."""
         if self.device.type != "cuda" or self.wgrad_stream is None:
             return
-        if _os.environ.get("FACEOFF_DIAG_QUEUE_SHIFT"):        # diagnostics: n throw-away streams take the next hardware queues first (what a communicator's would do)
-            self._shift = [torch.cuda.Stream(device=self.device) for _ in range(int(_os.environ["FACEOFF_DIAG_QUEUE_SHIFT"]))]
-            for st in self._shift:
-                with torch.cuda.stream(st):
-                    torch.zeros(1, device=self.device)
+        self.diag_queue_shift()
         if _os.environ.get("FACEOFF_NO_QUEUE_CHECK"):
             return
         for st in (self.pack_stream, self.aux_stream, self.vq_stream, self.wgrad_stream):       # (the order a step reaches them in)

@@ -9,6 +9,8 @@ synchronisation anywhere in the step: losses stay on the device until the caller
 """
 from __future__ import annotations
 
+import os as _os
+
 import torch
 
 from . import ops
@@ -66,10 +68,7 @@ class FaceOffTrainer:
         # one (their uses are still pending): the pool grew by 20-60 GB a few steps into a run -- device mallocs of gigabytes in the middle
         # of training (tools/probes/c3_steps_probe.py).  Two steps in flight keep the GPU fed; the wait costs nothing when it is the bottleneck.
         self.max_inflight_steps = int(_os.environ.get("FACEOFF_MAX_INFLIGHT_STEPS", "2"))
-        if self.lpips_stream is not None:                  # (first use, in the order a step reaches the streams: the ground-truth branch comes first)
-            with torch.cuda.stream(self.lpips_stream):
-                torch.zeros(1, device=engine.device)
-        engine.keep_wgrad_off_main_queue()
+        self.claim_queues()
         self._inflight = []
         self.reducer = None
         if self.world > 1 or force_collectives:
@@ -85,6 +84,43 @@ class FaceOffTrainer:
             else:
                 vq_ar = fused_vq_allreduce(group)
                 engine.vq_allreduce = (lambda st: vq_ar(st, always=True)) if force_collectives else vq_ar
+
+    def claim_queues(self):
+        """The side streams get their hardware queues by plan (see VQVAEEngine.keep_wgrad_off_main_queue for why the order of first use is not to be relied on: the
+        queues HIP hands out depend on every stream the process used before).  The plan is the mapping the step was tuned on -- what a fresh process gets by reaching
+        the streams in the order of a step: LPIPS' ground-truth branch alone, filter packs + filter gradients (never busy together), bottom Conv3d chain + quantiser
+        statistics, nothing on the main stream's queue -- made explicit with engine.streams_by_queue, so that it also holds behind a communicator's or another
+        engine's streams: config 3 31.85-31.93 ms with two or four foreign streams in front where the order of first use gave 33.0-33.6, config 2 39.8-39.9 where it
+        gave 40.2-41.5; in a fresh process the same as before (32.0 / 39.9).  ~50 ms and a transient 512 MB.  FACEOFF_NO_QUEUE_PLAN=1: order of first use, with the
+        filter-gradient stream checked."""
+        eng = self.engine
+        if eng.device.type != "cuda":
+            return
+        plan = None
+        eng.diag_queue_shift()
+        if not _os.environ.get("FACEOFF_NO_QUEUE_PLAN") and not _os.environ.get("FACEOFF_NO_QUEUE_CHECK"):
+            from .engine import streams_by_queue
+            plan = streams_by_queue(eng.device)
+        if plan is None:
+            if self.lpips_stream is not None:                  # (first use, in the order a step reaches the streams: the ground-truth branch comes first)
+                with torch.cuda.stream(self.lpips_stream):
+                    torch.zeros(1, device=eng.device)
+            eng.keep_wgrad_off_main_queue()
+            return
+        (a, b, c), _ = plan
+        if self.lpips_stream is not None:
+            self.lpips_stream = a[0]
+        else:                                                  # (no perceptual branch: the packs take the free queue)
+            b = [a[0], b[0]]
+        if eng.pack_stream is not None:
+            eng.pack_stream = b[0]
+        if eng.wgrad_stream is not None:
+            eng.wgrad_stream = b[1] if self.lpips_stream is not None else c[1]
+        if eng.aux_stream is not None:
+            eng.aux_stream = c[0] if self.lpips_stream is not None else b[1]
+        if eng.vq_stream is not None:
+            eng.vq_stream = c[1] if self.lpips_stream is not None else c[0]
+        eng._streams = (eng.wgrad_stream, eng.aux_stream, eng.pack_stream, eng.vq_stream)       # (set_stream_overlap(True) restores from this tuple)
 
     def step(self, img, ground_truth, T=None, force_ids=None):
         """img [B,T,6,H,W] or [N,6,H,W]; ground_truth likewise with 3 channels (utils.py:29-38).
