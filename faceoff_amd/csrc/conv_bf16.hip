@@ -1010,9 +1010,15 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_pp16_kernel(const ConvArgsH 
   constexpr int C8 = WCOLS / 8, RPP = 64 / C8;
   const int c8 = lane % C8, r0 = lane / C8;
   const int co = tile_n * BN + wn * WCOLS + c8 * 8;
+  // FO_DEPTH2SPACE, cell form (store_c_tile): GEMM column = phase * Cpp + channel; a lane's 8 columns are 8 channels of ONE output pixel, (2 cy - 1 + ph / 2, 2 cx - 1 + ph % 2)
+  const bool d2s = flags & FO_DEPTH2SPACE;
+  const int cpp = d.Cout >> 2;
+  const int ph = d2s ? co / cpp : 0;
+  const int cc = d2s ? co - ph * cpp : co;      // channel of the OUTPUT tensor (bias, mask, add, store)
+  const bool live = !d2s || cc < ((d.ophW + 7) & ~7);
   float bv[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) bv[e] = ((flags & FO_BIAS) && co + e < d.Cout) ? a.bias[co + e] : 0.f;
+  for (int e = 0; e < 8; ++e) bv[e] = ((flags & FO_BIAS) && cc + e < (d2s ? d.ophW : d.Cout)) ? a.bias[cc + e] : 0.f;
   const __bf16* mask = reinterpret_cast<const __bf16*>(a.mask);
   const __bf16* addp = reinterpret_cast<const __bf16*>(a.add);
 #pragma unroll
@@ -1026,30 +1032,43 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_pp16_kernel(const ConvArgsH 
         for (int r = 0; r < 4; ++r) Cs[(ii * 16 + quad * 4 + r) * C_LD + j * 16 + l15] = acc[i2 * 2 + ii][j][r];
     __builtin_amdgcn_wave_barrier();
     const int mbase = tile_m * BMB + wm * TM * 16 + i2 * 32;
+    size_t opix[32 / RPP];
+    bool ok[32 / RPP];
+#pragma unroll
+    for (int pp = 0; pp < 32 / RPP; ++pp) {
+      const int m = mbase + pp * RPP + r0;
+      ok[pp] = (m < a.M) & live;
+      const int mm = m < a.M ? m : 0;
+      opix[pp] = (size_t)mm;
+      if (d2s) {
+        const int n = mm / a.HWm;
+        const int rem = mm - n * a.HWm;
+        const int y = rem / d.Wm;
+        const int x = rem - y * d.Wm;
+        int oy = 2 * y + (ph >> 1) - d.ophH, ox = 2 * x + (ph & 1) - d.ophH;
+        ok[pp] = ok[pp] & ((unsigned)oy < (unsigned)d.Hout) & ((unsigned)ox < (unsigned)d.Wout);
+        oy = min(max(oy, 0), d.Hout - 1);
+        ox = min(max(ox, 0), d.Wout - 1);
+        opix[pp] = ((size_t)n * d.Hout + oy) * d.Wout + ox;
+      }
+    }
     bf16x8 mk[32 / RPP], ad[32 / RPP];                    // all mask / add loads of the round in flight before the first use
     if (flags & FO_MASK) {
 #pragma unroll
-      for (int pp = 0; pp < 32 / RPP; ++pp) {
-        const int m = mbase + pp * RPP + r0;
-        mk[pp] = load_mask8(a, (size_t)(m < a.M ? m : 0), co);
-      }
+      for (int pp = 0; pp < 32 / RPP; ++pp) mk[pp] = load_mask8(a, opix[pp], live ? cc : 0);
     }
     if (flags & FO_ADD) {
 #pragma unroll
-      for (int pp = 0; pp < 32 / RPP; ++pp) {
-        const int m = mbase + pp * RPP + r0;
-        ad[pp] = *reinterpret_cast<const bf16x8*>(addp + (size_t)(m < a.M ? m : 0) * d.ldAdd + co);
-      }
+      for (int pp = 0; pp < 32 / RPP; ++pp) ad[pp] = *reinterpret_cast<const bf16x8*>(addp + opix[pp] * d.ldAdd + (live ? cc : 0));
     }
 #pragma unroll
     for (int pp = 0; pp < 32 / RPP; ++pp) {
       const int row = pp * RPP + r0;
-      const int m = mbase + row;
       const float* crow = Cs + row * C_LD + c8 * 8;
       const f32x4 v0 = *reinterpret_cast<const f32x4*>(crow);
       const f32x4 v1 = *reinterpret_cast<const f32x4*>(crow + 4);
       float v[8] = {v0.x + bv[0], v0.y + bv[1], v0.z + bv[2], v0.w + bv[3], v1.x + bv[4], v1.y + bv[5], v1.z + bv[6], v1.w + bv[7]};
-      emit8(a, flags, v, mk[pp], ad[pp], (size_t)(m < a.M ? m : 0), co, m < a.M);
+      emit8(a, flags, v, mk[pp], ad[pp], opix[pp], cc, ok[pp]);
     }
   }
 }
@@ -2420,6 +2439,27 @@ static int conv_bf16_impl(const fo_conv_desc* d, const void* in, const void* wp,
   // on conv3_x / conv4_x, 128-column tiles +5...10 % on conv2_x and +12...15 % on 2-round launches, the 512 x 128 tile (32 MFMAs per
   // phase and wave instead of 16: half the barriers per FLOP) another +14...17 % where there are >= 5 whole rounds of them (round 3: the VQ-VAE's 64^2 latents are exactly 5 rounds, config 3 -0.6...-1.6 ms; the first threshold, 8, was only ever measured on the VGG shapes) (a 512 x 64 tile for the 64-column layers measured -8 %); 64-column layers
   // (K = 576: 18 phases) stay on conv_bf16_kernel, whose second workgroup hides the prologue and epilogue
+  // the cell form of a k4 s2 transposed layer (FO_DEPTH2SPACE, 4 Cpp >= 256 GEMM columns, K = 4 Cin: 16 phases of 32): the per-tap big-tile kernel instead of the
+  // 128-row one -- twice the MFMAs per barrier and the A tile staged once per 256 (128) columns (FACEOFF_BF16_CELLS_SMALL_TILES=1: the 128-row kernel)
+  if (d2s && d->ophH == 1 && !smallc && d->KD == 1 && d->KH == 2 && d->KW == 2 && d->stride == 1 && !(flags & FO_IN_RELU) && d->Cout % 128 == 0 && !maskBits && !outBits &&
+      !getenv("FACEOFF_BF16_CELLS_SMALL_TILES")) {
+    a.cinChunks = d->Cin / 32;
+    a.ksteps = a.Ktot / 32;
+    const long long tilesM256 = (a.M + 255) / 256;
+    const char* forceb = getenv("FACEOFF_BF16_BIG_TILES");           // tests: at any size
+    const long long cusb = (forceb && atoi(forceb)) ? 0 : fo_cu_count();
+    const char* n256 = getenv("FACEOFF_BF16_CELLS_NO_256");          // tests: the 256 x 128 tile where the 256 x 256 one would run
+    if (d->Cout % 256 == 0 && tilesM256 * (d->Cout / 256) >= 3 * cusb && !(n256 && atoi(n256))) {
+      a.tilesM = (int)tilesM256; a.tilesN = d->Cout / 256;
+      a.frameTiles = a.HWm % 256 == 0;
+      return launch_pp16<256, 256, 2, 4>(a, s);
+    }
+    if (tilesM256 * (d->Cout / 128) >= 2 * cusb) {
+      a.tilesM = (int)tilesM256; a.tilesN = d->Cout / 128;
+      a.frameTiles = a.HWm % 256 == 0;
+      return launch_pp16<256, 128, 4, 2>(a, s);
+    }
+  }
   const bool same = d->stride == 1 && d->ostride == 1 && d->Hm == d->Hout && d->Wm == d->Wout && d->Hin == d->Hm && d->Win == d->Wm && !d2s;
   const char* nobig = getenv("FACEOFF_BF16_SMALL_TILES");            // diagnostics / tests: never
   const char* force = getenv("FACEOFF_BF16_BIG_TILES");              // tests: at any size

@@ -123,23 +123,34 @@ def test_transposed_conv_phases_into_a_channel_slice_and_its_data_gradient():
     close_bf16(back(gin), gref, "convT data gradient")
 
 
+@pytest.mark.parametrize("big", [0, 1, 2])
 @pytest.mark.parametrize("ci,co,h,w", [(128, 64, 16, 16), (64, 64, 5, 7), (64, 128, 6, 10), (128, 40, 4, 4)])
-def test_transposed_conv_as_one_cell_form_launch_at_any_width(ci, co, h, w):
+def test_transposed_conv_as_one_cell_form_launch_at_any_width(ci, co, h, w, big, monkeypatch):
     """The k4 s2 p1 transposed convolutions with more than 8 output channels (dec.blocks.4, dec_t.blocks.4, upsample_t :147-151,222) and the data gradients
     of the k4 s2 convolutions (enc_b.blocks.2, enc_t.blocks.0) as ONE launch: a k2 p1 conv over the (H+1) x (W+1) cell grid, 4 x Cpp GEMM columns,
     depth-to-space in the epilogue (fo_pack_convT_k4s2_cells_n + FO_DEPTH2SPACE).  Forward use: bias + ReLU into a channel slice of a wider buffer; gradient
     use: ReLU mask and fan-in add at the output pixel.  Against torch on the same bf16 operands, and against the four sub-pixel phase launches."""
-    from faceoff_amd import ops
+    from faceoff_amd import ops, _lib
+    # big: 0 the 128-row kernel (what these small sizes get), 1 the per-tap big-tile kernel at 256 x 256 (the timed sizes), 2 at 256 x 128
+    if big:
+        monkeypatch.setenv("FACEOFF_BF16_BIG_TILES", "1")
+    if big == 2:
+        monkeypatch.setenv("FACEOFF_BF16_CELLS_NO_256", "1")
     g = gen(300 + ci + co + h)
     N = 2
     x = rb(torch.randn((N, ci, h, w), generator=g))
     wt = rb(torch.randn((ci, co, 4, 4), generator=g) / np.sqrt(4 * ci))
+    lib = _lib.load()
+    lib.fo_kernel_notes(1); lib.fo_last_kernel()
     b = torch.randn(co, generator=g)
     wc = packed_bf16(ops.pack_convT_cells(wt.cuda()))
     ld = (co + 7) // 8 * 8 + 64
     ref = F.relu(F.conv_transpose2d(x, wt, b, stride=2, padding=1))
     cat = torch.full((N, 2 * h, 2 * w, ld), 7.0, device="cuda", dtype=BF)
     ops.convT_cells_bf16(nhwc(x), wc, b.cuda(), cat[..., 0:(co + 7) // 8 * 8], cin=ci, cout=co, flags=ops.FO_OUT_RELU)
+    torch.cuda.synchronize()
+    kern = lib.fo_last_kernel().decode(); lib.fo_kernel_notes(0)
+    assert ("conv_bf16_pp16_kernel<256, 256" in kern) if big == 1 else ("conv_bf16_pp16_kernel<256, 128" in kern) if big == 2 else ("pp16" not in kern), kern
     close_bf16(back(cat[..., 0:co]), ref, "convT cells forward")
     assert bool((cat[..., (co + 7) // 8 * 8:] == 7.0).all())
     # gradient use: masked, added to a fan-in gradient
