@@ -326,10 +326,22 @@ def _runs_beside_current(stream, dev):
     return _runs_beside(stream, dev)
 
 
-def streams_by_queue(dev, classes=3, per_class=2, max_draw=24):
+_QUEUE_CLASSES = {}          # device index -> the result of the first streams_by_queue() of the process: the same streams serve every trainer after it
+
+
+def streams_by_queue(dev, classes=3, per_class=3, max_draw=24):
     """Pooled streams sorted by the hardware queue HIP gave them: `classes` lists of `per_class` streams each, every list on its own queue, none on the current
     stream's; plus the streams that were found on the current stream's queue.  Queues are told apart by _runs_beside (a process cannot ask for a stream's queue).
-    None when the pool does not yield that many (fewer hardware queues than expected)."""
+    None when the pool does not yield that many (fewer hardware queues than expected).  Sorted once per process and device (~50 ms, a transient 512 MB): later
+    trainers get the same streams -- a stream is an ordering, two engines that use one are merely ordered against each other where they would have run together."""
+    key = (torch.device(dev).index or 0, classes, per_class)
+    if key in _QUEUE_CLASSES:
+        return _QUEUE_CLASSES[key]
+    _QUEUE_CLASSES[key] = _sort_streams(dev, classes, per_class, max_draw)
+    return _QUEUE_CLASSES[key]
+
+
+def _sort_streams(dev, classes, per_class, max_draw):
     main = torch.cuda.current_stream(dev)
     groups, on_main = [], []
     for _ in range(max_draw):

@@ -81,7 +81,7 @@ class GANTrainer:
         if (not _os.environ.get("FACEOFF_NO_QUEUE_PLAN") and self.d2_stream is not None and None not in (eng.pack_stream, eng.aux_stream, eng.wgrad_stream, eng.vq_stream)
                 and self.d3._side() is not None and self.d2._side() is not None):
             from .engine import streams_by_queue
-            plan = streams_by_queue(eng.device, per_class=3)
+            plan = streams_by_queue(eng.device)
         if plan is None:
             eng.keep_wgrad_off_main_queue()
             return
